@@ -1,0 +1,249 @@
+/*
+ * infini_rocm.h — C ABI of the MI355X (gfx950 / CDNA4) operator backend for InfiniTensor.
+ *
+ * This is the drop-in boundary of the hot path `RuntimeObj::run -> Kernel::compute`
+ * (reference: include/core/runtime.h:38-101, include/core/kernel.h:32-103). The reference has no
+ * C ABI: a backend is a `RuntimeObj` subclass plus `Kernel` subclasses that pull raw device
+ * pointers, shapes and attributes out of an operator object and hand them to device code
+ * (e.g. src/kernels/cuda/matmul.cc:67-174 -> cuBLAS, src/kernels/cuda/softmax.cc:9-31 ->
+ * softmax.cu). Every entry point below is exactly that hand-off — plain pointers, sizes and
+ * attributes, no C++ or torch types — so that the C++ plugin in infinitensor_amd/plugin/
+ * (`RocmRuntimeObj` + `REGISTER_KERNEL(Device::ROCM, ...)`) and the ctypes host mirror in
+ * infinitensor_amd/ bind the same functions. Each declaration cites the reference interface it
+ * replaces.
+ *
+ * Conventions
+ *  - All functions return 0 (INFINI_ROCM_OK) on success or a non-zero infiniRocmStatus_t; a
+ *    human-readable message for the calling thread is available from infini_rocm_last_error().
+ *    The C++ plugin turns a non-zero status into `infini::Exception` (reference: IT_ASSERT,
+ *    include/core/common.h:44-55), the Python mirror into RuntimeError.
+ *  - dtype codes are the reference's `DataType::getIndex()` values (include/core/data_type.h:8-23).
+ *  - All tensors are dense, contiguous, row-major device buffers (reference: src/core/tensor.cc:74-82);
+ *    strides passed explicitly are in ELEMENTS and may be 0 for broadcast dimensions.
+ *  - Kernels are enqueued asynchronously on the runtime's stream (reference: thread-local
+ *    CUDAStream, include/cuda/cuda_common.h:115-139); nothing synchronises unless stated.
+ *  - Kernels never allocate persistent device memory; scratch comes from the runtime workspace
+ *    (reference: CudaRuntimeObj::getWorkspace, include/cuda/cuda_runtime.h:85-88).
+ */
+#ifndef INFINI_ROCM_H
+#define INFINI_ROCM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    INFINI_ROCM_OK = 0,
+    INFINI_ROCM_INVALID_ARGUMENT = 1,
+    INFINI_ROCM_UNSUPPORTED = 2,
+    INFINI_ROCM_HIP_ERROR = 3,
+    INFINI_ROCM_RCCL_ERROR = 4,
+    INFINI_ROCM_OUT_OF_MEMORY = 5,
+    INFINI_ROCM_CAPTURE_ERROR = 6
+} infiniRocmStatus_t;
+
+/* reference: include/core/data_type.h:8-23 (index of each DataType constant) */
+typedef enum {
+    INFINI_DT_F32 = 1,
+    INFINI_DT_U8 = 2,
+    INFINI_DT_I8 = 3,
+    INFINI_DT_U16 = 4,
+    INFINI_DT_I16 = 5,
+    INFINI_DT_I32 = 6,
+    INFINI_DT_I64 = 7,
+    INFINI_DT_BOOL = 9,
+    INFINI_DT_F16 = 10,
+    INFINI_DT_F64 = 11,
+    INFINI_DT_U32 = 12,
+    INFINI_DT_U64 = 13,
+    INFINI_DT_BF16 = 16
+} infiniRocmDType_t;
+
+#define INFINI_ROCM_MAX_DIMS 8 /* reference: SMALL_ARRAY_SIZE, include/utils/small_array.h:4-15 */
+
+typedef struct infiniRocmRuntime *infiniRocmRuntime_t;
+typedef struct infiniRocmGraph *infiniRocmGraph_t;
+typedef struct infiniRocmEvent *infiniRocmEvent_t;
+
+/* ------------------------------------------------------------------------------------------ */
+/* Errors / identification                                                                     */
+/* ------------------------------------------------------------------------------------------ */
+const char *infini_rocm_last_error(void);
+const char *infini_rocm_version(void);
+int infini_rocm_device_count(int *count);
+
+typedef struct {
+    char name[64];
+    char arch[32];
+    int compute_units;
+    int clock_mhz;          /* max engine clock */
+    int memory_clock_mhz;
+    int memory_bus_bits;
+    size_t total_memory;
+    int wavefront_size;
+    int lds_bytes_per_cu;
+} infiniRocmDeviceInfo;
+
+/* ------------------------------------------------------------------------------------------ */
+/* Runtime: one device + one stream + one workspace                                            */
+/* replaces CudaRuntimeObj ctor, dtor, alloc, dealloc, copyBlobFromCPU/ToCPU/InsideRuntime, sync */
+/* (reference: src/cuda/cuda_runtime.cc:30-120, 481-493; include/cuda/cuda_runtime.h:60-105)    */
+/* ------------------------------------------------------------------------------------------ */
+int infini_rocm_runtime_create(int device, infiniRocmRuntime_t *out);
+int infini_rocm_runtime_destroy(infiniRocmRuntime_t rt);
+int infini_rocm_runtime_device_info(infiniRocmRuntime_t rt, infiniRocmDeviceInfo *info);
+/* The native hipStream_t the runtime launches on. */
+int infini_rocm_runtime_get_stream(infiniRocmRuntime_t rt, void **stream);
+/* Adopt an externally owned stream (e.g. torch's current stream); NULL restores the own stream. */
+int infini_rocm_runtime_set_stream(infiniRocmRuntime_t rt, void *stream);
+int infini_rocm_runtime_sync(infiniRocmRuntime_t rt);
+int infini_rocm_alloc(infiniRocmRuntime_t rt, size_t bytes, void **ptr);
+int infini_rocm_dealloc(infiniRocmRuntime_t rt, void *ptr);
+int infini_rocm_copy_from_cpu(infiniRocmRuntime_t rt, void *dst, const void *src, size_t bytes);
+int infini_rocm_copy_to_cpu(infiniRocmRuntime_t rt, void *dst, const void *src, size_t bytes);
+/* async device-to-device copy on the runtime stream; also the Reshape/Flatten/Identity/Squeeze/
+ * Unsqueeze kernel (reference: src/kernels/cuda/reshape.cc:4-21) */
+int infini_rocm_copy_inside(infiniRocmRuntime_t rt, void *dst, const void *src, size_t bytes);
+int infini_rocm_memset(infiniRocmRuntime_t rt, void *dst, int value, size_t bytes);
+/* Scratch valid until the next call on the same runtime that asks for workspace
+ * (reference: getWorkspace, include/cuda/cuda_runtime.h:85-88; grows on demand instead of 7 GiB). */
+int infini_rocm_workspace(infiniRocmRuntime_t rt, size_t bytes, void **ptr);
+
+/* Events on the runtime stream, for timing (reference: timeit, src/core/common.cc:7-22). */
+int infini_rocm_event_create(infiniRocmEvent_t *ev);
+int infini_rocm_event_destroy(infiniRocmEvent_t ev);
+int infini_rocm_event_record(infiniRocmRuntime_t rt, infiniRocmEvent_t ev);
+int infini_rocm_event_elapsed_ms(infiniRocmEvent_t start, infiniRocmEvent_t stop, float *ms);
+
+/* hipGraph capture/replay of whatever is enqueued on the runtime stream between begin and end
+ * (reference: runWithCudaGraph / captureGraph, src/cuda/cuda_runtime.cc:252-426). */
+int infini_rocm_graph_begin_capture(infiniRocmRuntime_t rt);
+int infini_rocm_graph_end_capture(infiniRocmRuntime_t rt, infiniRocmGraph_t *graph);
+int infini_rocm_graph_abort_capture(infiniRocmRuntime_t rt);
+int infini_rocm_graph_launch(infiniRocmRuntime_t rt, infiniRocmGraph_t graph);
+int infini_rocm_graph_destroy(infiniRocmGraph_t graph);
+
+/* ------------------------------------------------------------------------------------------ */
+/* MatMul  (reference: matmulCublas::do_compute, src/kernels/cuda/matmul.cc:67-174;             */
+/*          op definition src/operators/matmul.cc:26-49)                                        */
+/*   C[b,m,n] = op(A)[b,m,k] . op(B)[b,k,n] (+ bias), row-major.                                */
+/*   A is stored [m,k] (trans_a=0) or [k,m] (trans_a=1); B is [k,n] or [n,k] (trans_b=1).       */
+/*   stride_a / stride_b: batch stride in elements, 0 = the operand is broadcast over the batch */
+/*   (reference matmul.cc:124-137). bias (may be NULL) is addressed as                          */
+/*   bias[ib*bias_stride_b + im*bias_stride_m + in*bias_stride_n] (reference expands it into C  */
+/*   and runs the GEMM with beta=1, matmul.cc:86-118).                                          */
+/*   dtype F32: exact-f32 MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate.                       */
+/*   dtype F16 / BF16: v_mfma_f32_16x16x32_{f16,bf16}, fp32 accumulate, one rounding on store.  */
+/*   act: 0 none, 1 relu, 2 sigmoid, 3 tanh (reference ActType, include/core/common.h; the      */
+/*   reference CUDA kernel ignores it — the plugin passes 0 to stay op-for-op identical).       */
+/* ------------------------------------------------------------------------------------------ */
+int infini_rocm_matmul(infiniRocmRuntime_t rt, int dtype, const void *a, const void *b,
+                       const void *bias, void *c, int64_t batch, int64_t m, int64_t n, int64_t k,
+                       int trans_a, int trans_b, int64_t stride_a, int64_t stride_b,
+                       int64_t bias_stride_b, int64_t bias_stride_m, int64_t bias_stride_n,
+                       int act);
+/* Select a specific GEMM kernel variant for the next matmul calls on this runtime
+ * (-1 = heuristic). Used by tune() (reference: 24-algo sweep, matmul.cc:187-208) and by bench.py. */
+int infini_rocm_matmul_set_variant(infiniRocmRuntime_t rt, int variant);
+int infini_rocm_matmul_num_variants(void);
+const char *infini_rocm_matmul_variant_name(int variant);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Softmax along one axis (reference: softmax_kernel, src/kernels/cuda/softmax.cu:242-404;      */
+/*   glue src/kernels/cuda/softmax.cc:9-31). The tensor is viewed as [outer, dimsize, inner]    */
+/*   (inner = stride of `axis`), F32 / F16 / BF16, fp32 math.                                   */
+/* ------------------------------------------------------------------------------------------ */
+int infini_rocm_softmax(infiniRocmRuntime_t rt, int dtype, const void *x, void *y, int64_t outer,
+                        int64_t dimsize, int64_t inner);
+
+/* ------------------------------------------------------------------------------------------ */
+/* LayerNormalization (reference: LaynormKernel, src/kernels/cuda/layer_norm.cu:339-558;        */
+/*   glue src/kernels/cuda/layer_norm.cc:9-58). x viewed as [outer, norm_size] with norm_size = */
+/*   prod(dims[axis..]) (ONNX-17 semantics; identical to the reference whenever axis is the     */
+/*   last dim, which is all its tests cover). scale/bias have scale_size/bias_size elements:    */
+/*   either norm_size (element j uses [j]) or 1 (scalar broadcast) (layer_norm.cu:41-89).       */
+/*   bias may be NULL. Statistics always accumulate in fp32 (deliberate deviation: the          */
+/*   reference fp16 path accumulates in half, layer_norm.cu:12,26).                             */
+/* ------------------------------------------------------------------------------------------ */
+int infini_rocm_layer_norm(infiniRocmRuntime_t rt, int dtype, const void *x, const void *scale,
+                           const void *bias, void *y, int64_t outer, int64_t norm_size,
+                           int64_t scale_size, int64_t bias_size, float eps);
+
+/* RMSNorm: y = x * rsqrt(mean(x^2) + eps) * w over the last dim
+ * (reference: src/kernels/cuda/rms_norm.cu:35-54; eps is hard-coded 1e-5 there, rms_norm.cu:46). */
+int infini_rocm_rms_norm(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, void *y,
+                         int64_t outer, int64_t norm_size, float eps);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Binary element-wise with numpy broadcasting                                                  */
+/* (reference: ElementWiseCudnn / ElementWiseCuda, src/kernels/cuda/element_wise.cc:13-175,     */
+/*  element_wise.cu:9-131; semantics src/kernels/cpu/element_wise.cc:43-112).                   */
+/*   c[i] = a[bcast(i)] OP b[bcast(i)]; ndim <= 8; shape = output shape;                        */
+/*   stride_a/stride_b in elements over the OUTPUT index space (0 where broadcast).             */
+/*   Comparison ops write 1/0 in the input dtype (reference CPU kernel: `(T)(a < b)`).          */
+/* ------------------------------------------------------------------------------------------ */
+typedef enum {
+    INFINI_BIN_ADD = 0,
+    INFINI_BIN_SUB = 1,
+    INFINI_BIN_MUL = 2,
+    INFINI_BIN_DIV = 3,
+    INFINI_BIN_POW = 4,
+    INFINI_BIN_MIN = 5,
+    INFINI_BIN_MAX = 6,
+    INFINI_BIN_EQUAL = 7,
+    INFINI_BIN_GREATER = 8,
+    INFINI_BIN_GREATER_EQUAL = 9,
+    INFINI_BIN_LESS = 10,
+    INFINI_BIN_LESS_EQUAL = 11
+} infiniRocmBinaryOp_t;
+
+int infini_rocm_binary(infiniRocmRuntime_t rt, int op, int dtype, const void *a, const void *b,
+                       void *c, int ndim, const int64_t *shape, const int64_t *stride_a,
+                       const int64_t *stride_b);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Unary element-wise (reference: unary_kernel, src/kernels/cuda/unary.cu:262-352; cuDNN        */
+/*  activations src/kernels/cuda/unary.cc:70-122; formulas src/kernels/cpu/unary.cc:8-72).      */
+/*  p0/p1: Clip min/max (NaN = absent), Elu/LeakyRelu alpha, HardSigmoid alpha/beta.            */
+/* ------------------------------------------------------------------------------------------ */
+typedef enum {
+    INFINI_UN_RELU = 0,
+    INFINI_UN_SIGMOID = 1,
+    INFINI_UN_TANH = 2,
+    INFINI_UN_ABS = 3,
+    INFINI_UN_SQRT = 4,
+    INFINI_UN_GELU = 5,       /* 0.5 x (1 + erf(x / sqrt 2)) */
+    INFINI_UN_SILU = 6,
+    INFINI_UN_NEG = 7,
+    INFINI_UN_ERF = 8,
+    INFINI_UN_HARD_SIGMOID = 9, /* max(0, min(1, 0.2 x + 0.5)) */
+    INFINI_UN_HARD_SWISH = 10,  /* x * max(0, min(1, x/6 + 0.5)) */
+    INFINI_UN_EXP = 11,
+    INFINI_UN_LOG = 12,
+    INFINI_UN_RECIPROCAL = 13,
+    INFINI_UN_ELU = 14,
+    INFINI_UN_LEAKY_RELU = 15,
+    INFINI_UN_CLIP = 16,
+    INFINI_UN_SIN = 17,
+    INFINI_UN_COS = 18,
+    INFINI_UN_CEIL = 19,
+    INFINI_UN_FLOOR = 20,
+    INFINI_UN_ROUND = 21
+} infiniRocmUnaryOp_t;
+
+int infini_rocm_unary(infiniRocmRuntime_t rt, int op, int dtype, const void *x, void *y,
+                      int64_t n, float p0, float p1);
+
+/* Cast between dtypes (reference: CastCuda, src/kernels/cuda/unary.cc:30-68, 5 of the 26
+ * CastTypes; here any pair of {F32,F16,BF16,F64,I8,U8,I16,I32,I64,U32,BOOL}). Float->int
+ * truncates toward zero like a C cast (reference cast kernel: `(T)x`). */
+int infini_rocm_cast(infiniRocmRuntime_t rt, int src_dtype, int dst_dtype, const void *x, void *y,
+                     int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INFINI_ROCM_H */

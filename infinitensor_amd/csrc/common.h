@@ -1,0 +1,108 @@
+// Shared host-side plumbing for the C-ABI implementation (gfx950 only; no CUDA compatibility paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "infini_rocm.h"
+
+namespace irocm {
+
+// ---- thread-local error message ---------------------------------------------------------------
+void set_error(const char *fmt, ...);
+
+#define IROCM_FAIL(code, ...)                                                                      \
+    do {                                                                                           \
+        ::irocm::set_error(__VA_ARGS__);                                                           \
+        return (code);                                                                             \
+    } while (0)
+
+#define IROCM_CHECK_ARG(cond, ...)                                                                 \
+    do {                                                                                           \
+        if (!(cond))                                                                               \
+            IROCM_FAIL(INFINI_ROCM_INVALID_ARGUMENT, __VA_ARGS__);                                 \
+    } while (0)
+
+#define IROCM_HIP(expr)                                                                            \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            IROCM_FAIL(_e == hipErrorOutOfMemory ? INFINI_ROCM_OUT_OF_MEMORY : INFINI_ROCM_HIP_ERROR, \
+                       "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+// Check the launch that was just enqueued (reference: checkCudaError(cudaGetLastError()),
+// src/cuda/cuda_runtime.cc:198).
+#define IROCM_LAUNCH_CHECK(what)                                                                   \
+    do {                                                                                           \
+        hipError_t _e = hipGetLastError();                                                         \
+        if (_e != hipSuccess)                                                                      \
+            IROCM_FAIL(INFINI_ROCM_HIP_ERROR, "launch of %s failed: %s", what,                     \
+                       hipGetErrorString(_e));                                                     \
+    } while (0)
+
+inline size_t dtype_size(int dt) {
+    switch (dt) {
+    case INFINI_DT_F32: case INFINI_DT_I32: case INFINI_DT_U32: return 4;
+    case INFINI_DT_U8: case INFINI_DT_I8: case INFINI_DT_BOOL: return 1;
+    case INFINI_DT_U16: case INFINI_DT_I16: case INFINI_DT_F16: case INFINI_DT_BF16: return 2;
+    case INFINI_DT_I64: case INFINI_DT_U64: case INFINI_DT_F64: return 8;
+    default: return 0;
+    }
+}
+
+inline const char *dtype_name(int dt) {
+    switch (dt) {
+    case INFINI_DT_F32: return "Float32";
+    case INFINI_DT_U8: return "UInt8";
+    case INFINI_DT_I8: return "Int8";
+    case INFINI_DT_U16: return "UInt16";
+    case INFINI_DT_I16: return "Int16";
+    case INFINI_DT_I32: return "Int32";
+    case INFINI_DT_I64: return "Int64";
+    case INFINI_DT_BOOL: return "Bool";
+    case INFINI_DT_F16: return "Float16";
+    case INFINI_DT_F64: return "Double";
+    case INFINI_DT_U32: return "UInt32";
+    case INFINI_DT_U64: return "UInt64";
+    case INFINI_DT_BF16: return "BFloat16";
+    default: return "Unknown";
+    }
+}
+
+constexpr int kNumXcd = 8; // MI355X: 8 XCDs, block b is dispatched to XCD b % 8 (speed only)
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+} // namespace irocm
+
+// The runtime object behind infiniRocmRuntime_t.
+struct infiniRocmRuntime {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr; // the stream kernels launch on (own or adopted)
+    void *workspace = nullptr;
+    size_t workspace_bytes = 0;
+    bool capturing = false;
+    int matmul_variant = -1;
+    int num_cu = 256;
+    void *comm = nullptr; // rcclComm_t, owned by comm.cc
+    int comm_world = 1, comm_rank = 0;
+    std::mutex mu;
+};
+
+struct infiniRocmGraph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+struct infiniRocmEvent {
+    hipEvent_t ev = nullptr;
+};

@@ -1,0 +1,538 @@
+// MatMul for gfx950: hand-written MFMA GEMM kernels behind infini_rocm_matmul.
+//
+// Replaces matmulCublas::do_compute (reference: src/kernels/cuda/matmul.cc:67-174), which
+// forwards to cublasGemmEx / cublasGemmStridedBatchedEx. Semantics (batch broadcast by zero
+// stride, transA/transB, bias broadcast into C) follow that file and the op definition
+// src/operators/matmul.cc:26-49.
+//
+// Kernels
+//   gemm_generic16 / gemm_generic32 : any shape / stride / alignment; 64x64 tile, LDS staged
+//       through registers with bounds checks, v_mfma_f32_16x16x32_{bf16,f16} or the exact-f32
+//       v_mfma_f32_16x16x4_f32. Correctness anchor and fallback for ragged shapes.
+//   gemm_fast128<A_KMAJOR,B_KMAJOR> : 16-bit, 128x128x64 tile, 4 waves (2x2, 64x64 each),
+//       global->LDS by LDS-DMA (global_load_lds_dwordx4) into a double buffer, one barrier per
+//       K-tile. K-major operands ([rows][k], k contiguous) are read with ds_read_b128 from an
+//       XOR-swizzled image (swizzle applied on the global SOURCE address because the DMA
+//       destination is lane-linear); M/N-major operands ([k][cols], the ONNX MatMul "NN" B and
+//       the transA A) are read with the gfx950 transpose read ds_read_b64_tr_b16, so no
+//       transposition pass is ever materialised.
+//   gemm_256 (gemm256.hip)         : 256x256x64 tile, 8 waves, deeper pipeline (headline shape).
+#include "gemm_common.h"
+#include <type_traits>
+
+namespace irocm {
+
+
+
+// ------------------------------------------------------------------------------------------------
+// Generic 16-bit kernel
+// ------------------------------------------------------------------------------------------------
+template <typename Tr> __global__ __launch_bounds__(256) void gemm_generic16(GemmArgs p) {
+    constexpr int BM = 64, BN = 64, BK = 32, PITCH = BK + 8;
+    __shared__ __attribute__((aligned(16))) unsigned short As[BM][PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[BN][PITCH];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int ib = blockIdx.z;
+    const int m0 = (blockIdx.x / p.tiles_n) * BM, n0 = (blockIdx.x % p.tiles_n) * BN;
+    const unsigned short *A = (const unsigned short *)p.a + (long)ib * p.a_bs;
+    const unsigned short *B = (const unsigned short *)p.b + (long)ib * p.b_bs;
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const bool a_kc = (p.a_cs == 1), b_kc = (p.b_rs == 1);
+    for (int k0 = 0; k0 < p.k; k0 += BK) {
+#pragma unroll
+        for (int j = 0; j < (BM * BK) / 256; ++j) {
+            const int idx = t + j * 256;
+            int i, kk;
+            if (a_kc) { kk = idx % BK; i = idx / BK; } else { i = idx % BM; kk = idx / BM; }
+            const int gi = m0 + i, gk = k0 + kk;
+            unsigned short v = 0;
+            if (gi < p.m && gk < p.k)
+                v = A[(long)gi * p.a_rs + (long)gk * p.a_cs];
+            As[i][kk] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < (BN * BK) / 256; ++j) {
+            const int idx = t + j * 256;
+            int jn, kk;
+            if (b_kc) { kk = idx % BK; jn = idx / BK; } else { jn = idx % BN; kk = idx / BN; }
+            const int gj = n0 + jn, gk = k0 + kk;
+            unsigned short v = 0;
+            if (gj < p.n && gk < p.k)
+                v = B[(long)gk * p.b_rs + (long)gj * p.b_cs];
+            Bs[jn][kk] = v;
+        }
+        __syncthreads();
+        s16x8_t af[2], bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            af[i] = *(const s16x8_t *)&As[wm * 32 + i * 16 + (lane & 15)][(lane >> 4) * 8];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            bf[j] = *(const s16x8_t *)&Bs[wn * 32 + j * 16 + (lane & 15)][(lane >> 4) * 8];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = Tr::mfma(af[i], bf[j], acc[i][j]);
+        __syncthreads();
+    }
+    // C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+    unsigned short *C = (unsigned short *)p.c + (long)ib * p.m * p.n;
+    const unsigned short *bias = (const unsigned short *)p.bias;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
+                const int col = n0 + wn * 32 + j * 16 + (lane & 15);
+                if (row < p.m && col < p.n) {
+                    float v = acc[i][j][r];
+                    if (bias)
+                        v += Tr::to_f32(bias[(long)ib * p.bias_b + (long)row * p.bias_m + (long)col * p.bias_n]);
+                    v = apply_act(v, p.act);
+                    C[(long)row * p.n + col] = Tr::from_f32(v);
+                }
+            }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic fp32 kernel: v_mfma_f32_16x16x4_f32 == an fmaf chain in k order (exact f32).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_generic32(GemmArgs p) {
+    constexpr int BM = 64, BN = 64, BK = 16, PITCH = BK + 1;
+    __shared__ float As[BM][PITCH];
+    __shared__ float Bs[BN][PITCH];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int ib = blockIdx.z;
+    const int m0 = (blockIdx.x / p.tiles_n) * BM, n0 = (blockIdx.x % p.tiles_n) * BN;
+    const float *A = (const float *)p.a + (long)ib * p.a_bs;
+    const float *B = (const float *)p.b + (long)ib * p.b_bs;
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const bool a_kc = (p.a_cs == 1), b_kc = (p.b_rs == 1);
+    for (int k0 = 0; k0 < p.k; k0 += BK) {
+#pragma unroll
+        for (int j = 0; j < (BM * BK) / 256; ++j) {
+            const int idx = t + j * 256;
+            int i, kk;
+            if (a_kc) { kk = idx % BK; i = idx / BK; } else { i = idx % BM; kk = idx / BM; }
+            const int gi = m0 + i, gk = k0 + kk;
+            float v = 0.f;
+            if (gi < p.m && gk < p.k)
+                v = A[(long)gi * p.a_rs + (long)gk * p.a_cs];
+            As[i][kk] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < (BN * BK) / 256; ++j) {
+            const int idx = t + j * 256;
+            int jn, kk;
+            if (b_kc) { kk = idx % BK; jn = idx / BK; } else { jn = idx % BN; kk = idx / BN; }
+            const int gj = n0 + jn, gk = k0 + kk;
+            float v = 0.f;
+            if (gj < p.n && gk < p.k)
+                v = B[(long)gk * p.b_rs + (long)gj * p.b_cs];
+            Bs[jn][kk] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            float af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                af[i] = As[wm * 32 + i * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bf[j] = Bs[wn * 32 + j * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float *C = (float *)p.c + (long)ib * p.m * p.n;
+    const float *bias = (const float *)p.bias;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
+                const int col = n0 + wn * 32 + j * 16 + (lane & 15);
+                if (row < p.m && col < p.n) {
+                    float v = acc[i][j][r];
+                    if (bias)
+                        v += bias[(long)ib * p.bias_b + (long)row * p.bias_m + (long)col * p.bias_n];
+                    C[(long)row * p.n + col] = apply_act(v, p.act);
+                }
+            }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fast 16-bit kernel, 128x128x64, LDS-DMA double buffer.
+// ------------------------------------------------------------------------------------------------
+namespace f128 {
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2; // 16 KiB per operand tile
+
+// K-major operand tile: image [128 rows][64 k] (128 B rows), physical 16-B chunk c' of row r holds
+// logical chunk c' ^ ((r >> 1) & 7): ds_read_b128 lane groups then hit 16 distinct 16-B slots.
+__device__ inline void stage_kmajor(const unsigned short *base, long ld, int row0, int rows, int k0,
+                                    char *lds_tile, int w, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = w * 4 + i;
+        const int r = piece * 8 + (lane >> 3);
+        const int c_log = (lane & 7) ^ ((r >> 1) & 7);
+        int gr = row0 + r;
+        gr = gr < rows ? gr : rows - 1;
+        const unsigned short *src = base + (long)gr * ld + k0 + c_log * 8;
+        __builtin_amdgcn_global_load_lds(IROCM_GLB_PTR(src), IROCM_LDS_PTR(lds_tile + piece * 1024), 16, 0, 0);
+    }
+}
+
+// M/N-major operand tile: image [64 k][128 cols] (256 B rows), 32-B chunk index XORed with
+// f(k) = (k & 3) | ((k >> 3) & 1) << 2 so the 8 k-rows one tr-read half-wave touches are spread
+// over the whole 256-B bank row.
+__device__ inline int mn_f(int kr) { return (kr & 3) | (((kr >> 3) & 1) << 2); }
+
+__device__ inline void stage_mnmajor(const unsigned short *base, long ld, int col0, int cols, int k0,
+                                     char *lds_tile, int w, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = w * 4 + i;
+        const int kr = piece * 4 + (lane >> 4);
+        const int c_log = (lane & 15) ^ (mn_f(kr) << 1);
+        int gc = col0 + c_log * 8;
+        gc = gc <= cols - 8 ? gc : cols - 8;
+        const unsigned short *src = base + (long)(k0 + kr) * ld + gc;
+        __builtin_amdgcn_global_load_lds(IROCM_GLB_PTR(src), IROCM_LDS_PTR(lds_tile + piece * 1024), 16, 0, 0);
+    }
+}
+
+// MFMA 16x16x32 operand fragment: lane l holds 8 consecutive k (ks*32 + (l>>4)*8 ..) of row/col
+// R0 + (l & 15).
+__device__ inline s16x8_t frag_kmajor(const char *lds_tile, int R0, int ks, int lane) {
+    const int r = R0 + (lane & 15);
+    const int c = (ks * 4 + (lane >> 4)) ^ ((r >> 1) & 7);
+    return *(const s16x8_t *)(lds_tile + r * 128 + c * 16);
+}
+
+__device__ inline s16x8_t frag_mnmajor(const char *lds_tile, int C0, int ks, int lane) {
+    // Two ds_read_b64_tr_b16: in each 16-lane group, lane p supplies the address of 4 consecutive
+    // columns (p & 3) * 4 of k-row (p >> 2) and receives column p of that 4x16 block.
+    const int p = lane & 15;
+    s16x4_t h[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int kr = ks * 32 + (lane >> 4) * 8 + hh * 4 + (p >> 2);
+        const int col = C0 + (p & 3) * 4;
+        const int c16 = (col >> 3) ^ (mn_f(kr) << 1);
+        const char *addr = lds_tile + kr * 256 + c16 * 16 + (col & 4) * 2;
+        h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t *)(addr));
+    }
+    return s16x8_t{h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
+}
+} // namespace f128
+
+template <typename Tr, bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(256) void gemm_fast128(GemmArgs p) {
+    using namespace f128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    auto a_tile = [&](int buf) -> char * { return smem + buf * TILE_BYTES; };
+    auto b_tile = [&](int buf) -> char * { return smem + (2 + buf) * TILE_BYTES; };
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = w >> 1, wn = w & 1;
+
+    // workgroup -> (batch, tile_m, tile_n): XCD-aware remap, then grouped raster (8 tile-rows).
+    const unsigned per_batch = (unsigned)p.tiles_m * p.tiles_n;
+    unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int ib = wg / per_batch;
+    wg -= ib * per_batch;
+    constexpr int GROUP_M = 8;
+    const unsigned per_group = GROUP_M * p.tiles_n;
+    const unsigned group = wg / per_group;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (wg % per_group) % gsz;
+    const int tn = (wg % per_group) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const unsigned short *A = (const unsigned short *)p.a + (long)ib * p.a_bs;
+    const unsigned short *B = (const unsigned short *)p.b + (long)ib * p.b_bs;
+    const long lda = A_KMAJOR ? p.a_rs : p.a_cs; // leading dimension of the stored matrix
+    const long ldb = B_KMAJOR ? p.b_cs : p.b_rs;
+
+    auto stage = [&](int buf, int k0) {
+        if constexpr (A_KMAJOR)
+            stage_kmajor(A, lda, m0, p.m, k0, a_tile(buf), w, lane);
+        else
+            stage_mnmajor(A, lda, m0, p.m, k0, a_tile(buf), w, lane);
+        if constexpr (B_KMAJOR)
+            stage_kmajor(B, ldb, n0, p.n, k0, b_tile(buf), w, lane);
+        else
+            stage_mnmajor(B, ldb, n0, p.n, k0, b_tile(buf), w, lane);
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.k / BK;
+    // One K-tile step with a COMPILE-TIME buffer index: hipcc only keeps the LDS-DMA of the next
+    // tile in flight across the ds_reads of the current one when it can prove the two LDS ranges
+    // distinct; a runtime (kt & 1) index makes it drain vmcnt(0) before the first ds_read.
+    auto step = [&](auto bufc, int kt) {
+        constexpr int buf = decltype(bufc)::value;
+        // tile kt has landed (own DMA waited for, then barrier => everybody's), and every wave has
+        // finished reading the other buffer (its compute of tile kt-1 precedes this barrier).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk)
+            stage(buf ^ 1, (kt + 1) * BK);
+        const char *at = a_tile(buf), *bt = b_tile(buf);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            s16x8_t af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                af[i] = A_KMAJOR ? frag_kmajor(at, wm * 64 + i * 16, ks, lane)
+                                 : frag_mnmajor(at, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                bf[j] = B_KMAJOR ? frag_kmajor(bt, wn * 64 + j * 16, ks, lane)
+                                 : frag_mnmajor(bt, wn * 64 + j * 16, ks, lane);
+            // swapped operands: D[i][j] = sum_k Bop[k][i] Aop[j][k] = C[m = j][n = i], so a lane
+            // ends up with 4 consecutive n of one m row (vector stores in the epilogue).
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = Tr::mfma(bf[j], af[i], acc[i][j]);
+        }
+    };
+    stage(0, 0);
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(std::integral_constant<int, 0>{}, kt);
+        if (kt + 1 < nk)
+            step(std::integral_constant<int, 1>{}, kt + 1);
+    }
+
+    unsigned short *C = (unsigned short *)p.c + (long)ib * p.m * p.n;
+    const unsigned short *bias = (const unsigned short *)p.bias;
+    const bool interior = (m0 + BM <= p.m) && (n0 + BN <= p.n) && (p.n % 4 == 0);
+    if (interior) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = m0 + wm * 64 + i * 16 + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r] = acc[i][j][r];
+                if (bias) {
+                    const unsigned short *bp = bias + (long)ib * p.bias_b + (long)row * p.bias_m + (long)col * p.bias_n;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        v[r] += Tr::to_f32(bp[(long)r * p.bias_n]);
+                }
+                if (p.act) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        v[r] = apply_act(v[r], p.act);
+                }
+                u32x2_t pk;
+                pk[0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
+                pk[1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
+                *(u32x2_t *)(C + (long)row * p.n + col) = pk;
+            }
+        }
+    } else {
+        for (int i = 0; i < 4; ++i) {
+            const int row = m0 + wm * 64 + i * 16 + (lane & 15);
+            for (int j = 0; j < 4; ++j) {
+                const int col = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+                for (int r = 0; r < 4; ++r) {
+                    // select the register with a static index (runtime-indexed vectors go to scratch)
+                    float v = 0.f;
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr)
+                                if (ii == i && jj == j && rr == r)
+                                    v = acc[ii][jj][rr];
+                    if (row < p.m && col + r < p.n) {
+                        if (bias)
+                            v += Tr::to_f32(bias[(long)ib * p.bias_b + (long)row * p.bias_m + (long)(col + r) * p.bias_n]);
+                        C[(long)row * p.n + col + r] = Tr::from_f32(apply_act(v, p.act));
+                    }
+                }
+            }
+        }
+    }
+}
+
+#ifdef IROCM_HAVE_GEMM256
+// implemented in gemm256.hip
+int launch_gemm256(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool a_kmajor, bool b_kmajor);
+bool gemm256_supported(const GemmArgs &p, bool a_kmajor, bool b_kmajor);
+#else
+static int launch_gemm256(infiniRocmRuntime_t, int, const GemmArgs &, bool, bool) { return INFINI_ROCM_UNSUPPORTED; }
+static bool gemm256_supported(const GemmArgs &, bool, bool) { return false; }
+#endif
+
+template <typename Tr> static int launch_fast128(infiniRocmRuntime_t rt, GemmArgs p, bool akm, bool bkm) {
+    p.tiles_m = (int)ceil_div(p.m, f128::BM);
+    p.tiles_n = (int)ceil_div(p.n, f128::BN);
+    const unsigned grid = (unsigned)p.tiles_m * p.tiles_n * p.batch;
+    const size_t lds = 4 * f128::TILE_BYTES;
+#define IROCM_F128(AK, BK_)                                                                        \
+    do {                                                                                           \
+        auto kern = gemm_fast128<Tr, AK, BK_>;                                                     \
+        static bool attr_done = false;                                                             \
+        if (!attr_done) {                                                                          \
+            IROCM_HIP(hipFuncSetAttribute((const void *)kern,                                      \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
+            attr_done = true;                                                                      \
+        }                                                                                          \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, rt->stream, p);                       \
+    } while (0)
+    if (akm && bkm) IROCM_F128(true, true);
+    else if (akm && !bkm) IROCM_F128(true, false);
+    else if (!akm && bkm) IROCM_F128(false, true);
+    else IROCM_F128(false, false);
+#undef IROCM_F128
+    IROCM_LAUNCH_CHECK("gemm_fast128");
+    return INFINI_ROCM_OK;
+}
+
+static bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+static bool fast128_supported(const GemmArgs &p, bool akm, bool bkm) {
+    if (p.k % f128::BK != 0 || p.k < f128::BK)
+        return false;
+    if (!aligned16(p.a) || !aligned16(p.b) || (p.a_bs % 8) || (p.b_bs % 8))
+        return false;
+    if (!akm && (p.m % 8 != 0 || p.m < 8))
+        return false;
+    if (!bkm && (p.n % 8 != 0 || p.n < 8))
+        return false;
+    if (!aligned16(p.c) && (p.n % 4 == 0))
+        return false;
+    return true;
+}
+
+static const char *kVariantNames[] = {"generic64", "fast128_glds", "tile256_8wave"};
+
+} // namespace irocm
+
+using namespace irocm;
+
+extern "C" {
+
+int infini_rocm_matmul_num_variants(void) { return 3; }
+
+const char *infini_rocm_matmul_variant_name(int v) {
+    return (v >= 0 && v < 3) ? kVariantNames[v] : "invalid";
+}
+
+int infini_rocm_matmul_set_variant(infiniRocmRuntime_t rt, int variant) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(variant >= -1 && variant < 3, "variant %d out of range", variant);
+    rt->matmul_variant = variant;
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_matmul(infiniRocmRuntime_t rt, int dtype, const void *a, const void *b,
+                       const void *bias, void *c, int64_t batch, int64_t m, int64_t n, int64_t k,
+                       int trans_a, int trans_b, int64_t stride_a, int64_t stride_b,
+                       int64_t bias_stride_b, int64_t bias_stride_m, int64_t bias_stride_n,
+                       int act) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(dtype == INFINI_DT_F32 || dtype == INFINI_DT_F16 || dtype == INFINI_DT_BF16,
+                    "matmul: unsupported dtype %s", dtype_name(dtype));
+    IROCM_CHECK_ARG(batch >= 0 && m >= 0 && n >= 0 && k >= 0, "matmul: negative dimension");
+    IROCM_CHECK_ARG(batch < 65536 && m < (1ll << 31) && n < (1ll << 31) && k < (1ll << 31),
+                    "matmul: dimension too large");
+    IROCM_CHECK_ARG(act >= 0 && act <= 3, "matmul: bad act %d", act);
+    if (batch == 0 || m == 0 || n == 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(a && b && c, "matmul: NULL operand");
+
+    GemmArgs p;
+    p.a = a; p.b = b; p.bias = bias; p.c = c;
+    p.m = (int)m; p.n = (int)n; p.k = (int)k; p.batch = (int)batch;
+    p.a_rs = trans_a ? 1 : k; p.a_cs = trans_a ? m : 1; p.a_bs = stride_a;
+    p.b_rs = trans_b ? 1 : n; p.b_cs = trans_b ? k : 1; p.b_bs = stride_b;
+    p.bias_b = bias_stride_b; p.bias_m = bias_stride_m; p.bias_n = bias_stride_n;
+    p.act = act;
+    p.tiles_m = p.tiles_n = 0;
+    const bool akm = !trans_a, bkm = trans_b != 0;
+
+    int variant = rt->matmul_variant;
+    if (dtype == INFINI_DT_F32)
+        variant = 0;
+    if (variant < 0) {
+        // heuristic: the 256^2 kernel wants at least ~one tile per CU; otherwise 128^2.
+        if (gemm256_supported(p, akm, bkm) &&
+            ceil_div(m, 256) * ceil_div(n, 256) * batch >= rt->num_cu / 2)
+            variant = 2;
+        else if (fast128_supported(p, akm, bkm))
+            variant = 1;
+        else
+            variant = 0;
+    } else if (variant == 2 && !gemm256_supported(p, akm, bkm)) {
+        variant = fast128_supported(p, akm, bkm) ? 1 : 0;
+    } else if (variant == 1 && !fast128_supported(p, akm, bkm)) {
+        variant = 0;
+    }
+
+    if (variant == 2)
+        return launch_gemm256(rt, dtype, p, akm, bkm);
+    if (variant == 1)
+        return dtype == INFINI_DT_BF16 ? launch_fast128<Bf16Traits>(rt, p, akm, bkm)
+                                       : launch_fast128<F16Traits>(rt, p, akm, bkm);
+    p.tiles_m = (int)ceil_div(m, 64);
+    p.tiles_n = (int)ceil_div(n, 64);
+    IROCM_CHECK_ARG((int64_t)p.tiles_m * p.tiles_n < (1ll << 31), "matmul: too many tiles");
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1, (unsigned)batch);
+    if (dtype == INFINI_DT_F32)
+        hipLaunchKernelGGL(gemm_generic32, grid, dim3(256), 0, rt->stream, p);
+    else if (dtype == INFINI_DT_BF16)
+        hipLaunchKernelGGL(gemm_generic16<Bf16Traits>, grid, dim3(256), 0, rt->stream, p);
+    else
+        hipLaunchKernelGGL(gemm_generic16<F16Traits>, grid, dim3(256), 0, rt->stream, p);
+    IROCM_LAUNCH_CHECK("gemm_generic");
+    return INFINI_ROCM_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,452 @@
+// HBM-bound row operators for gfx950: Softmax, LayerNormalization, RMSNorm.
+//
+// Softmax    replaces softmax_kernel      (reference: src/kernels/cuda/softmax.cu:242-404)
+// LayerNorm  replaces LaynormKernel       (reference: src/kernels/cuda/layer_norm.cu:339-558)
+// RMSNorm    replaces rmsnorm_kernel      (reference: src/kernels/cuda/rms_norm.cu:35-110)
+//
+// Design (MI355X): every row is read from HBM exactly once and written once — algorithmic bytes
+// 2 * numel * sizeof(T). A row of up to 64 * 16 * VPT elements lives in the registers
+// of ONE wave64 (16-byte loads per lane, `VEC` elements each); max / sum / mean / variance are
+// wave reductions through DPP/ds_swizzle shuffles (no LDS, no barrier). Longer rows use one
+// 256-thread block per row with the row cached in registers and a 4-wave LDS combine.
+// Strided (inner > 1) softmax maps lanes along the contiguous inner dimension instead, so
+// accesses stay coalesced, and walks the softmax axis with the online max/sum recurrence of the
+// reference (softmax.cu:8-17).
+// All arithmetic is fp32 regardless of the storage dtype.
+#include "common.h"
+
+namespace irocm {
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int VEC = 4; // 16 B
+    __device__ static inline float ld(const float *p) { return *p; }
+    __device__ static inline void st(float *p, float v) { *p = v; }
+};
+template <> struct Elem<__half> {
+    static constexpr int VEC = 8;
+    __device__ static inline float ld(const __half *p) { return __half2float(*p); }
+    __device__ static inline void st(__half *p, float v) { *p = __float2half_rn(v); }
+};
+template <> struct Elem<__hip_bfloat16> {
+    static constexpr int VEC = 8;
+    __device__ static inline float ld(const __hip_bfloat16 *p) { return __bfloat162float(*p); }
+    __device__ static inline void st(__hip_bfloat16 *p, float v) { *p = __float2bfloat16(v); }
+};
+
+template <typename T, int N> struct alignas(sizeof(T) * N) Pack {
+    T v[N];
+};
+
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Contiguous rows (inner == 1). One wave per row; CHUNKS 16-byte chunks per lane.
+// Handles any dimsize <= 64 * VEC * CHUNKS; vector loads when the row base is 16-B aligned,
+// otherwise element loads (same register image).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int CHUNKS, bool ALIGNED>
+__device__ inline void load_row(const T *row, int n, int lane, float (&x)[CHUNKS * Elem<T>::VEC], float fill) {
+    constexpr int VEC = Elem<T>::VEC;
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+        const int base = (c * 64 + lane) * VEC;
+        if (ALIGNED && base + VEC <= n) {
+            Pack<T, VEC> pk = *reinterpret_cast<const Pack<T, VEC> *>(row + base);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                x[c * VEC + j] = Elem<T>::ld(&pk.v[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                x[c * VEC + j] = (base + j < n) ? Elem<T>::ld(row + base + j) : fill;
+        }
+    }
+}
+
+template <typename T, int CHUNKS, bool ALIGNED>
+__device__ inline void store_row(T *row, int n, int lane, const float (&y)[CHUNKS * Elem<T>::VEC]) {
+    constexpr int VEC = Elem<T>::VEC;
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+        const int base = (c * 64 + lane) * VEC;
+        if (ALIGNED && base + VEC <= n) {
+            Pack<T, VEC> pk;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                Elem<T>::st(&pk.v[j], y[c * VEC + j]);
+            *reinterpret_cast<Pack<T, VEC> *>(row + base) = pk;
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                if (base + j < n)
+                    Elem<T>::st(row + base + j, y[c * VEC + j]);
+        }
+    }
+}
+
+template <typename T, int CHUNKS, bool ALIGNED>
+__global__ __launch_bounds__(256) void softmax_wave_kernel(const T *__restrict__ x, T *__restrict__ y,
+                                                           long rows, int n) {
+    constexpr int NV = CHUNKS * Elem<T>::VEC;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows)
+        return;
+    float v[NV];
+    load_row<T, CHUNKS, ALIGNED>(x + row * n, n, lane, v, -INFINITY);
+    float m = v[0];
+#pragma unroll
+    for (int i = 1; i < NV; ++i)
+        m = fmaxf(m, v[i]);
+    m = wave_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = __expf(v[i] - m);
+        s += v[i];
+    }
+    s = wave_sum(s);
+    const float inv = 1.0f / s;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        v[i] *= inv;
+    store_row<T, CHUNKS, ALIGNED>(y + row * n, n, lane, v);
+}
+
+// Long contiguous rows: one 256-thread block per row, grid-stride over rows, three passes over a
+// row kept in L2/MALL when it does not fit registers (rare: dimsize > 8192).
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_block_kernel(const T *__restrict__ x, T *__restrict__ y,
+                                                            long rows, long n) {
+    __shared__ float red[4];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const T *xr = x + row * n;
+        T *yr = y + row * n;
+        float m = -INFINITY, s = 0.f;
+        for (long i = t; i < n; i += 256) { // online max/sum (reference softmax.cu:8-17)
+            const float v = Elem<T>::ld(xr + i);
+            const float nm = fmaxf(m, v);
+            s = s * __expf(m - nm) + __expf(v - nm);
+            m = nm;
+        }
+        float gm = wave_max(m);
+        s *= __expf(m - gm);
+        s = wave_sum(s);
+        if (lane == 0)
+            red[w] = gm;
+        __syncthreads();
+        const float bm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __syncthreads();
+        s *= __expf(gm - bm);
+        if (lane == 0)
+            red[w] = s;
+        __syncthreads();
+        const float bs = red[0] + red[1] + red[2] + red[3];
+        __syncthreads();
+        const float inv = 1.0f / bs;
+        for (long i = t; i < n; i += 256)
+            Elem<T>::st(yr + i, __expf(Elem<T>::ld(xr + i) - bm) * inv);
+    }
+}
+
+// Strided softmax: tensor [outer, dimsize, inner], inner > 1. One thread per (outer, inner)
+// column; consecutive lanes take consecutive inner positions (coalesced); online recurrence.
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_strided_kernel(const T *__restrict__ x, T *__restrict__ y,
+                                                              long outer, long dimsize, long inner) {
+    const long total = outer * inner;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const long o = idx / inner, i = idx % inner;
+        const T *xp = x + o * dimsize * inner + i;
+        T *yp = y + o * dimsize * inner + i;
+        float m = -INFINITY, s = 0.f;
+        for (long d = 0; d < dimsize; ++d) {
+            const float v = Elem<T>::ld(xp + d * inner);
+            const float nm = fmaxf(m, v);
+            s = s * __expf(m - nm) + __expf(v - nm);
+            m = nm;
+        }
+        const float inv = 1.0f / s;
+        for (long d = 0; d < dimsize; ++d)
+            Elem<T>::st(yp + d * inner, __expf(Elem<T>::ld(xp + d * inner) - m) * inv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm / RMSNorm, one wave per row (row in registers), two-pass mean/variance in registers
+// (numerically the "centered" form: var = mean((x - mu)^2)), fp32 throughout.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int CHUNKS, bool ALIGNED, bool RMS>
+__global__ __launch_bounds__(256) void norm_wave_kernel(const T *__restrict__ x, const T *__restrict__ scale,
+                                                        const T *__restrict__ bias, T *__restrict__ y,
+                                                        long rows, int n, int scale_size, int bias_size,
+                                                        float eps) {
+    constexpr int VEC = Elem<T>::VEC;
+    constexpr int NV = CHUNKS * VEC;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows)
+        return;
+    float v[NV];
+    load_row<T, CHUNKS, ALIGNED>(x + row * n, n, lane, v, 0.f);
+    const float inv_n = 1.0f / (float)n;
+    float mu = 0.f;
+    if (!RMS) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            s += v[i];
+        mu = wave_sum(s) * inv_n;
+    }
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int col = (c * 64 + lane) * VEC + j;
+            const float d = (col < n) ? v[c * VEC + j] - mu : 0.f;
+            q += d * d;
+        }
+    const float rstd = rsqrtf(wave_sum(q) * inv_n + eps);
+    // scale / bias: per-element (size n) or scalar (size 1)
+    float sc[NV], bs[NV];
+    if (scale_size == 1) {
+        const float s0 = Elem<T>::ld(scale);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            sc[i] = s0;
+    } else {
+        load_row<T, CHUNKS, ALIGNED>(scale, n, lane, sc, 0.f);
+    }
+    if (bias == nullptr) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            bs[i] = 0.f;
+    } else if (bias_size == 1) {
+        const float b0 = Elem<T>::ld(bias);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            bs[i] = b0;
+    } else {
+        load_row<T, CHUNKS, ALIGNED>(bias, n, lane, bs, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        v[i] = (v[i] - mu) * rstd * sc[i] + bs[i];
+    store_row<T, CHUNKS, ALIGNED>(y + row * n, n, lane, v);
+}
+
+// Long rows: block per row, row re-read from L2.
+template <typename T, bool RMS>
+__global__ __launch_bounds__(256) void norm_block_kernel(const T *__restrict__ x, const T *__restrict__ scale,
+                                                         const T *__restrict__ bias, T *__restrict__ y,
+                                                         long rows, long n, int scale_size, int bias_size,
+                                                         float eps) {
+    __shared__ float red[4];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const T *xr = x + row * n;
+        T *yr = y + row * n;
+        float mu = 0.f;
+        if (!RMS) {
+            float s = 0.f;
+            for (long i = t; i < n; i += 256)
+                s += Elem<T>::ld(xr + i);
+            s = wave_sum(s);
+            if (lane == 0)
+                red[w] = s;
+            __syncthreads();
+            mu = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+            __syncthreads();
+        }
+        float q = 0.f;
+        for (long i = t; i < n; i += 256) {
+            const float d = Elem<T>::ld(xr + i) - mu;
+            q += d * d;
+        }
+        q = wave_sum(q);
+        if (lane == 0)
+            red[w] = q;
+        __syncthreads();
+        const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)n + eps);
+        __syncthreads();
+        for (long i = t; i < n; i += 256) {
+            const float s = Elem<T>::ld(scale + (scale_size == 1 ? 0 : i));
+            const float b = bias ? Elem<T>::ld(bias + (bias_size == 1 ? 0 : i)) : 0.f;
+            Elem<T>::st(yr + i, (Elem<T>::ld(xr + i) - mu) * rstd * s + b);
+        }
+    }
+}
+
+static inline bool is_aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+template <typename T>
+static int softmax_dispatch(infiniRocmRuntime_t rt, const T *x, T *y, int64_t outer, int64_t dimsize,
+                            int64_t inner) {
+    constexpr int VEC = Elem<T>::VEC;
+    if (inner == 1) {
+        const bool al = is_aligned16(x) && is_aligned16(y) && (dimsize % VEC == 0);
+        const int64_t per_chunk = 64 * VEC;
+        const int chunks = (int)ceil_div(dimsize, per_chunk);
+        const unsigned grid = (unsigned)ceil_div(outer, 4);
+#define SM_LAUNCH(C)                                                                               \
+    do {                                                                                           \
+        if (al)                                                                                    \
+            hipLaunchKernelGGL((softmax_wave_kernel<T, C, true>), dim3(grid), dim3(256), 0,        \
+                               rt->stream, x, y, (long)outer, (int)dimsize);                       \
+        else                                                                                       \
+            hipLaunchKernelGGL((softmax_wave_kernel<T, C, false>), dim3(grid), dim3(256), 0,       \
+                               rt->stream, x, y, (long)outer, (int)dimsize);                       \
+    } while (0)
+        if (chunks <= 1) SM_LAUNCH(1);
+        else if (chunks <= 2) SM_LAUNCH(2);
+        else if (chunks <= 4) SM_LAUNCH(4);
+        else if (chunks <= 8) SM_LAUNCH(8);
+        else {
+            const unsigned g = (unsigned)(outer < 8192 ? outer : 8192);
+            hipLaunchKernelGGL((softmax_block_kernel<T>), dim3(g), dim3(256), 0, rt->stream, x, y,
+                               (long)outer, (long)dimsize);
+        }
+#undef SM_LAUNCH
+    } else {
+        const int64_t total = outer * inner;
+        const unsigned g = (unsigned)(ceil_div(total, 256) < 16384 ? ceil_div(total, 256) : 16384);
+        hipLaunchKernelGGL((softmax_strided_kernel<T>), dim3(g), dim3(256), 0, rt->stream, x, y,
+                           (long)outer, (long)dimsize, (long)inner);
+    }
+    IROCM_LAUNCH_CHECK("softmax");
+    return INFINI_ROCM_OK;
+}
+
+template <typename T, bool RMS>
+static int norm_dispatch(infiniRocmRuntime_t rt, const T *x, const T *scale, const T *bias, T *y,
+                         int64_t outer, int64_t n, int64_t scale_size, int64_t bias_size, float eps) {
+    constexpr int VEC = Elem<T>::VEC;
+    const bool al = is_aligned16(x) && is_aligned16(y) && is_aligned16(scale) &&
+                    (bias == nullptr || is_aligned16(bias)) && (n % VEC == 0);
+    const int chunks = (int)ceil_div(n, (int64_t)64 * VEC);
+    const unsigned grid = (unsigned)ceil_div(outer, 4);
+#define NORM_LAUNCH(C)                                                                             \
+    do {                                                                                           \
+        if (al)                                                                                    \
+            hipLaunchKernelGGL((norm_wave_kernel<T, C, true, RMS>), dim3(grid), dim3(256), 0,      \
+                               rt->stream, x, scale, bias, y, (long)outer, (int)n,                 \
+                               (int)scale_size, (int)bias_size, eps);                              \
+        else                                                                                       \
+            hipLaunchKernelGGL((norm_wave_kernel<T, C, false, RMS>), dim3(grid), dim3(256), 0,     \
+                               rt->stream, x, scale, bias, y, (long)outer, (int)n,                 \
+                               (int)scale_size, (int)bias_size, eps);                              \
+    } while (0)
+    if (chunks <= 1) NORM_LAUNCH(1);
+    else if (chunks <= 2) NORM_LAUNCH(2);
+    else if (chunks <= 4) NORM_LAUNCH(4);
+    else {
+        const unsigned g = (unsigned)(outer < 8192 ? outer : 8192);
+        hipLaunchKernelGGL((norm_block_kernel<T, RMS>), dim3(g), dim3(256), 0, rt->stream, x, scale,
+                           bias, y, (long)outer, (long)n, (int)scale_size, (int)bias_size, eps);
+    }
+#undef NORM_LAUNCH
+    IROCM_LAUNCH_CHECK("norm");
+    return INFINI_ROCM_OK;
+}
+
+} // namespace irocm
+
+using namespace irocm;
+
+extern "C" {
+
+int infini_rocm_softmax(infiniRocmRuntime_t rt, int dtype, const void *x, void *y, int64_t outer,
+                        int64_t dimsize, int64_t inner) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(outer >= 0 && dimsize >= 0 && inner >= 0, "softmax: negative extent");
+    if (outer == 0 || dimsize == 0 || inner == 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(x && y, "softmax: NULL tensor");
+    IROCM_CHECK_ARG(dimsize < (1ll << 31), "softmax: dimsize too large");
+    switch (dtype) {
+    case INFINI_DT_F32:
+        return softmax_dispatch<float>(rt, (const float *)x, (float *)y, outer, dimsize, inner);
+    case INFINI_DT_F16:
+        return softmax_dispatch<__half>(rt, (const __half *)x, (__half *)y, outer, dimsize, inner);
+    case INFINI_DT_BF16:
+        return softmax_dispatch<__hip_bfloat16>(rt, (const __hip_bfloat16 *)x, (__hip_bfloat16 *)y,
+                                                outer, dimsize, inner);
+    default:
+        IROCM_FAIL(INFINI_ROCM_UNSUPPORTED, "softmax: unsupported dtype %s", dtype_name(dtype));
+    }
+}
+
+int infini_rocm_layer_norm(infiniRocmRuntime_t rt, int dtype, const void *x, const void *scale,
+                           const void *bias, void *y, int64_t outer, int64_t norm_size,
+                           int64_t scale_size, int64_t bias_size, float eps) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(outer >= 0 && norm_size >= 0, "layer_norm: negative extent");
+    if (outer == 0 || norm_size == 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(x && y && scale, "layer_norm: NULL tensor");
+    IROCM_CHECK_ARG(scale_size == 1 || scale_size == norm_size,
+                    "layer_norm: scale has %lld elements, expected 1 or %lld", (long long)scale_size,
+                    (long long)norm_size);
+    IROCM_CHECK_ARG(bias == nullptr || bias_size == 1 || bias_size == norm_size,
+                    "layer_norm: bias has %lld elements, expected 1 or %lld", (long long)bias_size,
+                    (long long)norm_size);
+    IROCM_CHECK_ARG(norm_size < (1ll << 31), "layer_norm: norm_size too large");
+    switch (dtype) {
+    case INFINI_DT_F32:
+        return norm_dispatch<float, false>(rt, (const float *)x, (const float *)scale,
+                                           (const float *)bias, (float *)y, outer, norm_size,
+                                           scale_size, bias_size, eps);
+    case INFINI_DT_F16:
+        return norm_dispatch<__half, false>(rt, (const __half *)x, (const __half *)scale,
+                                            (const __half *)bias, (__half *)y, outer, norm_size,
+                                            scale_size, bias_size, eps);
+    case INFINI_DT_BF16:
+        return norm_dispatch<__hip_bfloat16, false>(
+            rt, (const __hip_bfloat16 *)x, (const __hip_bfloat16 *)scale, (const __hip_bfloat16 *)bias,
+            (__hip_bfloat16 *)y, outer, norm_size, scale_size, bias_size, eps);
+    default:
+        IROCM_FAIL(INFINI_ROCM_UNSUPPORTED, "layer_norm: unsupported dtype %s", dtype_name(dtype));
+    }
+}
+
+int infini_rocm_rms_norm(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, void *y,
+                         int64_t outer, int64_t norm_size, float eps) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(outer >= 0 && norm_size >= 0, "rms_norm: negative extent");
+    if (outer == 0 || norm_size == 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(x && y && w, "rms_norm: NULL tensor");
+    IROCM_CHECK_ARG(norm_size < (1ll << 31), "rms_norm: norm_size too large");
+    switch (dtype) {
+    case INFINI_DT_F32:
+        return norm_dispatch<float, true>(rt, (const float *)x, (const float *)w, nullptr, (float *)y,
+                                          outer, norm_size, norm_size, 0, eps);
+    case INFINI_DT_F16:
+        return norm_dispatch<__half, true>(rt, (const __half *)x, (const __half *)w, nullptr,
+                                           (__half *)y, outer, norm_size, norm_size, 0, eps);
+    case INFINI_DT_BF16:
+        return norm_dispatch<__hip_bfloat16, true>(rt, (const __hip_bfloat16 *)x,
+                                                   (const __hip_bfloat16 *)w, nullptr,
+                                                   (__hip_bfloat16 *)y, outer, norm_size, norm_size, 0,
+                                                   eps);
+    default:
+        IROCM_FAIL(INFINI_ROCM_UNSUPPORTED, "rms_norm: unsupported dtype %s", dtype_name(dtype));
+    }
+}
+
+} // extern "C"

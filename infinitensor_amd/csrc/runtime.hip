@@ -1,0 +1,293 @@
+// Runtime part of the C ABI: device, stream, memory, workspace, events, hipGraph capture.
+// Mirrors what CudaRuntimeObj owns in the reference (src/cuda/cuda_runtime.cc:30-120, 252-426,
+// 481-493) but as a plain C handle; the C++ plugin's RocmRuntimeObj wraps one of these.
+#include "common.h"
+
+namespace irocm {
+static thread_local char g_err[1024] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+} // namespace irocm
+
+using namespace irocm;
+
+extern "C" {
+
+const char *infini_rocm_last_error(void) { return irocm::g_err; }
+
+const char *infini_rocm_version(void) { return "infinitensor_amd 0.1 (gfx950)"; }
+
+int infini_rocm_device_count(int *count) {
+    IROCM_CHECK_ARG(count, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_runtime_create(int device, infiniRocmRuntime_t *out) {
+    IROCM_CHECK_ARG(out, "out is NULL");
+    int n = 0;
+    IROCM_HIP(hipGetDeviceCount(&n));
+    IROCM_CHECK_ARG(device >= 0 && device < n, "device %d out of range (have %d)", device, n);
+    IROCM_HIP(hipSetDevice(device));
+    auto *rt = new infiniRocmRuntime();
+    rt->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&rt->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete rt;
+        IROCM_FAIL(INFINI_ROCM_HIP_ERROR, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    }
+    rt->stream = rt->own_stream;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess)
+        rt->num_cu = prop.multiProcessorCount;
+    *out = rt;
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_runtime_destroy(infiniRocmRuntime_t rt) {
+    if (!rt)
+        return INFINI_ROCM_OK;
+    (void)hipSetDevice(rt->device);
+    if (rt->own_stream) {
+        (void)hipStreamSynchronize(rt->own_stream);
+    }
+    if (rt->workspace)
+        (void)hipFree(rt->workspace);
+    if (rt->own_stream)
+        (void)hipStreamDestroy(rt->own_stream);
+    delete rt;
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_runtime_device_info(infiniRocmRuntime_t rt, infiniRocmDeviceInfo *info) {
+    IROCM_CHECK_ARG(rt && info, "NULL argument");
+    hipDeviceProp_t prop;
+    IROCM_HIP(hipGetDeviceProperties(&prop, rt->device));
+    memset(info, 0, sizeof(*info));
+    snprintf(info->name, sizeof(info->name), "%s", prop.name);
+    snprintf(info->arch, sizeof(info->arch), "%s", prop.gcnArchName);
+    info->compute_units = prop.multiProcessorCount;
+    info->clock_mhz = prop.clockRate / 1000;
+    info->memory_clock_mhz = prop.memoryClockRate / 1000;
+    info->memory_bus_bits = prop.memoryBusWidth;
+    info->total_memory = prop.totalGlobalMem;
+    info->wavefront_size = prop.warpSize;
+    info->lds_bytes_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_runtime_get_stream(infiniRocmRuntime_t rt, void **stream) {
+    IROCM_CHECK_ARG(rt && stream, "NULL argument");
+    *stream = (void *)rt->stream;
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_runtime_set_stream(infiniRocmRuntime_t rt, void *stream) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(!rt->capturing, "cannot change stream while capturing");
+    rt->stream = stream ? (hipStream_t)stream : rt->own_stream;
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_runtime_sync(infiniRocmRuntime_t rt) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_HIP(hipStreamSynchronize(rt->stream));
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_alloc(infiniRocmRuntime_t rt, size_t bytes, void **ptr) {
+    IROCM_CHECK_ARG(rt && ptr, "NULL argument");
+    IROCM_HIP(hipSetDevice(rt->device));
+    *ptr = nullptr;
+    if (bytes == 0)
+        return INFINI_ROCM_OK;
+    IROCM_HIP(hipMalloc(ptr, bytes));
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_dealloc(infiniRocmRuntime_t rt, void *ptr) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    if (ptr)
+        IROCM_HIP(hipFree(ptr));
+    return INFINI_ROCM_OK;
+}
+
+// Host<->device copies are ordered with the runtime stream and block the caller, like the
+// reference's cudaMemcpy-based copyBlobFromCPU/ToCPU (src/cuda/cuda_runtime.cc:485-493).
+int infini_rocm_copy_from_cpu(infiniRocmRuntime_t rt, void *dst, const void *src, size_t bytes) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    if (bytes == 0)
+        return INFINI_ROCM_OK;
+    IROCM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, rt->stream));
+    IROCM_HIP(hipStreamSynchronize(rt->stream));
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_copy_to_cpu(infiniRocmRuntime_t rt, void *dst, const void *src, size_t bytes) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    if (bytes == 0)
+        return INFINI_ROCM_OK;
+    IROCM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, rt->stream));
+    IROCM_HIP(hipStreamSynchronize(rt->stream));
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_copy_inside(infiniRocmRuntime_t rt, void *dst, const void *src, size_t bytes) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    if (bytes == 0 || dst == src)
+        return INFINI_ROCM_OK;
+    IROCM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, rt->stream));
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_memset(infiniRocmRuntime_t rt, void *dst, int value, size_t bytes) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    if (bytes == 0)
+        return INFINI_ROCM_OK;
+    IROCM_HIP(hipMemsetAsync(dst, value, bytes, rt->stream));
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_workspace(infiniRocmRuntime_t rt, size_t bytes, void **ptr) {
+    IROCM_CHECK_ARG(rt && ptr, "NULL argument");
+    if (bytes > rt->workspace_bytes) {
+        // Growing frees the old buffer: illegal while a capture is recording launches that use it.
+        if (rt->capturing)
+            IROCM_FAIL(INFINI_ROCM_CAPTURE_ERROR,
+                       "workspace must be pre-sized before graph capture (need %zu, have %zu)",
+                       bytes, rt->workspace_bytes);
+        IROCM_HIP(hipSetDevice(rt->device));
+        if (rt->workspace) {
+            IROCM_HIP(hipStreamSynchronize(rt->stream));
+            IROCM_HIP(hipFree(rt->workspace));
+            rt->workspace = nullptr;
+            rt->workspace_bytes = 0;
+        }
+        size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+        IROCM_HIP(hipMalloc(&rt->workspace, want));
+        rt->workspace_bytes = want;
+    }
+    *ptr = rt->workspace;
+    return INFINI_ROCM_OK;
+}
+
+// ---- events --------------------------------------------------------------------------------
+int infini_rocm_event_create(infiniRocmEvent_t *ev) {
+    IROCM_CHECK_ARG(ev, "NULL argument");
+    auto *e = new infiniRocmEvent();
+    hipError_t r = hipEventCreate(&e->ev);
+    if (r != hipSuccess) {
+        delete e;
+        IROCM_FAIL(INFINI_ROCM_HIP_ERROR, "hipEventCreate failed: %s", hipGetErrorString(r));
+    }
+    *ev = e;
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_event_destroy(infiniRocmEvent_t ev) {
+    if (ev) {
+        (void)hipEventDestroy(ev->ev);
+        delete ev;
+    }
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_event_record(infiniRocmRuntime_t rt, infiniRocmEvent_t ev) {
+    IROCM_CHECK_ARG(rt && ev, "NULL argument");
+    IROCM_HIP(hipEventRecord(ev->ev, rt->stream));
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_event_elapsed_ms(infiniRocmEvent_t start, infiniRocmEvent_t stop, float *ms) {
+    IROCM_CHECK_ARG(start && stop && ms, "NULL argument");
+    IROCM_HIP(hipEventSynchronize(stop->ev));
+    IROCM_HIP(hipEventElapsedTime(ms, start->ev, stop->ev));
+    return INFINI_ROCM_OK;
+}
+
+// ---- hipGraph capture ----------------------------------------------------------------------
+int infini_rocm_graph_begin_capture(infiniRocmRuntime_t rt) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(!rt->capturing, "capture already active");
+    // ThreadLocal mode, like the reference (cuda_runtime.cc:259-266): other threads/runtimes
+    // may keep using the device while this stream records.
+    IROCM_HIP(hipStreamBeginCapture(rt->stream, hipStreamCaptureModeThreadLocal));
+    rt->capturing = true;
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_graph_end_capture(infiniRocmRuntime_t rt, infiniRocmGraph_t *graph) {
+    IROCM_CHECK_ARG(rt && graph, "NULL argument");
+    IROCM_CHECK_ARG(rt->capturing, "no capture active");
+    rt->capturing = false;
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(rt->stream, &g);
+    if (e != hipSuccess || !g) {
+        (void)hipGetLastError();
+        IROCM_FAIL(INFINI_ROCM_CAPTURE_ERROR, "hipStreamEndCapture failed: %s",
+                   hipGetErrorString(e));
+    }
+    hipGraphExec_t x = nullptr;
+    e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        IROCM_FAIL(INFINI_ROCM_CAPTURE_ERROR, "hipGraphInstantiate failed: %s",
+                   hipGetErrorString(e));
+    }
+    auto *out = new infiniRocmGraph();
+    out->graph = g;
+    out->exec = x;
+    *graph = out;
+    return INFINI_ROCM_OK;
+}
+
+// Abandon a capture after a failure inside it (reference: recoverExecutionStreamAfterFailure,
+// cuda_runtime.cc:226-250 — the poisoned stream is destroyed and recreated).
+int infini_rocm_graph_abort_capture(infiniRocmRuntime_t rt) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    if (rt->capturing) {
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(rt->stream, &g);
+        if (g)
+            (void)hipGraphDestroy(g);
+        rt->capturing = false;
+    }
+    (void)hipGetLastError();
+    if (rt->stream == rt->own_stream) {
+        (void)hipStreamDestroy(rt->own_stream);
+        rt->own_stream = nullptr;
+        IROCM_HIP(hipStreamCreateWithFlags(&rt->own_stream, hipStreamNonBlocking));
+        rt->stream = rt->own_stream;
+    }
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_graph_launch(infiniRocmRuntime_t rt, infiniRocmGraph_t graph) {
+    IROCM_CHECK_ARG(rt && graph && graph->exec, "NULL argument");
+    IROCM_HIP(hipGraphLaunch(graph->exec, rt->stream));
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_graph_destroy(infiniRocmGraph_t graph) {
+    if (graph) {
+        if (graph->exec)
+            (void)hipGraphExecDestroy(graph->exec);
+        if (graph->graph)
+            (void)hipGraphDestroy(graph->graph);
+        delete graph;
+    }
+    return INFINI_ROCM_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,59 @@
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+_KATS = None
+
+
+def kat(file: str, line: int, kind: str | None = None, index: int = 0) -> np.ndarray:
+    """Golden vector asserted by the reference test `file` at `line` (tests/golden/kats.json,
+    produced by tests/golden/extract_kats.py). `index` picks among several literals on a line."""
+    global _KATS
+    if _KATS is None:
+        _KATS = json.loads((REPO / "tests" / "golden" / "kats.json").read_text())
+    recs = [r for r in _KATS[file] if r["line"] == line and (kind is None or r["kind"] == kind)]
+    if not recs:
+        raise KeyError(f"no golden literal at {file}:{line} (kind={kind})")
+    return np.array(recs[index]["values"])
+
+
+@pytest.fixture(scope="session")
+def ref_backend():
+    """The reference's own native-CPU backend (oracle/_ref, built from /root/reference)."""
+    import importlib.util
+    import sysconfig
+
+    p = REPO / "oracle" / "_ref" / f"backend{sysconfig.get_config_var('EXT_SUFFIX')}"
+    if not p.exists():
+        pytest.skip("oracle/_ref not built (run __graft_entry__.build() where /root/reference exists)")
+    if "backend" in sys.modules:
+        return sys.modules["backend"]
+    spec = importlib.util.spec_from_file_location("backend", p)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["backend"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="session")
+def rt():
+    """A RocmRuntime on cuda:0 launching on torch's current stream. Fails loudly without the lib."""
+    import torch
+
+    from infinitensor_amd import RocmRuntime
+
+    assert torch.cuda.is_available(), "gpu test needs a GPU"
+    r = RocmRuntime(0)
+    r.use_torch_stream()
+    return r
