@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X operator backend (BASELINE.json metric).
+
+Workload (config.workload): BASELINE.json configs[1] — ONE bf16 MatMul 4096 x 4096 x 4096
+(A, B ~ N(0,1) rounded to bf16, fp32 accumulate, bf16 C, no bias, no transpose), resident in HBM.
+A "step" is one launch of that MatMul through the C ABI (infini_rocm_matmul) on the runtime's
+stream. value = whole-job TFLOP/s = n_gpus * steps * 2*M*N*K / time, weak scaling (each rank owns an
+independent 4096^3 problem: the op has no exchange step when sharded by columns — SURVEY 8e).
+
+The JSON line also carries
+  roofline      dominant kernel (the GEMM) vs the dense bf16 MFMA peak, timed with HIP events on
+                the launch stream inside the timed region;
+  cpu_baseline  the reference's own native-CPU MatMul (oracle/_ref, built from /root/reference)
+                timed on a bounded row-slice of the same problem on this box's host cores
+                (rank 0, N=1 only), plus a torch/MKL sgemm figure as the intelcpu-family stand-in;
+  extras        stand-alone Softmax / LayerNorm HBM-roofline figures (SURVEY 8d C4 shapes).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+M = N = K = 4096
+PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0      # HBM3E spec peak, same guide
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--variant", type=int, default=-1, help="GEMM kernel variant (-1 = heuristic)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline_reference(budget_s: float = 12.0) -> dict | None:
+    """Reference native-CPU MatMul (src/kernels/cpu/matmul.cc:6-25, naive ijk, one thread, fp32 — it has
+    no bf16 kernel) on the first `rows` rows of the 4096^3 problem, sized to ~budget_s seconds."""
+    import importlib.util
+    import sysconfig
+
+    import numpy as np
+
+    p = REPO / "oracle" / "_ref" / f"backend{sysconfig.get_config_var('EXT_SUFFIX')}"
+    if not p.exists():
+        return None
+    spec = importlib.util.spec_from_file_location("backend", p)
+    backend = importlib.util.module_from_spec(spec)
+    sys.modules["backend"] = backend
+    spec.loader.exec_module(backend)
+    rng = np.random.default_rng(0)
+    b = rng.standard_normal((K, N)).astype(np.float32)
+
+    def run(rows: int) -> float:
+        a = rng.standard_normal((rows, K)).astype(np.float32)
+        h = backend.GraphHandler(backend.cpu_runtime())
+        ta, tb = h.tensor([rows, K], 1), h.tensor([K, N], 1)
+        h.matmul(ta, tb, None, False, False, None, backend.ActType.Linear, "default")
+        h.data_malloc()
+        ta.copyin_numpy(a)
+        tb.copyin_numpy(b)
+        t0 = time.perf_counter()
+        h.run()
+        return time.perf_counter() - t0
+
+    t_probe = run(8)
+    rows = int(max(8, min(1024, 8 * budget_s / max(t_probe, 1e-6))))
+    rows -= rows % 8
+    t = run(rows)
+    flops = 2.0 * rows * N * K
+    return {
+        "value": flops / t / 1e12,
+        "unit": "TFLOP/s",
+        "cores": 1,
+        "kind": "reference",
+        "sample": f"reference native-CPU NaiveMatmul fp32 on rows 0..{rows} of the 4096x4096x4096 problem "
+                  f"({flops / 1e9:.1f} GFLOP in {t:.1f} s); host has {os.cpu_count()} cores",
+    }
+
+
+def cpu_standin_mkl() -> dict:
+    import torch
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    a = torch.randn(M, K)
+    b = torch.randn(K, N)
+    (a @ b)
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        (a @ b)
+    t = (time.perf_counter() - t0) / reps
+    return {"value": 2.0 * M * N * K / t / 1e12, "unit": "TFLOP/s", "cores": os.cpu_count(),
+            "kind": "torch-MKL sgemm fp32 (intelcpu-family stand-in; intelcpu itself is unbuildable here)"}
+
+
+def extras(rt, ops, Event) -> dict:
+    """Stand-alone HBM-bound rows at the SURVEY 8d C4 shapes; algorithmic bytes = 2*numel*sizeof."""
+    import torch
+
+    out = {}
+
+    def timeit(fn, iters=50, warm=5):
+        for _ in range(warm):
+            fn()
+        e0, e1 = Event(), Event()
+        rt.record(e0)
+        for _ in range(iters):
+            fn()
+        rt.record(e1)
+        return rt.elapsed_ms(e0, e1) / iters * 1e-3
+
+    for name, dt in (("f16", torch.float16), ("f32", torch.float32)):
+        x = torch.randn(196608, 512, device="cuda").to(dt)
+        y = torch.empty_like(x)
+        t = timeit(lambda: ops.softmax(rt, x, 1, out=y))
+        gbs = 2 * x.numel() * x.element_size() / t / 1e9
+        out[f"softmax_196608x512_{name}"] = {"GB/s": round(gbs, 1), "frac_hbm_peak": round(gbs / PEAK_HBM_GBS, 4), "us": round(t * 1e6, 2)}
+        del x, y
+        x = torch.randn(16384, 768, device="cuda").to(dt)
+        g = torch.randn(768, device="cuda").to(dt)
+        b = torch.randn(768, device="cuda").to(dt)
+        y = torch.empty_like(x)
+        t = timeit(lambda: ops.layer_norm(rt, x, g, b, 1e-5, -1, out=y))
+        gbs = 2 * x.numel() * x.element_size() / t / 1e9
+        out[f"layernorm_16384x768_{name}"] = {"GB/s": round(gbs, 1), "frac_hbm_peak": round(gbs / PEAK_HBM_GBS, 4), "us": round(t * 1e6, 2)}
+        # a larger LayerNorm (does not fit the 256 MiB Infinity Cache): 131072 x 768
+        x = torch.randn(131072 * 2, 768, device="cuda").to(dt)
+        y = torch.empty_like(x)
+        t = timeit(lambda: ops.layer_norm(rt, x, g, b, 1e-5, -1, out=y), iters=20)
+        gbs = 2 * x.numel() * x.element_size() / t / 1e9
+        out[f"layernorm_262144x768_{name}"] = {"GB/s": round(gbs, 1), "frac_hbm_peak": round(gbs / PEAK_HBM_GBS, 4), "us": round(t * 1e6, 2)}
+        del x, y
+    return out
+
+
+def main() -> int:
+    args = parse()
+    import torch
+
+    from infinitensor_amd import RocmRuntime, ops
+    from infinitensor_amd.runtime import Event
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = world > 1
+    if dist:
+        import torch.distributed as td
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+        local_rank = 0
+    assert torch.cuda.is_available(), "bench.py needs a GPU; the HIP path has no fallback"
+
+    rt = RocmRuntime(local_rank)  # own non-blocking stream; kernels are timed on THIS stream
+    info = rt.device_info()
+    gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    a = torch.randn(M, K, device="cuda", generator=gen).to(torch.bfloat16)
+    b = torch.randn(K, N, device="cuda", generator=gen).to(torch.bfloat16)
+    c = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    torch.cuda.synchronize()
+    if args.variant >= 0:
+        ops.set_matmul_variant(rt, args.variant)
+
+    def step():
+        ops.matmul(rt, a, b, out=c)
+
+    for _ in range(args.warmup):
+        step()
+    rt.sync()
+
+    def barrier():
+        if dist:
+            td.barrier()
+
+    e0, e1 = Event(), Event()
+    barrier()
+    torch.cuda.synchronize()
+    rt.sync()
+    t0 = time.perf_counter()
+    rt.record(e0)
+    for _ in range(args.steps):
+        step()
+    rt.record(e1)
+    rt.sync()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_s = rt.elapsed_ms(e0, e1) * 1e-3 / args.steps  # avg launch duration from HIP events
+
+    if dist:
+        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        td.all_reduce(tmax, op=td.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    flop_per_step = 2.0 * M * N * K
+    value = world * args.steps * flop_per_step / elapsed / 1e12
+    achieved = flop_per_step / kernel_s / 1e12
+
+    if rank == 0:
+        line = {
+            "metric": "bf16 MatMul 4096x4096x4096 throughput (GEMM TFLOP/s, % dense MFMA peak)",
+            "value": round(value, 2),
+            "unit": "TFLOP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic (N(0,1) rounded to bf16, seeded)",
+            "config": {
+                "workload": "BASELINE configs[1]: one bf16 MatMul M=N=K=4096 per GPU, NN layout, fp32 accumulate, via infini_rocm_matmul",
+                "kernel_variant": ops.matmul_variants()[args.variant] if args.variant >= 0 else "heuristic",
+                "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"],
+                "clock_mhz": info["clock_mhz"],
+                "parallelism": f"{world} independent replicas (column-sharded GEMM has no collective)",
+            },
+            "roofline": {
+                "bound": "mfma",
+                "achieved": round(achieved, 2),
+                "peak": PEAK_BF16_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                "traffic": None,
+                "kernel_us": round(kernel_s * 1e6, 3),
+                "peak_from_device": round(info["compute_units"] * 4096 * info["clock_mhz"] * 1e6 / 1e12, 1),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cb = cpu_baseline_reference()
+            except Exception as e:  # keep the bench line even if the oracle module is missing
+                cb = {"error": repr(e)}
+            if cb is not None:
+                line["cpu_baseline"] = cb
+            try:
+                line["cpu_standin_mkl"] = cpu_standin_mkl()
+            except Exception as e:
+                line["cpu_standin_mkl"] = {"error": repr(e)}
+        if world == 1 and not args.no_extras:
+            try:
+                line["extras"] = extras(rt, ops, Event)
+            except Exception as e:
+                line["extras"] = {"error": repr(e)}
+        print(json.dumps(line), flush=True)
+    if dist:
+        td.barrier()
+        td.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,142 @@
+"""Element-wise (binary broadcast, unary, cast) parity on a real MI355X."""
+import numpy as np
+import pytest
+import torch
+from conftest import kat
+
+from infinitensor_amd import ops
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+EW = "test/kernels/cuda/test_cuda_element_wise.cc"
+NC = "test/kernels/nativecpu/test_nativecpu_elementwise.cc"
+UN = "test/kernels/cuda/test_cuda_unary.cc"
+TD = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return (t.to(dtype) if dtype is not None else t).cuda()
+
+
+def host(t):
+    return t.float().cpu().numpy().astype(np.float64) if t.is_floating_point() else t.cpu().numpy()
+
+
+G = {"inc": R.incremental, "one": R.ones}
+
+
+@pytest.mark.parametrize("op,g,shape,line", [("add", "inc", (1, 2, 2, 3), 50), ("sub", "inc", (1, 2, 2, 3), 53),
+                                             ("mul", "inc", (1, 2, 2, 3), 56), ("div", "one", (1, 2, 2, 3), 60),
+                                             ("min", "inc", (1, 2, 2, 3), 63), ("max", "inc", (1, 2, 2, 3), 66),
+                                             ("pow", "inc", (1, 2, 2, 1), 68)])
+def test_binary_reference_kats(rt, op, g, shape, line):
+    a = dev(G[g](shape))
+    assert R.equal_data(host(ops.binary(rt, op, a, a)).ravel(), kat(EW, line, "float"), 1e-6)
+
+
+@pytest.mark.parametrize("op,gb,line", [("add", "inc", 32), ("mul", "inc", 35), ("sub", "inc", 38), ("div", "one", 41)])
+def test_binary_rank5_broadcast_kats(rt, op, gb, line):
+    a, b = dev(G["inc"]((1, 2, 2, 3, 1))), dev(G[gb]((2, 1, 1)))
+    assert R.equal_data(host(ops.binary(rt, op, a, b)).ravel(), kat(NC, line, "float"), 1e-6)
+
+
+BCAST = [
+    ((128, 64, 56, 56), (1, 64, 1, 1)),   # conv bias (config 3)
+    ((64, 768), (768,)),                  # linear bias (config 4)
+    ((4, 12, 64, 64), (4, 1, 1, 64)),     # attention mask add
+    ((33, 17), ()),                       # scalar b
+    ((), (5, 3)),                         # scalar a
+    ((7, 1, 5), (1, 6, 1)),               # both broadcast
+    ((2, 3, 4, 5, 6), (2, 3, 4, 5, 6)),   # same shape, rank 5
+    ((1023,), (1023,)),                   # odd length (vector tail)
+    ((2, 3, 1, 2, 1, 2, 1, 3), (3, 1, 3, 1, 2, 1, 4, 1)),  # rank 8
+]
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("op", ["add", "sub", "mul", "div", "min", "max", "less", "equal"])
+@pytest.mark.parametrize("sa,sb", BCAST)
+def test_binary_broadcast_vs_oracle(rt, sa, sb, op, dt):
+    if len(sa) and sa[0] == 128:
+        sa = (4,) + sa[1:]
+    rng = np.random.default_rng(13)
+    a = rng.uniform(0.5, 2, sa).astype(np.float32)
+    b = rng.uniform(0.5, 2, sb).astype(np.float32)
+    if op == "equal":
+        b = np.broadcast_to(a, np.broadcast_shapes(sa, sb)).copy() if False else b
+    ar, br = R.round_to(a, dt), R.round_to(b, dt)
+    y = ops.binary(rt, op, dev(a, TD[dt]), dev(b, TD[dt]))
+    want = R.binary(op, ar, br)
+    tol = {"f32": 1e-6, "f16": 1e-3, "bf16": 8e-3}[dt]
+    assert y.shape == want.shape
+    assert np.allclose(host(y), want, rtol=tol, atol=tol * 1e-2)
+
+
+@pytest.mark.parametrize("tdt,ndt", [(torch.int32, np.int32), (torch.int64, np.int64), (torch.int8, np.int8), (torch.uint8, np.uint8)])
+@pytest.mark.parametrize("op", ["add", "sub", "mul", "div", "min", "max", "less", "pow"])
+def test_binary_integer_bit_exact(rt, tdt, ndt, op):
+    rng = np.random.default_rng(17)
+    lo, hi = (0, 12) if ndt == np.uint8 else (-11, 12)
+    a = rng.integers(lo, hi, (5, 7, 3)).astype(ndt)
+    b = rng.integers(lo, hi, (7, 1)).astype(ndt)
+    if op == "pow":
+        a, b = (np.abs(a) % 4).astype(ndt), (np.abs(b) % 3).astype(ndt)
+    if op == "div":
+        b = np.where(b == 0, 1, b).astype(ndt)
+    y = ops.binary(rt, op, dev(a), dev(b))
+    want = R.binary(op, a, b)
+    assert np.array_equal(host(y).astype(np.int64), np.asarray(want).astype(np.int64))
+
+
+UNARY = ["relu", "sigmoid", "tanh", "abs", "sqrt", "gelu", "silu", "neg", "erf", "hard_sigmoid", "hard_swish",
+         "exp", "log", "reciprocal", "sin", "cos", "ceil", "floor", "round"]
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("op", UNARY)
+def test_unary_vs_oracle(rt, op, dt):
+    rng = np.random.default_rng(19)
+    x = rng.uniform(-4, 4, (3, 1000 + 7)).astype(np.float32)
+    if op in ("sqrt", "log", "reciprocal"):
+        x = np.abs(x) + 0.1
+    xr = R.round_to(x, dt)
+    y = ops.unary(rt, op, dev(x, TD[dt]))
+    want = R.unary(op, xr)
+    tol = {"f32": 1e-4, "f16": 2e-3, "bf16": 1.6e-2}[dt]
+    assert np.allclose(host(y), want, rtol=tol, atol=tol * 0.1 if dt == "f32" else tol)
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 2, 3), (13,), (4, 3), (2, 3, 4, 5, 6), (1,), (1, 2)])
+@pytest.mark.parametrize("op", ["relu", "silu", "abs", "sigmoid", "tanh", "hard_sigmoid", "hard_swish", "sqrt", "neg", "erf", "gelu"])
+def test_unary_reference_differential_cases(rt, op, shape):
+    """test_cuda_unary.cc:122-143: IncrementalGenerator inputs, the reference compares device vs its
+    native-CPU kernel at 1e-6; here vs the oracle that is pinned to that kernel (tests/test_oracle.py)."""
+    x = R.incremental(shape)
+    assert R.equal_data(host(ops.unary(rt, op, dev(x))).ravel(), R.unary(op, x).ravel(), 2e-6)
+
+
+def test_unary_parameterised_kats(rt):
+    x = kat(UN, 77, "float").astype(np.float32)
+    assert R.equal_data(host(ops.unary(rt, "leaky_relu", dev(x), 0.01)), kat(UN, 95, "float"), 1e-6)
+    assert R.equal_data(host(ops.unary(rt, "elu", dev(R.incremental((2, 2, 3, 1))), 1.0)).ravel(), kat(UN, 119, "float"), 1e-6)
+    c = host(ops.unary(rt, "clip", dev(np.array([-3, -1, 0.5, 2, 9], dtype=np.float32)), -1.0, 2.0))
+    assert np.array_equal(c, [-1, -1, 0.5, 2, 2])
+    c = host(ops.unary(rt, "clip", dev(np.array([-3, 9], dtype=np.float32)), float("nan"), 2.0))
+    assert np.array_equal(c, [-3, 2])
+
+
+def test_cast_reference_kat_and_pairs(rt):
+    # test_cuda_unary.cc:133-134: Float2Float16 of 0..7
+    y = ops.cast(rt, dev(R.incremental((8, 1))), torch.float16)
+    assert y.dtype == torch.float16 and R.equal_data(host(y).ravel(), kat(UN, 134, "float"), 1e-6)
+    x = np.array([-1.7, -0.2, 0.0, 0.9, 2.5, 300.0, 1e5], dtype=np.float32)
+    assert np.array_equal(host(ops.cast(rt, dev(x), torch.int32)), R.cast(x, np.int32))
+    assert np.array_equal(host(ops.cast(rt, dev(x[:6]), torch.int64)), R.cast(x[:6], np.int64))
+    i = np.arange(-5, 6, dtype=np.int64)
+    assert np.array_equal(host(ops.cast(rt, dev(i), torch.float32)), i.astype(np.float64))
+    assert np.array_equal(host(ops.cast(rt, dev(i), torch.int8)), i.astype(np.int8))
+    assert np.array_equal(host(ops.cast(rt, dev(i), torch.bool)), i != 0)
+    bf = ops.cast(rt, dev(np.random.default_rng(0).standard_normal(1000).astype(np.float32)), torch.bfloat16)
+    want = R.f32_to_bf16_bits(np.random.default_rng(0).standard_normal(1000).astype(np.float32))
+    assert np.array_equal(bf.view(torch.int16).cpu().numpy().view(np.uint16), want)  # bit-exact RNE

@@ -1,0 +1,150 @@
+"""MatMul parity on a real MI355X: HIP kernels (through the C ABI) vs the oracle and the
+reference's golden vectors. Tolerances: fp32 1e-4 relative (north_star); bf16/fp16 against the
+fp64 GEMM of the rounded inputs, |err| <= 2^-7 |c| + small absolute slack (one output rounding +
+fp32 accumulation)."""
+import numpy as np
+import pytest
+import torch
+from conftest import kat
+
+from infinitensor_amd import ops
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+CU = "test/kernels/cuda/test_cuda_matmul.cc"
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def host(t):
+    return t.float().cpu().numpy().astype(np.float64)
+
+
+KAT_CASES = [
+    ("inc", "one", False, False, (1, 3, 5), (1, 5, 2), 50),
+    ("inc", "inc", True, False, (2, 3, 4), (2, 3, 2), 53),
+    ("inc", "inc", False, False, (2, 3, 5), (5, 2), 58),
+    ("inc", "inc", True, False, (2, 5, 3), (5, 2), 61),
+    ("inc", "inc", False, False, (3, 5), (5, 2), 65),
+]
+
+
+@pytest.mark.parametrize("case", KAT_CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_matmul_reference_kats(rt, case, dtype):
+    """test_cuda_matmul.cc:47-66 — small integers, exact in every dtype (bf16: values <= 695 need
+    rounding, so only fp32/fp16 are compared bit-for-value; bf16 within its 2^-8)."""
+    ga, gb, ta, tb, sa, sb, line = case
+    g = {"inc": R.incremental, "one": R.ones}
+    a, b = g[ga](sa), g[gb](sb)
+    c = ops.matmul(rt, dev(a, dtype), dev(b, dtype), None, ta, tb)
+    want = kat(CU, line, "float")
+    got = host(c).ravel()
+    if dtype == torch.bfloat16:
+        ar, br = R.round_to(a, "bf16"), R.round_to(b, "bf16")
+        want = R.matmul(ar, br, None, ta, tb).ravel()
+        assert np.allclose(got, want, rtol=2 ** -7, atol=1e-6)
+    else:
+        assert R.equal_data(got, want, 1e-6)
+
+
+SHAPES = [
+    # b, m, n, k
+    (1, 128, 128, 64),
+    (1, 256, 384, 128),
+    (1, 200, 136, 192),   # ragged m / n
+    (3, 130, 72, 64),
+    (2, 64, 64, 256),
+    (1, 512, 512, 512),
+    (1, 77, 53, 41),      # nothing aligned -> generic kernel
+]
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_matmul_16bit_variants(rt, shape, ta, tb, dtype, variant):
+    b, m, n, k = shape
+    rng = np.random.default_rng(hash((shape, ta, tb)) % 2 ** 32)
+    a = rng.standard_normal((b, k, m) if ta else (b, m, k)).astype(np.float32)
+    bm = rng.standard_normal((n, k) if tb else (k, n)).astype(np.float32)  # rank-2 B: broadcast batch
+    bias = rng.standard_normal((n,)).astype(np.float32)
+    name = "bf16" if dtype == torch.bfloat16 else "f16"
+    ops.set_matmul_variant(rt, variant)
+    try:
+        c = ops.matmul(rt, dev(a, dtype), dev(bm, dtype), dev(bias, dtype), ta, tb)
+    finally:
+        ops.set_matmul_variant(rt, -1)
+    want = R.matmul(R.round_to(a, name), R.round_to(bm, name), R.round_to(bias, name), ta, tb)
+    got = host(c)
+    assert got.shape == want.shape
+    tol = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -10
+    err = np.abs(got - want)
+    bound = tol * np.abs(want) + tol * np.sqrt(k)
+    assert (err <= bound).all(), f"max err {err.max()} at {np.unravel_index(err.argmax(), err.shape)}"
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 64, 64), (2, 100, 36, 50), (1, 512, 512, 512), (1, 3, 7, 1000)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (True, True)])
+def test_matmul_fp32(rt, shape, ta, tb):
+    """fp32 gate: 1e-4 relative to the fp64 oracle (exact-f32 MFMA path)."""
+    b, m, n, k = shape
+    rng = np.random.default_rng(7)
+    a = rng.uniform(-1, 1, (b, k, m) if ta else (b, m, k)).astype(np.float32)
+    bm = rng.uniform(-1, 1, (b, n, k) if tb else (b, k, n)).astype(np.float32)
+    c = ops.matmul(rt, dev(a), dev(bm), None, ta, tb)
+    want = R.matmul(a, bm, None, ta, tb)
+    got = host(c)
+    assert np.allclose(got, want, rtol=1e-4, atol=1e-4 * np.sqrt(k) * 0.1)
+
+
+def test_matmul_bias_broadcast_forms(rt):
+    """bias broadcast into C like the reference (matmul.cc:86-118): [n], [m,n], [1], [b,m,n]."""
+    rng = np.random.default_rng(11)
+    b, m, n, k = 2, 33, 48, 64
+    a = rng.standard_normal((b, m, k)).astype(np.float32)
+    w = rng.standard_normal((b, k, n)).astype(np.float32)
+    for bshape in [(n,), (m, n), (1,), (b, m, n), (m, 1)]:
+        bias = rng.standard_normal(bshape).astype(np.float32)
+        c = ops.matmul(rt, dev(a), dev(w), dev(bias))
+        assert np.allclose(host(c), R.matmul(a, w, bias), rtol=1e-4, atol=1e-4), bshape
+
+
+def test_matmul_headline_shape_sampled_rows(rt):
+    """bf16 4096^3 (BASELINE config 2): check 48 sampled rows of C against the fp64 oracle, NN and NT."""
+    rng = np.random.default_rng(0)
+    M = N = K = 4096
+    a = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(torch.bfloat16).cuda()
+    b = torch.from_numpy(rng.standard_normal((K, N)).astype(np.float32)).to(torch.bfloat16).cuda()
+    rows = rng.choice(M, 48, replace=False)
+    a64 = a[rows].float().cpu().numpy().astype(np.float64)
+    b64 = b.float().cpu().numpy().astype(np.float64)
+    want = a64 @ b64
+    for v, name in enumerate(ops.matmul_variants()):
+        if v == 0:
+            continue
+        ops.set_matmul_variant(rt, v)
+        try:
+            c = ops.matmul(rt, a, b)
+            ct = ops.matmul(rt, a, b.t().contiguous(), None, False, True)
+        finally:
+            ops.set_matmul_variant(rt, -1)
+        for res in (c, ct):
+            got = res[rows].float().cpu().numpy().astype(np.float64)
+            err = np.abs(got - want)
+            assert (err <= 2 ** -7 * np.abs(want) + 0.5).all(), (name, err.max())
+
+
+def test_matmul_rejects_bad_arguments(rt):
+    a = torch.zeros(4, 5, device="cuda")
+    b = torch.zeros(6, 3, device="cuda")
+    with pytest.raises(ValueError):
+        ops.matmul(rt, a, b)  # K mismatch: reference IT_ASSERT(kA == kB)
+    with pytest.raises(TypeError):
+        ops.matmul(rt, a.to(torch.complex64), b.to(torch.complex64))

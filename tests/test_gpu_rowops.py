@@ -1,0 +1,125 @@
+"""Softmax / LayerNorm / RMSNorm parity on a real MI355X vs the oracle and the reference KATs."""
+import numpy as np
+import pytest
+import torch
+from conftest import kat
+
+from infinitensor_amd import ops
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+SM = "test/kernels/cuda/test_cuda_softmax.cc"
+LN = "test/kernels/cuda/test_cuda_layernorm.cc"
+TD = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+TOL = {"f32": (1e-4, 1e-6), "f16": (2e-3, 1e-3), "bf16": (1.6e-2, 8e-3)}  # (rtol, atol): fp32 gate / 1 ulp of storage
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return (t.to(dtype) if dtype is not None else t).cuda()
+
+
+def host(t):
+    return t.float().cpu().numpy().astype(np.float64)
+
+
+@pytest.mark.parametrize("axis,in_line,out_line", [(0, 70, 73), (1, 83, 86), (2, 96, 99), (3, 107, 110)])
+def test_softmax_reference_kats_fp32(rt, axis, in_line, out_line):
+    x = kat(SM, in_line, "float").astype(np.float32).reshape(2, 3, 2, 2)
+    y = ops.softmax(rt, dev(x), axis)
+    assert R.equal_data(host(y).ravel(), kat(SM, out_line, "float"), 1e-6)
+
+
+@pytest.mark.parametrize("axis,line", [(0, 119), (1, 126)])
+def test_softmax_reference_kats_fp16(rt, axis, line):
+    x = R.value((2, 3, 2, 2), 2.0, np.float16)
+    y = ops.softmax(rt, dev(x), axis)
+    assert R.equal_data(host(y).ravel(), kat(SM, line, "float"), 1e-3)
+
+
+SOFTMAX_SHAPES = [
+    ((4, 12, 64, 512), 3), ((7, 1000), 1), ((3, 5, 17), 2), ((6, 33, 40), 1), ((5, 64, 3), 0),
+    ((2, 2048), 1), ((3, 5000), 1), ((2, 20000), 1), ((16, 1), 1), ((1, 7), 0), ((4, 513), 1),
+]
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("shape,axis", SOFTMAX_SHAPES)
+def test_softmax_vs_oracle(rt, shape, axis, dt):
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal(shape) * 3).astype(np.float32)
+    xs = R.round_to(x, dt)
+    y = ops.softmax(rt, dev(x, TD[dt]), axis)
+    want = R.softmax(xs, axis)
+    rtol, atol = TOL[dt]
+    got = host(y)
+    assert np.allclose(got, want, rtol=rtol, atol=atol)
+    assert np.allclose(got.sum(axis=axis), 1.0, atol=5e-2 if dt != "f32" else 1e-5)  # rows sum to 1
+
+
+def test_softmax_extreme_values(rt):
+    x = np.array([[-1e4, 0, 1e4], [88.0, 88.5, 89.0], [-np.inf, 0.0, 1.0]], dtype=np.float32)
+    y = host(ops.softmax(rt, dev(x), 1))
+    assert np.allclose(y, R.softmax(x, 1), rtol=1e-4, atol=1e-7)
+    assert np.isfinite(y).all()
+
+
+@pytest.mark.parametrize("xi,si,yi,bi", [(153, 157, 158, 165), (168, 172, 173, 180), (183, 187, 188, 195), (198, 202, 203, None)])
+def test_layernorm_reference_kats_fp32(rt, xi, si, yi, bi):
+    x = kat(LN, xi, "float").astype(np.float32).reshape(2, 3, 2, 3)
+    scale = kat(LN, si, "float").astype(np.float32)
+    bias = kat(LN, bi, "float").astype(np.float32) if bi else None
+    y = ops.layer_norm(rt, dev(x), dev(scale), dev(bias) if bias is not None else None, 1e-5, 3)
+    assert R.equal_data(host(y).ravel(), kat(LN, yi, "float"), 2e-6)
+
+
+def test_layernorm_reference_kat_fp16(rt):
+    two = lambda s: dev(R.value(s, 2, np.float16))
+    y = ops.layer_norm(rt, two((2, 3, 2, 3)), two((3,)), two((3,)), 1e-5, 3)
+    assert R.equal_data(host(y).ravel(), kat(LN, 216, "float"), 1e-3)
+
+
+LN_SHAPES = [((32, 512, 768), -1), ((5, 7, 33), -1), ((4, 3, 8, 16), 2), ((9, 1024), 1), ((3, 4096), 1),
+             ((2, 10000), 1), ((6, 1), 1), ((4, 257), 1)]
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("shape,axis", LN_SHAPES)
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_layernorm_vs_oracle(rt, shape, axis, dt, with_bias):
+    if shape[0] == 32 and dt != "f16":
+        shape = (4,) + shape[1:]
+    rng = np.random.default_rng(9)
+    x = (rng.standard_normal(shape) * 2 + 0.5).astype(np.float32)
+    nshape = shape[axis:] if axis >= 0 else shape[axis:]
+    scale = rng.standard_normal(nshape).astype(np.float32)
+    bias = rng.standard_normal(nshape).astype(np.float32) if with_bias else None
+    y = ops.layer_norm(rt, dev(x, TD[dt]), dev(scale, TD[dt]), dev(bias, TD[dt]) if with_bias else None, 1e-5, axis)
+    want = R.layer_norm(R.round_to(x, dt), R.round_to(scale, dt), R.round_to(bias, dt) if with_bias else None, 1e-5, axis)
+    rtol, atol = TOL[dt]
+    assert np.allclose(host(y), want, rtol=rtol, atol=max(atol, rtol))
+
+
+def test_layernorm_scalar_scale_and_large_mean(rt):
+    rng = np.random.default_rng(2)
+    x = (rng.standard_normal((16, 768)) + 1000.0).astype(np.float32)  # cancellation-prone
+    s = np.array([0.3], dtype=np.float32)
+    b = rng.standard_normal((768,)).astype(np.float32)
+    y = ops.layer_norm(rt, dev(x), dev(s), dev(b), 1e-5, -1)
+    assert np.allclose(host(y), R.layer_norm(x, s, b, 1e-5, -1), rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+def test_rmsnorm_vs_oracle(rt, dt):
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 37, 4096)).astype(np.float32)
+    w = rng.standard_normal((4096,)).astype(np.float32)
+    y = ops.rms_norm(rt, dev(x, TD[dt]), dev(w, TD[dt]), 1e-5)
+    rtol, atol = TOL[dt]
+    assert np.allclose(host(y), R.rms_norm(R.round_to(x, dt), R.round_to(w, dt), 1e-5), rtol=rtol, atol=max(atol, rtol))
+
+
+def test_empty_inputs_are_noops(rt):
+    x = torch.empty((0, 16), device="cuda")
+    assert ops.softmax(rt, x, 1).shape == (0, 16)
+    assert ops.layer_norm(rt, x, torch.ones(16, device="cuda"), None, 1e-5, 1).shape == (0, 16)
