@@ -97,8 +97,10 @@ int infini_rocm_runtime_destroy(infiniRocmRuntime_t rt);
 int infini_rocm_runtime_device_info(infiniRocmRuntime_t rt, infiniRocmDeviceInfo *info);
 /* The native hipStream_t the runtime launches on. */
 int infini_rocm_runtime_get_stream(infiniRocmRuntime_t rt, void **stream);
-/* Adopt an externally owned stream (e.g. torch's current stream); NULL restores the own stream. */
+/* Adopt an externally owned stream (e.g. torch's current stream). NULL is the legacy default
+ * stream, adopted like any other; infini_rocm_runtime_use_own_stream goes back to the own one. */
 int infini_rocm_runtime_set_stream(infiniRocmRuntime_t rt, void *stream);
+int infini_rocm_runtime_use_own_stream(infiniRocmRuntime_t rt);
 int infini_rocm_runtime_sync(infiniRocmRuntime_t rt);
 int infini_rocm_alloc(infiniRocmRuntime_t rt, size_t bytes, void **ptr);
 int infini_rocm_dealloc(infiniRocmRuntime_t rt, void *ptr);
@@ -242,6 +244,102 @@ int infini_rocm_unary(infiniRocmRuntime_t rt, int op, int dtype, const void *x, 
  * truncates toward zero like a C cast (reference cast kernel: `(T)x`). */
 int infini_rocm_cast(infiniRocmRuntime_t rt, int src_dtype, int dst_dtype, const void *x, void *y,
                      int64_t n);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Conv2d (reference: convCudnn, src/kernels/cuda/conv.cc:57-168; op src/operators/conv.cc:47-114; */
+/*   index math src/kernels/cpu/conv.cc:25-50). x [n,c,h,w], w [f, c/groups, r, s] -> y [n,f,oh,ow] */
+/*   with oh = (h - (r - sh)*dh + 2*ph) / sh (conv.cc:98-101). Cross-correlation, symmetric zero     */
+/*   padding. F16/BF16: implicit-GEMM on MFMA (fp32 accumulate); F32: exact fp32 fma chain.          */
+/*   bias ([f], may be NULL) and act (0 none, 1 relu, 2 sigmoid, 3 tanh) allow fusing the            */
+/*   Conv -> Add(bias) -> Relu chain the front-end emits (onnx.py:159-190); the reference Conv op    */
+/*   itself has neither (conv.cc:68-69, conv.cc:143-168), and the plugin passes NULL / 0.            */
+/* ------------------------------------------------------------------------------------------ */
+int infini_rocm_conv2d(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w,
+                       const void *bias, void *y, int64_t n, int64_t c, int64_t h, int64_t wd,
+                       int64_t f, int64_t r, int64_t s, int ph, int pw, int sh, int sw, int dh, int dw,
+                       int64_t groups, int act);
+
+/* ------------------------------------------------------------------------------------------ */
+/* ReduceSum / ReduceMean over arbitrary axes (reference: ReduceCudnnBase::compute,             */
+/*   src/kernels/cuda/reduce.cc:10-108). kind: 0 sum, 1 mean. reduced[d] != 0 marks reduced dims; */
+/*   the output is dense over the kept dims (keepdims only changes the shape, not the data).     */
+/* ------------------------------------------------------------------------------------------ */
+int infini_rocm_reduce(infiniRocmRuntime_t rt, int kind, int dtype, const void *x, void *y, int ndim,
+                       const int64_t *shape, const int *reduced);
+
+/* BatchNormalization, inference (reference: BatchNormCudnn, src/kernels/cuda/batch_norm.cc:7-67;   */
+/*   operator input order x, mean, var, scale, bias — include/operators/batch_norm.h:10-50).         */
+/*   x [n, c, inner]; mean/var/scale/bias are F32 [c] whatever the dtype of x.                        */
+int infini_rocm_batch_norm(infiniRocmRuntime_t rt, int dtype, const void *x, const void *mean,
+                           const void *var, const void *scale, const void *bias, void *y, int64_t n,
+                           int64_t c, int64_t inner, float eps);
+
+/* MaxPool / AveragePool 2-D, NCHW (reference: poolingCudnn, src/kernels/cuda/pooling.cc:6-95;      */
+/*   output size src/operators/pooling.cc:17-35). kind: 0 max, 1 average. Average divides by kh*kw   */
+/*   (COUNT_INCLUDE_PADDING, pooling.cc:86-90); max ignores padding. Dilation is honoured (ONNX);     */
+/*   cuDNN ignores it.                                                                               */
+int infini_rocm_pool2d(infiniRocmRuntime_t rt, int kind, int dtype, const void *x, void *y, int64_t n,
+                       int64_t c, int64_t h, int64_t w, int kh, int kw, int dh, int dw, int ph, int pw,
+                       int sh, int sw, int ceil_mode);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Data movement / indexing: bit-exact for every dtype (raw 1/2/4/8-byte elements).            */
+/* ------------------------------------------------------------------------------------------ */
+/* Transpose: y = permute(x, perm), rank <= 8 (reference: TransposeCuda, src/kernels/cuda/transpose.cc:8-45,
+ * transpose.cu:10-24). in_shape is the INPUT shape; output dim d has extent in_shape[perm[d]]. */
+int infini_rocm_transpose(infiniRocmRuntime_t rt, int dtype, const void *x, void *y, int ndim,
+                          const int64_t *in_shape, const int *perm);
+/* Expand: broadcast copy (reference: ExpandCuda, src/kernels/cuda/expand.cu:10-49). x_strides are the
+ * element strides of x over the OUTPUT index space (0 where broadcast). */
+int infini_rocm_expand(infiniRocmRuntime_t rt, int dtype, const void *x, void *y, int ndim,
+                       const int64_t *out_shape, const int64_t *x_strides);
+/* Gather along one axis (reference: GatherCuda, src/kernels/cuda/gather.cu:4-39, include/cuda/gather.h:33-55).
+ * data viewed as [outer, axis_dim, inner]; indices (I32 or I64, n_indices of them, negative wraps) ->
+ * y [outer, n_indices, inner]. */
+int infini_rocm_gather(infiniRocmRuntime_t rt, int dtype, int index_dtype, const void *data,
+                       const void *indices, void *y, int64_t outer, int64_t axis_dim, int64_t n_indices,
+                       int64_t inner);
+/* Where: out = cond ? x : y with 3-way broadcast; cond is 1 byte per element (reference: WhereCuda,
+ * src/kernels/cuda/where.cu:4-63). Strides are element strides over the OUTPUT index space. */
+int infini_rocm_where(infiniRocmRuntime_t rt, int dtype, const void *x, const void *y, const void *cond,
+                      void *out, int ndim, const int64_t *shape, const int64_t *stride_x,
+                      const int64_t *stride_y, const int64_t *stride_c);
+/* Pad (constant 0) and Slice in one kernel, like the reference (PadSliceCudaCompute,
+ * src/kernels/cuda/pad_slice.cc:4-45): out[i] = in[starts + i*steps] when inside `in`, else 0.
+ * Slice: starts >= 0 (steps honoured — the reference CUDA kernel ignores them, pad_slice.cc:35-40);
+ * Pad: starts = -pads_begin, steps = 1 (NULL = all ones). */
+int infini_rocm_pad_slice(infiniRocmRuntime_t rt, int dtype, const void *x, void *y, int ndim,
+                          const int64_t *in_shape, const int64_t *out_shape, const int64_t *starts,
+                          const int64_t *steps, int reserved);
+/* 2-D strided byte copy: `rows` rows of `row_bytes`, pitches in bytes. Concat / Split are one call per
+ * input / output (reference: ConcatCuda / SplitCuda, src/kernels/cuda/split_concat.cu:29-82). */
+int infini_rocm_strided_copy(infiniRocmRuntime_t rt, const void *src, void *dst, int64_t rows,
+                             int64_t row_bytes, int64_t src_pitch, int64_t dst_pitch);
+
+/* ------------------------------------------------------------------------------------------ */
+/* RCCL communicator + collectives (reference: NcclCommunicatorObj, include/cuda/nccl_communicator.h:22-68; */
+/*   CudaRuntimeObj::initComm, src/cuda/cuda_runtime.cc:495-509; kernels all_reduce.cc:8-63,        */
+/*   all_gather.cc:8-40, broadcast.cc:8-26, send.cc:8-37, recv.cc:8-41). One communicator per runtime, */
+/*   one process per GPU; every collective is enqueued on the runtime stream.                        */
+/* ------------------------------------------------------------------------------------------ */
+/* File-based rendezvous exactly like the reference: rank 0 writes ./<name>_nccl_id.bin, others poll
+ * (100 ms, 10 s limit). */
+int infini_rocm_comm_init(infiniRocmRuntime_t rt, const char *name, int world_size, int rank);
+/* Rendezvous through a channel the launcher already has: rank 0 creates the id, every rank passes it. */
+int infini_rocm_comm_unique_id(void *buf, size_t *nbytes);
+int infini_rocm_comm_init_id(infiniRocmRuntime_t rt, const void *unique_id, size_t nbytes,
+                             int world_size, int rank);
+int infini_rocm_comm_destroy(infiniRocmRuntime_t rt);
+int infini_rocm_comm_info(infiniRocmRuntime_t rt, int *world_size, int *rank);
+/* op: 0 sum, 1 prod, 2 min, 3 max, 4 avg; count in elements; in-place allowed (x == y). */
+int infini_rocm_all_reduce(infiniRocmRuntime_t rt, int op, int dtype, const void *x, void *y,
+                           int64_t count);
+/* y receives world_size * count elements, rank r's block at offset r * count. */
+int infini_rocm_all_gather(infiniRocmRuntime_t rt, int dtype, const void *x, void *y, int64_t count);
+int infini_rocm_broadcast(infiniRocmRuntime_t rt, int dtype, const void *x, void *y, int64_t count,
+                          int root);
+int infini_rocm_send(infiniRocmRuntime_t rt, int dtype, const void *x, int64_t count, int peer);
+int infini_rocm_recv(infiniRocmRuntime_t rt, int dtype, void *y, int64_t count, int peer);
 
 #ifdef __cplusplus
 }

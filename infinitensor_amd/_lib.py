@@ -62,6 +62,7 @@ def lib() -> C.CDLL:
     sig("infini_rocm_runtime_device_info", [vp, vp])
     sig("infini_rocm_runtime_get_stream", [vp, pvp])
     sig("infini_rocm_runtime_set_stream", [vp, vp])
+    sig("infini_rocm_runtime_use_own_stream", [vp])
     sig("infini_rocm_runtime_sync", [vp])
     sig("infini_rocm_alloc", [vp, sz, pvp])
     sig("infini_rocm_dealloc", [vp, vp])
@@ -89,33 +90,26 @@ def lib() -> C.CDLL:
     sig("infini_rocm_binary", [vp, i32, i32, vp, vp, vp, i32, pi64, pi64, pi64])
     sig("infini_rocm_unary", [vp, i32, i32, vp, vp, i64, f32, f32])
     sig("infini_rocm_cast", [vp, i32, i32, vp, vp, i64])
-    _optional = {
-        "infini_rocm_conv2d": [vp, i32, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, i64, i32],
-        "infini_rocm_reduce": [vp, i32, i32, vp, vp, i32, pi64, C.POINTER(i32)],
-        "infini_rocm_batch_norm": [vp, i32, vp, vp, vp, vp, vp, vp, i64, i64, i64, f32],
-        "infini_rocm_pool2d": [vp, i32, i32, vp, vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32],
-        "infini_rocm_transpose": [vp, i32, vp, vp, i32, pi64, C.POINTER(i32)],
-        "infini_rocm_gather": [vp, i32, i32, vp, vp, vp, i64, i64, i64, i64],
-        "infini_rocm_where": [vp, i32, vp, vp, vp, vp, i32, pi64, pi64, pi64, pi64],
-        "infini_rocm_strided_copy": [vp, i32, vp, vp, i32, pi64, pi64, pi64, i64, i64],
-        "infini_rocm_pad_slice": [vp, i32, vp, vp, i32, pi64, pi64, pi64, pi64, i32],
-        "infini_rocm_expand": [vp, i32, vp, vp, i32, pi64, pi64],
-        "infini_rocm_rope": [vp, i32, vp, vp, vp, i64, i64, i64, f32],
-        "infini_rocm_attention": [vp, i32, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, f32, i32],
-        "infini_rocm_comm_unique_id": [vp, C.POINTER(sz)],
-        "infini_rocm_comm_init_id": [vp, vp, sz, i32, i32],
-        "infini_rocm_comm_init": [vp, C.c_char_p, i32, i32],
-        "infini_rocm_comm_destroy": [vp],
-        "infini_rocm_comm_info": [vp, C.POINTER(i32), C.POINTER(i32)],
-        "infini_rocm_all_reduce": [vp, i32, i32, vp, vp, i64],
-        "infini_rocm_all_gather": [vp, i32, vp, vp, i64],
-        "infini_rocm_broadcast": [vp, i32, vp, vp, i64, i32],
-        "infini_rocm_send": [vp, i32, vp, i64, i32],
-        "infini_rocm_recv": [vp, i32, vp, i64, i32],
-    }
-    for name, args in _optional.items():
-        if hasattr(L, name):
-            sig(name, args)
+    sig("infini_rocm_conv2d", [vp, i32, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, i64, i32])
+    sig("infini_rocm_reduce", [vp, i32, i32, vp, vp, i32, pi64, C.POINTER(i32)])
+    sig("infini_rocm_batch_norm", [vp, i32, vp, vp, vp, vp, vp, vp, i64, i64, i64, f32])
+    sig("infini_rocm_pool2d", [vp, i32, i32, vp, vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32])
+    sig("infini_rocm_transpose", [vp, i32, vp, vp, i32, pi64, C.POINTER(i32)])
+    sig("infini_rocm_expand", [vp, i32, vp, vp, i32, pi64, pi64])
+    sig("infini_rocm_gather", [vp, i32, i32, vp, vp, vp, i64, i64, i64, i64])
+    sig("infini_rocm_where", [vp, i32, vp, vp, vp, vp, i32, pi64, pi64, pi64, pi64])
+    sig("infini_rocm_pad_slice", [vp, i32, vp, vp, i32, pi64, pi64, pi64, pi64, i32])
+    sig("infini_rocm_strided_copy", [vp, vp, vp, i64, i64, i64, i64])
+    sig("infini_rocm_comm_init", [vp, C.c_char_p, i32, i32])
+    sig("infini_rocm_comm_unique_id", [vp, C.POINTER(sz)])
+    sig("infini_rocm_comm_init_id", [vp, vp, sz, i32, i32])
+    sig("infini_rocm_comm_destroy", [vp])
+    sig("infini_rocm_comm_info", [vp, C.POINTER(i32), C.POINTER(i32)])
+    sig("infini_rocm_all_reduce", [vp, i32, i32, vp, vp, i64])
+    sig("infini_rocm_all_gather", [vp, i32, vp, vp, i64])
+    sig("infini_rocm_broadcast", [vp, i32, vp, vp, i64, i32])
+    sig("infini_rocm_send", [vp, i32, vp, i64, i32])
+    sig("infini_rocm_recv", [vp, i32, vp, i64, i32])
     _lib = L
     return L
 

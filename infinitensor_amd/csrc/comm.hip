@@ -1,0 +1,213 @@
+// RCCL communicator and collective operators over xGMI.
+//
+// Replaces NcclCommunicatorObj (reference: include/cuda/nccl_communicator.h:22-68),
+// CudaRuntimeObj::initComm (src/cuda/cuda_runtime.cc:495-509) and the collective kernels
+// AllReduceNCCL src/kernels/cuda/all_reduce.cc:8-63, AllGatherNCCL all_gather.cc:8-40,
+// BroadcastNCCL broadcast.cc:8-26, SendNCCL send.cc:8-37, RecvNCCL recv.cc:8-41.
+//
+// One communicator per runtime, one process per GPU. Differences from the reference, on purpose:
+//  - every collective is enqueued on the runtime's stream (the reference puts AllGather / Broadcast /
+//    Send / Recv on stream 0: all_gather.cc:30, broadcast.cc:23) so it orders with the kernels around
+//    it and is capturable in a hipGraph;
+//  - RCCL errors are returned (INFINI_ROCM_RCCL_ERROR) instead of exit(EXIT_FAILURE);
+//  - besides the file-based id exchange of the reference (kept, same file name scheme, for drop-in
+//    `init_comm(name, world, rank)`), the unique id can be passed as bytes so a launcher that already
+//    has a control channel (torch.distributed / multiprocessing) skips the filesystem;
+//  - f16, bf16, f32, f64, i8, u8, i32, i64 payloads (reference: f32/f16/i8 for all-reduce, f32 only for
+//    the others).
+// Topology note (MI355X): 8 GPUs fully connected by xGMI, 7 links x ~153 GB/s per GPU. RCCL picks the
+// algorithm; a message is the whole activation tensor (two per transformer block under Megatron TP).
+#include "common.h"
+
+#include <chrono>
+#include <fstream>
+#include <rccl/rccl.h>
+#include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
+
+namespace irocm {
+
+#define IROCM_NCCL(expr)                                                                           \
+    do {                                                                                           \
+        ncclResult_t _r = (expr);                                                                  \
+        if (_r != ncclSuccess)                                                                     \
+            IROCM_FAIL(INFINI_ROCM_RCCL_ERROR, "%s failed: %s", #expr, ncclGetErrorString(_r));    \
+    } while (0)
+
+static bool nccl_type(int dtype, ncclDataType_t *t) {
+    switch (dtype) {
+    case INFINI_DT_F32: *t = ncclFloat32; return true;
+    case INFINI_DT_F16: *t = ncclFloat16; return true;
+    case INFINI_DT_BF16: *t = ncclBfloat16; return true;
+    case INFINI_DT_F64: *t = ncclFloat64; return true;
+    case INFINI_DT_I8: *t = ncclInt8; return true;
+    case INFINI_DT_U8: case INFINI_DT_BOOL: *t = ncclUint8; return true;
+    case INFINI_DT_I32: *t = ncclInt32; return true;
+    case INFINI_DT_U32: *t = ncclUint32; return true;
+    case INFINI_DT_I64: *t = ncclInt64; return true;
+    case INFINI_DT_U64: *t = ncclUint64; return true;
+    default: return false;
+    }
+}
+
+static int comm_init_with_id(infiniRocmRuntime_t rt, const ncclUniqueId &id, int world, int rank) {
+    IROCM_CHECK_ARG(rt->comm == nullptr, "communicator already initialised");
+    IROCM_HIP(hipSetDevice(rt->device));
+    ncclComm_t comm = nullptr;
+    IROCM_NCCL(ncclCommInitRank(&comm, world, id, rank));
+    rt->comm = (void *)comm;
+    rt->comm_world = world;
+    rt->comm_rank = rank;
+    return INFINI_ROCM_OK;
+}
+
+} // namespace irocm
+
+using namespace irocm;
+
+extern "C" {
+
+int infini_rocm_comm_unique_id(void *buf, size_t *nbytes) {
+    IROCM_CHECK_ARG(buf && nbytes && *nbytes >= sizeof(ncclUniqueId), "buffer too small (need %zu)",
+                    sizeof(ncclUniqueId));
+    ncclUniqueId id;
+    IROCM_NCCL(ncclGetUniqueId(&id));
+    memcpy(buf, &id, sizeof(id));
+    *nbytes = sizeof(id);
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_comm_init_id(infiniRocmRuntime_t rt, const void *unique_id, size_t nbytes, int world_size,
+                             int rank) {
+    IROCM_CHECK_ARG(rt && unique_id, "NULL argument");
+    IROCM_CHECK_ARG(nbytes == sizeof(ncclUniqueId), "unique id must be %zu bytes", sizeof(ncclUniqueId));
+    IROCM_CHECK_ARG(world_size >= 1 && rank >= 0 && rank < world_size, "bad world/rank %d/%d", world_size, rank);
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    return comm_init_with_id(rt, id, world_size, rank);
+}
+
+// File-based rendezvous, same protocol as the reference (nccl_communicator.h:27-51): rank 0 writes
+// ./<name>_nccl_id.bin, the others poll for it (100 ms, 10 s limit); rank 0 removes it afterwards.
+// The id is written to a temporary name and renamed so that a reader never sees a partial file.
+int infini_rocm_comm_init(infiniRocmRuntime_t rt, const char *name, int world_size, int rank) {
+    IROCM_CHECK_ARG(rt && name, "NULL argument");
+    IROCM_CHECK_ARG(world_size >= 1 && rank >= 0 && rank < world_size, "bad world/rank %d/%d", world_size, rank);
+    const std::string path = std::string("./") + name + "_nccl_id.bin";
+    ncclUniqueId id;
+    if (rank == 0) {
+        IROCM_NCCL(ncclGetUniqueId(&id));
+        const std::string tmp = path + ".tmp";
+        {
+            std::ofstream ofs(tmp, std::ios::binary | std::ios::trunc);
+            ofs.write((const char *)&id, sizeof(id));
+        }
+        if (rename(tmp.c_str(), path.c_str()) != 0)
+            IROCM_FAIL(INFINI_ROCM_RCCL_ERROR, "cannot publish %s", path.c_str());
+    } else {
+        const auto begin = std::chrono::steady_clock::now();
+        struct stat st;
+        while (stat(path.c_str(), &st) != 0 || (size_t)st.st_size < sizeof(id)) {
+            if (std::chrono::steady_clock::now() > begin + std::chrono::seconds(10))
+                IROCM_FAIL(INFINI_ROCM_RCCL_ERROR, "time limit (10s) exceeded waiting for %s", path.c_str());
+            std::this_thread::sleep_for(std::chrono::milliseconds(100));
+        }
+        std::ifstream ifs(path, std::ios::binary);
+        ifs.read((char *)&id, sizeof(id));
+    }
+    const int st = comm_init_with_id(rt, id, world_size, rank);
+    if (rank == 0)
+        (void)unlink(path.c_str());
+    return st;
+}
+
+int infini_rocm_comm_destroy(infiniRocmRuntime_t rt) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    if (rt->comm) {
+        ncclComm_t c = (ncclComm_t)rt->comm;
+        (void)hipStreamSynchronize(rt->stream);
+        (void)ncclCommDestroy(c);
+        rt->comm = nullptr;
+        rt->comm_world = 1;
+        rt->comm_rank = 0;
+    }
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_comm_info(infiniRocmRuntime_t rt, int *world_size, int *rank) {
+    IROCM_CHECK_ARG(rt && world_size && rank, "NULL argument");
+    IROCM_CHECK_ARG(rt->comm, "communicator not initialised");
+    *world_size = rt->comm_world;
+    *rank = rt->comm_rank;
+    return INFINI_ROCM_OK;
+}
+
+// op: 0 sum, 1 prod, 2 min, 3 max, 4 avg (reference: AllReduce{Sum,Prod,Min,Max,Avg})
+int infini_rocm_all_reduce(infiniRocmRuntime_t rt, int op, int dtype, const void *x, void *y, int64_t count) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(rt->comm, "all_reduce: communicator not initialised (call init_comm)");
+    static const ncclRedOp_t ops[] = {ncclSum, ncclProd, ncclMin, ncclMax, ncclAvg};
+    IROCM_CHECK_ARG(op >= 0 && op <= 4, "all_reduce: bad op %d", op);
+    ncclDataType_t t;
+    IROCM_CHECK_ARG(nccl_type(dtype, &t), "all_reduce: unsupported dtype %s", dtype_name(dtype));
+    if (count == 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(x && y && count > 0, "all_reduce: bad buffer");
+    IROCM_NCCL(ncclAllReduce(x, y, (size_t)count, t, ops[op], (ncclComm_t)rt->comm, rt->stream));
+    return INFINI_ROCM_OK;
+}
+
+// y holds world_size * count elements, rank r's contribution at y + r * count.
+int infini_rocm_all_gather(infiniRocmRuntime_t rt, int dtype, const void *x, void *y, int64_t count) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(rt->comm, "all_gather: communicator not initialised (call init_comm)");
+    ncclDataType_t t;
+    IROCM_CHECK_ARG(nccl_type(dtype, &t), "all_gather: unsupported dtype %s", dtype_name(dtype));
+    if (count == 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(x && y && count > 0, "all_gather: bad buffer");
+    IROCM_NCCL(ncclAllGather(x, y, (size_t)count, t, (ncclComm_t)rt->comm, rt->stream));
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_broadcast(infiniRocmRuntime_t rt, int dtype, const void *x, void *y, int64_t count, int root) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(rt->comm, "broadcast: communicator not initialised (call init_comm)");
+    ncclDataType_t t;
+    IROCM_CHECK_ARG(nccl_type(dtype, &t), "broadcast: unsupported dtype %s", dtype_name(dtype));
+    IROCM_CHECK_ARG(root >= 0 && root < rt->comm_world, "broadcast: bad root %d", root);
+    if (count == 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(x && y && count > 0, "broadcast: bad buffer");
+    IROCM_NCCL(ncclBroadcast(x, y, (size_t)count, t, root, (ncclComm_t)rt->comm, rt->stream));
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_send(infiniRocmRuntime_t rt, int dtype, const void *x, int64_t count, int peer) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(rt->comm, "send: communicator not initialised (call init_comm)");
+    ncclDataType_t t;
+    IROCM_CHECK_ARG(nccl_type(dtype, &t), "send: unsupported dtype %s", dtype_name(dtype));
+    IROCM_CHECK_ARG(peer >= 0 && peer < rt->comm_world && peer != rt->comm_rank, "send: bad peer %d", peer);
+    if (count == 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(x && count > 0, "send: bad buffer");
+    IROCM_NCCL(ncclSend(x, (size_t)count, t, peer, (ncclComm_t)rt->comm, rt->stream));
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_recv(infiniRocmRuntime_t rt, int dtype, void *y, int64_t count, int peer) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(rt->comm, "recv: communicator not initialised (call init_comm)");
+    ncclDataType_t t;
+    IROCM_CHECK_ARG(nccl_type(dtype, &t), "recv: unsupported dtype %s", dtype_name(dtype));
+    IROCM_CHECK_ARG(peer >= 0 && peer < rt->comm_world && peer != rt->comm_rank, "recv: bad peer %d", peer);
+    if (count == 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(y && count > 0, "recv: bad buffer");
+    IROCM_NCCL(ncclRecv(y, (size_t)count, t, peer, (ncclComm_t)rt->comm, rt->stream));
+    return INFINI_ROCM_OK;
+}
+
+} // extern "C"

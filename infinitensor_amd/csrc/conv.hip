@@ -1,0 +1,316 @@
+// Conv2d for gfx950: implicit-GEMM on MFMA, NCHW x FCRS -> NFHW, no layout transform in HBM.
+//
+// Replaces convCudnn (reference: src/kernels/cuda/conv.cc:57-168, cudnnConvolutionForward, default
+// algo IMPLICIT_GEMM); op definition src/operators/conv.cc:47-114; index math as the native CPU
+// kernel src/kernels/cpu/conv.cc:25-50 (cross-correlation, symmetric zero padding, stride, dilation,
+// groups = C / channel_per_group). The reference op has no bias and its CUDA kernel ignores `act`;
+// `bias` ([F], optional) and `act` are here so a runtime can fuse the Conv -> Add(bias) -> Relu chain
+// the ONNX front-end emits (pyinfinitensor onnx.py:159-190) without changing results.
+//
+// GEMM view, per image n and group g:   Y[n, g*Fg + m, p] = sum_k W[g*Fg + m, k] * B[k, p]
+//   m in [0, Fg), p = oh*OW + ow in [0, OH*OW), k = (c*R + r)*S + s in [0, Cg*R*S)
+//   B[k, p] = X[n, g*Cg + c, oh*sh - ph + r*dh, ow*sw - pw + s*dw]  (0 outside the image)
+// W rows are K-major and contiguous (FCRS), B is pixel-major: exactly the "A K-major, B N-major"
+// case of gemm.hip, with B gathered on the fly.
+//
+// conv_igemm16 (f16 / bf16): 128(filters) x 128(pixels) x 32(k) tile, 4 waves (2x2, 64x64 each),
+//   v_mfma_f32_16x16x32, fp32 accumulate. A tile -> LDS [128][40] (16-byte ds_read_b128 fragments,
+//   80-byte pitch = conflict-free); B tile -> LDS [32 k][128 p] written as 16-byte pixel runs and read
+//   with ds_read_b64_tr_b16 (transpose read), XOR-swizzled like gemm.hip. Global loads of tile t+1
+//   are issued before the MFMAs of tile t and written to LDS after them (register-staged pipeline).
+//   1x1 / stride 1 / pad 0 convolutions never come here: they are plain batched GEMMs and are routed to
+//   infini_rocm_matmul's LDS-DMA kernels by the dispatcher when the plane size allows 16-byte rows.
+// conv_direct32 (f32): one output per thread, serial fp32 fma over k in the oracle's order.
+#include "gemm_common.h"
+
+extern "C" int infini_rocm_matmul(infiniRocmRuntime_t rt, int dtype, const void *a, const void *b,
+                                  const void *bias, void *c, int64_t batch, int64_t m, int64_t n,
+                                  int64_t k, int trans_a, int trans_b, int64_t stride_a, int64_t stride_b,
+                                  int64_t bias_stride_b, int64_t bias_stride_m, int64_t bias_stride_n,
+                                  int act);
+
+namespace irocm {
+
+struct ConvArgs {
+    const void *x, *w, *bias;
+    void *y;
+    int n, c, h, wd, f, r, s;
+    int ph, pw, sh, sw, dh, dw;
+    int groups, cg, fg; // channels / filters per group
+    int oh, ow;
+    int kdim;           // cg * r * s
+    int npix;           // oh * ow
+    int tiles_m, tiles_p;
+    int act;
+    unsigned magic_s;   // (65536 + s - 1) / s : rs / s == (rs * magic_s) >> 16 for rs < 4096
+};
+
+template <typename Tr> __global__ __launch_bounds__(256) void conv_igemm16(ConvArgs p) {
+    constexpr int BM = 128, BP = 128, BK = 32, APITCH = BK + 8;
+    __shared__ __attribute__((aligned(16))) unsigned short As[BM][APITCH]; // 10 KiB
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[BK * BP];    // 8 KiB, [32][128] swizzled
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wm = w >> 1, wn = w & 1;
+
+    // block -> (image, group, filter tile, pixel tile); pixel tiles fastest so neighbours share weights
+    unsigned bid = blockIdx.x;
+    const int tp = bid % p.tiles_p; bid /= p.tiles_p;
+    const int tm = bid % p.tiles_m; bid /= p.tiles_m;
+    const int g = bid % p.groups;
+    const int img = bid / p.groups;
+    const int m0 = tm * BM, p0 = tp * BP;
+
+    const unsigned short *W = (const unsigned short *)p.w + (long)(g * p.fg) * p.kdim;
+    const unsigned short *X = (const unsigned short *)p.x + ((long)img * p.c + (long)g * p.cg) * p.h * p.wd;
+    const int RS = p.r * p.s;
+
+    // ---- per-thread staging assignment --------------------------------------------------------
+    // A: 128 rows x 32 k = 512 chunks of 8 k; thread t takes chunks t and t + 256: row = ch >> 2, kc = ch & 3
+    // B: 32 k x 128 p = 512 chunks of 8 pixels; thread t takes chunks t and t + 256: kk = ch >> 4, pc = ch & 15
+    const bool a_vec = (p.kdim % 8 == 0) && ((((uintptr_t)p.w) & 15) == 0);
+    int b_oh[2], b_ow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ch = t + i * 256;
+        const int pix = p0 + (ch & 15) * 8;
+        b_oh[i] = pix / p.ow;
+        b_ow[i] = pix - b_oh[i] * p.ow;
+    }
+    s16x8_t a_reg[2], b_reg[2];
+
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ch = t + i * 256;
+            const int row = ch >> 2, kc = (ch & 3) * 8;
+            const int gm = m0 + row, gk = k0 + kc;
+            s16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (gm < p.fg) {
+                const unsigned short *src = W + (long)gm * p.kdim + gk;
+                if (a_vec && gk + 8 <= p.kdim) {
+                    v = *(const s16x8_t *)src;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (gk + j < p.kdim)
+                            v[j] = (short)src[j];
+                }
+            }
+            a_reg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ch = t + i * 256;
+            const int k = k0 + (ch >> 4);
+            s16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (k < p.kdim) {
+                const int cc = k / RS;
+                const int rs = k - cc * RS;
+                const int rr = (int)(((unsigned)rs * p.magic_s) >> 16);
+                const int ss = rs - rr * p.s;
+                const unsigned short *plane = X + (long)cc * p.h * p.wd;
+                int oh = b_oh[i], ow = b_ow[i];
+                const int ih0 = oh * p.sh - p.ph + rr * p.dh;
+                const int iw0 = ow * p.sw - p.pw + ss * p.dw;
+                const int pix = p0 + (ch & 15) * 8;
+                // fast path: 8 pixels in one output row, unit stride, all inside the image, 16-B aligned
+                if (p.sw == 1 && ow + 8 <= p.ow && pix + 8 <= p.npix && ih0 >= 0 && ih0 < p.h && iw0 >= 0 &&
+                    iw0 + 8 <= p.wd) {
+                    const unsigned short *src = plane + (long)ih0 * p.wd + iw0;
+                    if ((((uintptr_t)src) & 15) == 0) {
+                        v = *(const s16x8_t *)src;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            v[j] = (short)src[j];
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (pix + j < p.npix) {
+                            const int ih = oh * p.sh - p.ph + rr * p.dh;
+                            const int iw = ow * p.sw - p.pw + ss * p.dw;
+                            if (ih >= 0 && ih < p.h && iw >= 0 && iw < p.wd)
+                                v[j] = (short)plane[(long)ih * p.wd + iw];
+                        }
+                        if (++ow == p.ow) {
+                            ow = 0;
+                            ++oh;
+                        }
+                    }
+                }
+            }
+            b_reg[i] = v;
+        }
+    };
+
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ch = t + i * 256;
+            *(s16x8_t *)&As[ch >> 2][(ch & 3) * 8] = a_reg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ch = t + i * 256;
+            const int kk = ch >> 4, pc = ch & 15;
+            const int c16 = pc ^ (f128::mn_f(kk) << 1);
+            *(s16x8_t *)((char *)Bs + kk * 256 + c16 * 16) = b_reg[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.kdim + BK - 1) / BK;
+    load_tile(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < nk)
+            load_tile((kt + 1) * BK); // in flight during the MFMAs below
+        s16x8_t af[4], bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            af[i] = *(const s16x8_t *)&As[wm * 64 + i * 16 + (lane & 15)][(lane >> 4) * 8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            bf[j] = f128::frag_mnmajor((const char *)Bs, wn * 64 + j * 16, 0, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = Tr::mfma(bf[j], af[i], acc[i][j]); // swapped: lane holds 4 consecutive pixels
+        __syncthreads();
+    }
+
+    unsigned short *Y = (unsigned short *)p.y + ((long)img * p.f + (long)g * p.fg) * p.npix;
+    const unsigned short *bias = (const unsigned short *)p.bias;
+    const bool vec_ok = (p.npix % 4 == 0) && ((((uintptr_t)p.y) & 7) == 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int fm = m0 + wm * 64 + i * 16 + (lane & 15);
+        if (fm >= p.fg)
+            continue;
+        const float bv = bias ? Tr::to_f32(bias[g * p.fg + fm]) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pix = p0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+            if (pix >= p.npix)
+                continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                v[r] = apply_act(acc[i][j][r] + bv, p.act);
+            unsigned short *dst = Y + (long)fm * p.npix + pix;
+            if (vec_ok && pix + 3 < p.npix) {
+                u32x2_t pk;
+                pk[0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
+                pk[1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
+                *(u32x2_t *)dst = pk;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (pix + r < p.npix)
+                        dst[r] = Tr::from_f32(v[r]);
+            }
+        }
+    }
+}
+
+// fp32: exact-order fma chain per output (c, then r, then s — the loop nest of src/kernels/cpu/conv.cc)
+__global__ __launch_bounds__(256) void conv_direct32(ConvArgs p) {
+    const long total = (long)p.n * p.f * p.npix;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int pix = (int)(i % p.npix);
+        const int f = (int)((i / p.npix) % p.f);
+        const int img = (int)(i / ((long)p.npix * p.f));
+        const int g = f / p.fg;
+        const int oh = pix / p.ow, ow = pix - oh * p.ow;
+        const float *X = (const float *)p.x + ((long)img * p.c + (long)g * p.cg) * p.h * p.wd;
+        const float *W = (const float *)p.w + (long)f * p.kdim;
+        float acc = 0.f;
+        for (int c = 0; c < p.cg; ++c)
+            for (int r = 0; r < p.r; ++r) {
+                const int ih = oh * p.sh - p.ph + r * p.dh;
+                if (ih < 0 || ih >= p.h)
+                    continue;
+                for (int s = 0; s < p.s; ++s) {
+                    const int iw = ow * p.sw - p.pw + s * p.dw;
+                    if (iw < 0 || iw >= p.wd)
+                        continue;
+                    acc = fmaf(X[((long)c * p.h + ih) * p.wd + iw], W[(c * p.r + r) * p.s + s], acc);
+                }
+            }
+        if (p.bias)
+            acc += ((const float *)p.bias)[f];
+        ((float *)p.y)[i] = apply_act(acc, p.act);
+    }
+}
+
+} // namespace irocm
+
+using namespace irocm;
+
+extern "C" {
+
+int infini_rocm_conv2d(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, const void *bias,
+                       void *y, int64_t n, int64_t c, int64_t h, int64_t wd, int64_t f, int64_t r, int64_t s,
+                       int ph, int pw, int sh, int sw, int dh, int dw, int64_t groups, int act) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(dtype == INFINI_DT_F32 || dtype == INFINI_DT_F16 || dtype == INFINI_DT_BF16,
+                    "conv2d: unsupported dtype %s", dtype_name(dtype));
+    IROCM_CHECK_ARG(n >= 0 && c > 0 && h > 0 && wd > 0 && f > 0 && r > 0 && s > 0, "conv2d: bad extent");
+    IROCM_CHECK_ARG(groups > 0 && c % groups == 0 && f % groups == 0, "conv2d: groups %lld do not divide C=%lld / F=%lld",
+                    (long long)groups, (long long)c, (long long)f);
+    IROCM_CHECK_ARG(sh > 0 && sw > 0 && dh > 0 && dw > 0 && ph >= 0 && pw >= 0, "conv2d: bad attributes");
+    IROCM_CHECK_ARG(act >= 0 && act <= 3, "conv2d: bad act %d", act);
+    ConvArgs p;
+    p.x = x; p.w = w; p.bias = bias; p.y = y;
+    p.n = (int)n; p.c = (int)c; p.h = (int)h; p.wd = (int)wd; p.f = (int)f; p.r = (int)r; p.s = (int)s;
+    p.ph = ph; p.pw = pw; p.sh = sh; p.sw = sw; p.dh = dh; p.dw = dw;
+    p.groups = (int)groups; p.cg = (int)(c / groups); p.fg = (int)(f / groups);
+    // reference output size: src/operators/conv.cc:98-101
+    p.oh = (int)((h - (r - sh) * dh + 2 * ph) / sh);
+    p.ow = (int)((wd - (s - sw) * dw + 2 * pw) / sw);
+    IROCM_CHECK_ARG(p.oh > 0 && p.ow > 0, "conv2d: empty output %dx%d", p.oh, p.ow);
+    p.kdim = p.cg * p.r * p.s;
+    p.npix = p.oh * p.ow;
+    p.act = act;
+    p.magic_s = (65536u + (unsigned)s - 1) / (unsigned)s;
+    IROCM_CHECK_ARG((long)p.r * p.s < 4096, "conv2d: kernel window too large");
+    if (n == 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(x && w && y, "conv2d: NULL tensor");
+
+    if (dtype == INFINI_DT_F32) {
+        const long total = (long)n * f * p.npix;
+        long g = ceil_div(total, 256);
+        if (g > (long)rt->num_cu * 32) g = (long)rt->num_cu * 32;
+        hipLaunchKernelGGL(conv_direct32, dim3((unsigned)g), dim3(256), 0, rt->stream, p);
+        IROCM_LAUNCH_CHECK("conv_direct32");
+        return INFINI_ROCM_OK;
+    }
+    // pointwise convolution == batched GEMM  Y[n] = W[F x C] . X[n][C x HW]  (A broadcast over batch)
+    if (r == 1 && s == 1 && ph == 0 && pw == 0 && sh == 1 && sw == 1 && groups == 1 && (p.npix % 8 == 0) &&
+        c % 64 == 0) {
+        return infini_rocm_matmul(rt, dtype, w, x, bias, y, n, f, p.npix, c, 0, 0, 0, (int64_t)c * p.npix,
+                                  0, bias ? 1 : 0, 0, act);
+    }
+    p.tiles_m = (int)ceil_div(p.fg, 128);
+    p.tiles_p = (int)ceil_div(p.npix, 128);
+    const long blocks = (long)n * groups * p.tiles_m * p.tiles_p;
+    IROCM_CHECK_ARG(blocks < (1l << 31), "conv2d: too many tiles");
+    if (dtype == INFINI_DT_BF16)
+        hipLaunchKernelGGL(conv_igemm16<Bf16Traits>, dim3((unsigned)blocks), dim3(256), 0, rt->stream, p);
+    else
+        hipLaunchKernelGGL(conv_igemm16<F16Traits>, dim3((unsigned)blocks), dim3(256), 0, rt->stream, p);
+    IROCM_LAUNCH_CHECK("conv_igemm16");
+    return INFINI_ROCM_OK;
+}
+
+} // extern "C"

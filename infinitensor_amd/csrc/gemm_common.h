@@ -82,4 +82,70 @@ __device__ static inline unsigned xcd_remap(unsigned bid, unsigned nwg) {
     return base + idx;
 }
 
+// ---- 128-row LDS-DMA operand tiles shared by gemm.hip and conv.hip -------------------------------
+namespace f128 {
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2; // 16 KiB per operand tile
+
+// K-major operand tile: image [128 rows][64 k] (128 B rows), physical 16-B chunk c' of row r holds
+// logical chunk c' ^ ((r >> 1) & 7): ds_read_b128 lane groups then hit 16 distinct 16-B slots.
+__device__ inline void stage_kmajor(const unsigned short *base, long ld, int row0, int rows, int k0,
+                                    char *lds_tile, int w, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = w * 4 + i;
+        const int r = piece * 8 + (lane >> 3);
+        const int c_log = (lane & 7) ^ ((r >> 1) & 7);
+        int gr = row0 + r;
+        gr = gr < rows ? gr : rows - 1;
+        const unsigned short *src = base + (long)gr * ld + k0 + c_log * 8;
+        __builtin_amdgcn_global_load_lds(IROCM_GLB_PTR(src), IROCM_LDS_PTR(lds_tile + piece * 1024), 16, 0, 0);
+    }
+}
+
+// M/N-major operand tile: image [64 k][128 cols] (256 B rows), 32-B chunk index XORed with
+// f(k) = (k & 3) | ((k >> 3) & 1) << 2 so the 8 k-rows one tr-read half-wave touches are spread
+// over the whole 256-B bank row.
+__device__ inline int mn_f(int kr) { return (kr & 3) | (((kr >> 3) & 1) << 2); }
+
+__device__ inline void stage_mnmajor(const unsigned short *base, long ld, int col0, int cols, int k0,
+                                     char *lds_tile, int w, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = w * 4 + i;
+        const int kr = piece * 4 + (lane >> 4);
+        const int c_log = (lane & 15) ^ (mn_f(kr) << 1);
+        int gc = col0 + c_log * 8;
+        gc = gc <= cols - 8 ? gc : cols - 8;
+        const unsigned short *src = base + (long)(k0 + kr) * ld + gc;
+        __builtin_amdgcn_global_load_lds(IROCM_GLB_PTR(src), IROCM_LDS_PTR(lds_tile + piece * 1024), 16, 0, 0);
+    }
+}
+
+// MFMA 16x16x32 operand fragment: lane l holds 8 consecutive k (ks*32 + (l>>4)*8 ..) of row/col
+// R0 + (l & 15).
+__device__ inline s16x8_t frag_kmajor(const char *lds_tile, int R0, int ks, int lane) {
+    const int r = R0 + (lane & 15);
+    const int c = (ks * 4 + (lane >> 4)) ^ ((r >> 1) & 7);
+    return *(const s16x8_t *)(lds_tile + r * 128 + c * 16);
+}
+
+__device__ inline s16x8_t frag_mnmajor(const char *lds_tile, int C0, int ks, int lane) {
+    // Two ds_read_b64_tr_b16: in each 16-lane group, lane p supplies the address of 4 consecutive
+    // columns (p & 3) * 4 of k-row (p >> 2) and receives column p of that 4x16 block.
+    const int p = lane & 15;
+    s16x4_t h[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int kr = ks * 32 + (lane >> 4) * 8 + hh * 4 + (p >> 2);
+        const int col = C0 + (p & 3) * 4;
+        const int c16 = (col >> 3) ^ (mn_f(kr) << 1);
+        const char *addr = lds_tile + kr * 256 + c16 * 16 + (col & 4) * 2;
+        h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t *)(addr));
+    }
+    return s16x8_t{h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
+}
+} // namespace f128
+
 } // namespace irocm

@@ -1,0 +1,483 @@
+// Data-movement / indexing operators for gfx950 (bit-exact, any dtype: they move raw elements of
+// 1/2/4/8 bytes): Transpose, Gather, Where, Concat/Split (strided 2-D copy), Pad/Slice, Expand.
+//
+// Replaces (reference): TransposeCuda src/kernels/cuda/transpose.cc:8-90 + transpose.cu:10-24 (one
+// thread per element, uncoalesced gather); GatherCuda gather.cc + gather.cu:4-39, include/cuda/gather.h:33-55;
+// WhereCuda where.cc + where.cu:4-63; ConcatCuda/SplitCuda split_concat.cc + .cu:29-82;
+// SliceCuda/PadCuda pad_slice.cc:4-45 + .cu:25-101; ExpandCuda expand.cc + expand.cu:10-49.
+//
+// Design: all of these are HBM-bound (bytes in + bytes out). Dimensions are collapsed on the host;
+// whenever the innermost output dimension is contiguous in the input too, threads move 16-byte
+// vectors; a true 2-D transpose goes through a padded 64x64 LDS tile so that both the global read
+// and the global write are coalesced (the reference's transpose reads with stride).
+#include "common.h"
+
+namespace irocm {
+
+constexpr int MD = INFINI_ROCM_MAX_DIMS;
+
+struct IdxArgs {
+    int ndim;
+    long shape[MD];   // output (iteration) shape, collapsed
+    long sin[MD];     // input element stride per output dim
+    long total;       // number of iteration items
+};
+
+template <int BYTES> struct Raw;
+template <> struct Raw<1> { using t = uint8_t; };
+template <> struct Raw<2> { using t = uint16_t; };
+template <> struct Raw<4> { using t = uint32_t; };
+template <> struct Raw<8> { using t = uint64_t; };
+template <> struct Raw<16> { using t = uint4; };
+
+static inline unsigned grid_for(long items, int num_cu) {
+    long g = ceil_div(items, 256);
+    const long cap = (long)num_cu * 16;
+    return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// out[i] = in[sum_d idx_d * sin_d]; one item = one element of BYTES bytes (a whole 16-byte vector
+// when the host found the inner dimension contiguous on both sides).
+template <int BYTES>
+__global__ __launch_bounds__(256) void strided_gather_kernel(const void *__restrict__ in, void *__restrict__ out,
+                                                             IdxArgs p) {
+    using R = typename Raw<BYTES>::t;
+    const R *src = (const R *)in;
+    R *dst = (R *)out;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long)gridDim.x * 256) {
+        long rem = i, off = 0;
+        for (int d = p.ndim - 1; d >= 0; --d) {
+            const long q = rem / p.shape[d];
+            off += (rem - q * p.shape[d]) * p.sin[d];
+            rem = q;
+        }
+        dst[i] = src[off];
+    }
+}
+
+// Batched 2-D transpose [B, R, C] -> [B, C, R] through LDS (64x64 tile, +1 padding).
+template <int BYTES>
+__global__ __launch_bounds__(256) void transpose2d_kernel(const void *__restrict__ in, void *__restrict__ out,
+                                                          long rows, long cols, long tiles_r, long tiles_c) {
+    using R = typename Raw<BYTES>::t;
+    __shared__ R tile[64][65];
+    const long b = blockIdx.x / (tiles_r * tiles_c);
+    const long t = blockIdx.x % (tiles_r * tiles_c);
+    const long r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+    const R *src = (const R *)in + b * rows * cols;
+    R *dst = (R *)out + b * rows * cols;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const long r = r0 + ty * 16 + j, c = c0 + tx;
+        if (r < rows && c < cols)
+            tile[ty * 16 + j][tx] = src[r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const long c = c0 + ty * 16 + j, r = r0 + tx;
+        if (r < rows && c < cols)
+            dst[c * rows + r] = tile[tx][ty * 16 + j];
+    }
+}
+
+static int launch_strided(infiniRocmRuntime_t rt, int elem, const void *in, void *out, IdxArgs p) {
+    // widen the element when the innermost dim is contiguous (stride 1) and everything is aligned
+    int bytes = elem;
+    const int last = p.ndim - 1;
+    if (p.sin[last] == 1) {
+        int w = 16;
+        while (w > elem) {
+            const int f = w / elem;
+            bool ok = (p.shape[last] % f == 0) && ((uintptr_t)in % w == 0) && ((uintptr_t)out % w == 0);
+            for (int d = 0; d < last && ok; ++d)
+                ok = (p.sin[d] % f == 0);
+            if (ok)
+                break;
+            w >>= 1;
+        }
+        if (w > elem) {
+            const int f = w / elem;
+            p.shape[last] /= f;
+            for (int d = 0; d < last; ++d)
+                p.sin[d] /= f;
+            p.total /= f;
+            bytes = w;
+        }
+    }
+    const unsigned g = grid_for(p.total, rt->num_cu);
+    switch (bytes) {
+    case 1: hipLaunchKernelGGL(strided_gather_kernel<1>, dim3(g), dim3(256), 0, rt->stream, in, out, p); break;
+    case 2: hipLaunchKernelGGL(strided_gather_kernel<2>, dim3(g), dim3(256), 0, rt->stream, in, out, p); break;
+    case 4: hipLaunchKernelGGL(strided_gather_kernel<4>, dim3(g), dim3(256), 0, rt->stream, in, out, p); break;
+    case 8: hipLaunchKernelGGL(strided_gather_kernel<8>, dim3(g), dim3(256), 0, rt->stream, in, out, p); break;
+    case 16: hipLaunchKernelGGL(strided_gather_kernel<16>, dim3(g), dim3(256), 0, rt->stream, in, out, p); break;
+    default: IROCM_FAIL(INFINI_ROCM_UNSUPPORTED, "element size %d", elem);
+    }
+    IROCM_LAUNCH_CHECK("strided_gather");
+    return INFINI_ROCM_OK;
+}
+
+// ---- gather ------------------------------------------------------------------------------------
+template <int BYTES, typename I>
+__global__ __launch_bounds__(256) void gather_kernel(const void *__restrict__ data, const I *__restrict__ idx,
+                                                     void *__restrict__ out, long outer, long axis_dim,
+                                                     long n_idx, long inner) {
+    using R = typename Raw<BYTES>::t;
+    const R *src = (const R *)data;
+    R *dst = (R *)out;
+    const long total = outer * n_idx * inner;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long in_i = i % inner;
+        const long j = (i / inner) % n_idx;
+        const long o = i / (inner * n_idx);
+        long k = (long)idx[j];
+        if (k < 0)
+            k += axis_dim; // ONNX negative index
+        dst[i] = src[(o * axis_dim + k) * inner + in_i];
+    }
+}
+
+// ---- where -------------------------------------------------------------------------------------
+struct WhereArgs {
+    int ndim;
+    long shape[MD], sx[MD], sy[MD], sc[MD];
+    long total;
+};
+
+template <int BYTES>
+__global__ __launch_bounds__(256) void where_kernel(const void *__restrict__ x, const void *__restrict__ y,
+                                                    const uint8_t *__restrict__ c, void *__restrict__ out,
+                                                    WhereArgs p) {
+    using R = typename Raw<BYTES>::t;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long)gridDim.x * 256) {
+        long rem = i, ox = 0, oy = 0, oc = 0;
+        for (int d = p.ndim - 1; d >= 0; --d) {
+            const long q = rem / p.shape[d];
+            const long id = rem - q * p.shape[d];
+            ox += id * p.sx[d];
+            oy += id * p.sy[d];
+            oc += id * p.sc[d];
+            rem = q;
+        }
+        ((R *)out)[i] = c[oc] ? ((const R *)x)[ox] : ((const R *)y)[oy];
+    }
+}
+
+// ---- pad / slice -------------------------------------------------------------------------------
+struct PadSliceArgs {
+    int ndim;
+    long oshape[MD];  // output shape
+    long ishape[MD];  // input shape
+    long istride[MD]; // input element strides
+    long start[MD];   // input index of output index 0 (negative = padding before)
+    long step[MD];
+    long total;
+};
+
+template <int BYTES>
+__global__ __launch_bounds__(256) void pad_slice_kernel(const void *__restrict__ in, void *__restrict__ out,
+                                                        PadSliceArgs p) {
+    using R = typename Raw<BYTES>::t;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long)gridDim.x * 256) {
+        long rem = i, off = 0;
+        bool inb = true;
+        for (int d = p.ndim - 1; d >= 0; --d) {
+            const long q = rem / p.oshape[d];
+            const long id = p.start[d] + (rem - q * p.oshape[d]) * p.step[d];
+            inb = inb && id >= 0 && id < p.ishape[d];
+            off += id * p.istride[d];
+            rem = q;
+        }
+        R v{};
+        if (inb)
+            v = ((const R *)in)[off];
+        ((R *)out)[i] = v;
+    }
+}
+
+// ---- 2-D strided copy (Concat / Split) ---------------------------------------------------------
+template <int BYTES>
+__global__ __launch_bounds__(256) void copy2d_kernel(const char *__restrict__ src, char *__restrict__ dst,
+                                                     long rows, long row_items, long src_pitch, long dst_pitch) {
+    using R = typename Raw<BYTES>::t;
+    const long total = rows * row_items;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / row_items, c = i - r * row_items;
+        *(R *)(dst + r * dst_pitch + c * BYTES) = *(const R *)(src + r * src_pitch + c * BYTES);
+    }
+}
+
+static bool elem_ok(int e) { return e == 1 || e == 2 || e == 4 || e == 8; }
+
+} // namespace irocm
+
+using namespace irocm;
+
+extern "C" {
+
+int infini_rocm_transpose(infiniRocmRuntime_t rt, int dtype, const void *x, void *y, int ndim,
+                          const int64_t *in_shape, const int *perm) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(ndim >= 0 && ndim <= MD, "transpose: rank %d out of range", ndim);
+    const int elem = (int)dtype_size(dtype);
+    IROCM_CHECK_ARG(elem_ok(elem), "transpose: unsupported dtype %s", dtype_name(dtype));
+    long istr[MD];
+    long total = 1;
+    bool seen[MD] = {false};
+    for (int d = ndim - 1; d >= 0; --d) {
+        IROCM_CHECK_ARG(in_shape[d] >= 0, "transpose: negative extent");
+        istr[d] = total;
+        total *= in_shape[d];
+    }
+    for (int d = 0; d < ndim; ++d) {
+        IROCM_CHECK_ARG(perm[d] >= 0 && perm[d] < ndim && !seen[perm[d]], "transpose: bad permutation");
+        seen[perm[d]] = true;
+    }
+    if (total == 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(x && y, "transpose: NULL tensor");
+    // output dim d has extent in_shape[perm[d]] and input stride istr[perm[d]]; drop 1s, merge runs.
+    IdxArgs p;
+    p.ndim = 0;
+    for (int d = 0; d < ndim; ++d) {
+        const long e = in_shape[perm[d]], s = istr[perm[d]];
+        if (e == 1)
+            continue;
+        if (p.ndim > 0 && p.sin[p.ndim - 1] == s * e) {
+            p.shape[p.ndim - 1] *= e;
+            p.sin[p.ndim - 1] = s;
+        } else {
+            p.shape[p.ndim] = e;
+            p.sin[p.ndim] = s;
+            ++p.ndim;
+        }
+    }
+    if (p.ndim == 0) {
+        p.ndim = 1; p.shape[0] = 1; p.sin[0] = 1;
+    }
+    p.total = total;
+    if (p.ndim == 1 && p.sin[0] == 1)
+        return infini_rocm_copy_inside(rt, y, x, (size_t)total * elem);
+    // batched 2-D transpose: [B?, R, C] -> [B?, C, R]
+    const int nd = p.ndim;
+    if ((nd == 2 || nd == 3) && p.sin[nd - 1] == p.shape[nd - 2] && p.sin[nd - 2] == 1 &&
+        (nd == 2 || p.sin[0] == p.shape[1] * p.shape[2])) {
+        const long cols = p.shape[nd - 1], rows = p.shape[nd - 2]; // output is [.., rows_out = p.shape[nd-2], cols_out]
+        // input matrix: [in_rows = cols_out][in_cols = rows_out]
+        const long in_rows = cols, in_cols = rows, batch = nd == 3 ? p.shape[0] : 1;
+        const long tr = ceil_div(in_rows, 64), tc = ceil_div(in_cols, 64);
+        const long blocks = batch * tr * tc;
+        if (blocks < (1l << 31)) {
+            switch (elem) {
+            case 1: hipLaunchKernelGGL(transpose2d_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, rt->stream, x, y, in_rows, in_cols, tr, tc); break;
+            case 2: hipLaunchKernelGGL(transpose2d_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, rt->stream, x, y, in_rows, in_cols, tr, tc); break;
+            case 4: hipLaunchKernelGGL(transpose2d_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, rt->stream, x, y, in_rows, in_cols, tr, tc); break;
+            default: hipLaunchKernelGGL(transpose2d_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, rt->stream, x, y, in_rows, in_cols, tr, tc); break;
+            }
+            IROCM_LAUNCH_CHECK("transpose2d");
+            return INFINI_ROCM_OK;
+        }
+    }
+    return launch_strided(rt, elem, x, y, p);
+}
+
+int infini_rocm_expand(infiniRocmRuntime_t rt, int dtype, const void *x, void *y, int ndim,
+                       const int64_t *out_shape, const int64_t *x_strides) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(ndim >= 0 && ndim <= MD, "expand: rank %d out of range", ndim);
+    const int elem = (int)dtype_size(dtype);
+    IROCM_CHECK_ARG(elem_ok(elem), "expand: unsupported dtype %s", dtype_name(dtype));
+    IdxArgs p;
+    p.ndim = 0;
+    long total = 1;
+    for (int d = 0; d < ndim; ++d) {
+        IROCM_CHECK_ARG(out_shape[d] >= 0, "expand: negative extent");
+        total *= out_shape[d];
+        const long e = out_shape[d], s = x_strides[d];
+        if (e == 1)
+            continue;
+        if (p.ndim > 0 && p.sin[p.ndim - 1] == s * e) {
+            p.shape[p.ndim - 1] *= e;
+            p.sin[p.ndim - 1] = s;
+        } else {
+            p.shape[p.ndim] = e;
+            p.sin[p.ndim] = s;
+            ++p.ndim;
+        }
+    }
+    if (total == 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(x && y, "expand: NULL tensor");
+    if (p.ndim == 0) {
+        p.ndim = 1; p.shape[0] = 1; p.sin[0] = 1;
+    }
+    p.total = total;
+    return launch_strided(rt, elem, x, y, p);
+}
+
+int infini_rocm_gather(infiniRocmRuntime_t rt, int dtype, int index_dtype, const void *data,
+                       const void *indices, void *y, int64_t outer, int64_t axis_dim, int64_t n_indices,
+                       int64_t inner) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    const int elem = (int)dtype_size(dtype);
+    IROCM_CHECK_ARG(elem_ok(elem), "gather: unsupported dtype %s", dtype_name(dtype));
+    IROCM_CHECK_ARG(index_dtype == INFINI_DT_I32 || index_dtype == INFINI_DT_I64,
+                    "gather: indices must be int32 or int64 (reference gather.h:33-55)");
+    IROCM_CHECK_ARG(outer >= 0 && axis_dim >= 0 && n_indices >= 0 && inner >= 0, "gather: negative extent");
+    const long total = outer * n_indices * inner;
+    if (total == 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(data && indices && y, "gather: NULL tensor");
+    // widen along inner
+    int bytes = elem;
+    long inner_w = inner;
+    for (int w = 16; w > elem; w >>= 1) {
+        const int f = w / elem;
+        if (inner % f == 0 && (uintptr_t)data % w == 0 && (uintptr_t)y % w == 0) {
+            bytes = w;
+            inner_w = inner / f;
+            break;
+        }
+    }
+    const unsigned g = grid_for(outer * n_indices * inner_w, rt->num_cu);
+#define GO(B)                                                                                      \
+    if (index_dtype == INFINI_DT_I64)                                                              \
+        hipLaunchKernelGGL((gather_kernel<B, int64_t>), dim3(g), dim3(256), 0, rt->stream, data,   \
+                           (const int64_t *)indices, y, (long)outer, (long)axis_dim,               \
+                           (long)n_indices, inner_w);                                              \
+    else                                                                                           \
+        hipLaunchKernelGGL((gather_kernel<B, int32_t>), dim3(g), dim3(256), 0, rt->stream, data,   \
+                           (const int32_t *)indices, y, (long)outer, (long)axis_dim,               \
+                           (long)n_indices, inner_w);                                              \
+    break
+    switch (bytes) {
+    case 1: GO(1);
+    case 2: GO(2);
+    case 4: GO(4);
+    case 8: GO(8);
+    default: GO(16);
+    }
+#undef GO
+    IROCM_LAUNCH_CHECK("gather");
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_where(infiniRocmRuntime_t rt, int dtype, const void *x, const void *y, const void *cond,
+                      void *out, int ndim, const int64_t *shape, const int64_t *stride_x,
+                      const int64_t *stride_y, const int64_t *stride_c) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(ndim >= 0 && ndim <= MD, "where: rank %d out of range", ndim);
+    const int elem = (int)dtype_size(dtype);
+    IROCM_CHECK_ARG(elem_ok(elem), "where: unsupported dtype %s", dtype_name(dtype));
+    WhereArgs p;
+    p.ndim = 0;
+    long total = 1;
+    for (int d = 0; d < ndim; ++d) {
+        IROCM_CHECK_ARG(shape[d] >= 0, "where: negative extent");
+        total *= shape[d];
+        if (shape[d] == 1)
+            continue;
+        const long e = shape[d];
+        if (p.ndim > 0 && p.sx[p.ndim - 1] == stride_x[d] * e && p.sy[p.ndim - 1] == stride_y[d] * e &&
+            p.sc[p.ndim - 1] == stride_c[d] * e) {
+            p.shape[p.ndim - 1] *= e;
+            p.sx[p.ndim - 1] = stride_x[d];
+            p.sy[p.ndim - 1] = stride_y[d];
+            p.sc[p.ndim - 1] = stride_c[d];
+        } else {
+            p.shape[p.ndim] = e;
+            p.sx[p.ndim] = stride_x[d];
+            p.sy[p.ndim] = stride_y[d];
+            p.sc[p.ndim] = stride_c[d];
+            ++p.ndim;
+        }
+    }
+    if (total == 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(x && y && cond && out, "where: NULL tensor");
+    if (p.ndim == 0) {
+        p.ndim = 1; p.shape[0] = 1; p.sx[0] = p.sy[0] = p.sc[0] = 0;
+    }
+    p.total = total;
+    const unsigned g = grid_for(total, rt->num_cu);
+    switch (elem) {
+    case 1: hipLaunchKernelGGL(where_kernel<1>, dim3(g), dim3(256), 0, rt->stream, x, y, (const uint8_t *)cond, out, p); break;
+    case 2: hipLaunchKernelGGL(where_kernel<2>, dim3(g), dim3(256), 0, rt->stream, x, y, (const uint8_t *)cond, out, p); break;
+    case 4: hipLaunchKernelGGL(where_kernel<4>, dim3(g), dim3(256), 0, rt->stream, x, y, (const uint8_t *)cond, out, p); break;
+    default: hipLaunchKernelGGL(where_kernel<8>, dim3(g), dim3(256), 0, rt->stream, x, y, (const uint8_t *)cond, out, p); break;
+    }
+    IROCM_LAUNCH_CHECK("where");
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_pad_slice(infiniRocmRuntime_t rt, int dtype, const void *x, void *y, int ndim,
+                          const int64_t *in_shape, const int64_t *out_shape, const int64_t *starts,
+                          const int64_t *steps, int reserved) {
+    (void)reserved;
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(ndim >= 0 && ndim <= MD, "pad_slice: rank %d out of range", ndim);
+    const int elem = (int)dtype_size(dtype);
+    IROCM_CHECK_ARG(elem_ok(elem), "pad_slice: unsupported dtype %s", dtype_name(dtype));
+    PadSliceArgs p;
+    p.ndim = ndim > 0 ? ndim : 1;
+    long total = 1, istr = 1;
+    if (ndim == 0) {
+        p.oshape[0] = p.ishape[0] = 1; p.istride[0] = 1; p.start[0] = 0; p.step[0] = 1;
+    }
+    for (int d = ndim - 1; d >= 0; --d) {
+        IROCM_CHECK_ARG(in_shape[d] >= 0 && out_shape[d] >= 0, "pad_slice: negative extent");
+        p.oshape[d] = out_shape[d];
+        p.ishape[d] = in_shape[d];
+        p.istride[d] = istr;
+        p.start[d] = starts[d];
+        p.step[d] = steps ? steps[d] : 1;
+        IROCM_CHECK_ARG(p.step[d] != 0, "pad_slice: zero step");
+        istr *= in_shape[d];
+        total *= out_shape[d];
+    }
+    if (total == 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(y && (x || istr == 0), "pad_slice: NULL tensor");
+    p.total = total;
+    const unsigned g = grid_for(total, rt->num_cu);
+    switch (elem) {
+    case 1: hipLaunchKernelGGL(pad_slice_kernel<1>, dim3(g), dim3(256), 0, rt->stream, x, y, p); break;
+    case 2: hipLaunchKernelGGL(pad_slice_kernel<2>, dim3(g), dim3(256), 0, rt->stream, x, y, p); break;
+    case 4: hipLaunchKernelGGL(pad_slice_kernel<4>, dim3(g), dim3(256), 0, rt->stream, x, y, p); break;
+    default: hipLaunchKernelGGL(pad_slice_kernel<8>, dim3(g), dim3(256), 0, rt->stream, x, y, p); break;
+    }
+    IROCM_LAUNCH_CHECK("pad_slice");
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_strided_copy(infiniRocmRuntime_t rt, const void *src, void *dst, int64_t rows,
+                             int64_t row_bytes, int64_t src_pitch, int64_t dst_pitch) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(rows >= 0 && row_bytes >= 0, "strided_copy: negative extent");
+    if (rows == 0 || row_bytes == 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(src && dst, "strided_copy: NULL tensor");
+    if (src_pitch == row_bytes && dst_pitch == row_bytes)
+        return infini_rocm_copy_inside(rt, dst, src, (size_t)(rows * row_bytes));
+    int w = 16;
+    while (w > 1 && ((row_bytes % w) || (src_pitch % w) || (dst_pitch % w) || ((uintptr_t)src % w) ||
+                     ((uintptr_t)dst % w)))
+        w >>= 1;
+    const long items = row_bytes / w;
+    const unsigned g = grid_for(rows * items, rt->num_cu);
+    const char *s = (const char *)src;
+    char *d = (char *)dst;
+    switch (w) {
+    case 16: hipLaunchKernelGGL(copy2d_kernel<16>, dim3(g), dim3(256), 0, rt->stream, s, d, (long)rows, items, (long)src_pitch, (long)dst_pitch); break;
+    case 8: hipLaunchKernelGGL(copy2d_kernel<8>, dim3(g), dim3(256), 0, rt->stream, s, d, (long)rows, items, (long)src_pitch, (long)dst_pitch); break;
+    case 4: hipLaunchKernelGGL(copy2d_kernel<4>, dim3(g), dim3(256), 0, rt->stream, s, d, (long)rows, items, (long)src_pitch, (long)dst_pitch); break;
+    case 2: hipLaunchKernelGGL(copy2d_kernel<2>, dim3(g), dim3(256), 0, rt->stream, s, d, (long)rows, items, (long)src_pitch, (long)dst_pitch); break;
+    default: hipLaunchKernelGGL(copy2d_kernel<1>, dim3(g), dim3(256), 0, rt->stream, s, d, (long)rows, items, (long)src_pitch, (long)dst_pitch); break;
+    }
+    IROCM_LAUNCH_CHECK("strided_copy");
+    return INFINI_ROCM_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,339 @@
+// Reduce (Mean/Sum), BatchNormalization (inference), MaxPool / AveragePool for gfx950.
+//
+// Replaces (reference): ReduceCudnnBase::compute src/kernels/cuda/reduce.cc:10-108 (cudnnReduceTensor),
+// BatchNormCudnn src/kernels/cuda/batch_norm.cc:7-67 (cudnnBatchNormalizationForwardInference, SPATIAL),
+// poolingCudnn src/kernels/cuda/pooling.cc:6-95 (cudnnPoolingForward; AVERAGE_COUNT_INCLUDE_PADDING).
+// All HBM-bound: algorithmic bytes = (numel_in + numel_out) * sizeof(T). fp32 arithmetic throughout.
+#include "common.h"
+
+namespace irocm {
+
+constexpr int MD = INFINI_ROCM_MAX_DIMS;
+
+template <typename T> struct LdSt;
+template <> struct LdSt<float> {
+    __device__ static inline float ld(const float *p) { return *p; }
+    __device__ static inline void st(float *p, float v) { *p = v; }
+};
+template <> struct LdSt<__half> {
+    __device__ static inline float ld(const __half *p) { return __half2float(*p); }
+    __device__ static inline void st(__half *p, float v) { *p = __float2half_rn(v); }
+};
+template <> struct LdSt<__hip_bfloat16> {
+    __device__ static inline float ld(const __hip_bfloat16 *p) { return __bfloat162float(*p); }
+    __device__ static inline void st(__hip_bfloat16 *p, float v) { *p = __float2bfloat16(v); }
+};
+
+template <typename T, int N> struct alignas(sizeof(T) * N) PackN {
+    T v[N];
+};
+
+__device__ inline float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- Reduce: trailing dims reduced -> [rows, n] row sums, one wave per row ---------------------
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const T *__restrict__ x, T *__restrict__ y, long rows,
+                                                          long n, float scale) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows)
+        return;
+    const T *xr = x + row * n;
+    float s = 0.f;
+    const bool al = (((uintptr_t)xr) & 15) == 0;
+    long i = 0;
+    if (al) {
+        const long nv = n / VEC;
+        for (long v = lane; v < nv; v += 64) {
+            PackN<T, VEC> pk = reinterpret_cast<const PackN<T, VEC> *>(xr)[v];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                s += LdSt<T>::ld(&pk.v[j]);
+        }
+        i = nv * VEC;
+    }
+    for (long k = i + lane; k < n; k += 64)
+        s += LdSt<T>::ld(xr + k);
+    s = wsum(s);
+    if (lane == 0)
+        LdSt<T>::st(y + row, s * scale);
+}
+
+// ---- Reduce: general axes. One thread per output element (coalesced when the innermost kept dim
+// is the innermost input dim), serial loop over the reduced index space. -------------------------
+struct ReduceArgs {
+    int nk, nr;           // number of kept / reduced (collapsed) dims
+    long kshape[MD], kstride[MD];
+    long rshape[MD], rstride[MD];
+    long nout, nred;
+    float scale;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_general_kernel(const T *__restrict__ x, T *__restrict__ y,
+                                                             ReduceArgs p) {
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < p.nout; o += (long)gridDim.x * 256) {
+        long rem = o, base = 0;
+        for (int d = p.nk - 1; d >= 0; --d) {
+            const long q = rem / p.kshape[d];
+            base += (rem - q * p.kshape[d]) * p.kstride[d];
+            rem = q;
+        }
+        float s = 0.f;
+        for (long r = 0; r < p.nred; ++r) {
+            long rr = r, off = base;
+            for (int d = p.nr - 1; d >= 0; --d) {
+                const long q = rr / p.rshape[d];
+                off += (rr - q * p.rshape[d]) * p.rstride[d];
+                rr = q;
+            }
+            s += LdSt<T>::ld(x + off);
+        }
+        LdSt<T>::st(y + o, s * p.scale);
+    }
+}
+
+template <typename T>
+static int reduce_dispatch(infiniRocmRuntime_t rt, const void *x, void *y, int ndim, const int64_t *shape,
+                           const int *reduced, bool mean) {
+    long stride[MD], total = 1;
+    for (int d = ndim - 1; d >= 0; --d) {
+        stride[d] = total;
+        total *= shape[d];
+    }
+    ReduceArgs p;
+    p.nk = p.nr = 0;
+    p.nout = p.nred = 1;
+    bool trailing = true; // all reduced dims (extent > 1) come after all kept dims (extent > 1)
+    bool seen_red = false;
+    for (int d = 0; d < ndim; ++d) {
+        if (shape[d] == 1)
+            continue;
+        if (reduced[d]) {
+            seen_red = true;
+            if (p.nr > 0 && p.rstride[p.nr - 1] == stride[d] * shape[d]) {
+                p.rshape[p.nr - 1] *= shape[d];
+                p.rstride[p.nr - 1] = stride[d];
+            } else {
+                p.rshape[p.nr] = shape[d];
+                p.rstride[p.nr] = stride[d];
+                ++p.nr;
+            }
+            p.nred *= shape[d];
+        } else {
+            if (seen_red)
+                trailing = false;
+            if (p.nk > 0 && p.kstride[p.nk - 1] == stride[d] * shape[d]) {
+                p.kshape[p.nk - 1] *= shape[d];
+                p.kstride[p.nk - 1] = stride[d];
+            } else {
+                p.kshape[p.nk] = shape[d];
+                p.kstride[p.nk] = stride[d];
+                ++p.nk;
+            }
+            p.nout *= shape[d];
+        }
+    }
+    if (total == 0)
+        return INFINI_ROCM_OK; // empty input: nothing to write that the reference defines
+    p.scale = mean ? 1.0f / (float)p.nred : 1.0f;
+    if (trailing && p.nred >= 64) {
+        hipLaunchKernelGGL((reduce_rows_kernel<T>), dim3((unsigned)ceil_div(p.nout, 4)), dim3(256), 0,
+                           rt->stream, (const T *)x, (T *)y, p.nout, p.nred, p.scale);
+    } else {
+        long g = ceil_div(p.nout, 256);
+        if (g > (long)rt->num_cu * 16) g = (long)rt->num_cu * 16;
+        hipLaunchKernelGGL((reduce_general_kernel<T>), dim3((unsigned)g), dim3(256), 0, rt->stream,
+                           (const T *)x, (T *)y, p);
+    }
+    IROCM_LAUNCH_CHECK("reduce");
+    return INFINI_ROCM_OK;
+}
+
+// ---- BatchNorm inference: x [N, C, inner]; mean/var/scale/bias fp32 [C] ------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void batch_norm_kernel(const T *__restrict__ x, const float *__restrict__ mean,
+                                                         const float *__restrict__ var,
+                                                         const float *__restrict__ scale,
+                                                         const float *__restrict__ bias, T *__restrict__ y,
+                                                         long nc, long c, long inner, float eps) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    // one block per (n, c) plane chunk: blockIdx.y = plane, blockIdx.x = chunk
+    const long plane = blockIdx.y + (long)blockIdx.z * 65535;
+    if (plane >= nc)
+        return;
+    const long ch = plane % c;
+    const float a = scale[ch] * rsqrtf(var[ch] + eps);
+    const float b = bias[ch] - mean[ch] * a;
+    const T *xp = x + plane * inner;
+    T *yp = y + plane * inner;
+    const bool al = ((((uintptr_t)xp) | ((uintptr_t)yp)) & 15) == 0;
+    if (al) {
+        const long nv = inner / VEC;
+        for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nv; v += (long)gridDim.x * 256) {
+            PackN<T, VEC> pk = reinterpret_cast<const PackN<T, VEC> *>(xp)[v], o;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                LdSt<T>::st(&o.v[j], LdSt<T>::ld(&pk.v[j]) * a + b);
+            reinterpret_cast<PackN<T, VEC> *>(yp)[v] = o;
+        }
+        for (long i = nv * VEC + (long)blockIdx.x * 256 + threadIdx.x; i < inner; i += (long)gridDim.x * 256)
+            LdSt<T>::st(yp + i, LdSt<T>::ld(xp + i) * a + b);
+    } else {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < inner; i += (long)gridDim.x * 256)
+            LdSt<T>::st(yp + i, LdSt<T>::ld(xp + i) * a + b);
+    }
+}
+
+// ---- Pooling -----------------------------------------------------------------------------------
+struct PoolArgs {
+    long n, c, h, w, oh, ow;
+    int kh, kw, dh, dw, ph, pw, sh, sw;
+};
+
+template <typename T, bool MAX>
+__global__ __launch_bounds__(256) void pool2d_kernel(const T *__restrict__ x, T *__restrict__ y, PoolArgs p) {
+    const long total = p.n * p.c * p.oh * p.ow;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long ox = i % p.ow, oy = (i / p.ow) % p.oh, plane = i / (p.ow * p.oh);
+        const T *xp = x + plane * p.h * p.w;
+        float acc = MAX ? -INFINITY : 0.f;
+        for (int r = 0; r < p.kh; ++r) {
+            const long iy = oy * p.sh - p.ph + (long)r * p.dh;
+            if (iy < 0 || iy >= p.h)
+                continue;
+            for (int s = 0; s < p.kw; ++s) {
+                const long ix = ox * p.sw - p.pw + (long)s * p.dw;
+                if (ix < 0 || ix >= p.w)
+                    continue;
+                const float v = LdSt<T>::ld(xp + iy * p.w + ix);
+                acc = MAX ? fmaxf(acc, v) : acc + v;
+            }
+        }
+        // AveragePool counts padding (reference pooling.cc:86-90: COUNT_INCLUDE_PADDING)
+        LdSt<T>::st(y + i, MAX ? acc : acc / (float)(p.kh * p.kw));
+    }
+}
+
+// Global average pool fast path (kernel == whole plane, no pad): one wave per plane.
+template <typename T>
+__global__ __launch_bounds__(256) void global_avgpool_kernel(const T *__restrict__ x, T *__restrict__ y,
+                                                             long planes, long hw) {
+    const int lane = threadIdx.x & 63;
+    const long plane = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (plane >= planes)
+        return;
+    float s = 0.f;
+    for (long i = lane; i < hw; i += 64)
+        s += LdSt<T>::ld(x + plane * hw + i);
+    s = wsum(s);
+    if (lane == 0)
+        LdSt<T>::st(y + plane, s / (float)hw);
+}
+
+} // namespace irocm
+
+using namespace irocm;
+
+extern "C" {
+
+int infini_rocm_reduce(infiniRocmRuntime_t rt, int kind, int dtype, const void *x, void *y, int ndim,
+                       const int64_t *shape, const int *reduced) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(kind == 0 || kind == 1, "reduce: kind must be 0 (sum) or 1 (mean)");
+    IROCM_CHECK_ARG(ndim >= 0 && ndim <= MD, "reduce: rank %d out of range", ndim);
+    for (int d = 0; d < ndim; ++d)
+        IROCM_CHECK_ARG(shape[d] >= 0, "reduce: negative extent");
+    IROCM_CHECK_ARG(x && y, "reduce: NULL tensor");
+    switch (dtype) {
+    case INFINI_DT_F32: return reduce_dispatch<float>(rt, x, y, ndim, shape, reduced, kind == 1);
+    case INFINI_DT_F16: return reduce_dispatch<__half>(rt, x, y, ndim, shape, reduced, kind == 1);
+    case INFINI_DT_BF16: return reduce_dispatch<__hip_bfloat16>(rt, x, y, ndim, shape, reduced, kind == 1);
+    default: IROCM_FAIL(INFINI_ROCM_UNSUPPORTED, "reduce: unsupported dtype %s", dtype_name(dtype));
+    }
+}
+
+int infini_rocm_batch_norm(infiniRocmRuntime_t rt, int dtype, const void *x, const void *mean,
+                           const void *var, const void *scale, const void *bias, void *y, int64_t n,
+                           int64_t c, int64_t inner, float eps) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(n >= 0 && c >= 0 && inner >= 0, "batch_norm: negative extent");
+    if (n * c * inner == 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(x && y && mean && var && scale && bias, "batch_norm: NULL tensor");
+    const long nc = n * c;
+    const int vec = 16 / (int)dtype_size(dtype);
+    long gx = ceil_div(ceil_div(inner, vec), 256);
+    if (gx > 64) gx = 64;
+    if (gx < 1) gx = 1;
+    dim3 grid((unsigned)gx, (unsigned)(nc < 65535 ? nc : 65535), (unsigned)ceil_div(nc, 65535));
+#define GO(T)                                                                                      \
+    hipLaunchKernelGGL((batch_norm_kernel<T>), grid, dim3(256), 0, rt->stream, (const T *)x,       \
+                       (const float *)mean, (const float *)var, (const float *)scale,              \
+                       (const float *)bias, (T *)y, nc, (long)c, (long)inner, eps)
+    switch (dtype) {
+    case INFINI_DT_F32: GO(float); break;
+    case INFINI_DT_F16: GO(__half); break;
+    case INFINI_DT_BF16: GO(__hip_bfloat16); break;
+    default: IROCM_FAIL(INFINI_ROCM_UNSUPPORTED, "batch_norm: unsupported dtype %s", dtype_name(dtype));
+    }
+#undef GO
+    IROCM_LAUNCH_CHECK("batch_norm");
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_pool2d(infiniRocmRuntime_t rt, int kind, int dtype, const void *x, void *y, int64_t n,
+                       int64_t c, int64_t h, int64_t w, int kh, int kw, int dh, int dw, int ph, int pw,
+                       int sh, int sw, int ceil_mode) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(kind == 0 || kind == 1, "pool2d: kind must be 0 (max) or 1 (average)");
+    IROCM_CHECK_ARG(n >= 0 && c >= 0 && h >= 0 && w >= 0, "pool2d: negative extent");
+    IROCM_CHECK_ARG(kh > 0 && kw > 0 && sh > 0 && sw > 0 && dh > 0 && dw > 0 && ph >= 0 && pw >= 0,
+                    "pool2d: bad window attributes");
+    // output size: reference src/operators/pooling.cc:17-35
+    auto osz = [&](int64_t i, int k, int d, int p, int s) -> int64_t {
+        const double v = ((double)(i + 2 * p - d * (k - 1) - 1)) / s + 1;
+        return (int64_t)(ceil_mode ? ceil(v) : floor(v));
+    };
+    PoolArgs p;
+    p.n = n; p.c = c; p.h = h; p.w = w;
+    p.oh = osz(h, kh, dh, ph, sh);
+    p.ow = osz(w, kw, dw, pw, sw);
+    p.kh = kh; p.kw = kw; p.dh = dh; p.dw = dw; p.ph = ph; p.pw = pw; p.sh = sh; p.sw = sw;
+    const long total = n * c * p.oh * p.ow;
+    if (total <= 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(x && y, "pool2d: NULL tensor");
+    const bool global_avg = kind == 1 && p.oh == 1 && p.ow == 1 && kh == h && kw == w && ph == 0 && pw == 0 &&
+                            dh == 1 && dw == 1;
+    long g = ceil_div(total, 256);
+    if (g > (long)rt->num_cu * 16) g = (long)rt->num_cu * 16;
+#define GO(T)                                                                                      \
+    if (global_avg)                                                                                \
+        hipLaunchKernelGGL((global_avgpool_kernel<T>), dim3((unsigned)ceil_div(n * c, 4)),         \
+                           dim3(256), 0, rt->stream, (const T *)x, (T *)y, (long)(n * c),          \
+                           (long)(h * w));                                                         \
+    else if (kind == 0)                                                                            \
+        hipLaunchKernelGGL((pool2d_kernel<T, true>), dim3((unsigned)g), dim3(256), 0, rt->stream,  \
+                           (const T *)x, (T *)y, p);                                               \
+    else                                                                                           \
+        hipLaunchKernelGGL((pool2d_kernel<T, false>), dim3((unsigned)g), dim3(256), 0, rt->stream, \
+                           (const T *)x, (T *)y, p)
+    switch (dtype) {
+    case INFINI_DT_F32: GO(float); break;
+    case INFINI_DT_F16: GO(__half); break;
+    case INFINI_DT_BF16: GO(__hip_bfloat16); break;
+    default: IROCM_FAIL(INFINI_ROCM_UNSUPPORTED, "pool2d: unsupported dtype %s", dtype_name(dtype));
+    }
+#undef GO
+    IROCM_LAUNCH_CHECK("pool2d");
+    return INFINI_ROCM_OK;
+}
+
+} // extern "C"

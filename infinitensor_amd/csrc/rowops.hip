@@ -96,33 +96,43 @@ __device__ inline void store_row(T *row, int n, int lane, const float (&y)[CHUNK
     }
 }
 
-template <typename T, int CHUNKS, bool ALIGNED>
+// ROWS rows per wave: all loads of the wave's rows are issued before any arithmetic, so a wave keeps
+// ROWS * row_bytes (~4 KiB) in flight — 16-bit rows of <= 1 KiB are latency-bound at one row per wave.
+template <typename T, int CHUNKS, bool ALIGNED, int ROWS>
 __global__ __launch_bounds__(256) void softmax_wave_kernel(const T *__restrict__ x, T *__restrict__ y,
                                                            long rows, int n) {
     constexpr int NV = CHUNKS * Elem<T>::VEC;
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows)
+    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+    if (row0 >= rows)
         return;
-    float v[NV];
-    load_row<T, CHUNKS, ALIGNED>(x + row * n, n, lane, v, -INFINITY);
-    float m = v[0];
+    float v[ROWS][NV];
 #pragma unroll
-    for (int i = 1; i < NV; ++i)
-        m = fmaxf(m, v[i]);
-    m = wave_max(m);
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        v[i] = __expf(v[i] - m);
-        s += v[i];
+    for (int r = 0; r < ROWS; ++r) {
+        const long row = row0 + r < rows ? row0 + r : rows - 1; // tail rows recompute the last row
+        load_row<T, CHUNKS, ALIGNED>(x + row * n, n, lane, v[r], -INFINITY);
     }
-    s = wave_sum(s);
-    const float inv = 1.0f / s;
 #pragma unroll
-    for (int i = 0; i < NV; ++i)
-        v[i] *= inv;
-    store_row<T, CHUNKS, ALIGNED>(y + row * n, n, lane, v);
+    for (int r = 0; r < ROWS; ++r) {
+        float m = v[r][0];
+#pragma unroll
+        for (int i = 1; i < NV; ++i)
+            m = fmaxf(m, v[r][i]);
+        m = wave_max(m);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[r][i] = sizeof(T) == 4 ? expf(v[r][i] - m) : __expf(v[r][i] - m);
+            s += v[r][i];
+        }
+        s = wave_sum(s);
+        const float inv = 1.0f / s;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            v[r][i] *= inv;
+        if (row0 + r < rows)
+            store_row<T, CHUNKS, ALIGNED>(y + (row0 + r) * n, n, lane, v[r]);
+    }
 }
 
 // Long contiguous rows: one 256-thread block per row, grid-stride over rows, three passes over a
@@ -190,7 +200,7 @@ __global__ __launch_bounds__(256) void softmax_strided_kernel(const T *__restric
 // LayerNorm / RMSNorm, one wave per row (row in registers), two-pass mean/variance in registers
 // (numerically the "centered" form: var = mean((x - mu)^2)), fp32 throughout.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int CHUNKS, bool ALIGNED, bool RMS>
+template <typename T, int CHUNKS, bool ALIGNED, bool RMS, int ROWS>
 __global__ __launch_bounds__(256) void norm_wave_kernel(const T *__restrict__ x, const T *__restrict__ scale,
                                                         const T *__restrict__ bias, T *__restrict__ y,
                                                         long rows, int n, int scale_size, int bias_size,
@@ -198,31 +208,16 @@ __global__ __launch_bounds__(256) void norm_wave_kernel(const T *__restrict__ x,
     constexpr int VEC = Elem<T>::VEC;
     constexpr int NV = CHUNKS * VEC;
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows)
+    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+    if (row0 >= rows)
         return;
-    float v[NV];
-    load_row<T, CHUNKS, ALIGNED>(x + row * n, n, lane, v, 0.f);
-    const float inv_n = 1.0f / (float)n;
-    float mu = 0.f;
-    if (!RMS) {
-        float s = 0.f;
+    float v[ROWS][NV];
 #pragma unroll
-        for (int i = 0; i < NV; ++i)
-            s += v[i];
-        mu = wave_sum(s) * inv_n;
+    for (int r = 0; r < ROWS; ++r) {
+        const long row = row0 + r < rows ? row0 + r : rows - 1;
+        load_row<T, CHUNKS, ALIGNED>(x + row * n, n, lane, v[r], 0.f);
     }
-    float q = 0.f;
-#pragma unroll
-    for (int c = 0; c < CHUNKS; ++c)
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            const int col = (c * 64 + lane) * VEC + j;
-            const float d = (col < n) ? v[c * VEC + j] - mu : 0.f;
-            q += d * d;
-        }
-    const float rstd = rsqrtf(wave_sum(q) * inv_n + eps);
-    // scale / bias: per-element (size n) or scalar (size 1)
+    // scale / bias: per-element (size n) or scalar (size 1); shared by the wave's rows
     float sc[NV], bs[NV];
     if (scale_size == 1) {
         const float s0 = Elem<T>::ld(scale);
@@ -244,10 +239,33 @@ __global__ __launch_bounds__(256) void norm_wave_kernel(const T *__restrict__ x,
     } else {
         load_row<T, CHUNKS, ALIGNED>(bias, n, lane, bs, 0.f);
     }
+    const float inv_n = 1.0f / (float)n;
 #pragma unroll
-    for (int i = 0; i < NV; ++i)
-        v[i] = (v[i] - mu) * rstd * sc[i] + bs[i];
-    store_row<T, CHUNKS, ALIGNED>(y + row * n, n, lane, v);
+    for (int r = 0; r < ROWS; ++r) {
+        float mu = 0.f;
+        if (!RMS) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                s += v[r][i];
+            mu = wave_sum(s) * inv_n;
+        }
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < CHUNKS; ++c)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const int col = (c * 64 + lane) * VEC + j;
+                const float d = (col < n) ? v[r][c * VEC + j] - mu : 0.f;
+                q += d * d;
+            }
+        const float rstd = rsqrtf(wave_sum(q) * inv_n + eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            v[r][i] = (v[r][i] - mu) * rstd * sc[i] + bs[i];
+        if (row0 + r < rows)
+            store_row<T, CHUNKS, ALIGNED>(y + (row0 + r) * n, n, lane, v[r]);
+    }
 }
 
 // Long rows: block per row, row re-read from L2.
@@ -302,26 +320,32 @@ static int softmax_dispatch(infiniRocmRuntime_t rt, const T *x, T *y, int64_t ou
         const bool al = is_aligned16(x) && is_aligned16(y) && (dimsize % VEC == 0);
         const int64_t per_chunk = 64 * VEC;
         const int chunks = (int)ceil_div(dimsize, per_chunk);
-        const unsigned grid = (unsigned)ceil_div(outer, 4);
-#define SM_LAUNCH(C)                                                                               \
-    do {                                                                                           \
-        if (al)                                                                                    \
-            hipLaunchKernelGGL((softmax_wave_kernel<T, C, true>), dim3(grid), dim3(256), 0,        \
-                               rt->stream, x, y, (long)outer, (int)dimsize);                       \
-        else                                                                                       \
-            hipLaunchKernelGGL((softmax_wave_kernel<T, C, false>), dim3(grid), dim3(256), 0,       \
-                               rt->stream, x, y, (long)outer, (int)dimsize);                       \
-    } while (0)
-        if (chunks <= 1) SM_LAUNCH(1);
-        else if (chunks <= 2) SM_LAUNCH(2);
-        else if (chunks <= 4) SM_LAUNCH(4);
-        else if (chunks <= 8) SM_LAUNCH(8);
+        // rows per wave: keep ~4 KiB of loads in flight per wave
+        const int64_t row_bytes = dimsize * (int64_t)sizeof(T);
+        const int rpw = (!al || outer < 4096) ? 1 : (row_bytes <= 1024 ? 4 : (row_bytes <= 2048 ? 2 : 1));
+#define SM_GO(C, A, R)                                                                             \
+    hipLaunchKernelGGL((softmax_wave_kernel<T, C, A, R>), dim3((unsigned)ceil_div(outer, 4 * R)),  \
+                       dim3(256), 0, rt->stream, x, y, (long)outer, (int)dimsize)
+        if (chunks <= 1) {
+            if (!al) SM_GO(1, false, 1);
+            else if (rpw == 4) SM_GO(1, true, 4);
+            else if (rpw == 2) SM_GO(1, true, 2);
+            else SM_GO(1, true, 1);
+        } else if (chunks <= 2) {
+            if (!al) SM_GO(2, false, 1);
+            else if (rpw >= 2) SM_GO(2, true, 2);
+            else SM_GO(2, true, 1);
+        } else if (chunks <= 4) {
+            if (al) SM_GO(4, true, 1); else SM_GO(4, false, 1);
+        } else if (chunks <= 8) {
+            if (al) SM_GO(8, true, 1); else SM_GO(8, false, 1);
+        }
         else {
             const unsigned g = (unsigned)(outer < 8192 ? outer : 8192);
             hipLaunchKernelGGL((softmax_block_kernel<T>), dim3(g), dim3(256), 0, rt->stream, x, y,
                                (long)outer, (long)dimsize);
         }
-#undef SM_LAUNCH
+#undef SM_GO
     } else {
         const int64_t total = outer * inner;
         const unsigned g = (unsigned)(ceil_div(total, 256) < 16384 ? ceil_div(total, 256) : 16384);
@@ -339,27 +363,29 @@ static int norm_dispatch(infiniRocmRuntime_t rt, const T *x, const T *scale, con
     const bool al = is_aligned16(x) && is_aligned16(y) && is_aligned16(scale) &&
                     (bias == nullptr || is_aligned16(bias)) && (n % VEC == 0);
     const int chunks = (int)ceil_div(n, (int64_t)64 * VEC);
-    const unsigned grid = (unsigned)ceil_div(outer, 4);
-#define NORM_LAUNCH(C)                                                                             \
-    do {                                                                                           \
-        if (al)                                                                                    \
-            hipLaunchKernelGGL((norm_wave_kernel<T, C, true, RMS>), dim3(grid), dim3(256), 0,      \
-                               rt->stream, x, scale, bias, y, (long)outer, (int)n,                 \
-                               (int)scale_size, (int)bias_size, eps);                              \
-        else                                                                                       \
-            hipLaunchKernelGGL((norm_wave_kernel<T, C, false, RMS>), dim3(grid), dim3(256), 0,     \
-                               rt->stream, x, scale, bias, y, (long)outer, (int)n,                 \
-                               (int)scale_size, (int)bias_size, eps);                              \
-    } while (0)
-    if (chunks <= 1) NORM_LAUNCH(1);
-    else if (chunks <= 2) NORM_LAUNCH(2);
-    else if (chunks <= 4) NORM_LAUNCH(4);
-    else {
+    const int64_t row_bytes = n * (int64_t)sizeof(T);
+    const int rpw = (!al || outer < 4096) ? 1 : (row_bytes <= 1024 ? 4 : (row_bytes <= 2048 ? 2 : 1));
+#define NORM_GO(C, A, R)                                                                           \
+    hipLaunchKernelGGL((norm_wave_kernel<T, C, A, RMS, R>), dim3((unsigned)ceil_div(outer, 4 * R)), \
+                       dim3(256), 0, rt->stream, x, scale, bias, y, (long)outer, (int)n,           \
+                       (int)scale_size, (int)bias_size, eps)
+    if (chunks <= 1) {
+        if (!al) NORM_GO(1, false, 1);
+        else if (rpw == 4) NORM_GO(1, true, 4);
+        else if (rpw == 2) NORM_GO(1, true, 2);
+        else NORM_GO(1, true, 1);
+    } else if (chunks <= 2) {
+        if (!al) NORM_GO(2, false, 1);
+        else if (rpw >= 2) NORM_GO(2, true, 2);
+        else NORM_GO(2, true, 1);
+    } else if (chunks <= 4) {
+        if (al) NORM_GO(4, true, 1); else NORM_GO(4, false, 1);
+    } else {
         const unsigned g = (unsigned)(outer < 8192 ? outer : 8192);
         hipLaunchKernelGGL((norm_block_kernel<T, RMS>), dim3(g), dim3(256), 0, rt->stream, x, scale,
                            bias, y, (long)outer, (long)n, (int)scale_size, (int)bias_size, eps);
     }
-#undef NORM_LAUNCH
+#undef NORM_GO
     IROCM_LAUNCH_CHECK("norm");
     return INFINI_ROCM_OK;
 }

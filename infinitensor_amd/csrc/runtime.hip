@@ -15,6 +15,8 @@ void set_error(const char *fmt, ...) {
 
 using namespace irocm;
 
+extern "C" int infini_rocm_comm_destroy(infiniRocmRuntime_t rt);
+
 extern "C" {
 
 const char *infini_rocm_last_error(void) { return irocm::g_err; }
@@ -61,6 +63,7 @@ int infini_rocm_runtime_destroy(infiniRocmRuntime_t rt) {
     if (rt->own_stream) {
         (void)hipStreamSynchronize(rt->own_stream);
     }
+    (void)infini_rocm_comm_destroy(rt);
     if (rt->workspace)
         (void)hipFree(rt->workspace);
     if (rt->own_stream)
@@ -95,7 +98,14 @@ int infini_rocm_runtime_get_stream(infiniRocmRuntime_t rt, void **stream) {
 int infini_rocm_runtime_set_stream(infiniRocmRuntime_t rt, void *stream) {
     IROCM_CHECK_ARG(rt, "NULL runtime");
     IROCM_CHECK_ARG(!rt->capturing, "cannot change stream while capturing");
-    rt->stream = stream ? (hipStream_t)stream : rt->own_stream;
+    rt->stream = (hipStream_t)stream;
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_runtime_use_own_stream(infiniRocmRuntime_t rt) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(!rt->capturing, "cannot change stream while capturing");
+    rt->stream = rt->own_stream;
     return INFINI_ROCM_OK;
 }
 

@@ -248,3 +248,252 @@ def cast(rt: RocmRuntime, x: torch.Tensor, dst: torch.dtype, out: torch.Tensor |
         out = torch.empty(x.shape, dtype=dst, device=x.device)
     check(lib().infini_rocm_cast(rt.handle, dtype_of(x), int(_TORCH2DT[dst]), _ptr(x), _ptr(out), x.numel()))
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# Conv2d / Pool / BatchNorm / Reduce
+# ------------------------------------------------------------------------------------------------
+def conv2d(rt: RocmRuntime, x: torch.Tensor, w: torch.Tensor, ph: int = 0, pw: int = 0, sh: int = 1,
+           sw: int = 1, dh: int = 1, dw: int = 1, bias: torch.Tensor | None = None, act: int = 0,
+           out: torch.Tensor | None = None) -> torch.Tensor:
+    """NCHW x FCRS cross-correlation. Shape rule: src/operators/conv.cc:47-114 (groups = C / w.shape[1]);
+    glue mirrored: src/kernels/cuda/conv.cc:57-168."""
+    n, c, h, wd = x.shape
+    f, cpg, r, s = w.shape
+    if c % cpg != 0:
+        raise ValueError("input channels not divisible by weight channels")  # reference: IT_ASSERT
+    groups = c // cpg
+    if f % groups != 0:
+        raise ValueError("filters not divisible by groups")
+    oh = (h - (r - sh) * dh + ph * 2) // sh
+    ow = (wd - (s - sw) * dw + pw * 2) // sw
+    if out is None:
+        out = torch.empty((n, f, oh, ow), dtype=x.dtype, device=x.device)
+    check(lib().infini_rocm_conv2d(rt.handle, dtype_of(x), _ptr(x), _ptr(w), _ptr(bias), _ptr(out), n, c, h, wd,
+                                   f, r, s, ph, pw, sh, sw, dh, dw, groups, int(act)))
+    return out
+
+
+def _pool(rt, kind, x, kh, kw, dh, dw, ph, pw, sh, sw, ceil_mode, out):
+    rank3 = x.dim() == 3  # reference: rank-3 input is treated as H = 1 (src/operators/pooling.cc:10-13)
+    n, c = x.shape[0], x.shape[1]
+    h = 1 if rank3 else x.shape[2]
+    w = x.shape[-1]
+
+    def osz(i, k, d, p, s):
+        v = (i + 2 * p - d * (k - 1) - 1) / s + 1
+        return int(math.ceil(v) if ceil_mode else math.floor(v))
+
+    oh, ow = osz(h, kh, dh, ph, sh), osz(w, kw, dw, pw, sw)
+    if out is None:
+        out = torch.empty((n, c, ow) if rank3 else (n, c, oh, ow), dtype=x.dtype, device=x.device)
+    check(lib().infini_rocm_pool2d(rt.handle, kind, dtype_of(x), _ptr(x), _ptr(out), n, c, h, w, kh, kw, dh, dw,
+                                   ph, pw, sh, sw, int(ceil_mode)))
+    return out
+
+
+def max_pool(rt, x, kh, kw, dh=1, dw=1, ph=0, pw=0, sh=1, sw=1, ceil_mode=0, out=None):
+    return _pool(rt, 0, x, kh, kw, dh, dw, ph, pw, sh, sw, ceil_mode, out)
+
+
+def avg_pool(rt, x, kh, kw, dh=1, dw=1, ph=0, pw=0, sh=1, sw=1, ceil_mode=0, out=None):
+    return _pool(rt, 1, x, kh, kw, dh, dw, ph, pw, sh, sw, ceil_mode, out)
+
+
+def batch_norm(rt: RocmRuntime, x: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, scale: torch.Tensor,
+               bias: torch.Tensor, eps: float = 1e-5, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Inference BN over dim 1; operator input order x, mean, var, scale, bias
+    (include/operators/batch_norm.h:10-50); parameters are fp32 [C] (batch_norm.cc:13)."""
+    for t in (mean, var, scale, bias):
+        if t.dtype != torch.float32 or t.numel() != x.shape[1]:
+            raise ValueError("batch_norm parameters must be float32 of shape [C]")
+    if out is None:
+        out = torch.empty_like(x)
+    n, c = x.shape[0], x.shape[1]
+    check(lib().infini_rocm_batch_norm(rt.handle, dtype_of(x), _ptr(x), _ptr(mean), _ptr(var), _ptr(scale),
+                                       _ptr(bias), _ptr(out), n, c, math.prod(x.shape[2:]), float(eps)))
+    return out
+
+
+def reduce(rt: RocmRuntime, kind: str, x: torch.Tensor, axes: Sequence[int] | None = None, keepdims: bool = True,
+           out: torch.Tensor | None = None) -> torch.Tensor:
+    """ReduceSum / ReduceMean (src/operators/reduce.cc; kernel glue src/kernels/cuda/reduce.cc:10-108)."""
+    rank = x.dim()
+    ax = sorted({_real_axis(a, rank) for a in axes}) if axes else list(range(rank))
+    flags = [1 if d in ax else 0 for d in range(rank)]
+    oshape = [1 if flags[d] else x.shape[d] for d in range(rank)] if keepdims else \
+        [x.shape[d] for d in range(rank) if not flags[d]]
+    if out is None:
+        out = torch.empty(oshape, dtype=x.dtype, device=x.device)
+    check(lib().infini_rocm_reduce(rt.handle, {"sum": 0, "mean": 1}[kind], dtype_of(x), _ptr(x), _ptr(out), rank,
+                                   _i64arr(list(x.shape)), _i32arr(flags)))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# Data movement / indexing
+# ------------------------------------------------------------------------------------------------
+def transpose(rt: RocmRuntime, x: torch.Tensor, perm: Sequence[int], out: torch.Tensor | None = None) -> torch.Tensor:
+    perm = [int(p) for p in perm]
+    if sorted(perm) != list(range(x.dim())):
+        raise ValueError("bad permutation")
+    if out is None:
+        out = torch.empty([x.shape[p] for p in perm], dtype=x.dtype, device=x.device)
+    check(lib().infini_rocm_transpose(rt.handle, dtype_of(x), _ptr(x), _ptr(out), x.dim(), _i64arr(list(x.shape)),
+                                      _i32arr(perm)))
+    return out
+
+
+def reshape(rt: RocmRuntime, x: torch.Tensor, shape: Sequence[int], out: torch.Tensor | None = None) -> torch.Tensor:
+    """Reshape / Flatten / Identity / Squeeze / Unsqueeze: a device copy (reshape.cc:4-21; the planner
+    never aliases input and output)."""
+    if out is None:
+        out = torch.empty(list(shape), dtype=x.dtype, device=x.device)
+    if out.numel() != x.numel():
+        raise ValueError("reshape changes the element count")
+    check(lib().infini_rocm_copy_inside(rt.handle, _ptr(out), _ptr(x), x.numel() * x.element_size()))
+    return out
+
+
+def expand(rt: RocmRuntime, x: torch.Tensor, shape: Sequence[int], out: torch.Tensor | None = None) -> torch.Tensor:
+    oshape = infer_broadcast(list(x.shape), list(shape))
+    if out is None:
+        out = torch.empty(oshape, dtype=x.dtype, device=x.device)
+    check(lib().infini_rocm_expand(rt.handle, dtype_of(x), _ptr(x), _ptr(out), len(oshape), _i64arr(oshape),
+                                   _i64arr(broadcast_strides(list(x.shape), oshape))))
+    return out
+
+
+def gather(rt: RocmRuntime, data: torch.Tensor, indices: torch.Tensor, axis: int = 0,
+           out: torch.Tensor | None = None) -> torch.Tensor:
+    """Output rank = data rank - 1 + index rank (include/operators/gather.h:27-49)."""
+    axis = _real_axis(axis, data.dim())
+    if indices.dtype not in (torch.int32, torch.int64):
+        raise TypeError("gather indices must be int32 or int64")
+    oshape = list(data.shape[:axis]) + list(indices.shape) + list(data.shape[axis + 1:])
+    if out is None:
+        out = torch.empty(oshape, dtype=data.dtype, device=data.device)
+    check(lib().infini_rocm_gather(rt.handle, dtype_of(data), dtype_of(indices), _ptr(data), _ptr(indices), _ptr(out),
+                                   math.prod(data.shape[:axis]), data.shape[axis], indices.numel(),
+                                   math.prod(data.shape[axis + 1:])))
+    return out
+
+
+def where(rt: RocmRuntime, x: torch.Tensor, y: torch.Tensor, cond: torch.Tensor,
+          out: torch.Tensor | None = None) -> torch.Tensor:
+    """cond ? x : y; operator input order x, y, cond (include/operators/where.h:9-34)."""
+    if cond.element_size() != 1:
+        raise TypeError("where condition must be a 1-byte type (bool / uint8)")
+    oshape = infer_broadcast(infer_broadcast(list(x.shape), list(y.shape)), list(cond.shape))
+    if out is None:
+        out = torch.empty(oshape, dtype=x.dtype, device=x.device)
+    check(lib().infini_rocm_where(rt.handle, dtype_of(x), _ptr(x), _ptr(y), _ptr(cond), _ptr(out), len(oshape),
+                                  _i64arr(oshape), _i64arr(broadcast_strides(list(x.shape), oshape)),
+                                  _i64arr(broadcast_strides(list(y.shape), oshape)),
+                                  _i64arr(broadcast_strides(list(cond.shape), oshape))))
+    return out
+
+
+def concat(rt: RocmRuntime, xs: Sequence[torch.Tensor], axis: int, out: torch.Tensor | None = None) -> torch.Tensor:
+    axis = _real_axis(axis, xs[0].dim())
+    oshape = list(xs[0].shape)
+    oshape[axis] = sum(t.shape[axis] for t in xs)
+    if out is None:
+        out = torch.empty(oshape, dtype=xs[0].dtype, device=xs[0].device)
+    outer = math.prod(oshape[:axis])
+    inner_bytes = math.prod(oshape[axis + 1:]) * out.element_size()
+    dst_pitch = oshape[axis] * inner_bytes
+    off = 0
+    for t in xs:
+        rb = t.shape[axis] * inner_bytes
+        check(lib().infini_rocm_strided_copy(rt.handle, _ptr(t), C.c_void_p(out.data_ptr() + off), outer, rb, rb, dst_pitch))
+        off += rb
+    return out
+
+
+def split(rt: RocmRuntime, x: torch.Tensor, axis: int, sizes: Sequence[int]) -> list[torch.Tensor]:
+    axis = _real_axis(axis, x.dim())
+    if sum(sizes) != x.shape[axis]:
+        raise ValueError("split sizes do not add up")
+    outer = math.prod(x.shape[:axis])
+    inner_bytes = math.prod(x.shape[axis + 1:]) * x.element_size()
+    src_pitch = x.shape[axis] * inner_bytes
+    outs, off = [], 0
+    for sz in sizes:
+        shp = list(x.shape)
+        shp[axis] = sz
+        o = torch.empty(shp, dtype=x.dtype, device=x.device)
+        rb = sz * inner_bytes
+        check(lib().infini_rocm_strided_copy(rt.handle, C.c_void_p(x.data_ptr() + off), _ptr(o), outer, rb, src_pitch, rb))
+        outs.append(o)
+        off += rb
+    return outs
+
+
+def slice_(rt: RocmRuntime, x: torch.Tensor, starts: Sequence[int], ends: Sequence[int],
+           axes: Sequence[int] | None = None, steps: Sequence[int] | None = None) -> torch.Tensor:
+    """ONNX Slice with positive steps (src/operators/slice.cc normalises starts/ends)."""
+    rank = x.dim()
+    axes = list(range(len(starts))) if axes is None else [_real_axis(a, rank) for a in axes]
+    steps = [1] * len(starts) if steps is None else list(steps)
+    st, sp, oshape = [0] * rank, [1] * rank, list(x.shape)
+    for a, s, e, k in zip(axes, starts, ends, steps):
+        d = x.shape[a]
+        if k <= 0:
+            raise ValueError("only positive steps are supported")
+        s = min(max(s + d if s < 0 else s, 0), d)
+        e = min(max(e + d if e < 0 else e, 0), d)
+        st[a], sp[a], oshape[a] = s, k, max(0, -(-(e - s) // k))
+    out = torch.empty(oshape, dtype=x.dtype, device=x.device)
+    check(lib().infini_rocm_pad_slice(rt.handle, dtype_of(x), _ptr(x), _ptr(out), rank, _i64arr(list(x.shape)),
+                                      _i64arr(oshape), _i64arr(st), _i64arr(sp), 0))
+    return out
+
+
+def pad(rt: RocmRuntime, x: torch.Tensor, pads: Sequence[int]) -> torch.Tensor:
+    """Constant-0 pad; pads = [begin_0..begin_{r-1}, end_0..end_{r-1}] (include/operators/pad.h)."""
+    rank = x.dim()
+    if len(pads) != 2 * rank:
+        raise ValueError("pads must have 2*rank entries")
+    oshape = [x.shape[d] + pads[d] + pads[d + rank] for d in range(rank)]
+    out = torch.empty(oshape, dtype=x.dtype, device=x.device)
+    check(lib().infini_rocm_pad_slice(rt.handle, dtype_of(x), _ptr(x), _ptr(out), rank, _i64arr(list(x.shape)),
+                                      _i64arr(oshape), _i64arr([-p for p in pads[:rank]]), None, 0))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# Collectives (operators AllReduce{Sum,Prod,Min,Max,Avg}, AllGather, Broadcast, Send, Recv)
+# ------------------------------------------------------------------------------------------------
+_RED = {"sum": 0, "prod": 1, "min": 2, "max": 3, "avg": 4}
+
+
+def all_reduce(rt: RocmRuntime, kind: str, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().infini_rocm_all_reduce(rt.handle, _RED[kind], dtype_of(x), _ptr(x), _ptr(out), x.numel()))
+    return out
+
+
+def all_gather(rt: RocmRuntime, x: torch.Tensor) -> list[torch.Tensor]:
+    world, _ = rt.comm_info()
+    buf = torch.empty((world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+    check(lib().infini_rocm_all_gather(rt.handle, dtype_of(x), _ptr(x), _ptr(buf), x.numel()))
+    return [buf[i] for i in range(world)]
+
+
+def broadcast(rt: RocmRuntime, x: torch.Tensor, root: int, out: torch.Tensor | None = None) -> torch.Tensor:
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().infini_rocm_broadcast(rt.handle, dtype_of(x), _ptr(x), _ptr(out), x.numel(), int(root)))
+    return out
+
+
+def send(rt: RocmRuntime, x: torch.Tensor, peer: int) -> None:
+    check(lib().infini_rocm_send(rt.handle, dtype_of(x), _ptr(x), x.numel(), int(peer)))
+
+
+def recv(rt: RocmRuntime, shape: Sequence[int], dtype: torch.dtype, peer: int, device=None) -> torch.Tensor:
+    out = torch.empty(list(shape), dtype=dtype, device=device or f"cuda:{rt.device}")
+    check(lib().infini_rocm_recv(rt.handle, int(_TORCH2DT[dtype]), _ptr(out), out.numel(), int(peer)))
+    return out

@@ -112,8 +112,12 @@ class RocmRuntime:
         check(lib().infini_rocm_runtime_get_stream(self._h, C.byref(s)))
         return s.value or 0
 
-    def set_stream(self, stream: int | None) -> None:
+    def set_stream(self, stream: int) -> None:
+        """Adopt a native hipStream_t (0 = the legacy default stream)."""
         check(lib().infini_rocm_runtime_set_stream(self._h, C.c_void_p(stream or 0)))
+
+    def use_own_stream(self) -> None:
+        check(lib().infini_rocm_runtime_use_own_stream(self._h))
 
     def use_torch_stream(self) -> None:
         """Launch on torch's current stream so kernels order with torch allocations/copies."""

@@ -147,4 +147,9 @@ def test_matmul_rejects_bad_arguments(rt):
     with pytest.raises(ValueError):
         ops.matmul(rt, a, b)  # K mismatch: reference IT_ASSERT(kA == kB)
     with pytest.raises(TypeError):
-        ops.matmul(rt, a.to(torch.complex64), b.to(torch.complex64))
+        ops.matmul(rt, a.to(torch.complex64), torch.zeros(5, 3, device="cuda", dtype=torch.complex64))
+    from infinitensor_amd import InfiniRocmError, lib
+    import ctypes
+    with pytest.raises(InfiniRocmError):  # the C ABI itself rejects an unsupported dtype, loudly
+        from infinitensor_amd._lib import check
+        check(lib().infini_rocm_matmul(rt.handle, 7, None, None, None, None, 1, 4, 4, 4, 0, 0, 16, 16, 0, 0, 0, 0))

@@ -1,0 +1,131 @@
+"""Data-movement / indexing ops on a real MI355X: bit-exact vs the oracle and the reference KATs."""
+import numpy as np
+import pytest
+import torch
+from conftest import kat
+
+from infinitensor_amd import ops
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+CU = "test/kernels/cuda/"
+NPDT = [np.float32, np.float16, np.int64, np.int32, np.int8, np.uint8, np.float64]
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def rnd(shape, dtype, seed=0):
+    rng = np.random.default_rng(seed)
+    if np.issubdtype(dtype, np.integer):
+        return rng.integers(0, 100, shape).astype(dtype)
+    return rng.standard_normal(shape).astype(dtype)
+
+
+def test_transpose_reference_kat(rt):
+    y = ops.transpose(rt, dev(R.incremental((1, 2, 3, 4))), (0, 2, 1, 3))
+    assert np.array_equal(host(y).ravel(), kat(CU + "test_cuda_transpose.cc", 37, "float"))
+
+
+@pytest.mark.parametrize("dtype", NPDT)
+@pytest.mark.parametrize("shape,perm", [((4, 512, 12, 64), (0, 2, 1, 3)), ((3, 130, 70), (0, 2, 1)), ((65, 33), (1, 0)),
+                                        ((2, 3, 4, 5), (3, 2, 1, 0)), ((2, 3, 4, 5, 6), (4, 0, 3, 1, 2)), ((7,), (0,)),
+                                        ((2, 1, 3, 1, 4), (3, 4, 1, 0, 2)), ((5, 6, 7), (0, 1, 2)), ((2, 3, 2, 3, 2, 3, 2, 3), (7, 6, 5, 4, 3, 2, 1, 0))])
+def test_transpose_bit_exact(rt, shape, perm, dtype):
+    x = rnd(shape, dtype)
+    assert np.array_equal(host(ops.transpose(rt, dev(x), perm)), R.transpose(x, perm))
+
+
+def test_gather_reference_kats(rt):
+    f = CU + "test_cuda_gather.cc"
+    y = ops.gather(rt, dev(kat(f, 184, "float").astype(np.float32).reshape(3, 2)), dev(kat(f, 185, "int").astype(np.int32).reshape(2, 2)), 0)
+    assert np.array_equal(host(y).ravel(), kat(f, 200, "float"))
+    y = ops.gather(rt, dev(R.incremental((3, 3))), dev(kat(f, 209, "int").astype(np.int32).reshape(1, 2)), 1)
+    assert np.array_equal(host(y).ravel(), kat(f, 224, "float"))
+    for idt in (np.int32, np.int64):  # :227-274, int32 and int64 indices
+        y = ops.gather(rt, dev(R.incremental((2, 4, 2))), dev(np.array([0, 3, 1], dtype=idt).reshape(3, 1)), 1)
+        assert np.array_equal(host(y).ravel(), kat(f, 249, "float"))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float16, np.int8, np.int64])
+@pytest.mark.parametrize("idt", [np.int32, np.int64])
+def test_gather_embedding_bit_exact(rt, dtype, idt):
+    table = rnd((3052, 768), dtype, 1)
+    ids = np.random.default_rng(2).integers(-3052, 3052, (4, 128)).astype(idt)  # negative indices wrap
+    y = ops.gather(rt, dev(table), dev(ids), 0)
+    assert np.array_equal(host(y), R.gather(table, ids, 0))
+    x = rnd((3, 7, 5), dtype, 3)
+    ix = np.array([[6, 0], [2, -1]], dtype=idt)
+    assert np.array_equal(host(ops.gather(rt, dev(x), dev(ix), 1)), R.gather(x, ix, 1))
+
+
+def test_where_reference_kats(rt):
+    f = CU + "test_cuda_where.cc"
+    y = ops.where(rt, dev(kat(f, 88, "float").astype(np.float32).reshape(2, 2, 3, 1)), dev(kat(f, 89, "float").astype(np.float32).reshape(2, 2, 3, 1)),
+                  dev(kat(f, 90, "uint8_t").astype(np.uint8).reshape(2, 2, 3, 1)))
+    assert np.array_equal(host(y).ravel(), kat(f, 91, "float"))
+    # :93-101 three-way broadcast
+    x = np.array([0, 1, 2, 3, 4, 5], np.float32).reshape(2, 1, 1, 3)
+    yv = np.ones((1, 2, 1, 1), np.float32)
+    c = np.array([0, 1, 1, 0, 0, 0], np.uint8).reshape(2, 1, 3, 1)
+    got = host(ops.where(rt, dev(x), dev(yv), dev(c)))
+    assert np.array_equal(got, R.where(x, yv, c))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float16, np.int64])
+def test_where_mask_bit_exact(rt, dtype):
+    x, y = rnd((4, 12, 32, 32), dtype, 5), rnd((1,), dtype, 6)
+    c = (np.random.default_rng(7).random((4, 1, 1, 32)) > 0.5)
+    assert np.array_equal(host(ops.where(rt, dev(x), dev(y), dev(c))), R.where(x, y, c))
+
+
+def test_concat_split_slice_pad_expand_reference_kats(rt):
+    t1 = R.incremental((2, 2, 3, 1))
+    y = ops.concat(rt, [dev(t1), dev(R.ones((2, 2, 1, 1))), dev(R.ones((2, 2, 2, 1)))], 2)
+    assert np.array_equal(host(y).ravel(), kat(CU + "test_cuda_concat.cc", 93, "float"))
+    outs = ops.split(rt, dev(R.incremental((2, 10, 2, 1))), 1, [3, 3, 4])
+    for o, line in zip(outs, (35, 37, 38)):
+        assert np.array_equal(host(o).ravel(), kat(CU + "test_cuda_split.cc", line, "float"))
+    y = ops.slice_(rt, dev(R.incremental((3, 2, 1, 5))), [1, 1], [2, 5], [0, 3])
+    assert np.array_equal(host(y).ravel(), kat(CU + "test_cuda_slice.cc", 38, "float"))
+    y = ops.pad(rt, dev(R.incremental((1, 2, 3, 2))), [1, 0, 0, 0, 1, 0, 0, 1])
+    assert np.array_equal(host(y).ravel(), kat(CU + "test_cuda_pad.cc", 36, "float"))
+    y = ops.expand(rt, dev(R.incremental((2, 1, 2, 1))), (2, 2, 2, 3))
+    assert np.array_equal(host(y).ravel(), kat(CU + "test_cuda_expand.cc", 37, "float"))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float16, np.int8, np.int64])
+def test_concat_split_roundtrip(rt, dtype):
+    """split(concat(xs)) == xs, any axis (size-independent property), ragged sizes incl. an empty part."""
+    xs = [rnd((3, n, 5, 2), dtype, n) for n in (4, 1, 0, 7)]
+    cat = ops.concat(rt, [dev(x) for x in xs], 1)
+    assert np.array_equal(host(cat), R.concat(xs, 1))
+    back = ops.split(rt, cat, 1, [4, 1, 0, 7])
+    for b, x in zip(back, xs):
+        assert np.array_equal(host(b), x)
+    xs = [rnd((2, 3, n), dtype, n) for n in (3, 5)]
+    assert np.array_equal(host(ops.concat(rt, [dev(x) for x in xs], -1)), R.concat(xs, 2))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float16, np.int64])
+def test_slice_pad_bit_exact(rt, dtype):
+    x = rnd((4, 6, 7, 9), dtype, 11)
+    y = ops.slice_(rt, dev(x), [1, 2, -5], [3, 7, 100], [0, 2, 3], [1, 2, 3])
+    assert np.array_equal(host(y), R.slice_(x, [1, 2, -5], [3, 7, 100], [0, 2, 3], [1, 2, 3]))
+    p = [0, 1, 2, 0, 3, 0, 1, 4]
+    assert np.array_equal(host(ops.pad(rt, dev(x), p)), R.pad(x, p))
+    # pad then slice back is the identity
+    z = ops.slice_(rt, ops.pad(rt, dev(x), p), [0, 1, 2, 0], [4, 7, 9, 9])
+    assert np.array_equal(host(z), x)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float16, np.int32])
+def test_expand_reshape_bit_exact(rt, dtype):
+    x = rnd((3, 1, 5), dtype, 13)
+    assert np.array_equal(host(ops.expand(rt, dev(x), (2, 3, 4, 5))), R.expand(x, (2, 3, 4, 5)))
+    assert np.array_equal(host(ops.reshape(rt, dev(x), (5, 3))), x.reshape(5, 3))

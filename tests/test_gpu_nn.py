@@ -1,0 +1,160 @@
+"""Conv2d / Reduce / BatchNorm / Pool parity on a real MI355X vs the oracle and the reference KATs."""
+import numpy as np
+import pytest
+import torch
+from conftest import kat
+
+from infinitensor_amd import ops
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+CU = "test/kernels/cuda/"
+TD = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return (t.to(dtype) if dtype is not None else t).cuda()
+
+
+def host(t):
+    return t.float().cpu().numpy().astype(np.float64)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16"])
+@pytest.mark.parametrize("g,line", [(R.ones, 50), (R.incremental, 53)])
+def test_conv_reference_kats(rt, g, line, dt):
+    """test_cuda_conv.cc:48-54 (fp32) and test_cuda_conv_fp16.cc:50-53 (fp16, ones)."""
+    if dt == "f16" and g is R.incremental:
+        pytest.skip("the reference fp16 KAT uses the all-ones generator only (values up to 20835 overflow fp16 ulp)")
+    y = ops.conv2d(rt, dev(g((1, 3, 4, 4)), TD[dt]), dev(g((2, 3, 3, 3)), TD[dt]), 1, 1, 2, 1, 1, 2)
+    assert tuple(y.shape) == (1, 2, 2, 2)
+    want = kat(CU + "test_cuda_conv.cc", line, "float") if dt == "f32" else kat(CU + "test_cuda_conv_fp16.cc", 52, "float")
+    assert R.equal_data(host(y).ravel(), want, 1e-6)
+
+
+CONVS = [
+    # n, c, h, w, f, cpg, r, s, ph, pw, sh, sw, dh, dw
+    (2, 64, 56, 56, 64, 64, 1, 1, 0, 0, 1, 1, 1, 1),     # ResNet 1x1 (GEMM route)
+    (2, 64, 28, 28, 128, 64, 3, 3, 1, 1, 1, 1, 1, 1),    # ResNet 3x3
+    (2, 3, 64, 64, 64, 3, 7, 7, 3, 3, 2, 2, 1, 1),       # stem 7x7/2 (K = 147, ragged)
+    (2, 128, 14, 14, 256, 128, 1, 1, 0, 0, 1, 1, 1, 1),  # 1x1 on 14x14 (196 pixels, not 16-B rows)
+    (1, 256, 14, 14, 128, 256, 1, 1, 0, 0, 2, 2, 1, 1),  # strided 1x1 (downsample)
+    (3, 32, 9, 11, 48, 8, 3, 2, 2, 0, 2, 1, 1, 2),       # groups = 4, asymmetric everything
+    (1, 16, 7, 7, 24, 16, 3, 3, 1, 1, 1, 1, 1, 1),       # 7x7 plane
+    (1, 512, 7, 7, 130, 512, 3, 3, 1, 1, 1, 1, 1, 1),    # ragged filter count
+]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv_vs_oracle(rt, cfg, dt):
+    n, c, h, w, f, cpg, r, s, ph, pw, sh, sw, dh, dw = cfg
+    rng = np.random.default_rng(abs(hash(cfg)) % 2 ** 32)
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((f, cpg, r, s)) / np.sqrt(cpg * r * s)).astype(np.float32)
+    y = ops.conv2d(rt, dev(x, TD[dt]), dev(wt, TD[dt]), ph, pw, sh, sw, dh, dw)
+    want = R.conv2d(R.round_to(x, dt), R.round_to(wt, dt), ph, pw, sh, sw, dh, dw)
+    assert tuple(y.shape) == want.shape
+    tol = {"f32": 1e-4, "f16": 2e-3, "bf16": 1.6e-2}[dt]
+    assert np.allclose(host(y), want, rtol=tol, atol=tol)
+
+
+def test_conv_fused_bias_relu_equals_unfused_chain(rt):
+    """Fusion must be invisible: conv(bias, relu) == relu(conv + bias) computed op by op."""
+    rng = np.random.default_rng(4)
+    x = dev(rng.standard_normal((2, 32, 20, 20)).astype(np.float32), torch.float16)
+    w = dev((rng.standard_normal((64, 32, 3, 3)) / 17).astype(np.float32), torch.float16)
+    b = dev(rng.standard_normal((64,)).astype(np.float32), torch.float16)
+    fused = ops.conv2d(rt, x, w, 1, 1, bias=b, act=1)
+    y = ops.conv2d(rt, x, w, 1, 1)
+    y = ops.binary(rt, "add", y, b.reshape(1, 64, 1, 1).contiguous())
+    y = ops.unary(rt, "relu", y)
+    # the unfused chain rounds to fp16 after the conv and after the add; the fused kernel rounds once
+    assert np.allclose(host(fused), host(y), rtol=2e-3, atol=2e-3)
+
+
+def _reduce_cases():
+    import json
+    from conftest import REPO
+
+    recs = json.loads((REPO / "tests/golden/kats.json").read_text())[CU + "test_cuda_reduce.cc"]
+    cases, i = [], 0
+    while i < len(recs):
+        shape, x = recs[i]["values"], recs[i + 1]["values"]
+        if recs[i + 2]["kind"] == "int":
+            axes, want = recs[i + 2]["values"], recs[i + 3]["values"]
+            i += 4
+        else:
+            axes, want = None, recs[i + 2]["values"]
+            i += 3
+        cases.append((shape, x, axes, want))
+    return cases
+
+
+def test_reduce_reference_kats(rt):
+    """test_cuda_reduce.cc:42-75 (keepdims alternates true/false; data identical)."""
+    for n, (shape, x, axes, want) in enumerate(_reduce_cases()):
+        kind = "mean" if n < 4 else "sum"
+        y = ops.reduce(rt, kind, dev(np.array(x, dtype=np.float32).reshape(shape)), axes, keepdims=bool(n % 2 == 0))
+        assert R.equal_data(host(y).ravel(), np.array(want, dtype=np.float64), 1e-6), (n, kind)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("shape,axes", [((4, 512, 768), [2]), ((3, 5, 7, 9), [1, 3]), ((6, 40), [0]), ((2, 3, 4, 5), None),
+                                        ((8, 2048, 7, 7), [2, 3]), ((5, 1, 6), [0, 1]), ((3, 1000), [-1])])
+def test_reduce_vs_oracle(rt, shape, axes, dt):
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal(shape).astype(np.float32)
+    for kind in ("sum", "mean"):
+        y = ops.reduce(rt, kind, dev(x, TD[dt]), axes, keepdims=True)
+        want = R.reduce(kind, R.round_to(x, dt), axes or [], True)
+        tol = {"f32": 1e-4, "f16": 2e-3, "bf16": 1.6e-2}[dt]
+        assert y.shape == want.shape
+        assert np.allclose(host(y), want, rtol=tol, atol=tol * max(1.0, np.sqrt(x.size / want.size)))
+
+
+def test_batchnorm_reference_kat(rt):
+    f = CU + "test_cuda_batch_norm.cc"
+    y = ops.batch_norm(rt, dev(R.incremental((1, 3, 2, 2))), dev(kat(f, 25, "float").astype(np.float32)),
+                       dev(kat(f, 26, "float").astype(np.float32)), dev(R.ones((3,))), dev(np.zeros(3, np.float32)), 0.0)
+    assert R.equal_data(host(y).ravel(), kat(f, 51, "float"), 2e-6)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("shape", [(4, 64, 56, 56), (2, 3, 5, 7), (3, 10), (2, 7, 9)])
+def test_batchnorm_vs_oracle(rt, shape, dt):
+    rng = np.random.default_rng(23)
+    c = shape[1]
+    x = rng.standard_normal(shape).astype(np.float32)
+    m, v = rng.standard_normal(c).astype(np.float32), rng.uniform(0.5, 2, c).astype(np.float32)
+    s, b = rng.standard_normal(c).astype(np.float32), rng.standard_normal(c).astype(np.float32)
+    y = ops.batch_norm(rt, dev(x, TD[dt]), dev(m), dev(v), dev(s), dev(b), 1e-5)
+    want = R.batch_norm(R.round_to(x, dt), m, v, s, b, 1e-5)
+    tol = {"f32": 1e-4, "f16": 2e-3, "bf16": 1.6e-2}[dt]
+    assert np.allclose(host(y), want, rtol=tol, atol=tol)
+
+
+def test_pooling_reference_kats(rt):
+    f = CU + "test_cuda_pooling.cc"
+    x = dev(R.incremental((1, 2, 5, 5)))
+    assert R.equal_data(host(ops.max_pool(rt, x, 3, 3, 1, 1, 1, 1, 2, 2)).ravel(), kat(f, 48, "float"), 1e-6)
+    assert R.equal_data(host(ops.avg_pool(rt, x, 3, 3, 1, 1, 1, 1, 2, 2)).ravel(), kat(f, 55, "float"), 2e-6)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16"])
+@pytest.mark.parametrize("cfg", [((2, 64, 112, 112), 3, 3, 1, 1, 1, 1, 2, 2, 0), ((2, 2048, 7, 7), 7, 7, 1, 1, 0, 0, 1, 1, 0),
+                                 ((1, 3, 10, 9), 2, 3, 2, 1, 1, 0, 1, 2, 1), ((2, 5, 8), 1, 3, 1, 1, 0, 1, 1, 2, 0)])
+def test_pooling_vs_oracle(rt, cfg, dt):
+    shape, kh, kw, dh, dw, ph, pw, sh, sw, ceil = cfg
+    rng = np.random.default_rng(29)
+    x = rng.standard_normal(shape).astype(np.float32)
+    x4 = x if x.ndim == 4 else x[:, :, None, :]
+    for kind, fn in (("max", ops.max_pool), ("avg", ops.avg_pool)):
+        y = fn(rt, dev(x, TD[dt]), kh, kw, dh, dw, ph, pw, sh, sw, ceil)
+        want = R.pool2d(R.round_to(x4, dt), kind, kh, kw, dh, dw, ph, pw, sh, sw, ceil)
+        if x.ndim == 3:
+            want = want[:, :, 0, :]
+        assert tuple(y.shape) == want.shape, kind
+        tol = {"f32": 1e-5, "f16": 2e-3}[dt]
+        assert np.allclose(host(y), want, rtol=tol, atol=tol), kind

@@ -1,0 +1,143 @@
+"""Pin the oracle for Conv / Reduce / BatchNorm / Pool and the data-movement ops against the reference's
+golden vectors (tests/golden/kats.json) and, where implemented, its native-CPU backend (oracle/_ref)."""
+import numpy as np
+import pytest
+from conftest import kat
+
+from oracle import ref_ops as R
+
+CU = "test/kernels/cuda/"
+
+
+def eq(a, b, rel=1e-6):
+    return R.equal_data(np.asarray(a, dtype=np.float64).ravel(), np.asarray(b, dtype=np.float64).ravel(), rel)
+
+
+# Conv: test_cuda_conv.cc:12-54 — x [1,3,4,4], w [2,3,3,3], ph=pw=1, sh=2, sw=1, dh=1, dw=2
+@pytest.mark.parametrize("g,line", [(R.ones, 50), (R.incremental, 53)])
+def test_conv_kats(g, line):
+    y = R.conv2d(g((1, 3, 4, 4)), g((2, 3, 3, 3)), 1, 1, 2, 1, 1, 2)
+    assert y.shape == (1, 2, 2, 2)
+    assert eq(y, kat(CU + "test_cuda_conv.cc", line, "float"))
+    assert np.array_equal(kat(CU + "test_cuda_conv.cc", line, "float"),
+                          kat("test/kernels/intelcpu/test_mkl_conv.cc", {50: 33, 53: 36}[line], "float"))
+
+
+def test_conv_vs_reference_native_cpu(ref_backend):
+    """NaiveConv (src/kernels/cpu/conv.cc:8-52) incl. groups, stride, dilation, padding."""
+    rng = np.random.default_rng(0)
+    for (n, c, h, w, f, cpg, r, s, ph, pw, sh, sw, dh, dw) in [
+        (2, 4, 9, 8, 6, 4, 3, 3, 1, 1, 1, 1, 1, 1), (1, 6, 10, 10, 4, 3, 3, 2, 2, 0, 2, 1, 1, 2),
+        (2, 3, 12, 12, 8, 3, 7, 7, 3, 3, 2, 2, 1, 1), (1, 8, 5, 5, 8, 8, 1, 1, 0, 0, 1, 1, 1, 1)]:
+        x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+        wt = rng.standard_normal((f, cpg, r, s)).astype(np.float32)
+        hd = ref_backend.GraphHandler(ref_backend.cpu_runtime())
+        tx, tw = hd.tensor([n, c, h, w], 1), hd.tensor([f, cpg, r, s], 1)
+        ty = hd.conv(tx, tw, None, ph, pw, sh, sw, dh, dw)
+        hd.data_malloc()
+        tx.copyin_numpy(x)
+        tw.copyin_numpy(wt)
+        hd.run()
+        want = R.conv2d(x, wt, ph, pw, sh, sw, dh, dw)
+        got = np.array(ty.copyout_float()).reshape(want.shape)
+        assert np.allclose(got, want, rtol=1e-4, atol=1e-4)
+
+
+# Reduce: test_cuda_reduce.cc:42-75
+RF = CU + "test_cuda_reduce.cc"
+
+
+def _reduce_cases():
+    import json
+    from conftest import REPO
+
+    recs = json.loads((REPO / "tests/golden/kats.json").read_text())[RF]
+    # literals come in groups: shape, input, [axes], expected
+    cases, i = [], 0
+    while i < len(recs):
+        assert recs[i]["kind"] == "shape"
+        shape, x = recs[i]["values"], recs[i + 1]["values"]
+        if recs[i + 2]["kind"] == "int":
+            axes, want = recs[i + 2]["values"], recs[i + 3]["values"]
+            i += 4
+        else:
+            axes, want = None, recs[i + 2]["values"]
+            i += 3
+        cases.append((shape, x, axes, want, recs[i - 1]["line"]))
+    return cases
+
+
+def test_reduce_kats():
+    cases = _reduce_cases()
+    assert len(cases) == 8
+    for n, (shape, x, axes, want, line) in enumerate(cases):
+        kind = "mean" if n < 4 else "sum"  # CUDA_ReduceMean then CUDA_ReduceSum
+        y = R.reduce(kind, np.array(x, dtype=np.float32).reshape(shape), axes or [], True)
+        assert eq(y, want), (line, kind)
+
+
+# BatchNorm: test_cuda_batch_norm.cc:10-53 (eps = 0)
+def test_batchnorm_kat():
+    f = CU + "test_cuda_batch_norm.cc"
+    y = R.batch_norm(R.incremental((1, 3, 2, 2)), kat(f, 25, "float"), kat(f, 26, "float"), np.ones(3), np.zeros(3), 0.0)
+    assert eq(y, kat(f, 51, "float"), 2e-6)
+
+
+# Pooling: test_cuda_pooling.cc:45-60, KDPS{3,3,1,1,1,1,2,2} = kh,kw,dh,dw,ph,pw,sh,sw
+def test_pooling_kats():
+    f = CU + "test_cuda_pooling.cc"
+    x = R.incremental((1, 2, 5, 5))
+    assert eq(R.pool2d(x, "max", 3, 3, 1, 1, 1, 1, 2, 2), kat(f, 48, "float"))
+    assert eq(R.pool2d(x, "avg", 3, 3, 1, 1, 1, 1, 2, 2), kat(f, 55, "float"), 2e-6)
+
+
+def test_pooling_vs_reference_native_cpu(ref_backend):
+    rng = np.random.default_rng(1)
+    # positive inputs: the native-CPU MaxPool starts from maxval = 0 (src/kernels/cpu/pooling.cc:9), a quirk
+    # (negative windows clamp to 0) that is NOT part of the op definition and is not replicated.
+    x = np.abs(rng.standard_normal((2, 3, 9, 7))).astype(np.float32) + 0.1
+    for kind, fn in (("max", "maxPool"), ("avg", "avgPool")):
+        hd = ref_backend.GraphHandler(ref_backend.cpu_runtime())
+        tx = hd.tensor(list(x.shape), 1)
+        ty = getattr(hd, fn)(tx, None, 3, 2, 1, 1, 1, 0, 2, 1, 0)
+        hd.data_malloc()
+        tx.copyin_numpy(x)
+        hd.run()
+        want = R.pool2d(x, kind, 3, 2, 1, 1, 1, 0, 2, 1)
+        got = np.array(ty.copyout_float()).reshape(want.shape)
+        assert np.allclose(got, want, rtol=1e-6), kind  # avg: both divide by kh*kw (padding counted)
+
+
+# Data movement
+def test_transpose_kat():
+    want = kat(CU + "test_cuda_transpose.cc", 37, "float")
+    assert np.array_equal(R.transpose(R.incremental((1, 2, 3, 4)), (0, 2, 1, 3)).ravel(), want)
+    assert np.array_equal(kat("test/kernels/nativecpu/test_nativecpu_transpose.cc", 23, "float"), want)
+
+
+def test_gather_kats():
+    f = CU + "test_cuda_gather.cc"
+    assert np.array_equal(R.gather(kat(f, 184, "float").reshape(3, 2), kat(f, 185, "int").reshape(2, 2), 0).ravel(), kat(f, 200, "float"))
+    assert np.array_equal(R.gather(R.incremental((3, 3)), kat(f, 209, "int").reshape(1, 2), 1).ravel(), kat(f, 224, "float"))
+    assert np.array_equal(R.gather(R.incremental((2, 4, 2)), np.array([0, 3, 1]).reshape(3, 1), 1).ravel(), kat(f, 249, "float"))
+
+
+def test_where_kats():
+    f = CU + "test_cuda_where.cc"
+    y = R.where(kat(f, 88, "float").reshape(2, 2, 3, 1), kat(f, 89, "float").reshape(2, 2, 3, 1), kat(f, 90, "uint8_t").reshape(2, 2, 3, 1))
+    assert np.array_equal(y.ravel(), kat(f, 91, "float"))
+
+
+def test_concat_split_slice_pad_expand_kats():
+    t1, one = R.incremental((2, 2, 3, 1)), R.ones
+    y = R.concat([t1, one((2, 2, 1, 1)), one((2, 2, 2, 1))], 2)
+    assert np.array_equal(y.ravel(), kat(CU + "test_cuda_concat.cc", 93, "float"))
+    outs = R.split(R.incremental((2, 10, 2, 1)), 1, [3, 3, 4])
+    for o, line in zip(outs, (35, 37, 38)):
+        assert np.array_equal(o.ravel(), kat(CU + "test_cuda_split.cc", line, "float"))
+    y = R.slice_(R.incremental((3, 2, 1, 5)), [1, 1], [2, 5], [0, 3])
+    assert np.array_equal(y.ravel(), kat(CU + "test_cuda_slice.cc", 38, "float"))
+    y = R.pad(R.incremental((1, 2, 3, 2)), [1, 0, 0, 0, 1, 0, 0, 1])  # axes {0,3}: begin (1,0), end (1,1)
+    assert np.array_equal(y.ravel(), kat(CU + "test_cuda_pad.cc", 36, "float"))
+    y = R.expand(R.incremental((2, 1, 2, 1)), (2, 2, 2, 3))
+    assert np.array_equal(y.ravel(), kat(CU + "test_cuda_expand.cc", 37, "float"))
