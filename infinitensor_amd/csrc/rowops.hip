@@ -52,61 +52,70 @@ __device__ inline float wave_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Contiguous rows (inner == 1). One wave per row; CHUNKS 16-byte chunks per lane.
-// Handles any dimsize <= 64 * VEC * CHUNKS; vector loads when the row base is 16-B aligned,
-// otherwise element loads (same register image).
+// Contiguous rows (inner == 1). One wave handles ROWS rows; a row is CHUNKS 16-byte chunks per lane,
+// kept PACKED in registers (storage dtype) and converted on the fly in every pass: for 16-bit types
+// this halves the register footprint, which is what buys the occupancy (bytes in flight) the HBM
+// pipe needs. Handles any dimsize <= 64 * VEC * CHUNKS. ALIGNED: row bases 16-B aligned and
+// dimsize % VEC == 0 (pure vector loads); otherwise element loads into the same register image.
 // ------------------------------------------------------------------------------------------------
+template <typename T, int CHUNKS> struct RowRegs {
+    Pack<T, Elem<T>::VEC> c[CHUNKS];
+};
+
 template <typename T, int CHUNKS, bool ALIGNED>
-__device__ inline void load_row(const T *row, int n, int lane, float (&x)[CHUNKS * Elem<T>::VEC], float fill) {
+__device__ inline void load_row(const T *row, int n, int lane, RowRegs<T, CHUNKS> &r, float fill) {
     constexpr int VEC = Elem<T>::VEC;
 #pragma unroll
     for (int c = 0; c < CHUNKS; ++c) {
         const int base = (c * 64 + lane) * VEC;
-        if (ALIGNED && base + VEC <= n) {
-            Pack<T, VEC> pk = *reinterpret_cast<const Pack<T, VEC> *>(row + base);
+        if (ALIGNED) {
+            if (base < n) {
+                r.c[c] = *reinterpret_cast<const Pack<T, VEC> *>(row + base);
+            } else {
 #pragma unroll
-            for (int j = 0; j < VEC; ++j)
-                x[c * VEC + j] = Elem<T>::ld(&pk.v[j]);
+                for (int j = 0; j < VEC; ++j)
+                    Elem<T>::st(&r.c[c].v[j], fill);
+            }
         } else {
 #pragma unroll
-            for (int j = 0; j < VEC; ++j)
-                x[c * VEC + j] = (base + j < n) ? Elem<T>::ld(row + base + j) : fill;
+            for (int j = 0; j < VEC; ++j) {
+                if (base + j < n)
+                    r.c[c].v[j] = row[base + j];
+                else
+                    Elem<T>::st(&r.c[c].v[j], fill);
+            }
         }
     }
 }
 
 template <typename T, int CHUNKS, bool ALIGNED>
-__device__ inline void store_row(T *row, int n, int lane, const float (&y)[CHUNKS * Elem<T>::VEC]) {
+__device__ inline void store_row(T *row, int n, int lane, const RowRegs<T, CHUNKS> &r) {
     constexpr int VEC = Elem<T>::VEC;
 #pragma unroll
     for (int c = 0; c < CHUNKS; ++c) {
         const int base = (c * 64 + lane) * VEC;
-        if (ALIGNED && base + VEC <= n) {
-            Pack<T, VEC> pk;
-#pragma unroll
-            for (int j = 0; j < VEC; ++j)
-                Elem<T>::st(&pk.v[j], y[c * VEC + j]);
-            *reinterpret_cast<Pack<T, VEC> *>(row + base) = pk;
+        if (ALIGNED) {
+            if (base < n)
+                *reinterpret_cast<Pack<T, VEC> *>(row + base) = r.c[c];
         } else {
 #pragma unroll
             for (int j = 0; j < VEC; ++j)
                 if (base + j < n)
-                    Elem<T>::st(row + base + j, y[c * VEC + j]);
+                    row[base + j] = r.c[c].v[j];
         }
     }
 }
 
-// ROWS rows per wave: all loads of the wave's rows are issued before any arithmetic, so a wave keeps
-// ROWS * row_bytes (~4 KiB) in flight — 16-bit rows of <= 1 KiB are latency-bound at one row per wave.
+// ROWS rows per wave: all loads of the wave's rows are issued before any arithmetic.
 template <typename T, int CHUNKS, bool ALIGNED, int ROWS>
 __global__ __launch_bounds__(256) void softmax_wave_kernel(const T *__restrict__ x, T *__restrict__ y,
                                                            long rows, int n) {
-    constexpr int NV = CHUNKS * Elem<T>::VEC;
+    constexpr int VEC = Elem<T>::VEC;
     const int lane = threadIdx.x & 63;
     const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
     if (row0 >= rows)
         return;
-    float v[ROWS][NV];
+    RowRegs<T, CHUNKS> v[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         const long row = row0 + r < rows ? row0 + r : rows - 1; // tail rows recompute the last row
@@ -114,22 +123,31 @@ __global__ __launch_bounds__(256) void softmax_wave_kernel(const T *__restrict__
     }
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
-        float m = v[r][0];
+        float m = -INFINITY;
 #pragma unroll
-        for (int i = 1; i < NV; ++i)
-            m = fmaxf(m, v[r][i]);
+        for (int c = 0; c < CHUNKS; ++c)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                m = fmaxf(m, Elem<T>::ld(&v[r].c[c].v[j]));
         m = wave_max(m);
+        float e[CHUNKS * VEC];
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            v[r][i] = sizeof(T) == 4 ? expf(v[r][i] - m) : __expf(v[r][i] - m);
-            s += v[r][i];
-        }
+        for (int c = 0; c < CHUNKS; ++c)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float d = Elem<T>::ld(&v[r].c[c].v[j]) - m;
+                const float ev = sizeof(T) == 4 ? expf(d) : __expf(d);
+                e[c * VEC + j] = ev;
+                s += ev;
+            }
         s = wave_sum(s);
         const float inv = 1.0f / s;
 #pragma unroll
-        for (int i = 0; i < NV; ++i)
-            v[r][i] *= inv;
+        for (int c = 0; c < CHUNKS; ++c)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                Elem<T>::st(&v[r].c[c].v[j], e[c * VEC + j] * inv);
         if (row0 + r < rows)
             store_row<T, CHUNKS, ALIGNED>(y + (row0 + r) * n, n, lane, v[r]);
     }
@@ -206,49 +224,40 @@ __global__ __launch_bounds__(256) void norm_wave_kernel(const T *__restrict__ x,
                                                         long rows, int n, int scale_size, int bias_size,
                                                         float eps) {
     constexpr int VEC = Elem<T>::VEC;
-    constexpr int NV = CHUNKS * VEC;
     const int lane = threadIdx.x & 63;
     const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
     if (row0 >= rows)
         return;
-    float v[ROWS][NV];
+    RowRegs<T, CHUNKS> v[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         const long row = row0 + r < rows ? row0 + r : rows - 1;
         load_row<T, CHUNKS, ALIGNED>(x + row * n, n, lane, v[r], 0.f);
     }
-    // scale / bias: per-element (size n) or scalar (size 1); shared by the wave's rows
-    float sc[NV], bs[NV];
-    if (scale_size == 1) {
-        const float s0 = Elem<T>::ld(scale);
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-            sc[i] = s0;
-    } else {
+    // scale / bias: per-element (size n) or scalar (size 1); shared by the wave's rows, kept packed
+    RowRegs<T, CHUNKS> sc, bs;
+    float s0 = 1.f, b0 = 0.f;
+    const bool sc_vec = scale_size != 1, bs_vec = bias != nullptr && bias_size != 1;
+    if (sc_vec)
         load_row<T, CHUNKS, ALIGNED>(scale, n, lane, sc, 0.f);
-    }
-    if (bias == nullptr) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-            bs[i] = 0.f;
-    } else if (bias_size == 1) {
-        const float b0 = Elem<T>::ld(bias);
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-            bs[i] = b0;
-    } else {
+    else
+        s0 = Elem<T>::ld(scale);
+    if (bs_vec)
         load_row<T, CHUNKS, ALIGNED>(bias, n, lane, bs, 0.f);
-    }
-    const float inv_n = 1.0f / (float)n;
+    else if (bias != nullptr)
+        b0 = Elem<T>::ld(bias);
+    const float fn = (float)n;
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         float mu = 0.f;
         if (!RMS) {
             float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < NV; ++i)
-                s += v[r][i];
-            mu = wave_sum(s) * inv_n;
+            for (int c = 0; c < CHUNKS; ++c)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+                    s += Elem<T>::ld(&v[r].c[c].v[j]); // padding lanes hold 0
+            mu = wave_sum(s) / fn; // correctly rounded division: integer-valued rows give exact means
         }
         float q = 0.f;
 #pragma unroll
@@ -256,13 +265,18 @@ __global__ __launch_bounds__(256) void norm_wave_kernel(const T *__restrict__ x,
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 const int col = (c * 64 + lane) * VEC + j;
-                const float d = (col < n) ? v[r][c * VEC + j] - mu : 0.f;
+                const float d = (col < n) ? Elem<T>::ld(&v[r].c[c].v[j]) - mu : 0.f;
                 q += d * d;
             }
-        const float rstd = rsqrtf(wave_sum(q) * inv_n + eps);
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / fn + eps);
 #pragma unroll
-        for (int i = 0; i < NV; ++i)
-            v[r][i] = (v[r][i] - mu) * rstd * sc[i] + bs[i];
+        for (int c = 0; c < CHUNKS; ++c)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float g = sc_vec ? Elem<T>::ld(&sc.c[c].v[j]) : s0;
+                const float b = bs_vec ? Elem<T>::ld(&bs.c[c].v[j]) : b0;
+                Elem<T>::st(&v[r].c[c].v[j], (Elem<T>::ld(&v[r].c[c].v[j]) - mu) * rstd * g + b);
+            }
         if (row0 + r < rows)
             store_row<T, CHUNKS, ALIGNED>(y + (row0 + r) * n, n, lane, v[r]);
     }
@@ -300,7 +314,7 @@ __global__ __launch_bounds__(256) void norm_block_kernel(const T *__restrict__ x
         if (lane == 0)
             red[w] = q;
         __syncthreads();
-        const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)n + eps);
+        const float rstd = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)n + eps);
         __syncthreads();
         for (long i = t; i < n; i += 256) {
             const float s = Elem<T>::ld(scale + (scale_size == 1 ? 0 : i));
@@ -322,7 +336,7 @@ static int softmax_dispatch(infiniRocmRuntime_t rt, const T *x, T *y, int64_t ou
         const int chunks = (int)ceil_div(dimsize, per_chunk);
         // rows per wave: keep ~4 KiB of loads in flight per wave
         const int64_t row_bytes = dimsize * (int64_t)sizeof(T);
-        const int rpw = (!al || outer < 4096) ? 1 : (row_bytes <= 1024 ? 4 : (row_bytes <= 2048 ? 2 : 1));
+        const int rpw = (!al || outer < 4096) ? 1 : (row_bytes <= 1024 ? 4 : (row_bytes <= 3072 ? 2 : 1));
 #define SM_GO(C, A, R)                                                                             \
     hipLaunchKernelGGL((softmax_wave_kernel<T, C, A, R>), dim3((unsigned)ceil_div(outer, 4 * R)),  \
                        dim3(256), 0, rt->stream, x, y, (long)outer, (int)dimsize)
@@ -364,7 +378,7 @@ static int norm_dispatch(infiniRocmRuntime_t rt, const T *x, const T *scale, con
                     (bias == nullptr || is_aligned16(bias)) && (n % VEC == 0);
     const int chunks = (int)ceil_div(n, (int64_t)64 * VEC);
     const int64_t row_bytes = n * (int64_t)sizeof(T);
-    const int rpw = (!al || outer < 4096) ? 1 : (row_bytes <= 1024 ? 4 : (row_bytes <= 2048 ? 2 : 1));
+    const int rpw = (!al || outer < 4096) ? 1 : (row_bytes <= 1024 ? 4 : (row_bytes <= 3072 ? 2 : 1));
 #define NORM_GO(C, A, R)                                                                           \
     hipLaunchKernelGGL((norm_wave_kernel<T, C, A, RMS, R>), dim3((unsigned)ceil_div(outer, 4 * R)), \
                        dim3(256), 0, rt->stream, x, scale, bias, y, (long)outer, (int)n,           \

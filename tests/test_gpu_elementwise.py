@@ -50,7 +50,7 @@ BCAST = [
     ((7, 1, 5), (1, 6, 1)),               # both broadcast
     ((2, 3, 4, 5, 6), (2, 3, 4, 5, 6)),   # same shape, rank 5
     ((1023,), (1023,)),                   # odd length (vector tail)
-    ((2, 3, 1, 2, 1, 2, 1, 3), (3, 1, 3, 1, 2, 1, 4, 1)),  # rank 8
+    ((2, 3, 1, 2, 1, 2, 1, 3), (1, 1, 3, 1, 2, 1, 4, 1)),  # rank 8
 ]
 
 

@@ -21,16 +21,20 @@ def host(t):
     return t.float().cpu().numpy().astype(np.float64)
 
 
-@pytest.mark.parametrize("dt", ["f32", "f16"])
 @pytest.mark.parametrize("g,line", [(R.ones, 50), (R.incremental, 53)])
-def test_conv_reference_kats(rt, g, line, dt):
-    """test_cuda_conv.cc:48-54 (fp32) and test_cuda_conv_fp16.cc:50-53 (fp16, ones)."""
-    if dt == "f16" and g is R.incremental:
-        pytest.skip("the reference fp16 KAT uses the all-ones generator only (values up to 20835 overflow fp16 ulp)")
-    y = ops.conv2d(rt, dev(g((1, 3, 4, 4)), TD[dt]), dev(g((2, 3, 3, 3)), TD[dt]), 1, 1, 2, 1, 1, 2)
+def test_conv_reference_kats_fp32(rt, g, line):
+    """test_cuda_conv.cc:48-54 (== test_mkl_conv.cc:32-37)."""
+    y = ops.conv2d(rt, dev(g((1, 3, 4, 4))), dev(g((2, 3, 3, 3))), 1, 1, 2, 1, 1, 2)
     assert tuple(y.shape) == (1, 2, 2, 2)
-    want = kat(CU + "test_cuda_conv.cc", line, "float") if dt == "f32" else kat(CU + "test_cuda_conv_fp16.cc", 52, "float")
-    assert R.equal_data(host(y).ravel(), want, 1e-6)
+    assert R.equal_data(host(y).ravel(), kat(CU + "test_cuda_conv.cc", line, "float"), 1e-6)
+
+
+def test_conv_reference_kat_fp16(rt):
+    """test_cuda_conv_fp16.cc:50-53. The reference's IncrementalGenerator fills fp16 tensors with 2.0
+    (include/utils/data_generator.h:45-51), so the inputs are all-2 and the answer is 4x the ones case."""
+    two = lambda s: dev(R.value(s, 2.0, np.float16))
+    y = ops.conv2d(rt, two((1, 3, 4, 4)), two((2, 3, 3, 3)), 1, 1, 2, 1, 1, 2)
+    assert R.equal_data(host(y).ravel(), kat(CU + "test_cuda_conv_fp16.cc", 52, "float"), 1e-6)
 
 
 CONVS = [
