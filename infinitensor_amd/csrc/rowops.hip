@@ -106,50 +106,69 @@ __device__ inline void store_row(T *row, int n, int lane, const RowRegs<T, CHUNK
     }
 }
 
-// ROWS rows per wave: all loads of the wave's rows are issued before any arithmetic.
+// ROWS rows per wave per iteration; waves are persistent (grid-stride over row groups) and software
+// pipelined: the loads of group g+1 are issued before the arithmetic of group g, so every wave has
+// loads in flight during its reductions instead of only at its start.
 template <typename T, int CHUNKS, bool ALIGNED, int ROWS>
 __global__ __launch_bounds__(256) void softmax_wave_kernel(const T *__restrict__ x, T *__restrict__ y,
                                                            long rows, int n) {
     constexpr int VEC = Elem<T>::VEC;
     const int lane = threadIdx.x & 63;
-    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
-    if (row0 >= rows)
+    const long ngroups = (rows + ROWS - 1) / ROWS;
+    const long stride = (long)gridDim.x * 4;
+    long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= ngroups)
         return;
-    RowRegs<T, CHUNKS> v[ROWS];
+    RowRegs<T, CHUNKS> cur[ROWS], nxt[ROWS];
+    auto load_group = [&](RowRegs<T, CHUNKS>(&dst)[ROWS], long grp) {
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-        const long row = row0 + r < rows ? row0 + r : rows - 1; // tail rows recompute the last row
-        load_row<T, CHUNKS, ALIGNED>(x + row * n, n, lane, v[r], -INFINITY);
-    }
+        for (int r = 0; r < ROWS; ++r) {
+            long row = grp * ROWS + r;
+            row = row < rows ? row : rows - 1; // tail rows recompute the last row (never stored)
+            load_row<T, CHUNKS, ALIGNED>(x + row * n, n, lane, dst[r], -INFINITY);
+        }
+    };
+    load_group(cur, g);
+    for (; g < ngroups; g += stride) {
+        const bool more = g + stride < ngroups;
+        if (more)
+            load_group(nxt, g + stride);
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-        float m = -INFINITY;
+        for (int r = 0; r < ROWS; ++r) {
+            float m = -INFINITY;
 #pragma unroll
-        for (int c = 0; c < CHUNKS; ++c)
+            for (int c = 0; c < CHUNKS; ++c)
 #pragma unroll
-            for (int j = 0; j < VEC; ++j)
-                m = fmaxf(m, Elem<T>::ld(&v[r].c[c].v[j]));
-        m = wave_max(m);
-        float e[CHUNKS * VEC];
-        float s = 0.f;
+                for (int j = 0; j < VEC; ++j)
+                    m = fmaxf(m, Elem<T>::ld(&cur[r].c[c].v[j]));
+            m = wave_max(m);
+            float e[CHUNKS * VEC];
+            float s = 0.f;
 #pragma unroll
-        for (int c = 0; c < CHUNKS; ++c)
+            for (int c = 0; c < CHUNKS; ++c)
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const float d = Elem<T>::ld(&v[r].c[c].v[j]) - m;
-                const float ev = sizeof(T) == 4 ? expf(d) : __expf(d);
-                e[c * VEC + j] = ev;
-                s += ev;
-            }
-        s = wave_sum(s);
-        const float inv = 1.0f / s;
+                for (int j = 0; j < VEC; ++j) {
+                    const float d = Elem<T>::ld(&cur[r].c[c].v[j]) - m;
+                    const float ev = sizeof(T) == 4 ? expf(d) : __expf(d);
+                    e[c * VEC + j] = ev;
+                    s += ev;
+                }
+            s = wave_sum(s);
+            const float inv = 1.0f / s;
 #pragma unroll
-        for (int c = 0; c < CHUNKS; ++c)
+            for (int c = 0; c < CHUNKS; ++c)
 #pragma unroll
-            for (int j = 0; j < VEC; ++j)
-                Elem<T>::st(&v[r].c[c].v[j], e[c * VEC + j] * inv);
-        if (row0 + r < rows)
-            store_row<T, CHUNKS, ALIGNED>(y + (row0 + r) * n, n, lane, v[r]);
+                for (int j = 0; j < VEC; ++j)
+                    Elem<T>::st(&cur[r].c[c].v[j], e[c * VEC + j] * inv);
+            const long row = g * ROWS + r;
+            if (row < rows)
+                store_row<T, CHUNKS, ALIGNED>(y + row * n, n, lane, cur[r]);
+        }
+        if (more) {
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r)
+                cur[r] = nxt[r];
+        }
     }
 }
 
@@ -225,16 +244,22 @@ __global__ __launch_bounds__(256) void norm_wave_kernel(const T *__restrict__ x,
                                                         float eps) {
     constexpr int VEC = Elem<T>::VEC;
     const int lane = threadIdx.x & 63;
-    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
-    if (row0 >= rows)
+    const long ngroups = (rows + ROWS - 1) / ROWS;
+    const long stride = (long)gridDim.x * 4;
+    long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= ngroups)
         return;
-    RowRegs<T, CHUNKS> v[ROWS];
+    RowRegs<T, CHUNKS> cur[ROWS], nxt[ROWS];
+    auto load_group = [&](RowRegs<T, CHUNKS>(&dst)[ROWS], long grp) {
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-        const long row = row0 + r < rows ? row0 + r : rows - 1;
-        load_row<T, CHUNKS, ALIGNED>(x + row * n, n, lane, v[r], 0.f);
-    }
-    // scale / bias: per-element (size n) or scalar (size 1); shared by the wave's rows, kept packed
+        for (int r = 0; r < ROWS; ++r) {
+            long row = grp * ROWS + r;
+            row = row < rows ? row : rows - 1;
+            load_row<T, CHUNKS, ALIGNED>(x + row * n, n, lane, dst[r], 0.f);
+        }
+    };
+    load_group(cur, g);
+    // scale / bias: per-element (size n) or scalar (size 1); loaded once per (persistent) wave, packed
     RowRegs<T, CHUNKS> sc, bs;
     float s0 = 1.f, b0 = 0.f;
     const bool sc_vec = scale_size != 1, bs_vec = bias != nullptr && bias_size != 1;
@@ -247,38 +272,49 @@ __global__ __launch_bounds__(256) void norm_wave_kernel(const T *__restrict__ x,
     else if (bias != nullptr)
         b0 = Elem<T>::ld(bias);
     const float fn = (float)n;
+    for (; g < ngroups; g += stride) {
+        const bool more = g + stride < ngroups;
+        if (more)
+            load_group(nxt, g + stride);
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-        float mu = 0.f;
-        if (!RMS) {
-            float s = 0.f;
+        for (int r = 0; r < ROWS; ++r) {
+            float mu = 0.f;
+            if (!RMS) {
+                float s = 0.f;
+#pragma unroll
+                for (int c = 0; c < CHUNKS; ++c)
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j)
+                        s += Elem<T>::ld(&cur[r].c[c].v[j]); // padding lanes hold 0
+                mu = wave_sum(s) / fn; // correctly rounded: integer-valued rows give exact means
+            }
+            float q = 0.f;
 #pragma unroll
             for (int c = 0; c < CHUNKS; ++c)
 #pragma unroll
-                for (int j = 0; j < VEC; ++j)
-                    s += Elem<T>::ld(&v[r].c[c].v[j]); // padding lanes hold 0
-            mu = wave_sum(s) / fn; // correctly rounded division: integer-valued rows give exact means
+                for (int j = 0; j < VEC; ++j) {
+                    const int col = (c * 64 + lane) * VEC + j;
+                    const float d = (col < n) ? Elem<T>::ld(&cur[r].c[c].v[j]) - mu : 0.f;
+                    q += d * d;
+                }
+            const float rstd = 1.0f / sqrtf(wave_sum(q) / fn + eps);
+#pragma unroll
+            for (int c = 0; c < CHUNKS; ++c)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float gg = sc_vec ? Elem<T>::ld(&sc.c[c].v[j]) : s0;
+                    const float bb = bs_vec ? Elem<T>::ld(&bs.c[c].v[j]) : b0;
+                    Elem<T>::st(&cur[r].c[c].v[j], (Elem<T>::ld(&cur[r].c[c].v[j]) - mu) * rstd * gg + bb);
+                }
+            const long row = g * ROWS + r;
+            if (row < rows)
+                store_row<T, CHUNKS, ALIGNED>(y + row * n, n, lane, cur[r]);
         }
-        float q = 0.f;
+        if (more) {
 #pragma unroll
-        for (int c = 0; c < CHUNKS; ++c)
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const int col = (c * 64 + lane) * VEC + j;
-                const float d = (col < n) ? Elem<T>::ld(&v[r].c[c].v[j]) - mu : 0.f;
-                q += d * d;
-            }
-        const float rstd = 1.0f / sqrtf(wave_sum(q) / fn + eps);
-#pragma unroll
-        for (int c = 0; c < CHUNKS; ++c)
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const float g = sc_vec ? Elem<T>::ld(&sc.c[c].v[j]) : s0;
-                const float b = bs_vec ? Elem<T>::ld(&bs.c[c].v[j]) : b0;
-                Elem<T>::st(&v[r].c[c].v[j], (Elem<T>::ld(&v[r].c[c].v[j]) - mu) * rstd * g + b);
-            }
-        if (row0 + r < rows)
-            store_row<T, CHUNKS, ALIGNED>(y + (row0 + r) * n, n, lane, v[r]);
+            for (int r = 0; r < ROWS; ++r)
+                cur[r] = nxt[r];
+        }
     }
 }
 
@@ -325,6 +361,11 @@ __global__ __launch_bounds__(256) void norm_block_kernel(const T *__restrict__ x
 }
 
 static inline bool is_aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+// persistent grid: at most 8 blocks (32 waves) per CU
+static inline unsigned pgrid(int64_t blocks, int num_cu) {
+    const int64_t cap = (int64_t)num_cu * 8;
+    return (unsigned)(blocks < cap ? (blocks < 1 ? 1 : blocks) : cap);
+}
 
 template <typename T>
 static int softmax_dispatch(infiniRocmRuntime_t rt, const T *x, T *y, int64_t outer, int64_t dimsize,
@@ -338,7 +379,7 @@ static int softmax_dispatch(infiniRocmRuntime_t rt, const T *x, T *y, int64_t ou
         const int64_t row_bytes = dimsize * (int64_t)sizeof(T);
         const int rpw = (!al || outer < 4096) ? 1 : (row_bytes <= 1024 ? 4 : (row_bytes <= 3072 ? 2 : 1));
 #define SM_GO(C, A, R)                                                                             \
-    hipLaunchKernelGGL((softmax_wave_kernel<T, C, A, R>), dim3((unsigned)ceil_div(outer, 4 * R)),  \
+    hipLaunchKernelGGL((softmax_wave_kernel<T, C, A, R>), dim3(pgrid(ceil_div(outer, 4 * R), rt->num_cu)), \
                        dim3(256), 0, rt->stream, x, y, (long)outer, (int)dimsize)
         if (chunks <= 1) {
             if (!al) SM_GO(1, false, 1);
@@ -347,7 +388,8 @@ static int softmax_dispatch(infiniRocmRuntime_t rt, const T *x, T *y, int64_t ou
             else SM_GO(1, true, 1);
         } else if (chunks <= 2) {
             if (!al) SM_GO(2, false, 1);
-            else if (rpw >= 2) SM_GO(2, true, 2);
+            else if (rpw == 4) SM_GO(2, true, 4);
+            else if (rpw == 2) SM_GO(2, true, 2);
             else SM_GO(2, true, 1);
         } else if (chunks <= 4) {
             if (al) SM_GO(4, true, 1); else SM_GO(4, false, 1);
@@ -380,7 +422,7 @@ static int norm_dispatch(infiniRocmRuntime_t rt, const T *x, const T *scale, con
     const int64_t row_bytes = n * (int64_t)sizeof(T);
     const int rpw = (!al || outer < 4096) ? 1 : (row_bytes <= 1024 ? 4 : (row_bytes <= 3072 ? 2 : 1));
 #define NORM_GO(C, A, R)                                                                           \
-    hipLaunchKernelGGL((norm_wave_kernel<T, C, A, RMS, R>), dim3((unsigned)ceil_div(outer, 4 * R)), \
+    hipLaunchKernelGGL((norm_wave_kernel<T, C, A, RMS, R>), dim3(pgrid(ceil_div(outer, 4 * R), rt->num_cu)), \
                        dim3(256), 0, rt->stream, x, scale, bias, y, (long)outer, (int)n,           \
                        (int)scale_size, (int)bias_size, eps)
     if (chunks <= 1) {
@@ -390,7 +432,8 @@ static int norm_dispatch(infiniRocmRuntime_t rt, const T *x, const T *scale, con
         else NORM_GO(1, true, 1);
     } else if (chunks <= 2) {
         if (!al) NORM_GO(2, false, 1);
-        else if (rpw >= 2) NORM_GO(2, true, 2);
+        else if (rpw == 4) NORM_GO(2, true, 4);
+        else if (rpw == 2) NORM_GO(2, true, 2);
         else NORM_GO(2, true, 1);
     } else if (chunks <= 4) {
         if (al) NORM_GO(4, true, 1); else NORM_GO(4, false, 1);
