@@ -337,14 +337,9 @@ __global__ __launch_bounds__(256) void gemm_fast128(GemmArgs p) {
     }
 }
 
-#ifdef IROCM_HAVE_GEMM256
 // implemented in gemm256.hip
 int launch_gemm256(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool a_kmajor, bool b_kmajor);
 bool gemm256_supported(const GemmArgs &p, bool a_kmajor, bool b_kmajor);
-#else
-static int launch_gemm256(infiniRocmRuntime_t, int, const GemmArgs &, bool, bool) { return INFINI_ROCM_UNSUPPORTED; }
-static bool gemm256_supported(const GemmArgs &, bool, bool) { return false; }
-#endif
 
 template <typename Tr> static int launch_fast128(infiniRocmRuntime_t rt, GemmArgs p, bool akm, bool bkm) {
     p.tiles_m = (int)ceil_div(p.m, f128::BM);
