@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void gemm_fast128(GemmArgs p) {
 }
 
 // implemented in gemm256.hip
-int launch_gemm256(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool a_kmajor, bool b_kmajor);
+int launch_gemm256(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool a_kmajor, bool b_kmajor, int sched);
 bool gemm256_supported(const GemmArgs &p, bool a_kmajor, bool b_kmajor);
 
 template <typename Tr> static int launch_fast128(infiniRocmRuntime_t rt, GemmArgs p, bool akm, bool bkm) {
@@ -382,7 +382,9 @@ static bool fast128_supported(const GemmArgs &p, bool akm, bool bkm) {
     return true;
 }
 
-static const char *kVariantNames[] = {"generic64", "fast128_glds", "tile256_8wave"};
+static const char *kVariantNames[] = {"generic64", "fast128_glds", "tile256_stagger", "tile256_pipelined"};
+constexpr int kNumVariants = 4;
+constexpr int kDefault256 = 2; // schedule used by the heuristic
 
 } // namespace irocm
 
@@ -390,15 +392,15 @@ using namespace irocm;
 
 extern "C" {
 
-int infini_rocm_matmul_num_variants(void) { return 3; }
+int infini_rocm_matmul_num_variants(void) { return kNumVariants; }
 
 const char *infini_rocm_matmul_variant_name(int v) {
-    return (v >= 0 && v < 3) ? kVariantNames[v] : "invalid";
+    return (v >= 0 && v < kNumVariants) ? kVariantNames[v] : "invalid";
 }
 
 int infini_rocm_matmul_set_variant(infiniRocmRuntime_t rt, int variant) {
     IROCM_CHECK_ARG(rt, "NULL runtime");
-    IROCM_CHECK_ARG(variant >= -1 && variant < 3, "variant %d out of range", variant);
+    IROCM_CHECK_ARG(variant >= -1 && variant < kNumVariants, "variant %d out of range", variant);
     rt->matmul_variant = variant;
     return INFINI_ROCM_OK;
 }
@@ -436,19 +438,19 @@ int infini_rocm_matmul(infiniRocmRuntime_t rt, int dtype, const void *a, const v
         // heuristic: the 256^2 kernel wants at least ~one tile per CU; otherwise 128^2.
         if (gemm256_supported(p, akm, bkm) &&
             ceil_div(m, 256) * ceil_div(n, 256) * batch >= rt->num_cu / 2)
-            variant = 2;
+            variant = kDefault256;
         else if (fast128_supported(p, akm, bkm))
             variant = 1;
         else
             variant = 0;
-    } else if (variant == 2 && !gemm256_supported(p, akm, bkm)) {
+    } else if (variant >= 2 && !gemm256_supported(p, akm, bkm)) {
         variant = fast128_supported(p, akm, bkm) ? 1 : 0;
     } else if (variant == 1 && !fast128_supported(p, akm, bkm)) {
         variant = 0;
     }
 
-    if (variant == 2)
-        return launch_gemm256(rt, dtype, p, akm, bkm);
+    if (variant >= 2)
+        return launch_gemm256(rt, dtype, p, akm, bkm, variant - 2);
     if (variant == 1)
         return dtype == INFINI_DT_BF16 ? launch_fast128<Bf16Traits>(rt, p, akm, bkm)
                                        : launch_fast128<F16Traits>(rt, p, akm, bkm);

@@ -1,31 +1,37 @@
-// gemm256: the headline GEMM kernel for gfx950 — 256x256x64 tile, 8 waves, 128 KiB LDS, one
+// gemm256: the headline GEMM kernels for gfx950 — 256x256x64 tile, 8 waves, 128 KiB LDS, one
 // workgroup per CU (4096^3 = exactly 256 tiles = one wave of workgroups on the 256 CUs).
 //
-// Structure (derived from the bank / pipe rules of MI355X_MICROARCH.md, not from any library):
+// Common structure (derived from the bank / pipe rules of MI355X_MICROARCH.md, not from any library):
 //  * waves: 2 (M) x 4 (N); wave (wr, wc) owns C rows wr*128..+127, cols wc*64..+63 = 8 x 4 MFMA
-//    16x16 tiles, 128 fp32 accumulators per lane.
-//  * LDS: two K-tile buffers, each [A 32 KiB | B 32 KiB]; filled by LDS-DMA (global_load_lds_dwordx4,
-//    1 KiB per wave-instruction). K-major operands: image [256 rows][64 k], 16-byte chunk index XORed
-//    with (row >> 1) & 7 (ds_read_b128 conflict-free); M/N-major operands: image [64 k][256 cols],
-//    32-byte chunk index XORed with f(k) and read with ds_read_b64_tr_b16 (transpose read). The XOR is
-//    applied on the global SOURCE address because the DMA destination is lane-linear.
-//  * schedule per K-tile: 4 phases, each a LOAD segment (inline-asm ds_reads of one operand sub-tile,
-//    counted waits) and a COMPUTE segment (16 MFMAs = one 64x32 C quadrant x K=64), separated by
-//    s_barrier. The two wave rows run the same stream offset by ONE barrier interval, and waves w and
-//    w+4 share a SIMD: in every interval each SIMD has one wave issuing MFMAs (s_setprio 1) while its
-//    partner issues LDS reads / DMA — the matrix pipe never waits for an LDS read of its own wave.
-//  * prefetch distance one full K-tile: tile t+2 is DMA'd into the buffer of tile t as soon as that
-//    buffer's last reads have retired (B half after phase 2, A half after phase 3); the only vmcnt wait
-//    (counted, never 0 in steady state) sits in phase 4 and guards tile t+1.
+//    16x16 tiles, 128 fp32 accumulators per lane (swapped MFMA operands: a lane holds 4 consecutive n).
+//  * LDS: two K-tile buffers, each [A 32 KiB | B 32 KiB], filled by LDS-DMA (global_load_lds_dwordx4,
+//    1 KiB per wave-instruction; per-lane 32-bit source offsets are computed once per workgroup, a
+//    K-tile step only advances a wave-uniform base). K-major operands: image [256 rows][64 k], 16-byte
+//    chunk index XORed with (row >> 1) & 7 (ds_read_b128 conflict-free); M/N-major operands: image
+//    [64 k][256 cols], 32-byte chunk index XORed with f(k), read with ds_read_b64_tr_b16 (transpose
+//    read). The XOR is applied on the global SOURCE address because the DMA destination is lane-linear.
+//    rocprofv3: SQ_LDS_BANK_CONFLICT = 0 for all four layouts (profiles/r01_gemm256_v1_pmc.json).
 //  * ds_reads are inline asm on purpose: hipcc drains vmcnt(0) before any LDS read it can see while an
 //    LDS-DMA is in flight (no alias info on the DMA), which would serialise the pipeline.
 //
-// WAR / RAW argument (intervals of group G0; G1 = G0 + 1):
-//   reads of buffer b:  B sub-tiles in L1,L2 (intervals 0,2 / 1,3), A sub-tiles in L1,L3 (0,4 / 1,5);
-//   every LOAD segment ends with lgkmcnt(0) BEFORE its barrier, so reads retire inside their interval.
-//   DMA into buffer b:  B(t+2) issued in L3 (interval 4 / 5 >= 4 > 3), A(t+2) in L4 (6 / 7 > 5)  => WAR safe.
-//   tile t+1 (other buffer) was issued in L3/L4 of tile t-1; each wave waits vmcnt(8) in L4(t)
-//   (interval 6 / 7) and the barrier ending interval 7 precedes the first read at interval 8      => RAW safe.
+// Two schedules (template SCHED), selectable as matmul variants for within-run A/B:
+//  SCHED 0 "staggered": per K-tile 2 phases per wave, LOAD (ds_reads + DMA issue) | COMPUTE (32 MFMAs),
+//    4 s_barriers per K-tile; the two wave rows run offset by one barrier interval and waves w / w+4 share
+//    a SIMD, so each SIMD always has one wave in COMPUTE. (The first version used 16-MFMA segments and
+//    8 barriers: 57 % MFMA-busy — each barrier + restart costs ~150 cycles of matrix-pipe idle.)
+//      WAR/RAW (intervals of G0; G1 = +1): reads of tile t: B0,B1,A0 in L1 (0/1), A1 in L2 (2/3), each
+//      LOAD ends with lgkmcnt(0) before its barrier. DMA A(t+1) -> other buffer in L1(t) (that A half
+//      was last read in L2(t-1) = -2/-1); DMA B(t+2) -> this buffer in L2(t) (B half last read in L1(t)
+//      = 0/1). Tile t+1 = {B issued L2(t-1), A issued L1(t)}; vmcnt(4) in L2(t) + the barrier ending
+//      interval 3 precede its first read at interval 4.
+//  SCHED 1 "pipelined": every wave software-pipelines its own stream: the ds_reads of the operand
+//    sub-tile needed by quadrant q+1 are issued BEFORE the 16 MFMAs of quadrant q (two A register sets,
+//    two B register sets), so the matrix pipe never waits on the wave's own LDS latency, and there is
+//    ONE s_barrier per K-tile (between quadrants 3 and 4): before it each wave has waited for its own
+//    DMA pieces of tile t+1 (vmcnt) and has retired all its LDS reads of tile t (the last ones, A1(t),
+//    were waited for before quadrant 3); after it tile t's buffer is dead (A1(t), B0/B1(t) live in
+//    registers) and is refilled with tile t+2 — a full K-tile of prefetch distance — and quadrant 4
+//    prefetches A0(t+1), B0(t+1) from the other buffer. B register sets swap roles every tile.
 #include "gemm_common.h"
 #include <type_traits>
 #include <utility>
@@ -34,7 +40,7 @@ namespace irocm {
 namespace g256 {
 
 constexpr int BM = 256, BN = 256, BK = 64;
-constexpr int OPER_BYTES = 256 * 64 * 2; // 32 KiB per operand tile
+constexpr int OPER_BYTES = 256 * 64 * 2;  // 32 KiB per operand tile
 constexpr int BUF_BYTES = 2 * OPER_BYTES; // A | B
 constexpr int LDS_BYTES = 2 * BUF_BYTES;  // 128 KiB
 
@@ -74,6 +80,7 @@ __device__ __forceinline__ void wait_lgkm0() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
+__device__ __forceinline__ void fence_sched() { __builtin_amdgcn_sched_barrier(0); }
 __device__ __forceinline__ void barrier() {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -82,23 +89,20 @@ __device__ __forceinline__ void barrier() {
 
 // ---- staging (LDS-DMA) -----------------------------------------------------------------------
 // K-major operand: 32 pieces of 8 rows; wave w issues pieces w*4 .. w*4+3.
-__device__ __forceinline__ void stage_k(const unsigned short *base, long ld, int row0, int rows, int k0,
-                                        char *lds_oper, int w, int lane) {
+__device__ __forceinline__ void offs_k(unsigned (&off)[4], long ld, int row0, int rows, int w, int lane) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int piece = w * 4 + i;
         const int r = piece * 8 + (lane >> 3);
         const int c_log = (lane & 7) ^ ((r >> 1) & 7);
         int gr = row0 + r;
-        gr = gr < rows ? gr : rows - 1;
-        const unsigned short *src = base + (long)gr * ld + k0 + c_log * 8;
-        __builtin_amdgcn_global_load_lds(IROCM_GLB_PTR(src), IROCM_LDS_PTR(lds_oper + piece * 1024), 16, 0, 0);
+        gr = gr < rows ? gr : rows - 1; // rows beyond the matrix re-read its last row; never stored
+        off[i] = (unsigned)(((long)gr * ld + c_log * 8) * 2);
     }
 }
 // M/N-major operand: image [64 k][256 cols] (512-B rows), 32 pieces of 2 k-rows.
 __device__ __forceinline__ int mn_f(int kr) { return (kr & 3) | (((kr >> 3) & 1) << 2); }
-__device__ __forceinline__ void stage_mn(const unsigned short *base, long ld, int col0, int cols, int k0,
-                                         char *lds_oper, int w, int lane) {
+__device__ __forceinline__ void offs_mn(unsigned (&off)[4], long ld, int col0, int cols, int w, int lane) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int piece = w * 4 + i;
@@ -106,12 +110,17 @@ __device__ __forceinline__ void stage_mn(const unsigned short *base, long ld, in
         const int c_log = (lane & 31) ^ (mn_f(kr) << 1);
         int gc = col0 + c_log * 8;
         gc = gc <= cols - 8 ? gc : cols - 8;
-        const unsigned short *src = base + (long)(k0 + kr) * ld + gc;
-        __builtin_amdgcn_global_load_lds(IROCM_GLB_PTR(src), IROCM_LDS_PTR(lds_oper + piece * 1024), 16, 0, 0);
+        off[i] = (unsigned)(((long)kr * ld + gc) * 2);
     }
 }
+__device__ __forceinline__ void stage4(const char *ubase, const unsigned (&off)[4], char *lds_oper, int w) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds(IROCM_GLB_PTR(ubase + (unsigned long)off[i]),
+                                         IROCM_LDS_PTR(lds_oper + (w * 4 + i) * 1024), 16, 0, 0);
+}
 
-template <typename Tr, bool A_KMAJOR, bool B_KMAJOR>
+template <typename Tr, bool A_KMAJOR, bool B_KMAJOR, int SCHED>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63;
@@ -137,15 +146,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     const long ldb = B_KMAJOR ? p.b_cs : p.b_rs;
     const int nk = p.k / BK;
 
+    unsigned a_off[4], b_off[4];
+    if constexpr (A_KMAJOR) offs_k(a_off, lda, m0, p.m, w, lane);
+    else offs_mn(a_off, lda, m0, p.m, w, lane);
+    if constexpr (B_KMAJOR) offs_k(b_off, ldb, n0, p.n, w, lane);
+    else offs_mn(b_off, ldb, n0, p.n, w, lane);
+    const long a_step = A_KMAJOR ? (long)BK * 2 : (long)BK * lda * 2; // bytes per K-tile (wave-uniform)
+    const long b_step = B_KMAJOR ? (long)BK * 2 : (long)BK * ldb * 2;
     auto stage_a = [&](int buf, int kt) {
-        char *dst = smem + buf * BUF_BYTES;
-        if constexpr (A_KMAJOR) stage_k(A, lda, m0, p.m, kt * BK, dst, w, lane);
-        else stage_mn(A, lda, m0, p.m, kt * BK, dst, w, lane);
+        stage4((const char *)A + (long)kt * a_step, a_off, smem + buf * BUF_BYTES, w);
     };
     auto stage_b = [&](int buf, int kt) {
-        char *dst = smem + buf * BUF_BYTES + OPER_BYTES;
-        if constexpr (B_KMAJOR) stage_k(B, ldb, n0, p.n, kt * BK, dst, w, lane);
-        else stage_mn(B, ldb, n0, p.n, kt * BK, dst, w, lane);
+        stage4((const char *)B + (long)kt * b_step, b_off, smem + buf * BUF_BYTES + OPER_BYTES, w);
     };
 
     // ---- per-lane LDS read addresses (byte offsets in the workgroup's LDS) ----------------------
@@ -153,29 +165,42 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     const int l15 = lane & 15, g4 = lane >> 4;
     // K-major fragment of row r0 + l15: chunk (ks*4 + g4) ^ (l15 >> 1); ks flips address bit 6.
     const unsigned kmaj_lane = (unsigned)(l15 * 128 + (((g4 ^ (l15 >> 1)) & 3) | (((l15 >> 1) >> 2) << 2)) * 16);
-    unsigned a_k[2][2], b_k[2][2];   // [buf][ks]
-    unsigned a_mn[2][8], b_mn[2][4]; // [buf][tile]
+    // Addresses of the CURRENT read buffer; flip_buf() moves them to the other K-tile buffer (one VALU
+    // add per address register per tile — cheaper than a second register set, and registers are the
+    // scarce resource here: 128 accumulators + 96 operand registers per lane).
+    unsigned a_k[2], b_k[2];   // K-major: [ks]
+    unsigned a_mn[8], b_mn[4]; // M/N-major: [tile]
     // M/N-major fragment: lane p = l15 supplies k-row (p >> 2) (+ hh*4 + g4*8 + ks*32), 4 cols (p & 3)*4
     const int mnf = ((l15 >> 2) & 3) | ((g4 & 1) << 2);
     const unsigned mn_lane = (unsigned)((g4 * 8 + (l15 >> 2)) * 512 + (l15 & 1) * 8);
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            a_k[b][ks] = lds0 + b * BUF_BYTES + wr * (128 * 128) + (kmaj_lane ^ (ks * 64));
-            b_k[b][ks] = lds0 + b * BUF_BYTES + OPER_BYTES + wc * (64 * 128) + (kmaj_lane ^ (ks * 64));
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c16 = ((l15 >> 1) & 1) | ((((wr * 8 + i) ^ mnf)) << 1);
-            a_mn[b][i] = lds0 + b * BUF_BYTES + mn_lane + c16 * 16;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c16 = ((l15 >> 1) & 1) | ((((wc * 4 + j) ^ mnf)) << 1);
-            b_mn[b][j] = lds0 + b * BUF_BYTES + OPER_BYTES + mn_lane + c16 * 16;
-        }
+    for (int ks = 0; ks < 2; ++ks) {
+        a_k[ks] = lds0 + wr * (128 * 128) + (kmaj_lane ^ (ks * 64));
+        b_k[ks] = lds0 + OPER_BYTES + wc * (64 * 128) + (kmaj_lane ^ (ks * 64));
     }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c16 = ((l15 >> 1) & 1) | ((((wr * 8 + i) ^ mnf)) << 1);
+        a_mn[i] = lds0 + mn_lane + c16 * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c16 = ((l15 >> 1) & 1) | ((((wc * 4 + j) ^ mnf)) << 1);
+        b_mn[j] = lds0 + OPER_BYTES + mn_lane + c16 * 16;
+    }
+    auto flip_buf = [&](auto toc) { // toc = index of the buffer to read from next
+        constexpr int d = decltype(toc)::value ? BUF_BYTES : -BUF_BYTES;
+        if constexpr (A_KMAJOR) { a_k[0] += d; a_k[1] += d; }
+        else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a_mn[i] += d;
+        }
+        if constexpr (B_KMAJOR) { b_k[0] += d; b_k[1] += d; }
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b_mn[j] += d;
+        }
+    };
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -184,115 +209,168 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         for (int j = 0; j < 4; ++j)
             acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    Frag<A_KMAJOR> aq[4][2];
-    Frag<B_KMAJOR> bq0[2][2], bq1[2][2];
-
-    // read A sub-tile q (4 m-tiles x 2 k-steps) of buffer `buf` into aq
-    auto read_a = [&](auto bufc, auto qc) {
-        constexpr int buf = decltype(bufc)::value, q = decltype(qc)::value;
+    using FA = Frag<A_KMAJOR>;
+    using FB = Frag<B_KMAJOR>;
+    // read A sub-tile q (4 m-tiles x 2 k-steps) of buffer `buf`
+    auto read_a = [&](auto qc, FA(&aq)[4][2]) {
+        constexpr int q = decltype(qc)::value;
         sfor<4>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             sfor<2>([&](auto kc) {
                 constexpr int ks = decltype(kc)::value;
                 if constexpr (A_KMAJOR) {
-                    aq[i][ks].v = lds_read_b128<(q * 4 + i) * 2048>(a_k[buf][ks]);
+                    aq[i][ks].v = lds_read_b128<(q * 4 + i) * 2048>(a_k[ks]);
                 } else {
-                    aq[i][ks].lo = lds_read_tr_b64<ks * 16384>(a_mn[buf][q * 4 + i]);
-                    aq[i][ks].hi = lds_read_tr_b64<ks * 16384 + 2048>(a_mn[buf][q * 4 + i]);
+                    aq[i][ks].lo = lds_read_tr_b64<ks * 16384>(a_mn[q * 4 + i]);
+                    aq[i][ks].hi = lds_read_tr_b64<ks * 16384 + 2048>(a_mn[q * 4 + i]);
                 }
             });
         });
     };
-    auto read_b = [&](auto bufc, auto qc, Frag<B_KMAJOR>(&bq)[2][2]) {
-        constexpr int buf = decltype(bufc)::value, q = decltype(qc)::value;
+    auto read_b = [&](auto qc, FB(&bq)[2][2]) {
+        constexpr int q = decltype(qc)::value;
         sfor<2>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             sfor<2>([&](auto kc) {
                 constexpr int ks = decltype(kc)::value;
                 if constexpr (B_KMAJOR) {
-                    bq[j][ks].v = lds_read_b128<(q * 2 + j) * 2048>(b_k[buf][ks]);
+                    bq[j][ks].v = lds_read_b128<(q * 2 + j) * 2048>(b_k[ks]);
                 } else {
-                    bq[j][ks].lo = lds_read_tr_b64<ks * 16384>(b_mn[buf][q * 2 + j]);
-                    bq[j][ks].hi = lds_read_tr_b64<ks * 16384 + 2048>(b_mn[buf][q * 2 + j]);
+                    bq[j][ks].lo = lds_read_tr_b64<ks * 16384>(b_mn[q * 2 + j]);
+                    bq[j][ks].hi = lds_read_tr_b64<ks * 16384 + 2048>(b_mn[q * 2 + j]);
                 }
             });
         });
     };
-    // 16 MFMAs: C quadrant (A sub qa, B sub qb) x K = 64. Swapped operands: a lane ends up holding 4
-    // consecutive n of one m row.
-    auto compute = [&](auto qac, auto qbc, Frag<B_KMAJOR>(&bq)[2][2]) {
+    // 16 MFMAs: C quadrant (A sub qa, B sub qb) x K = 64
+    auto compute = [&](auto qac, auto qbc, FA(&aq)[4][2], FB(&bq)[2][2]) {
         constexpr int qa = decltype(qac)::value, qb = decltype(qbc)::value;
-        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[qa * 4 + i][qb * 2 + j] = Tr::mfma(bq[j][ks].get(), aq[i][ks].get(), acc[qa * 4 + i][qb * 2 + j]);
-        __builtin_amdgcn_s_setprio(0);
+                    acc[qa * 4 + i][qb * 2 + j] =
+                        Tr::mfma(bq[j][ks].get(), aq[i][ks].get(), acc[qa * 4 + i][qb * 2 + j]);
     };
 
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 
-    auto ktile = [&](auto bufc, int kt) {
-        constexpr int buf = decltype(bufc)::value;
-        const bool pf = kt + 2 < nk; // prefetch tile kt+2 into THIS buffer
-        // L1 | C1
-        read_b(bufc, I0{}, bq0);
-        read_a(bufc, I0{});
-        wait_lgkm0();
-        barrier();
-        compute(I0{}, I0{}, bq0);
-        barrier();
-        // L2 | C2
-        read_b(bufc, I1{}, bq1);
-        wait_lgkm0();
-        barrier();
-        compute(I0{}, I1{}, bq1);
-        barrier();
-        // L3 | C3   (B half of this buffer is dead: start refilling it)
-        read_a(bufc, I1{});
-        if (pf)
-            stage_b(buf, kt + 2);
-        wait_lgkm0();
-        barrier();
-        compute(I1{}, I1{}, bq1);
-        barrier();
-        // L4 | C4   (A half dead too); guard tile kt+1 with a COUNTED wait
-        if (pf) {
-            stage_a(buf, kt + 2);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if constexpr (SCHED == 0) {
+        // ======================= staggered LOAD | COMPUTE schedule ==================================
+        FA aq[4][2];
+        FB bq0[2][2], bq1[2][2];
+        auto ktile = [&](auto bufc, int kt) {
+            constexpr int buf = decltype(bufc)::value;
+            using OB = std::integral_constant<int, buf ^ 1>;
+            // L1
+            read_b(I0{}, bq0);
+            read_b(I1{}, bq1);
+            read_a(I0{}, aq);
+            if (kt + 1 < nk)
+                stage_a(buf ^ 1, kt + 1);
+            wait_lgkm0();
+            barrier();
+            // C1
+            __builtin_amdgcn_s_setprio(1);
+            compute(I0{}, I0{}, aq, bq0);
+            compute(I0{}, I1{}, aq, bq1);
+            __builtin_amdgcn_s_setprio(0);
+            barrier();
+            // L2
+            read_a(I1{}, aq);
+            flip_buf(OB{}); // every read of this tile is issued: next reads come from the other buffer
+            if (kt + 2 < nk) {
+                stage_b(buf, kt + 2);
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            wait_lgkm0();
+            barrier();
+            // C2
+            __builtin_amdgcn_s_setprio(1);
+            compute(I1{}, I1{}, aq, bq1);
+            compute(I1{}, I0{}, aq, bq0);
+            __builtin_amdgcn_s_setprio(0);
+            barrier();
+        };
+        stage_b(0, 0);
+        stage_a(0, 0);
+        if (nk > 1) {
+            stage_b(1, 1);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         barrier();
-        compute(I1{}, I0{}, bq0);
-        barrier();
-    };
-
-    // ---- prologue ------------------------------------------------------------------------------
-    stage_b(0, 0);
-    stage_a(0, 0);
-    if (nk > 1) {
-        stage_b(1, 1);
-        stage_a(1, 1);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (wr == 1)
+            barrier(); // stagger: wave row 1 runs one barrier interval behind wave row 0
+        for (int kt = 0; kt < nk; kt += 2) {
+            ktile(I0{}, kt);
+            if (kt + 1 < nk)
+                ktile(I1{}, kt + 1);
+        }
+        if (wr == 0)
+            barrier(); // balance the stagger
     } else {
+        // ======================= per-wave software-pipelined schedule ===============================
+        FA aqA[4][2], aqB[4][2]; // A0 set, A1 set
+        FB bqX[2][2], bqY[2][2]; // the two B sets swap roles (B0 / B1) every tile
+        // tile kt lives in buffer BUF; on entry aqA = A0(kt), b0 = B0(kt) are loaded and waited for.
+        auto ktile = [&](auto bufc, int kt, FB(&b0)[2][2], FB(&b1)[2][2]) {
+            constexpr int buf = decltype(bufc)::value;
+            using OB = std::integral_constant<int, buf ^ 1>;
+            const bool more = kt + 1 < nk;
+            // Q1: prefetch B1, compute (A0,B0)
+            read_b(I1{}, b1);
+            fence_sched();
+            compute(I0{}, I0{}, aqA, b0);
+            wait_lgkm0();
+            // Q2: prefetch A1, compute (A0,B1)
+            read_a(I1{}, aqB);
+            fence_sched();
+            compute(I0{}, I1{}, aqA, b1);
+            wait_lgkm0();
+            // Q3: compute (A1,B1); then the tile hand-off
+            flip_buf(OB{}); // all reads of this tile are issued
+            compute(I1{}, I1{}, aqB, b1);
+            fence_sched();
+            if (more) {
+                // own DMA pieces of tile kt+1 have landed (they were issued a full tile ago) ...
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                barrier(); // ... everybody's have, and everybody's LDS reads of tile kt have retired
+                if (kt + 2 < nk) { // refill this tile's buffer with tile kt+2
+                    stage_a(buf, kt + 2);
+                    stage_b(buf, kt + 2);
+                }
+                // Q4: prefetch A0, B0 of tile kt+1 (into the A0 set and the dead B1 set), compute (A1,B0)
+                read_b(I0{}, b1);
+                read_a(I0{}, aqA);
+                fence_sched();
+            }
+            compute(I1{}, I0{}, aqB, b0);
+            wait_lgkm0();
+        };
+        stage_a(0, 0);
+        stage_b(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        barrier();
+        if (nk > 1) {
+            stage_a(1, 1);
+            stage_b(1, 1);
+        }
+        read_b(I0{}, bqX);
+        read_a(I0{}, aqA);
+        wait_lgkm0();
+        for (int kt = 0; kt < nk; kt += 2) {
+            ktile(I0{}, kt, bqX, bqY);
+            if (kt + 1 < nk)
+                ktile(I1{}, kt + 1, bqY, bqX);
+        }
     }
-    barrier();
-    if (wr == 1)
-        barrier(); // stagger: wave row 1 runs one barrier interval behind wave row 0
-
-    for (int kt = 0; kt < nk; kt += 2) {
-        ktile(I0{}, kt);
-        if (kt + 1 < nk)
-            ktile(I1{}, kt + 1);
-    }
-    if (wr == 0)
-        barrier(); // balance the stagger
 
     // ---- epilogue ------------------------------------------------------------------------------
     unsigned short *C = (unsigned short *)p.c + (long)ib * p.m * p.n;
@@ -362,16 +440,19 @@ bool gemm256_supported(const GemmArgs &p, bool akm, bool bkm) {
         return false;
     if ((((uintptr_t)p.c) & 7) != 0)
         return false;
+    // per-lane DMA offsets are 32-bit byte offsets inside one operand matrix
+    if ((long)p.m * p.k >= (1l << 31) || (long)p.n * p.k >= (1l << 31))
+        return false;
     return true;
 }
 
-template <typename Tr> static int launch256(infiniRocmRuntime_t rt, GemmArgs p, bool akm, bool bkm) {
+template <typename Tr, int SCHED> static int launch256(infiniRocmRuntime_t rt, GemmArgs p, bool akm, bool bkm) {
     p.tiles_m = (int)ceil_div(p.m, g256::BM);
     p.tiles_n = (int)ceil_div(p.n, g256::BN);
     const unsigned grid = (unsigned)p.tiles_m * p.tiles_n * p.batch;
 #define IROCM_G256(AK, BK_)                                                                        \
     do {                                                                                           \
-        auto kern = g256::gemm256_kernel<Tr, AK, BK_>;                                             \
+        auto kern = g256::gemm256_kernel<Tr, AK, BK_, SCHED>;                                      \
         static bool attr_done = false;                                                             \
         if (!attr_done) {                                                                          \
             IROCM_HIP(hipFuncSetAttribute((const void *)kern,                                      \
@@ -390,8 +471,10 @@ template <typename Tr> static int launch256(infiniRocmRuntime_t rt, GemmArgs p, 
     return INFINI_ROCM_OK;
 }
 
-int launch_gemm256(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool akm, bool bkm) {
-    return dtype == INFINI_DT_BF16 ? launch256<Bf16Traits>(rt, p, akm, bkm) : launch256<F16Traits>(rt, p, akm, bkm);
+int launch_gemm256(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool akm, bool bkm, int sched) {
+    if (sched == 0)
+        return dtype == INFINI_DT_BF16 ? launch256<Bf16Traits, 0>(rt, p, akm, bkm) : launch256<F16Traits, 0>(rt, p, akm, bkm);
+    return dtype == INFINI_DT_BF16 ? launch256<Bf16Traits, 1>(rt, p, akm, bkm) : launch256<F16Traits, 1>(rt, p, akm, bkm);
 }
 
 } // namespace irocm

@@ -38,7 +38,7 @@ def main():
                         ops.matmul(rt, a, w, None, ta, tb, out=c)
                     rt.record(e1)
                     ms = rt.elapsed_ms(e0, e1) / iters
-                    row.append(f"{variants[v]}={2.0 * b * m * n * k / ms / 1e9:8.1f}TF({ms * 1e3:7.1f}us)")
+                    row.append(f"{variants[v][-9:]}={2.0 * b * m * n * k / ms / 1e9:7.1f}TF")
                 ops.set_matmul_variant(rt, -1)
                 print(f"{str(dt)[6:]:9s} b{b} m{m} n{n} k{k} tA{int(ta)} tB{int(tb)}: " + "  ".join(row), flush=True)
     # fp32 generic
