@@ -1,0 +1,105 @@
+// Device::ROCM runtime for the InfiniTensor graph executor — the MI355X peer of CudaRuntimeObj
+// (reference: include/cuda/cuda_runtime.h:12-140, src/cuda/cuda_runtime.cc). It is a thin C++ shell
+// over the C ABI in include/infini_rocm.h: the handle owns the device, one non-blocking HIP stream,
+// the scratch workspace and (optionally) one RCCL communicator; this class adds what only the
+// graph layer knows — walking the operator list through KernelRegistry, and the hipGraph
+// capture/replay cache keyed by the graph's capture state (same invalidation rules as the reference's
+// CUDA-graph cache, cuda_runtime.cc:210-426).
+#pragma once
+#include "core/communicator.h"
+#include "core/runtime.h"
+#include "infini_rocm.h"
+#include <list>
+#include <memory>
+#include <mutex>
+#include <unordered_map>
+
+namespace infini {
+
+// reference: NcclCommunicatorObj (include/cuda/nccl_communicator.h:22-68). The RCCL communicator
+// itself lives behind the C ABI (one per runtime handle); this object only carries world/rank.
+class RcclCommunicatorObj final : public CommunicatorObj {
+  public:
+    RcclCommunicatorObj(int worldSize, int rank) : CommunicatorObj(worldSize, rank) {}
+    string toString() const final { return "RCCL communicator"; }
+};
+
+class RocmRuntimeObj : public RuntimeObj {
+  public:
+    explicit RocmRuntimeObj(int deviceId = 0, size_t hipGraphCacheCapacity = 16);
+    ~RocmRuntimeObj() override;
+    string toString() const override;
+
+    void run(const Graph &graph, bool tune = false, bool profiling = false) const override;
+    void runWithoutSync(const Graph &graph) const;
+    void sync() const;
+    // capture-once / replay (reference: runWithCudaGraph)
+    void runWithHipGraph(const Graph &graph);
+    void clearHipGraphCache();
+    size_t getHipGraphCacheSize() const;
+    size_t getHipGraphCaptureCount() const;
+    void invalidateGraphCaptureCache(uint64_t graphId) noexcept override;
+
+    void *alloc(size_t size) override;
+    void dealloc(void *ptr) override;
+    void copyBlobFromCPU(void *dst, const void *src, size_t bytes) const override;
+    void copyBlobToCPU(void *dst, const void *src, size_t bytes) const override;
+    void copyBlobInsideRuntime(void *dst, const void *src, size_t bytes) const override;
+
+    // scratch valid inside one Kernel::compute (reference: getWorkspace, cuda_runtime.h:85-88)
+    void *getWorkspace(size_t size) const;
+    infiniRocmRuntime_t handle() const { return rt; }
+
+    void initComm(const string &name, int worldSize, int rank) final;
+    CommunicatorObj &getCommunicator() const final;
+
+  private:
+    struct TensorState {
+        const void *tensor;
+        int dtype;
+        vector<int> shape;
+        uint64_t storageId;
+        size_t storageOffset;
+        const void *address;
+        bool operator==(const TensorState &o) const {
+            return tensor == o.tensor && dtype == o.dtype && shape == o.shape && storageId == o.storageId &&
+                   storageOffset == o.storageOffset && address == o.address;
+        }
+    };
+    struct GraphState {
+        uint64_t graphId;
+        size_t topologyEpoch;
+        vector<TensorState> tensors;
+        bool operator==(const GraphState &o) const {
+            return graphId == o.graphId && topologyEpoch == o.topologyEpoch && tensors == o.tensors;
+        }
+    };
+    struct CacheEntry {
+        WRef<GraphObj> owner;
+        GraphState state;
+        size_t generation;
+        infiniRocmGraph_t graph = nullptr;
+        ~CacheEntry();
+    };
+    using Cache = std::list<std::unique_ptr<CacheEntry>>;
+
+    void launchAll(const Graph &graph, bool validate) const;
+    void tuneImpl(const Graph &graph, bool profiling) const;
+    GraphState stateOf(const Graph &graph) const;
+    void replay(CacheEntry &entry);
+
+    infiniRocmRuntime_t rt = nullptr;
+    std::unique_ptr<CommunicatorObj> comm;
+    size_t cacheCapacity;
+    size_t captureCount = 0;
+    Cache cache; // most recently used first
+    mutable std::recursive_mutex executionMutex;
+    mutable std::recursive_mutex cacheMutex;
+};
+
+// Throw infini::Exception with the C ABI's message when a call fails
+// (reference: checkCudaError, include/cuda/cuda_common.h:10-14).
+void rocmCheck(int status, const char *what);
+#define ROCM_CALL(expr) ::infini::rocmCheck((expr), #expr)
+
+} // namespace infini

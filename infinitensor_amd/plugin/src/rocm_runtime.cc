@@ -1,0 +1,244 @@
+#include "rocm/rocm_runtime.h"
+#include "core/graph.h"
+#include "core/kernel.h"
+#include "core/perf_engine.h"
+#include <algorithm>
+
+namespace infini {
+
+void rocmCheck(int status, const char *what) {
+    if (status != INFINI_ROCM_OK) {
+        const std::string msg = std::string(what) + " failed (status " + std::to_string(status) + "): " +
+                                infini_rocm_last_error();
+        // `<< msg`: without BACKWARD_TRACE the reference's Exception leaves what() empty (utils/exception.cc)
+        throw(::infini::Exception(msg) << msg);
+    }
+}
+
+RocmRuntimeObj::RocmRuntimeObj(int deviceId, size_t hipGraphCacheCapacity)
+    : RuntimeObj(Device::ROCM, deviceId), cacheCapacity(hipGraphCacheCapacity) {
+    ROCM_CALL(infini_rocm_runtime_create(deviceId, &rt));
+}
+
+RocmRuntimeObj::~RocmRuntimeObj() {
+    cache.clear();
+    if (rt)
+        infini_rocm_runtime_destroy(rt);
+}
+
+string RocmRuntimeObj::toString() const { return "ROCM Runtime"; }
+
+void *RocmRuntimeObj::alloc(size_t size) {
+    void *p = nullptr;
+    ROCM_CALL(infini_rocm_alloc(rt, size, &p));
+    return p;
+}
+void RocmRuntimeObj::dealloc(void *ptr) { ROCM_CALL(infini_rocm_dealloc(rt, ptr)); }
+void RocmRuntimeObj::copyBlobFromCPU(void *dst, const void *src, size_t bytes) const {
+    ROCM_CALL(infini_rocm_copy_from_cpu(rt, dst, src, bytes));
+}
+void RocmRuntimeObj::copyBlobToCPU(void *dst, const void *src, size_t bytes) const {
+    ROCM_CALL(infini_rocm_copy_to_cpu(rt, dst, src, bytes));
+}
+void RocmRuntimeObj::copyBlobInsideRuntime(void *dst, const void *src, size_t bytes) const {
+    ROCM_CALL(infini_rocm_copy_inside(rt, dst, src, bytes));
+    ROCM_CALL(infini_rocm_runtime_sync(rt)); // reference semantics: cudaMemcpy D2D is synchronous
+}
+void *RocmRuntimeObj::getWorkspace(size_t size) const {
+    void *p = nullptr;
+    ROCM_CALL(infini_rocm_workspace(rt, size, &p));
+    return p;
+}
+void RocmRuntimeObj::sync() const { ROCM_CALL(infini_rocm_runtime_sync(rt)); }
+
+void RocmRuntimeObj::initComm(const string &name, int worldSize, int rank) {
+    std::lock_guard<std::recursive_mutex> lock(executionMutex);
+    IT_ASSERT(worldSize > 0);
+    IT_ASSERT(rank >= 0 && rank < worldSize);
+    IT_ASSERT(!comm, "communicator is already initialized.");
+    ROCM_CALL(infini_rocm_comm_init(rt, name.c_str(), worldSize, rank));
+    comm = std::make_unique<RcclCommunicatorObj>(worldSize, rank);
+}
+
+CommunicatorObj &RocmRuntimeObj::getCommunicator() const {
+    IT_ASSERT(comm != nullptr, "communicator is not initialized (call init_comm)");
+    return *comm;
+}
+
+// ---- the hot loop: one Kernel::compute per operator, asynchronously on the runtime stream -------
+void RocmRuntimeObj::launchAll(const Graph &graph, bool validate) const {
+    IT_ASSERT(graph != nullptr, "Cannot run a null graph");
+    if (validate)
+        graph->validateMemory();
+    const auto &registry = KernelRegistry::getInstance();
+    auto &perfEngine = PerfEngine::getInstance();
+    for (auto &op : graph->getOperators()) {
+        auto attrs = KernelAttrs{device, op->getOpType().underlying()};
+        Kernel *kernel = registry.getKernel(attrs);
+        auto perfKey = PerfEngine::Key{attrs, op->getOpPerfKey()};
+        auto perfData = perfEngine.getPerfData(perfKey);
+        try {
+            if (perfData)
+                kernel->getComputeFunc(perfKey)(op, perfData, this);
+            else
+                kernel->compute(op, this);
+        } catch (Exception &e) {
+            e << " while launching " << op->toString();
+            throw;
+        }
+    }
+}
+
+void RocmRuntimeObj::runWithoutSync(const Graph &graph) const {
+    std::lock_guard<std::recursive_mutex> lock(executionMutex);
+    launchAll(graph, true);
+}
+
+void RocmRuntimeObj::tuneImpl(const Graph &graph, bool profiling) const {
+    IT_ASSERT(graph != nullptr, "Cannot tune a null graph");
+    graph->validateMemory();
+    const auto &registry = KernelRegistry::getInstance();
+    auto &perfEngine = PerfEngine::getInstance();
+    double total = 0;
+    std::map<OpType, double> opTime;
+    std::map<OpType, int> opCnt;
+    for (auto &op : graph->getOperators()) {
+        auto attrs = KernelAttrs{device, op->getOpType().underlying()};
+        Kernel *kernel = registry.getKernel(attrs);
+        auto perfKey = PerfEngine::Key{attrs, op->getOpPerfKey()};
+        PerfRecord record = perfEngine.getPerfData(perfKey);
+        if (!record) {
+            record = kernel->tune(op, this);
+            perfEngine.setPerfData(perfKey, record);
+        }
+        total += record->time;
+        kernel->computeFuncTune(perfKey, op, record, this);
+        if (profiling) {
+            double t = timeit([&]() { kernel->getComputeFunc(perfKey)(op, record, this); }, [&]() { sync(); }, 1, 1);
+            op->print();
+            printf(" op_time on rocm %lf\n", t);
+            opTime[op->getOpType()] += t;
+            opCnt[op->getOpType()]++;
+            total += t;
+        }
+    }
+    if (profiling)
+        printProfilingData(total, opTime, opCnt);
+}
+
+void RocmRuntimeObj::run(const Graph &graph, bool tune, bool profiling) const {
+    std::lock_guard<std::recursive_mutex> lock(executionMutex);
+    if (tune || profiling) {
+        tuneImpl(graph, profiling);
+        sync();
+        return;
+    }
+    launchAll(graph, true);
+    sync(); // host blocks once per graph (reference: syncImpl, cuda_runtime.cc:481-483)
+}
+
+// ---- hipGraph capture / replay cache -------------------------------------------------------------
+RocmRuntimeObj::CacheEntry::~CacheEntry() {
+    if (graph)
+        infini_rocm_graph_destroy(graph);
+}
+
+RocmRuntimeObj::GraphState RocmRuntimeObj::stateOf(const Graph &graph) const {
+    GraphState st{graph->getCaptureStateId(), graph->getTopologyEpoch(), {}};
+    st.tensors.reserve(graph->getTensors().size());
+    for (const auto &t : graph->getTensors()) {
+        const auto &blob = t->getDataBlob();
+        IT_ASSERT(blob != nullptr, "Cannot capture a Tensor without memory");
+        st.tensors.push_back(TensorState{t.get(), t->getDTypeIndex(), t->getDims(), blob->getStorageId(),
+                                         blob->getStorageOffset(), t->getRawDataPtr<const void *>()});
+    }
+    return st;
+}
+
+void RocmRuntimeObj::replay(CacheEntry &entry) {
+    try {
+        ROCM_CALL(infini_rocm_graph_launch(rt, entry.graph));
+        sync();
+    } catch (...) {
+        // a failed replay poisons nothing but this entry: drop every capture of that graph
+        const uint64_t id = entry.state.graphId;
+        cache.remove_if([id](const std::unique_ptr<CacheEntry> &e) { return e->state.graphId == id; });
+        infini_rocm_graph_abort_capture(rt);
+        throw;
+    }
+}
+
+void RocmRuntimeObj::runWithHipGraph(const Graph &graph) {
+    IT_ASSERT(graph != nullptr, "Cannot run a null graph");
+    std::lock_guard<std::recursive_mutex> executionLock(executionMutex);
+    std::lock_guard<std::recursive_mutex> cacheLock(cacheMutex);
+    // drop captures whose graph object is gone
+    cache.remove_if([](const std::unique_ptr<CacheEntry> &e) { return e->owner.expired(); });
+
+    const size_t generation = graph->getCaptureGeneration();
+    // fast path: the most recent capture of this very graph at this generation (nothing about its
+    // topology, shapes or storage changed since — GraphObj bumps the generation whenever it does)
+    for (auto it = cache.begin(); it != cache.end(); ++it) {
+        auto owner = (*it)->owner.lock();
+        if (owner && owner.get() == graph.get() && (*it)->generation == generation) {
+            cache.splice(cache.begin(), cache, it);
+            replay(*cache.front());
+            return;
+        }
+    }
+    graph->validateMemory();
+    GraphState state = stateOf(graph);
+    for (auto it = cache.begin(); it != cache.end(); ++it) {
+        auto owner = (*it)->owner.lock();
+        if (owner && owner.get() == graph.get() && (*it)->state == state) {
+            (*it)->generation = generation;
+            cache.splice(cache.begin(), cache, it);
+            replay(*cache.front());
+            return;
+        }
+    }
+    // capture. Kernels must not allocate or synchronise while the stream records; a kernel that does
+    // makes the capture fail, the stream is rebuilt and the error propagates (reference:
+    // recoverExecutionStreamAfterFailure, cuda_runtime.cc:226-250; test_cudagraph.cc:18-27).
+    auto entry = std::make_unique<CacheEntry>();
+    entry->owner = WRef<GraphObj>(graph);
+    entry->state = std::move(state);
+    entry->generation = generation;
+    ROCM_CALL(infini_rocm_graph_begin_capture(rt));
+    try {
+        launchAll(graph, false);
+        ROCM_CALL(infini_rocm_graph_end_capture(rt, &entry->graph));
+    } catch (...) {
+        infini_rocm_graph_abort_capture(rt);
+        throw;
+    }
+    IT_ASSERT(generation == graph->getCaptureGeneration(), "Graph changed while hipGraph capture was in progress");
+    ROCM_CALL(infini_rocm_graph_launch(rt, entry->graph));
+    sync();
+    ++captureCount;
+    cache.push_front(std::move(entry));
+    while (cache.size() > cacheCapacity)
+        cache.pop_back();
+}
+
+void RocmRuntimeObj::invalidateGraphCaptureCache(uint64_t graphId) noexcept {
+    std::lock_guard<std::recursive_mutex> executionLock(executionMutex);
+    std::lock_guard<std::recursive_mutex> cacheLock(cacheMutex);
+    cache.remove_if([graphId](const std::unique_ptr<CacheEntry> &e) { return e->state.graphId == graphId; });
+}
+
+void RocmRuntimeObj::clearHipGraphCache() {
+    std::lock_guard<std::recursive_mutex> executionLock(executionMutex);
+    std::lock_guard<std::recursive_mutex> cacheLock(cacheMutex);
+    cache.clear();
+}
+size_t RocmRuntimeObj::getHipGraphCacheSize() const {
+    std::lock_guard<std::recursive_mutex> lock(cacheMutex);
+    return cache.size();
+}
+size_t RocmRuntimeObj::getHipGraphCaptureCount() const {
+    std::lock_guard<std::recursive_mutex> lock(cacheMutex);
+    return captureCount;
+}
+
+} // namespace infini

@@ -28,21 +28,45 @@ def kat(file: str, line: int, kind: str | None = None, index: int = 0) -> np.nda
     return np.array(recs[index]["values"])
 
 
-@pytest.fixture(scope="session")
-def ref_backend():
-    """The reference's own native-CPU backend (oracle/_ref, built from /root/reference)."""
+def load_backend_module():
+    """Load the reference's pybind module `backend`. Only ONE copy can live in a process (pybind11 type
+    registry), so the build that contains the Device::ROCM plugin is preferred when it exists — it is the
+    same reference sources (core, operators, native-CPU kernels, ffi) plus the plugin and the five-line
+    device patch of infinitensor_amd/plugin/build_plugin.py; otherwise the pure oracle/_ref build."""
     import importlib.util
     import sysconfig
 
-    p = REPO / "oracle" / "_ref" / f"backend{sysconfig.get_config_var('EXT_SUFFIX')}"
-    if not p.exists():
-        pytest.skip("oracle/_ref not built (run __graft_entry__.build() where /root/reference exists)")
     if "backend" in sys.modules:
         return sys.modules["backend"]
-    spec = importlib.util.spec_from_file_location("backend", p)
-    mod = importlib.util.module_from_spec(spec)
-    sys.modules["backend"] = mod
-    spec.loader.exec_module(mod)
+    suffix = sysconfig.get_config_var("EXT_SUFFIX")
+    for p in (REPO / "infinitensor_amd" / "plugin" / "_build" / f"backend{suffix}", REPO / "oracle" / "_ref" / f"backend{suffix}"):
+        if p.exists():
+            import torch  # noqa: F401  one HIP runtime per process: torch's must be mapped first (see _lib.py)
+
+            spec = importlib.util.spec_from_file_location("backend", p)
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules["backend"] = mod
+            spec.loader.exec_module(mod)
+            mod.__irocm_path__ = str(p)
+            return mod
+    return None
+
+
+@pytest.fixture(scope="session")
+def ref_backend():
+    """The reference's own native-CPU backend (`backend.cpu_runtime()`), built from /root/reference."""
+    mod = load_backend_module()
+    if mod is None:
+        pytest.skip("reference backend not built (run __graft_entry__.build() where /root/reference exists)")
+    return mod
+
+
+@pytest.fixture(scope="session")
+def plugin_backend():
+    """The reference graph executor WITH the Device::ROCM plugin (`backend.RocmRuntime`)."""
+    mod = load_backend_module()
+    if mod is None or not hasattr(mod, "RocmRuntime"):
+        pytest.skip("plugin build (infinitensor_amd/plugin/_build) not present")
     return mod
 
 

@@ -1,0 +1,247 @@
+"""The drop-in test: the REFERENCE's graph executor (GraphHandler / GraphObj / KernelRegistry, compiled
+from /root/reference) driving OUR Device::ROCM kernels through backend.RocmRuntime. Written like the
+reference's own kernel tests: build the graph, copy inputs in, run, copy out, compare with the golden
+vector — and, like its differential tests (test_cuda_unary.cc:12-41), with the same graph run on the
+reference's native-CPU runtime in the same process."""
+import numpy as np
+import pytest
+from conftest import kat
+
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+CU = "test/kernels/cuda/"
+F32, F16, I64, I32, U8 = 1, 10, 7, 6, 2
+
+
+@pytest.fixture(scope="module")
+def B(plugin_backend):
+    return plugin_backend
+
+
+@pytest.fixture(scope="module")
+def rocm(B):
+    return B.RocmRuntime(0)
+
+
+def put(t, a):
+    t.copyin_numpy(np.ascontiguousarray(a))
+
+
+def get(t, shape=None):
+    a = t.copyout_numpy()
+    return a if shape is None else a.reshape(shape)
+
+
+def build(B, runtime, fn, inputs):
+    """inputs: list of (shape, dtype_code, array). fn(handler, tensors) -> output tensor(s)."""
+    h = B.GraphHandler(runtime)
+    ts = [h.tensor(list(s), d) for s, d, _ in inputs]
+    out = fn(h, ts)
+    h.data_malloc()
+    for t, (_, _, a) in zip(ts, inputs):
+        put(t, a)
+    return h, out
+
+
+def run_both(B, rocm, fn, inputs):
+    h, out = build(B, rocm, fn, inputs)
+    h.run()
+    got = get(out)
+    hc, outc = build(B, B.cpu_runtime(), fn, inputs)
+    hc.run()
+    return got, get(outc)
+
+
+MATMUL = [("inc", "one", False, False, (1, 3, 5), (1, 5, 2), 50), ("inc", "inc", True, False, (2, 3, 4), (2, 3, 2), 53),
+          ("inc", "inc", False, False, (2, 3, 5), (5, 2), 58), ("inc", "inc", True, False, (2, 5, 3), (5, 2), 61),
+          ("inc", "inc", False, False, (3, 5), (5, 2), 65)]
+
+
+@pytest.mark.parametrize("case", MATMUL)
+def test_matmul_kats_through_reference_executor(B, rocm, case):
+    ga, gb, ta, tb, sa, sb, line = case
+    g = {"inc": R.incremental, "one": R.ones}
+    h, c = build(B, rocm, lambda h, t: h.matmul(t[0], t[1], None, ta, tb, None, B.ActType.Linear, "default"),
+                 [(sa, F32, g[ga](sa)), (sb, F32, g[gb](sb))])
+    h.run()
+    assert R.equal_data(get(c).ravel(), kat(CU + "test_cuda_matmul.cc", line, "float"), 1e-6)
+
+
+def test_matmul_with_bias_and_fp16(B, rocm):
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((4, 128, 64)).astype(np.float16)
+    w = rng.standard_normal((64, 256)).astype(np.float16)
+    bias = rng.standard_normal((256,)).astype(np.float16)
+    h, c = build(B, rocm, lambda h, t: h.matmul(t[0], t[1], None, False, False, t[2], B.ActType.Linear, "default"),
+                 [(a.shape, F16, a), (w.shape, F16, w), (bias.shape, F16, bias)])
+    h.run()
+    want = R.matmul(a.astype(np.float64), w.astype(np.float64), bias.astype(np.float64))
+    assert np.allclose(get(c).astype(np.float64).reshape(want.shape), want, rtol=2e-3, atol=3e-2)
+
+
+@pytest.mark.parametrize("g,line", [(R.ones, 50), (R.incremental, 53)])
+def test_conv_kats_through_reference_executor(B, rocm, g, line):
+    h, y = build(B, rocm, lambda h, t: h.conv(t[0], t[1], None, 1, 1, 2, 1, 1, 2),
+                 [((1, 3, 4, 4), F32, g((1, 3, 4, 4))), ((2, 3, 3, 3), F32, g((2, 3, 3, 3)))])
+    h.run()
+    assert R.equal_data(get(y).ravel(), kat(CU + "test_cuda_conv.cc", line, "float"), 1e-6)
+
+
+@pytest.mark.parametrize("axis,line", [(0, 73), (1, 86), (2, 99), (3, 110)])
+def test_softmax_kats_through_reference_executor(B, rocm, axis, line):
+    x = np.arange(24, dtype=np.float32).reshape(2, 3, 2, 2)
+    h, y = build(B, rocm, lambda h, t: h.softmax(t[0], None, axis), [(x.shape, F32, x)])
+    h.run()
+    assert R.equal_data(get(y).ravel(), kat(CU + "test_cuda_softmax.cc", line, "float"), 1e-6)
+
+
+@pytest.mark.parametrize("si,yi,bi", [(157, 158, 165), (172, 173, 180), (187, 188, 195), (202, 203, None)])
+def test_layernorm_kats_through_reference_executor(B, rocm, si, yi, bi):
+    f = CU + "test_cuda_layernorm.cc"
+    x = np.arange(36, dtype=np.float32).reshape(2, 3, 2, 3)
+    scale = kat(f, si, "float").astype(np.float32)
+    ins = [(x.shape, F32, x), (scale.shape, F32, scale)]
+    if bi:
+        bias = kat(f, bi, "float").astype(np.float32)
+        ins.append((bias.shape, F32, bias))
+    h, y = build(B, rocm, lambda h, t: h.layerNormalization(t[0], t[1], None, t[2] if bi else None, 1e-5, 3, 1), ins)
+    h.run()
+    assert R.equal_data(get(y).ravel(), kat(f, yi, "float"), 2e-6)
+
+
+@pytest.mark.parametrize("name", ["relu", "silu", "abs", "sigmoid", "tanh", "hardSigmoid", "hardSwish", "sqrt", "neg", "erf", "gelu"])
+@pytest.mark.parametrize("shape", [(1, 2, 2, 3), (13,), (2, 3, 4, 5, 6)])
+def test_unary_device_vs_reference_native_cpu(B, rocm, name, shape):
+    """test_cuda_unary.cc:122-143 verbatim in spirit: same op on the device and on the reference's CPU kernel."""
+    x = R.incremental(shape)
+    got, ref = run_both(B, rocm, lambda h, t: getattr(h, name)(t[0], None), [(shape, F32, x)])
+    assert R.equal_data(got.ravel(), ref.ravel(), 2e-6), name
+
+
+@pytest.mark.parametrize("name", ["add", "sub", "mul", "div"])
+def test_binary_device_vs_reference_native_cpu(B, rocm, name):
+    rng = np.random.default_rng(1)
+    a = rng.uniform(0.5, 2, (2, 3, 4, 5)).astype(np.float32)
+    b = rng.uniform(0.5, 2, (3, 1, 5)).astype(np.float32)
+    got, ref = run_both(B, rocm, lambda h, t: getattr(h, name)(t[0], t[1], None), [(a.shape, F32, a), (b.shape, F32, b)])
+    assert np.allclose(got, ref, rtol=1e-6, atol=1e-7)
+
+
+def test_conv_pool_concat_transpose_vs_reference_native_cpu(B, rocm):
+    rng = np.random.default_rng(2)
+    x = np.abs(rng.standard_normal((2, 4, 9, 8))).astype(np.float32)
+    w = rng.standard_normal((6, 4, 3, 3)).astype(np.float32)
+
+    def net(h, t):
+        y = h.conv(t[0], t[1], None, 1, 1, 1, 1, 1, 1)
+        y = h.relu(y, None)
+        p = h.maxPool(y, None, 3, 3, 1, 1, 1, 1, 2, 2, 0)
+        q = h.avgPool(y, None, 3, 3, 1, 1, 1, 1, 2, 2, 0)
+        c = h.concat([p, q], None, 1)
+        return h.transpose(c, None, [0, 2, 3, 1])
+
+    got, ref = run_both(B, rocm, net, [(x.shape, F32, x), (w.shape, F32, w)])
+    assert got.shape == ref.shape or got.size == ref.size
+    assert np.allclose(got.ravel(), ref.ravel(), rtol=1e-4, atol=1e-4)
+
+
+def test_gather_int64_indices_bit_exact(B, rocm):
+    table = np.random.default_rng(3).standard_normal((1000, 64)).astype(np.float32)
+    ids = np.random.default_rng(4).integers(0, 1000, (4, 16)).astype(np.int64)
+    h, y = build(B, rocm, lambda h, t: h.gather(t[0], t[1], None, 0), [(table.shape, F32, table), (ids.shape, I64, ids)])
+    h.run()
+    assert np.array_equal(get(y).reshape(4, 16, 64), table[ids])
+
+
+def test_transformer_block_graph_eager_vs_hipgraph(B, rocm):
+    """A BERT-style encoder block built op by op (MatMul, Add, Reshape, Transpose, Div, Softmax, LayerNorm,
+    Gelu) through the reference GraphHandler; eager run == hipGraph replay == fp64 oracle."""
+    rng = np.random.default_rng(5)
+    Bt, S, Hd, NH = 2, 32, 64, 4
+    D = Hd // NH
+    x = rng.standard_normal((Bt, S, Hd)).astype(np.float32)
+    W = {k: (rng.standard_normal((Hd, Hd)) / 8).astype(np.float32) for k in "qkvo"}
+    W1 = (rng.standard_normal((Hd, 4 * Hd)) / 8).astype(np.float32)
+    W2 = (rng.standard_normal((4 * Hd, Hd)) / 16).astype(np.float32)
+    g = np.ones(Hd, np.float32)
+    bt = np.zeros(Hd, np.float32)
+    sc = np.array(np.sqrt(D), np.float32).reshape(1)
+    ins = [(x.shape, F32, x)] + [(W[k].shape, F32, W[k]) for k in "qkvo"] + [(W1.shape, F32, W1), (W2.shape, F32, W2),
+                                                                            (g.shape, F32, g), (bt.shape, F32, bt), ((1,), F32, sc)]
+    lin = B.ActType.Linear
+
+    def net(h, t):
+        xin, wq, wk, wv, wo, w1, w2, gg, bb, scale = t
+        mm = lambda a, b, tb=False: h.matmul(a, b, None, False, tb, None, lin, "default")
+        heads = lambda y: h.transpose(h.reshape(y, None, [Bt, S, NH, D]), None, [0, 2, 1, 3])
+        q, k, v = heads(mm(xin, wq)), heads(mm(xin, wk)), heads(mm(xin, wv))
+        s = h.div(mm(q, k, True), scale, None)
+        p = h.softmax(s, None, 3)
+        ctx = h.reshape(h.transpose(mm(p, v), None, [0, 2, 1, 3]), None, [Bt, S, Hd])
+        y = h.layerNormalization(h.add(xin, mm(ctx, wo), None), gg, None, bb, 1e-5, 2, 1)
+        f = mm(h.gelu(mm(y, w1), None), w2)
+        return h.layerNormalization(h.add(y, f, None), gg, None, bb, 1e-5, 2, 1)
+
+    h, out = build(B, rocm, net, ins)
+    h.run()
+    eager = get(out).copy()
+    before = rocm.hip_graph_capture_count()
+    h.run_with_hipgraph()
+    h.run_with_hipgraph()
+    assert rocm.hip_graph_capture_count() == before + 1  # captured once, replayed once
+    assert np.array_equal(get(out), eager)
+    # oracle
+    X = x.astype(np.float64)
+    hd = lambda y: y.reshape(Bt, S, NH, D).transpose(0, 2, 1, 3)
+    q, k, v = hd(X @ W["q"]), hd(X @ W["k"]), hd(X @ W["v"])
+    p = R.softmax(q @ k.transpose(0, 1, 3, 2) / np.sqrt(D), 3)
+    ctx = (p @ v).transpose(0, 2, 1, 3).reshape(Bt, S, Hd)
+    y = R.layer_norm(X + ctx @ W["o"], g, bt, 1e-5, 2)
+    want = R.layer_norm(y + R.unary("gelu", y @ W1) @ W2, g, bt, 1e-5, 2)
+    assert np.allclose(eager.reshape(want.shape), want, rtol=1e-4, atol=1e-4)
+
+
+def test_hipgraph_cache_semantics(B):
+    """test/cuda/test_cudagraph.cc: capture once, replay; a second graph gets its own capture; the LRU is bounded;
+    new input CONTENTS in the same buffers need no recapture."""
+    rt = B.RocmRuntime(0, 2)
+
+    def make(n):
+        h = B.GraphHandler(rt)
+        a = h.tensor([n, n], F32)
+        y = h.relu(h.add(a, a, None), None)
+        h.data_malloc()
+        return h, a, y
+
+    h1, a1, y1 = make(8)
+    put(a1, np.full((8, 8), -1, np.float32))
+    h1.run_with_hipgraph()
+    assert rt.hip_graph_capture_count() == 1 and np.all(get(y1) == 0)
+    put(a1, np.full((8, 8), 2, np.float32))
+    h1.run_with_hipgraph()
+    assert rt.hip_graph_capture_count() == 1 and np.all(get(y1) == 4)  # replay sees the new contents
+    h2, a2, y2 = make(16)
+    put(a2, np.ones((16, 16), np.float32))
+    h2.run_with_hipgraph()
+    assert rt.hip_graph_capture_count() == 2 and rt.hip_graph_cache_size() == 2
+    h3, a3, y3 = make(4)
+    put(a3, np.ones((4, 4), np.float32))
+    h3.run_with_hipgraph()
+    assert rt.hip_graph_cache_size() == 2  # bounded LRU (capacity 2)
+    h1.run_with_hipgraph()  # evicted -> recaptured, still correct
+    assert rt.hip_graph_capture_count() == 4 and np.all(get(y1) == 4)
+    rt.clear_hip_graph_cache()
+    assert rt.hip_graph_cache_size() == 0
+
+
+def test_missing_kernel_is_a_loud_error(B, rocm):
+    h = B.GraphHandler(rocm)
+    x = h.tensor([2, 3, 4, 4], F32)
+    h.resize(x, None, None, h.tensor([4], I64), None, None, [2, 3, 8, 8], "nearest", "floor", "half_pixel") if False else None
+    # LRN has no ROCM kernel registered: running it must raise, not silently fall back
+    y = h.lrn(x, None, 0.1, 0.75, 1.0, 3)
+    h.data_malloc()
+    put(x, np.ones((2, 3, 4, 4), np.float32))
+    with pytest.raises(RuntimeError):
+        h.run()
