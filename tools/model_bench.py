@@ -1,0 +1,189 @@
+"""Graph-level benchmarks through the REFERENCE graph executor + the Device::ROCM plugin
+(BASELINE configs 3 and 4): the graphs are built op by op with backend.GraphHandler exactly as
+OnnxStub would emit them (onnx/onnxsim are not installed here): BN folded -> Conv + Add(bias) + Relu,
+MatMul + Add(bias), decomposed attention (MatMul, Div, Add(mask), Softmax, MatMul).
+
+  python tools/model_bench.py resnet50 [--batch 128] [--dtype f16]
+  python tools/model_bench.py bert     [--batch 32] [--seq 512] [--layers 12]
+
+Prints one JSON line per model: eager ms/run (host loop + launches + one sync) and hipGraph replay ms/run.
+Weights: N(0, sqrt(2/fan_in)) / N(0, 0.02), seed 0; inputs seeded. The parity of these graphs is
+covered by tests (tests/test_gpu_plugin.py, tests/test_gpu_models.py) on small slices.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
+sys.path.insert(0, str(REPO / "tests"))
+
+DT = {"f32": (1, np.float32), "f16": (10, np.float16)}
+
+
+def load_backend():
+    from conftest import load_backend_module
+
+    b = load_backend_module()
+    if b is None or not hasattr(b, "RocmRuntime"):
+        raise SystemExit("plugin build missing: run __graft_entry__.build() where /root/reference exists")
+    return b
+
+
+class Builder:
+    """Tiny helper that creates weight tensors and remembers what to copy in after data_malloc."""
+
+    def __init__(self, B, rt, dtype: str, seed: int = 0):
+        self.B, self.h = B, B.GraphHandler(rt)
+        self.code, self.np = DT[dtype]
+        self.rng = np.random.default_rng(seed)
+        self.feeds = []
+        self.flops = 0.0
+
+    def weight(self, shape, std):
+        t = self.h.tensor(list(shape), self.code)
+        t.set_weight()
+        self.feeds.append((t, (self.rng.standard_normal(shape) * std).astype(self.np)))
+        return t
+
+    def const(self, arr, code=None):
+        t = self.h.tensor(list(arr.shape), code or self.code)
+        t.set_weight()
+        self.feeds.append((t, arr))
+        return t
+
+    def input(self, arr, code=None):
+        t = self.h.tensor(list(arr.shape), code or self.code)
+        t.set_input()
+        self.feeds.append((t, arr))
+        return t
+
+    def finish(self):
+        self.h.data_malloc()
+        for t, a in self.feeds:
+            t.copyin_numpy(np.ascontiguousarray(a))
+
+
+def build_resnet50(bl: Builder, batch: int, image: int = 224):
+    h = bl.h
+
+    def conv_bn_act(x, cin, cout, k, stride, pad, relu=True, hw=None):
+        w = bl.weight((cout, cin, k, k), np.sqrt(2.0 / (cin * k * k)))
+        b = bl.weight((1, cout, 1, 1), 0.01)
+        y = h.conv(x, w, None, pad, pad, stride, stride, 1, 1)
+        oh = (hw + 2 * pad - k) // stride + 1
+        bl.flops += 2.0 * batch * cout * oh * oh * cin * k * k
+        y = h.add(y, b, None)
+        return (h.relu(y, None) if relu else y), oh
+
+    x = bl.input(bl.rng.uniform(0, 1, (batch, 3, image, image)).astype(bl.np))
+    y, hw = conv_bn_act(x, 3, 64, 7, 2, 3, hw=image)
+    y = h.maxPool(y, None, 3, 3, 1, 1, 1, 1, 2, 2, 0)
+    hw = (hw + 2 - 3) // 2 + 1
+    cin = 64
+    for width, blocks, stride in ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)):
+        for bi in range(blocks):
+            s = stride if bi == 0 else 1
+            idt = y
+            o, hw1 = conv_bn_act(y, cin, width, 1, 1, 0, hw=hw)
+            o, hw2 = conv_bn_act(o, width, width, 3, s, 1, hw=hw1)
+            o, hw3 = conv_bn_act(o, width, width * 4, 1, 1, 0, relu=False, hw=hw2)
+            if bi == 0:
+                idt, _ = conv_bn_act(y, cin, width * 4, 1, s, 0, relu=False, hw=hw)
+            y = h.relu(h.add(o, idt, None), None)
+            cin, hw = width * 4, hw3
+    y = h.avgPool(y, None, hw, hw, 1, 1, 0, 0, 1, 1, 0)
+    y = h.flatten(y, None, 1)
+    wfc = bl.weight((2048, 1000), np.sqrt(1.0 / 2048))
+    bfc = bl.weight((1000,), 0.01)
+    y = h.matmul(y, wfc, None, False, False, bfc, bl.B.ActType.Linear, "default")
+    bl.flops += 2.0 * batch * 2048 * 1000
+    return y
+
+
+def build_bert(bl: Builder, batch: int, seq: int, layers: int, hidden: int = 768, heads: int = 12, ffn: int = 3072,
+               vocab: int = 30522):
+    h, B = bl.h, bl.B
+    lin = B.ActType.Linear
+    D = hidden // heads
+    ids = bl.input(bl.rng.integers(0, vocab, (batch, seq)).astype(np.int64), 7)
+    emb = bl.weight((vocab, hidden), 0.02)
+    pos = bl.weight((1, seq, hidden), 0.02)
+    mask = bl.const(np.zeros((batch, 1, 1, seq), bl.np))
+    scale = bl.const(np.array([np.sqrt(D)], bl.np))
+    x = h.add(h.gather(emb, ids, None, 0), pos, None)
+
+    def ln(t):
+        return h.layerNormalization(t, bl.const(np.ones(hidden, bl.np)), None, bl.const(np.zeros(hidden, bl.np)), 1e-12, 2, 1)
+
+    def linear(t, cin, cout):
+        w = bl.weight((cin, cout), 0.02)
+        b = bl.weight((cout,), 0.02)
+        bl.flops += 2.0 * batch * seq * cin * cout
+        return h.matmul(t, w, None, False, False, b, lin, "default")
+
+    x = ln(x)
+    for _ in range(layers):
+        def heads_of(t):
+            return h.transpose(h.reshape(t, None, [batch, seq, heads, D]), None, [0, 2, 1, 3])
+        q, k, v = heads_of(linear(x, hidden, hidden)), heads_of(linear(x, hidden, hidden)), heads_of(linear(x, hidden, hidden))
+        s = h.matmul(q, k, None, False, True, None, lin, "default")
+        bl.flops += 2.0 * batch * heads * seq * seq * D * 2
+        s = h.add(h.div(s, scale, None), mask, None)
+        p = h.softmax(s, None, 3)
+        ctx = h.matmul(p, v, None, False, False, None, lin, "default")
+        ctx = h.reshape(h.transpose(ctx, None, [0, 2, 1, 3]), None, [batch, seq, hidden])
+        x = ln(h.add(x, linear(ctx, hidden, hidden), None))
+        f = linear(h.gelu(linear(x, hidden, ffn), None), ffn, hidden)
+        x = ln(h.add(x, f, None))
+    return x
+
+
+def timed(fn, iters, warm=2):
+    for _ in range(warm):
+        fn()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("model", choices=["resnet50", "bert"])
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--seq", type=int, default=512)
+    ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--dtype", default="f16")
+    ap.add_argument("--iters", type=int, default=10)
+    args = ap.parse_args()
+    B = load_backend()
+    rt = B.RocmRuntime(0)
+    bl = Builder(B, rt, args.dtype)
+    if args.model == "resnet50":
+        batch = args.batch or 128
+        out = build_resnet50(bl, batch)
+        name = f"ResNet-50 bs{batch} {args.dtype}"
+    else:
+        batch = args.batch or 32
+        out = build_bert(bl, batch, args.seq, args.layers)
+        name = f"BERT-base L{args.layers} bs{batch} seq{args.seq} {args.dtype}"
+    nops = len(bl.h.operators())
+    bl.finish()
+    eager = timed(bl.h.run, args.iters)
+    graph = timed(bl.h.run_with_hipgraph, args.iters)
+    y = out.copyout_numpy()
+    print(json.dumps({"model": name, "ops": nops, "gemm_conv_TFLOP": round(bl.flops / 1e12, 3),
+                      "eager_ms": round(eager, 3), "hipgraph_ms": round(graph, 3),
+                      "hipgraph_TFLOPs": round(bl.flops / graph / 1e9, 1),
+                      "per_unit": f"{batch / graph * 1e3:.0f} samples/s", "finite": bool(np.isfinite(y.astype(np.float32)).all())}))
+
+
+if __name__ == "__main__":
+    main()
