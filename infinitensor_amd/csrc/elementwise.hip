@@ -173,14 +173,23 @@ static int binary_launch(infiniRocmRuntime_t rt, const void *a, const void *b, v
     const bool last_ok = (sa[nd - 1] == 0 || sa[nd - 1] == 1) && (sb[nd - 1] == 0 || sb[nd - 1] == 1);
     if (last_ok && VMAX > 1) {
         vec = VMAX;
+        // only operands that are READ AS VECTORS (unit stride in the last dim) constrain the width:
+        // their outer strides and base must keep every vector aligned. A broadcast operand (last-dim
+        // stride 0, e.g. a [1,C,1,1] bias against [N,C,H,W]) is read as a scalar at any offset.
         auto ok = [&](int v) {
             if (shp[nd - 1] % v) return false;
-            for (int d = 0; d < nd - 1; ++d)
-                if ((sa[d] % v) || (sb[d] % v)) return false;
             const uintptr_t m = (uintptr_t)(v * sizeof(T)) - 1;
             if (((uintptr_t)c & m)) return false;
-            if (sa[nd - 1] == 1 && ((uintptr_t)a & m)) return false;
-            if (sb[nd - 1] == 1 && ((uintptr_t)b & m)) return false;
+            if (sa[nd - 1] == 1) {
+                if ((uintptr_t)a & m) return false;
+                for (int d = 0; d < nd - 1; ++d)
+                    if (sa[d] % v) return false;
+            }
+            if (sb[nd - 1] == 1) {
+                if ((uintptr_t)b & m) return false;
+                for (int d = 0; d < nd - 1; ++d)
+                    if (sb[d] % v) return false;
+            }
             return true;
         };
         while (vec > 1 && !ok(vec))

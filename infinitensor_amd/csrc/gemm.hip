@@ -340,6 +340,7 @@ __global__ __launch_bounds__(256) void gemm_fast128(GemmArgs p) {
 // implemented in gemm256.hip
 int launch_gemm256(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool a_kmajor, bool b_kmajor, int sched);
 bool gemm256_supported(const GemmArgs &p, bool a_kmajor, bool b_kmajor);
+int launch_gemm256m32(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool a_kmajor, bool b_kmajor);
 
 template <typename Tr> static int launch_fast128(infiniRocmRuntime_t rt, GemmArgs p, bool akm, bool bkm) {
     p.tiles_m = (int)ceil_div(p.m, f128::BM);
@@ -382,8 +383,8 @@ static bool fast128_supported(const GemmArgs &p, bool akm, bool bkm) {
     return true;
 }
 
-static const char *kVariantNames[] = {"generic64", "fast128_glds", "tile256_stagger", "tile256_pipelined"};
-constexpr int kNumVariants = 4;
+static const char *kVariantNames[] = {"generic64", "fast128_glds", "tile256_stagger", "tile256_pipelined", "tile256_mfma32"};
+constexpr int kNumVariants = 5;
 constexpr int kDefault256 = 2; // schedule used by the heuristic
 
 } // namespace irocm
@@ -449,6 +450,8 @@ int infini_rocm_matmul(infiniRocmRuntime_t rt, int dtype, const void *a, const v
         variant = 0;
     }
 
+    if (variant == 4)
+        return launch_gemm256m32(rt, dtype, p, akm, bkm);
     if (variant >= 2)
         return launch_gemm256(rt, dtype, p, akm, bkm, variant - 2);
     if (variant == 1)

@@ -1,0 +1,92 @@
+// Shared pieces of the 256x256x64 GEMM kernels (gemm256.hip: 16x16x32 MFMA; gemm256m32.hip: 32x32x16 MFMA).
+#pragma once
+#include "gemm_common.h"
+#include <type_traits>
+#include <utility>
+
+namespace irocm {
+namespace g256 {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int OPER_BYTES = 256 * 64 * 2;  // 32 KiB per operand tile
+constexpr int BUF_BYTES = 2 * OPER_BYTES; // A | B
+constexpr int LDS_BYTES = 2 * BUF_BYTES;  // 128 KiB
+
+template <typename F, int... I> __device__ __forceinline__ void sfor_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void sfor(F &&f) {
+    sfor_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+template <int OFF> __device__ __forceinline__ s16x8_t lds_read_b128(unsigned addr) {
+    s16x8_t v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+    return v;
+}
+template <int OFF> __device__ __forceinline__ s16x4_t lds_read_tr_b64(unsigned addr) {
+    s16x4_t v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+    return v;
+}
+// One MFMA operand fragment (8 x 16-bit). K-major: one ds_read_b128. M/N-major: two transpose reads
+// whose halves are only joined into one 128-bit value AFTER the lgkmcnt wait (a v_mov issued between the
+// asm read and the wait would copy stale registers: hipcc does not know the asm is a load).
+template <bool KMAJOR> struct Frag;
+template <> struct Frag<true> {
+    s16x8_t v;
+    __device__ __forceinline__ s16x8_t get() const { return v; }
+};
+template <> struct Frag<false> {
+    s16x4_t lo, hi;
+    __device__ __forceinline__ s16x8_t get() const {
+        return s16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+};
+
+__device__ __forceinline__ void wait_lgkm0() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void fence_sched() { __builtin_amdgcn_sched_barrier(0); }
+__device__ __forceinline__ void barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// ---- staging (LDS-DMA) -----------------------------------------------------------------------
+// K-major operand: 32 pieces of 8 rows; wave w issues pieces w*4 .. w*4+3.
+__device__ __forceinline__ void offs_k(unsigned (&off)[4], long ld, int row0, int rows, int w, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = w * 4 + i;
+        const int r = piece * 8 + (lane >> 3);
+        const int c_log = (lane & 7) ^ ((r >> 1) & 7);
+        int gr = row0 + r;
+        gr = gr < rows ? gr : rows - 1; // rows beyond the matrix re-read its last row; never stored
+        off[i] = (unsigned)(((long)gr * ld + c_log * 8) * 2);
+    }
+}
+// M/N-major operand: image [64 k][256 cols] (512-B rows), 32 pieces of 2 k-rows.
+__device__ __forceinline__ int mn_f(int kr) { return (kr & 3) | (((kr >> 3) & 1) << 2); }
+__device__ __forceinline__ void offs_mn(unsigned (&off)[4], long ld, int col0, int cols, int w, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = w * 4 + i;
+        const int kr = piece * 2 + (lane >> 5);
+        const int c_log = (lane & 31) ^ (mn_f(kr) << 1);
+        int gc = col0 + c_log * 8;
+        gc = gc <= cols - 8 ? gc : cols - 8;
+        off[i] = (unsigned)(((long)kr * ld + gc) * 2);
+    }
+}
+__device__ __forceinline__ void stage4(const char *ubase, const unsigned (&off)[4], char *lds_oper, int w) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds(IROCM_GLB_PTR(ubase + (unsigned long)off[i]),
+                                         IROCM_LDS_PTR(lds_oper + (w * 4 + i) * 1024), 16, 0, 0);
+}
+
+} // namespace g256
+} // namespace irocm
