@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--variant", type=int, default=-1, help="GEMM kernel variant (-1 = heuristic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-tp", action="store_true", help="skip the tensor-parallel block timing")
     return ap.parse_args()
 
 
@@ -144,6 +145,94 @@ def extras(rt, ops, Event) -> dict:
     return out
 
 
+def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
+    """BASELINE config 5: one Llama-7B-style decoder block (H=4096, 32 heads x 128, FFN 11008), tokens
+    B*S = 4*512 = 2048, fp16, Megatron tensor-parallel over `world` ranks (infinitensor_amd/tp.py, mirroring
+    examples/distributed/parallel_opt.py): qkv / gate / up column-parallel, o_proj / down row-parallel, ONE
+    RCCL all-reduce (16 MiB) after each row-parallel GEMM, on the runtime stream. RoPE is not applied (no
+    kernel yet: SURVEY 8f-2); it is element-wise and does not change the GEMM / collective structure.
+    Strong scaling: the block is fixed, the weights are sharded."""
+    import torch
+
+    from infinitensor_amd import tp
+
+    Bt, S, H, NH, D, F = 4, 512, 4096, 32, 128, 11008
+    T = Bt * S
+    nh = NH // world
+    dt = torch.float16
+    g = torch.Generator(device="cuda").manual_seed(7)  # same full weights on every rank, then sharded
+    rnd = lambda *shape: (torch.randn(*shape, device="cuda", generator=g) * 0.02).to(dt)
+    x = rnd(T, H)
+    wq, wk, wv = (tp.shard_column(rnd(H, H), world, rank)[0].contiguous() for _ in range(3))
+    wo = tp.shard_row(rnd(H, H), world, rank).contiguous()
+    wg, wu = (tp.shard_column(rnd(H, F), world, rank)[0].contiguous() for _ in range(2))
+    wd = tp.shard_row(rnd(F, H), world, rank).contiguous()
+    n1, n2 = torch.ones(H, device="cuda", dtype=dt), torch.ones(H, device="cuda", dtype=dt)
+    scale = torch.full((1,), float(D) ** 0.5, device="cuda", dtype=dt)
+    torch.cuda.synchronize()
+    # communicator: rank 0 creates the RCCL id, torch.distributed (already up) carries it
+    if world > 1:
+        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid = rt.comm_unique_id()
+            idt[: len(uid)] = torch.tensor(list(uid), dtype=torch.uint8)
+        dist_mod.broadcast(idt, 0)
+        rt.init_comm_with_id(bytes(idt.cpu().tolist()), world, rank)
+    else:
+        rt.init_comm_with_id(rt.comm_unique_id(), 1, 0)
+
+    def heads(t):  # [T, nh*D] -> [Bt*nh, S, D]
+        return ops.transpose(rt, t.view(Bt, S, nh, D), (0, 2, 1, 3)).view(Bt * nh, S, D)
+
+    def block():
+        h = ops.rms_norm(rt, x, n1, 1e-5)
+        q, k, v = heads(ops.matmul(rt, h, wq)), heads(ops.matmul(rt, h, wk)), heads(ops.matmul(rt, h, wv))
+        s = ops.binary(rt, "div", ops.matmul(rt, q, k, None, False, True), scale)
+        ctx = ops.matmul(rt, ops.softmax(rt, s, -1), v)
+        ctx = ops.transpose(rt, ctx.view(Bt, nh, S, D), (0, 2, 1, 3)).view(T, nh * D)
+        o = ops.matmul(rt, ctx, wo)
+        ops.all_reduce(rt, "sum", o, out=o)
+        x1 = ops.binary(rt, "add", x, o)
+        h2 = ops.rms_norm(rt, x1, n2, 1e-5)
+        a = ops.binary(rt, "mul", ops.unary(rt, "silu", ops.matmul(rt, h2, wg)), ops.matmul(rt, h2, wu))
+        d = ops.matmul(rt, a, wd)
+        ops.all_reduce(rt, "sum", d, out=d)
+        return ops.binary(rt, "add", x1, d)
+
+    for _ in range(3):
+        y = block()
+    rt.sync()
+    e0, e1 = Event(), Event()
+    iters = 20
+    rt.record(e0)
+    for _ in range(iters):
+        y = block()
+    rt.record(e1)
+    ms = rt.elapsed_ms(e0, e1) / iters
+    # all-reduce alone: 16 MiB fp16 message
+    buf = torch.zeros(T, H, device="cuda", dtype=dt)
+    for _ in range(3):
+        ops.all_reduce(rt, "sum", buf, out=buf)
+    rt.record(e0)
+    for _ in range(iters):
+        ops.all_reduce(rt, "sum", buf, out=buf)
+    rt.record(e1)
+    ar_ms = rt.elapsed_ms(e0, e1) / iters
+    nbytes = buf.numel() * 2
+    tmax = torch.tensor([ms, ar_ms], device="cuda", dtype=torch.float64)
+    if world > 1:
+        dist_mod.all_reduce(tmax, op=dist_mod.ReduceOp.MAX)
+    ms, ar_ms = (float(v) for v in tmax.tolist())
+    return {
+        "workload": "Llama-7B-style block, tokens 2048, fp16, TP=%d (2 all-reduces of 16 MiB)" % world,
+        "ms_per_block": round(ms, 4),
+        "gemm_TFLOPs_aggregate": round(tp.llama_block_flops(T, H, F, 1) / ms / 1e9, 1),
+        "allreduce_16MiB_ms": round(ar_ms, 4),
+        "allreduce_busbw_GBs": round(2 * (world - 1) / world * nbytes / (ar_ms * 1e-3) / 1e9, 1) if world > 1 else None,
+        "finite": bool(torch.isfinite(y.float()).all().item()),
+    }
+
+
 def main() -> int:
     args = parse()
     import torch
@@ -207,6 +296,13 @@ def main() -> int:
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    tp_res = None
+    if not args.no_tp:
+        try:  # never let the secondary measurement take the headline line down
+            tp_res = tp_block(rt, ops, Event, world, rank, td if dist else None)
+        except Exception as e:  # noqa: BLE001
+            tp_res = {"error": repr(e)[:300]}
+
     flop_per_step = 2.0 * M * N * K
     value = world * args.steps * flop_per_step / elapsed / 1e12
     achieved = flop_per_step / kernel_s / 1e12
@@ -254,6 +350,8 @@ def main() -> int:
                 line["cpu_standin_mkl"] = cpu_standin_mkl()
             except Exception as e:
                 line["cpu_standin_mkl"] = {"error": repr(e)}
+        if tp_res is not None:
+            line["tp_block"] = tp_res
         if world == 1 and not args.no_extras:
             try:
                 line["extras"] = extras(rt, ops, Event)
