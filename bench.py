@@ -334,7 +334,8 @@ def main() -> int:
                 "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                "traffic": None,
+                "traffic": pmc_traffic(),
+                "traffic_source": "profiles/r01_gemm256_v2_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel and shape; bytes per launch, FETCH_SIZE x2 per the gfx950 note)",
                 "kernel_us": round(kernel_s * 1e6, 3),
                 "peak_from_device": round(info["compute_units"] * 4096 * info["clock_mhz"] * 1e6 / 1e12, 1),
             },

@@ -179,6 +179,13 @@ int infini_rocm_layer_norm(infiniRocmRuntime_t rt, int dtype, const void *x, con
 int infini_rocm_rms_norm(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, void *y,
                          int64_t outer, int64_t norm_size, float eps);
 
+/* RoPE, rotate-half form (reference: _rope_kernel, src/kernels/cuda/rope.cu:6-31; glue rope.cc:8-33).
+ * x, y: [tokens, dim_model] with dim_model a multiple of dim_head; pos: one position per token
+ * (I32 / U32 / I64). The reference hard-codes dim_head = 128 and theta = 10000 and its launch covers a
+ * single (batch, position) (rope.cu:85): here every token is rotated. */
+int infini_rocm_rope(infiniRocmRuntime_t rt, int dtype, int pos_dtype, const void *pos, const void *x,
+                     void *y, int64_t tokens, int64_t dim_model, int64_t dim_head, float theta);
+
 /* ------------------------------------------------------------------------------------------ */
 /* Binary element-wise with numpy broadcasting                                                  */
 /* (reference: ElementWiseCudnn / ElementWiseCuda, src/kernels/cuda/element_wise.cc:13-175,     */

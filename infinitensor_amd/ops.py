@@ -203,6 +203,18 @@ def rms_norm(rt: RocmRuntime, x: torch.Tensor, weight: torch.Tensor, eps: float 
     return out
 
 
+def rope(rt: RocmRuntime, pos: torch.Tensor, x: torch.Tensor, dim_head: int = 128, theta: float = 10000.0,
+         out: torch.Tensor | None = None) -> torch.Tensor:
+    """RoPE(pos [B, S], x [B, S, dim_model]) (operators/rope.h; dim_head 128 / theta 1e4 as rope.cc:25)."""
+    if x.dim() != 3 or pos.dim() != 2 or tuple(pos.shape) != tuple(x.shape[:2]):
+        raise ValueError("rope expects pos [B, S] and x [B, S, dim_model]")  # reference: IT_ASSERT(nDims == 3 ...)
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().infini_rocm_rope(rt.handle, dtype_of(x), dtype_of(pos), _ptr(pos), _ptr(x), _ptr(out),
+                                 x.shape[0] * x.shape[1], x.shape[2], int(dim_head), float(theta)))
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # Element-wise
 # ------------------------------------------------------------------------------------------------

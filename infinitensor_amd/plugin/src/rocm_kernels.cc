@@ -21,6 +21,7 @@
 #include "operators/reduce.h"
 #include "operators/reshape.h"
 #include "operators/rms_norm.h"
+#include "operators/rope.h"
 #include "operators/send.h"
 #include "operators/slice.h"
 #include "operators/softmax.h"
@@ -166,6 +167,19 @@ class RMSNormRocm : public RocmKernelWithoutConfig {
     }
 };
 REGISTER_KERNEL(Device::ROCM, OpType::RMSNorm, RMSNormRocm, "RMSNorm_ROCM");
+
+class RoPERocm : public RocmKernelWithoutConfig {
+    void compute(const Operator &_op, const RuntimeObj *ctx) const override {
+        auto op = as<RoPEObj>(_op);
+        const auto pos = op->getInputs(0), x = op->getInputs(1);
+        const auto &d = x->getDims();
+        IT_ASSERT(d.size() == 3 && pos->getDims().size() == 2 && d[1] == pos->getDims()[1]); // rope.cc:21-22
+        // head dim 128 and theta 1e4 are hard-coded by the reference (rope.cc:25, rope.cu:18)
+        ROCM_CALL(infini_rocm_rope(H(ctx), DTI(x), DTI(pos), P(pos), P(x), P(op->getOutput()), (int64_t)d[0] * d[1],
+                                   d[2], 128, 10000.0f));
+    }
+};
+REGISTER_KERNEL(Device::ROCM, OpType::RoPE, RoPERocm, "RoPE_ROCM");
 
 // ---- element-wise binary -------------------------------------------------------------------------
 template <int OP> class BinaryRocm : public RocmKernelWithoutConfig {

@@ -258,3 +258,19 @@ def test_missing_kernel_is_a_loud_error(B, rocm):
     put(x, np.ones((2, 3, 4, 4), np.float32))
     with pytest.raises(RuntimeError):
         h.run()
+
+
+def test_rope_through_reference_executor(B, rocm):
+    """h.RoPE(pos, x) on Device::ROCM vs the oracle (head dim 128, theta 1e4 as rope.cc:25 / rope.cu:18), every
+    (batch, position) rotated; first 32 columns of a ones/position-1 row reproduce test_cuda_rope.cc:29."""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 9, 256)).astype(np.float32)
+    x[0, 1, :] = 0
+    x[0, 1, :32] = 1
+    pos = np.tile(np.arange(9, dtype=np.uint32), (2, 1))
+    U32 = 12
+    h, out = build(B, rocm, lambda h, t: h.RoPE(t[0], t[1], None), [((2, 9), U32, pos), ((2, 9, 256), F32, x)])
+    h.run()
+    got = get(out, (2, 9, 256))
+    assert np.allclose(got, R.rope(pos, x, 128), rtol=1e-4, atol=1e-5)
+    assert R.equal_data(got[0, 1, :32], kat(CU + "test_cuda_rope.cc", 29, "float"), 2e-6)

@@ -123,3 +123,23 @@ def test_empty_inputs_are_noops(rt):
     x = torch.empty((0, 16), device="cuda")
     assert ops.softmax(rt, x, 1).shape == (0, 16)
     assert ops.layer_norm(rt, x, torch.ones(16, device="cuda"), None, 1e-5, 1).shape == (0, 16)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+def test_rope_vs_oracle(rt, dt):
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((2, 37, 512)).astype(np.float32)
+    pos = np.tile(np.arange(37, dtype=np.int64) * 3, (2, 1))
+    for pdt in (np.int64, np.int32):
+        y = ops.rope(rt, dev(pos.astype(pdt)), dev(x, TD[dt]), 128)
+        want = R.rope(pos, R.round_to(x, dt), 128)
+        rtol, atol = TOL[dt]
+        assert np.allclose(host(y), want, rtol=rtol, atol=max(atol, 2e-4))
+
+
+def test_rope_reference_kat(rt):
+    """test_cuda_rope.cc:17-31 with the row zero-padded to one 128-wide head (see tests/test_oracle_nn.py)."""
+    x = np.zeros((1, 1, 128), np.float32)
+    x[..., :32] = 1
+    y = ops.rope(rt, dev(np.array([[1]], np.int32)), dev(x), 128)
+    assert R.equal_data(host(y)[0, 0, :32], kat("test/kernels/cuda/test_cuda_rope.cc", 29, "float"), 2e-6)

@@ -141,3 +141,12 @@ def test_concat_split_slice_pad_expand_kats():
     assert np.array_equal(y.ravel(), kat(CU + "test_cuda_pad.cc", 36, "float"))
     y = R.expand(R.incremental((2, 1, 2, 1)), (2, 2, 2, 3))
     assert np.array_equal(y.ravel(), kat(CU + "test_cuda_expand.cc", 37, "float"))
+
+
+def test_rope_kat():
+    """test_cuda_rope.cc:17-31: ones, position 1, dim_model 32 with the kernel's hard-coded head dim 128 — the
+    partner element x[j + 64] lies outside the row and reads as 0 there, i.e. the row zero-padded to one head."""
+    x = np.zeros((1, 1, 128))
+    x[..., :32] = 1.0
+    y = R.rope(np.array([[1]]), x, 128)
+    assert eq(y[0, 0, :32], kat(CU + "test_cuda_rope.cc", 29, "float"), 2e-6)
