@@ -265,6 +265,10 @@ int infini_rocm_conv2d(infiniRocmRuntime_t rt, int dtype, const void *x, const v
                        const void *bias, void *y, int64_t n, int64_t c, int64_t h, int64_t wd,
                        int64_t f, int64_t r, int64_t s, int ph, int pw, int sh, int sw, int dh, int dw,
                        int64_t groups, int act);
+/* Kernel choice for the next f16 / bf16 conv2d calls: -1 heuristic, 1 generic implicit GEMM only,
+ * 2 tap-shifted implicit GEMM (conv_s1) for every unit-stride same-size shape, 3 batched-GEMM route for every
+ * eligible pointwise shape. All variants compute the same sums (fp32 accumulate). Used by tune() and tests. */
+int infini_rocm_conv2d_set_variant(infiniRocmRuntime_t rt, int variant);
 
 /* ------------------------------------------------------------------------------------------ */
 /* ReduceSum / ReduceMean over arbitrary axes (reference: ReduceCudnnBase::compute,             */

@@ -92,6 +92,7 @@ struct infiniRocmRuntime {
     size_t workspace_bytes = 0;
     bool capturing = false;
     int matmul_variant = -1;
+    int conv_variant = -1;
     int num_cu = 256;
     void *comm = nullptr; // rcclComm_t, owned by comm.cc
     int comm_world = 1, comm_rank = 0;

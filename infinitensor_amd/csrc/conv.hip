@@ -31,6 +31,10 @@ extern "C" int infini_rocm_matmul(infiniRocmRuntime_t rt, int dtype, const void 
 
 namespace irocm {
 
+int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, const void *bias, void *y,
+                   int n, int c, int h, int wd, int f, int r, int s, int ph, int pw, int sh, int sw, int dh, int dw,
+                   int oh, int ow, int act); // conv_s1.hip
+
 struct ConvArgs {
     const void *x, *w, *bias;
     void *y;
@@ -295,12 +299,30 @@ int infini_rocm_conv2d(infiniRocmRuntime_t rt, int dtype, const void *x, const v
         IROCM_LAUNCH_CHECK("conv_direct32");
         return INFINI_ROCM_OK;
     }
+    const int variant = rt->conv_variant;
+    const bool same_s1 = sh == 1 && sw == 1 && dh == 1 && dw == 1 && groups == 1 && p.oh == p.h && p.ow == p.wd;
+    const bool pointwise_gemm = r == 1 && s == 1 && ph == 0 && pw == 0 && same_s1 && (p.npix % 8 == 0) && c % 64 == 0;
+    // big-plane pointwise layers with >= 256 filters are plain batched GEMMs (LDS-DMA kernels); everything else whose
+    // output extent is ceil(input / stride) goes to the tap-shifted implicit GEMM of conv_s1.hip (measured per
+    // ResNet-50 layer with tools/conv_bench.py)
+    // a single K-step leaves nothing to pipeline: the small generic tile (more workgroups per CU) hides the latency better
+    const bool one_kstep = (long)c * r * s <= 64 && f >= 128;
+    if (variant < 0 && one_kstep)
+        goto generic;
+    if (groups == 1 && variant != 1 && !(variant == 3 && pointwise_gemm) &&
+        (variant == 2 || !(pointwise_gemm && f >= 256 && c >= 128 && p.npix >= 512))) {
+        const int st = launch_conv_s1(rt, dtype, x, w, bias, y, (int)n, (int)c, (int)h, (int)wd, (int)f, (int)r, (int)s,
+                                      ph, pw, sh, sw, dh, dw, p.oh, p.ow, act);
+        if (st >= 0)
+            return st;
+    }
     // pointwise convolution == batched GEMM  Y[n] = W[F x C] . X[n][C x HW]  (A broadcast over batch)
-    if (r == 1 && s == 1 && ph == 0 && pw == 0 && sh == 1 && sw == 1 && groups == 1 && (p.npix % 8 == 0) &&
+    if (variant != 1 && r == 1 && s == 1 && ph == 0 && pw == 0 && sh == 1 && sw == 1 && groups == 1 && (p.npix % 8 == 0) &&
         c % 64 == 0) {
         return infini_rocm_matmul(rt, dtype, w, x, bias, y, n, f, p.npix, c, 0, 0, 0, (int64_t)c * p.npix,
                                   0, bias ? 1 : 0, 0, act);
     }
+generic:
     p.tiles_m = (int)ceil_div(p.fg, 128);
     p.tiles_p = (int)ceil_div(p.npix, 128);
     const long blocks = (long)n * groups * p.tiles_m * p.tiles_p;
@@ -310,6 +332,13 @@ int infini_rocm_conv2d(infiniRocmRuntime_t rt, int dtype, const void *x, const v
     else
         hipLaunchKernelGGL(conv_igemm16<F16Traits>, dim3((unsigned)blocks), dim3(256), 0, rt->stream, p);
     IROCM_LAUNCH_CHECK("conv_igemm16");
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_conv2d_set_variant(infiniRocmRuntime_t rt, int variant) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(variant >= -1 && variant <= 3, "conv2d: bad variant %d", variant);
+    rt->conv_variant = variant;
     return INFINI_ROCM_OK;
 }
 

@@ -1,0 +1,409 @@
+// conv_s1: the fast Conv2d path for gfx950 — unit-stride "same" convolutions (OH == H, OW == W,
+// dilation 1, groups 1, C % BK == 0) in f16 / bf16 as an implicit GEMM on MFMA, NCHW in, NCHW out,
+// no im2col buffer and no layout change of the activations in HBM.
+//
+// Replaces convCudnn for these shapes (reference: src/kernels/cuda/conv.cc:57-168); semantics as the
+// native CPU kernel src/kernels/cpu/conv.cc:25-50. ResNet-50's 3x3 and (small-plane) 1x1 layers land here.
+//
+// GEMM view:  Y[f, col] = sum_{rs} sum_{c} W'[rs][f][c] * X[img(col), c, pix(col) + (r - ph) * W + (s - pw)]
+//   * columns are "pixel slots": col = img * HWp + pix, HWp = H*W rounded up to 8, so a 16-byte run of 8
+//     slots never crosses an image and tiles span images (a 7x7 or 14x14 plane does not waste a tile).
+//     For a same-size unit-stride convolution the 8 input elements of a run are CONTIGUOUS in memory for
+//     every tap (r, s) — the tap only shifts the address — so the B operand is fetched with one 16-byte
+//     buffer load per run (2-byte aligned: measured on MI355X at 4.5 TB/s vs 6.4 TB/s aligned, tools/probes/
+//     bufprobe.hip) and the halo / zero padding is an 8-bit mask per (run, tap) built once per thread from
+//     row / column validity bit sets. Runs that would touch bytes outside the tensor are fetched by element.
+//   * K order is tap-major (rs outer, channel inner): the masks and the address shift change only every C/BK
+//     K-steps. Weights are re-packed once per call FCRS -> [RS][F][C] (tiny; K-major 16-byte runs).
+//   * tile BM x BN x BK with 4 waves of 64x64 (4 x 4 MFMA 16x16x32, swapped operands so a lane owns 4
+//     consecutive pixel slots of one filter): <2,2,64> = 128 x 128 x 64, <1,4,32> = 64 x 256 x 32 for F <= 64.
+//     A -> LDS [BM][BK + 8] (ds_read_b128), B -> LDS [BK][BN] XOR-swizzled, read with ds_read_b64_tr_b16.
+//     Register-staged double buffering: the global loads of K-step t+1 are in flight during the MFMAs of
+//     step t; one barrier per K-step; 2-3 workgroups per CU hide each other's barriers.
+//   * epilogue: + bias[f], activation, 8-byte stores of 4 pixels when the plane size allows.
+//   * strides > 1 (the ResNet down-sampling layers): a pre-pass de-interleaves X into the sh*sw "phase planes"
+//     Xp[py][px][n][c][OH][OW] = X[n][c][i*sh + py][j*sw + px] that some tap reads (1 of 4 for a 1x1/2, all 4 for a
+//     3x3/2); on a phase plane every tap is again a constant shift of a unit-stride same-size access, so the same
+//     kernel runs with a per-tap (plane, shift) pair. Needs OH == ceil(H / sh) and OW == ceil(W / sw).
+#include "gemm_common.h"
+
+namespace irocm {
+
+struct ConvS1Args {
+    const void *x, *w, *bias; // x: input or its phase planes; w: [RS][F][C]
+    void *y;
+    int nimg, c, f, r, s, ph, pw, sh, sw, dh, dw;
+    int in_h, in_w;  // input extent (padding validity)
+    int h, wd;       // plane extent = output extent
+    int hw, hwp, ncols;
+    int tiles_m, tiles_n;
+    int act;
+    unsigned x_bytes;    // bytes of everything behind x
+    long plane_elems;    // elements of one phase plane set [n][c][h][wd]
+    signed char slot[16]; // phase py*sw + px -> index of its plane set behind x
+};
+
+struct PhaseSplitArgs {
+    const unsigned short *x;
+    unsigned short *o;
+    long planes; // n * c
+    int in_h, in_w, oh, ow, sh, sw, nslots;
+    signed char py[16], px[16];
+};
+
+// o[slot][plane][i][j] = x[plane][i*sh + py][j*sw + px] (0 outside the input)
+__global__ __launch_bounds__(256) void conv_phase_split(PhaseSplitArgs a) {
+    const long per_slot = a.planes * a.oh * a.ow;
+    const long total = per_slot * a.nslots;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int sl = (int)(i / per_slot);
+        long q = i - (long)sl * per_slot;
+        const int j = (int)(q % a.ow);
+        q /= a.ow;
+        const int ii = (int)(q % a.oh);
+        const long pl = q / a.oh;
+        const int ih = ii * a.sh + a.py[sl], iw = j * a.sw + a.px[sl];
+        a.o[i] = (ih < a.in_h && iw < a.in_w) ? a.x[(pl * a.in_h + ih) * a.in_w + iw] : (unsigned short)0;
+    }
+}
+
+__global__ __launch_bounds__(256) void conv_repack_w(const unsigned short *__restrict__ w,
+                                                     unsigned short *__restrict__ o, int f, int c, int rs) {
+    // o[t][f][c] = w[f][c][t]
+    const long total = (long)f * c * rs;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cc = (int)(i % c);
+        const long q = i / c;
+        const int ff = (int)(q % f);
+        const int t = (int)(q / f);
+        o[i] = w[((long)ff * c + cc) * rs + t];
+    }
+}
+
+template <typename Tr, int WM, int WN, int BK>
+__global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args p) {
+    constexpr int BM = WM * 64, BN = WN * 64, APITCH = BK + 8;
+    constexpr int A_BYTES = BM * APITCH * 2, ROWB = BN * 2, B_BYTES = BK * ROWB, STAGE = A_BYTES + B_BYTES;
+    constexpr int NA = BM * (BK / 8) / 256;       // 16-byte A runs per thread per K-step
+    constexpr int CPR = BN / 8;                   // B runs per k-row
+    constexpr int KSTEP = 256 / CPR;              // k-rows covered by one pass of the workgroup
+    constexpr int NB = BK / KSTEP;                // B runs per thread per K-step
+    static_assert(WM * WN == 4 && NA >= 1 && NB >= 1, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wm = w / WN, wn = w % WN;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = wg % p.tiles_m, tn = wg / p.tiles_m; // filter tiles fastest: neighbours share the B tile
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const unsigned short *Wp = (const unsigned short *)p.w;
+    const __amdgpu_buffer_rsrc_t xrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.x), 0, (int)p.x_bytes, 0x00020000);
+
+    // ---- A staging assignment: run ch = t + i*256 -> row ch / (BK/8), k-chunk ch % (BK/8) ------------
+    long a_off[NA]; // element offset inside one tap's [F][C] matrix
+    int a_lds[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int ch = t + i * 256;
+        const int row = ch / (BK / 8), kc = (ch % (BK / 8)) * 8;
+        int gm = m0 + row;
+        gm = gm < p.f ? gm : p.f - 1; // rows past F re-read the last filter; never stored
+        a_off[i] = (long)gm * p.c + kc;
+        a_lds[i] = (row * APITCH + kc) * 2;
+    }
+    // ---- B staging assignment: one column run per thread, k-rows t / CPR + i * KSTEP ------------------
+    const int cchunk = t % CPR, krow0 = t / CPR;
+    const int col8 = n0 + cchunk * 8;
+    const int img = col8 / p.hwp, pp = col8 - img * p.hwp;
+    // validity bit sets: rowm bit (8*r + j) = pixel j of the run has input row oh + r - ph inside the image
+    unsigned long rowm = 0, colm = 0;
+    if (col8 < p.ncols) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int pix = pp + j;
+            if (pix < p.hw) {
+                const int oh = pix / p.wd, ow = pix - oh * p.wd;
+                for (int r = 0; r < p.r; ++r)
+                    if ((unsigned)(oh * p.sh + r * p.dh - p.ph) < (unsigned)p.in_h)
+                        rowm |= 1ul << (8 * r + j);
+                for (int s = 0; s < p.s; ++s)
+                    if ((unsigned)(ow * p.sw + s * p.dw - p.pw) < (unsigned)p.in_w)
+                        colm |= 1ul << (8 * s + j);
+            }
+        }
+    }
+    const int b_base = (int)((((long)img * p.c + krow0) * p.hw + pp) * 2); // bytes; x_bytes < 2^31
+    int b_lds[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int kr = krow0 + i * KSTEP;
+        b_lds[i] = kr * ROWB + ((cchunk ^ (f128::mn_f(kr) << 1)) * 16);
+    }
+
+    s16x8_t a_reg[NA];
+    u32x4_t b_reg[NB];
+    unsigned bm[4]; // and-masks of the runs held in b_reg
+    int tap = 0, rr = 0, ss = 0, cb = 0; // position of the NEXT K-step to load
+    int tap_shift = 0;                   // bytes
+    const long tap_stride = (long)p.f * p.c;
+    const int kstep_bytes = KSTEP * p.hw * 2;
+    auto set_tap = [&]() {
+        const unsigned m8 = (unsigned)((rowm >> (8 * rr)) & (colm >> (8 * ss)) & 0xff);
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            bm[d] = ((m8 >> (2 * d)) & 1u) * 0xffffu | ((m8 >> (2 * d + 1)) & 1u) * 0xffff0000u;
+        // tap -> (phase plane, shift inside it): input row oh*sh + dy = (oh + qy)*sh + py
+        const int dy = rr * p.dh - p.ph, dx = ss * p.dw - p.pw;
+        const int qy = dy >= 0 ? dy / p.sh : -((p.sh - 1 - dy) / p.sh), py = dy - qy * p.sh;
+        const int qx = dx >= 0 ? dx / p.sw : -((p.sw - 1 - dx) / p.sw), px = dx - qx * p.sw;
+        tap_shift = (int)(((long)p.slot[py * p.sw + px] * p.plane_elems + qy * p.wd + qx) * 2);
+    };
+    set_tap();
+    const int ncb = p.c / BK;
+    auto load_tile = [&]() {
+        const unsigned short *wsrc = Wp + (long)tap * tap_stride + cb * BK;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            a_reg[i] = *(const s16x8_t *)(wsrc + a_off[i]);
+        const int voff0 = b_base + cb * BK * p.hw * 2 + tap_shift;
+        const bool any = (bm[0] | bm[1] | bm[2] | bm[3]) != 0;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int voff = voff0 + i * kstep_bytes;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (any) {
+                if ((unsigned)voff <= p.x_bytes - 16) {
+                    v = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, 0, 0);
+                } else {
+                    // run straddles the start or the end of the tensor: the range check of a 16-byte load works on
+                    // whole (possibly misaligned) dwords and a negative offset voids all of it — fetch by element
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int eo = voff + 2 * j;
+                        const unsigned e = (unsigned)eo < p.x_bytes ? (unsigned)__builtin_amdgcn_raw_buffer_load_b16(xrs, eo, 0, 0) : 0u;
+                        v[j >> 1] |= e << ((j & 1) * 16);
+                    }
+                }
+            }
+            b_reg[i] = v;
+        }
+    };
+    auto advance = [&]() { // move (tap, cb) to the following K-step; masks follow the tap
+        if (++cb == ncb) {
+            cb = 0;
+            ++tap;
+            if (++ss == p.s) {
+                ss = 0;
+                ++rr;
+            }
+            set_tap();
+        }
+    };
+    auto store_tile = [&](char *stage, const unsigned (&m)[4]) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            *(s16x8_t *)(stage + a_lds[i]) = a_reg[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            u32x4_t v = b_reg[i];
+            v[0] &= m[0]; v[1] &= m[1]; v[2] &= m[2]; v[3] &= m[3];
+            *(u32x4_t *)(stage + A_BYTES + b_lds[i]) = v;
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // per-lane LDS fragment offsets
+    const int a_frag = ((wm * 64 + l15) * APITCH + g4 * 8) * 2; // + i*16*APITCH*2 + ks*64
+    int b_frag[2];                                              // [hh]: + ks*32*ROWB, XOR per (j) below
+    // tr-read: lane p supplies k-row g4*8 + hh*4 + (p >> 2), 4 columns (p & 3) * 4 of the 16-column block
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+        b_frag[hh] = (g4 * 8 + hh * 4 + (l15 >> 2)) * ROWB + (l15 & 1) * 8;
+    const int mnf_lane[2] = {f128::mn_f(g4 * 8 + (l15 >> 2)), f128::mn_f(g4 * 8 + 4 + (l15 >> 2))};
+
+    const int nk = p.r * p.s * ncb;
+    unsigned m_cur[4];
+    load_tile();
+#pragma unroll
+    for (int d = 0; d < 4; ++d) m_cur[d] = bm[d];
+    advance();
+    store_tile(smem, m_cur);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const char *cur = smem + (kt & 1) * STAGE;
+        char *nxt = smem + ((kt + 1) & 1) * STAGE;
+        if (kt + 1 < nk) {
+            load_tile(); // in flight during the MFMAs below
+#pragma unroll
+            for (int d = 0; d < 4; ++d) m_cur[d] = bm[d];
+            advance();
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            s16x8_t af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                af[i] = *(const s16x8_t *)(cur + a_frag + i * 16 * APITCH * 2 + ks * 64);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cblk = (wn * 64 + j * 16) >> 3; // 16-byte chunk index of the block's first column
+                s16x4_t h[2];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    // k-row bits 5.. (ks) do not enter mn_f: the lane's swizzle term is K-step invariant
+                    const int c16 = (cblk + ((l15 >> 1) & 1)) ^ (mnf_lane[hh] << 1);
+                    const char *addr = cur + A_BYTES + ks * 32 * ROWB + b_frag[hh] + c16 * 16;
+                    h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t *)(addr));
+                }
+                bf[j] = s16x8_t{h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = Tr::mfma(bf[j], af[i], acc[i][j]);
+        }
+        if (kt + 1 < nk)
+            store_tile(nxt, m_cur);
+        __syncthreads();
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------
+    unsigned short *Y = (unsigned short *)p.y;
+    const unsigned short *bias = (const unsigned short *)p.bias;
+    const bool vec_ok = (p.hw % 4 == 0) && ((((uintptr_t)p.y) & 7) == 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn * 64 + j * 16 + g4 * 4;
+        if (col >= p.ncols)
+            continue;
+        const int im = col / p.hwp, pix = col - im * p.hwp;
+        if (pix >= p.hw)
+            continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int fm = m0 + wm * 64 + i * 16 + l15;
+            if (fm >= p.f)
+                continue;
+            const float bv = bias ? Tr::to_f32(bias[fm]) : 0.f;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                v[r] = apply_act(acc[i][j][r] + bv, p.act);
+            unsigned short *dst = Y + ((long)im * p.f + fm) * p.hw + pix;
+            if (vec_ok && pix + 3 < p.hw) {
+                u32x2_t pk;
+                pk[0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
+                pk[1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
+                *(u32x2_t *)dst = pk;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (pix + r < p.hw)
+                        dst[r] = Tr::from_f32(v[r]);
+            }
+        }
+    }
+}
+
+template <typename Tr, int WM, int WN, int BK> static int launch_s1(infiniRocmRuntime_t rt, ConvS1Args &p) {
+    constexpr int BM = WM * 64, BN = WN * 64;
+    constexpr int LDS = 2 * (BM * (BK + 8) * 2 + BK * BN * 2);
+    p.tiles_m = (int)ceil_div(p.f, BM);
+    p.tiles_n = (int)ceil_div(p.ncols, BN);
+    const long blocks = (long)p.tiles_m * p.tiles_n;
+    IROCM_CHECK_ARG(blocks < (1l << 31), "conv2d: too many tiles");
+    auto kern = conv_s1_kernel<Tr, WM, WN, BK>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        IROCM_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), LDS, rt->stream, p);
+    IROCM_LAUNCH_CHECK("conv_s1");
+    return INFINI_ROCM_OK;
+}
+
+// Returns -1 when the shape is not a conv_s1 shape (caller falls through to the generic kernel).
+int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, const void *bias, void *y,
+                   int n, int c, int h, int wd, int f, int r, int s, int ph, int pw, int sh, int sw, int dh, int dw,
+                   int oh, int ow, int act) {
+    if (r > 7 || s > 7 || c % 32 != 0 || ((uintptr_t)w & 15) != 0 || ((uintptr_t)x & 3) != 0)
+        return -1;
+    if (sh * sw > 16 || oh != (h + sh - 1) / sh || ow != (wd + sw - 1) / sw)
+        return -1;
+    ConvS1Args p;
+    p.x = x; p.w = w; p.bias = bias; p.y = y;
+    p.nimg = n; p.c = c; p.f = f; p.r = r; p.s = s; p.ph = ph; p.pw = pw;
+    p.sh = sh; p.sw = sw; p.dh = dh; p.dw = dw;
+    p.in_h = h; p.in_w = wd; p.h = oh; p.wd = ow;
+    p.hw = oh * ow;
+    p.hwp = (p.hw + 7) & ~7;
+    if ((long)n * p.hwp >= (1l << 31))
+        return -1;
+    p.ncols = n * p.hwp;
+    p.act = act;
+    p.plane_elems = (long)n * c * p.hw;
+    // phases read by some tap
+    PhaseSplitArgs ps;
+    ps.nslots = 0;
+    for (int i = 0; i < 16; ++i)
+        p.slot[i] = -1;
+    for (int rr = 0; rr < r; ++rr)
+        for (int ss = 0; ss < s; ++ss) {
+            const int py = ((rr * dh - ph) % sh + sh) % sh, px = ((ss * dw - pw) % sw + sw) % sw;
+            if (p.slot[py * sw + px] < 0) {
+                ps.py[ps.nslots] = (signed char)py;
+                ps.px[ps.nslots] = (signed char)px;
+                p.slot[py * sw + px] = (signed char)ps.nslots++;
+            }
+        }
+    const bool split = sh * sw > 1;
+    const long x_bytes = p.plane_elems * 2 * (split ? ps.nslots : 1);
+    if (x_bytes >= (1l << 31) - 64)
+        return -1;
+    p.x_bytes = (unsigned)x_bytes;
+    // workspace: [ re-packed weights | phase planes ]
+    const size_t w_bytes = r * s > 1 ? (((size_t)f * c * r * s * 2 + 255) & ~(size_t)255) : 0;
+    const size_t ws_bytes = w_bytes + (split ? (size_t)x_bytes : 0);
+    char *ws = nullptr;
+    if (ws_bytes) {
+        int st = infini_rocm_workspace(rt, ws_bytes, (void **)&ws);
+        if (st != INFINI_ROCM_OK)
+            return st;
+    }
+    if (w_bytes) { // FCRS -> [RS][F][C]
+        long g = ceil_div((long)f * c * r * s, 256);
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(conv_repack_w, dim3((unsigned)g), dim3(256), 0, rt->stream, (const unsigned short *)w,
+                           (unsigned short *)ws, f, c, r * s);
+        IROCM_LAUNCH_CHECK("conv_repack_w");
+        p.w = ws;
+    }
+    if (split) {
+        ps.x = (const unsigned short *)x;
+        ps.o = (unsigned short *)(ws + w_bytes);
+        ps.planes = (long)n * c;
+        ps.in_h = h; ps.in_w = wd; ps.oh = oh; ps.ow = ow; ps.sh = sh; ps.sw = sw;
+        long g = ceil_div(p.plane_elems * ps.nslots, 256);
+        if (g > (long)rt->num_cu * 32) g = (long)rt->num_cu * 32;
+        hipLaunchKernelGGL(conv_phase_split, dim3((unsigned)g), dim3(256), 0, rt->stream, ps);
+        IROCM_LAUNCH_CHECK("conv_phase_split");
+        p.x = ps.o;
+    }
+    const bool bf = dtype == INFINI_DT_BF16;
+    if (f <= 64 || c % 64 != 0)
+        return bf ? launch_s1<Bf16Traits, 1, 4, 32>(rt, p) : launch_s1<F16Traits, 1, 4, 32>(rt, p);
+    return bf ? launch_s1<Bf16Traits, 2, 2, 64>(rt, p) : launch_s1<F16Traits, 2, 2, 64>(rt, p);
+}
+
+} // namespace irocm

@@ -154,6 +154,11 @@ def set_matmul_variant(rt: RocmRuntime, variant: int) -> None:
     check(lib().infini_rocm_matmul_set_variant(rt.handle, int(variant)))
 
 
+def set_conv_variant(rt: RocmRuntime, variant: int) -> None:
+    """-1 heuristic, 1 generic implicit GEMM, 2 conv_s1 wherever eligible, 3 batched-GEMM route for pointwise."""
+    check(lib().infini_rocm_conv2d_set_variant(rt.handle, int(variant)))
+
+
 def matmul_variants() -> list[str]:
     n = lib().infini_rocm_matmul_num_variants()
     return [lib().infini_rocm_matmul_variant_name(i).decode() for i in range(n)]

@@ -64,6 +64,64 @@ def test_conv_vs_oracle(rt, cfg, dt):
     assert np.allclose(host(y), want, rtol=tol, atol=tol)
 
 
+S1_CONVS = [
+    # unit-stride same-size shapes of conv_s1.hip: n, c, h, w, f, r, s
+    (5, 64, 7, 7, 64, 3, 3),      # 49-pixel planes: slots padded to 56, tile spans images, scalar stores
+    (3, 128, 14, 14, 200, 3, 3),  # 196-pixel planes, ragged filter count (two 128-row tiles)
+    (2, 32, 5, 9, 40, 3, 3),      # C = 32 -> BK 32 tile, odd plane
+    (2, 96, 12, 10, 72, 5, 5),    # 5x5 pad 2, C % 64 != 0
+    (1, 64, 1, 1, 16, 3, 3),      # 1x1 plane: every tap but the centre is padding
+    (2, 64, 3, 17, 130, 1, 7),    # 1x7 window
+    (4, 256, 14, 14, 64, 1, 1),   # pointwise, F <= 64 tile
+    (1, 64, 56, 56, 64, 3, 3),    # ResNet stage-1 3x3
+    (130, 64, 2, 2, 8, 3, 3),     # many tiny images per tile
+    # strided: phase planes (conv_phase_split); n, c, h, w, f, r, s, sh, sw, dh, dw
+    (3, 64, 14, 14, 96, 3, 3, 2, 2, 1, 1),    # ResNet 3x3/2 (all four phases)
+    (2, 128, 28, 28, 256, 1, 1, 2, 2, 1, 1),  # ResNet 1x1/2 down-sample (one phase)
+    (2, 32, 7, 9, 40, 3, 3, 2, 2, 1, 1),      # odd extents: last phase row / column is padding
+    (2, 32, 9, 10, 24, 5, 3, 3, 2, 1, 1),     # stride 3 x 2
+    (2, 64, 11, 11, 70, 3, 3, 1, 1, 2, 2),    # dilation 2, same size (pad 2)
+    (1, 32, 13, 8, 16, 7, 7, 2, 2, 1, 1),     # 7x7/2 pad 3
+]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("cfg", S1_CONVS)
+def test_conv_s1_vs_oracle_and_generic_kernel(rt, cfg, dt):
+    n, c, h, w, f, r, s, sh, sw, dh, dw = cfg + (1, 1, 1, 1) if len(cfg) == 7 else cfg
+    ph, pw = (r - 1) * dh // 2, (s - 1) * dw // 2
+    rng = np.random.default_rng(abs(hash(cfg)) % 2 ** 32)
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((f, c, r, s)) / np.sqrt(c * r * s)).astype(np.float32)
+    b = rng.standard_normal((f,)).astype(np.float32)
+    xd, wd, bd = dev(x, TD[dt]), dev(wt, TD[dt]), dev(b, TD[dt])
+    try:
+        ops.set_conv_variant(rt, 2)
+        y = ops.conv2d(rt, xd, wd, ph, pw, sh, sw, dh, dw, bias=bd, act=1)
+        ops.set_conv_variant(rt, 1)
+        yg = ops.conv2d(rt, xd, wd, ph, pw, sh, sw, dh, dw, bias=bd, act=1)
+    finally:
+        ops.set_conv_variant(rt, -1)
+    want = np.maximum(R.conv2d(R.round_to(x, dt), R.round_to(wt, dt), ph, pw, sh, sw, dh, dw) + R.round_to(b, dt).reshape(1, f, 1, 1), 0)
+    tol = {"f16": 2e-3, "bf16": 1.6e-2}[dt]
+    assert np.allclose(host(y), want, rtol=tol, atol=tol)
+    # same products, fp32 accumulation in a different order: the two kernels agree to rounding of the output type
+    assert np.allclose(host(y), host(yg), rtol=tol, atol=tol)
+
+
+def test_conv_s1_zero_padding_is_exact(rt):
+    """An all-ones 3x3 over an all-ones image counts the taps inside the image: 4 / 6 / 9 exactly."""
+    x = torch.ones((2, 64, 6, 7), dtype=torch.float16).cuda()
+    w = torch.ones((3, 64, 3, 3), dtype=torch.float16).cuda()
+    ops.set_conv_variant(rt, 2)
+    try:
+        y = host(ops.conv2d(rt, x, w, 1, 1))
+    finally:
+        ops.set_conv_variant(rt, -1)
+    cnt = R.conv2d(np.ones((1, 1, 6, 7)), np.ones((1, 1, 3, 3)), 1, 1, 1, 1, 1, 1)[0, 0]
+    assert np.array_equal(y, np.broadcast_to(cnt * 64, y.shape))
+
+
 def test_conv_fused_bias_relu_equals_unfused_chain(rt):
     """Fusion must be invisible: conv(bias, relu) == relu(conv + bias) computed op by op."""
     rng = np.random.default_rng(4)

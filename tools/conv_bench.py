@@ -1,0 +1,83 @@
+"""Per-layer Conv2d timing on the GPU (ResNet-50 bs128 layer shapes), per kernel variant.
+
+  python tools/conv_bench.py [--batch 128] [--dtype f16] [--variants -1,1,2,3] [--iters 10]
+Prints one line per distinct layer: shape, GFLOP, and for each variant ms and TFLOP/s (HIP events on the
+runtime's stream), then the total over the whole network weighted by layer multiplicity.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from infinitensor_amd import RocmRuntime, ops  # noqa: E402
+from infinitensor_amd.runtime import Event  # noqa: E402
+
+# (count, C, H, F, R, stride, pad)
+RESNET50 = [
+    (1, 3, 224, 64, 7, 2, 3),
+    # stage 1 (56x56)
+    (1, 64, 56, 64, 1, 1, 0), (3, 64, 56, 64, 3, 1, 1), (4, 64, 56, 256, 1, 1, 0), (2, 256, 56, 64, 1, 1, 0),
+    # stage 2
+    (1, 256, 56, 128, 1, 1, 0), (1, 128, 56, 128, 3, 2, 1), (4, 128, 28, 512, 1, 1, 0), (1, 256, 56, 512, 1, 2, 0),
+    (3, 512, 28, 128, 1, 1, 0), (3, 128, 28, 128, 3, 1, 1),
+    # stage 3
+    (1, 512, 28, 256, 1, 1, 0), (1, 256, 28, 256, 3, 2, 1), (6, 256, 14, 1024, 1, 1, 0), (1, 512, 28, 1024, 1, 2, 0),
+    (5, 1024, 14, 256, 1, 1, 0), (5, 256, 14, 256, 3, 1, 1),
+    # stage 4
+    (1, 1024, 14, 512, 1, 1, 0), (1, 512, 14, 512, 3, 2, 1), (3, 512, 7, 2048, 1, 1, 0), (1, 1024, 14, 2048, 1, 2, 0),
+    (2, 2048, 7, 512, 1, 1, 0), (2, 512, 7, 512, 3, 1, 1),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--dtype", default="f16")
+    ap.add_argument("--variants", default="-1,1,2,3")
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--layers", default="", help="comma-separated indices into the layer table (default: all)")
+    args = ap.parse_args()
+    dt = {"f16": torch.float16, "bf16": torch.bfloat16}[args.dtype]
+    rt = RocmRuntime(0)
+    variants = [int(v) for v in args.variants.split(",")]
+    totals = {v: 0.0 for v in variants}
+    tot_flop = 0.0
+    table = [RESNET50[int(i)] for i in args.layers.split(",")] if args.layers else RESNET50
+    for cnt, c, h, f, r, st, pad in table:
+        x = torch.randn((args.batch, c, h, h), device="cuda").to(dt)
+        w = (torch.randn((f, c, r, r), device="cuda") / (c * r * r) ** 0.5).to(dt)
+        b = torch.randn((f,), device="cuda").to(dt)
+        oh = (h + 2 * pad - r) // st + 1
+        y = torch.empty((args.batch, f, oh, oh), device="cuda", dtype=dt)
+        flop = 2.0 * args.batch * f * oh * oh * c * r * r
+        tot_flop += flop * cnt
+        line = f"x{cnt} C{c:<4d} {h:>3d}x{h:<3d} F{f:<4d} {r}x{r}/s{st} {flop / 1e9:8.2f} GF |"
+        if os.environ.get("CONV_BENCH_PTRS"):
+            print(f"x {x.data_ptr():#x}+{x.numel() * 2:#x} w {w.data_ptr():#x} b {b.data_ptr():#x} y {y.data_ptr():#x}+{y.numel() * 2:#x} "
+                  f"ws {rt.workspace(1):#x}", flush=True)
+        torch.cuda.synchronize()
+        for v in variants:
+            ops.set_conv_variant(rt, v)
+            for _ in range(2):
+                ops.conv2d(rt, x, w, pad, pad, st, st, bias=b, act=1, out=y)
+            e0, e1 = Event(), Event()
+            rt.record(e0)
+            for _ in range(args.iters):
+                ops.conv2d(rt, x, w, pad, pad, st, st, bias=b, act=1, out=y)
+            rt.record(e1)
+            rt.sync()
+            ms = rt.elapsed_ms(e0, e1) / args.iters
+            totals[v] += ms * cnt
+            line += f" v{v}: {ms * 1e3:8.1f} us {flop / ms / 1e9:7.1f} TF |"
+        print(line, flush=True)
+    ops.set_conv_variant(rt, -1)
+    print("network conv total: " + "  ".join(f"v{v}: {t:.3f} ms ({tot_flop / t / 1e9:.1f} TF/s)" for v, t in totals.items()))
+
+
+if __name__ == "__main__":
+    main()
