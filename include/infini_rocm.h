@@ -206,7 +206,8 @@ typedef enum {
     INFINI_BIN_GREATER = 8,
     INFINI_BIN_GREATER_EQUAL = 9,
     INFINI_BIN_LESS = 10,
-    INFINI_BIN_LESS_EQUAL = 11
+    INFINI_BIN_LESS_EQUAL = 11,
+    INFINI_BIN_ADD_RELU = 12 /* max(a + b, 0): the fused residual join (Add -> Relu), bit-identical to the chain */
 } infiniRocmBinaryOp_t;
 
 int infini_rocm_binary(infiniRocmRuntime_t rt, int op, int dtype, const void *a, const void *b,

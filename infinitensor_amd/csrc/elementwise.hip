@@ -72,7 +72,10 @@ template <int OP, typename A> __device__ inline A bin_op(A x, A y) {
     else if constexpr (OP == INFINI_BIN_GREATER) return (A)(x > y);
     else if constexpr (OP == INFINI_BIN_GREATER_EQUAL) return (A)(x >= y);
     else if constexpr (OP == INFINI_BIN_LESS) return (A)(x < y);
-    else return (A)(x <= y);
+    else if constexpr (OP == INFINI_BIN_ADD_RELU) {
+        const A v = x + y;
+        return v > (A)0 ? v : (A)0;
+    } else return (A)(x <= y);
 }
 
 struct BinArgs {
@@ -235,7 +238,7 @@ static int binary_op_dispatch(infiniRocmRuntime_t rt, int op, const void *a, con
         CASE(INFINI_BIN_ADD) CASE(INFINI_BIN_SUB) CASE(INFINI_BIN_MUL) CASE(INFINI_BIN_DIV)
         CASE(INFINI_BIN_POW) CASE(INFINI_BIN_MIN) CASE(INFINI_BIN_MAX) CASE(INFINI_BIN_EQUAL)
         CASE(INFINI_BIN_GREATER) CASE(INFINI_BIN_GREATER_EQUAL) CASE(INFINI_BIN_LESS)
-        CASE(INFINI_BIN_LESS_EQUAL)
+        CASE(INFINI_BIN_LESS_EQUAL) CASE(INFINI_BIN_ADD_RELU)
 #undef CASE
     default:
         IROCM_FAIL(INFINI_ROCM_INVALID_ARGUMENT, "binary: unknown op %d", op);

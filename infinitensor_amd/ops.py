@@ -225,7 +225,7 @@ def rope(rt: RocmRuntime, pos: torch.Tensor, x: torch.Tensor, dim_head: int = 12
 # ------------------------------------------------------------------------------------------------
 BINARY_OPS = {
     "add": 0, "sub": 1, "mul": 2, "div": 3, "pow": 4, "min": 5, "max": 6,
-    "equal": 7, "greater": 8, "greater_equal": 9, "less": 10, "less_equal": 11,
+    "equal": 7, "greater": 8, "greater_equal": 9, "less": 10, "less_equal": 11, "add_relu": 12,
 }
 UNARY_OPS = {
     "relu": 0, "sigmoid": 1, "tanh": 2, "abs": 3, "sqrt": 4, "gelu": 5, "silu": 6, "neg": 7,

@@ -70,6 +70,8 @@ PATCHES = [
      "        .def(\"hip_graph_cache_size\", &RocmRuntimeObj::getHipGraphCacheSize)\n"
      "        .def(\"hip_graph_capture_count\", &RocmRuntimeObj::getHipGraphCaptureCount)\n"
      "        .def(\"sync\", &RocmRuntimeObj::sync)\n"
+     "        .def(\"set_fusion\", &RocmRuntimeObj::setFusion)\n"
+     "        .def(\"get_fusion\", &RocmRuntimeObj::getFusion)\n"
      "        .def(\"init_comm\", &RocmRuntimeObj::initComm);\n"
      "#endif\n"
      "#ifdef USE_BANG\n    py::class_<BangRuntimeObj, std::shared_ptr<BangRuntimeObj>, RuntimeObj>("),

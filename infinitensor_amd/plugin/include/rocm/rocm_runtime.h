@@ -50,6 +50,11 @@ class RocmRuntimeObj : public RuntimeObj {
     void *getWorkspace(size_t size) const;
     infiniRocmRuntime_t handle() const { return rt; }
 
+    // launch-time fusion of element-wise tails into the producing kernel (src/rocm_fusion.cc); default on,
+    // INFINI_ROCM_FUSION=0 in the environment turns it off at construction
+    void setFusion(bool on);
+    bool getFusion() const { return fusion; }
+
     void initComm(const string &name, int worldSize, int rank) final;
     CommunicatorObj &getCommunicator() const final;
 
@@ -84,6 +89,8 @@ class RocmRuntimeObj : public RuntimeObj {
     using Cache = std::list<std::unique_ptr<CacheEntry>>;
 
     void launchAll(const Graph &graph, bool validate) const;
+    // launches ops[i .. i+k) as one kernel when a fusion rule applies; returns k (0 = no rule)
+    size_t tryLaunchFused(const OpVec &ops, size_t i) const;
     void tuneImpl(const Graph &graph, bool profiling) const;
     GraphState stateOf(const Graph &graph) const;
     void replay(CacheEntry &entry);
@@ -92,6 +99,7 @@ class RocmRuntimeObj : public RuntimeObj {
     std::unique_ptr<CommunicatorObj> comm;
     size_t cacheCapacity;
     size_t captureCount = 0;
+    bool fusion = true;
     Cache cache; // most recently used first
     mutable std::recursive_mutex executionMutex;
     mutable std::recursive_mutex cacheMutex;

@@ -1,4 +1,5 @@
 #include "rocm/rocm_runtime.h"
+#include <cstdlib>
 #include "core/graph.h"
 #include "core/kernel.h"
 #include "core/perf_engine.h"
@@ -18,6 +19,16 @@ void rocmCheck(int status, const char *what) {
 RocmRuntimeObj::RocmRuntimeObj(int deviceId, size_t hipGraphCacheCapacity)
     : RuntimeObj(Device::ROCM, deviceId), cacheCapacity(hipGraphCacheCapacity) {
     ROCM_CALL(infini_rocm_runtime_create(deviceId, &rt));
+    if (const char *e = std::getenv("INFINI_ROCM_FUSION"))
+        fusion = std::string(e) != "0";
+}
+
+void RocmRuntimeObj::setFusion(bool on) {
+    std::lock_guard<std::recursive_mutex> lock(executionMutex);
+    if (on != fusion) {
+        fusion = on;
+        clearHipGraphCache(); // captured launch sequences embed the fusion decisions
+    }
 }
 
 RocmRuntimeObj::~RocmRuntimeObj() {
@@ -72,7 +83,22 @@ void RocmRuntimeObj::launchAll(const Graph &graph, bool validate) const {
         graph->validateMemory();
     const auto &registry = KernelRegistry::getInstance();
     auto &perfEngine = PerfEngine::getInstance();
-    for (auto &op : graph->getOperators()) {
+    const OpVec &ops = graph->getOperators();
+    for (size_t i = 0; i < ops.size(); ++i) {
+        const Operator &op = ops[i];
+        if (fusion) {
+            size_t fused = 0;
+            try {
+                fused = tryLaunchFused(ops, i);
+            } catch (Exception &e) {
+                e << " while launching (fused) " << op->toString();
+                throw;
+            }
+            if (fused) {
+                i += fused - 1;
+                continue;
+            }
+        }
         auto attrs = KernelAttrs{device, op->getOpType().underlying()};
         Kernel *kernel = registry.getKernel(attrs);
         auto perfKey = PerfEngine::Key{attrs, op->getOpPerfKey()};

@@ -140,3 +140,15 @@ def test_cast_reference_kat_and_pairs(rt):
     bf = ops.cast(rt, dev(np.random.default_rng(0).standard_normal(1000).astype(np.float32)), torch.bfloat16)
     want = R.f32_to_bf16_bits(np.random.default_rng(0).standard_normal(1000).astype(np.float32))
     assert np.array_equal(bf.view(torch.int16).cpu().numpy().view(np.uint16), want)  # bit-exact RNE
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+def test_add_relu_is_bit_identical_to_the_chain(rt, dt):
+    """INFINI_BIN_ADD_RELU (the fused residual join) == relu(add(a, b)) bit for bit: rounding is monotonic."""
+    rng = np.random.default_rng(14)
+    a = dev(rng.standard_normal((3, 64, 14, 14)).astype(np.float32), TD[dt])
+    b = dev(rng.standard_normal((3, 64, 14, 14)).astype(np.float32), TD[dt])
+    fused = ops.binary(rt, "add_relu", a, b)
+    chain = ops.unary(rt, "relu", ops.binary(rt, "add", a, b))
+    assert torch.equal(fused, chain)
+    assert np.array_equal(host(fused), np.maximum(host(ops.binary(rt, "add", a, b)), 0))

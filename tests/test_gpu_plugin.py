@@ -274,3 +274,59 @@ def test_rope_through_reference_executor(B, rocm):
     got = get(out, (2, 9, 256))
     assert np.allclose(got, R.rope(pos, x, 128), rtol=1e-4, atol=1e-5)
     assert R.equal_data(got[0, 1, :32], kat(CU + "test_cuda_rope.cc", 29, "float"), 2e-6)
+
+
+def _resblock(h, t):
+    """conv -> add(bias) -> relu -> conv -> add(bias) -> add(identity) -> relu, as onnx.py emits a folded-BN block."""
+    y = h.relu(h.add(h.conv(t[0], t[1], None, 1, 1, 1, 1, 1, 1), t[2], None), None)
+    z = h.add(h.conv(y, t[3], None, 1, 1, 1, 1, 1, 1), t[4], None)
+    return h.relu(h.add(z, t[0], None), None)
+
+
+@pytest.mark.parametrize("code,npdt", [(F32, np.float32), (F16, np.float16)])
+def test_fusion_is_invisible(B, rocm, code, npdt):
+    """Launch-time fusion (rocm_fusion.cc) vs one kernel per operator vs the reference's native-CPU runtime."""
+    rng = np.random.default_rng(11)
+    c = 32
+    ins = [((2, c, 9, 10), code, rng.standard_normal((2, c, 9, 10)).astype(npdt)),
+           ((c, c, 3, 3), code, (rng.standard_normal((c, c, 3, 3)) / 17).astype(npdt)),
+           ((1, c, 1, 1), code, rng.standard_normal((1, c, 1, 1)).astype(npdt)),
+           ((c, c, 3, 3), code, (rng.standard_normal((c, c, 3, 3)) / 17).astype(npdt)),
+           ((1, c, 1, 1), code, rng.standard_normal((1, c, 1, 1)).astype(npdt))]
+    got = {}
+    try:
+        for on in (True, False):
+            rocm.set_fusion(on)
+            assert rocm.get_fusion() == on
+            h, out = build(B, rocm, _resblock, ins)
+            h.run()
+            got[on] = get(out).astype(np.float64)
+    finally:
+        rocm.set_fusion(True)
+    if code == F32:
+        assert np.array_equal(got[True], got[False])  # same operations in the same order
+        hc, outc = build(B, B.cpu_runtime(), _resblock, ins)
+        hc.run()
+        assert np.allclose(got[True], get(outc), rtol=1e-4, atol=1e-5)
+    else:
+        assert np.allclose(got[True], got[False], rtol=2e-3, atol=2e-3)
+        x, w1, b1, w2, b2 = [a.astype(np.float64) for _, _, a in ins]
+        y = np.maximum(R.conv2d(x, w1, 1, 1, 1, 1, 1, 1) + b1, 0)
+        want = np.maximum(R.conv2d(y, w2, 1, 1, 1, 1, 1, 1) + b2 + x, 0)
+        assert np.allclose(got[True], want, rtol=4e-3, atol=4e-3)
+
+
+def test_fusion_keeps_tensors_that_someone_else_reads(B, rocm):
+    """The conv output feeds the bias-add AND a second consumer: it must be materialised (no fusion across it)."""
+    rng = np.random.default_rng(12)
+    ins = [((1, 32, 6, 6), F32, rng.standard_normal((1, 32, 6, 6)).astype(np.float32)),
+           ((32, 32, 3, 3), F32, (rng.standard_normal((32, 32, 3, 3)) / 17).astype(np.float32)),
+           ((1, 32, 1, 1), F32, rng.standard_normal((1, 32, 1, 1)).astype(np.float32))]
+
+    def fn(h, t):
+        y = h.conv(t[0], t[1], None, 1, 1, 1, 1, 1, 1)
+        a = h.relu(h.add(y, t[2], None), None)
+        return h.mul(a, y, None)
+
+    got, want = run_both(B, rocm, fn, ins)
+    assert np.allclose(got, want, rtol=1e-4, atol=1e-5)
