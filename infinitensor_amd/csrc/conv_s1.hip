@@ -21,6 +21,9 @@
 //     Register-staged double buffering: the global loads of K-step t+1 are in flight during the MFMAs of
 //     step t; one barrier per K-step; 2-3 workgroups per CU hide each other's barriers.
 //   * epilogue: + bias[f], activation, 8-byte stores of 4 pixels when the plane size allows.
+//   * ROWTAP variant for channel counts that are not a multiple of 32 (the 3-channel 7x7/2 stem): K is the flat
+//     index k = tap * C + c padded to 32, weights are re-packed to [F][Kpad], and every B row carries its own
+//     (plane, shift, mask) — decoded per row per K-step, which is cheap next to the 16 MFMAs it feeds.
 //   * strides > 1 (the ResNet down-sampling layers): a pre-pass de-interleaves X into the sh*sw "phase planes"
 //     Xp[py][px][n][c][OH][OW] = X[n][c][i*sh + py][j*sw + px] that some tap reads (1 of 4 for a 1x1/2, all 4 for a
 //     3x3/2); on a phase plane every tap is again a constant shift of a unit-stride same-size access, so the same
@@ -38,6 +41,7 @@ struct ConvS1Args {
     int hw, hwp, ncols;
     int tiles_m, tiles_n;
     int act;
+    int kdim, kpad;      // ROWTAP: C*R*S and its round-up to 32 (w is [F][kpad])
     unsigned x_bytes;    // bytes of everything behind x
     long plane_elems;    // elements of one phase plane set [n][c][h][wd]
     signed char slot[16]; // phase py*sw + px -> index of its plane set behind x
@@ -80,7 +84,19 @@ __global__ __launch_bounds__(256) void conv_repack_w(const unsigned short *__res
     }
 }
 
-template <typename Tr, int WM, int WN, int BK>
+// o[f][t*c + cc] = w[f][cc][t], zero for k in [c*rs, kpad)
+__global__ __launch_bounds__(256) void conv_repack_w_flat(const unsigned short *__restrict__ w,
+                                                          unsigned short *__restrict__ o, int f, int c, int rs, int kpad) {
+    const long total = (long)f * kpad;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int k = (int)(i % kpad);
+        const int ff = (int)(i / kpad);
+        const int t = k / c, cc = k - t * c;
+        o[i] = k < c * rs ? w[((long)ff * c + cc) * rs + t] : (unsigned short)0;
+    }
+}
+
+template <typename Tr, int WM, int WN, int BK, bool ROWTAP>
 __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args p) {
     constexpr int BM = WM * 64, BN = WN * 64, APITCH = BK + 8;
     constexpr int A_BYTES = BM * APITCH * 2, ROWB = BN * 2, B_BYTES = BK * ROWB, STAGE = A_BYTES + B_BYTES;
@@ -111,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args p) {
         const int row = ch / (BK / 8), kc = (ch % (BK / 8)) * 8;
         int gm = m0 + row;
         gm = gm < p.f ? gm : p.f - 1; // rows past F re-read the last filter; never stored
-        a_off[i] = (long)gm * p.c + kc;
+        a_off[i] = (long)gm * (ROWTAP ? p.kpad : p.c) + kc;
         a_lds[i] = (row * APITCH + kc) * 2;
     }
     // ---- B staging assignment: one column run per thread, k-rows t / CPR + i * KSTEP ------------------
@@ -135,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args p) {
             }
         }
     }
-    const int b_base = (int)((((long)img * p.c + krow0) * p.hw + pp) * 2); // bytes; x_bytes < 2^31
+    const int b_base = (int)((((long)img * p.c + (ROWTAP ? 0 : krow0)) * p.hw + pp) * 2); // bytes; x_bytes < 2^31
     int b_lds[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -145,54 +161,87 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args p) {
 
     s16x8_t a_reg[NA];
     u32x4_t b_reg[NB];
-    unsigned bm[4]; // and-masks of the runs held in b_reg
+    unsigned bm[4];        // and-masks of the runs held in b_reg (one tap per K-step)
+    unsigned m8row[NB];    // ROWTAP: 8-bit validity per row
     int tap = 0, rr = 0, ss = 0, cb = 0; // position of the NEXT K-step to load
+    int kl = 0;                          // ROWTAP: index of the next K-step to load
     int tap_shift = 0;                   // bytes
     const long tap_stride = (long)p.f * p.c;
     const int kstep_bytes = KSTEP * p.hw * 2;
-    auto set_tap = [&]() {
-        const unsigned m8 = (unsigned)((rowm >> (8 * rr)) & (colm >> (8 * ss)) & 0xff);
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-            bm[d] = ((m8 >> (2 * d)) & 1u) * 0xffffu | ((m8 >> (2 * d + 1)) & 1u) * 0xffff0000u;
-        // tap -> (phase plane, shift inside it): input row oh*sh + dy = (oh + qy)*sh + py
-        const int dy = rr * p.dh - p.ph, dx = ss * p.dw - p.pw;
+    // tap -> (phase plane, shift inside it) in bytes: input row oh*sh + dy = (oh + qy)*sh + py
+    auto shift_of = [&](int r_, int s_) {
+        const int dy = r_ * p.dh - p.ph, dx = s_ * p.dw - p.pw;
         const int qy = dy >= 0 ? dy / p.sh : -((p.sh - 1 - dy) / p.sh), py = dy - qy * p.sh;
         const int qx = dx >= 0 ? dx / p.sw : -((p.sw - 1 - dx) / p.sw), px = dx - qx * p.sw;
-        tap_shift = (int)(((long)p.slot[py * p.sw + px] * p.plane_elems + qy * p.wd + qx) * 2);
+        return (int)(((long)p.slot[py * p.sw + px] * p.plane_elems + qy * p.wd + qx) * 2);
+    };
+    auto expand = [&](unsigned m8, unsigned (&m)[4]) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            m[d] = ((m8 >> (2 * d)) & 1u) * 0xffffu | ((m8 >> (2 * d + 1)) & 1u) * 0xffff0000u;
+    };
+    auto set_tap = [&]() {
+        if constexpr (!ROWTAP) {
+            expand((unsigned)((rowm >> (8 * rr)) & (colm >> (8 * ss)) & 0xff), bm);
+            tap_shift = shift_of(rr, ss);
+        }
     };
     set_tap();
     const int ncb = p.c / BK;
-    auto load_tile = [&]() {
-        const unsigned short *wsrc = Wp + (long)tap * tap_stride + cb * BK;
+    auto fetch_run = [&](int voff, bool any) {
+        u32x4_t v = {0u, 0u, 0u, 0u};
+        if (any) {
+            if ((unsigned)voff <= p.x_bytes - 16) {
+                v = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, 0, 0);
+            } else {
+                // run straddles the start or the end of the tensor: the range check of a 16-byte load works on
+                // whole (possibly misaligned) dwords and a negative offset voids all of it — fetch by element
 #pragma unroll
-        for (int i = 0; i < NA; ++i)
-            a_reg[i] = *(const s16x8_t *)(wsrc + a_off[i]);
-        const int voff0 = b_base + cb * BK * p.hw * 2 + tap_shift;
-        const bool any = (bm[0] | bm[1] | bm[2] | bm[3]) != 0;
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int voff = voff0 + i * kstep_bytes;
-            u32x4_t v = {0u, 0u, 0u, 0u};
-            if (any) {
-                if ((unsigned)voff <= p.x_bytes - 16) {
-                    v = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, 0, 0);
-                } else {
-                    // run straddles the start or the end of the tensor: the range check of a 16-byte load works on
-                    // whole (possibly misaligned) dwords and a negative offset voids all of it — fetch by element
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int eo = voff + 2 * j;
-                        const unsigned e = (unsigned)eo < p.x_bytes ? (unsigned)__builtin_amdgcn_raw_buffer_load_b16(xrs, eo, 0, 0) : 0u;
-                        v[j >> 1] |= e << ((j & 1) * 16);
-                    }
+                for (int j = 0; j < 8; ++j) {
+                    const int eo = voff + 2 * j;
+                    const unsigned e = (unsigned)eo < p.x_bytes ? (unsigned)__builtin_amdgcn_raw_buffer_load_b16(xrs, eo, 0, 0) : 0u;
+                    v[j >> 1] |= e << ((j & 1) * 16);
                 }
             }
-            b_reg[i] = v;
+        }
+        return v;
+    };
+    auto load_tile = [&]() {
+        if constexpr (ROWTAP) {
+            const unsigned short *wsrc = Wp + kl * BK;
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                a_reg[i] = *(const s16x8_t *)(wsrc + a_off[i]);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int k = kl * BK + krow0 + i * KSTEP;
+                unsigned m8 = 0;
+                int voff = 0;
+                if (k < p.kdim) {
+                    const int tp = k / p.c, cc = k - tp * p.c;
+                    const int r_ = tp / p.s, s_ = tp - r_ * p.s;
+                    m8 = (unsigned)((rowm >> (8 * r_)) & (colm >> (8 * s_)) & 0xff);
+                    voff = b_base + cc * p.hw * 2 + shift_of(r_, s_);
+                }
+                m8row[i] = m8;
+                b_reg[i] = fetch_run(voff, m8 != 0);
+            }
+        } else {
+            const unsigned short *wsrc = Wp + (long)tap * tap_stride + cb * BK;
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                a_reg[i] = *(const s16x8_t *)(wsrc + a_off[i]);
+            const int voff0 = b_base + cb * BK * p.hw * 2 + tap_shift;
+            const bool any = (bm[0] | bm[1] | bm[2] | bm[3]) != 0;
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                b_reg[i] = fetch_run(voff0 + i * kstep_bytes, any);
         }
     };
-    auto advance = [&]() { // move (tap, cb) to the following K-step; masks follow the tap
-        if (++cb == ncb) {
+    auto advance = [&]() { // move to the following K-step; masks follow the tap
+        if constexpr (ROWTAP) {
+            ++kl;
+        } else if (++cb == ncb) {
             cb = 0;
             ++tap;
             if (++ss == p.s) {
@@ -209,7 +258,13 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args p) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             u32x4_t v = b_reg[i];
-            v[0] &= m[0]; v[1] &= m[1]; v[2] &= m[2]; v[3] &= m[3];
+            if constexpr (ROWTAP) {
+                unsigned mr[4];
+                expand(m8row[i], mr);
+                v[0] &= mr[0]; v[1] &= mr[1]; v[2] &= mr[2]; v[3] &= mr[3];
+            } else {
+                v[0] &= m[0]; v[1] &= m[1]; v[2] &= m[2]; v[3] &= m[3];
+            }
             *(u32x4_t *)(stage + A_BYTES + b_lds[i]) = v;
         }
     };
@@ -230,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args p) {
         b_frag[hh] = (g4 * 8 + hh * 4 + (l15 >> 2)) * ROWB + (l15 & 1) * 8;
     const int mnf_lane[2] = {f128::mn_f(g4 * 8 + (l15 >> 2)), f128::mn_f(g4 * 8 + 4 + (l15 >> 2))};
 
-    const int nk = p.r * p.s * ncb;
+    const int nk = ROWTAP ? p.kpad / BK : p.r * p.s * ncb;
     unsigned m_cur[4];
     load_tile();
 #pragma unroll
@@ -315,14 +370,15 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args p) {
     }
 }
 
-template <typename Tr, int WM, int WN, int BK> static int launch_s1(infiniRocmRuntime_t rt, ConvS1Args &p) {
+template <typename Tr, int WM, int WN, int BK, bool ROWTAP = false>
+static int launch_s1(infiniRocmRuntime_t rt, ConvS1Args &p) {
     constexpr int BM = WM * 64, BN = WN * 64;
     constexpr int LDS = 2 * (BM * (BK + 8) * 2 + BK * BN * 2);
     p.tiles_m = (int)ceil_div(p.f, BM);
     p.tiles_n = (int)ceil_div(p.ncols, BN);
     const long blocks = (long)p.tiles_m * p.tiles_n;
     IROCM_CHECK_ARG(blocks < (1l << 31), "conv2d: too many tiles");
-    auto kern = conv_s1_kernel<Tr, WM, WN, BK>;
+    auto kern = conv_s1_kernel<Tr, WM, WN, BK, ROWTAP>;
     static bool attr_done = false;
     if (!attr_done) {
         IROCM_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -337,8 +393,9 @@ template <typename Tr, int WM, int WN, int BK> static int launch_s1(infiniRocmRu
 int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, const void *bias, void *y,
                    int n, int c, int h, int wd, int f, int r, int s, int ph, int pw, int sh, int sw, int dh, int dw,
                    int oh, int ow, int act) {
-    if (r > 7 || s > 7 || c % 32 != 0 || ((uintptr_t)w & 15) != 0 || ((uintptr_t)x & 3) != 0)
+    if (r > 7 || s > 7 || ((uintptr_t)w & 15) != 0 || ((uintptr_t)x & 3) != 0)
         return -1;
+    const bool rowtap = c % 32 != 0;
     if (sh * sw > 16 || oh != (h + sh - 1) / sh || ow != (wd + sw - 1) / sw)
         return -1;
     ConvS1Args p;
@@ -373,7 +430,10 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
         return -1;
     p.x_bytes = (unsigned)x_bytes;
     // workspace: [ re-packed weights | phase planes ]
-    const size_t w_bytes = r * s > 1 ? (((size_t)f * c * r * s * 2 + 255) & ~(size_t)255) : 0;
+    p.kdim = c * r * s;
+    p.kpad = (p.kdim + 31) & ~31;
+    const size_t w_bytes = rowtap ? (((size_t)f * p.kpad * 2 + 255) & ~(size_t)255)
+                                  : (r * s > 1 ? (((size_t)f * c * r * s * 2 + 255) & ~(size_t)255) : 0);
     const size_t ws_bytes = w_bytes + (split ? (size_t)x_bytes : 0);
     char *ws = nullptr;
     if (ws_bytes) {
@@ -381,7 +441,14 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
         if (st != INFINI_ROCM_OK)
             return st;
     }
-    if (w_bytes) { // FCRS -> [RS][F][C]
+    if (rowtap) { // FCRS -> [F][Kpad], k = tap * C + c
+        long g = ceil_div((long)f * p.kpad, 256);
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(conv_repack_w_flat, dim3((unsigned)g), dim3(256), 0, rt->stream, (const unsigned short *)w,
+                           (unsigned short *)ws, f, c, r * s, p.kpad);
+        IROCM_LAUNCH_CHECK("conv_repack_w_flat");
+        p.w = ws;
+    } else if (w_bytes) { // FCRS -> [RS][F][C]
         long g = ceil_div((long)f * c * r * s, 256);
         if (g > 4096) g = 4096;
         hipLaunchKernelGGL(conv_repack_w, dim3((unsigned)g), dim3(256), 0, rt->stream, (const unsigned short *)w,
@@ -401,6 +468,8 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
         p.x = ps.o;
     }
     const bool bf = dtype == INFINI_DT_BF16;
+    if (rowtap)
+        return bf ? launch_s1<Bf16Traits, 1, 4, 32, true>(rt, p) : launch_s1<F16Traits, 1, 4, 32, true>(rt, p);
     if (f <= 64 || c % 64 != 0)
         return bf ? launch_s1<Bf16Traits, 1, 4, 32>(rt, p) : launch_s1<F16Traits, 1, 4, 32>(rt, p);
     return bf ? launch_s1<Bf16Traits, 2, 2, 64>(rt, p) : launch_s1<F16Traits, 2, 2, 64>(rt, p);

@@ -10,7 +10,8 @@
 //   * the ops are CONSECUTIVE in the graph's operator order and each intermediate tensor has exactly one
 //     consumer (so it is not a graph output and nobody else reads it);
 //   * the buffer of the final tensor does not overlap an input of the fused kernel — the memory planner reuses
-//     dead tensors' storage, and the fused kernel writes the final tensor earlier than the unfused chain would;
+//     dead tensors' storage, and the fused kernel writes the final tensor earlier than the unfused chain would
+//     (exception: Add -> Relu exactly in place over a same-extent input, which is index-wise safe);
 //   * same dtype throughout. Intermediate tensors are simply not materialised.
 // Numerics: fp32 is bit-identical (same operations in the same order); f16 / bf16 round once instead of after
 // every op (a result at least as close to the exact value); Add -> Relu is bit-identical in every type.
@@ -98,9 +99,15 @@ size_t RocmRuntimeObj::tryLaunchFused(const OpVec &ops, size_t i) const {
     if (type == OpType::Add && i + 1 < ops.size() && ops[i + 1]->getOpType() == OpType::Relu &&
         soleConsumerIs(op->getOutput(), ops[i + 1])) {
         const Tensor a = op->getInputs(0), b = op->getInputs(1), out = ops[i + 1]->getOutput();
-        if (!(a->getDType() == b->getDType()) || overlaps(out, a) || overlaps(out, b))
-            return 0;
         const auto &od = op->getOutput()->getDims();
+        // element-wise with identical extents may run exactly in place (the planner likes to give the Relu output the
+        // storage of a dead Add input); any other overlap is a hazard
+        auto hazard = [&](const Tensor &t) {
+            const bool inPlace = t->getRawDataPtr<void *>() == out->getRawDataPtr<void *>() && t->getDims() == od;
+            return overlaps(out, t) && !inPlace;
+        };
+        if (!(a->getDType() == b->getDType()) || hazard(a) || hazard(b))
+            return 0;
         const auto shape = std::vector<int64_t>(od.begin(), od.end());
         const auto sa = strides64(a->getDims(), od), sb = strides64(b->getDims(), od);
         ROCM_CALL(infini_rocm_binary(rt, INFINI_BIN_ADD_RELU, a->getDTypeIndex(), a->getRawDataPtr<void *>(),

@@ -82,6 +82,11 @@ S1_CONVS = [
     (2, 32, 9, 10, 24, 5, 3, 3, 2, 1, 1),     # stride 3 x 2
     (2, 64, 11, 11, 70, 3, 3, 1, 1, 2, 2),    # dilation 2, same size (pad 2)
     (1, 32, 13, 8, 16, 7, 7, 2, 2, 1, 1),     # 7x7/2 pad 3
+    # ROWTAP (C % 32 != 0): flat K = tap * C + c padded to 32
+    (2, 3, 32, 32, 64, 7, 7, 2, 2, 1, 1),     # ResNet stem
+    (2, 48, 9, 9, 20, 3, 3),                  # 48 channels
+    (2, 5, 11, 7, 70, 3, 5, 2, 1, 1, 1),      # 5 channels, 70 filters (two filter tiles), stride 2 x 1
+    (3, 1, 6, 6, 8, 1, 1),                    # K = 1
 ]
 
 
