@@ -40,11 +40,26 @@ def parse():
     ap.add_argument("--variant", type=int, default=-1, help="GEMM kernel variant (-1 = heuristic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="skip the ResNet-50 graph-latency row")
     ap.add_argument("--no-tp", action="store_true", help="skip the tensor-parallel block timing")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
-def cpu_baseline_reference(budget_s: float = 12.0) -> dict | None:
+def cpu_baseline_reference() -> dict | None:
+    """Runs _cpu_baseline_worker in a fresh interpreter: only one copy of the reference's pybind module can live in a
+    process, and this one may already hold the plugin build (graph_resnet50)."""
+    import subprocess
+
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--cpu-baseline-worker"], capture_output=True, text=True,
+                       timeout=300)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") or ln == "null"]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError(f"cpu baseline worker failed rc={r.returncode}: {r.stderr[-300:]}")
+    return json.loads(lines[-1])
+
+
+def _cpu_baseline_worker(budget_s: float = 12.0) -> dict | None:
     """Reference native-CPU MatMul (src/kernels/cpu/matmul.cc:6-25, naive ijk, one thread, fp32 — it has
     no bf16 kernel) on the first `rows` rows of the 4096^3 problem, sized to ~budget_s seconds."""
     import importlib.util
@@ -145,6 +160,25 @@ def extras(rt, ops, Event) -> dict:
     return out
 
 
+def graph_resnet50(local_rank: int, world: int, dist_mod) -> dict:
+    """BASELINE config 3: ResNet-50 bs128 fp16 per GPU through the REFERENCE graph executor + the Device::ROCM plugin
+    (tools/model_bench.py; hipGraph replay). Data-parallel inference has no collective: N replicas, max-over-ranks."""
+    import torch
+
+    sys.path.insert(0, str(REPO / "tools"))
+    from model_bench import run_model
+
+    r = run_model("resnet50", local_rank, 128, iters=10)
+    ms = torch.tensor([r["hipgraph_ms"], r["eager_ms"]], device="cuda", dtype=torch.float64)
+    if world > 1:
+        dist_mod.all_reduce(ms, op=dist_mod.ReduceOp.MAX)
+    g, e = (float(v) for v in ms.tolist())
+    return {"workload": f"ResNet-50 bs128 fp16 per GPU x {world} replicas, reference executor + ROCM plugin, launch-time fusion "
+                        + ("on" if r["fusion"] else "off"),
+            "hipgraph_ms": round(g, 3), "eager_ms": round(e, 3), "samples_per_s": round(world * 128 / g * 1e3, 0),
+            "conv_gemm_TFLOPs_aggregate": round(world * r["gemm_conv_TFLOP"] / g * 1e3, 1), "ops": r["ops"], "finite": r["finite"]}
+
+
 def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
     """BASELINE config 5: one Llama-7B-style decoder block (H=4096, 32 heads x 128, FFN 11008), tokens
     B*S = 4*512 = 2048, fp16, Megatron tensor-parallel over `world` ranks (infinitensor_amd/tp.py, mirroring
@@ -233,8 +267,20 @@ def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
     }
 
 
+def pmc_traffic():
+    """HBM-side bytes per GEMM launch from the committed PMC passes (tools/profile_gemm.sh); None if absent."""
+    p = REPO / "profiles" / "r01_gemm256_v2_pmc.json"
+    try:
+        return float(json.loads(p.read_text())["traffic_bytes_per_launch"])
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def main() -> int:
     args = parse()
+    if args.cpu_baseline_worker:
+        print(json.dumps(_cpu_baseline_worker()), flush=True)
+        return 0
     import torch
 
     from infinitensor_amd import RocmRuntime, ops
@@ -303,6 +349,13 @@ def main() -> int:
         except Exception as e:  # noqa: BLE001
             tp_res = {"error": repr(e)[:300]}
 
+    rn_res = None
+    if not args.no_graph:
+        try:
+            rn_res = graph_resnet50(local_rank, world, td if dist else None)
+        except BaseException as e:  # noqa: BLE001  (SystemExit when the plugin build is absent)
+            rn_res = {"error": repr(e)[:300]}
+
     flop_per_step = 2.0 * M * N * K
     value = world * args.steps * flop_per_step / elapsed / 1e12
     achieved = flop_per_step / kernel_s / 1e12
@@ -353,6 +406,8 @@ def main() -> int:
                 line["cpu_standin_mkl"] = {"error": repr(e)}
         if tp_res is not None:
             line["tp_block"] = tp_res
+        if rn_res is not None:
+            line["graph_resnet50"] = rn_res
         if world == 1 and not args.no_extras:
             try:
                 line["extras"] = extras(rt, ops, Event)

@@ -154,6 +154,30 @@ def timed(fn, iters, warm=2):
     return (time.perf_counter() - t0) / iters * 1e3
 
 
+def run_model(model: str, device: int = 0, batch: int | None = None, seq: int = 512, layers: int = 12,
+              dtype: str = "f16", iters: int = 10) -> dict:
+    B = load_backend()
+    rt = B.RocmRuntime(device)
+    bl = Builder(B, rt, dtype)
+    if model == "resnet50":
+        batch = batch or 128
+        out = build_resnet50(bl, batch)
+        name = f"ResNet-50 bs{batch} {dtype}"
+    else:
+        batch = batch or 32
+        out = build_bert(bl, batch, seq, layers)
+        name = f"BERT-base L{layers} bs{batch} seq{seq} {dtype}"
+    nops = len(bl.h.operators())
+    bl.finish()
+    eager = timed(bl.h.run, iters)
+    graph = timed(bl.h.run_with_hipgraph, iters)
+    y = out.copyout_numpy()
+    return {"model": name, "ops": nops, "fusion": bool(rt.get_fusion()), "gemm_conv_TFLOP": round(bl.flops / 1e12, 3),
+            "eager_ms": round(eager, 3), "hipgraph_ms": round(graph, 3),
+            "hipgraph_TFLOPs": round(bl.flops / graph / 1e9, 1), "batch": batch,
+            "per_unit": f"{batch / graph * 1e3:.0f} samples/s", "finite": bool(np.isfinite(y.astype(np.float32)).all())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("model", choices=["resnet50", "bert"])
@@ -163,26 +187,7 @@ def main():
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--iters", type=int, default=10)
     args = ap.parse_args()
-    B = load_backend()
-    rt = B.RocmRuntime(0)
-    bl = Builder(B, rt, args.dtype)
-    if args.model == "resnet50":
-        batch = args.batch or 128
-        out = build_resnet50(bl, batch)
-        name = f"ResNet-50 bs{batch} {args.dtype}"
-    else:
-        batch = args.batch or 32
-        out = build_bert(bl, batch, args.seq, args.layers)
-        name = f"BERT-base L{args.layers} bs{batch} seq{args.seq} {args.dtype}"
-    nops = len(bl.h.operators())
-    bl.finish()
-    eager = timed(bl.h.run, args.iters)
-    graph = timed(bl.h.run_with_hipgraph, args.iters)
-    y = out.copyout_numpy()
-    print(json.dumps({"model": name, "ops": nops, "gemm_conv_TFLOP": round(bl.flops / 1e12, 3),
-                      "eager_ms": round(eager, 3), "hipgraph_ms": round(graph, 3),
-                      "hipgraph_TFLOPs": round(bl.flops / graph / 1e9, 1),
-                      "per_unit": f"{batch / graph * 1e3:.0f} samples/s", "finite": bool(np.isfinite(y.astype(np.float32)).all())}))
+    print(json.dumps(run_model(args.model, 0, args.batch, args.seq, args.layers, args.dtype, args.iters)))
 
 
 if __name__ == "__main__":
