@@ -413,6 +413,9 @@ def main() -> int:
                 line["extras"] = extras(rt, ops, Event)
             except Exception as e:
                 line["extras"] = {"error": repr(e)}
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)  # RCCL prints a version banner through C stdio: keep the JSON line last
         print(json.dumps(line), flush=True)
     if dist:
         td.barrier()
