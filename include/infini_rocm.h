@@ -179,6 +179,20 @@ int infini_rocm_layer_norm(infiniRocmRuntime_t rt, int dtype, const void *x, con
 int infini_rocm_rms_norm(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, void *y,
                          int64_t outer, int64_t norm_size, float eps);
 
+/* Fused prefill attention  O = softmax(scale * Q K^T + mask) V  per (batch x head); f16 / bf16, head dim 64 or 128.
+ * Replaces the chain MatMul(Q, K^T) -> Div/Mul(scalar) -> Add(mask) -> Softmax -> MatMul(P, V) of the reference graph
+ * (matmul.cc:67-174, element_wise.cu, softmax.cu) without materialising the score matrix.
+ *   q, out: [batch_heads, seq_q, head_dim]; k, v: [batch_heads, seq_k, head_dim]; dense, 16-byte aligned.
+ *   mask (optional, same dtype): additive, [batch_heads / mask_group, seq_k], broadcast over the query rows
+ *     (a BERT [B,1,1,S] padding mask has mask_group = heads; [1,1,1,S] has mask_group = batch_heads).
+ *   scale: scale_dev != NULL -> one element of `dtype` in device memory, applied as multiply (scale_is_div = 0) or
+ *     divide (1); otherwise the immediate `scale`.
+ *   causal: keys with index > query index + (seq_k - seq_q) are excluded. Rows with no admissible key give 0. */
+int infini_rocm_attention(infiniRocmRuntime_t rt, int dtype, const void *q, const void *k, const void *v,
+                          const void *mask, void *out, int64_t batch_heads, int64_t seq_q, int64_t seq_k,
+                          int64_t head_dim, int64_t mask_group, const void *scale_dev, int scale_is_div,
+                          float scale, int causal);
+
 /* RoPE, rotate-half form (reference: _rope_kernel, src/kernels/cuda/rope.cu:6-31; glue rope.cc:8-33).
  * x, y: [tokens, dim_model] with dim_model a multiple of dim_head; pos: one position per token
  * (I32 / U32 / I64). The reference hard-codes dim_head = 128 and theta = 10000 and its launch covers a

@@ -1,0 +1,297 @@
+// Fused prefill attention for gfx950:  O = softmax(scale * Q K^T + mask) V   per (batch x head), f16 / bf16, head dim 64 / 128.
+//
+// Replaces the five-operator chain the ONNX front-end leaves in a transformer graph — MatMul(Q, K^T) -> Div/Mul(scalar) ->
+// Add(mask) -> Softmax -> MatMul(P, V) (reference kernels: matmul.cc:67-174, element_wise.cu, softmax.cu; BASELINE config 4
+// "Attention MatMul+Softmax fused path") — without ever writing the [Sq, Sk] score matrix to HBM
+// (BERT-base bs32 seq512: 5 x 201 MB of traffic per layer -> Q, K, V, O only).
+//
+// One workgroup = 4 waves = 4 * QW query rows of one (batch, head); keys are swept in tiles of 64 with the running
+// max / sum recurrence of online softmax (fp32, base-2 exponent with scale * log2(e) folded in).
+//   * Both contractions run on v_mfma_f32_16x16x32 with SWAPPED roles so that every lane owns one query column:
+//       S^T[key, q] = K Q^T   (A = K rows from LDS via ds_read_b128, B = Q fragments kept in registers for the whole sweep)
+//       O^T[d, q]  += V^T P^T (A = V^T via ds_read_b64_tr_b16 from the [key][d] LDS image, B = P packed from the S^T
+//                              accumulators IN REGISTERS: a lane's 4 + 4 scores of two 16-key tiles are exactly the 8
+//                              k-slots of its B fragment once the V rows are fetched in the same permuted key order)
+//     so the row statistics, the rescale of O and the final 1/l are per-lane scalars and P never touches LDS.
+//   * K / V tiles: register-staged double buffering (global loads of tile t+1 fly during the MFMAs of tile t), LDS images
+//     padded to conflict-free pitches (K: D*2 + 16 B for ds_read_b128, V: D*2 + 32 B for the transpose reads).
+//   * mask: additive, one value per (batch-group, key) broadcast over the query rows (the BERT [B,1,1,S] padding mask);
+//     optional causal masking (bottom-right aligned: key > query + Sk - Sq -> -inf). Keys past Sk are -inf. Fully masked rows produce 0.
+//   * scale comes from device memory (the graph's scalar constant), multiply or divide — the launch stays capturable.
+#include "gemm_common.h"
+
+namespace irocm {
+
+struct AttnArgs {
+    const void *q, *k, *v, *mask, *scale;
+    void *o;
+    int bh, sq, sk;
+    int mask_group;   // mask row index = bh / mask_group (heads per mask row); mask row stride = sk
+    int scale_is_div; // effective scale = scale_value (0) or 1 / scale_value (1)
+    float scale_imm;  // used when scale == nullptr
+    int causal;
+};
+
+template <typename Tr, int D, int NT>
+__global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
+    constexpr int QW = NT * 16;              // query rows per wave
+    constexpr int KT = 64;                   // keys per tile
+    constexpr int KP = D * 2 + 16;           // K image pitch (bytes)
+    constexpr int VP = D * 2 + 32;           // V image pitch (bytes)
+    constexpr int K_BYTES = KT * KP, V_BYTES = KT * VP, STAGE = K_BYTES + V_BYTES;
+    constexpr int NCH = KT * (D / 8) / 256;  // 16-byte runs per thread per operand tile
+    constexpr int KS = D / 32;               // k-steps of the S contraction
+    constexpr int DT = D / 16;               // d tiles of O^T
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int bh = blockIdx.y;
+    const int q0 = blockIdx.x * (4 * QW) + w * QW;
+    const unsigned short *Q = (const unsigned short *)p.q + (long)bh * p.sq * D;
+    const unsigned short *K = (const unsigned short *)p.k + (long)bh * p.sk * D;
+    const unsigned short *V = (const unsigned short *)p.v + (long)bh * p.sk * D;
+    const unsigned short *M = p.mask ? (const unsigned short *)p.mask + (long)(bh / p.mask_group) * p.sk : nullptr;
+
+    float scale = p.scale_imm;
+    if (p.scale) {
+        const float sv = Tr::to_f32(*(const unsigned short *)p.scale);
+        scale = p.scale_is_div ? 1.0f / sv : sv;
+    }
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float c = scale * LOG2E;
+
+    // Q fragments (B operand: lane = query column l15, 8 consecutive d)
+    s16x8_t qf[NT][KS];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        int qr = q0 + nt * 16 + l15;
+        qr = qr < p.sq ? qr : p.sq - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            qf[nt][ks] = *(const s16x8_t *)(Q + (long)qr * D + ks * 32 + g4 * 8);
+    }
+
+    // staging assignment
+    int st_row[NCH], st_col[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = t + i * 256;
+        st_row[i] = ch / (D / 8);
+        st_col[i] = (ch % (D / 8)) * 8;
+    }
+    s16x8_t kreg[NCH], vreg[NCH];
+    auto load_tile = [&](int kbase) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            int kr = kbase + st_row[i];
+            kr = kr < p.sk ? kr : p.sk - 1; // clamped rows are masked to -inf below
+            kreg[i] = *(const s16x8_t *)(K + (long)kr * D + st_col[i]);
+            vreg[i] = *(const s16x8_t *)(V + (long)kr * D + st_col[i]);
+        }
+    };
+    auto store_tile = [&](char *stage) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            *(s16x8_t *)(stage + st_row[i] * KP + st_col[i] * 2) = kreg[i];
+            *(s16x8_t *)(stage + K_BYTES + st_row[i] * VP + st_col[i] * 2) = vreg[i];
+        }
+    };
+
+    f32x4 o[DT][NT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            o[dt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[NT], l_run[NT]; // running max (log2 units, reduced over the 4 lanes of a column) and per-lane partial sum
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        m_run[nt] = -INFINITY;
+        l_run[nt] = 0.f;
+    }
+
+    // key tiles this workgroup needs (causal: nothing past its last query row)
+    int nkt = (p.sk + KT - 1) / KT;
+    if (p.causal) {
+        const int last_q = min(p.sq, (int)(blockIdx.x + 1) * 4 * QW) - 1;
+        nkt = max(1, min(nkt, (last_q + p.sk - p.sq) / KT + 1));
+    }
+
+    load_tile(0);
+    store_tile(smem);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const char *cur = smem + (kt & 1) * STAGE;
+        const int kbase = kt * KT;
+        if (kt + 1 < nkt)
+            load_tile(kbase + KT);
+
+        // ---- S^T = K Q^T : 4 key sub-tiles x NT query tiles ------------------------------------------
+        f32x4 s[4][NT];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            s16x8_t kf[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                kf[ks] = *(const s16x8_t *)(cur + (mt * 16 + l15) * KP + (ks * 32 + g4 * 8) * 2);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    a = Tr::mfma(kf[ks], qf[nt][ks], a);
+                s[mt][nt] = a;
+            }
+        }
+        // ---- scale, mask, online softmax (lane: query column l15, keys kbase + mt*16 + 4*g4 + r) -----
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int key = kbase + mt * 16 + 4 * g4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float mv = 0.f;
+                if (key + r >= p.sk)
+                    mv = -INFINITY;
+                else if (M)
+                    mv = Tr::to_f32(M[key + r]) * LOG2E;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    float v = s[mt][nt][r] * c + mv;
+                    if (p.causal && key + r > q0 + nt * 16 + l15 + (p.sk - p.sq))
+                        v = -INFINITY;
+                    s[mt][nt][r] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    mx = fmaxf(mx, s[mt][nt][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run[nt], mx);
+            const float m_use = m_new == -INFINITY ? 0.f : m_new;
+            const float alpha = exp2f(m_run[nt] - m_use);
+            m_run[nt] = m_new;
+            float ps = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = exp2f(s[mt][nt][r] - m_use);
+                    s[mt][nt][r] = e;
+                    ps += e;
+                }
+            l_run[nt] = l_run[nt] * alpha + ps;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                o[dt][nt] *= alpha;
+        }
+        // ---- P fragments (B operand): k-slots 0..3 = keys 4*g4 + e of sub-tile 2*kk, 4..7 = of sub-tile 2*kk+1 ----
+        s16x8_t pf[NT][2];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                s16x8_t f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f[e] = (short)Tr::from_f32(s[2 * kk][nt][e]);
+                    f[4 + e] = (short)Tr::from_f32(s[2 * kk + 1][nt][e]);
+                }
+                pf[nt][kk] = f;
+            }
+        // ---- O^T += V^T P^T ---------------------------------------------------------------------------
+        const char *vimg = cur + K_BYTES;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                // transpose read: lane p of a 16-lane group supplies key row (p >> 2) of its 4-row block and
+                // 4 d-columns (p & 3) * 4, receives d-column p of that block
+                const int d4 = dt * 16 + (l15 & 3) * 4;
+                const char *a0 = vimg + (kk * 32 + 4 * g4 + (l15 >> 2)) * VP + d4 * 2;
+                const char *a1 = a0 + 16 * VP;
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t *)(a0));
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t *)(a1));
+                const s16x8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    o[dt][nt] = Tr::mfma(vf, pf[nt][kk], o[dt][nt]);
+            }
+        if (kt + 1 < nkt)
+            store_tile(smem + ((kt + 1) & 1) * STAGE);
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane holds O[q = .. + l15][d = dt*16 + 4*g4 + r] ------------------------------
+    unsigned short *O = (unsigned short *)p.o + (long)bh * p.sq * D;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        float l = l_run[nt];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        const int qi = q0 + nt * 16 + l15;
+        if (qi >= p.sq)
+            continue;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            u32x2_t pk;
+            pk[0] = (unsigned)Tr::from_f32(o[dt][nt][0] * inv) | ((unsigned)Tr::from_f32(o[dt][nt][1] * inv) << 16);
+            pk[1] = (unsigned)Tr::from_f32(o[dt][nt][2] * inv) | ((unsigned)Tr::from_f32(o[dt][nt][3] * inv) << 16);
+            *(u32x2_t *)(O + (long)qi * D + dt * 16 + 4 * g4) = pk;
+        }
+    }
+}
+
+template <typename Tr, int D, int NT> static int launch_attn(infiniRocmRuntime_t rt, const AttnArgs &p) {
+    constexpr int LDS = 2 * (64 * (D * 2 + 16) + 64 * (D * 2 + 32));
+    auto kern = attention_kernel<Tr, D, NT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        IROCM_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_done = true;
+    }
+    dim3 grid((unsigned)ceil_div(p.sq, 4 * NT * 16), (unsigned)p.bh);
+    hipLaunchKernelGGL(kern, grid, dim3(256), LDS, rt->stream, p);
+    IROCM_LAUNCH_CHECK("attention");
+    return INFINI_ROCM_OK;
+}
+
+} // namespace irocm
+
+using namespace irocm;
+
+extern "C" int infini_rocm_attention(infiniRocmRuntime_t rt, int dtype, const void *q, const void *k, const void *v,
+                                     const void *mask, void *out, int64_t batch_heads, int64_t seq_q, int64_t seq_k,
+                                     int64_t head_dim, int64_t mask_group, const void *scale_dev, int scale_is_div,
+                                     float scale, int causal) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(dtype == INFINI_DT_F16 || dtype == INFINI_DT_BF16, "attention: f16 / bf16 only (got %s)", dtype_name(dtype));
+    IROCM_CHECK_ARG(head_dim == 64 || head_dim == 128, "attention: head dim %lld not in {64, 128}", (long long)head_dim);
+    IROCM_CHECK_ARG(batch_heads >= 0 && seq_q >= 0 && seq_k > 0 && batch_heads < 65536 && seq_q < (1ll << 31) && seq_k < (1ll << 31),
+                    "attention: bad extent");
+    IROCM_CHECK_ARG(!mask || mask_group > 0, "attention: mask_group must be positive");
+    if (batch_heads == 0 || seq_q == 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(q && k && v && out, "attention: NULL tensor");
+    IROCM_CHECK_ARG(((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v)) & 15) == 0 && (((uintptr_t)out) & 7) == 0,
+                    "attention: operands must be 16-byte aligned");
+    AttnArgs p;
+    p.q = q; p.k = k; p.v = v; p.mask = mask; p.scale = scale_dev; p.o = out;
+    p.bh = (int)batch_heads; p.sq = (int)seq_q; p.sk = (int)seq_k;
+    p.mask_group = mask ? (int)mask_group : 1;
+    p.scale_is_div = scale_is_div;
+    p.scale_imm = scale;
+    p.causal = causal;
+    const bool bf = dtype == INFINI_DT_BF16;
+    if (head_dim == 64)
+        return bf ? launch_attn<Bf16Traits, 64, 4>(rt, p) : launch_attn<F16Traits, 64, 4>(rt, p);
+    return bf ? launch_attn<Bf16Traits, 128, 2>(rt, p) : launch_attn<F16Traits, 128, 2>(rt, p);
+}

@@ -341,6 +341,7 @@ __global__ __launch_bounds__(256) void gemm_fast128(GemmArgs p) {
 int launch_gemm256(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool a_kmajor, bool b_kmajor, int sched);
 bool gemm256_supported(const GemmArgs &p, bool a_kmajor, bool b_kmajor);
 int launch_gemm256m32(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool a_kmajor, bool b_kmajor);
+int launch_gemm256w4(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool a_kmajor, bool b_kmajor);
 
 template <typename Tr> static int launch_fast128(infiniRocmRuntime_t rt, GemmArgs p, bool akm, bool bkm) {
     p.tiles_m = (int)ceil_div(p.m, f128::BM);
@@ -383,8 +384,9 @@ static bool fast128_supported(const GemmArgs &p, bool akm, bool bkm) {
     return true;
 }
 
-static const char *kVariantNames[] = {"generic64", "fast128_glds", "tile256_stagger", "tile256_pipelined", "tile256_mfma32"};
-constexpr int kNumVariants = 5;
+static const char *kVariantNames[] = {"generic64", "fast128_glds", "tile256_stagger", "tile256_pipelined", "tile256_mfma32",
+                                      "tile256_4wave"};
+constexpr int kNumVariants = 6;
 constexpr int kDefault256 = 2; // schedule used by the heuristic
 
 } // namespace irocm
@@ -450,6 +452,8 @@ int infini_rocm_matmul(infiniRocmRuntime_t rt, int dtype, const void *a, const v
         variant = 0;
     }
 
+    if (variant == 5)
+        return launch_gemm256w4(rt, dtype, p, akm, bkm);
     if (variant == 4)
         return launch_gemm256m32(rt, dtype, p, akm, bkm);
     if (variant >= 2)

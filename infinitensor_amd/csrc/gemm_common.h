@@ -35,13 +35,9 @@ struct Bf16Traits {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
                                                        __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
     }
-    // round-to-nearest-even, NaN preserved (same rounding torch / the oracle use)
+    // round-to-nearest-even (same rounding torch / the oracle use): one v_cvt_pk_bf16_f32 on gfx950
     __device__ static inline unsigned short from_f32(float f) {
-        unsigned int u = __builtin_bit_cast(unsigned int, f);
-        if ((u & 0x7fffffffu) > 0x7f800000u)
-            return (unsigned short)((u >> 16) | 0x40);
-        u += 0x7fffu + ((u >> 16) & 1u);
-        return (unsigned short)(u >> 16);
+        return __builtin_bit_cast(unsigned short, (__bf16)f);
     }
     __device__ static inline float to_f32(unsigned short h) {
         return __builtin_bit_cast(float, ((unsigned int)h) << 16);

@@ -208,6 +208,32 @@ def rms_norm(rt: RocmRuntime, x: torch.Tensor, weight: torch.Tensor, eps: float 
     return out
 
 
+def attention(rt: RocmRuntime, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float | torch.Tensor,
+              mask: torch.Tensor | None = None, causal: bool = False, scale_is_div: bool = False,
+              out: torch.Tensor | None = None) -> torch.Tensor:
+    """softmax(scale * q k^T + mask) v over [..., S, D] (leading dims = batch x heads). `mask`: additive, shape
+    [G, Sk] with G dividing the number of (batch, head) pairs (row g serves pairs g*BH/G .. (g+1)*BH/G - 1).
+    `scale`: a float, or a one-element device tensor (then multiply / divide per scale_is_div)."""
+    if q.dim() < 3 or k.shape != v.shape or q.shape[:-2] != k.shape[:-2] or q.shape[-1] != k.shape[-1]:
+        raise ValueError("attention expects q [..., Sq, D] and k, v [..., Sk, D]")
+    bh = 1
+    for d in q.shape[:-2]:
+        bh *= d
+    sq, sk, hd = q.shape[-2], k.shape[-2], q.shape[-1]
+    if out is None:
+        out = torch.empty_like(q)
+    group = 1
+    if mask is not None:
+        if mask.dim() != 2 or mask.shape[1] != sk or bh % mask.shape[0] != 0 or mask.dtype != q.dtype:
+            raise ValueError("mask must be [G, Sk] of q's dtype with G dividing batch x heads")
+        group = bh // mask.shape[0]
+    dev_scale = scale if isinstance(scale, torch.Tensor) else None
+    check(lib().infini_rocm_attention(rt.handle, dtype_of(q), _ptr(q), _ptr(k), _ptr(v), _ptr(mask), _ptr(out), bh, sq, sk,
+                                      hd, group, _ptr(dev_scale), int(scale_is_div),
+                                      0.0 if dev_scale is not None else float(scale), int(causal)))
+    return out
+
+
 def rope(rt: RocmRuntime, pos: torch.Tensor, x: torch.Tensor, dim_head: int = 128, theta: float = 10000.0,
          out: torch.Tensor | None = None) -> torch.Tensor:
     """RoPE(pos [B, S], x [B, S, dim_model]) (operators/rope.h; dim_head 128 / theta 1e4 as rope.cc:25)."""

@@ -72,6 +72,7 @@ PATCHES = [
      "        .def(\"sync\", &RocmRuntimeObj::sync)\n"
      "        .def(\"set_fusion\", &RocmRuntimeObj::setFusion)\n"
      "        .def(\"get_fusion\", &RocmRuntimeObj::getFusion)\n"
+     "        .def(\"fused_launch_count\", &RocmRuntimeObj::getFusedLaunchCount)\n"
      "        .def(\"init_comm\", &RocmRuntimeObj::initComm);\n"
      "#endif\n"
      "#ifdef USE_BANG\n    py::class_<BangRuntimeObj, std::shared_ptr<BangRuntimeObj>, RuntimeObj>("),

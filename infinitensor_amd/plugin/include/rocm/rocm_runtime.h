@@ -54,6 +54,7 @@ class RocmRuntimeObj : public RuntimeObj {
     // INFINI_ROCM_FUSION=0 in the environment turns it off at construction
     void setFusion(bool on);
     bool getFusion() const { return fusion; }
+    size_t getFusedLaunchCount() const { return fusedCount; } // fused kernels launched so far (tests)
 
     void initComm(const string &name, int worldSize, int rank) final;
     CommunicatorObj &getCommunicator() const final;
@@ -91,6 +92,7 @@ class RocmRuntimeObj : public RuntimeObj {
     void launchAll(const Graph &graph, bool validate) const;
     // launches ops[i .. i+k) as one kernel when a fusion rule applies; returns k (0 = no rule)
     size_t tryLaunchFused(const OpVec &ops, size_t i) const;
+    size_t tryLaunchFusedAttention(const OpVec &ops, size_t i) const;
     void tuneImpl(const Graph &graph, bool profiling) const;
     GraphState stateOf(const Graph &graph) const;
     void replay(CacheEntry &entry);
@@ -100,6 +102,7 @@ class RocmRuntimeObj : public RuntimeObj {
     size_t cacheCapacity;
     size_t captureCount = 0;
     bool fusion = true;
+    mutable size_t fusedCount = 0;
     Cache cache; // most recently used first
     mutable std::recursive_mutex executionMutex;
     mutable std::recursive_mutex cacheMutex;

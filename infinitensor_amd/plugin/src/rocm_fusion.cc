@@ -5,6 +5,9 @@
 //   Conv -> Add(per-channel bias [1,F,1,1] / [F,1,1]) [-> Relu]   =>  conv2d(bias, act)        (onnx.py:159-190
 //   Conv -> Relu                                                   =>  conv2d(act)              emits these chains)
 //   Add  -> Relu                                                   =>  binary(ADD_RELU)         (residual join)
+//   MatMul(Q, K^T) [-> Div|Mul(scalar)] [-> Add(mask)] -> Softmax(last axis) -> MatMul(P, V)
+//                                                                  =>  attention (csrc/attention.hip): the score
+//        matrix is never written; Q, K, V rank-4 [b, h, S, D] with D in {64, 128}, f16 / bf16, mask [b|1, 1, 1, Sk]
 //
 // Conditions (checked every launch, nothing is cached across graph mutations):
 //   * the ops are CONSECUTIVE in the graph's operator order and each intermediate tensor has exactly one
@@ -18,6 +21,8 @@
 // INFINI_ROCM_FUSION=0 or RocmRuntimeObj::setFusion(false) restores one kernel per operator.
 #include "operators/conv.h"
 #include "operators/element_wise.h"
+#include "operators/matmul.h"
+#include "operators/softmax.h"
 #include "operators/unary.h"
 #include "rocm/rocm_runtime.h"
 
@@ -59,9 +64,75 @@ std::vector<int64_t> strides64(const Shape &shape, const Shape &outShape) {
 }
 } // namespace
 
+size_t RocmRuntimeObj::tryLaunchFusedAttention(const OpVec &ops, size_t i) const {
+    auto mm1 = as<MatmulObj>(ops[i]);
+    if (mm1->getTransA() || !mm1->getTransB() || mm1->getBias() || mm1->getAct() != ActType::None)
+        return 0;
+    const Tensor q = mm1->getInputs(0), k = mm1->getInputs(1);
+    const auto &qd = q->getDims(), &kd = k->getDims();
+    const int dt = q->getDTypeIndex();
+    if (qd.size() != 4 || kd.size() != 4 || qd[0] != kd[0] || qd[1] != kd[1] || qd[3] != kd[3] || (qd[3] != 64 && qd[3] != 128) ||
+        (dt != INFINI_DT_F16 && dt != INFINI_DT_BF16) || !(k->getDType() == q->getDType()))
+        return 0;
+    const int b = qd[0], h = qd[1], sq = qd[2], sk = kd[2], d = qd[3];
+    Tensor cur = mm1->getOutput(), scale = nullptr, mask = nullptr;
+    size_t j = i + 1;
+    bool isDiv = false;
+    auto next = [&](OpType t) { return j < ops.size() && ops[j]->getOpType() == t && soleConsumerIs(cur, ops[j]); };
+    if (next(OpType::Div) || next(OpType::Mul)) {
+        const Tensor a0 = ops[j]->getInputs(0), a1 = ops[j]->getInputs(1);
+        isDiv = ops[j]->getOpType() == OpType::Div;
+        const Tensor other = a0 == cur ? a1 : a0;
+        if (other == cur || other->size() != 1 || !(other->getDType() == q->getDType()) || (isDiv && a0 != cur))
+            return 0;
+        scale = other;
+        cur = ops[j++]->getOutput();
+    }
+    if (next(OpType::Add)) {
+        const Tensor a0 = ops[j]->getInputs(0), a1 = ops[j]->getInputs(1);
+        const Tensor other = a0 == cur ? a1 : a0;
+        const auto &md = other->getDims();
+        if (other == cur || md.size() != 4 || (md[0] != b && md[0] != 1) || md[1] != 1 || md[2] != 1 || md[3] != sk ||
+            !(other->getDType() == q->getDType()))
+            return 0;
+        mask = other;
+        cur = ops[j++]->getOutput();
+    }
+    if (!next(OpType::Softmax) || as<SoftmaxObj>(ops[j])->getAxis() != 3)
+        return 0;
+    cur = ops[j++]->getOutput();
+    if (!next(OpType::MatMul))
+        return 0;
+    auto mm2 = as<MatmulObj>(ops[j]);
+    const Tensor v = mm2->getInputs(1), out = mm2->getOutput();
+    if (mm2->getInputs(0) != cur || mm2->getTransA() || mm2->getTransB() || mm2->getBias() || mm2->getAct() != ActType::None ||
+        v->getDims() != kd || !(v->getDType() == q->getDType()))
+        return 0;
+    // O may sit exactly on Q (the planner likes to: Q is dead after the first MatMul and has O's size): a workgroup
+    // loads its query rows before the key sweep and writes the same rows of O after it. K / V are read by everyone.
+    // Any other overlap (K and V die after their MatMul too, and have O's size) is bridged through the workspace:
+    // O is [Sq, D] per head, the copy is small next to the score traffic the fusion removes.
+    const bool onQ = out->getRawDataPtr<void *>() == q->getRawDataPtr<void *>() && out->getDims() == qd;
+    const bool hazard = (overlaps(out, q) && !onQ) || overlaps(out, k) || overlaps(out, v) ||
+                        (mask && overlaps(out, mask)) || (scale && overlaps(out, scale));
+    void *dst = out->getRawDataPtr<void *>();
+    if (hazard)
+        dst = getWorkspace(out->getBytes());
+    const int64_t group = mask ? (mask->getDims()[0] == 1 ? (int64_t)b * h : h) : 1;
+    ROCM_CALL(infini_rocm_attention(rt, dt, q->getRawDataPtr<void *>(), k->getRawDataPtr<void *>(), v->getRawDataPtr<void *>(),
+                                    mask ? mask->getRawDataPtr<void *>() : nullptr, dst,
+                                    (int64_t)b * h, sq, sk, d, group, scale ? scale->getRawDataPtr<void *>() : nullptr,
+                                    isDiv ? 1 : 0, 1.0f, 0));
+    if (hazard)
+        ROCM_CALL(infini_rocm_copy_inside(rt, out->getRawDataPtr<void *>(), dst, out->getBytes()));
+    return j + 1 - i;
+}
+
 size_t RocmRuntimeObj::tryLaunchFused(const OpVec &ops, size_t i) const {
     const Operator &op = ops[i];
     const auto type = op->getOpType();
+    if (type == OpType::MatMul)
+        return tryLaunchFusedAttention(ops, i);
     if (type == OpType::Conv) {
         auto conv = as<ConvObj>(op);
         const Tensor x = conv->getInputs(0), w = conv->getInputs(1);

@@ -95,6 +95,7 @@ void RocmRuntimeObj::launchAll(const Graph &graph, bool validate) const {
                 throw;
             }
             if (fused) {
+                ++fusedCount;
                 i += fused - 1;
                 continue;
             }
@@ -230,13 +231,21 @@ void RocmRuntimeObj::runWithHipGraph(const Graph &graph) {
     entry->owner = WRef<GraphObj>(graph);
     entry->state = std::move(state);
     entry->generation = generation;
-    ROCM_CALL(infini_rocm_graph_begin_capture(rt));
-    try {
-        launchAll(graph, false);
-        ROCM_CALL(infini_rocm_graph_end_capture(rt, &entry->graph));
-    } catch (...) {
-        infini_rocm_graph_abort_capture(rt);
-        throw;
+    // Kernels take scratch from the runtime workspace, which cannot grow while the stream records: if the first
+    // attempt fails, run the graph once eagerly (that sizes the workspace; results are the same) and capture again.
+    for (int attempt = 0;; ++attempt) {
+        ROCM_CALL(infini_rocm_graph_begin_capture(rt));
+        try {
+            launchAll(graph, false);
+            ROCM_CALL(infini_rocm_graph_end_capture(rt, &entry->graph));
+            break;
+        } catch (...) {
+            infini_rocm_graph_abort_capture(rt);
+            if (attempt > 0)
+                throw;
+        }
+        launchAll(graph, false); // a genuine kernel error throws again here, outside any capture
+        sync();
     }
     IT_ASSERT(generation == graph->getCaptureGeneration(), "Graph changed while hipGraph capture was in progress");
     ROCM_CALL(infini_rocm_graph_launch(rt, entry->graph));

@@ -1,0 +1,79 @@
+"""Fused prefill attention (csrc/attention.hip) vs the oracle and vs the unfused five-kernel chain it replaces."""
+import numpy as np
+import pytest
+import torch
+
+from infinitensor_amd import ops
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+TD = {"f16": torch.float16, "bf16": torch.bfloat16}
+TOL = {"f16": 3e-3, "bf16": 2e-2}
+
+
+def dev(a, dtype):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).cuda()
+
+
+def host(t):
+    return t.float().cpu().numpy().astype(np.float64)
+
+
+CASES = [
+    # b, h, sq, sk, d, mask, causal
+    (2, 3, 128, 128, 64, True, False),
+    (1, 2, 512, 512, 64, True, False),    # BERT head
+    (2, 2, 100, 77, 64, True, False),     # ragged: partial query tile, partial key tile
+    (1, 4, 256, 256, 128, False, True),   # Llama head, causal
+    (1, 2, 65, 65, 128, False, True),
+    (1, 1, 40, 200, 64, False, True),     # causal with Sk > Sq (bottom-right aligned)
+    (3, 1, 17, 5, 128, True, False),
+    (1, 2, 300, 300, 64, False, False),
+]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("case", CASES)
+def test_attention_vs_oracle(rt, case, dt):
+    b, h, sq, sk, d, use_mask, causal = case
+    rng = np.random.default_rng(abs(hash(case)) % 2 ** 32)
+    q = rng.standard_normal((b, h, sq, d)).astype(np.float32)
+    k = rng.standard_normal((b, h, sk, d)).astype(np.float32)
+    v = rng.standard_normal((b, h, sk, d)).astype(np.float32)
+    scale = 1.0 / np.sqrt(d)
+    mask = None
+    if use_mask:  # BERT padding mask: 0 for kept keys, large negative for padded ones (never all padded)
+        mask = np.where(rng.random((b, sk)) < 0.8, 0.0, -10000.0).astype(np.float32)
+        mask[:, 0] = 0.0
+    qd, kd, vd = dev(q, TD[dt]), dev(k, TD[dt]), dev(v, TD[dt])
+    md = dev(mask, TD[dt]) if use_mask else None
+    y = ops.attention(rt, qd, kd, vd, scale, md, causal)
+    want = R.attention(R.round_to(q, dt), R.round_to(k, dt), R.round_to(v, dt), scale,
+                       None if mask is None else R.round_to(mask, dt)[:, None, None, :], causal)
+    assert np.allclose(host(y), want, rtol=TOL[dt], atol=TOL[dt])
+
+
+def test_attention_equals_the_unfused_chain(rt):
+    """Same graph as BERT emits: MatMul(q, k^T) -> Div(sqrt d) -> Add(mask) -> Softmax -> MatMul(p, v), scale taken
+    from device memory as the graph's scalar constant."""
+    rng = np.random.default_rng(3)
+    b, h, s, d = 2, 4, 192, 64
+    q, k, v = (dev(rng.standard_normal((b, h, s, d)).astype(np.float32), torch.float16) for _ in range(3))
+    mask = dev(np.where(rng.random((b, 1, 1, s)) < 0.9, 0.0, -10000.0).astype(np.float32), torch.float16)
+    sc = torch.tensor([np.sqrt(d)], dtype=torch.float16).cuda()
+    sm = ops.matmul(rt, q, k, None, False, True)
+    sm = ops.binary(rt, "add", ops.binary(rt, "div", sm, sc), mask)
+    chain = ops.matmul(rt, ops.softmax(rt, sm, -1), v)
+    fused = ops.attention(rt, q, k, v, sc, mask.reshape(b, s), scale_is_div=True)
+    assert np.allclose(host(fused), host(chain), rtol=4e-3, atol=4e-3)
+
+
+def test_attention_fully_masked_rows_and_errors(rt):
+    q = torch.randn(1, 1, 16, 64, device="cuda").half()
+    k = torch.randn(1, 1, 16, 64, device="cuda").half()
+    y = ops.attention(rt, q, k, k.clone(), 0.125, None, True)
+    assert torch.isfinite(y).all()
+    with pytest.raises(RuntimeError):
+        ops.attention(rt, q[..., :32].contiguous(), k[..., :32].contiguous(), k[..., :32].contiguous(), 1.0)
+    with pytest.raises(RuntimeError):
+        ops.attention(rt, q.float(), k.float(), k.float(), 1.0)

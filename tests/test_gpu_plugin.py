@@ -299,7 +299,9 @@ def test_fusion_is_invisible(B, rocm, code, npdt):
             rocm.set_fusion(on)
             assert rocm.get_fusion() == on
             h, out = build(B, rocm, _resblock, ins)
+            before = rocm.fused_launch_count()
             h.run()
+            assert (rocm.fused_launch_count() - before > 0) == on
             got[on] = get(out).astype(np.float64)
     finally:
         rocm.set_fusion(True)
@@ -330,3 +332,38 @@ def test_fusion_keeps_tensors_that_someone_else_reads(B, rocm):
 
     got, want = run_both(B, rocm, fn, ins)
     assert np.allclose(got, want, rtol=1e-4, atol=1e-5)
+
+
+def test_attention_chain_fusion(B, rocm):
+    """MatMul(q, k^T) -> Div -> Add(mask) -> Softmax -> MatMul(p, v) as BERT emits it: one fused attention launch
+    (rocm_fusion.cc) vs five kernels vs the fp64 oracle."""
+    rng = np.random.default_rng(21)
+    b, h, s, d = 2, 3, 96, 64
+    mask = np.where(rng.random((b, 1, 1, s)) < 0.85, 0.0, -10000.0).astype(np.float16)
+    ins = [((b, h, s, d), F16, rng.standard_normal((b, h, s, d)).astype(np.float16)),
+           ((b, h, s, d), F16, rng.standard_normal((b, h, s, d)).astype(np.float16)),
+           ((b, h, s, d), F16, rng.standard_normal((b, h, s, d)).astype(np.float16)),
+           ((1,), F16, np.array([np.sqrt(d)], np.float16)),
+           ((b, 1, 1, s), F16, mask)]
+
+    def fn(hd, t):
+        lin = B.ActType.Linear
+        sc = hd.matmul(t[0], t[1], None, False, True, None, lin, "default")
+        sc = hd.add(hd.div(sc, t[3], None), t[4], None)
+        return hd.matmul(hd.softmax(sc, None, 3), t[2], None, False, False, None, lin, "default")
+
+    got = {}
+    try:
+        for on in (True, False):
+            rocm.set_fusion(on)
+            hh, out = build(B, rocm, fn, ins)
+            before = rocm.fused_launch_count()
+            hh.run()
+            assert rocm.fused_launch_count() - before == (1 if on else 0)  # the whole chain is ONE launch
+            got[on] = get(out).astype(np.float64).reshape(b, h, s, d)
+    finally:
+        rocm.set_fusion(True)
+    q, k, v = (a.astype(np.float64) for _, _, a in ins[:3])
+    want = R.attention(q, k, v, 1.0 / float(np.float16(np.sqrt(d))), mask.astype(np.float64))
+    assert np.allclose(got[True], want, rtol=3e-3, atol=3e-3)
+    assert np.allclose(got[True], got[False], rtol=4e-3, atol=4e-3)
