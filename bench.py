@@ -221,8 +221,7 @@ def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
     def block():
         h = ops.rms_norm(rt, x, n1, 1e-5)
         q, k, v = heads(ops.matmul(rt, h, wq)), heads(ops.matmul(rt, h, wk)), heads(ops.matmul(rt, h, wv))
-        s = ops.binary(rt, "div", ops.matmul(rt, q, k, None, False, True), scale)
-        ctx = ops.matmul(rt, ops.softmax(rt, s, -1), v)
+        ctx = ops.attention(rt, q, k, v, scale, scale_is_div=True)  # fused prefill attention (csrc/attention.hip)
         ctx = ops.transpose(rt, ctx.view(Bt, nh, S, D), (0, 2, 1, 3)).view(T, nh * D)
         o = ops.matmul(rt, ctx, wo)
         ops.all_reduce(rt, "sum", o, out=o)

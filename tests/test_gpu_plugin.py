@@ -367,3 +367,21 @@ def test_attention_chain_fusion(B, rocm):
     want = R.attention(q, k, v, 1.0 / float(np.float16(np.sqrt(d))), mask.astype(np.float64))
     assert np.allclose(got[True], want, rtol=3e-3, atol=3e-3)
     assert np.allclose(got[True], got[False], rtol=4e-3, atol=4e-3)
+
+
+def test_first_hipgraph_run_sizes_the_workspace(B):
+    """A graph whose kernels need scratch (conv_s1 re-packs weights into the workspace) captured on a FRESH runtime
+    with no eager run before: the first capture fails on workspace growth, the runtime runs the graph once eagerly
+    and captures again (rocm_runtime.cc::runWithHipGraph)."""
+    rt = B.RocmRuntime(0)
+    rng = np.random.default_rng(31)
+    ins = [((2, 32, 12, 12), F16, rng.standard_normal((2, 32, 12, 12)).astype(np.float16)),
+           ((48, 32, 3, 3), F16, (rng.standard_normal((48, 32, 3, 3)) / 17).astype(np.float16))]
+    h, out = build(B, rt, lambda hd, t: hd.conv(t[0], t[1], None, 1, 1, 1, 1, 1, 1), ins)
+    h.run_with_hipgraph()
+    got = get(out).astype(np.float64).reshape(2, 48, 12, 12)
+    assert rt.hip_graph_capture_count() == 1
+    want = R.conv2d(ins[0][2].astype(np.float64), ins[1][2].astype(np.float64), 1, 1, 1, 1, 1, 1)
+    assert np.allclose(got, want, rtol=3e-3, atol=3e-3)
+    h.run_with_hipgraph()
+    assert rt.hip_graph_capture_count() == 1 and np.allclose(get(out).astype(np.float64).reshape(2, 48, 12, 12), want, rtol=3e-3, atol=3e-3)
