@@ -193,6 +193,14 @@ int infini_rocm_attention(infiniRocmRuntime_t rt, int dtype, const void *q, cons
                           int64_t head_dim, int64_t mask_group, const void *scale_dev, int scale_is_div,
                           float scale, int causal);
 
+/* AttentionKVCache: one decode step with in-place cache append (reference: attention_kvcache.cu:8-169).
+ *   n = position_id[0] + 1; k_cache/v_cache[bh, n-1, :] = k/v[bh, :]; out[bh, :] = softmax(q . K[0:n]^T / sqrt(D)) V[0:n].
+ * caches [batch_heads, max_seq, D]; q, k, v, out [batch_heads, D]; position_id: device I32 / U32 / I64 (element 0 is
+ * used for all heads, as in the reference). f32 (the reference's only type) / f16 / bf16; D in {128, 256}. */
+int infini_rocm_attention_kvcache(infiniRocmRuntime_t rt, int dtype, void *k_cache, void *v_cache, const void *q,
+                                  const void *k, const void *v, int pos_dtype, const void *position_id, void *out,
+                                  int64_t batch_heads, int64_t max_seq, int64_t head_dim);
+
 /* RoPE, rotate-half form (reference: _rope_kernel, src/kernels/cuda/rope.cu:6-31; glue rope.cc:8-33).
  * x, y: [tokens, dim_model] with dim_model a multiple of dim_head; pos: one position per token
  * (I32 / U32 / I64). The reference hard-codes dim_head = 128 and theta = 10000 and its launch covers a

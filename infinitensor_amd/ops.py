@@ -234,6 +234,23 @@ def attention(rt: RocmRuntime, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor
     return out
 
 
+def attention_kvcache(rt: RocmRuntime, k_cache: torch.Tensor, v_cache: torch.Tensor, q: torch.Tensor, k: torch.Tensor,
+                      v: torch.Tensor, position_id: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Decode step (operators/attention_kvcache.h): caches [B, H, max_seq, D] are appended IN PLACE at
+    position_id[0]; q, k, v [B, H, 1, D]; returns [B, H, 1, D]."""
+    if k_cache.dim() != 4 or k_cache.shape != v_cache.shape:
+        raise ValueError("caches must be rank-4 [B, H, max_seq, D]")  # reference: IT_ASSERT(rank == 4)
+    b, h, ms, d = k_cache.shape
+    for t_ in (q, k, v):
+        if tuple(t_.shape) != (b, h, 1, d) or t_.dtype != k_cache.dtype:
+            raise ValueError("q, k, v must be [B, H, 1, D] of the caches' dtype")
+    if out is None:
+        out = torch.empty_like(q)
+    check(lib().infini_rocm_attention_kvcache(rt.handle, dtype_of(q), _ptr(k_cache), _ptr(v_cache), _ptr(q), _ptr(k),
+                                              _ptr(v), dtype_of(position_id), _ptr(position_id), _ptr(out), b * h, ms, d))
+    return out
+
+
 def rope(rt: RocmRuntime, pos: torch.Tensor, x: torch.Tensor, dim_head: int = 128, theta: float = 10000.0,
          out: torch.Tensor | None = None) -> torch.Tensor:
     """RoPE(pos [B, S], x [B, S, dim_model]) (operators/rope.h; dim_head 128 / theta 1e4 as rope.cc:25)."""

@@ -6,6 +6,7 @@
 #include "core/kernel.h"
 #include "operators/all_gather.h"
 #include "operators/all_reduce.h"
+#include "operators/attention_kvcache.h"
 #include "operators/batch_norm.h"
 #include "operators/broadcast.h"
 #include "operators/concat.h"
@@ -167,6 +168,18 @@ class RMSNormRocm : public RocmKernelWithoutConfig {
     }
 };
 REGISTER_KERNEL(Device::ROCM, OpType::RMSNorm, RMSNormRocm, "RMSNorm_ROCM");
+
+class AttentionKVCacheRocm : public RocmKernelWithoutConfig {
+    void compute(const Operator &_op, const RuntimeObj *ctx) const override {
+        auto op = as<AttentionKVCacheObj>(_op);
+        const auto kc = op->getInputs(0), vc = op->getInputs(1), q = op->getInputs(2), pos = op->getInputs(5);
+        const auto &d = kc->getDims(); // [B, H, max_seq, D] (attention_kvcache.cc:21-27)
+        IT_ASSERT(d.size() == 4 && q->getDims()[2] == 1);
+        ROCM_CALL(infini_rocm_attention_kvcache(H(ctx), DTI(q), P(kc), P(vc), P(q), P(op->getInputs(3)), P(op->getInputs(4)),
+                                                DTI(pos), P(pos), P(op->getOutput()), (int64_t)d[0] * d[1], d[2], d[3]));
+    }
+};
+REGISTER_KERNEL(Device::ROCM, OpType::AttentionKVCache, AttentionKVCacheRocm, "AttentionKVCache_ROCM");
 
 class RoPERocm : public RocmKernelWithoutConfig {
     void compute(const Operator &_op, const RuntimeObj *ctx) const override {

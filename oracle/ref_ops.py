@@ -401,3 +401,16 @@ def attention(q, k, v, scale: float, mask=None, causal: bool = False) -> np.ndar
 def all_reduce(kind: str, xs: Sequence[np.ndarray]) -> np.ndarray:
     S = np.stack([np.asarray(x, dtype=np.float64) for x in xs], 0)
     return {"sum": S.sum(0), "prod": S.prod(0), "min": S.min(0), "max": S.max(0), "avg": S.mean(0)}[kind]
+
+
+# AttentionKVCache (reference: src/kernels/cuda/attention_kvcache.cu:8-169 — n = position_id[0] + 1 keys, the newest
+# one taken from k / v and appended to the caches in place, scores / sqrt(D), softmax, times V)
+def attention_kvcache(k_cache, v_cache, q, k, v, position: int):
+    KC, VC = np.array(k_cache, dtype=np.float64), np.array(v_cache, dtype=np.float64)
+    Q, K, V = (np.asarray(t, dtype=np.float64) for t in (q, k, v))
+    n = int(position) + 1
+    KC[:, :, n - 1, :] = K[:, :, 0, :]
+    VC[:, :, n - 1, :] = V[:, :, 0, :]
+    s = np.einsum("bhd,bhnd->bhn", Q[:, :, 0, :], KC[:, :, :n, :]) / np.sqrt(Q.shape[-1])
+    p = softmax(s, -1)
+    return np.einsum("bhn,bhnd->bhd", p, VC[:, :, :n, :])[:, :, None, :], KC, VC

@@ -50,6 +50,7 @@ FILES = [
     "test/kernels/cuda/test_cuda_reshape.cc",
     "test/kernels/cuda/test_cuda_clip.cc",
     "test/kernels/cuda/test_cuda_rope.cc",
+    "test/kernels/cuda/test_cuda_attention.cc",
     "test/kernels/cuda/test_cuda_all_reduce.cc",
     "test/kernels/cuda/test_cuda_all_gather.cc",
     "test/kernels/cuda/test_cuda_broadcast.cc",

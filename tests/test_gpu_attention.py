@@ -77,3 +77,28 @@ def test_attention_fully_masked_rows_and_errors(rt):
         ops.attention(rt, q[..., :32].contiguous(), k[..., :32].contiguous(), k[..., :32].contiguous(), 1.0)
     with pytest.raises(RuntimeError):
         ops.attention(rt, q.float(), k.float(), k.float(), 1.0)
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-5), (torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+@pytest.mark.parametrize("pos,ms", [(0, 1), (5, 16), (16, 17), (100, 128), (511, 512)])
+def test_attention_kvcache_vs_oracle(rt, dt, tol, pos, ms):
+    rng = np.random.default_rng(pos + 7)
+    b, h, d = 2, 3, 128
+    mk = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).to(dt).cuda()  # noqa: E731
+    kc, vc, q, k, v = mk(b, h, ms, d), mk(b, h, ms, d), mk(b, h, 1, d), mk(b, h, 1, d), mk(b, h, 1, d)
+    kc0, vc0 = host(kc), host(vc)
+    p = torch.tensor([[pos]], dtype=torch.int32).cuda()
+    y = ops.attention_kvcache(rt, kc, vc, q, k, v, p)
+    want, kc_w, vc_w = R.attention_kvcache(kc0, vc0, host(q), host(k), host(v), pos)
+    assert np.allclose(host(y), want, rtol=tol, atol=tol)
+    assert np.array_equal(host(kc), kc_w) and np.array_equal(host(vc), vc_w)  # appended in place, nothing else touched
+
+
+def test_attention_kvcache_reference_kat(rt):
+    """test_cuda_attention.cc:17-43: ones everywhere, position 0 -> ones."""
+    from conftest import kat
+
+    one = lambda *s: torch.ones(s, dtype=torch.float32).cuda()  # noqa: E731
+    y = ops.attention_kvcache(rt, torch.zeros(1, 1, 1, 128).cuda(), torch.zeros(1, 1, 1, 128).cuda(), one(1, 1, 1, 128),
+                              one(1, 1, 1, 128), one(1, 1, 1, 128), torch.zeros(1, 1, dtype=torch.int32).cuda())
+    assert R.equal_data(host(y).ravel(), kat("test/kernels/cuda/test_cuda_attention.cc", 36, "float"), 1e-6)

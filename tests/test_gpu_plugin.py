@@ -385,3 +385,22 @@ def test_first_hipgraph_run_sizes_the_workspace(B):
     assert np.allclose(got, want, rtol=3e-3, atol=3e-3)
     h.run_with_hipgraph()
     assert rt.hip_graph_capture_count() == 1 and np.allclose(get(out).astype(np.float64).reshape(2, 48, 12, 12), want, rtol=3e-3, atol=3e-3)
+
+
+def test_attention_kvcache_through_reference_executor(B, rocm):
+    """test_cuda_attention.cc:10-43 on Device::ROCM, plus a second decode step at position 3 vs the oracle."""
+    U32 = 12
+    one = np.ones((1, 1, 1, 128), np.float32)
+    ins = [((1, 1, 1, 128), F32, np.zeros((1, 1, 1, 128), np.float32)), ((1, 1, 1, 128), F32, np.zeros((1, 1, 1, 128), np.float32)),
+           ((1, 1, 1, 128), F32, one), ((1, 1, 1, 128), F32, one), ((1, 1, 1, 128), F32, one), ((1, 1), U32, np.zeros((1, 1), np.uint32))]
+    h, out = build(B, rocm, lambda hd, t: hd.attentionKVCache(t[0], t[1], t[2], t[3], t[4], t[5], None), ins)
+    h.run()
+    assert R.equal_data(get(out).ravel(), kat(CU + "test_cuda_attention.cc", 36, "float"), 1e-6)
+    rng = np.random.default_rng(9)
+    b, hh, ms, d, pos = 2, 2, 8, 128, 3
+    arrs = [rng.standard_normal(s).astype(np.float32) for s in [(b, hh, ms, d), (b, hh, ms, d), (b, hh, 1, d), (b, hh, 1, d), (b, hh, 1, d)]]
+    ins = [(a.shape, F32, a) for a in arrs] + [((1, 1), U32, np.full((1, 1), pos, np.uint32))]
+    h, out = build(B, rocm, lambda hd, t: hd.attentionKVCache(t[0], t[1], t[2], t[3], t[4], t[5], None), ins)
+    h.run()
+    want, _, _ = R.attention_kvcache(*arrs, pos)
+    assert np.allclose(get(out).reshape(b, hh, 1, d), want, rtol=1e-5, atol=1e-5)

@@ -150,3 +150,12 @@ def test_rope_kat():
     x[..., :32] = 1.0
     y = R.rope(np.array([[1]]), x, 128)
     assert eq(y[0, 0, :32], kat(CU + "test_cuda_rope.cc", 29, "float"), 2e-6)
+
+
+def test_attention_kvcache_kat():
+    """test_cuda_attention.cc:17-43: caches [1,1,1,128] (uninitialised: never read at position 0), q = k = v = ones,
+    position 0 -> ones (softmax over the single, newly appended key)."""
+    z = np.zeros((1, 1, 1, 128))
+    y, kc, vc = R.attention_kvcache(z, z, np.ones((1, 1, 1, 128)), np.ones((1, 1, 1, 128)), np.ones((1, 1, 1, 128)), 0)
+    assert eq(y.ravel(), kat(CU + "test_cuda_attention.cc", 36, "float"))
+    assert np.array_equal(kc, np.ones((1, 1, 1, 128))) and np.array_equal(vc, np.ones((1, 1, 1, 128)))
