@@ -14,6 +14,7 @@
 // reference (softmax.cu:8-17).
 // All arithmetic is fp32 regardless of the storage dtype.
 #include "common.h"
+#include <cstdlib>
 
 namespace irocm {
 
@@ -360,10 +361,149 @@ __global__ __launch_bounds__(256) void norm_block_kernel(const T *__restrict__ x
     }
 }
 
+// Long aligned rows (up to 256 * VEC * CH elements): one 256-thread block per row, the row kept PACKED in registers
+// (CH 16-byte chunks per thread), 16-byte loads / stores, one read and one write of HBM per element; the two
+// reductions go wave-shuffle -> 4-entry LDS combine. (The scalar three-pass kernels above ran a 16384 x 4096 f16
+// LayerNorm at 1.9 TB/s.)
+__device__ inline float block_sum(float v, float *red, int lane, int w) {
+    v = wave_sum(v);
+    if (lane == 0)
+        red[w] = v;
+    __syncthreads();
+    const float r = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return r;
+}
+__device__ inline float block_max(float v, float *red, int lane, int w) {
+    v = wave_max(v);
+    if (lane == 0)
+        red[w] = v;
+    __syncthreads();
+    const float r = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    return r;
+}
+
+template <typename T, int CH, bool RMS>
+__global__ __launch_bounds__(256) void norm_blockreg_kernel(const T *__restrict__ x, const T *__restrict__ scale,
+                                                            const T *__restrict__ bias, T *__restrict__ y, long rows,
+                                                            int n, int scale_size, int bias_size, float eps) {
+    constexpr int VEC = Elem<T>::VEC;
+    using P = Pack<T, VEC>;
+    __shared__ float red[4];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const T *xr = x + row * (long)n;
+        T *yr = y + row * (long)n;
+        P c[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int base = (i * 256 + t) * VEC;
+            if (base < n)
+                c[i] = *reinterpret_cast<const P *>(xr + base);
+        }
+        float mu = 0.f;
+        if (!RMS) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+                if ((i * 256 + t) * VEC < n) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j)
+                        s += Elem<T>::ld(&c[i].v[j]);
+                }
+            mu = block_sum(s, red, lane, w) / (float)n;
+        }
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if ((i * 256 + t) * VEC < n) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float d = Elem<T>::ld(&c[i].v[j]) - mu;
+                    q += d * d;
+                }
+            }
+        const float rstd = 1.0f / sqrtf(block_sum(q, red, lane, w) / (float)n + eps);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int base = (i * 256 + t) * VEC;
+            if (base < n) {
+                P sc, bi, o;
+                if (scale_size != 1)
+                    sc = *reinterpret_cast<const P *>(scale + base);
+                if (bias && bias_size != 1)
+                    bi = *reinterpret_cast<const P *>(bias + base);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float sv = scale_size == 1 ? Elem<T>::ld(scale) : Elem<T>::ld(&sc.v[j]);
+                    const float bv = bias ? (bias_size == 1 ? Elem<T>::ld(bias) : Elem<T>::ld(&bi.v[j])) : 0.f;
+                    Elem<T>::st(&o.v[j], (Elem<T>::ld(&c[i].v[j]) - mu) * rstd * sv + bv);
+                }
+                *reinterpret_cast<P *>(yr + base) = o;
+            }
+        }
+    }
+}
+
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void softmax_blockreg_kernel(const T *__restrict__ x, T *__restrict__ y, long rows,
+                                                               int n) {
+    constexpr int VEC = Elem<T>::VEC;
+    using P = Pack<T, VEC>;
+    __shared__ float red[4];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const T *xr = x + row * (long)n;
+        T *yr = y + row * (long)n;
+        P c[CH];
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int base = (i * 256 + t) * VEC;
+            if (base < n) {
+                c[i] = *reinterpret_cast<const P *>(xr + base);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+                    m = fmaxf(m, Elem<T>::ld(&c[i].v[j]));
+            }
+        }
+        m = block_max(m, red, lane, w);
+        float e[CH][VEC];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if ((i * 256 + t) * VEC < n) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    e[i][j] = __expf(Elem<T>::ld(&c[i].v[j]) - m);
+                    s += e[i][j];
+                }
+            }
+        const float inv = 1.0f / block_sum(s, red, lane, w);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int base = (i * 256 + t) * VEC;
+            if (base < n) {
+                P o;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+                    Elem<T>::st(&o.v[j], e[i][j] * inv);
+                *reinterpret_cast<P *>(yr + base) = o;
+            }
+        }
+    }
+}
+
 static inline bool is_aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 // persistent grid: at most 8 blocks (32 waves) per CU
+static inline int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
 static inline unsigned pgrid(int64_t blocks, int num_cu) {
-    const int64_t cap = (int64_t)num_cu * 8;
+    static const int per_cu = env_int("IROCM_ROWOPS_BLOCKS_PER_CU", 8); // tuning hook
+    const int64_t cap = (int64_t)num_cu * per_cu;
     return (unsigned)(blocks < cap ? (blocks < 1 ? 1 : blocks) : cap);
 }
 
@@ -398,8 +538,16 @@ static int softmax_dispatch(infiniRocmRuntime_t rt, const T *x, T *y, int64_t ou
         }
         else {
             const unsigned g = (unsigned)(outer < 8192 ? outer : 8192);
-            hipLaunchKernelGGL((softmax_block_kernel<T>), dim3(g), dim3(256), 0, rt->stream, x, y,
-                               (long)outer, (long)dimsize);
+            const int bch = (int)ceil_div(dimsize, (int64_t)256 * VEC);
+            if (al && bch <= 4)
+                hipLaunchKernelGGL((softmax_blockreg_kernel<T, 4>), dim3(g), dim3(256), 0, rt->stream, x, y, (long)outer,
+                                   (int)dimsize);
+            else if (al && bch <= 8)
+                hipLaunchKernelGGL((softmax_blockreg_kernel<T, 8>), dim3(g), dim3(256), 0, rt->stream, x, y, (long)outer,
+                                   (int)dimsize);
+            else
+                hipLaunchKernelGGL((softmax_block_kernel<T>), dim3(g), dim3(256), 0, rt->stream, x, y,
+                                   (long)outer, (long)dimsize);
         }
 #undef SM_GO
     } else {
@@ -420,7 +568,10 @@ static int norm_dispatch(infiniRocmRuntime_t rt, const T *x, const T *scale, con
                     (bias == nullptr || is_aligned16(bias)) && (n % VEC == 0);
     const int chunks = (int)ceil_div(n, (int64_t)64 * VEC);
     const int64_t row_bytes = n * (int64_t)sizeof(T);
-    const int rpw = (!al || outer < 4096) ? 1 : (row_bytes <= 1024 ? 4 : (row_bytes <= 3072 ? 2 : 1));
+    int rpw = (!al || outer < 4096) ? 1 : (row_bytes <= 1024 ? 4 : (row_bytes <= 3072 ? 2 : 1));
+    static const int rpw_env = env_int("IROCM_NORM_RPW", 0); // tuning hook
+    if (rpw_env && al)
+        rpw = rpw_env;
 #define NORM_GO(C, A, R)                                                                           \
     hipLaunchKernelGGL((norm_wave_kernel<T, C, A, RMS, R>), dim3(pgrid(ceil_div(outer, 4 * R), rt->num_cu)), \
                        dim3(256), 0, rt->stream, x, scale, bias, y, (long)outer, (int)n,           \
@@ -439,8 +590,17 @@ static int norm_dispatch(infiniRocmRuntime_t rt, const T *x, const T *scale, con
         if (al) NORM_GO(4, true, 1); else NORM_GO(4, false, 1);
     } else {
         const unsigned g = (unsigned)(outer < 8192 ? outer : 8192);
-        hipLaunchKernelGGL((norm_block_kernel<T, RMS>), dim3(g), dim3(256), 0, rt->stream, x, scale,
-                           bias, y, (long)outer, (long)n, (int)scale_size, (int)bias_size, eps);
+        const int bch = (int)ceil_div(n, (int64_t)256 * VEC); // 16-byte chunks per thread of a block-resident row
+#define NORM_BR(C)                                                                                 \
+    hipLaunchKernelGGL((norm_blockreg_kernel<T, C, RMS>), dim3(g), dim3(256), 0, rt->stream, x, scale, bias, y, \
+                       (long)outer, (int)n, (int)scale_size, (int)bias_size, eps)
+        if (al && bch <= 2) NORM_BR(2);
+        else if (al && bch <= 4) NORM_BR(4);
+        else if (al && bch <= 8) NORM_BR(8);
+        else
+            hipLaunchKernelGGL((norm_block_kernel<T, RMS>), dim3(g), dim3(256), 0, rt->stream, x, scale,
+                               bias, y, (long)outer, (long)n, (int)scale_size, (int)bias_size, eps);
+#undef NORM_BR
     }
 #undef NORM_GO
     IROCM_LAUNCH_CHECK("norm");

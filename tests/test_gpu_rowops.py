@@ -40,6 +40,7 @@ def test_softmax_reference_kats_fp16(rt, axis, line):
 SOFTMAX_SHAPES = [
     ((4, 12, 64, 512), 3), ((7, 1000), 1), ((3, 5, 17), 2), ((6, 33, 40), 1), ((5, 64, 3), 0),
     ((2, 2048), 1), ((3, 5000), 1), ((2, 20000), 1), ((16, 1), 1), ((1, 7), 0), ((4, 513), 1),
+    ((3, 8192), 1), ((2, 16384), 1), ((3, 4104), 1), ((300, 6144), 1),  # block-resident rows (softmax_blockreg_kernel)
 ]
 
 
@@ -80,7 +81,8 @@ def test_layernorm_reference_kat_fp16(rt):
 
 
 LN_SHAPES = [((32, 512, 768), -1), ((5, 7, 33), -1), ((4, 3, 8, 16), 2), ((9, 1024), 1), ((3, 4096), 1),
-             ((2, 10000), 1), ((6, 1), 1), ((4, 257), 1)]
+             ((2, 10000), 1), ((6, 1), 1), ((4, 257), 1),
+             ((5, 8192), 1), ((3, 16384), 1), ((2, 12288), 1), ((300, 5120), 1)]  # block-resident rows (norm_blockreg_kernel)
 
 
 @pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
