@@ -84,6 +84,48 @@ __global__ __launch_bounds__(256) void conv_repack_w(const unsigned short *__res
     }
 }
 
+// Stride 2 x 2 (every ResNet down-sampling layer): one thread per 4 consecutive input columns of one (virtual) input
+// row -> two outputs in each of the two column phases of that row's phase; 32-bit index math.
+// slot[py*2 + px] < 0: that phase is not read by any tap and is not materialised.
+struct PhaseSplit2Args {
+    const unsigned short *x;
+    unsigned short *o;
+    int planes, in_h, in_w, oh, ow;
+    long plane_elems; // planes * oh * ow
+    signed char slot[4];
+};
+__global__ __launch_bounds__(256) void conv_phase_split_2x2(PhaseSplit2Args a) {
+    const int quads = (a.ow + 1) / 2; // 4 input columns = 2 output columns per thread
+    const int rows = 2 * a.oh;
+    const int total = a.planes * rows * quads;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int jq = i % quads;
+        const int q = i / quads;
+        const int iy = q % rows, pl = q / rows;
+        const int py = iy & 1, oy = iy >> 1;
+        if (a.slot[py * 2] < 0 && a.slot[py * 2 + 1] < 0)
+            continue; // no tap reads this row parity (1x1 / 2: odd rows)
+        const unsigned short *src = a.x + ((long)pl * a.in_h + iy) * a.in_w + 4 * jq;
+        unsigned short v[4] = {0, 0, 0, 0};
+        if (iy < a.in_h) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * jq + e < a.in_w)
+                    v[e] = src[e];
+        }
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+            const int sl = a.slot[py * 2 + px];
+            if (sl < 0)
+                continue;
+            unsigned short *dst = a.o + sl * a.plane_elems + ((long)pl * a.oh + oy) * a.ow + 2 * jq;
+            dst[0] = v[px];
+            if (2 * jq + 1 < a.ow)
+                dst[1] = v[2 + px];
+        }
+    }
+}
+
 // o[f][t*c + cc] = w[f][cc][t], zero for k in [c*rs, kpad)
 __global__ __launch_bounds__(256) void conv_repack_w_flat(const unsigned short *__restrict__ w,
                                                           unsigned short *__restrict__ o, int f, int c, int rs, int kpad) {
@@ -461,9 +503,22 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
         ps.o = (unsigned short *)(ws + w_bytes);
         ps.planes = (long)n * c;
         ps.in_h = h; ps.in_w = wd; ps.oh = oh; ps.ow = ow; ps.sh = sh; ps.sw = sw;
-        long g = ceil_div(p.plane_elems * ps.nslots, 256);
-        if (g > (long)rt->num_cu * 32) g = (long)rt->num_cu * 32;
-        hipLaunchKernelGGL(conv_phase_split, dim3((unsigned)g), dim3(256), 0, rt->stream, ps);
+        const long work2 = (long)n * c * 2 * oh * ((ow + 1) / 2);
+        // all four phases wanted (3x3/2, 7x7/2): the quad kernel; a 1x1/2 reads one phase and is faster element-wise
+        if (sh == 2 && sw == 2 && ps.nslots == 4 && work2 + (long)rt->num_cu * 32 * 256 < (1l << 31)) {
+            PhaseSplit2Args a2;
+            a2.x = ps.x; a2.o = ps.o; a2.planes = n * c; a2.in_h = h; a2.in_w = wd; a2.oh = oh; a2.ow = ow;
+            a2.plane_elems = p.plane_elems;
+            for (int i = 0; i < 4; ++i)
+                a2.slot[i] = p.slot[i];
+            long g = ceil_div(work2, 256);
+            if (g > (long)rt->num_cu * 32) g = (long)rt->num_cu * 32;
+            hipLaunchKernelGGL(conv_phase_split_2x2, dim3((unsigned)g), dim3(256), 0, rt->stream, a2);
+        } else {
+            long g = ceil_div(p.plane_elems * ps.nslots, 256);
+            if (g > (long)rt->num_cu * 32) g = (long)rt->num_cu * 32;
+            hipLaunchKernelGGL(conv_phase_split, dim3((unsigned)g), dim3(256), 0, rt->stream, ps);
+        }
         IROCM_LAUNCH_CHECK("conv_phase_split");
         p.x = ps.o;
     }

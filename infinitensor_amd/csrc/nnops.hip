@@ -197,22 +197,26 @@ struct PoolArgs {
     int kh, kw, dh, dw, ph, pw, sh, sw;
 };
 
-template <typename T, bool MAX>
+// IDX = int when every index fits 31 bits (64-bit div/mod per output is most of the cost of this kernel otherwise)
+template <typename T, bool MAX, typename IDX>
 __global__ __launch_bounds__(256) void pool2d_kernel(const T *__restrict__ x, T *__restrict__ y, PoolArgs p) {
-    const long total = p.n * p.c * p.oh * p.ow;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long ox = i % p.ow, oy = (i / p.ow) % p.oh, plane = i / (p.ow * p.oh);
-        const T *xp = x + plane * p.h * p.w;
+    const IDX total = (IDX)(p.n * p.c * p.oh * p.ow);
+    const IDX ow = (IDX)p.ow, oh = (IDX)p.oh, w = (IDX)p.w, h = (IDX)p.h;
+    const int sh = (int)p.sh, sw = (int)p.sw, ph = (int)p.ph, pw = (int)p.pw, dh = (int)p.dh, dw = (int)p.dw;
+    for (IDX i = (IDX)blockIdx.x * 256 + threadIdx.x; i < total; i += (IDX)gridDim.x * 256) {
+        const IDX q = i / ow, ox = i - q * ow;
+        const IDX plane = q / oh, oy = q - plane * oh;
+        const T *xp = x + (long)plane * h * w;
         float acc = MAX ? -INFINITY : 0.f;
         for (int r = 0; r < p.kh; ++r) {
-            const long iy = oy * p.sh - p.ph + (long)r * p.dh;
-            if (iy < 0 || iy >= p.h)
+            const IDX iy = oy * sh - ph + r * dh;
+            if (iy < 0 || iy >= h)
                 continue;
             for (int s = 0; s < p.kw; ++s) {
-                const long ix = ox * p.sw - p.pw + (long)s * p.dw;
-                if (ix < 0 || ix >= p.w)
+                const IDX ix = ox * sw - pw + s * dw;
+                if (ix < 0 || ix >= w)
                     continue;
-                const float v = LdSt<T>::ld(xp + iy * p.w + ix);
+                const float v = LdSt<T>::ld(xp + iy * w + ix);
                 acc = MAX ? fmaxf(acc, v) : acc + v;
             }
         }
@@ -314,16 +318,23 @@ int infini_rocm_pool2d(infiniRocmRuntime_t rt, int kind, int dtype, const void *
                             dh == 1 && dw == 1;
     long g = ceil_div(total, 256);
     if (g > (long)rt->num_cu * 16) g = (long)rt->num_cu * 16;
+    const bool small = total + g * 256 < (1l << 31) && h * w < (1l << 31); // 32-bit index math is safe
 #define GO(T)                                                                                      \
     if (global_avg)                                                                                \
         hipLaunchKernelGGL((global_avgpool_kernel<T>), dim3((unsigned)ceil_div(n * c, 4)),         \
                            dim3(256), 0, rt->stream, (const T *)x, (T *)y, (long)(n * c),          \
                            (long)(h * w));                                                         \
+    else if (kind == 0 && small)                                                                   \
+        hipLaunchKernelGGL((pool2d_kernel<T, true, int>), dim3((unsigned)g), dim3(256), 0, rt->stream, \
+                           (const T *)x, (T *)y, p);                                               \
     else if (kind == 0)                                                                            \
-        hipLaunchKernelGGL((pool2d_kernel<T, true>), dim3((unsigned)g), dim3(256), 0, rt->stream,  \
+        hipLaunchKernelGGL((pool2d_kernel<T, true, long>), dim3((unsigned)g), dim3(256), 0, rt->stream, \
+                           (const T *)x, (T *)y, p);                                               \
+    else if (small)                                                                                \
+        hipLaunchKernelGGL((pool2d_kernel<T, false, int>), dim3((unsigned)g), dim3(256), 0, rt->stream, \
                            (const T *)x, (T *)y, p);                                               \
     else                                                                                           \
-        hipLaunchKernelGGL((pool2d_kernel<T, false>), dim3((unsigned)g), dim3(256), 0, rt->stream, \
+        hipLaunchKernelGGL((pool2d_kernel<T, false, long>), dim3((unsigned)g), dim3(256), 0, rt->stream, \
                            (const T *)x, (T *)y, p)
     switch (dtype) {
     case INFINI_DT_F32: GO(float); break;
