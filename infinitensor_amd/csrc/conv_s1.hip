@@ -29,6 +29,7 @@
 //     3x3/2); on a phase plane every tap is again a constant shift of a unit-stride same-size access, so the same
 //     kernel runs with a per-tap (plane, shift) pair. Needs OH == ceil(H / sh) and OW == ceil(W / sw).
 #include "gemm_common.h"
+#include <cstdlib>
 
 namespace irocm {
 
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void conv_repack_w_flat(const unsigned short *
 }
 
 template <typename Tr, int WM, int WN, int BK, bool ROWTAP>
-__global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args p) {
+__global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void conv_s1_kernel(ConvS1Args p) {
     constexpr int BM = WM * 64, BN = WN * 64, APITCH = BK + 8;
     constexpr int A_BYTES = BM * APITCH * 2, ROWB = BN * 2, B_BYTES = BK * ROWB, STAGE = A_BYTES + B_BYTES;
     constexpr int NA = BM * (BK / 8) / 256;       // 16-byte A runs per thread per K-step
@@ -525,8 +526,11 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
     const bool bf = dtype == INFINI_DT_BF16;
     if (rowtap)
         return bf ? launch_s1<Bf16Traits, 1, 4, 32, true>(rt, p) : launch_s1<F16Traits, 1, 4, 32, true>(rt, p);
-    if (f <= 64 || c % 64 != 0)
+    if (f <= 64)
         return bf ? launch_s1<Bf16Traits, 1, 4, 32>(rt, p) : launch_s1<F16Traits, 1, 4, 32>(rt, p);
+    static const int cfg = getenv("IROCM_CONV_CFG") ? atoi(getenv("IROCM_CONV_CFG")) : 0; // tuning hook
+    if (c % 64 != 0 || cfg == 1)
+        return bf ? launch_s1<Bf16Traits, 2, 2, 32>(rt, p) : launch_s1<F16Traits, 2, 2, 32>(rt, p);
     return bf ? launch_s1<Bf16Traits, 2, 2, 64>(rt, p) : launch_s1<F16Traits, 2, 2, 64>(rt, p);
 }
 
