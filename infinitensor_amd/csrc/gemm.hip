@@ -342,6 +342,7 @@ int launch_gemm256(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool a_
 bool gemm256_supported(const GemmArgs &p, bool a_kmajor, bool b_kmajor);
 int launch_gemm256m32(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool a_kmajor, bool b_kmajor);
 int launch_gemm256w4(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool a_kmajor, bool b_kmajor);
+int launch_gemm256_splitk(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool a_kmajor, bool b_kmajor, int splits);
 
 template <typename Tr> static int launch_fast128(infiniRocmRuntime_t rt, GemmArgs p, bool akm, bool bkm) {
     p.tiles_m = (int)ceil_div(p.m, f128::BM);
@@ -385,8 +386,8 @@ static bool fast128_supported(const GemmArgs &p, bool akm, bool bkm) {
 }
 
 static const char *kVariantNames[] = {"generic64", "fast128_glds", "tile256_stagger", "tile256_pipelined", "tile256_mfma32",
-                                      "tile256_4wave"};
-constexpr int kNumVariants = 6;
+                                      "tile256_4wave", "tile256_splitk"};
+constexpr int kNumVariants = 7;
 constexpr int kDefault256 = 2; // schedule used by the heuristic
 
 } // namespace irocm
@@ -432,16 +433,29 @@ int infini_rocm_matmul(infiniRocmRuntime_t rt, int dtype, const void *a, const v
     p.bias_b = bias_stride_b; p.bias_m = bias_stride_m; p.bias_n = bias_stride_n;
     p.act = act;
     p.tiles_m = p.tiles_n = 0;
+    p.splitk = 1;
+    p.partial = nullptr;
     const bool akm = !trans_a, bkm = trans_b != 0;
 
     int variant = rt->matmul_variant;
     if (dtype == INFINI_DT_F32)
         variant = 0;
+    // split-K factor for the 256^2 kernel: fill the CUs when the tiles alone cannot and K is long enough that every
+    // slice still runs >= 8 K-tiles (the fp32 partial planes cost 8 bytes per output element and slice)
+    const long tiles256 = ceil_div(m, 256) * ceil_div(n, 256) * batch;
+    int splits = 1;
+    if (gemm256_supported(p, akm, bkm) && tiles256 * 2 <= rt->num_cu + rt->num_cu / 4) {
+        splits = (int)(rt->num_cu / tiles256);
+        const int max_by_k = (int)(k / (8 * 64));
+        if (splits > max_by_k) splits = max_by_k;
+        if (splits > 16) splits = 16;
+    }
     if (variant < 0) {
-        // heuristic: the 256^2 kernel wants at least ~one tile per CU; otherwise 128^2.
-        if (gemm256_supported(p, akm, bkm) &&
-            ceil_div(m, 256) * ceil_div(n, 256) * batch >= rt->num_cu / 2)
+        // heuristic: the 256^2 kernel wants at least ~one tile per CU; otherwise split-K; otherwise 128^2.
+        if (gemm256_supported(p, akm, bkm) && tiles256 >= rt->num_cu / 2 && splits < 2)
             variant = kDefault256;
+        else if (splits >= 2)
+            variant = 6;
         else if (fast128_supported(p, akm, bkm))
             variant = 1;
         else
@@ -452,6 +466,8 @@ int infini_rocm_matmul(infiniRocmRuntime_t rt, int dtype, const void *a, const v
         variant = 0;
     }
 
+    if (variant == 6)
+        return launch_gemm256_splitk(rt, dtype, p, akm, bkm, splits < 2 ? 2 : splits);
     if (variant == 5)
         return launch_gemm256w4(rt, dtype, p, akm, bkm);
     if (variant == 4)

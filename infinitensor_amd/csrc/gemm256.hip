@@ -37,7 +37,7 @@
 namespace irocm {
 namespace g256 {
 
-template <typename Tr, bool A_KMAJOR, bool B_KMAJOR, int SCHED>
+template <typename Tr, bool A_KMAJOR, bool B_KMAJOR, int SCHED, bool SPLITK = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63;
@@ -46,6 +46,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 
     const unsigned per_batch = (unsigned)p.tiles_m * p.tiles_n;
     unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+    int sp = 0; // K slice of this workgroup (slices of one tile are neighbours: they share nothing but the output tile)
+    if constexpr (SPLITK) {
+        sp = wg % p.splitk;
+        wg /= p.splitk;
+    }
     const int ib = wg / per_batch;
     wg -= ib * per_batch;
     constexpr int GROUP_M = 8;
@@ -61,7 +66,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     const unsigned short *B = (const unsigned short *)p.b + (long)ib * p.b_bs;
     const long lda = A_KMAJOR ? p.a_rs : p.a_cs;
     const long ldb = B_KMAJOR ? p.b_cs : p.b_rs;
-    const int nk = p.k / BK;
+    int nk = p.k / BK;
+    int kt0 = 0; // first K-tile of this workgroup
+    if constexpr (SPLITK) {
+        const int per = (nk + p.splitk - 1) / p.splitk;
+        kt0 = sp * per;
+        nk = min(per, nk - kt0); // host guarantees >= 1
+    }
 
     unsigned a_off[4], b_off[4];
     if constexpr (A_KMAJOR) offs_k(a_off, lda, m0, p.m, w, lane);
@@ -71,10 +82,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     const long a_step = A_KMAJOR ? (long)BK * 2 : (long)BK * lda * 2; // bytes per K-tile (wave-uniform)
     const long b_step = B_KMAJOR ? (long)BK * 2 : (long)BK * ldb * 2;
     auto stage_a = [&](int buf, int kt) {
-        stage4((const char *)A + (long)kt * a_step, a_off, smem + buf * BUF_BYTES, w);
+        stage4((const char *)A + (long)(kt0 + kt) * a_step, a_off, smem + buf * BUF_BYTES, w);
     };
     auto stage_b = [&](int buf, int kt) {
-        stage4((const char *)B + (long)kt * b_step, b_off, smem + buf * BUF_BYTES + OPER_BYTES, w);
+        stage4((const char *)B + (long)(kt0 + kt) * b_step, b_off, smem + buf * BUF_BYTES + OPER_BYTES, w);
     };
 
     // ---- per-lane LDS read addresses (byte offsets in the workgroup's LDS) ----------------------
@@ -290,6 +301,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     }
 
     // ---- epilogue ------------------------------------------------------------------------------
+    if constexpr (SPLITK) { // raw fp32 partial sums of this K slice; bias / activation / rounding in splitk_reduce
+        float *P = p.partial + ((long)sp * p.batch + ib) * p.m * p.n;
+        const bool inner = (m0 + BM <= p.m) && (n0 + BN <= p.n) && (p.n % 4 == 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = m0 + wr * 128 + i * 16 + l15;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = n0 + wc * 64 + j * 16 + g4 * 4;
+                if (inner) {
+                    *(f32x4 *)(P + (long)row * p.n + col) = acc[i][j];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (row < p.m && col + r < p.n)
+                            P[(long)row * p.n + col + r] = acc[i][j][r];
+                }
+            }
+        }
+        return;
+    }
     unsigned short *C = (unsigned short *)p.c + (long)ib * p.m * p.n;
     const unsigned short *bias = (const unsigned short *)p.bias;
     const bool interior = (m0 + BM <= p.m) && (n0 + BN <= p.n) && (p.n % 4 == 0);
@@ -342,6 +374,47 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     }
 }
 
+// out = round(act(sum_s partial[s] + bias)); one thread per 4 consecutive columns when n % 4 == 0
+template <typename Tr>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
+    const long mn = (long)p.m * p.n, total = (long)p.batch * mn;
+    const long plane = total; // elements per split plane
+    const unsigned short *bias = (const unsigned short *)p.bias;
+    unsigned short *C = (unsigned short *)p.c;
+    const bool vec = (p.n % 4 == 0);
+    const long items = vec ? total / 4 : total;
+    for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const long e0 = vec ? it * 4 : it;
+        const int cnt = vec ? 4 : 1;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < p.splitk; ++s) {
+            if (vec) {
+                const f32x4 t = *(const f32x4 *)(p.partial + s * plane + e0);
+                v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+            } else {
+                v[0] += p.partial[s * plane + e0];
+            }
+        }
+        const long ib = e0 / mn, rem = e0 - ib * mn;
+        const long row = rem / p.n, col = rem - row * p.n;
+        unsigned short o[4];
+        for (int r = 0; r < cnt; ++r) {
+            float x = v[r];
+            if (bias)
+                x += Tr::to_f32(bias[ib * p.bias_b + row * p.bias_m + (col + r) * p.bias_n]);
+            o[r] = Tr::from_f32(apply_act(x, p.act));
+        }
+        if (vec) {
+            u32x2_t pk;
+            pk[0] = (unsigned)o[0] | ((unsigned)o[1] << 16);
+            pk[1] = (unsigned)o[2] | ((unsigned)o[3] << 16);
+            *(u32x2_t *)(C + e0) = pk;
+        } else {
+            C[e0] = o[0];
+        }
+    }
+}
+
 } // namespace g256
 
 static bool al16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
@@ -361,6 +434,53 @@ bool gemm256_supported(const GemmArgs &p, bool akm, bool bkm) {
     if ((long)p.m * p.k >= (1l << 31) || (long)p.n * p.k >= (1l << 31))
         return false;
     return true;
+}
+
+// Split-K launch: `splits` workgroups per output tile + one reduce pass. For shapes whose 256^2 tiles cannot fill the
+// 256 CUs (a 2048-token activation times a 4096-wide weight is 128 tiles) but whose K is long.
+template <typename Tr> static int launch256_splitk(infiniRocmRuntime_t rt, GemmArgs p, bool akm, bool bkm, int splits) {
+    p.tiles_m = (int)ceil_div(p.m, g256::BM);
+    p.tiles_n = (int)ceil_div(p.n, g256::BN);
+    const int nk = p.k / g256::BK;
+    const int per = (nk + splits - 1) / splits;
+    splits = (nk + per - 1) / per; // no empty slice
+    void *ws = nullptr;
+    const size_t bytes = (size_t)splits * p.batch * p.m * p.n * sizeof(float);
+    int st = infini_rocm_workspace(rt, bytes, &ws);
+    if (st != INFINI_ROCM_OK)
+        return st;
+    p.splitk = splits;
+    p.partial = (float *)ws;
+    const unsigned grid = (unsigned)p.tiles_m * p.tiles_n * p.batch * splits;
+#define IROCM_G256S(AK, BK_)                                                                       \
+    do {                                                                                           \
+        auto kern = g256::gemm256_kernel<Tr, AK, BK_, 0, true>;                                    \
+        static bool attr_done = false;                                                             \
+        if (!attr_done) {                                                                          \
+            IROCM_HIP(hipFuncSetAttribute((const void *)kern,                                      \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,              \
+                                          g256::LDS_BYTES));                                       \
+            attr_done = true;                                                                      \
+        }                                                                                          \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), g256::LDS_BYTES, rt->stream, p);           \
+    } while (0)
+    if (akm && bkm) IROCM_G256S(true, true);
+    else if (akm && !bkm) IROCM_G256S(true, false);
+    else if (!akm && bkm) IROCM_G256S(false, true);
+    else IROCM_G256S(false, false);
+#undef IROCM_G256S
+    IROCM_LAUNCH_CHECK("gemm256_splitk");
+    const long items = (long)p.batch * p.m * p.n / ((p.n % 4 == 0) ? 4 : 1);
+    long g = ceil_div(items, 256);
+    if (g > (long)rt->num_cu * 16) g = (long)rt->num_cu * 16;
+    hipLaunchKernelGGL(g256::splitk_reduce_kernel<Tr>, dim3((unsigned)g), dim3(256), 0, rt->stream, p);
+    IROCM_LAUNCH_CHECK("splitk_reduce");
+    return INFINI_ROCM_OK;
+}
+
+int launch_gemm256_splitk(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool akm, bool bkm, int splits) {
+    return dtype == INFINI_DT_BF16 ? launch256_splitk<Bf16Traits>(rt, p, akm, bkm, splits)
+                                   : launch256_splitk<F16Traits>(rt, p, akm, bkm, splits);
 }
 
 template <typename Tr, int SCHED> static int launch256(infiniRocmRuntime_t rt, GemmArgs p, bool akm, bool bkm) {

@@ -26,6 +26,10 @@ struct GemmArgs {
     long bias_b, bias_m, bias_n;
     int act;
     int tiles_m, tiles_n;
+    // split-K (gemm256 only): `splitk` workgroups share one output tile, each sums a slice of K into its own fp32
+    // plane of `partial` [splitk][batch][m][n]; splitk_reduce adds the planes, the bias and the activation
+    int splitk;
+    float *partial;
 };
 
 // 16-bit element traits: how to feed v_mfma_f32_16x16x32_{bf16,f16} and convert on store.

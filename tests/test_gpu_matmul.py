@@ -62,10 +62,11 @@ SHAPES = [
     (2, 64, 64, 256),
     (1, 512, 512, 512),
     (1, 77, 53, 41),      # nothing aligned -> generic kernel
+    (1, 300, 264, 2048),  # long K, few tiles: the split-K heuristic (4 tiles x up to 4 K slices)
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("shape", SHAPES)
@@ -88,6 +89,23 @@ def test_matmul_16bit_variants(rt, shape, ta, tb, dtype, variant):
     err = np.abs(got - want)
     bound = tol * np.abs(want) + tol * np.sqrt(k)
     assert (err <= bound).all(), f"max err {err.max()} at {np.unravel_index(err.argmax(), err.shape)}"
+
+
+def test_matmul_splitk_heuristic_shapes(rt):
+    """Shapes the heuristic routes to split-K (Llama projections at 2048 tokens; a TP-8 shard): vs the fp64 oracle on a
+    row sample, and bit-identical across repeats (the reduce pass sums the slices in a fixed order)."""
+    rng = np.random.default_rng(17)
+    for m, n, k in ((2048, 4096, 4096), (2048, 512, 4096), (2048, 1024, 11008)):
+        a = rng.standard_normal((m, k)).astype(np.float32)
+        w = rng.standard_normal((k, n)).astype(np.float32)
+        ad, wd = dev(a, torch.bfloat16), dev(w, torch.bfloat16)
+        c1 = ops.matmul(rt, ad, wd)
+        c2 = ops.matmul(rt, ad, wd)
+        assert torch.equal(c1, c2)
+        rows = rng.choice(m, 16, replace=False)
+        want = R.matmul(R.round_to(a[rows], "bf16"), R.round_to(w, "bf16"))
+        err = np.abs(host(c1)[rows] - want)
+        assert (err <= 2 ** -7 * np.abs(want) + 2 ** -7 * np.sqrt(k)).all()
 
 
 @pytest.mark.parametrize("shape", [(1, 64, 64, 64), (2, 100, 36, 50), (1, 512, 512, 512), (1, 3, 7, 1000)])

@@ -16,7 +16,11 @@ def main():
     print("variants:", variants)
     shapes = [(1, 4096, 4096, 4096), (1, 8192, 8192, 8192), (1, 2048, 2048, 2048), (1, 16384, 768, 768),
               (1, 16384, 3072, 768), (1, 16384, 768, 3072), (384, 512, 512, 64), (384, 512, 64, 512),
-              (1, 2048, 12288, 4096), (1, 2048, 4096, 11008)]
+              (1, 2048, 12288, 4096), (1, 2048, 4096, 11008), (1, 2048, 4096, 4096), (1, 2048, 512, 4096),
+              (1, 2048, 4096, 1376), (1, 128, 1000, 2048)]
+    import os
+    if os.environ.get("PROBE_SHAPES") == "tp":
+        shapes = shapes[-6:]
     for dt in (torch.bfloat16, torch.float16):
         for (b, m, n, k) in shapes:
             for ta, tb in ((False, False), (False, True)):
@@ -39,6 +43,16 @@ def main():
                     rt.record(e1)
                     ms = rt.elapsed_ms(e0, e1) / iters
                     row.append(f"{variants[v][-9:]}={2.0 * b * m * n * k / ms / 1e9:7.1f}TF")
+                ops.set_matmul_variant(rt, -1)
+                for _ in range(3):
+                    ops.matmul(rt, a, w, None, ta, tb, out=c)
+                e0, e1 = Event(), Event()
+                rt.record(e0)
+                for _ in range(20):
+                    ops.matmul(rt, a, w, None, ta, tb, out=c)
+                rt.record(e1)
+                ms = rt.elapsed_ms(e0, e1) / 20
+                row.append(f"heuristic={2.0 * b * m * n * k / ms / 1e9:7.1f}TF")
                 ops.set_matmul_variant(rt, -1)
                 print(f"{str(dt)[6:]:9s} b{b} m{m} n{n} k{k} tA{int(ta)} tB{int(tb)}: " + "  ".join(row), flush=True)
     # fp32 generic
