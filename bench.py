@@ -201,13 +201,6 @@ def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
     wo = tp.shard_row(rnd(H, H), world, rank).contiguous()
     wg, wu = (tp.shard_column(rnd(H, F), world, rank)[0].contiguous() for _ in range(2))
     wd = tp.shard_row(rnd(F, H), world, rank).contiguous()
-    # the FFN slice of a rank (11008 / 8 = 1376) is padded with zero columns / rows to a multiple of the GEMM K-tile
-    # (64): silu(0) * 0 = 0 times zero rows of W_down adds nothing; FLOPs are counted on the real sizes
-    fl = wg.shape[1]
-    if fl % 64:
-        padn = 64 - fl % 64
-        wg, wu = (torch.nn.functional.pad(w_, (0, padn)).contiguous() for w_ in (wg, wu))
-        wd = torch.nn.functional.pad(wd, (0, 0, 0, padn)).contiguous()
     n1, n2 = torch.ones(H, device="cuda", dtype=dt), torch.ones(H, device="cuda", dtype=dt)
     scale = torch.full((1,), float(D) ** 0.5, device="cuda", dtype=dt)
     torch.cuda.synchronize()

@@ -93,6 +93,7 @@ struct infiniRocmRuntime {
     bool capturing = false;
     int matmul_variant = -1;
     int conv_variant = -1;
+    void *zeros = nullptr; // 256 zero bytes (K-tail source for the LDS-DMA GEMM staging)
     int num_cu = 256;
     void *comm = nullptr; // rcclComm_t, owned by comm.cc
     int comm_world = 1, comm_rank = 0;

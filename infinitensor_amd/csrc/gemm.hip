@@ -221,15 +221,17 @@ __global__ __launch_bounds__(256) void gemm_fast128(GemmArgs p) {
     const long lda = A_KMAJOR ? p.a_rs : p.a_cs; // leading dimension of the stored matrix
     const long ldb = B_KMAJOR ? p.b_cs : p.b_rs;
 
+    // chunks of the last K-tile that start at k >= p.k come from a block of zeros (k % 8 == 0 but k % 64 != 0)
+    const unsigned short *Z = (const unsigned short *)p.zeros;
     auto stage = [&](int buf, int k0) {
         if constexpr (A_KMAJOR)
-            stage_kmajor(A, lda, m0, p.m, k0, a_tile(buf), w, lane);
+            stage_kmajor(A, lda, m0, p.m, k0, a_tile(buf), w, lane, p.k, Z);
         else
-            stage_mnmajor(A, lda, m0, p.m, k0, a_tile(buf), w, lane);
+            stage_mnmajor(A, lda, m0, p.m, k0, a_tile(buf), w, lane, p.k, Z);
         if constexpr (B_KMAJOR)
-            stage_kmajor(B, ldb, n0, p.n, k0, b_tile(buf), w, lane);
+            stage_kmajor(B, ldb, n0, p.n, k0, b_tile(buf), w, lane, p.k, Z);
         else
-            stage_mnmajor(B, ldb, n0, p.n, k0, b_tile(buf), w, lane);
+            stage_mnmajor(B, ldb, n0, p.n, k0, b_tile(buf), w, lane, p.k, Z);
     };
 
     f32x4 acc[4][4];
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(256) void gemm_fast128(GemmArgs p) {
         for (int j = 0; j < 4; ++j)
             acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.k / BK;
+    const int nk = (p.k + BK - 1) / BK;
     // One K-tile step with a COMPILE-TIME buffer index: hipcc only keeps the LDS-DMA of the next
     // tile in flight across the ds_reads of the current one when it can prove the two LDS ranges
     // distinct; a runtime (kt & 1) index makes it drain vmcnt(0) before the first ds_read.
@@ -372,7 +374,7 @@ template <typename Tr> static int launch_fast128(infiniRocmRuntime_t rt, GemmArg
 static bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
 static bool fast128_supported(const GemmArgs &p, bool akm, bool bkm) {
-    if (p.k % f128::BK != 0 || p.k < f128::BK)
+    if (p.k % 8 != 0 || p.k < 8) // 16-byte K runs; a K tail inside the last 64-wide tile is zero-filled
         return false;
     if (!aligned16(p.a) || !aligned16(p.b) || (p.a_bs % 8) || (p.b_bs % 8))
         return false;
@@ -435,6 +437,7 @@ int infini_rocm_matmul(infiniRocmRuntime_t rt, int dtype, const void *a, const v
     p.tiles_m = p.tiles_n = 0;
     p.splitk = 1;
     p.partial = nullptr;
+    p.zeros = rt->zeros;
     const bool akm = !trans_a, bkm = trans_b != 0;
 
     int variant = rt->matmul_variant;

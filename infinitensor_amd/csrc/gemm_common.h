@@ -30,6 +30,7 @@ struct GemmArgs {
     // plane of `partial` [splitk][batch][m][n]; splitk_reduce adds the planes, the bias and the activation
     int splitk;
     float *partial;
+    const void *zeros; // >= 16 zero bytes in device memory: source of K-tail chunks past k (fast128)
 };
 
 // 16-bit element traits: how to feed v_mfma_f32_16x16x32_{bf16,f16} and convert on store.
@@ -89,8 +90,11 @@ constexpr int TILE_BYTES = 128 * 64 * 2; // 16 KiB per operand tile
 
 // K-major operand tile: image [128 rows][64 k] (128 B rows), physical 16-B chunk c' of row r holds
 // logical chunk c' ^ ((r >> 1) & 7): ds_read_b128 lane groups then hit 16 distinct 16-B slots.
+// `kend`: chunks starting at k >= kend are fetched from `zeros` instead (K tail of a matrix whose k is a multiple of 8
+// but not of BK); pass kend = INT_MAX-like and zeros = nullptr-safe value when there is no tail.
 __device__ inline void stage_kmajor(const unsigned short *base, long ld, int row0, int rows, int k0,
-                                    char *lds_tile, int w, int lane) {
+                                    char *lds_tile, int w, int lane, int kend = 0x7fffffff,
+                                    const unsigned short *zeros = nullptr) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int piece = w * 4 + i;
@@ -99,6 +103,8 @@ __device__ inline void stage_kmajor(const unsigned short *base, long ld, int row
         int gr = row0 + r;
         gr = gr < rows ? gr : rows - 1;
         const unsigned short *src = base + (long)gr * ld + k0 + c_log * 8;
+        if (k0 + c_log * 8 >= kend)
+            src = zeros;
         __builtin_amdgcn_global_load_lds(IROCM_GLB_PTR(src), IROCM_LDS_PTR(lds_tile + piece * 1024), 16, 0, 0);
     }
 }
@@ -109,7 +115,8 @@ __device__ inline void stage_kmajor(const unsigned short *base, long ld, int row
 __device__ inline int mn_f(int kr) { return (kr & 3) | (((kr >> 3) & 1) << 2); }
 
 __device__ inline void stage_mnmajor(const unsigned short *base, long ld, int col0, int cols, int k0,
-                                     char *lds_tile, int w, int lane) {
+                                     char *lds_tile, int w, int lane, int kend = 0x7fffffff,
+                                     const unsigned short *zeros = nullptr) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int piece = w * 4 + i;
@@ -118,6 +125,8 @@ __device__ inline void stage_mnmajor(const unsigned short *base, long ld, int co
         int gc = col0 + c_log * 8;
         gc = gc <= cols - 8 ? gc : cols - 8;
         const unsigned short *src = base + (long)(k0 + kr) * ld + gc;
+        if (k0 + kr >= kend)
+            src = zeros;
         __builtin_amdgcn_global_load_lds(IROCM_GLB_PTR(src), IROCM_LDS_PTR(lds_tile + piece * 1024), 16, 0, 0);
     }
 }

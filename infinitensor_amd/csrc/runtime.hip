@@ -49,6 +49,11 @@ int infini_rocm_runtime_create(int device, infiniRocmRuntime_t *out) {
         IROCM_FAIL(INFINI_ROCM_HIP_ERROR, "hipStreamCreate failed: %s", hipGetErrorString(e));
     }
     rt->stream = rt->own_stream;
+    if (hipMalloc(&rt->zeros, 256) != hipSuccess || hipMemset(rt->zeros, 0, 256) != hipSuccess) {
+        (void)hipStreamDestroy(rt->own_stream);
+        delete rt;
+        IROCM_FAIL(INFINI_ROCM_HIP_ERROR, "cannot allocate the runtime's zero block");
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess)
         rt->num_cu = prop.multiProcessorCount;
@@ -66,6 +71,8 @@ int infini_rocm_runtime_destroy(infiniRocmRuntime_t rt) {
     (void)infini_rocm_comm_destroy(rt);
     if (rt->workspace)
         (void)hipFree(rt->workspace);
+    if (rt->zeros)
+        (void)hipFree(rt->zeros);
     if (rt->own_stream)
         (void)hipStreamDestroy(rt->own_stream);
     delete rt;

@@ -63,6 +63,9 @@ SHAPES = [
     (1, 512, 512, 512),
     (1, 77, 53, 41),      # nothing aligned -> generic kernel
     (1, 300, 264, 2048),  # long K, few tiles: the split-K heuristic (4 tiles x up to 4 K slices)
+    (2, 136, 200, 1376),  # K % 64 = 32 (Llama FFN / 8): zero-filled K tail in the LDS-DMA kernel
+    (1, 128, 128, 72),    # K = 64 + 8
+    (1, 64, 72, 8),       # K smaller than one tile
 ]
 
 
