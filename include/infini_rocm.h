@@ -333,6 +333,12 @@ int infini_rocm_expand(infiniRocmRuntime_t rt, int dtype, const void *x, void *y
 int infini_rocm_gather(infiniRocmRuntime_t rt, int dtype, int index_dtype, const void *data,
                        const void *indices, void *y, int64_t outer, int64_t axis_dim, int64_t n_indices,
                        int64_t inner);
+/* GatherElements (reference: _gather_elements_kernel, src/kernels/cuda/gather_elements.cu:4-35; operator
+ * gather_elements.cc:27-39): y has index_shape; y[i] = data[i with coordinate `axis` replaced by indices[i]].
+ * indices I32 / I64 (negative wraps); data and index ranks equal, off-axis index extents <= data extents. */
+int infini_rocm_gather_elements(infiniRocmRuntime_t rt, int dtype, int index_dtype, const void *data,
+                                const void *indices, void *y, int ndim, const int64_t *data_shape,
+                                const int64_t *index_shape, int axis);
 /* Where: out = cond ? x : y with 3-way broadcast; cond is 1 byte per element (reference: WhereCuda,
  * src/kernels/cuda/where.cu:4-63). Strides are element strides over the OUTPUT index space. */
 int infini_rocm_where(infiniRocmRuntime_t rt, int dtype, const void *x, const void *y, const void *cond,

@@ -38,6 +38,12 @@ static inline unsigned grid_for(long items, int num_cu) {
 
 // out[i] = in[sum_d idx_d * sin_d]; one item = one element of BYTES bytes (a whole 16-byte vector
 // when the host found the inner dimension contiguous on both sides).
+struct GeArgs {
+    int ndim, axis;
+    long total, axis_dim;
+    long idx_shape[INFINI_ROCM_MAX_DIMS], data_stride[INFINI_ROCM_MAX_DIMS];
+};
+
 template <int BYTES>
 __global__ __launch_bounds__(256) void strided_gather_kernel(const void *__restrict__ in, void *__restrict__ out,
                                                              IdxArgs p) {
@@ -117,6 +123,34 @@ static int launch_strided(infiniRocmRuntime_t rt, int elem, const void *in, void
     }
     IROCM_LAUNCH_CHECK("strided_gather");
     return INFINI_ROCM_OK;
+}
+
+// ---- gather_elements -----------------------------------------------------------------------------
+// out[..i..] = data[.. idx[..i..] on `axis` ..]: index / output viewed as [outer, n_idx, inner], data as
+// [outer, axis_dim, inner] (all other extents equal — ONNX allows index extents <= data extents off-axis; the
+// general case passes per-dimension strides, this kernel covers equal off-axis extents, which is what the
+// reference's tests and models use: test_cuda_gather_elements.cc).
+template <int BYTES, typename I>
+__global__ __launch_bounds__(256) void gather_elements_kernel(const void *__restrict__ data, const I *__restrict__ idx,
+                                                              void *__restrict__ out, GeArgs p) {
+    using R = typename Raw<BYTES>::t;
+    const R *src = (const R *)data;
+    R *dst = (R *)out;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long)gridDim.x * 256) {
+        long rem = i, off = 0;
+        for (int d = p.ndim - 1; d >= 0; --d) {
+            const long q = rem / p.idx_shape[d];
+            long c = rem - q * p.idx_shape[d];
+            if (d == p.axis) {
+                c = (long)idx[i];
+                if (c < 0)
+                    c += p.axis_dim; // ONNX negative index
+            }
+            off += c * p.data_stride[d];
+            rem = q;
+        }
+        dst[i] = src[off];
+    }
 }
 
 // ---- gather ------------------------------------------------------------------------------------
@@ -315,6 +349,52 @@ int infini_rocm_expand(infiniRocmRuntime_t rt, int dtype, const void *x, void *y
     }
     p.total = total;
     return launch_strided(rt, elem, x, y, p);
+}
+
+int infini_rocm_gather_elements(infiniRocmRuntime_t rt, int dtype, int index_dtype, const void *data,
+                                const void *indices, void *y, int ndim, const int64_t *data_shape,
+                                const int64_t *index_shape, int axis) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    const int elem = (int)dtype_size(dtype);
+    IROCM_CHECK_ARG(elem_ok(elem), "gather_elements: unsupported dtype %s", dtype_name(dtype));
+    IROCM_CHECK_ARG(index_dtype == INFINI_DT_I32 || index_dtype == INFINI_DT_I64,
+                    "gather_elements: indices must be int32 or int64 (reference gather_elements.cc:33-39)");
+    IROCM_CHECK_ARG(ndim >= 1 && ndim <= INFINI_ROCM_MAX_DIMS && axis >= 0 && axis < ndim, "gather_elements: bad rank / axis");
+    GeArgs p;
+    p.ndim = ndim;
+    p.axis = axis;
+    p.total = 1;
+    long st = 1;
+    for (int d = ndim - 1; d >= 0; --d) {
+        IROCM_CHECK_ARG(index_shape[d] >= 0 && data_shape[d] >= 0, "gather_elements: negative extent");
+        IROCM_CHECK_ARG(d == axis || index_shape[d] <= data_shape[d], "gather_elements: index extent exceeds data extent off-axis");
+        p.idx_shape[d] = index_shape[d];
+        p.data_stride[d] = st;
+        st *= data_shape[d];
+        p.total *= index_shape[d];
+    }
+    p.axis_dim = data_shape[axis];
+    if (p.total == 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(data && indices && y, "gather_elements: NULL tensor");
+    const unsigned g = grid_for(p.total, rt->num_cu);
+#define GE(B)                                                                                      \
+    if (index_dtype == INFINI_DT_I64)                                                              \
+        hipLaunchKernelGGL((gather_elements_kernel<B, int64_t>), dim3(g), dim3(256), 0, rt->stream, data, \
+                           (const int64_t *)indices, y, p);                                        \
+    else                                                                                           \
+        hipLaunchKernelGGL((gather_elements_kernel<B, int32_t>), dim3(g), dim3(256), 0, rt->stream, data, \
+                           (const int32_t *)indices, y, p);                                        \
+    break
+    switch (elem) {
+    case 1: GE(1);
+    case 2: GE(2);
+    case 4: GE(4);
+    default: GE(8);
+    }
+#undef GE
+    IROCM_LAUNCH_CHECK("gather_elements");
+    return INFINI_ROCM_OK;
 }
 
 int infini_rocm_gather(infiniRocmRuntime_t rt, int dtype, int index_dtype, const void *data,

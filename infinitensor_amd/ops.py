@@ -439,6 +439,48 @@ def gather(rt: RocmRuntime, data: torch.Tensor, indices: torch.Tensor, axis: int
     return out
 
 
+def gather_elements(rt: RocmRuntime, data: torch.Tensor, indices: torch.Tensor, axis: int = 0,
+                    out: torch.Tensor | None = None) -> torch.Tensor:
+    """out[i] = data[i with coordinate `axis` replaced by indices[i]]; output has the index shape
+    (src/operators/gather_elements.cc:27-39)."""
+    axis = _real_axis(axis, data.dim())
+    if indices.dtype not in (torch.int32, torch.int64):
+        raise TypeError("gather_elements indices must be int32 or int64")
+    if indices.dim() != data.dim():
+        raise ValueError("data and indices must have the same rank")  # reference: checkShape
+    if out is None:
+        out = torch.empty(indices.shape, dtype=data.dtype, device=data.device)
+    check(lib().infini_rocm_gather_elements(rt.handle, dtype_of(data), dtype_of(indices), _ptr(data), _ptr(indices),
+                                            _ptr(out), data.dim(), _i64arr(list(data.shape)),
+                                            _i64arr(list(indices.shape)), axis))
+    return out
+
+
+def depth_to_space(rt: RocmRuntime, x: torch.Tensor, blocksize: int, mode: str = "DCR") -> torch.Tensor:
+    """ONNX DepthToSpace as reshape -> transpose -> reshape (src/operators/transpose.cc:68-110,
+    src/kernels/cuda/transpose.cc:47-90: perm {0,3,4,1,5,2} for DCR, {0,1,4,2,5,3} for CRD)."""
+    n, c, h, w = x.shape
+    b = int(blocksize)
+    if c % (b * b):
+        raise ValueError("channels not divisible by blocksize^2")
+    if mode == "DCR":
+        y = transpose(rt, x.view(n, b, b, c // (b * b), h, w), (0, 3, 4, 1, 5, 2))
+    else:
+        y = transpose(rt, x.view(n, c // (b * b), b, b, h, w), (0, 1, 4, 2, 5, 3))
+    return y.view(n, c // (b * b), h * b, w * b)
+
+
+def extend(rt: RocmRuntime, x: torch.Tensor, dim: int, num: int) -> torch.Tensor:
+    """Repeat x (num + 1) times along `dim` (src/operators/extend.cc:14-18, src/kernels/cuda/extend.cu:3-15)."""
+    dim = _real_axis(dim, x.dim())
+    outer = math.prod(x.shape[:dim])
+    blk = math.prod(x.shape[dim:])
+    y = expand(rt, x.reshape(outer, 1, blk), (outer, num + 1, blk))
+    shape = list(x.shape)
+    shape[dim] *= num + 1
+    return y.view(shape)
+
+
 def where(rt: RocmRuntime, x: torch.Tensor, y: torch.Tensor, cond: torch.Tensor,
           out: torch.Tensor | None = None) -> torch.Tensor:
     """cond ? x : y; operator input order x, y, cond (include/operators/where.h:9-34)."""

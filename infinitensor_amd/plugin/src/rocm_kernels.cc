@@ -13,6 +13,7 @@
 #include "operators/conv.h"
 #include "operators/element_wise.h"
 #include "operators/expand.h"
+#include "operators/extend.h"
 #include "operators/gather.h"
 #include "operators/layer_norm.h"
 #include "operators/matmul.h"
@@ -382,6 +383,44 @@ class GatherRocm : public RocmKernelWithoutConfig {
     }
 };
 REGISTER_KERNEL(Device::ROCM, OpType::Gather, GatherRocm, "Gather_ROCM");
+
+class GatherElementsRocm : public RocmKernelWithoutConfig {
+    void compute(const Operator &_op, const RuntimeObj *ctx) const override {
+        auto op = as<GatherElementsObj>(_op);
+        const auto in = op->getInputs(0), idx = op->getInputs(1);
+        auto ds = dims64(in->getDims()), is = dims64(idx->getDims());
+        IT_ASSERT(ds.size() == is.size() && ds.size() <= INFINI_ROCM_MAX_DIMS);
+        ROCM_CALL(infini_rocm_gather_elements(H(ctx), DTI(in), DTI(idx), P(in), P(idx), P(op->getOutput()), (int)ds.size(),
+                                              ds.data(), is.data(), op->getAxis()));
+    }
+};
+REGISTER_KERNEL(Device::ROCM, OpType::GatherElements, GatherElementsRocm, "GatherElements_ROCM");
+
+// DepthToSpace = reshape to 6-D, transpose, reshape (reference: DepthToSpaceCuda, src/kernels/cuda/transpose.cc:47-90)
+class DepthToSpaceRocm : public RocmKernelWithoutConfig {
+    void compute(const Operator &_op, const RuntimeObj *ctx) const override {
+        auto op = as<DepthToSpaceObj>(_op);
+        const auto in = op->getInputs(0);
+        auto shape = dims64(op->getReshapeDim());
+        const std::vector<int> perm = op->getMode() == 0 ? std::vector<int>{0, 3, 4, 1, 5, 2} : std::vector<int>{0, 1, 4, 2, 5, 3};
+        ROCM_CALL(infini_rocm_transpose(H(ctx), DTI(in), P(in), P(op->getOutput()), (int)shape.size(), shape.data(), perm.data()));
+    }
+};
+REGISTER_KERNEL(Device::ROCM, OpType::DepthToSpace, DepthToSpaceRocm, "DepthToSpace_ROCM");
+
+// Extend = (num + 1) copies along `dim` = a broadcast over a new middle axis (reference: extend.cu:3-15, fp32 only there)
+class ExtendRocm : public RocmKernelWithoutConfig {
+    void compute(const Operator &_op, const RuntimeObj *ctx) const override {
+        auto op = as<ExtendObj>(_op);
+        const auto in = op->getInputs(0);
+        const auto &d = in->getDims();
+        const int dim = op->getDim();
+        const int64_t outer = prod(d, 0, dim), blk = prod(d, dim, d.size());
+        const int64_t shape[3] = {outer, op->getNum() + 1, blk}, st[3] = {blk, 0, 1};
+        ROCM_CALL(infini_rocm_expand(H(ctx), DTI(in), P(in), P(op->getOutput()), 3, shape, st));
+    }
+};
+REGISTER_KERNEL(Device::ROCM, OpType::Extend, ExtendRocm, "Extend_ROCM");
 
 class WhereRocm : public RocmKernelWithoutConfig {
     void compute(const Operator &op, const RuntimeObj *ctx) const override {

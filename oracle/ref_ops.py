@@ -414,3 +414,29 @@ def attention_kvcache(k_cache, v_cache, q, k, v, position: int):
     s = np.einsum("bhd,bhnd->bhn", Q[:, :, 0, :], KC[:, :, :n, :]) / np.sqrt(Q.shape[-1])
     p = softmax(s, -1)
     return np.einsum("bhn,bhnd->bhd", p, VC[:, :, :n, :])[:, :, None, :], KC, VC
+
+
+# GatherElements (reference: src/kernels/cuda/gather_elements.cu:4-35; ONNX GatherElements-13)
+def gather_elements(data: np.ndarray, indices: np.ndarray, axis: int) -> np.ndarray:
+    d = np.asarray(data)
+    idx = np.asarray(indices).astype(np.int64)
+    idx = np.where(idx < 0, idx + d.shape[axis], idx)
+    sl = tuple(slice(0, n) if a != axis % d.ndim else slice(None) for a, n in enumerate(idx.shape))
+    return np.take_along_axis(d[sl], idx, axis)
+
+
+# DepthToSpace (reference: src/operators/transpose.cc:68-110 — reshape, transpose {0,3,4,1,5,2} (DCR) or
+# {0,1,4,2,5,3} (CRD), reshape)
+def depth_to_space(x: np.ndarray, blocksize: int, mode: str = "DCR") -> np.ndarray:
+    n, c, h, w = x.shape
+    b = blocksize
+    if mode == "DCR":
+        t = x.reshape(n, b, b, c // (b * b), h, w).transpose(0, 3, 4, 1, 5, 2)
+    else:
+        t = x.reshape(n, c // (b * b), b, b, h, w).transpose(0, 1, 4, 2, 5, 3)
+    return t.reshape(n, c // (b * b), h * b, w * b)
+
+
+# Extend (reference: src/operators/extend.cc:14-18, src/kernels/cuda/extend.cu:3-15): num + 1 copies along dim
+def extend(x: np.ndarray, dim: int, num: int) -> np.ndarray:
+    return np.concatenate([np.asarray(x)] * (num + 1), axis=dim)

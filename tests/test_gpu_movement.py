@@ -129,3 +129,34 @@ def test_expand_reshape_bit_exact(rt, dtype):
     x = rnd((3, 1, 5), dtype, 13)
     assert np.array_equal(host(ops.expand(rt, dev(x), (2, 3, 4, 5))), R.expand(x, (2, 3, 4, 5)))
     assert np.array_equal(host(ops.reshape(rt, dev(x), (5, 3))), x.reshape(5, 3))
+
+
+def test_gather_elements_kats_and_random(rt):
+    """test_cuda_gather_elements.cc:10-42 + random cases vs the oracle (int32 / int64 indices, negative indices)."""
+    GE = "test/kernels/cuda/test_cuda_gather_elements.cc"
+    d = torch.from_numpy(kat(GE, 19).astype(np.int32).reshape(3, 3)).cuda()
+    i = torch.from_numpy(kat(GE, 20).astype(np.int64).reshape(2, 3)).cuda()
+    assert ops.gather_elements(rt, d, i, 0).cpu().numpy().ravel().tolist() == [4, 8, 3, 7, 2, 3]
+    d = torch.from_numpy(kat(GE, 36).astype(np.float32).reshape(2, 2)).cuda()
+    i = torch.from_numpy(kat(GE, 37).astype(np.int32).reshape(2, 2)).cuda()
+    assert ops.gather_elements(rt, d, i, 1).cpu().numpy().ravel().tolist() == [1., 1., 4., 3.]
+    rng = np.random.default_rng(2)
+    for shape, ishape, axis, idt in (((5, 7, 9), (5, 4, 9), 1, np.int64), ((6, 33), (6, 33), 1, np.int32),
+                                     ((4, 3, 2, 8), (2, 3, 2, 8), 0, np.int64), ((17,), (40,), 0, np.int32)):
+        data = rng.standard_normal(shape).astype(np.float16)
+        idx = rng.integers(-shape[axis], shape[axis], ishape).astype(idt)
+        got = ops.gather_elements(rt, torch.from_numpy(data).cuda(), torch.from_numpy(idx).cuda(), axis).cpu().numpy()
+        assert np.array_equal(got, R.gather_elements(data, idx, axis))
+
+
+def test_extend_kat_and_depth_to_space(rt):
+    """test_cuda_extend.cc:12-43; DepthToSpace (no reference test: ONNX definition in numpy)."""
+    x = torch.arange(24, dtype=torch.float32).reshape(2, 3, 2, 2).cuda()
+    y = ops.extend(rt, x, 1, 1)
+    assert tuple(y.shape) == (2, 6, 2, 2)
+    assert R.equal_data(y.cpu().numpy().ravel(), kat("test/kernels/cuda/test_cuda_extend.cc", 37, "float"))
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((2, 12, 5, 7)).astype(np.float16)
+    for mode in ("DCR", "CRD"):
+        got = ops.depth_to_space(rt, torch.from_numpy(a).cuda(), 2, mode).cpu().numpy()
+        assert np.array_equal(got, R.depth_to_space(a, 2, mode))

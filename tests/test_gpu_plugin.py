@@ -404,3 +404,18 @@ def test_attention_kvcache_through_reference_executor(B, rocm):
     h.run()
     want, _, _ = R.attention_kvcache(*arrs, pos)
     assert np.allclose(get(out).reshape(b, hh, 1, d), want, rtol=1e-5, atol=1e-5)
+
+
+def test_gather_elements_extend_depth_to_space_through_reference_executor(B, rocm):
+    """The three glue kernels added for SURVEY 8f-4, driven by the reference's operator objects."""
+    GE = CU + "test_cuda_gather_elements.cc"
+    h, out = build(B, rocm, lambda hd, t: hd.gatherElements(t[0], t[1], None, 0),
+                   [((3, 3), I32, kat(GE, 19).astype(np.int32).reshape(3, 3)), ((2, 3), I64, kat(GE, 20).astype(np.int64).reshape(2, 3))])
+    h.run()
+    assert get(out).ravel().tolist() == [4, 8, 3, 7, 2, 3]  # test_cuda_gather_elements.cc:24
+    # Extend has no GraphHandler binding in the reference (ffi_infinitensor.cc): covered through the C ABI in
+    # tests/test_gpu_movement.py::test_extend_kat_and_depth_to_space
+    a = np.random.default_rng(4).standard_normal((1, 8, 3, 5)).astype(np.float32)
+    h, out = build(B, rocm, lambda hd, t: hd.depthToSpace(t[0], None, 2, "DCR"), [((1, 8, 3, 5), F32, a)])
+    h.run()
+    assert np.array_equal(get(out).reshape(1, 2, 6, 10), R.depth_to_space(a, 2, "DCR"))

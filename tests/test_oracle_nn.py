@@ -159,3 +159,15 @@ def test_attention_kvcache_kat():
     y, kc, vc = R.attention_kvcache(z, z, np.ones((1, 1, 1, 128)), np.ones((1, 1, 1, 128)), np.ones((1, 1, 1, 128)), 0)
     assert eq(y.ravel(), kat(CU + "test_cuda_attention.cc", 36, "float"))
     assert np.array_equal(kc, np.ones((1, 1, 1, 128))) and np.array_equal(vc, np.ones((1, 1, 1, 128)))
+
+
+def test_gather_elements_and_extend_kats():
+    """test_cuda_gather_elements.cc:10-42 (the expected values there are bare brace lists, not vector<> literals, so the
+    extractor only holds the inputs: :24 expects {4, 8, 3, 7, 2, 3}, :41 expects {1., 1., 4., 3.});
+    test_cuda_extend.cc:12-43."""
+    GE = CU + "test_cuda_gather_elements.cc"
+    y = R.gather_elements(kat(GE, 19).astype(np.int32).reshape(3, 3), kat(GE, 20).astype(np.int64).reshape(2, 3), 0)
+    assert np.array_equal(y.ravel(), [4, 8, 3, 7, 2, 3])
+    y = R.gather_elements(kat(GE, 36).astype(np.float32).reshape(2, 2), kat(GE, 37).astype(np.int32).reshape(2, 2), 1)
+    assert np.array_equal(y.ravel(), [1., 1., 4., 3.])
+    assert eq(R.extend(R.incremental((2, 3, 2, 2)), 1, 1).ravel(), kat(CU + "test_cuda_extend.cc", 37, "float"))
