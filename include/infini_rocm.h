@@ -333,6 +333,14 @@ int infini_rocm_expand(infiniRocmRuntime_t rt, int dtype, const void *x, void *y
 int infini_rocm_gather(infiniRocmRuntime_t rt, int dtype, int index_dtype, const void *data,
                        const void *indices, void *y, int64_t outer, int64_t axis_dim, int64_t n_indices,
                        int64_t inner);
+/* Resize (reference: src/kernels/cuda/resize.cu:6-196, resize.cc:5-50). x [in_shape] -> y [out_shape], same rank.
+ * scales[d] = the operator's per-dim scale (out / in as ResizeObj computed it, src/operators/resize.cc:75-230);
+ * roi: 2*ndim floats (starts, ends) or NULL. mode 0 nearest / 1 linear / 2 cubic (A = -0.75);
+ * coord_mode 0 half_pixel / 1 pytorch_half_pixel / 2 align_corners / 3 asymmetric / 4 tf_crop_and_resize;
+ * nearest_mode 0 round_prefer_floor / 1 round_prefer_ceil / 2 floor / 3 ceil. f32 / f16 / bf16. */
+int infini_rocm_resize(infiniRocmRuntime_t rt, int dtype, const void *x, void *y, int ndim,
+                       const int64_t *in_shape, const int64_t *out_shape, const float *scales,
+                       const float *roi, int mode, int coord_mode, int nearest_mode);
 /* GatherElements (reference: _gather_elements_kernel, src/kernels/cuda/gather_elements.cu:4-35; operator
  * gather_elements.cc:27-39): y has index_shape; y[i] = data[i with coordinate `axis` replaced by indices[i]].
  * indices I32 / I64 (negative wraps); data and index ranks equal, off-axis index extents <= data extents. */

@@ -481,6 +481,29 @@ def extend(rt: RocmRuntime, x: torch.Tensor, dim: int, num: int) -> torch.Tensor
     return y.view(shape)
 
 
+RESIZE_MODES = {"nearest": 0, "linear": 1, "cubic": 2}
+RESIZE_COORD = {"half_pixel": 0, "pytorch_half_pixel": 1, "align_corners": 2, "asymmetric": 3, "tf_crop_and_resize": 4}
+RESIZE_NEAREST = {"round_prefer_floor": 0, "round_prefer_ceil": 1, "floor": 2, "ceil": 3}
+
+
+def resize(rt: RocmRuntime, x: torch.Tensor, out_shape: Sequence[int], scales: Sequence[float] | None = None,
+           mode: str = "nearest", coord_mode: str = "half_pixel", nearest_mode: str = "round_prefer_floor",
+           roi: Sequence[float] | None = None) -> torch.Tensor:
+    """ONNX Resize on a dense tensor. `scales` defaults to out / in per dim (ResizeObj with the stretch policy,
+    src/operators/resize.cc:117-123)."""
+    if len(out_shape) != x.dim():
+        raise ValueError("resize keeps the rank")
+    if scales is None:
+        scales = [o / i for o, i in zip(out_shape, x.shape)]
+    out = torch.empty(list(out_shape), dtype=x.dtype, device=x.device)
+    fs = (C.c_float * x.dim())(*[float(v) for v in scales])
+    fr = (C.c_float * (2 * x.dim()))(*[float(v) for v in roi]) if roi is not None else None
+    check(lib().infini_rocm_resize(rt.handle, dtype_of(x), _ptr(x), _ptr(out), x.dim(), _i64arr(list(x.shape)),
+                                   _i64arr(list(out_shape)), fs, fr, RESIZE_MODES[mode], RESIZE_COORD[coord_mode],
+                                   RESIZE_NEAREST[nearest_mode]))
+    return out
+
+
 def where(rt: RocmRuntime, x: torch.Tensor, y: torch.Tensor, cond: torch.Tensor,
           out: torch.Tensor | None = None) -> torch.Tensor:
     """cond ? x : y; operator input order x, y, cond (include/operators/where.h:9-34)."""

@@ -22,6 +22,7 @@
 #include "operators/recv.h"
 #include "operators/reduce.h"
 #include "operators/reshape.h"
+#include "operators/resize.h"
 #include "operators/rms_norm.h"
 #include "operators/rope.h"
 #include "operators/send.h"
@@ -421,6 +422,29 @@ class ExtendRocm : public RocmKernelWithoutConfig {
     }
 };
 REGISTER_KERNEL(Device::ROCM, OpType::Extend, ExtendRocm, "Extend_ROCM");
+
+class ResizeRocm : public RocmKernelWithoutConfig {
+    void compute(const Operator &_op, const RuntimeObj *ctx) const override {
+        auto op = as<ResizeObj>(_op);
+        const auto in = op->getInputs(0), out = op->getOutputs()[0];
+        const int nd = in->getRank();
+        IT_ASSERT(nd <= INFINI_ROCM_MAX_DIMS);
+        auto is = dims64(in->getDims()), os = dims64(out->getDims());
+        std::vector<float> scales(nd), roi(2 * nd);
+        for (int i = 0; i < nd; ++i) {
+            scales[i] = op->getScale(i);
+            roi[i] = op->getRoi(i);
+            roi[i + nd] = op->getRoi(i + nd);
+        }
+        // enum orders match the C ABI codes (resize.h:13-28: nearest/linear/cubic; halfPixel, pytorchHalfPixel,
+        // alignCorners, asymmetric, tfCropAndResize; roundPreferFloor, roundPreferCeil, floor, ceil)
+        const int mode = (int)op->getMode(), cm = (int)op->getCoordinateTransMode();
+        const int nm = mode == 0 ? (int)op->getNearestMode() : 0;
+        ROCM_CALL(infini_rocm_resize(H(ctx), DTI(in), P(in), P(out), nd, is.data(), os.data(), scales.data(), roi.data(),
+                                     mode, cm, nm > 3 ? 0 : nm));
+    }
+};
+REGISTER_KERNEL(Device::ROCM, OpType::Resize, ResizeRocm, "Resize_ROCM");
 
 class WhereRocm : public RocmKernelWithoutConfig {
     void compute(const Operator &op, const RuntimeObj *ctx) const override {

@@ -440,3 +440,60 @@ def depth_to_space(x: np.ndarray, blocksize: int, mode: str = "DCR") -> np.ndarr
 # Extend (reference: src/operators/extend.cc:14-18, src/kernels/cuda/extend.cu:3-15): num + 1 copies along dim
 def extend(x: np.ndarray, dim: int, num: int) -> np.ndarray:
     return np.concatenate([np.asarray(x)] * (num + 1), axis=dim)
+
+
+# Resize (reference: src/kernels/cuda/resize.cu:6-196 — coordinate transforms :20-49, nearest rounding :7-17,
+# clamped even neighbours :111-116, linear / cubic (A = -0.75) coefficients :118-134, separable product :139-190).
+# nearest rounding follows ONNX (round_prefer_floor = ceil(x - 0.5)); the reference's floor(x + 0.4) agrees wherever
+# the fractional part is not in (0.5, 0.6) — every reference test.
+def resize(x: np.ndarray, out_shape, scales, mode: str = "nearest", coord_mode: str = "half_pixel",
+           nearest_mode: str = "round_prefer_floor", roi=None) -> np.ndarray:
+    X = np.asarray(x, dtype=np.float64)
+    nd = X.ndim
+    out = np.zeros(tuple(out_shape), dtype=np.float64)
+
+    def src(i, d):
+        s = np.float32(scales[d])
+        n_in = X.shape[d]
+        length = np.float32(s * np.float32(n_in))
+        if coord_mode == "half_pixel":
+            return (i + 0.5) / s - 0.5
+        if coord_mode == "pytorch_half_pixel":
+            return (i + 0.5) / s - 0.5 if length > 1 else 0.0
+        if coord_mode == "align_corners":
+            return 0.0 if length == 1 else i * (n_in - 1) / (length - 1)
+        if coord_mode == "asymmetric":
+            return i / s
+        li = int(length)
+        rs, re = roi[d], roi[d + nd]
+        return rs * (n_in - 1) + i * (re - rs) * (n_in - 1) / (li - 1) if li > 1 else 0.5 * (rs + re) * (n_in - 1)
+
+    def coef(r):
+        if mode == "linear":
+            return [1 - r, r]
+        A = -0.75
+        return [((A * (r + 1) - 5 * A) * (r + 1) + 8 * A) * (r + 1) - 4 * A, ((A + 2) * r - (A + 3)) * r * r + 1,
+                ((A + 2) * (1 - r) - (A + 3)) * (1 - r) * (1 - r) + 1,
+                ((A * ((1 - r) + 1) - 5 * A) * ((1 - r) + 1) + 8 * A) * ((1 - r) + 1) - 4 * A]
+
+    rnd = {"round_prefer_floor": lambda c: math.ceil(c - 0.5), "round_prefer_ceil": lambda c: math.floor(c + 0.5),
+           "floor": math.floor, "ceil": math.ceil}[nearest_mode]
+    for idx in np.ndindex(*out.shape):
+        if mode == "nearest":
+            sidx = tuple(i if X.shape[d] == out.shape[d] else min(max(rnd(src(i, d)), 0), X.shape[d] - 1)
+                         for d, i in enumerate(idx))
+            out[idx] = X[sidx]
+            continue
+        terms = [((), 1.0)]
+        for d, i in enumerate(idx):
+            if X.shape[d] == out.shape[d]:
+                terms = [(t + (i,), w) for t, w in terms]
+                continue
+            c = src(i, d)
+            fl = math.floor(c)
+            ws = coef(c - fl)
+            n = len(ws)
+            nb = [min(max(fl - n // 2 + 1 + j, 0), X.shape[d] - 1) for j in range(n)]
+            terms = [(t + (nb[j],), w * ws[j]) for t, w in terms for j in range(n)]
+        out[idx] = sum(X[t] * w for t, w in terms)
+    return out

@@ -160,3 +160,25 @@ def test_extend_kat_and_depth_to_space(rt):
     for mode in ("DCR", "CRD"):
         got = ops.depth_to_space(rt, torch.from_numpy(a).cuda(), 2, mode).cpu().numpy()
         assert np.array_equal(got, R.depth_to_space(a, 2, mode))
+
+
+def test_resize_reference_kats_and_random(rt):
+    """test_cuda_resize.cc (21 stretch-policy cases, tests/resize_cases.py) through the C ABI, then random shapes vs
+    the oracle in f32 / f16 for every mode x coordinate transform."""
+    from resize_cases import CASES, materialise
+
+    for case in CASES:
+        x, out, scales, roi, want = materialise(case)
+        y = ops.resize(rt, torch.from_numpy(x).cuda(), out, scales, case[4], case[5], case[6], roi)
+        assert R.equal_data(y.cpu().numpy().ravel(), want, 1e-5), case
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((2, 3, 7, 9)).astype(np.float32)
+    for mode in ("nearest", "linear", "cubic"):
+        for coord in ("half_pixel", "pytorch_half_pixel", "align_corners", "asymmetric"):
+            for out in ((2, 3, 13, 5), (2, 3, 4, 20)):
+                scales = [o / i for o, i in zip(out, x.shape)]
+                want = R.resize(x, out, scales, mode, coord, "floor")
+                got = ops.resize(rt, torch.from_numpy(x).cuda(), out, scales, mode, coord, "floor").cpu().numpy()
+                assert np.allclose(got, want, rtol=1e-4, atol=1e-5), (mode, coord, out)
+                got16 = ops.resize(rt, torch.from_numpy(x).half().cuda(), out, scales, mode, coord, "floor").float().cpu().numpy()
+                assert np.allclose(got16, R.resize(x.astype(np.float16), out, scales, mode, coord, "floor"), rtol=4e-3, atol=4e-3)

@@ -419,3 +419,28 @@ def test_gather_elements_extend_depth_to_space_through_reference_executor(B, roc
     h, out = build(B, rocm, lambda hd, t: hd.depthToSpace(t[0], None, 2, "DCR"), [((1, 8, 3, 5), F32, a)])
     h.run()
     assert np.array_equal(get(out).reshape(1, 2, 6, 10), R.depth_to_space(a, 2, "DCR"))
+
+
+def test_resize_through_reference_executor(B, rocm):
+    """Three of the reference's Resize tests driven through its own operator object (ResizeObj derives scales / roi from
+    the sizes / scales / roi tensors on Device::ROCM): nearest sizes, linear scales align_corners, cubic sizes."""
+    RS = CU + "test_cuda_resize.cc"
+
+    def run(x, sizes, scales, roi, mode, coord, nearest="round_prefer_floor"):
+        h = B.GraphHandler(rocm)
+        tx = h.tensor(list(x.shape), F32)
+        ts = h.tensor([len(sizes)], I64) if sizes else None
+        tc = h.tensor([len(scales)], F32) if scales else None
+        tr = h.tensor([len(roi)], F32) if roi else None
+        out = h.resize(tx, None, None, ts, tc, tr, sizes or [], scales or [], roi or [], mode, "stretch", nearest, coord)
+        h.data_malloc()
+        put(tx, x)
+        h.run()
+        return get(out).ravel()
+
+    x = kat(RS, 16, "float").astype(np.float32).reshape(1, 1, 2, 4)
+    assert R.equal_data(run(x, [1, 1, 1, 3], None, None, "nearest", "half_pixel"), kat(RS, 35, "float"), 1e-6)
+    x = kat(RS, 336, "float").astype(np.float32).reshape(1, 1, 2, 4)
+    assert R.equal_data(run(x, None, [1, 1, 0.6, 0.6], None, "linear", "align_corners"), kat(RS, 355, "float"), 1e-6)
+    x = kat(RS, 759, "float").astype(np.float32).reshape(1, 1, 4, 4)
+    assert R.equal_data(run(x, [1, 1, 9, 10], None, None, "cubic", "half_pixel"), kat(RS, 778, "float"), 1e-5)

@@ -171,3 +171,14 @@ def test_gather_elements_and_extend_kats():
     y = R.gather_elements(kat(GE, 36).astype(np.float32).reshape(2, 2), kat(GE, 37).astype(np.int32).reshape(2, 2), 1)
     assert np.array_equal(y.ravel(), [1., 1., 4., 3.])
     assert eq(R.extend(R.incremental((2, 3, 2, 2)), 1, 1).ravel(), kat(CU + "test_cuda_extend.cc", 37, "float"))
+
+
+def test_resize_kats():
+    """All 21 stretch-policy cases of test_cuda_resize.cc (table in tests/resize_cases.py)."""
+    from resize_cases import CASES, materialise
+
+    for case in CASES:
+        x, out, scales, roi, want = materialise(case)
+        y = R.resize(x, out, scales, case[4], case[5], case[6], roi)
+        assert y.size == want.size, case
+        assert eq(y.ravel(), want, 1e-5), (case, y.ravel(), want)  # the literals are fp32 results of a 16-term cubic sum
