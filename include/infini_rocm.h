@@ -288,6 +288,14 @@ int infini_rocm_conv2d(infiniRocmRuntime_t rt, int dtype, const void *x, const v
                        const void *bias, void *y, int64_t n, int64_t c, int64_t h, int64_t wd,
                        int64_t f, int64_t r, int64_t s, int ph, int pw, int sh, int sw, int dh, int dw,
                        int64_t groups, int act);
+/* ConvTranspose2d (reference: convBackwardDataCudnn, src/kernels/cuda/conv_transposed.cc:46-230; shape rule
+ * src/operators/conv.cc:252-268): x [n, f, h, w], w [f, c_per_group, r, s] -> y [n, c_per_group * groups, oh, ow],
+ * oh = (h - 1) sh - 2 ph + dh (r - 1) + oph + 1. bias ([C], optional) and act as for conv2d. Gather-form direct
+ * kernel, fp32 accumulation. */
+int infini_rocm_conv_transpose2d(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, const void *bias,
+                                 void *y, int64_t n, int64_t f, int64_t h, int64_t wd, int64_t c_per_group, int64_t r,
+                                 int64_t s, int ph, int pw, int sh, int sw, int dh, int dw, int oph, int opw,
+                                 int64_t groups, int act);
 /* Kernel choice for the next f16 / bf16 conv2d calls: -1 heuristic, 1 generic implicit GEMM only,
  * 2 tap-shifted implicit GEMM (conv_s1) for every unit-stride same-size shape, 3 batched-GEMM route for every
  * eligible pointwise shape. All variants compute the same sums (fp32 accumulate). Used by tune() and tests. */

@@ -31,6 +31,20 @@ extern "C" int infini_rocm_matmul(infiniRocmRuntime_t rt, int dtype, const void 
 
 namespace irocm {
 
+template <typename T> struct CvtT;
+template <> struct CvtT<float> {
+    __device__ static inline float ld(const float *p) { return *p; }
+    __device__ static inline void st(float *p, float v) { *p = v; }
+};
+template <> struct CvtT<__half> {
+    __device__ static inline float ld(const __half *p) { return __half2float(*p); }
+    __device__ static inline void st(__half *p, float v) { *p = __float2half_rn(v); }
+};
+template <> struct CvtT<__hip_bfloat16> {
+    __device__ static inline float ld(const __hip_bfloat16 *p) { return __bfloat162float(*p); }
+    __device__ static inline void st(__hip_bfloat16 *p, float v) { *p = __float2bfloat16(v); }
+};
+
 int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, const void *bias, void *y,
                    int n, int c, int h, int wd, int f, int r, int s, int ph, int pw, int sh, int sw, int dh, int dw,
                    int oh, int ow, int act); // conv_s1.hip
@@ -256,11 +270,100 @@ __global__ __launch_bounds__(256) void conv_direct32(ConvArgs p) {
     }
 }
 
+// ConvTranspose2d (gather form): one output element per thread, fp32 accumulation in the (f, r, s) order.
+// Replaces convBackwardDataCudnn (reference: src/kernels/cuda/conv_transposed.cc:46-230); shape rule
+// src/operators/conv.cc:252-268: x [N, F, H, W], w [F, C/g, R, S] -> y [N, C, OH, OW],
+//   OH = (H - 1) sh - 2 ph + dh (R - 1) + oph + 1;  y[n, c, oy, ox] = sum_{f, r, s} x[n, f, iy, ix] w[f, c, r, s]
+//   with iy * sh = oy + ph - r * dh (terms whose iy is fractional or outside the input are absent).
+// Functional coverage of SURVEY 8f-4 (not a tuned kernel: no MFMA path yet).
+struct ConvTArgs {
+    int n, f, h, w, c, r, s, ph, pw, sh, sw, dh, dw, groups, fg, cg, oh, ow, act;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void conv_transpose_direct(const T *__restrict__ x, const T *__restrict__ w,
+                                                             const T *__restrict__ bias, T *__restrict__ y, ConvTArgs p) {
+    const long total = (long)p.n * p.c * p.oh * p.ow;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ox = (int)(i % p.ow);
+        long q = i / p.ow;
+        const int oy = (int)(q % p.oh);
+        q /= p.oh;
+        const int c = (int)(q % p.c), n = (int)(q / p.c);
+        const int g = c / p.cg, cl = c - g * p.cg;
+        float acc = 0.f;
+        for (int fl = 0; fl < p.fg; ++fl) {
+            const int f = g * p.fg + fl;
+            const T *xp = x + ((long)n * p.f + f) * p.h * p.w;
+            const T *wp = w + ((long)f * p.cg + cl) * p.r * p.s;
+            for (int r = 0; r < p.r; ++r) {
+                const int ty = oy + p.ph - r * p.dh;
+                if (ty < 0 || ty % p.sh)
+                    continue;
+                const int iy = ty / p.sh;
+                if (iy >= p.h)
+                    continue;
+                for (int s = 0; s < p.s; ++s) {
+                    const int tx = ox + p.pw - s * p.dw;
+                    if (tx < 0 || tx % p.sw)
+                        continue;
+                    const int ix = tx / p.sw;
+                    if (ix >= p.w)
+                        continue;
+                    acc = fmaf(CvtT<T>::ld(xp + (long)iy * p.w + ix), CvtT<T>::ld(wp + r * p.s + s), acc);
+                }
+            }
+        }
+        if (bias)
+            acc += CvtT<T>::ld(bias + c);
+        CvtT<T>::st(y + i, apply_act(acc, p.act));
+    }
+}
+
 } // namespace irocm
 
 using namespace irocm;
 
 extern "C" {
+
+int infini_rocm_conv_transpose2d(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, const void *bias,
+                                 void *y, int64_t n, int64_t f, int64_t h, int64_t wd, int64_t c_per_group, int64_t r,
+                                 int64_t s, int ph, int pw, int sh, int sw, int dh, int dw, int oph, int opw,
+                                 int64_t groups, int act) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(dtype == INFINI_DT_F32 || dtype == INFINI_DT_F16 || dtype == INFINI_DT_BF16,
+                    "conv_transpose2d: unsupported dtype %s", dtype_name(dtype));
+    IROCM_CHECK_ARG(n >= 0 && f > 0 && h > 0 && wd > 0 && c_per_group > 0 && r > 0 && s > 0, "conv_transpose2d: bad extent");
+    IROCM_CHECK_ARG(groups > 0 && f % groups == 0, "conv_transpose2d: groups %lld do not divide F=%lld", (long long)groups,
+                    (long long)f);
+    IROCM_CHECK_ARG(sh > 0 && sw > 0 && dh > 0 && dw > 0 && ph >= 0 && pw >= 0 && oph >= 0 && opw >= 0 && act >= 0 && act <= 3,
+                    "conv_transpose2d: bad attributes");
+    ConvTArgs p;
+    p.n = (int)n; p.f = (int)f; p.h = (int)h; p.w = (int)wd; p.cg = (int)c_per_group; p.c = (int)(c_per_group * groups);
+    p.r = (int)r; p.s = (int)s; p.ph = ph; p.pw = pw; p.sh = sh; p.sw = sw; p.dh = dh; p.dw = dw;
+    p.groups = (int)groups; p.fg = (int)(f / groups);
+    p.oh = (int)((h - 1) * sh - 2 * ph + dh * (r - 1) + oph + 1);
+    p.ow = (int)((wd - 1) * sw - 2 * pw + dw * (s - 1) + opw + 1);
+    p.act = act;
+    IROCM_CHECK_ARG(p.oh > 0 && p.ow > 0, "conv_transpose2d: empty output %dx%d", p.oh, p.ow);
+    const long total = (long)n * p.c * p.oh * p.ow;
+    if (total == 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(x && w && y, "conv_transpose2d: NULL tensor");
+    long g = ceil_div(total, 256);
+    if (g > (long)rt->num_cu * 32) g = (long)rt->num_cu * 32;
+#define GO(T)                                                                                              \
+    hipLaunchKernelGGL(conv_transpose_direct<T>, dim3((unsigned)g), dim3(256), 0, rt->stream, (const T *)x, \
+                       (const T *)w, (const T *)bias, (T *)y, p)
+    switch (dtype) {
+    case INFINI_DT_F32: GO(float); break;
+    case INFINI_DT_F16: GO(__half); break;
+    default: GO(__hip_bfloat16); break;
+    }
+#undef GO
+    IROCM_LAUNCH_CHECK("conv_transpose_direct");
+    return INFINI_ROCM_OK;
+}
+
 
 int infini_rocm_conv2d(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, const void *bias,
                        void *y, int64_t n, int64_t c, int64_t h, int64_t wd, int64_t f, int64_t r, int64_t s,

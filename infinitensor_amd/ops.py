@@ -334,6 +334,22 @@ def conv2d(rt: RocmRuntime, x: torch.Tensor, w: torch.Tensor, ph: int = 0, pw: i
     return out
 
 
+def conv_transpose2d(rt: RocmRuntime, x: torch.Tensor, w: torch.Tensor, ph: int = 0, pw: int = 0, sh: int = 1, sw: int = 1,
+                     dh: int = 1, dw: int = 1, oph: int = 0, opw: int = 0, groups: int = 1,
+                     bias: torch.Tensor | None = None, act: int = 0) -> torch.Tensor:
+    """x [N, F, H, W], w [F, C/g, R, S] -> [N, C, OH, OW] (src/operators/conv.cc:252-268)."""
+    n, f, h, wd = x.shape
+    f2, cg, r, s = w.shape
+    if f != f2:
+        raise ValueError("input channels != weight dim 0")  # reference: IT_ASSERT(f == weight->getDims()[0])
+    oh = (h - 1) * sh - 2 * ph + dh * (r - 1) + oph + 1
+    ow = (wd - 1) * sw - 2 * pw + dw * (s - 1) + opw + 1
+    out = torch.empty((n, cg * groups, oh, ow), dtype=x.dtype, device=x.device)
+    check(lib().infini_rocm_conv_transpose2d(rt.handle, dtype_of(x), _ptr(x), _ptr(w), _ptr(bias), _ptr(out), n, f, h, wd,
+                                             cg, r, s, ph, pw, sh, sw, dh, dw, oph, opw, groups, int(act)))
+    return out
+
+
 def _pool(rt, kind, x, kh, kw, dh, dw, ph, pw, sh, sw, ceil_mode, out):
     rank3 = x.dim() == 3  # reference: rank-3 input is treated as H = 1 (src/operators/pooling.cc:10-13)
     n, c = x.shape[0], x.shape[1]

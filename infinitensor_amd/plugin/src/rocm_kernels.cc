@@ -132,6 +132,19 @@ class ConvRocm : public RocmKernelWithoutConfig {
 };
 REGISTER_KERNEL(Device::ROCM, OpType::Conv, ConvRocm, "Conv_ImplicitGemm_MFMA_ROCM");
 
+class ConvTransposed2dRocm : public RocmKernelWithoutConfig {
+    void compute(const Operator &_op, const RuntimeObj *ctx) const override {
+        auto op = as<ConvTransposed2dObj>(_op);
+        const auto [n, c, h, w, f, r, s] = op->getNCHWFRS(); // c = weight dim 1 = channels per group (conv.cc:258)
+        const auto [ph, pw, sh, sw, dh, dw] = op->getPadStrideDilation();
+        const auto [oph, opw] = op->getOutputPadding();
+        ROCM_CALL(infini_rocm_conv_transpose2d(H(ctx), DTI(op->getInputs(0)), P(op->getInputs(0)), P(op->getInputs(1)), nullptr,
+                                               P(op->getOutput()), n, f, h, w, c, r, s, ph, pw, sh, sw, dh, dw, oph, opw,
+                                               op->getNumGroups(), 0));
+    }
+};
+REGISTER_KERNEL(Device::ROCM, OpType::ConvTranspose, ConvTransposed2dRocm, "ConvTranspose_Direct_ROCM");
+
 // ---- Softmax / LayerNorm / RMSNorm ------------------------------------------------------------------
 class SoftmaxRocm : public RocmKernelWithoutConfig {
     void compute(const Operator &_op, const RuntimeObj *ctx) const override {

@@ -497,3 +497,26 @@ def resize(x: np.ndarray, out_shape, scales, mode: str = "nearest", coord_mode: 
             terms = [(t + (nb[j],), w * ws[j]) for t, w in terms for j in range(n)]
         out[idx] = sum(X[t] * w for t, w in terms)
     return out
+
+
+# ConvTranspose2d (reference: src/operators/conv.cc:252-268 shape rule; cuDNN backward-data semantics,
+# src/kernels/cuda/conv_transposed.cc:46-230): scatter form — every input element adds x * w[f, c, :, :] at
+# (iy * sh - ph + r * dh, ix * sw - pw + s * dw).
+def conv_transpose2d(x, w, ph=0, pw=0, sh=1, sw=1, dh=1, dw=1, oph=0, opw=0, groups=1) -> np.ndarray:
+    X, W = np.asarray(x, dtype=np.float64), np.asarray(w, dtype=np.float64)
+    n, f, h, wd = X.shape
+    f2, cg, r, s = W.shape
+    assert f == f2
+    oh = (h - 1) * sh - 2 * ph + dh * (r - 1) + oph + 1
+    ow = (wd - 1) * sw - 2 * pw + dw * (s - 1) + opw + 1
+    fg = f // groups
+    full = np.zeros((n, cg * groups, oh + 2 * ph + dh * r, ow + 2 * pw + dw * s))
+    for g in range(groups):
+        for fl in range(fg):
+            ff = g * fg + fl
+            for rr in range(r):
+                for ss in range(s):
+                    contrib = X[:, ff, :, :, None] * W[ff, :, rr, ss]  # [n, h, w, cg]
+                    full[:, g * cg:(g + 1) * cg, rr * dh:rr * dh + (h - 1) * sh + 1:sh,
+                         ss * dw:ss * dw + (wd - 1) * sw + 1:sw] += np.moveaxis(contrib, -1, 1)
+    return full[:, :, ph:ph + oh, pw:pw + ow]

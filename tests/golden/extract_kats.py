@@ -54,6 +54,7 @@ FILES = [
     "test/kernels/cuda/test_cuda_gather_elements.cc",
     "test/kernels/cuda/test_cuda_extend.cc",
     "test/kernels/cuda/test_cuda_resize.cc",
+    "test/kernels/cuda/test_cuda_conv_transposed_2d.cc",
     "test/kernels/cuda/test_cuda_all_reduce.cc",
     "test/kernels/cuda/test_cuda_all_gather.cc",
     "test/kernels/cuda/test_cuda_broadcast.cc",

@@ -225,3 +225,35 @@ def test_pooling_vs_oracle(rt, cfg, dt):
         assert tuple(y.shape) == want.shape, kind
         tol = {"f32": 1e-5, "f16": 2e-3}[dt]
         assert np.allclose(host(y), want, rtol=tol, atol=tol), kind
+
+
+CONVT = [
+    # n, f, h, w, cg, r, s, ph, pw, sh, sw, dh, dw, oph, opw, groups
+    (2, 8, 5, 6, 4, 3, 3, 1, 1, 2, 2, 1, 1, 1, 1, 1),   # the usual 2x up-sampling deconv
+    (1, 16, 4, 4, 8, 4, 4, 1, 1, 2, 2, 1, 1, 0, 0, 1),  # DCGAN 4x4 / 2
+    (2, 6, 7, 5, 2, 3, 2, 0, 1, 1, 3, 2, 1, 0, 2, 3),   # groups, dilation, asymmetric stride + output padding
+    (1, 4, 3, 3, 5, 1, 1, 0, 0, 1, 1, 1, 1, 0, 0, 1),   # 1x1
+]
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("cfg", CONVT)
+def test_conv_transpose_vs_oracle(rt, cfg, dt):
+    n, f, h, w, cg, r, s, ph, pw, sh, sw, dh, dw, oph, opw, g = cfg
+    rng = np.random.default_rng(abs(hash(cfg)) % 2 ** 32)
+    x = rng.standard_normal((n, f, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((f, cg, r, s)) / np.sqrt(f * r * s / g)).astype(np.float32)
+    y = ops.conv_transpose2d(rt, dev(x, TD[dt]), dev(wt, TD[dt]), ph, pw, sh, sw, dh, dw, oph, opw, g)
+    want = R.conv_transpose2d(R.round_to(x, dt), R.round_to(wt, dt), ph, pw, sh, sw, dh, dw, oph, opw, g)
+    assert tuple(y.shape) == want.shape
+    tol = {"f32": 1e-5, "f16": 2e-3, "bf16": 1.6e-2}[dt]
+    assert np.allclose(host(y), want, rtol=tol, atol=tol)
+
+
+def test_conv_transpose_reference_kats(rt):
+    """test_cuda_conv_transposed_2d.cc:85-91 and :101-135."""
+    CT = CU + "test_cuda_conv_transposed_2d.cc"
+    y = ops.conv_transpose2d(rt, dev(R.incremental((1, 1, 2, 2))), dev(R.incremental((1, 1, 4, 4))))
+    assert R.equal_data(host(y).ravel(), kat(CT, 87, "float"), 1e-6)
+    y = ops.conv_transpose2d(rt, dev(R.incremental((1, 2, 3, 3))), dev(R.incremental((2, 2, 3, 3))))
+    assert R.equal_data(host(y).ravel(), kat(CT, 129, "float"), 1e-6)

@@ -444,3 +444,11 @@ def test_resize_through_reference_executor(B, rocm):
     assert R.equal_data(run(x, None, [1, 1, 0.6, 0.6], None, "linear", "align_corners"), kat(RS, 355, "float"), 1e-6)
     x = kat(RS, 759, "float").astype(np.float32).reshape(1, 1, 4, 4)
     assert R.equal_data(run(x, [1, 1, 9, 10], None, None, "cubic", "half_pixel"), kat(RS, 778, "float"), 1e-5)
+
+
+def test_conv_transpose_through_reference_executor(B, rocm):
+    """test_cuda_conv_transposed_2d.cc:101-135 on Device::ROCM."""
+    h, out = build(B, rocm, lambda hd, t: hd.convTransposed2d(t[0], t[1], None, 0, 0, 1, 1, 1, 1, 0, 0),
+                   [((1, 2, 3, 3), F32, R.incremental((1, 2, 3, 3))), ((2, 2, 3, 3), F32, R.incremental((2, 2, 3, 3)))])
+    h.run()
+    assert R.equal_data(get(out).ravel(), kat(CU + "test_cuda_conv_transposed_2d.cc", 129, "float"), 1e-6)

@@ -182,3 +182,13 @@ def test_resize_kats():
         y = R.resize(x, out, scales, case[4], case[5], case[6], roi)
         assert y.size == want.size, case
         assert eq(y.ravel(), want, 1e-5), (case, y.ravel(), want)  # the literals are fp32 results of a 16-term cubic sum
+
+
+def test_conv_transpose_kats():
+    """test_cuda_conv_transposed_2d.cc:13-46 + :85-91 (1x1x2x2 input, 1x1x4x4 weight, incremental) and :101-135
+    (1x2x3x3 input, 2x2x3x3 weight, incremental; pad 0, stride 1)."""
+    CT = CU + "test_cuda_conv_transposed_2d.cc"
+    y = R.conv_transpose2d(R.incremental((1, 1, 2, 2)), R.incremental((1, 1, 4, 4)))
+    assert eq(y.ravel(), kat(CT, 87, "float"))
+    y = R.conv_transpose2d(R.incremental((1, 2, 3, 3)), R.incremental((2, 2, 3, 3)))
+    assert eq(y.ravel(), kat(CT, 129, "float"))
