@@ -70,6 +70,7 @@ __device__ static inline float apply_act(float v, int act) {
     case 1: return v > 0.f ? v : 0.f;
     case 2: return 1.f / (1.f + __expf(-v));
     case 3: return tanhf(v);
+    case 4: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); // Gelu (erf form, unary.cu) — fusion only
     default: return v;
     }
 }

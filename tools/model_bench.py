@@ -169,10 +169,13 @@ def run_model(model: str, device: int = 0, batch: int | None = None, seq: int = 
         name = f"BERT-base L{layers} bs{batch} seq{seq} {dtype}"
     nops = len(bl.h.operators())
     bl.finish()
+    f0 = rt.fused_launch_count()
+    bl.h.run()
+    fused = rt.fused_launch_count() - f0
     eager = timed(bl.h.run, iters)
     graph = timed(bl.h.run_with_hipgraph, iters)
     y = out.copyout_numpy()
-    return {"model": name, "ops": nops, "fusion": bool(rt.get_fusion()), "gemm_conv_TFLOP": round(bl.flops / 1e12, 3),
+    return {"model": name, "ops": nops, "fusion": bool(rt.get_fusion()), "fused_launches_per_run": int(fused), "gemm_conv_TFLOP": round(bl.flops / 1e12, 3),
             "eager_ms": round(eager, 3), "hipgraph_ms": round(graph, 3),
             "hipgraph_TFLOPs": round(bl.flops / graph / 1e9, 1), "batch": batch,
             "per_unit": f"{batch / graph * 1e3:.0f} samples/s", "finite": bool(np.isfinite(y.astype(np.float32)).all())}
