@@ -93,7 +93,6 @@ class RocmRuntimeObj : public RuntimeObj {
     // launches ops[i .. i+k) as one kernel when a fusion rule applies; returns k (0 = no rule)
     size_t tryLaunchFused(const OpVec &ops, size_t i) const;
     size_t tryLaunchFusedAttention(const OpVec &ops, size_t i) const;
-    size_t tryLaunchFusedMatmulGelu(const OpVec &ops, size_t i) const;
     void tuneImpl(const Graph &graph, bool profiling) const;
     GraphState stateOf(const Graph &graph) const;
     void replay(CacheEntry &entry);

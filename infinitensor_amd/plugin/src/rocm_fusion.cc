@@ -5,7 +5,6 @@
 //   Conv -> Add(per-channel bias [1,F,1,1] / [F,1,1]) [-> Relu]   =>  conv2d(bias, act)        (onnx.py:159-190
 //   Conv -> Relu                                                   =>  conv2d(act)              emits these chains)
 //   Add  -> Relu                                                   =>  binary(ADD_RELU)         (residual join)
-//   MatMul(+bias) -> Gelu                                          =>  matmul(act = gelu)       (BERT FFN)
 //   MatMul(Q, K^T) [-> Div|Mul(scalar)] [-> Add(mask)] -> Softmax(last axis) -> MatMul(P, V)
 //                                                                  =>  attention (csrc/attention.hip): the score
 //        matrix is never written; Q, K, V rank-4 [b, h, S, D] with D in {64, 128}, f16 / bf16, mask [b|1, 1, 1, Sk]
@@ -129,48 +128,11 @@ size_t RocmRuntimeObj::tryLaunchFusedAttention(const OpVec &ops, size_t i) const
     return j + 1 - i;
 }
 
-// MatMul(A, B[, bias]) -> Gelu  =>  matmul with the Gelu in the epilogue (BERT's FFN up-projection). 16-bit types only
-// (the fp32 GEMM path has no fused activation); same conditions as the other rules.
-size_t RocmRuntimeObj::tryLaunchFusedMatmulGelu(const OpVec &ops, size_t i) const {
-    if (i + 1 >= ops.size() || ops[i + 1]->getOpType() != OpType::Gelu)
-        return 0;
-    auto mm = as<MatmulObj>(ops[i]);
-    const Tensor A = mm->getInputs(0), B = mm->getInputs(1), C = mm->getOutput(), out = ops[i + 1]->getOutput();
-    const int dt = A->getDTypeIndex();
-    if ((dt != INFINI_DT_F16 && dt != INFINI_DT_BF16) || !soleConsumerIs(C, ops[i + 1]) || mm->getAct() != ActType::None)
-        return 0;
-    const auto [b, m, n, k] = mm->getBMNK();
-    const int64_t ba = A->size() / ((int64_t)m * k), bb = B->size() / ((int64_t)n * k);
-    if ((ba != 1 && ba != b) || (bb != 1 && bb != b))
-        return 0;
-    const void *bias = nullptr;
-    int64_t bsm = 0, bsn = 0;
-    Tensor bt = mm->getBias();
-    if (bt) { // only the common [n] / [1, n] row bias; anything else stays unfused
-        if ((int64_t)bt->size() != n || bt->getDims().back() != n)
-            return 0;
-        bias = bt->getRawDataPtr<void *>();
-        bsn = 1;
-    }
-    for (const Tensor &t : {A, B})
-        if (overlaps(out, t))
-            return 0;
-    if (bt && overlaps(out, bt))
-        return 0;
-    ROCM_CALL(infini_rocm_matmul(rt, dt, A->getRawDataPtr<void *>(), B->getRawDataPtr<void *>(), bias, out->getRawDataPtr<void *>(),
-                                 b, m, n, k, mm->getTransA(), mm->getTransB(), (ba == 1 && b > 1) ? 0 : (int64_t)m * k,
-                                 (bb == 1 && b > 1) ? 0 : (int64_t)n * k, 0, bsm, bsn, 4));
-    return 2;
-}
-
 size_t RocmRuntimeObj::tryLaunchFused(const OpVec &ops, size_t i) const {
     const Operator &op = ops[i];
     const auto type = op->getOpType();
-    if (type == OpType::MatMul) {
-        if (const size_t n = tryLaunchFusedAttention(ops, i))
-            return n;
-        return tryLaunchFusedMatmulGelu(ops, i);
-    }
+    if (type == OpType::MatMul)
+        return tryLaunchFusedAttention(ops, i);
     if (type == OpType::Conv) {
         auto conv = as<ConvObj>(op);
         const Tensor x = conv->getInputs(0), w = conv->getInputs(1);
