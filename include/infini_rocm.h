@@ -289,6 +289,11 @@ int infini_rocm_conv2d(infiniRocmRuntime_t rt, int dtype, const void *x, const v
                        const void *bias, void *y, int64_t n, int64_t c, int64_t h, int64_t wd,
                        int64_t f, int64_t r, int64_t s, int ph, int pw, int sh, int sw, int dh, int dw,
                        int64_t groups, int act);
+/* conv2d with a residual: y = act(conv(x, w) + bias + residual), residual of y's shape (optional). Used by the
+ * runtime's fusion of Conv -> Add(bias) -> Add(identity) -> Relu (the tail of every ResNet bottleneck). */
+int infini_rocm_conv2d_res(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, const void *bias,
+                           const void *residual, void *y, int64_t n, int64_t c, int64_t h, int64_t wd, int64_t f, int64_t r,
+                           int64_t s, int ph, int pw, int sh, int sw, int dh, int dw, int64_t groups, int act);
 /* ConvTranspose2d (reference: convBackwardDataCudnn, src/kernels/cuda/conv_transposed.cc:46-230; shape rule
  * src/operators/conv.cc:252-268): x [n, f, h, w], w [f, c_per_group, r, s] -> y [n, c_per_group * groups, oh, ow],
  * oh = (h - 1) sh - 2 ph + dh (r - 1) + oph + 1. bias ([C], optional) and act as for conv2d. Gather-form direct

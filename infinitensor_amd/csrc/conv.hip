@@ -45,12 +45,12 @@ template <> struct CvtT<__hip_bfloat16> {
     __device__ static inline void st(__hip_bfloat16 *p, float v) { *p = __float2bfloat16(v); }
 };
 
-int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, const void *bias, void *y,
-                   int n, int c, int h, int wd, int f, int r, int s, int ph, int pw, int sh, int sw, int dh, int dw,
+int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, const void *bias, const void *res,
+                   void *y, int n, int c, int h, int wd, int f, int r, int s, int ph, int pw, int sh, int sw, int dh, int dw,
                    int oh, int ow, int act); // conv_s1.hip
 
 struct ConvArgs {
-    const void *x, *w, *bias;
+    const void *x, *w, *bias, *res; // res: optional residual of y's shape, added before the activation
     void *y;
     int n, c, h, wd, f, r, s;
     int ph, pw, sh, sw, dh, dw;
@@ -221,9 +221,14 @@ template <typename Tr> __global__ __launch_bounds__(256) void conv_igemm16(ConvA
             if (pix >= p.npix)
                 continue;
             float v[4];
+            const unsigned short *rp = p.res ? (const unsigned short *)p.res + ((long)img * p.f + (long)g * p.fg + fm) * p.npix + pix : nullptr;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                v[r] = apply_act(acc[i][j][r] + bv, p.act);
+            for (int r = 0; r < 4; ++r) {
+                float t = acc[i][j][r] + bv;
+                if (rp && pix + r < p.npix)
+                    t += Tr::to_f32(rp[r]);
+                v[r] = apply_act(t, p.act);
+            }
             unsigned short *dst = Y + (long)fm * p.npix + pix;
             if (vec_ok && pix + 3 < p.npix) {
                 u32x2_t pk;
@@ -266,6 +271,8 @@ __global__ __launch_bounds__(256) void conv_direct32(ConvArgs p) {
             }
         if (p.bias)
             acc += ((const float *)p.bias)[f];
+        if (p.res)
+            acc += ((const float *)p.res)[i];
         ((float *)p.y)[i] = apply_act(acc, p.act);
     }
 }
@@ -368,6 +375,12 @@ int infini_rocm_conv_transpose2d(infiniRocmRuntime_t rt, int dtype, const void *
 int infini_rocm_conv2d(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, const void *bias,
                        void *y, int64_t n, int64_t c, int64_t h, int64_t wd, int64_t f, int64_t r, int64_t s,
                        int ph, int pw, int sh, int sw, int dh, int dw, int64_t groups, int act) {
+    return infini_rocm_conv2d_res(rt, dtype, x, w, bias, nullptr, y, n, c, h, wd, f, r, s, ph, pw, sh, sw, dh, dw, groups, act);
+}
+
+int infini_rocm_conv2d_res(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, const void *bias,
+                           const void *residual, void *y, int64_t n, int64_t c, int64_t h, int64_t wd, int64_t f, int64_t r,
+                           int64_t s, int ph, int pw, int sh, int sw, int dh, int dw, int64_t groups, int act) {
     IROCM_CHECK_ARG(rt, "NULL runtime");
     IROCM_CHECK_ARG(dtype == INFINI_DT_F32 || dtype == INFINI_DT_F16 || dtype == INFINI_DT_BF16,
                     "conv2d: unsupported dtype %s", dtype_name(dtype));
@@ -377,7 +390,7 @@ int infini_rocm_conv2d(infiniRocmRuntime_t rt, int dtype, const void *x, const v
     IROCM_CHECK_ARG(sh > 0 && sw > 0 && dh > 0 && dw > 0 && ph >= 0 && pw >= 0, "conv2d: bad attributes");
     IROCM_CHECK_ARG(act >= 0 && act <= 3, "conv2d: bad act %d", act);
     ConvArgs p;
-    p.x = x; p.w = w; p.bias = bias; p.y = y;
+    p.x = x; p.w = w; p.bias = bias; p.res = residual; p.y = y;
     p.n = (int)n; p.c = (int)c; p.h = (int)h; p.wd = (int)wd; p.f = (int)f; p.r = (int)r; p.s = (int)s;
     p.ph = ph; p.pw = pw; p.sh = sh; p.sw = sw; p.dh = dh; p.dw = dw;
     p.groups = (int)groups; p.cg = (int)(c / groups); p.fg = (int)(f / groups);
@@ -413,14 +426,14 @@ int infini_rocm_conv2d(infiniRocmRuntime_t rt, int dtype, const void *x, const v
     if (variant < 0 && one_kstep)
         goto generic;
     if (groups == 1 && variant != 1 && !(variant == 3 && pointwise_gemm) &&
-        (variant == 2 || !(pointwise_gemm && f >= 256 && c >= 128 && p.npix >= 512))) {
-        const int st = launch_conv_s1(rt, dtype, x, w, bias, y, (int)n, (int)c, (int)h, (int)wd, (int)f, (int)r, (int)s,
+        (variant == 2 || residual || !(pointwise_gemm && f >= 256 && c >= 128 && p.npix >= 512))) {
+        const int st = launch_conv_s1(rt, dtype, x, w, bias, residual, y, (int)n, (int)c, (int)h, (int)wd, (int)f, (int)r, (int)s,
                                       ph, pw, sh, sw, dh, dw, p.oh, p.ow, act);
         if (st >= 0)
             return st;
     }
     // pointwise convolution == batched GEMM  Y[n] = W[F x C] . X[n][C x HW]  (A broadcast over batch)
-    if (variant != 1 && r == 1 && s == 1 && ph == 0 && pw == 0 && sh == 1 && sw == 1 && groups == 1 && (p.npix % 8 == 0) &&
+    if (variant != 1 && !residual && r == 1 && s == 1 && ph == 0 && pw == 0 && sh == 1 && sw == 1 && groups == 1 && (p.npix % 8 == 0) &&
         c % 64 == 0) {
         return infini_rocm_matmul(rt, dtype, w, x, bias, y, n, f, p.npix, c, 0, 0, 0, (int64_t)c * p.npix,
                                   0, bias ? 1 : 0, 0, act);

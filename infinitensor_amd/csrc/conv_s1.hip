@@ -36,6 +36,7 @@ namespace irocm {
 
 struct ConvS1Args {
     const void *x, *w, *bias; // x: input or its phase planes; w: [RS][F][C]
+    const void *res;          // optional residual, same shape as y, added before the activation
     void *y;
     int nimg, c, f, r, s, ph, pw, sh, sw, dh, dw;
     int in_h, in_w;  // input extent (padding validity)
@@ -415,11 +416,28 @@ __global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void conv_s1_kernel(ConvS1
             if (fm >= p.f)
                 continue;
             const float bv = bias ? Tr::to_f32(bias[fm]) : 0.f;
+            const long yoff = ((long)im * p.f + fm) * p.hw + pix;
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                v[r] = apply_act(acc[i][j][r] + bv, p.act);
-            unsigned short *dst = Y + ((long)im * p.f + fm) * p.hw + pix;
+                v[r] = acc[i][j][r] + bv;
+            if (p.res) {
+                const unsigned short *rp = (const unsigned short *)p.res + yoff;
+                if (vec_ok && pix + 3 < p.hw && ((((uintptr_t)p.res) & 7) == 0)) {
+                    const u32x2_t rk = *(const u32x2_t *)rp;
+                    v[0] += Tr::to_f32((unsigned short)(rk[0] & 0xffff)); v[1] += Tr::to_f32((unsigned short)(rk[0] >> 16));
+                    v[2] += Tr::to_f32((unsigned short)(rk[1] & 0xffff)); v[3] += Tr::to_f32((unsigned short)(rk[1] >> 16));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (pix + r < p.hw)
+                            v[r] += Tr::to_f32(rp[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                v[r] = apply_act(v[r], p.act);
+            unsigned short *dst = Y + yoff;
             if (vec_ok && pix + 3 < p.hw) {
                 u32x2_t pk;
                 pk[0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
@@ -455,8 +473,8 @@ static int launch_s1(infiniRocmRuntime_t rt, ConvS1Args &p) {
 }
 
 // Returns -1 when the shape is not a conv_s1 shape (caller falls through to the generic kernel).
-int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, const void *bias, void *y,
-                   int n, int c, int h, int wd, int f, int r, int s, int ph, int pw, int sh, int sw, int dh, int dw,
+int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, const void *bias, const void *res,
+                   void *y, int n, int c, int h, int wd, int f, int r, int s, int ph, int pw, int sh, int sw, int dh, int dw,
                    int oh, int ow, int act) {
     if (r > 7 || s > 7 || ((uintptr_t)w & 15) != 0 || ((uintptr_t)x & 3) != 0)
         return -1;
@@ -464,7 +482,7 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
     if (sh * sw > 16 || oh != (h + sh - 1) / sh || ow != (wd + sw - 1) / sw)
         return -1;
     ConvS1Args p;
-    p.x = x; p.w = w; p.bias = bias; p.y = y;
+    p.x = x; p.w = w; p.bias = bias; p.res = res; p.y = y;
     p.nimg = n; p.c = c; p.f = f; p.r = r; p.s = s; p.ph = ph; p.pw = pw;
     p.sh = sh; p.sw = sw; p.dh = dh; p.dw = dw;
     p.in_h = h; p.in_w = wd; p.h = oh; p.wd = ow;

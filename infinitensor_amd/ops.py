@@ -315,7 +315,7 @@ def cast(rt: RocmRuntime, x: torch.Tensor, dst: torch.dtype, out: torch.Tensor |
 # ------------------------------------------------------------------------------------------------
 def conv2d(rt: RocmRuntime, x: torch.Tensor, w: torch.Tensor, ph: int = 0, pw: int = 0, sh: int = 1,
            sw: int = 1, dh: int = 1, dw: int = 1, bias: torch.Tensor | None = None, act: int = 0,
-           out: torch.Tensor | None = None) -> torch.Tensor:
+           out: torch.Tensor | None = None, residual: torch.Tensor | None = None) -> torch.Tensor:
     """NCHW x FCRS cross-correlation. Shape rule: src/operators/conv.cc:47-114 (groups = C / w.shape[1]);
     glue mirrored: src/kernels/cuda/conv.cc:57-168."""
     n, c, h, wd = x.shape
@@ -329,8 +329,10 @@ def conv2d(rt: RocmRuntime, x: torch.Tensor, w: torch.Tensor, ph: int = 0, pw: i
     ow = (wd - (s - sw) * dw + pw * 2) // sw
     if out is None:
         out = torch.empty((n, f, oh, ow), dtype=x.dtype, device=x.device)
-    check(lib().infini_rocm_conv2d(rt.handle, dtype_of(x), _ptr(x), _ptr(w), _ptr(bias), _ptr(out), n, c, h, wd,
-                                   f, r, s, ph, pw, sh, sw, dh, dw, groups, int(act)))
+    if residual is not None and (tuple(residual.shape) != tuple(out.shape) or residual.dtype != x.dtype):
+        raise ValueError("residual must have the output's shape and dtype")
+    check(lib().infini_rocm_conv2d_res(rt.handle, dtype_of(x), _ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(out), n, c,
+                                       h, wd, f, r, s, ph, pw, sh, sw, dh, dw, groups, int(act)))
     return out
 
 

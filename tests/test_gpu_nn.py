@@ -257,3 +257,20 @@ def test_conv_transpose_reference_kats(rt):
     assert R.equal_data(host(y).ravel(), kat(CT, 87, "float"), 1e-6)
     y = ops.conv_transpose2d(rt, dev(R.incremental((1, 2, 3, 3))), dev(R.incremental((2, 2, 3, 3))))
     assert R.equal_data(host(y).ravel(), kat(CT, 129, "float"), 1e-6)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16"])
+@pytest.mark.parametrize("cfg", [(2, 64, 14, 14, 128, 1, 1, 0, 1), (2, 32, 9, 9, 40, 3, 3, 1, 1), (1, 64, 8, 8, 256, 1, 1, 0, 2), (2, 3, 16, 16, 8, 7, 7, 3, 2)])
+def test_conv_with_residual(rt, cfg, dt):
+    """conv2d_res: act(conv + bias + residual) vs the oracle, on the conv_s1 / generic / fp32 paths."""
+    n, c, h, w, f, r, s, pad, st = cfg
+    rng = np.random.default_rng(abs(hash(cfg)) % 2 ** 32)
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((f, c, r, s)) / np.sqrt(c * r * s)).astype(np.float32)
+    b = rng.standard_normal((f,)).astype(np.float32)
+    base = R.conv2d(R.round_to(x, dt), R.round_to(wt, dt), pad, pad, st, st, 1, 1)
+    res = rng.standard_normal(base.shape).astype(np.float32)
+    y = ops.conv2d(rt, dev(x, TD[dt]), dev(wt, TD[dt]), pad, pad, st, st, bias=dev(b, TD[dt]), act=1, residual=dev(res, TD[dt]))
+    want = np.maximum(base + R.round_to(b, dt).reshape(1, f, 1, 1) + R.round_to(res, dt), 0)
+    tol = {"f32": 1e-4, "f16": 3e-3}[dt]
+    assert np.allclose(host(y), want, rtol=tol, atol=tol)
