@@ -252,16 +252,50 @@ def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
     rt.record(e1)
     ar_ms = rt.elapsed_ms(e0, e1) / iters
     nbytes = buf.numel() * 2
-    tmax = torch.tensor([ms, ar_ms], device="cuda", dtype=torch.float64)
+    # strong-scaling shards of the headline GEMM: column shard (no exchange) and K shard (one all-reduce of
+    # the 32 MiB bf16 result); at world = 1 both are the plain 4096^3 GEMM
+    G = 4096
+    bt = torch.bfloat16
+    a_full = torch.randn(G, G, device="cuda", generator=g).to(bt)
+    b_col = torch.randn(G, G // world, device="cuda", generator=g).to(bt)
+    c_col = torch.empty(G, G // world, device="cuda", dtype=bt)
+    a_k = torch.randn(G, G // world, device="cuda", generator=g).to(bt)
+    b_k = torch.randn(G // world, G, device="cuda", generator=g).to(bt)
+    c_k = torch.empty(G, G, device="cuda", dtype=bt)
+    torch.cuda.synchronize()
+
+    def col():
+        ops.matmul(rt, a_full, b_col, out=c_col)
+
+    def ksh():
+        ops.matmul(rt, a_k, b_k, out=c_k)
+        ops.all_reduce(rt, "sum", c_k, out=c_k)
+
+    shard_ms = []
+    for fn in (col, ksh):
+        for _ in range(3):
+            fn()
+        rt.record(e0)
+        for _ in range(iters):
+            fn()
+        rt.record(e1)
+        shard_ms.append(rt.elapsed_ms(e0, e1) / iters)
+    tmax = torch.tensor([ms, ar_ms, *shard_ms], device="cuda", dtype=torch.float64)
     if world > 1:
         dist_mod.all_reduce(tmax, op=dist_mod.ReduceOp.MAX)
-    ms, ar_ms = (float(v) for v in tmax.tolist())
+    ms, ar_ms, col_ms, k_ms = (float(v) for v in tmax.tolist())
+    gemm_shards = {
+        "workload": "one bf16 4096^3 GEMM strong-scaled over %d GPUs" % world,
+        "column_shard_ms": round(col_ms, 4), "column_shard_TFLOPs_aggregate": round(2.0 * G ** 3 / col_ms / 1e9, 1),
+        "k_shard_allreduce_ms": round(k_ms, 4), "k_shard_TFLOPs_aggregate": round(2.0 * G ** 3 / k_ms / 1e9, 1),
+    }
     return {
         "workload": "Llama-7B-style block, tokens 2048, fp16, TP=%d (2 all-reduces of 16 MiB)" % world,
         "ms_per_block": round(ms, 4),
         "gemm_TFLOPs_aggregate": round(tp.llama_block_flops(T, H, F, 1) / ms / 1e9, 1),
         "allreduce_16MiB_ms": round(ar_ms, 4),
         "allreduce_busbw_GBs": round(2 * (world - 1) / world * nbytes / (ar_ms * 1e-3) / 1e9, 1) if world > 1 else None,
+        "gemm_strong_scaling": gemm_shards,
         "finite": bool(torch.isfinite(y.float()).all().item()),
     }
 
