@@ -32,7 +32,12 @@ struct AttnArgs {
     int causal;
 };
 
-template <typename Tr, int D, int NT>
+// raw v_exp_f32 (exp2f() wraps it in a denormal range fix-up: 5 extra VALU instructions per score); results below
+// 2^-126 flush to 0, which is what a softmax weight that small is worth
+__device__ static inline float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// CAUSAL / MASK are compile-time so that the unmasked, non-causal sweep carries no select / compare per score.
+template <typename Tr, int D, int NT, bool CAUSAL, bool MASK>
 __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     constexpr int QW = NT * 16;              // query rows per wave
     constexpr int KT = 64;                   // keys per tile
@@ -145,23 +150,48 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
             }
         }
         // ---- scale, mask, online softmax (lane: query column l15, keys kbase + mt*16 + 4*g4 + r) -----
+        // additive term per key (mask * log2 e, -inf past Sk): only when there is a mask or this is the ragged last tile
+        const bool ragged = kbase + KT > p.sk; // wave-uniform
+        if constexpr (MASK) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int key = kbase + mt * 16 + 4 * g4;
+            for (int mt = 0; mt < 4; ++mt) {
+                const int key = kbase + mt * 16 + 4 * g4;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float mv = 0.f;
-                if (key + r >= p.sk)
-                    mv = -INFINITY;
-                else if (M)
-                    mv = Tr::to_f32(M[key + r]) * LOG2E;
+                for (int r = 0; r < 4; ++r) {
+                    const float mv = key + r < p.sk ? Tr::to_f32(M[key + r]) * LOG2E : -INFINITY;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    float v = s[mt][nt][r] * c + mv;
-                    if (p.causal && key + r > q0 + nt * 16 + l15 + (p.sk - p.sq))
-                        v = -INFINITY;
-                    s[mt][nt][r] = v;
+                    for (int nt = 0; nt < NT; ++nt)
+                        s[mt][nt][r] = fmaf(s[mt][nt][r], c, mv);
                 }
+            }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    s[mt][nt] *= c;
+            if (ragged) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kbase + mt * 16 + 4 * g4 + r >= p.sk) {
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                s[mt][nt][r] = -INFINITY;
+                        }
+            }
+        }
+        if (CAUSAL) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int lim = q0 + nt * 16 + l15 + (p.sk - p.sq); // last admissible key of this query column
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kbase + mt * 16 + 4 * g4 + r > lim)
+                            s[mt][nt][r] = -INFINITY;
             }
         }
 #pragma unroll
@@ -176,21 +206,24 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float m_new = fmaxf(m_run[nt], mx);
             const float m_use = m_new == -INFINITY ? 0.f : m_new;
-            const float alpha = exp2f(m_run[nt] - m_use);
+            const float alpha = fast_exp2(m_run[nt] - m_use);
             m_run[nt] = m_new;
             float ps = 0.f;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = exp2f(s[mt][nt][r] - m_use);
+                    const float e = fast_exp2(s[mt][nt][r] - m_use);
                     s[mt][nt][r] = e;
                     ps += e;
                 }
             l_run[nt] = l_run[nt] * alpha + ps;
+            // the running maximum settles after the first tiles: skip the 16 multiplies when no lane's changed
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-                o[dt][nt] *= alpha;
+                for (int dt = 0; dt < DT; ++dt)
+                    o[dt][nt] *= alpha;
+            }
         }
         // ---- P fragments (B operand): k-slots 0..3 = keys 4*g4 + e of sub-tile 2*kk, 4..7 = of sub-tile 2*kk+1 ----
         s16x8_t pf[NT][2];
@@ -250,9 +283,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     }
 }
 
-template <typename Tr, int D, int NT> static int launch_attn(infiniRocmRuntime_t rt, const AttnArgs &p) {
+template <typename Tr, int D, int NT, bool CAUSAL, bool MASK>
+static int launch_attn2(infiniRocmRuntime_t rt, const AttnArgs &p) {
     constexpr int LDS = 2 * (64 * (D * 2 + 16) + 64 * (D * 2 + 32));
-    auto kern = attention_kernel<Tr, D, NT>;
+    auto kern = attention_kernel<Tr, D, NT, CAUSAL, MASK>;
     static bool attr_done = false;
     if (!attr_done) {
         IROCM_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -262,6 +296,11 @@ template <typename Tr, int D, int NT> static int launch_attn(infiniRocmRuntime_t
     hipLaunchKernelGGL(kern, grid, dim3(256), LDS, rt->stream, p);
     IROCM_LAUNCH_CHECK("attention");
     return INFINI_ROCM_OK;
+}
+template <typename Tr, int D, int NT> static int launch_attn(infiniRocmRuntime_t rt, const AttnArgs &p) {
+    if (p.causal)
+        return p.mask ? launch_attn2<Tr, D, NT, true, true>(rt, p) : launch_attn2<Tr, D, NT, true, false>(rt, p);
+    return p.mask ? launch_attn2<Tr, D, NT, false, true>(rt, p) : launch_attn2<Tr, D, NT, false, false>(rt, p);
 }
 
 } // namespace irocm
