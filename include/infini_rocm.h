@@ -236,6 +236,10 @@ typedef enum {
 int infini_rocm_binary(infiniRocmRuntime_t rt, int op, int dtype, const void *a, const void *b,
                        void *c, int ndim, const int64_t *shape, const int64_t *stride_a,
                        const int64_t *stride_b);
+/* out[o, c, i] = act(a[o, c, i] + bias[c] + residual[o, c, i]) with the intermediate sum rounded like the unfused
+ * Add -> Add [-> Relu] chain (bit-identical to it); relu: 0 / 1. One pass instead of two or three. */
+int infini_rocm_bias_residual(infiniRocmRuntime_t rt, int dtype, const void *a, const void *bias, const void *residual,
+                              void *out, int64_t outer, int64_t channels, int64_t inner, int relu);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Unary element-wise (reference: unary_kernel, src/kernels/cuda/unary.cu:262-352; cuDNN        */

@@ -245,6 +245,62 @@ static int binary_op_dispatch(infiniRocmRuntime_t rt, int op, const void *a, con
     }
 }
 
+// ---- bias + residual (+ relu) ------------------------------------------------------------------
+// out[o, c, i] = act(round(a[o, c, i] + bias[c]) + res[o, c, i]) — the element-wise tail of a ResNet bottleneck,
+// Add(per-channel bias) -> Add(identity) [-> Relu], in one pass (used by the runtime's fusion when the bias cannot go
+// into the conv epilogue). The intermediate is rounded to T exactly like the unfused chain: bit-identical results.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bias_residual_kernel(const T *__restrict__ a, const T *__restrict__ bias,
+                                                            const T *__restrict__ res, T *__restrict__ out, long outer,
+                                                            int channels, long inner_v, int relu) {
+    using A = typename Cvt<T>::acc_t;
+    const long total = outer * channels * inner_v;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long)gridDim.x * 256) {
+        const int c = (int)((v / inner_v) % channels);
+        const A bv = Cvt<T>::load(bias + c);
+        const VecT<T, VEC> av = *reinterpret_cast<const VecT<T, VEC> *>(a + v * VEC);
+        const VecT<T, VEC> rv = *reinterpret_cast<const VecT<T, VEC> *>(res + v * VEC);
+        VecT<T, VEC> o;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            T mid;
+            Cvt<T>::store(&mid, Cvt<T>::load(&av.v[j]) + bv);
+            A x = Cvt<T>::load(&mid) + Cvt<T>::load(&rv.v[j]);
+            if (relu)
+                x = x > (A)0 ? x : (A)0;
+            Cvt<T>::store(&o.v[j], x);
+        }
+        *reinterpret_cast<VecT<T, VEC> *>(out + v * VEC) = o;
+    }
+}
+
+template <typename T>
+static int bias_residual_launch(infiniRocmRuntime_t rt, const void *a, const void *bias, const void *res, void *out,
+                                int64_t outer, int64_t channels, int64_t inner, int relu) {
+    constexpr int VMAX = 16 / (int)sizeof(T);
+    int vec = VMAX;
+    auto ok = [&](int v) {
+        const uintptr_t m = (uintptr_t)(v * sizeof(T)) - 1;
+        return inner % v == 0 && !(((uintptr_t)a | (uintptr_t)res | (uintptr_t)out) & m);
+    };
+    while (vec > 1 && !ok(vec))
+        vec >>= 1;
+    const long total = outer * channels * (inner / vec);
+    const unsigned grid = capped_grid(total, rt->num_cu);
+#define BR(V)                                                                                             \
+    hipLaunchKernelGGL((bias_residual_kernel<T, V>), dim3(grid), dim3(256), 0, rt->stream, (const T *)a,  \
+                       (const T *)bias, (const T *)res, (T *)out, (long)outer, (int)channels, (long)(inner / V), relu)
+    switch (vec) {
+    case 8: if constexpr (VMAX >= 8) { BR(8); } break;
+    case 4: if constexpr (VMAX >= 4) { BR(4); } break;
+    case 2: if constexpr (VMAX >= 2) { BR(2); } break;
+    default: BR(1); break;
+    }
+#undef BR
+    IROCM_LAUNCH_CHECK("bias_residual");
+    return INFINI_ROCM_OK;
+}
+
 // ---- unary ops -------------------------------------------------------------------------------
 template <int OP> __device__ inline float un_op(float x, float p0, float p1) {
     if constexpr (OP == INFINI_UN_RELU) return fmaxf(x, 0.f);
@@ -398,6 +454,21 @@ static int cast_dst_dispatch(infiniRocmRuntime_t rt, int dst, const void *x, voi
 using namespace irocm;
 
 extern "C" {
+
+int infini_rocm_bias_residual(infiniRocmRuntime_t rt, int dtype, const void *a, const void *bias, const void *residual,
+                              void *out, int64_t outer, int64_t channels, int64_t inner, int relu) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(outer >= 0 && channels > 0 && inner > 0 && channels < (1ll << 31), "bias_residual: bad extent");
+    if (outer == 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(a && bias && residual && out, "bias_residual: NULL tensor");
+    switch (dtype) {
+    case INFINI_DT_F32: return bias_residual_launch<float>(rt, a, bias, residual, out, outer, channels, inner, relu);
+    case INFINI_DT_F16: return bias_residual_launch<__half>(rt, a, bias, residual, out, outer, channels, inner, relu);
+    case INFINI_DT_BF16: return bias_residual_launch<__hip_bfloat16>(rt, a, bias, residual, out, outer, channels, inner, relu);
+    default: IROCM_FAIL(INFINI_ROCM_UNSUPPORTED, "bias_residual: unsupported dtype %s", dtype_name(dtype));
+    }
+}
 
 int infini_rocm_binary(infiniRocmRuntime_t rt, int op, int dtype, const void *a, const void *b,
                        void *c, int ndim, const int64_t *shape, const int64_t *stride_a,

@@ -294,6 +294,21 @@ def binary(rt: RocmRuntime, op: str, a: torch.Tensor, b: torch.Tensor,
     return out
 
 
+def bias_residual(rt: RocmRuntime, a: torch.Tensor, bias: torch.Tensor, residual: torch.Tensor, relu: bool = True,
+                  out: torch.Tensor | None = None) -> torch.Tensor:
+    """relu?(a + bias[c] + residual) for a [N, C, ...] tensor and a per-channel bias: the fused Add -> Add -> Relu tail."""
+    if a.shape != residual.shape or bias.numel() != a.shape[1]:
+        raise ValueError("bias_residual: a / residual [N, C, ...], bias [C]")
+    if out is None:
+        out = torch.empty_like(a)
+    inner = 1
+    for d in a.shape[2:]:
+        inner *= d
+    check(lib().infini_rocm_bias_residual(rt.handle, dtype_of(a), _ptr(a), _ptr(bias), _ptr(residual), _ptr(out), a.shape[0],
+                                          a.shape[1], inner, int(relu)))
+    return out
+
+
 def unary(rt: RocmRuntime, op: str, x: torch.Tensor, p0: float = float("nan"), p1: float = float("nan"),
           out: torch.Tensor | None = None) -> torch.Tensor:
     if out is None:

@@ -7,6 +7,8 @@
 //   Conv -> Add(bias) -> Add(identity) [-> Relu]                   =>  conv2d_res(bias, residual, act)   [opt-in:
 //        INFINI_ROCM_FUSE_RES=1; measured 1 % slower than conv + ADD_RELU on ResNet-50]
 //   Add  -> Relu                                                   =>  binary(ADD_RELU)         (residual join)
+//   Add(bias) -> Add(identity) [-> Relu]                           =>  bias_residual            (when the conv could not
+//        take the bias: its input's storage was recycled for the output)
 //   MatMul(Q, K^T) [-> Div|Mul(scalar)] [-> Add(mask)] -> Softmax(last axis) -> MatMul(P, V)
 //                                                                  =>  attention (csrc/attention.hip): the score
 //        matrix is never written; Q, K, V rank-4 [b, h, S, D] with D in {64, 128}, f16 / bf16, mask [b|1, 1, 1, Sk]
@@ -49,6 +51,25 @@ bool isChannelBias(const Tensor &b, int f) {
         return d[0] == 1 && d[1] == f && d[2] == 1 && d[3] == 1;
     if (d.size() == 3)
         return d[0] == f && d[1] == 1 && d[2] == 1;
+    return false;
+}
+// `b` is a per-channel bias of a tensor with dims `d` ([N, C, ...]): [1, C, 1, ...] or [C, 1, ...]
+bool isChannelBiasOf(const Tensor &b, const Shape &d) {
+    const auto &bd = b->getDims();
+    if ((int64_t)b->size() != d[1])
+        return false;
+    if (bd.size() == d.size()) {
+        for (size_t i = 0; i < bd.size(); ++i)
+            if (bd[i] != (i == 1 ? d[1] : 1))
+                return false;
+        return true;
+    }
+    if (bd.size() + 1 == d.size()) {
+        for (size_t i = 0; i < bd.size(); ++i)
+            if (bd[i] != (i == 0 ? d[1] : 1))
+                return false;
+        return true;
+    }
     return false;
 }
 std::vector<int64_t> strides64(const Shape &shape, const Shape &outShape) {
@@ -202,6 +223,43 @@ size_t RocmRuntimeObj::tryLaunchFused(const OpVec &ops, size_t i) const {
             return c.used;
         }
         return 0;
+    }
+    // Add(x, per-channel bias) -> Add(., identity) [-> Relu]: the bottleneck tail when the bias could not ride in the conv
+    if (type == OpType::Add && i + 1 < ops.size() && ops[i + 1]->getOpType() == OpType::Add &&
+        soleConsumerIs(op->getOutput(), ops[i + 1])) {
+        const Tensor t = op->getOutput();
+        const Tensor a0 = op->getInputs(0), a1 = op->getInputs(1);
+        const auto &td = t->getDims();
+        Tensor xin = nullptr, bias = nullptr;
+        if (td.size() >= 2 && isChannelBiasOf(a1, td) && a0->getDims() == td) { xin = a0; bias = a1; }
+        else if (td.size() >= 2 && isChannelBiasOf(a0, td) && a1->getDims() == td) { xin = a1; bias = a0; }
+        if (xin) {
+            const Operator &add2 = ops[i + 1];
+            const Tensor res = add2->getInputs(0) == t ? add2->getInputs(1) : add2->getInputs(0);
+            Tensor out = add2->getOutput();
+            size_t used = 2;
+            int relu = 0;
+            if (res != t && res->getDims() == td && res->getDType() == t->getDType() && bias->getDType() == t->getDType()) {
+                if (i + 2 < ops.size() && ops[i + 2]->getOpType() == OpType::Relu && soleConsumerIs(out, ops[i + 2])) {
+                    out = ops[i + 2]->getOutput();
+                    relu = 1;
+                    used = 3;
+                }
+                auto hazard = [&](const Tensor &u) {
+                    const bool inPlace = u->getRawDataPtr<void *>() == out->getRawDataPtr<void *>() && u->getDims() == td;
+                    return overlaps(out, u) && !inPlace;
+                };
+                if (!hazard(xin) && !hazard(res) && !overlaps(out, bias)) {
+                    int64_t inner = 1;
+                    for (size_t d = 2; d < td.size(); ++d)
+                        inner *= td[d];
+                    ROCM_CALL(infini_rocm_bias_residual(rt, t->getDTypeIndex(), xin->getRawDataPtr<void *>(),
+                                                        bias->getRawDataPtr<void *>(), res->getRawDataPtr<void *>(),
+                                                        out->getRawDataPtr<void *>(), td[0], td[1], inner, relu));
+                    return used;
+                }
+            }
+        }
     }
     if (type == OpType::Add && i + 1 < ops.size() && ops[i + 1]->getOpType() == OpType::Relu &&
         soleConsumerIs(op->getOutput(), ops[i + 1])) {

@@ -152,3 +152,20 @@ def test_add_relu_is_bit_identical_to_the_chain(rt, dt):
     chain = ops.unary(rt, "relu", ops.binary(rt, "add", a, b))
     assert torch.equal(fused, chain)
     assert np.array_equal(host(fused), np.maximum(host(ops.binary(rt, "add", a, b)), 0))
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("shape", [(3, 64, 14, 14), (2, 5, 7), (2, 3, 1, 1), (4, 8)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_bias_residual_is_bit_identical_to_the_chain(rt, shape, relu, dt):
+    """infini_rocm_bias_residual == [relu](add(add(a, bias), res)) bit for bit (the intermediate is rounded the same way)."""
+    rng = np.random.default_rng(15)
+    a = dev(rng.standard_normal(shape).astype(np.float32), TD[dt])
+    r = dev(rng.standard_normal(shape).astype(np.float32), TD[dt])
+    bshape = (1, shape[1]) + (1,) * (len(shape) - 2)
+    b = dev(rng.standard_normal(bshape).astype(np.float32), TD[dt])
+    fused = ops.bias_residual(rt, a, b.reshape(-1).contiguous(), r, relu)
+    chain = ops.binary(rt, "add", ops.binary(rt, "add", a, b), r)
+    if relu:
+        chain = ops.unary(rt, "relu", chain)
+    assert torch.equal(fused, chain)
