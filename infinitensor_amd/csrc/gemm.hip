@@ -388,9 +388,9 @@ static bool fast128_supported(const GemmArgs &p, bool akm, bool bkm) {
 }
 
 static const char *kVariantNames[] = {"generic64", "fast128_glds", "tile256_stagger", "tile256_pipelined", "tile256_mfma32",
-                                      "tile256_4wave", "tile256_splitk"};
-constexpr int kNumVariants = 7;
-constexpr int kDefault256 = 2; // schedule used by the heuristic
+                                      "tile256_4wave", "tile256_splitk", "tile256_stagger_st16"};
+constexpr int kNumVariants = 8;
+constexpr int kDefault256 = 7; // schedule used by the heuristic (staggered + 16-byte epilogue stores)
 
 } // namespace irocm
 
@@ -438,6 +438,7 @@ int infini_rocm_matmul(infiniRocmRuntime_t rt, int dtype, const void *a, const v
     p.splitk = 1;
     p.partial = nullptr;
     p.zeros = rt->zeros;
+    p.epi16 = 1; // 16-byte epilogue stores (variant 2 forces the 8-byte epilogue for A/B runs)
     const bool akm = !trans_a, bkm = trans_b != 0;
 
     int variant = rt->matmul_variant;
@@ -469,6 +470,10 @@ int infini_rocm_matmul(infiniRocmRuntime_t rt, int dtype, const void *a, const v
         variant = 0;
     }
 
+    if (variant == 7)
+        return launch_gemm256(rt, dtype, p, akm, bkm, 0);
+    if (variant == 2 && rt->matmul_variant == 2)
+        p.epi16 = 0; // explicitly requested: the plain staggered kernel
     if (variant == 6)
         return launch_gemm256_splitk(rt, dtype, p, akm, bkm, splits < 2 ? 2 : splits);
     if (variant == 5)

@@ -30,6 +30,7 @@ struct GemmArgs {
     // plane of `partial` [splitk][batch][m][n]; splitk_reduce adds the planes, the bias and the activation
     int splitk;
     float *partial;
+    int epi16;         // gemm256: 16-byte stores in the epilogue (pair exchange between lane groups)
     const void *zeros; // >= 16 zero bytes in device memory: source of K-tail chunks past k (fast128)
 };
 
