@@ -209,6 +209,50 @@ template <typename Tr> __global__ __launch_bounds__(256) void conv_igemm16(ConvA
     unsigned short *Y = (unsigned short *)p.y + ((long)img * p.f + (long)g * p.fg) * p.npix;
     const unsigned short *bias = (const unsigned short *)p.bias;
     const bool vec_ok = (p.npix % 4 == 0) && ((((uintptr_t)p.y) & 7) == 0);
+    // wide path: 16-byte stores by swapping half tiles between lane groups g4 / g4^1 (see gemm256.hip / conv_s1.hip)
+    const bool wide = (p.npix % 16 == 0) && ((((uintptr_t)p.y) & 15) == 0) && (p0 + wn * 64 + 64 <= p.npix) &&
+                      (m0 + wm * 64 + 64 <= p.fg) && (!p.res || ((((uintptr_t)p.res) & 7) == 0));
+    if (wide) {
+        const int l15 = lane & 15, g4 = lane >> 4;
+        const bool odd = g4 & 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int fm = m0 + wm * 64 + i * 16 + l15;
+            const float bv = bias ? Tr::to_f32(bias[g * p.fg + fm]) : 0.f;
+            const long rowoff = (long)fm * p.npix;
+            const unsigned short *R = p.res ? (const unsigned short *)p.res + ((long)img * p.f + (long)g * p.fg) * p.npix : nullptr;
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                unsigned pk[2][2];
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    const int pix = p0 + wn * 64 + (jp * 2 + t2) * 16 + g4 * 4;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        v[r] = acc[i][jp * 2 + t2][r] + bv;
+                    if (R) {
+                        const u32x2_t rk = *(const u32x2_t *)(R + rowoff + pix);
+                        v[0] += Tr::to_f32((unsigned short)(rk[0] & 0xffff)); v[1] += Tr::to_f32((unsigned short)(rk[0] >> 16));
+                        v[2] += Tr::to_f32((unsigned short)(rk[1] & 0xffff)); v[3] += Tr::to_f32((unsigned short)(rk[1] >> 16));
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        v[r] = apply_act(v[r], p.act);
+                    pk[t2][0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
+                    pk[t2][1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
+                }
+                const unsigned s0 = odd ? pk[0][0] : pk[1][0], s1 = odd ? pk[0][1] : pk[1][1];
+                const unsigned r0 = (unsigned)__shfl_xor((int)s0, 16), r1 = (unsigned)__shfl_xor((int)s1, 16);
+                u32x4_t o;
+                if (odd) { o[0] = r0; o[1] = r1; o[2] = pk[1][0]; o[3] = pk[1][1]; }
+                else { o[0] = pk[0][0]; o[1] = pk[0][1]; o[2] = r0; o[3] = r1; }
+                const int pix = p0 + wn * 64 + (jp * 2 + (odd ? 1 : 0)) * 16 + (g4 & ~1) * 4;
+                *(u32x4_t *)(Y + rowoff + pix) = o;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int fm = m0 + wm * 64 + i * 16 + (lane & 15);
@@ -418,15 +462,20 @@ int infini_rocm_conv2d_res(infiniRocmRuntime_t rt, int dtype, const void *x, con
     const int variant = rt->conv_variant;
     const bool same_s1 = sh == 1 && sw == 1 && dh == 1 && dw == 1 && groups == 1 && p.oh == p.h && p.ow == p.wd;
     const bool pointwise_gemm = r == 1 && s == 1 && ph == 0 && pw == 0 && same_s1 && (p.npix % 8 == 0) && c % 64 == 0;
-    // big-plane pointwise layers with >= 256 filters are plain batched GEMMs (LDS-DMA kernels); everything else whose
+    // big-plane pointwise layers with >= 256 filters and channels are plain batched GEMMs (LDS-DMA kernels); everything else whose
     // output extent is ceil(input / stride) goes to the tap-shifted implicit GEMM of conv_s1.hip (measured per
     // ResNet-50 layer with tools/conv_bench.py)
     // a single K-step leaves nothing to pipeline: the small generic tile (more workgroups per CU) hides the latency better
     const bool one_kstep = (long)c * r * s <= 64 && f >= 128;
-    if (variant < 0 && one_kstep)
+    // measured per layer (tools/conv_bench.py, same box): on 56x56 planes the memory-bound pointwise layers with >= 128
+    // filters and <= 256 channels run 20-30 % faster on the small generic tile (6 workgroups per CU keep more bytes in
+    // flight): C64->F256 108 vs 143 us, C256->F128 107 vs 137 us; from 28x28 down conv_s1 wins everywhere
+    const bool big_plane_pointwise = r == 1 && s == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0 && groups == 1 &&
+                                     p.npix >= 2048 && f >= 128 && c <= 256;
+    if (variant < 0 && (one_kstep || big_plane_pointwise))
         goto generic;
     if (groups == 1 && variant != 1 && !(variant == 3 && pointwise_gemm) &&
-        (variant == 2 || residual || !(pointwise_gemm && f >= 256 && c >= 128 && p.npix >= 512))) {
+        (variant == 2 || residual || !(pointwise_gemm && f >= 256 && c >= 256 && p.npix >= 512))) {
         const int st = launch_conv_s1(rt, dtype, x, w, bias, residual, y, (int)n, (int)c, (int)h, (int)wd, (int)f, (int)r, (int)s,
                                       ph, pw, sh, sw, dh, dw, p.oh, p.ow, act);
         if (st >= 0)

@@ -45,6 +45,7 @@ struct ConvS1Args {
     int tiles_m, tiles_n;
     int act;
     int kdim, kpad;      // ROWTAP: C*R*S and its round-up to 32 (w is [F][kpad])
+    int wide_epilogue;   // 16-byte stores where the plane allows (tuning hook IROCM_CONV_WIDE=0 turns it off)
     unsigned x_bytes;    // bytes of everything behind x
     long plane_elems;    // elements of one phase plane set [n][c][h][wd]
     signed char slot[16]; // phase py*sw + px -> index of its plane set behind x
@@ -402,6 +403,51 @@ __global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void conv_s1_kernel(ConvS1
     unsigned short *Y = (unsigned short *)p.y;
     const unsigned short *bias = (const unsigned short *)p.bias;
     const bool vec_ok = (p.hw % 4 == 0) && ((((uintptr_t)p.y) & 7) == 0);
+    // Wide path (planes that are a multiple of 16 pixels, i.e. hwp == hw: 56x56, 28x28, ...): lane groups g4 / g4^1 swap
+    // halves of a pair of 16-pixel tiles so that every lane stores 8 consecutive pixels of one filter row with ONE
+    // 16-byte store (same exchange as the GEMM epilogue); wave-uniform condition, so the shuffles are convergent.
+    const bool wide = p.wide_epilogue && (p.hw % 16 == 0) && ((((uintptr_t)p.y) & 15) == 0) && (n0 + wn * 64 + 64 <= p.ncols) &&
+                      (m0 + wm * 64 + 64 <= p.f) && (!p.res || ((((uintptr_t)p.res) & 7) == 0));
+    if (wide) {
+        const bool odd = g4 & 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int fm = m0 + wm * 64 + i * 16 + l15;
+            const float bv = bias ? Tr::to_f32(bias[fm]) : 0.f;
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                unsigned pk[2][2];
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    const int col = n0 + wn * 64 + (jp * 2 + t2) * 16 + g4 * 4;
+                    const int im = col / p.hw, pix = col - im * p.hw; // hwp == hw here
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        v[r] = acc[i][jp * 2 + t2][r] + bv;
+                    if (p.res) {
+                        const u32x2_t rk = *(const u32x2_t *)((const unsigned short *)p.res + ((long)im * p.f + fm) * p.hw + pix);
+                        v[0] += Tr::to_f32((unsigned short)(rk[0] & 0xffff)); v[1] += Tr::to_f32((unsigned short)(rk[0] >> 16));
+                        v[2] += Tr::to_f32((unsigned short)(rk[1] & 0xffff)); v[3] += Tr::to_f32((unsigned short)(rk[1] >> 16));
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        v[r] = apply_act(v[r], p.act);
+                    pk[t2][0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
+                    pk[t2][1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
+                }
+                const unsigned s0 = odd ? pk[0][0] : pk[1][0], s1 = odd ? pk[0][1] : pk[1][1];
+                const unsigned r0 = (unsigned)__shfl_xor((int)s0, 16), r1 = (unsigned)__shfl_xor((int)s1, 16);
+                u32x4_t o;
+                if (odd) { o[0] = r0; o[1] = r1; o[2] = pk[1][0]; o[3] = pk[1][1]; }
+                else { o[0] = pk[0][0]; o[1] = pk[0][1]; o[2] = r0; o[3] = r1; }
+                const int col = n0 + wn * 64 + (jp * 2 + (odd ? 1 : 0)) * 16 + (g4 & ~1) * 4;
+                const int im = col / p.hw, pix = col - im * p.hw;
+                *(u32x4_t *)(Y + ((long)im * p.f + fm) * p.hw + pix) = o;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int col = n0 + wn * 64 + j * 16 + g4 * 4;
@@ -492,6 +538,8 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
         return -1;
     p.ncols = n * p.hwp;
     p.act = act;
+    static const int wide = getenv("IROCM_CONV_WIDE") ? atoi(getenv("IROCM_CONV_WIDE")) : 1;
+    p.wide_epilogue = wide;
     p.plane_elems = (long)n * c * p.hw;
     // phases read by some tap
     PhaseSplitArgs ps;
