@@ -284,7 +284,47 @@ __global__ __launch_bounds__(256) void gemm_fast128(GemmArgs p) {
     unsigned short *C = (unsigned short *)p.c + (long)ib * p.m * p.n;
     const unsigned short *bias = (const unsigned short *)p.bias;
     const bool interior = (m0 + BM <= p.m) && (n0 + BN <= p.n) && (p.n % 4 == 0);
-    if (interior) {
+    if (interior && (p.n % 8 == 0) && ((((uintptr_t)p.c) & 15) == 0)) {
+        // 16-byte stores by swapping half tiles between lane groups g4 / g4^1 (same exchange as gemm256.hip)
+        const int l15 = lane & 15, g4 = lane >> 4;
+        const bool odd = g4 & 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = m0 + wm * 64 + i * 16 + l15;
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                unsigned pk[2][2];
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    const int col = n0 + wn * 64 + (jp * 2 + t2) * 16 + g4 * 4;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        v[r] = acc[i][jp * 2 + t2][r];
+                    if (bias) {
+                        const unsigned short *bp = bias + (long)ib * p.bias_b + (long)row * p.bias_m + (long)col * p.bias_n;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            v[r] += Tr::to_f32(bp[(long)r * p.bias_n]);
+                    }
+                    if (p.act) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            v[r] = apply_act(v[r], p.act);
+                    }
+                    pk[t2][0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
+                    pk[t2][1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
+                }
+                const unsigned s0 = odd ? pk[0][0] : pk[1][0], s1 = odd ? pk[0][1] : pk[1][1];
+                const unsigned r0 = (unsigned)__shfl_xor((int)s0, 16), r1 = (unsigned)__shfl_xor((int)s1, 16);
+                u32x4_t o;
+                if (odd) { o[0] = r0; o[1] = r1; o[2] = pk[1][0]; o[3] = pk[1][1]; }
+                else { o[0] = pk[0][0]; o[1] = pk[0][1]; o[2] = r0; o[3] = r1; }
+                const int col = n0 + wn * 64 + (jp * 2 + (odd ? 1 : 0)) * 16 + (g4 & ~1) * 4;
+                *(u32x4_t *)(C + (long)row * p.n + col) = o;
+            }
+        }
+    } else if (interior) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = m0 + wm * 64 + i * 16 + (lane & 15);
