@@ -130,6 +130,37 @@ __global__ __launch_bounds__(256) void conv_phase_split_2x2(PhaseSplit2Args a) {
     }
 }
 
+// Same split, 8 input columns per thread: one 16-byte load, one 8-byte store into each column phase. Needs
+// in_w % 8 == 0 (so ow % 4 == 0), 16-byte aligned x and 8-byte aligned planes. Rows past the input (odd heights) are
+// written as zeros like in the scalar kernels.
+__global__ __launch_bounds__(256) void conv_phase_split_2x2_v8(PhaseSplit2Args a) {
+    const int octs = a.in_w / 8;
+    const int rows = 2 * a.oh;
+    const int total = a.planes * rows * octs;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int jo = i % octs;
+        const int q = i / octs;
+        const int iy = q % rows, pl = q / rows;
+        const int py = iy & 1, oy = iy >> 1;
+        if (a.slot[py * 2] < 0 && a.slot[py * 2 + 1] < 0)
+            continue;
+        u32x4_t v = {0u, 0u, 0u, 0u};
+        if (iy < a.in_h)
+            v = *(const u32x4_t *)(a.x + ((long)pl * a.in_h + iy) * a.in_w + 8 * jo);
+        // even / odd elements of the 8: dword d holds elements 2d (low half) and 2d+1 (high half)
+        u32x2_t ev, od;
+        ev[0] = (v[0] & 0xffffu) | (v[1] << 16);
+        ev[1] = (v[2] & 0xffffu) | (v[3] << 16);
+        od[0] = (v[0] >> 16) | (v[1] & 0xffff0000u);
+        od[1] = (v[2] >> 16) | (v[3] & 0xffff0000u);
+        const long off = ((long)pl * a.oh + oy) * a.ow + 4 * jo;
+        if (a.slot[py * 2] >= 0)
+            *(u32x2_t *)(a.o + a.slot[py * 2] * a.plane_elems + off) = ev;
+        if (a.slot[py * 2 + 1] >= 0)
+            *(u32x2_t *)(a.o + a.slot[py * 2 + 1] * a.plane_elems + off) = od;
+    }
+}
+
 // o[f][t*c + cc] = w[f][cc][t], zero for k in [c*rs, kpad)
 __global__ __launch_bounds__(256) void conv_repack_w_flat(const unsigned short *__restrict__ w,
                                                           unsigned short *__restrict__ o, int f, int c, int rs, int kpad) {
@@ -593,16 +624,23 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
         ps.planes = (long)n * c;
         ps.in_h = h; ps.in_w = wd; ps.oh = oh; ps.ow = ow; ps.sh = sh; ps.sw = sw;
         const long work2 = (long)n * c * 2 * oh * ((ow + 1) / 2);
-        // all four phases wanted (3x3/2, 7x7/2): the quad kernel; a 1x1/2 reads one phase and is faster element-wise
-        if (sh == 2 && sw == 2 && ps.nslots == 4 && work2 + (long)rt->num_cu * 32 * 256 < (1l << 31)) {
+        // vector kernels: 8 columns per thread when the row length allows (any phase set), else the quad kernel when all
+        // four phases are wanted (3x3/2, 7x7/2); a 1x1/2 on odd-sized rows reads one phase and is faster element-wise
+        const bool v8ok = wd % 8 == 0 && (((uintptr_t)x) & 15) == 0 && (w_bytes % 8 == 0) && (p.plane_elems % 4 == 0);
+        if (sh == 2 && sw == 2 && (ps.nslots == 4 || v8ok) && work2 + (long)rt->num_cu * 32 * 256 < (1l << 31)) {
             PhaseSplit2Args a2;
             a2.x = ps.x; a2.o = ps.o; a2.planes = n * c; a2.in_h = h; a2.in_w = wd; a2.oh = oh; a2.ow = ow;
             a2.plane_elems = p.plane_elems;
             for (int i = 0; i < 4; ++i)
                 a2.slot[i] = p.slot[i];
-            long g = ceil_div(work2, 256);
+            const bool v8 = wd % 8 == 0 && (((uintptr_t)a2.x) & 15) == 0 && (((uintptr_t)a2.o) & 7) == 0 &&
+                            (p.plane_elems % 4 == 0);
+            long g = ceil_div(v8 ? work2 / 2 : work2, 256);
             if (g > (long)rt->num_cu * 32) g = (long)rt->num_cu * 32;
-            hipLaunchKernelGGL(conv_phase_split_2x2, dim3((unsigned)g), dim3(256), 0, rt->stream, a2);
+            if (v8)
+                hipLaunchKernelGGL(conv_phase_split_2x2_v8, dim3((unsigned)g), dim3(256), 0, rt->stream, a2);
+            else
+                hipLaunchKernelGGL(conv_phase_split_2x2, dim3((unsigned)g), dim3(256), 0, rt->stream, a2);
         } else {
             long g = ceil_div(p.plane_elems * ps.nslots, 256);
             if (g > (long)rt->num_cu * 32) g = (long)rt->num_cu * 32;
