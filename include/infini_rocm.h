@@ -179,6 +179,11 @@ int infini_rocm_layer_norm(infiniRocmRuntime_t rt, int dtype, const void *x, con
  * (reference: src/kernels/cuda/rms_norm.cu:35-54; eps is hard-coded 1e-5 there, rms_norm.cu:46). */
 int infini_rocm_rms_norm(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, void *y,
                          int64_t outer, int64_t norm_size, float eps);
+/* y = LayerNorm / RMSNorm (rms != 0) of (a + b): the residual join in front of a transformer normalisation in one
+ * pass; the sum is rounded to the storage type first like in Add -> Norm (equal to it up to rounding ties). Arguments as layer_norm. */
+int infini_rocm_add_norm(infiniRocmRuntime_t rt, int dtype, int rms, const void *a, const void *b, const void *scale,
+                         const void *bias, void *y, int64_t outer, int64_t norm_size, int64_t scale_size,
+                         int64_t bias_size, float eps);
 
 /* Fused prefill attention  O = softmax(scale * Q K^T + mask) V  per (batch x head); f16 / bf16, head dim 64 or 128.
  * Replaces the chain MatMul(Q, K^T) -> Div/Mul(scalar) -> Add(mask) -> Softmax -> MatMul(P, V) of the reference graph

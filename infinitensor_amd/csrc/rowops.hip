@@ -52,6 +52,12 @@ __device__ inline float wave_sum(float v) {
     return v;
 }
 
+// One expression for every normalisation kernel (explicit, non-contractable steps), so that the fused Add -> Norm
+// kernel and the stand-alone kernels round identically.
+__device__ inline float norm_apply(float x, float mu, float rstd, float g, float b) {
+    return fmaf(__fmul_rn(__fsub_rn(x, mu), rstd), g, b);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Contiguous rows (inner == 1). One wave handles ROWS rows; a row is CHUNKS 16-byte chunks per lane,
 // kept PACKED in registers (storage dtype) and converted on the fly in every pass: for 16-bit types
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(256) void norm_wave_kernel(const T *__restrict__ x,
                 for (int j = 0; j < VEC; ++j) {
                     const int col = (c * 64 + lane) * VEC + j;
                     const float d = (col < n) ? Elem<T>::ld(&cur[r].c[c].v[j]) - mu : 0.f;
-                    q += d * d;
+                    q = fmaf(d, d, q);
                 }
             const float rstd = 1.0f / sqrtf(wave_sum(q) / fn + eps);
 #pragma unroll
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(256) void norm_wave_kernel(const T *__restrict__ x,
                 for (int j = 0; j < VEC; ++j) {
                     const float gg = sc_vec ? Elem<T>::ld(&sc.c[c].v[j]) : s0;
                     const float bb = bs_vec ? Elem<T>::ld(&bs.c[c].v[j]) : b0;
-                    Elem<T>::st(&cur[r].c[c].v[j], (Elem<T>::ld(&cur[r].c[c].v[j]) - mu) * rstd * gg + bb);
+                    Elem<T>::st(&cur[r].c[c].v[j], norm_apply(Elem<T>::ld(&cur[r].c[c].v[j]), mu, rstd, gg, bb));
                 }
             const long row = g * ROWS + r;
             if (row < rows)
@@ -345,7 +351,7 @@ __global__ __launch_bounds__(256) void norm_block_kernel(const T *__restrict__ x
         float q = 0.f;
         for (long i = t; i < n; i += 256) {
             const float d = Elem<T>::ld(xr + i) - mu;
-            q += d * d;
+            q = fmaf(d, d, q);
         }
         q = wave_sum(q);
         if (lane == 0)
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(256) void norm_block_kernel(const T *__restrict__ x
         for (long i = t; i < n; i += 256) {
             const float s = Elem<T>::ld(scale + (scale_size == 1 ? 0 : i));
             const float b = bias ? Elem<T>::ld(bias + (bias_size == 1 ? 0 : i)) : 0.f;
-            Elem<T>::st(yr + i, (Elem<T>::ld(xr + i) - mu) * rstd * s + b);
+            Elem<T>::st(yr + i, norm_apply(Elem<T>::ld(xr + i), mu, rstd, s, b));
         }
     }
 }
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(256) void norm_blockreg_kernel(const T *__restrict_
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     const float d = Elem<T>::ld(&c[i].v[j]) - mu;
-                    q += d * d;
+                    q = fmaf(d, d, q);
                 }
             }
         const float rstd = 1.0f / sqrtf(block_sum(q, red, lane, w) / (float)n + eps);
@@ -438,7 +444,7 @@ __global__ __launch_bounds__(256) void norm_blockreg_kernel(const T *__restrict_
                 for (int j = 0; j < VEC; ++j) {
                     const float sv = scale_size == 1 ? Elem<T>::ld(scale) : Elem<T>::ld(&sc.v[j]);
                     const float bv = bias ? (bias_size == 1 ? Elem<T>::ld(bias) : Elem<T>::ld(&bi.v[j])) : 0.f;
-                    Elem<T>::st(&o.v[j], (Elem<T>::ld(&c[i].v[j]) - mu) * rstd * sv + bv);
+                    Elem<T>::st(&o.v[j], norm_apply(Elem<T>::ld(&c[i].v[j]), mu, rstd, sv, bv));
                 }
                 *reinterpret_cast<P *>(yr + base) = o;
             }
@@ -492,6 +498,68 @@ __global__ __launch_bounds__(256) void softmax_blockreg_kernel(const T *__restri
                 *reinterpret_cast<P *>(yr + base) = o;
             }
         }
+    }
+}
+
+// Add -> LayerNorm / RMSNorm in one pass (the residual join in front of every transformer normalisation):
+// y = norm(round_T(a + b)). The sum is rounded to the storage type before the statistics, exactly like the unfused
+// Add -> Norm chain, so the result equals it up to fp32 rounding ties of the final store. One wave per row, rows of up to 64 * VEC * CHUNKS elements,
+// 16-byte loads of both operands, grid-stride over rows.
+template <typename T, int CHUNKS, bool RMS>
+__global__ __launch_bounds__(256) void add_norm_wave_kernel(const T *__restrict__ a, const T *__restrict__ b,
+                                                            const T *__restrict__ scale, const T *__restrict__ bias,
+                                                            T *__restrict__ y, long rows, int n, int scale_size,
+                                                            int bias_size, float eps) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int lane = threadIdx.x & 63;
+    const float fn = (float)n;
+    for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
+        RowRegs<T, CHUNKS> ra, rb;
+        load_row<T, CHUNKS, true>(a + row * n, n, lane, ra, 0.f);
+        load_row<T, CHUNKS, true>(b + row * n, n, lane, rb, 0.f);
+#pragma unroll
+        for (int c = 0; c < CHUNKS; ++c)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                Elem<T>::st(&ra.c[c].v[j], Elem<T>::ld(&ra.c[c].v[j]) + Elem<T>::ld(&rb.c[c].v[j]));
+        float mu = 0.f;
+        if (!RMS) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < CHUNKS; ++c)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+                    s += Elem<T>::ld(&ra.c[c].v[j]);
+            mu = wave_sum(s) / fn;
+        }
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < CHUNKS; ++c)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const int col = (c * 64 + lane) * VEC + j;
+                const float d = (col < n) ? Elem<T>::ld(&ra.c[c].v[j]) - mu : 0.f;
+                q = fmaf(d, d, q);
+            }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / fn + eps);
+#pragma unroll
+        for (int c = 0; c < CHUNKS; ++c) {
+            const int base = (c * 64 + lane) * VEC;
+            if (base < n) {
+                Pack<T, VEC> sc, bs;
+                if (scale_size != 1)
+                    sc = *reinterpret_cast<const Pack<T, VEC> *>(scale + base);
+                if (bias && bias_size != 1)
+                    bs = *reinterpret_cast<const Pack<T, VEC> *>(bias + base);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float gg = scale_size == 1 ? Elem<T>::ld(scale) : Elem<T>::ld(&sc.v[j]);
+                    const float bb = bias ? (bias_size == 1 ? Elem<T>::ld(bias) : Elem<T>::ld(&bs.v[j])) : 0.f;
+                    Elem<T>::st(&ra.c[c].v[j], norm_apply(Elem<T>::ld(&ra.c[c].v[j]), mu, rstd, gg, bb));
+                }
+            }
+        }
+        store_row<T, CHUNKS, true>(y + row * n, n, lane, ra);
     }
 }
 
@@ -607,6 +675,28 @@ static int norm_dispatch(infiniRocmRuntime_t rt, const T *x, const T *scale, con
     return INFINI_ROCM_OK;
 }
 
+// Returns INFINI_ROCM_UNSUPPORTED (without setting an error) when the shape is outside the fused kernel's reach.
+template <typename T, bool RMS>
+static int add_norm_dispatch(infiniRocmRuntime_t rt, const T *a, const T *b, const T *scale, const T *bias, T *y,
+                             int64_t outer, int64_t n, int64_t scale_size, int64_t bias_size, float eps) {
+    constexpr int VEC = Elem<T>::VEC;
+    const bool al = is_aligned16(a) && is_aligned16(b) && is_aligned16(y) && is_aligned16(scale) &&
+                    (bias == nullptr || is_aligned16(bias)) && (n % VEC == 0);
+    const int chunks = (int)ceil_div(n, (int64_t)64 * VEC);
+    if (!al || chunks > 4)
+        return INFINI_ROCM_UNSUPPORTED;
+    const unsigned g = pgrid(ceil_div(outer, 4), rt->num_cu);
+#define AN(C)                                                                                                  \
+    hipLaunchKernelGGL((add_norm_wave_kernel<T, C, RMS>), dim3(g), dim3(256), 0, rt->stream, a, b, scale, bias, y, \
+                       (long)outer, (int)n, (int)scale_size, (int)bias_size, eps)
+    if (chunks <= 1) AN(1);
+    else if (chunks <= 2) AN(2);
+    else AN(4);
+#undef AN
+    IROCM_LAUNCH_CHECK("add_norm");
+    return INFINI_ROCM_OK;
+}
+
 } // namespace irocm
 
 using namespace irocm;
@@ -665,6 +755,40 @@ int infini_rocm_layer_norm(infiniRocmRuntime_t rt, int dtype, const void *x, con
     default:
         IROCM_FAIL(INFINI_ROCM_UNSUPPORTED, "layer_norm: unsupported dtype %s", dtype_name(dtype));
     }
+}
+
+int infini_rocm_add_norm(infiniRocmRuntime_t rt, int dtype, int rms, const void *a, const void *b, const void *scale,
+                         const void *bias, void *y, int64_t outer, int64_t norm_size, int64_t scale_size,
+                         int64_t bias_size, float eps) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(outer >= 0 && norm_size >= 0 && norm_size < (1ll << 31), "add_norm: bad extent");
+    if (outer == 0 || norm_size == 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(a && b && y && scale, "add_norm: NULL tensor");
+    IROCM_CHECK_ARG(scale_size == 1 || scale_size == norm_size, "add_norm: bad scale size");
+    IROCM_CHECK_ARG(bias == nullptr || bias_size == 1 || bias_size == norm_size, "add_norm: bad bias size");
+    int st = INFINI_ROCM_UNSUPPORTED;
+#define GO(T)                                                                                                   \
+    st = rms ? add_norm_dispatch<T, true>(rt, (const T *)a, (const T *)b, (const T *)scale, (const T *)bias, (T *)y, \
+                                          outer, norm_size, scale_size, bias_size, eps)                        \
+             : add_norm_dispatch<T, false>(rt, (const T *)a, (const T *)b, (const T *)scale, (const T *)bias, (T *)y, \
+                                           outer, norm_size, scale_size, bias_size, eps)
+    switch (dtype) {
+    case INFINI_DT_F32: GO(float); break;
+    case INFINI_DT_F16: GO(__half); break;
+    case INFINI_DT_BF16: GO(__hip_bfloat16); break;
+    default: IROCM_FAIL(INFINI_ROCM_UNSUPPORTED, "add_norm: unsupported dtype %s", dtype_name(dtype));
+    }
+#undef GO
+    if (st != INFINI_ROCM_UNSUPPORTED)
+        return st;
+    // outside the fused kernel's reach (long or unaligned rows): the two-kernel chain, in place over y
+    const int64_t shape[2] = {outer, norm_size}, str[2] = {norm_size, 1};
+    st = infini_rocm_binary(rt, INFINI_BIN_ADD, dtype, a, b, y, 2, shape, str, str);
+    if (st != INFINI_ROCM_OK)
+        return st;
+    return rms ? infini_rocm_rms_norm(rt, dtype, y, scale, y, outer, norm_size, eps)
+               : infini_rocm_layer_norm(rt, dtype, y, scale, bias, y, outer, norm_size, scale_size, bias_size, eps);
 }
 
 int infini_rocm_rms_norm(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, void *y,

@@ -251,6 +251,19 @@ def attention_kvcache(rt: RocmRuntime, k_cache: torch.Tensor, v_cache: torch.Ten
     return out
 
 
+def add_layer_norm(rt: RocmRuntime, a: torch.Tensor, b: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor | None,
+                   eps: float, rms: bool = False, out: torch.Tensor | None = None) -> torch.Tensor:
+    """LayerNorm (or RMSNorm) over the last dim of a + b in one pass (the sum is rounded like the chain's)."""
+    if a.shape != b.shape or a.dtype != b.dtype:
+        raise ValueError("add_layer_norm: operands must match")
+    n = a.shape[-1]
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib().infini_rocm_add_norm(rt.handle, dtype_of(a), int(rms), _ptr(a), _ptr(b), _ptr(scale), _ptr(bias), _ptr(out),
+                                     a.numel() // n, n, scale.numel(), bias.numel() if bias is not None else 0, float(eps)))
+    return out
+
+
 def rope(rt: RocmRuntime, pos: torch.Tensor, x: torch.Tensor, dim_head: int = 128, theta: float = 10000.0,
          out: torch.Tensor | None = None) -> torch.Tensor:
     """RoPE(pos [B, S], x [B, S, dim_model]) (operators/rope.h; dim_head 128 / theta 1e4 as rope.cc:25)."""

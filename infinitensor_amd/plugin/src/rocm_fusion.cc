@@ -7,6 +7,7 @@
 //   Conv -> Add(bias) -> Add(identity) [-> Relu]                   =>  conv2d_res(bias, residual, act)   [opt-in:
 //        INFINI_ROCM_FUSE_RES=1; measured 1 % slower than conv + ADD_RELU on ResNet-50]
 //   Add  -> Relu                                                   =>  binary(ADD_RELU)         (residual join)
+//   Add  -> LayerNormalization(last axis) | RMSNorm                =>  add_norm                 (transformer residual)
 //   Add(bias) -> Add(identity) [-> Relu]                           =>  bias_residual            (when the conv could not
 //        take the bias: its input's storage was recycled for the output)
 //   MatMul(Q, K^T) [-> Div|Mul(scalar)] [-> Add(mask)] -> Softmax(last axis) -> MatMul(P, V)
@@ -27,6 +28,8 @@
 #include <cstdlib>
 #include <string>
 #include "operators/element_wise.h"
+#include "operators/layer_norm.h"
+#include "operators/rms_norm.h"
 #include "operators/matmul.h"
 #include "operators/softmax.h"
 #include "operators/unary.h"
@@ -223,6 +226,38 @@ size_t RocmRuntimeObj::tryLaunchFused(const OpVec &ops, size_t i) const {
             return c.used;
         }
         return 0;
+    }
+    // Add(a, b) (same extents) -> LayerNormalization over the last axis / RMSNorm: one pass
+    if (type == OpType::Add && i + 1 < ops.size() && soleConsumerIs(op->getOutput(), ops[i + 1]) &&
+        (ops[i + 1]->getOpType() == OpType::LayerNormalization || ops[i + 1]->getOpType() == OpType::RMSNorm)) {
+        const Operator &nrm = ops[i + 1];
+        const Tensor a = op->getInputs(0), b = op->getInputs(1), t = op->getOutput(), out = nrm->getOutput();
+        const auto &td = t->getDims();
+        const bool rms = nrm->getOpType() == OpType::RMSNorm;
+        bool ok = a->getDims() == td && b->getDims() == td && a->getDType() == b->getDType() && nrm->getInputs(0) == t;
+        float eps = 1e-5f; // RMSNorm: hard-coded in the reference (rms_norm.cu:46)
+        Tensor scale = nrm->getInputs(1), bias = nullptr;
+        if (ok && !rms) {
+            auto ln = as<LayerNormObj>(nrm);
+            ok = ln->getAxis() == (int)td.size() - 1;
+            eps = ln->getEps();
+            if (ln->numInputs() == 3)
+                bias = ln->getInputs(2);
+        }
+        if (ok) {
+            auto hazard = [&](const Tensor &u) { // row-wise in place over an operand of identical extent is safe
+                const bool inPlace = u->getRawDataPtr<void *>() == out->getRawDataPtr<void *>() && u->getDims() == td;
+                return overlaps(out, u) && !inPlace;
+            };
+            if (!hazard(a) && !hazard(b) && !overlaps(out, scale) && !(bias && overlaps(out, bias))) {
+                const int64_t n = td.back(), outer = (int64_t)t->size() / n;
+                ROCM_CALL(infini_rocm_add_norm(rt, t->getDTypeIndex(), rms ? 1 : 0, a->getRawDataPtr<void *>(),
+                                               b->getRawDataPtr<void *>(), scale->getRawDataPtr<void *>(),
+                                               bias ? bias->getRawDataPtr<void *>() : nullptr, out->getRawDataPtr<void *>(),
+                                               outer, n, (int64_t)scale->size(), bias ? (int64_t)bias->size() : 0, eps));
+                return 2;
+            }
+        }
     }
     // Add(x, per-channel bias) -> Add(., identity) [-> Relu]: the bottleneck tail when the bias could not ride in the conv
     if (type == OpType::Add && i + 1 < ops.size() && ops[i + 1]->getOpType() == OpType::Add &&

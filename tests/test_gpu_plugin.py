@@ -452,3 +452,28 @@ def test_conv_transpose_through_reference_executor(B, rocm):
                    [((1, 2, 3, 3), F32, R.incremental((1, 2, 3, 3))), ((2, 2, 3, 3), F32, R.incremental((2, 2, 3, 3)))])
     h.run()
     assert R.equal_data(get(out).ravel(), kat(CU + "test_cuda_conv_transposed_2d.cc", 129, "float"), 1e-6)
+
+
+def test_add_layernorm_fusion(B, rocm):
+    """Add -> LayerNormalization (BERT's residual join) as one launch; equal to the two-kernel chain up to rounding ties."""
+    rng = np.random.default_rng(61)
+    ins = [((4, 10, 96), F16, rng.standard_normal((4, 10, 96)).astype(np.float16)),
+           ((4, 10, 96), F16, rng.standard_normal((4, 10, 96)).astype(np.float16)),
+           ((96,), F16, rng.standard_normal((96,)).astype(np.float16)), ((96,), F16, rng.standard_normal((96,)).astype(np.float16))]
+
+    def fn(hd, t):
+        y = hd.layerNormalization(hd.add(t[0], t[1], None), t[2], None, t[3], 1e-5, 2, 1)
+        return hd.mul(y, t[0], None)  # keeps t[0] alive past the pair
+
+    got = {}
+    try:
+        for on in (True, False):
+            rocm.set_fusion(on)
+            hh, out = build(B, rocm, fn, ins)
+            before = rocm.fused_launch_count()
+            hh.run()
+            assert rocm.fused_launch_count() - before == (1 if on else 0)
+            got[on] = get(out).astype(np.float64)
+    finally:
+        rocm.set_fusion(True)
+    assert np.allclose(got[True], got[False], rtol=2.0 ** -9, atol=1e-5)

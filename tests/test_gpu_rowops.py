@@ -145,3 +145,22 @@ def test_rope_reference_kat(rt):
     x[..., :32] = 1
     y = ops.rope(rt, dev(np.array([[1]], np.int32)), dev(x), 128)
     assert R.equal_data(host(y)[0, 0, :32], kat("test/kernels/cuda/test_cuda_rope.cc", 29, "float"), 2e-6)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("shape", [(64, 768), (3, 7, 1024), (5, 33), (2, 4096), (4, 520)])
+@pytest.mark.parametrize("rms", [False, True])
+def test_add_norm_matches_the_chain(rt, shape, rms, dt):
+    """infini_rocm_add_norm vs Norm(Add(a, b)): the sum is rounded like the chain's, so the two agree except where the
+    fp32 result sits on a rounding tie of the output type (a handful of elements per 10^5, one output ulp apart)."""
+    rng = np.random.default_rng(19)
+    a, b = (dev(rng.standard_normal(shape).astype(np.float32), TD[dt]) for _ in range(2))
+    g = dev(rng.standard_normal(shape[-1:]).astype(np.float32), TD[dt])
+    be = None if rms else dev(rng.standard_normal(shape[-1:]).astype(np.float32), TD[dt])
+    fused = ops.add_layer_norm(rt, a, b, g, be, 1e-5, rms)
+    s = ops.binary(rt, "add", a, b)
+    chain = ops.rms_norm(rt, s, g, 1e-5) if rms else ops.layer_norm(rt, s, g, be, 1e-5, -1)
+    ulp = {"f32": 2.0 ** -22, "f16": 2.0 ** -10, "bf16": 2.0 ** -7}[dt]
+    f, c = fused.float(), chain.float()
+    assert torch.allclose(f, c, rtol=ulp, atol=ulp * 1e-2)
+    assert (f != c).float().mean().item() < 1e-3
