@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     }
     constexpr float LOG2E = 1.4426950408889634f;
     const float c = scale * LOG2E;
+    const bool mask_vec = MASK && (p.sk % 4 == 0) && ((((uintptr_t)p.mask) & 7) == 0);
 
     // Q fragments (B operand: lane = query column l15, 8 consecutive d)
     s16x8_t qf[NT][KS];
@@ -153,12 +154,24 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
         // additive term per key (mask * log2 e, -inf past Sk): only when there is a mask or this is the ragged last tile
         const bool ragged = kbase + KT > p.sk; // wave-uniform
         if constexpr (MASK) {
+            const bool mvec = !ragged && mask_vec; // 4 consecutive keys = one 8-byte load
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const int key = kbase + mt * 16 + 4 * g4;
+                unsigned short mh[4] = {0, 0, 0, 0};
+                if (mvec) {
+                    const u32x2_t mk = *(const u32x2_t *)(M + key);
+                    mh[0] = (unsigned short)(mk[0] & 0xffff); mh[1] = (unsigned short)(mk[0] >> 16);
+                    mh[2] = (unsigned short)(mk[1] & 0xffff); mh[3] = (unsigned short)(mk[1] >> 16);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (key + r < p.sk)
+                            mh[r] = M[key + r];
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float mv = key + r < p.sk ? Tr::to_f32(M[key + r]) * LOG2E : -INFINITY;
+                    const float mv = key + r < p.sk ? Tr::to_f32(mh[r]) * LOG2E : -INFINITY;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
                         s[mt][nt][r] = fmaf(s[mt][nt][r], c, mv);
