@@ -338,6 +338,11 @@ int infini_rocm_batch_norm(infiniRocmRuntime_t rt, int dtype, const void *x, con
 int infini_rocm_pool2d(infiniRocmRuntime_t rt, int kind, int dtype, const void *x, void *y, int64_t n,
                        int64_t c, int64_t h, int64_t w, int kh, int kw, int dh, int dw, int ph, int pw,
                        int sh, int sw, int ceil_mode);
+/* max pooling of relu(x) (relu != 0; kind must be 0): Relu -> MaxPool in one pass — max and relu commute, so the result
+ * is bit-identical to the chain. relu == 0: plain pool2d. */
+int infini_rocm_pool2d_relu(infiniRocmRuntime_t rt, int kind, int dtype, const void *x, void *y, int64_t n,
+                            int64_t c, int64_t h, int64_t w, int kh, int kw, int dh, int dw, int ph, int pw,
+                            int sh, int sw, int ceil_mode, int relu);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Data movement / indexing: bit-exact for every dtype (raw 1/2/4/8-byte elements).            */

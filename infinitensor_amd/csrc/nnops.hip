@@ -195,6 +195,7 @@ __global__ __launch_bounds__(256) void batch_norm_kernel(const T *__restrict__ x
 struct PoolArgs {
     long n, c, h, w, oh, ow;
     int kh, kw, dh, dw, ph, pw, sh, sw;
+    int relu; // max pool of relu(x) == relu of the max pool: the preceding Relu folded in
 };
 
 // IDX = int when every index fits 31 bits (64-bit div/mod per output is most of the cost of this kernel otherwise)
@@ -221,6 +222,8 @@ __global__ __launch_bounds__(256) void pool2d_kernel(const T *__restrict__ x, T 
             }
         }
         // AveragePool counts padding (reference pooling.cc:86-90: COUNT_INCLUDE_PADDING)
+        if (MAX && p.relu)
+            acc = fmaxf(acc, 0.f);
         LdSt<T>::st(y + i, MAX ? acc : acc / (float)(p.kh * p.kw));
     }
 }
@@ -230,14 +233,15 @@ __global__ __launch_bounds__(256) void pool2d_kernel(const T *__restrict__ x, T 
 // kernel issues 9 two-byte loads per output and ran this 256 MB layer at 1.4 TB/s.
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T *__restrict__ x, T *__restrict__ y, int planes, int h,
-                                                           int w, int oh, int ow) {
+                                                           int w, int oh, int ow, int relu) {
     const int quads = ow / 4;
     const int total = planes * oh * quads;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int jq = i % quads;
         const int q = i / quads;
         const int oy = q % oh, pl = q / oh;
-        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        const float m0 = relu ? 0.f : -INFINITY;
+        float m[4] = {m0, m0, m0, m0};
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int iy = 2 * oy - 1 + r;
@@ -334,6 +338,13 @@ int infini_rocm_batch_norm(infiniRocmRuntime_t rt, int dtype, const void *x, con
 int infini_rocm_pool2d(infiniRocmRuntime_t rt, int kind, int dtype, const void *x, void *y, int64_t n,
                        int64_t c, int64_t h, int64_t w, int kh, int kw, int dh, int dw, int ph, int pw,
                        int sh, int sw, int ceil_mode) {
+    return infini_rocm_pool2d_relu(rt, kind, dtype, x, y, n, c, h, w, kh, kw, dh, dw, ph, pw, sh, sw, ceil_mode, 0);
+}
+
+int infini_rocm_pool2d_relu(infiniRocmRuntime_t rt, int kind, int dtype, const void *x, void *y, int64_t n,
+                            int64_t c, int64_t h, int64_t w, int kh, int kw, int dh, int dw, int ph, int pw,
+                            int sh, int sw, int ceil_mode, int relu) {
+    IROCM_CHECK_ARG(!relu || kind == 0, "pool2d: the fused Relu needs max pooling");
     IROCM_CHECK_ARG(rt, "NULL runtime");
     IROCM_CHECK_ARG(kind == 0 || kind == 1, "pool2d: kind must be 0 (max) or 1 (average)");
     IROCM_CHECK_ARG(n >= 0 && c >= 0 && h >= 0 && w >= 0, "pool2d: negative extent");
@@ -349,6 +360,7 @@ int infini_rocm_pool2d(infiniRocmRuntime_t rt, int kind, int dtype, const void *
     p.oh = osz(h, kh, dh, ph, sh);
     p.ow = osz(w, kw, dw, pw, sw);
     p.kh = kh; p.kw = kw; p.dh = dh; p.dw = dw; p.ph = ph; p.pw = pw; p.sh = sh; p.sw = sw;
+    p.relu = relu;
     const long total = n * c * p.oh * p.ow;
     if (total <= 0)
         return INFINI_ROCM_OK;
@@ -367,10 +379,10 @@ int infini_rocm_pool2d(infiniRocmRuntime_t rt, int kind, int dtype, const void *
         if (g3 > (long)rt->num_cu * 16) g3 = (long)rt->num_cu * 16;
         if (dtype == INFINI_DT_F16)
             hipLaunchKernelGGL(maxpool3x3s2_kernel<__half>, dim3((unsigned)g3), dim3(256), 0, rt->stream, (const __half *)x,
-                               (__half *)y, (int)(n * c), (int)h, (int)w, (int)p.oh, (int)p.ow);
+                               (__half *)y, (int)(n * c), (int)h, (int)w, (int)p.oh, (int)p.ow, relu);
         else
             hipLaunchKernelGGL(maxpool3x3s2_kernel<__hip_bfloat16>, dim3((unsigned)g3), dim3(256), 0, rt->stream,
-                               (const __hip_bfloat16 *)x, (__hip_bfloat16 *)y, (int)(n * c), (int)h, (int)w, (int)p.oh, (int)p.ow);
+                               (const __hip_bfloat16 *)x, (__hip_bfloat16 *)y, (int)(n * c), (int)h, (int)w, (int)p.oh, (int)p.ow, relu);
         IROCM_LAUNCH_CHECK("maxpool3x3s2");
         return INFINI_ROCM_OK;
     }

@@ -7,6 +7,7 @@
 //   Conv -> Add(bias) -> Add(identity) [-> Relu]                   =>  conv2d_res(bias, residual, act)   [opt-in:
 //        INFINI_ROCM_FUSE_RES=1; measured 1 % slower than conv + ADD_RELU on ResNet-50]
 //   Add  -> Relu                                                   =>  binary(ADD_RELU)         (residual join)
+//   Relu -> MaxPool                                                =>  pool2d_relu              (ResNet stem)
 //   Add  -> LayerNormalization(last axis) | RMSNorm                =>  add_norm                 (transformer residual)
 //   Add(bias) -> Add(identity) [-> Relu]                           =>  bias_residual            (when the conv could not
 //        take the bias: its input's storage was recycled for the output)
@@ -31,6 +32,7 @@
 #include "operators/layer_norm.h"
 #include "operators/rms_norm.h"
 #include "operators/matmul.h"
+#include "operators/pooling.h"
 #include "operators/softmax.h"
 #include "operators/unary.h"
 #include "rocm/rocm_runtime.h"
@@ -226,6 +228,19 @@ size_t RocmRuntimeObj::tryLaunchFused(const OpVec &ops, size_t i) const {
             return c.used;
         }
         return 0;
+    }
+    // Relu -> MaxPool: max and relu commute (bit-identical); the stem of every ResNet
+    if (type == OpType::Relu && i + 1 < ops.size() && ops[i + 1]->getOpType() == OpType::MaxPool &&
+        soleConsumerIs(op->getOutput(), ops[i + 1])) {
+        auto pool = as<PoolingObj>(ops[i + 1]);
+        const Tensor x = op->getInputs(0), out = pool->getOutput();
+        if (!overlaps(out, x)) {
+            const auto [n, c, h, w, kh, kw] = pool->getNCHWRS();
+            const auto [ph, pw, sh, sw, dh, dw] = pool->getPadStrideDilation();
+            ROCM_CALL(infini_rocm_pool2d_relu(rt, 0, x->getDTypeIndex(), x->getRawDataPtr<void *>(), out->getRawDataPtr<void *>(),
+                                              n, c, h, w, kh, kw, dh, dw, ph, pw, sh, sw, pool->getCeilMode(), 1));
+            return 2;
+        }
     }
     // Add(a, b) (same extents) -> LayerNormalization over the last axis / RMSNorm: one pass
     if (type == OpType::Add && i + 1 < ops.size() && soleConsumerIs(op->getOutput(), ops[i + 1]) &&

@@ -477,3 +477,31 @@ def test_add_layernorm_fusion(B, rocm):
     finally:
         rocm.set_fusion(True)
     assert np.allclose(got[True], got[False], rtol=2.0 ** -9, atol=1e-5)
+
+
+def test_relu_maxpool_fusion_is_bit_exact(B, rocm):
+    """Relu -> MaxPool (ResNet stem) as one launch; max and relu commute, so fused == unfused bit for bit
+    (both the specialised 3x3/2 kernel and the generic one). The input stays live (second consumer), otherwise the
+    planner puts the pool output on top of it and the rule must not fire."""
+    rng = np.random.default_rng(71)
+    for shape, k, pad, st in (((2, 8, 16, 16), 3, 1, 2), ((1, 3, 9, 7), 2, 0, 1)):
+        x = rng.standard_normal(shape).astype(np.float16)
+        got = {}
+
+        def fn(hd, t):
+            y = hd.maxPool(hd.relu(t[0], None), None, k, k, 1, 1, pad, pad, st, st, 0)
+            return [y, hd.neg(t[0], None)]
+
+        try:
+            for on in (True, False):
+                rocm.set_fusion(on)
+                hh, outs = build(B, rocm, fn, [(shape, F16, x)])
+                before = rocm.fused_launch_count()
+                hh.run()
+                assert rocm.fused_launch_count() - before == (1 if on else 0)
+                got[on] = get(outs[0])
+        finally:
+            rocm.set_fusion(True)
+        assert np.array_equal(got[True], got[False])
+        want = R.pool2d(np.maximum(x.astype(np.float64), 0), "max", k, k, 1, 1, pad, pad, st, st, 0)
+        assert np.array_equal(got[True].reshape(want.shape).astype(np.float64), want)
