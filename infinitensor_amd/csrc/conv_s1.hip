@@ -588,7 +588,7 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
         }
     const bool split = sh * sw > 1;
     const long x_bytes = p.plane_elems * 2 * (split ? ps.nslots : 1);
-    if (x_bytes >= (1l << 31) - 64)
+    if (x_bytes >= (1l << 31) - 64 || x_bytes < 64) // 32-bit buffer offsets; `x_bytes - 16` must not wrap
         return -1;
     p.x_bytes = (unsigned)x_bytes;
     // workspace: [ re-packed weights | phase planes ]

@@ -87,6 +87,8 @@ S1_CONVS = [
     (2, 48, 9, 9, 20, 3, 3),                  # 48 channels
     (2, 5, 11, 7, 70, 3, 5, 2, 1, 1, 1),      # 5 channels, 70 filters (two filter tiles), stride 2 x 1
     (3, 1, 6, 6, 8, 1, 1),                    # K = 1
+    (1, 1, 2, 2, 4, 3, 3),                    # 8-byte input: falls back to the generic kernel
+    (1, 2, 3, 5, 4, 3, 3),                    # 60-byte input
 ]
 
 
