@@ -236,6 +236,25 @@ __global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void conv_s1_kernel(ConvS1
         b_lds[i] = kr * ROWB + ((cchunk ^ (f128::mn_f(kr) << 1)) * 16);
     }
 
+    // ROWTAP: k -> (offset, tap selectors), once per workgroup instead of four integer divisions per row and K-step
+    int2 *ktab = reinterpret_cast<int2 *>(smem + 2 * STAGE);
+    if constexpr (ROWTAP) {
+        for (int k = t; k < p.kpad; k += 256) {
+            int2 e = {0, 0}; // bit 16 of y = valid
+            if (k < p.kdim) {
+                const int tp = k / p.c, cc = k - tp * p.c;
+                const int r_ = tp / p.s, s_ = tp - r_ * p.s;
+                const int dy = r_ * p.dh - p.ph, dx = s_ * p.dw - p.pw;
+                const int qy = dy >= 0 ? dy / p.sh : -((p.sh - 1 - dy) / p.sh), py = dy - qy * p.sh;
+                const int qx = dx >= 0 ? dx / p.sw : -((p.sw - 1 - dx) / p.sw), px = dx - qx * p.sw;
+                e.x = (int)((((long)p.slot[py * p.sw + px] * p.plane_elems + qy * p.wd + qx) + (long)cc * p.hw) * 2);
+                e.y = (8 * r_) | ((8 * s_) << 8) | (1 << 16);
+            }
+            ktab[k] = e;
+        }
+        __syncthreads();
+    }
+
     s16x8_t a_reg[NA];
     u32x4_t b_reg[NB];
     unsigned bm[4];        // and-masks of the runs held in b_reg (one tap per K-step)
@@ -297,13 +316,12 @@ __global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void conv_s1_kernel(ConvS1
                 a_reg[i] = *(const s16x8_t *)(wsrc + a_off[i]);
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
+                // per-k table (built once per workgroup): byte offset of (channel, tap) and the tap's row / column
+                // selectors (8 * r, 8 * s, bit 16 = k exists)
                 const int k = kl * BK + krow0 + i * KSTEP;
-                const bool in_k = k < p.kdim;
-                const int kk = in_k ? k : 0;
-                const int tp = kk / p.c, cc = kk - tp * p.c;
-                const int r_ = tp / p.s, s_ = tp - r_ * p.s;
-                const unsigned m8 = in_k ? (unsigned)((rowm >> (8 * r_)) & (colm >> (8 * s_)) & 0xff) : 0u;
-                const int voff = b_base + cc * p.hw * 2 + shift_of(r_, s_);
+                const int2 e = ktab[k];
+                const unsigned m8 = (unsigned)((rowm >> (e.y & 0xff)) & (colm >> ((e.y >> 8) & 0xff)) & 0xff) & ((e.y >> 16) ? 0xffu : 0u);
+                const int voff = b_base + e.x;
                 m8row[i] = m8;
                 if constexpr (SAFE) b_reg[i] = fetch_run(voff, m8 != 0);
                 else b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, 0, 0);
@@ -541,10 +559,11 @@ static int launch_s1(infiniRocmRuntime_t rt, ConvS1Args &p) {
     auto kern = conv_s1_kernel<Tr, WM, WN, BK, ROWTAP>;
     static bool attr_done = false;
     if (!attr_done) {
-        IROCM_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        IROCM_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + (ROWTAP ? 16384 : 0)));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), LDS, rt->stream, p);
+    const int lds = LDS + (ROWTAP ? p.kpad * 8 : 0); // + the per-k table
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, rt->stream, p);
     IROCM_LAUNCH_CHECK("conv_s1");
     return INFINI_ROCM_OK;
 }
@@ -556,6 +575,8 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
     if (r > 7 || s > 7 || ((uintptr_t)w & 15) != 0 || ((uintptr_t)x & 3) != 0)
         return -1;
     const bool rowtap = c % 32 != 0;
+    if (rowtap && (((long)c * r * s + 31) & ~31l) > 2048)
+        return -1; // the per-k LDS table holds 2048 entries
     if (sh * sw > 16 || oh != (h + sh - 1) / sh || ow != (wd + sw - 1) / sw)
         return -1;
     ConvS1Args p;
