@@ -70,7 +70,9 @@ class Builder:
             t.copyin_numpy(np.ascontiguousarray(a))
 
 
-def build_resnet50(bl: Builder, batch: int, image: int = 224):
+def build_resnet50(bl: Builder, batch: int, image: int = 224, fc_bias_as_add: bool = False):
+    """fc_bias_as_add: emit the classifier as MatMul + Add (the reference's native-CPU MatMul has no bias input), so the
+    same graph also runs on `backend.cpu_runtime()` for end-to-end parity (tests/test_gpu_models.py)."""
     h = bl.h
 
     def conv_bn_act(x, cin, cout, k, stride, pad, relu=True, hw=None):
@@ -102,7 +104,10 @@ def build_resnet50(bl: Builder, batch: int, image: int = 224):
     y = h.flatten(y, None, 1)
     wfc = bl.weight((2048, 1000), np.sqrt(1.0 / 2048))
     bfc = bl.weight((1000,), 0.01)
-    y = h.matmul(y, wfc, None, False, False, bfc, bl.B.ActType.Linear, "default")
+    if fc_bias_as_add:
+        y = h.add(h.matmul(y, wfc, None, False, False, None, bl.B.ActType.Linear, "default"), bfc, None)
+    else:
+        y = h.matmul(y, wfc, None, False, False, bfc, bl.B.ActType.Linear, "default")
     bl.flops += 2.0 * batch * 2048 * 1000
     return y
 
