@@ -157,6 +157,14 @@ def extras(rt, ops, Event) -> dict:
         gbs = 2 * x.numel() * x.element_size() / t / 1e9
         out[f"layernorm_262144x768_{name}"] = {"GB/s": round(gbs, 1), "frac_hbm_peak": round(gbs / PEAK_HBM_GBS, 4), "us": round(t * 1e6, 2)}
         del x, y
+    # the headline GEMM in the other layouts / dtypes the reference's MatMul takes (transB = 1 is what ONNX Gemm exports)
+    n = 4096
+    for name, dt, tb in (("bf16_NT", torch.bfloat16, True), ("f16_NN", torch.float16, False), ("f16_NT", torch.float16, True)):
+        a = torch.randn(n, n, device="cuda").to(dt)
+        b = torch.randn(n, n, device="cuda").to(dt)
+        c = torch.empty(n, n, device="cuda", dtype=dt)
+        t = timeit(lambda: ops.matmul(rt, a, b, trans_b=tb, out=c), iters=30)
+        out[f"matmul_4096_{name}"] = {"TFLOP/s": round(2.0 * n ** 3 / t / 1e12, 1), "frac_mfma_peak": round(2.0 * n ** 3 / t / 1e12 / PEAK_BF16_TFLOPS, 4), "us": round(t * 1e6, 2)}
     return out
 
 
@@ -169,6 +177,7 @@ def graph_resnet50(local_rank: int, world: int, dist_mod) -> dict:
     from model_bench import run_model
 
     r = run_model("resnet50", local_rank, 128, iters=10)
+    mm = run_model("matmul", local_rank, dtype="f16", iters=50)  # one-operator graph: executor overhead per launch
     ms = torch.tensor([r["hipgraph_ms"], r["eager_ms"]], device="cuda", dtype=torch.float64)
     if world > 1:
         dist_mod.all_reduce(ms, op=dist_mod.ReduceOp.MAX)
@@ -176,16 +185,18 @@ def graph_resnet50(local_rank: int, world: int, dist_mod) -> dict:
     return {"workload": f"ResNet-50 bs128 fp16 per GPU x {world} replicas, reference executor + ROCM plugin, launch-time fusion "
                         + ("on" if r["fusion"] else "off"),
             "hipgraph_ms": round(g, 3), "eager_ms": round(e, 3), "samples_per_s": round(world * 128 / g * 1e3, 0),
-            "conv_gemm_TFLOPs_aggregate": round(world * r["gemm_conv_TFLOP"] / g * 1e3, 1), "ops": r["ops"], "finite": r["finite"]}
+            "conv_gemm_TFLOPs_aggregate": round(world * r["gemm_conv_TFLOP"] / g * 1e3, 1), "ops": r["ops"], "finite": r["finite"],
+            "matmul_4096_f16_via_executor": {"eager_ms_incl_sync": mm["eager_ms"], "hipgraph_ms_incl_sync": mm["hipgraph_ms"],
+                                             "hipgraph_TFLOPs": mm["hipgraph_TFLOPs"]}}
 
 
 def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
     """BASELINE config 5: one Llama-7B-style decoder block (H=4096, 32 heads x 128, FFN 11008), tokens
     B*S = 4*512 = 2048, fp16, Megatron tensor-parallel over `world` ranks (infinitensor_amd/tp.py, mirroring
     examples/distributed/parallel_opt.py): qkv / gate / up column-parallel, o_proj / down row-parallel, ONE
-    RCCL all-reduce (16 MiB) after each row-parallel GEMM, on the runtime stream. RoPE is not applied (no
-    kernel yet: SURVEY 8f-2); it is element-wise and does not change the GEMM / collective structure.
-    Strong scaling: the block is fixed, the weights are sharded."""
+    RCCL all-reduce (16 MiB) after each row-parallel GEMM, on the runtime stream; RoPE (csrc/rope.hip) on q and k.
+    Strong scaling: the block is fixed, the weights are sharded. After timing, the same block is run once unsharded
+    on this GPU and the max-abs difference to the sharded result is reported (exactly 0 at TP=1)."""
     import torch
 
     from infinitensor_amd import tp
@@ -197,10 +208,12 @@ def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
     g = torch.Generator(device="cuda").manual_seed(7)  # same full weights on every rank, then sharded
     rnd = lambda *shape: (torch.randn(*shape, device="cuda", generator=g) * 0.02).to(dt)
     x = rnd(T, H)
-    wq, wk, wv = (tp.shard_column(rnd(H, H), world, rank)[0].contiguous() for _ in range(3))
-    wo = tp.shard_row(rnd(H, H), world, rank).contiguous()
-    wg, wu = (tp.shard_column(rnd(H, F), world, rank)[0].contiguous() for _ in range(2))
-    wd = tp.shard_row(rnd(F, H), world, rank).contiguous()
+    full = {"q": rnd(H, H), "k": rnd(H, H), "v": rnd(H, H), "o": rnd(H, H), "g": rnd(H, F), "u": rnd(H, F), "d": rnd(F, H)}
+    wq, wk, wv = (tp.shard_column(full[n], world, rank)[0].contiguous() for n in "qkv")
+    wo = tp.shard_row(full["o"], world, rank).contiguous()
+    wg, wu = (tp.shard_column(full[n], world, rank)[0].contiguous() for n in "gu")
+    wd = tp.shard_row(full["d"], world, rank).contiguous()
+    pos = torch.arange(S, device="cuda", dtype=torch.int32).repeat(Bt, 1).contiguous()
     n1, n2 = torch.ones(H, device="cuda", dtype=dt), torch.ones(H, device="cuda", dtype=dt)
     scale = torch.full((1,), float(D) ** 0.5, device="cuda", dtype=dt)
     torch.cuda.synchronize()
@@ -215,22 +228,31 @@ def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
     else:
         rt.init_comm_with_id(rt.comm_unique_id(), 1, 0)
 
-    def heads(t):  # [T, nh*D] -> [Bt*nh, S, D]
-        return ops.transpose(rt, t.view(Bt, S, nh, D), (0, 2, 1, 3)).view(Bt * nh, S, D)
+    def run_block(w_q, w_k, w_v, w_o, w_g, w_u, w_d, heads_local, reduce):
+        def heads(t):  # [T, heads_local*D] -> [Bt*heads_local, S, D]
+            return ops.transpose(rt, t.view(Bt, S, heads_local, D), (0, 2, 1, 3)).view(Bt * heads_local, S, D)
 
-    def block():
+        def rope(t):  # rotary embedding per head (head dim 128, theta 1e4: rope.cc:25)
+            return ops.rope(rt, pos, t.view(Bt, S, heads_local * D), D).view(T, heads_local * D)
+
         h = ops.rms_norm(rt, x, n1, 1e-5)
-        q, k, v = heads(ops.matmul(rt, h, wq)), heads(ops.matmul(rt, h, wk)), heads(ops.matmul(rt, h, wv))
+        q, k = heads(rope(ops.matmul(rt, h, w_q))), heads(rope(ops.matmul(rt, h, w_k)))
+        v = heads(ops.matmul(rt, h, w_v))
         ctx = ops.attention(rt, q, k, v, scale, scale_is_div=True)  # fused prefill attention (csrc/attention.hip)
-        ctx = ops.transpose(rt, ctx.view(Bt, nh, S, D), (0, 2, 1, 3)).view(T, nh * D)
-        o = ops.matmul(rt, ctx, wo)
-        ops.all_reduce(rt, "sum", o, out=o)
+        ctx = ops.transpose(rt, ctx.view(Bt, heads_local, S, D), (0, 2, 1, 3)).view(T, heads_local * D)
+        o = ops.matmul(rt, ctx, w_o)
+        if reduce:
+            ops.all_reduce(rt, "sum", o, out=o)
         x1 = ops.binary(rt, "add", x, o)
         h2 = ops.rms_norm(rt, x1, n2, 1e-5)
-        a = ops.binary(rt, "mul", ops.unary(rt, "silu", ops.matmul(rt, h2, wg)), ops.matmul(rt, h2, wu))
-        d = ops.matmul(rt, a, wd)
-        ops.all_reduce(rt, "sum", d, out=d)
+        a = ops.binary(rt, "mul", ops.unary(rt, "silu", ops.matmul(rt, h2, w_g)), ops.matmul(rt, h2, w_u))
+        d = ops.matmul(rt, a, w_d)
+        if reduce:
+            ops.all_reduce(rt, "sum", d, out=d)
         return ops.binary(rt, "add", x1, d)
+
+    def block():
+        return run_block(wq, wk, wv, wo, wg, wu, wd, nh, True)
 
     for _ in range(3):
         y = block()
@@ -242,6 +264,14 @@ def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
         y = block()
     rt.record(e1)
     ms = rt.elapsed_ms(e0, e1) / iters
+    # parity of the sharded block against the unsharded one on the same GPU (reference launcher: cuda_launch.py:70-76)
+    tp_diff = 0.0
+    if full is not None:
+        y_full = run_block(full["q"], full["k"], full["v"], full["o"], full["g"], full["u"], full["d"], NH, False)
+        rt.sync()
+        tp_diff = float((y.float() - y_full.float()).abs().max().item())
+        del y_full
+        full = None
     # all-reduce alone: 16 MiB fp16 message
     buf = torch.zeros(T, H, device="cuda", dtype=dt)
     for _ in range(3):
@@ -290,12 +320,13 @@ def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
         "k_shard_allreduce_ms": round(k_ms, 4), "k_shard_TFLOPs_aggregate": round(2.0 * G ** 3 / k_ms / 1e9, 1),
     }
     return {
-        "workload": "Llama-7B-style block, tokens 2048, fp16, TP=%d (2 all-reduces of 16 MiB)" % world,
+        "workload": "Llama-7B-style block (RMSNorm, q/k/v, RoPE, attention, o, RMSNorm, gate/up/SiLU, down), tokens 2048, fp16, TP=%d (2 all-reduces of 16 MiB)" % world,
         "ms_per_block": round(ms, 4),
         "gemm_TFLOPs_aggregate": round(tp.llama_block_flops(T, H, F, 1) / ms / 1e9, 1),
         "allreduce_16MiB_ms": round(ar_ms, 4),
         "allreduce_busbw_GBs": round(2 * (world - 1) / world * nbytes / (ar_ms * 1e-3) / 1e9, 1) if world > 1 else None,
         "gemm_strong_scaling": gemm_shards,
+        "max_abs_diff_vs_unsharded": tp_diff,
         "finite": bool(torch.isfinite(y.float()).all().item()),
     }
 

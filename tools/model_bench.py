@@ -150,6 +150,14 @@ def build_bert(bl: Builder, batch: int, seq: int, layers: int, hidden: int = 768
     return x
 
 
+def build_matmul(bl: Builder, n: int = 4096, trans_b: bool = False):
+    """One n^3 MatMul as a one-operator graph: what a single launch costs through the reference executor."""
+    a = bl.input((bl.rng.standard_normal((n, n))).astype(bl.np))
+    w = bl.weight((n, n), 1.0)
+    bl.flops += 2.0 * n ** 3
+    return bl.h.matmul(a, w, None, False, trans_b, None, bl.B.ActType.Linear, "default")
+
+
 def timed(fn, iters, warm=2):
     for _ in range(warm):
         fn()
@@ -168,6 +176,10 @@ def run_model(model: str, device: int = 0, batch: int | None = None, seq: int = 
         batch = batch or 128
         out = build_resnet50(bl, batch)
         name = f"ResNet-50 bs{batch} {dtype}"
+    elif model in ("matmul", "matmul_nt"):
+        batch = 1
+        out = build_matmul(bl, 4096, model == "matmul_nt")
+        name = f"MatMul 4096^3 {dtype} " + ("NT" if model == "matmul_nt" else "NN")
     else:
         batch = batch or 32
         out = build_bert(bl, batch, seq, layers)
@@ -188,7 +200,7 @@ def run_model(model: str, device: int = 0, batch: int | None = None, seq: int = 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("model", choices=["resnet50", "bert"])
+    ap.add_argument("model", choices=["resnet50", "bert", "matmul", "matmul_nt"])
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--seq", type=int, default=512)
     ap.add_argument("--layers", type=int, default=12)
