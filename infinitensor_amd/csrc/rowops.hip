@@ -39,23 +39,43 @@ template <typename T, int N> struct alignas(sizeof(T) * N) Pack {
     T v[N];
 };
 
+// Wave64 all-reduce on the DPP cross-lane paths (no LDS round trip: __shfl_xor is ds_bpermute, ~100+ cycles a step):
+// quad swaps, half-row / row mirrors give every lane of a 16-lane row the row total; row_bcast15 / row_bcast31 chain
+// the four rows so lane 63 holds the wave total, which v_readlane broadcasts. The order of the additions is fixed.
+template <int CTRL, int ROW_MASK> __device__ inline float dpp_move(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                                 CTRL, ROW_MASK, 0xf, false));
+}
+__device__ inline float wave_bcast63(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 __device__ inline float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_move<0xB1, 0xf>(v, v));  // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_move<0x4E, 0xf>(v, v));  // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_move<0x141, 0xf>(v, v)); // row_half_mirror
+    v = fmaxf(v, dpp_move<0x140, 0xf>(v, v)); // row_mirror
+    v = fmaxf(v, dpp_move<0x142, 0xa>(v, v)); // row_bcast15 into rows 1, 3
+    v = fmaxf(v, dpp_move<0x143, 0xc>(v, v)); // row_bcast31 into rows 2, 3
+    return wave_bcast63(v);
 }
 __device__ inline float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_move<0xB1, 0xf>(0.f, v);
+    v += dpp_move<0x4E, 0xf>(0.f, v);
+    v += dpp_move<0x141, 0xf>(0.f, v);
+    v += dpp_move<0x140, 0xf>(0.f, v);
+    v += dpp_move<0x142, 0xa>(0.f, v);
+    v += dpp_move<0x143, 0xc>(0.f, v);
+    return wave_bcast63(v);
 }
 
 // One expression for every normalisation kernel (explicit, non-contractable steps), so that the fused Add -> Norm
 // kernel and the stand-alone kernels round identically.
 __device__ inline float norm_apply(float x, float mu, float rstd, float g, float b) {
     return fmaf(__fmul_rn(__fsub_rn(x, mu), rstd), g, b);
+}
+
+__device__ inline float norm_apply_centered(float d, float rstd, float g, float b) { // d = x - mu
+    return fmaf(__fmul_rn(d, rstd), g, b);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -325,6 +345,245 @@ __global__ __launch_bounds__(256) void norm_wave_kernel(const T *__restrict__ x,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Aligned contiguous rows, the fast path (BERT / Llama hidden sizes). Measured on the first version of the wave
+// kernel: LayerNorm f16 16384 x 768 ran at ~1470 SIMD cycles per row whatever the byte count -- VALU-issue bound
+// (per-element selects and conversions, ds_bpermute reductions, a vmcnt(0) behind the prefetch branch), not HBM bound.
+// This kernel
+//  * addresses a row through a per-row BUFFER descriptor (the row base is wave-uniform): lanes past the row end read 0
+//    and their stores are dropped by the hardware range check, so loads / stores carry no predicate and no branch, and
+//    the next row's prefetch is cancelled by a zero-sized descriptor instead of a branch (a branch join would force
+//    vmcnt(0) and serialise prefetch and arithmetic);
+//  * picks the chunk width B (16 or 8 bytes per lane) that leaves the fewest idle lanes: n = 768 f16 is 3 chunks of 8 B
+//    (12 elements per lane) instead of 2 chunks of 16 B with half the lanes idle in the second;
+//  * does the arithmetic on float2 (v_pk_add / v_pk_mul / v_pk_fma_f32), converts once, keeps scale / bias in fp32
+//    registers for the life of the persistent wave, masks the variance only in the last chunk;
+//  * reduces with the DPP wave_sum above.
+// Same value semantics as norm_apply(): fp32, centered variance, (x - mu) * rstd * g + b with one fma.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int rw_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int rw_u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 rw_f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 rw_bf16x2 __attribute__((ext_vector_type(2)));
+
+typedef float rw_f32x4 __attribute__((ext_vector_type(4)));
+
+// One chunk = the B bytes a lane loads at once, kept as the loaded dword vector; Chunk converts it to / from float2 pairs
+// with whole-vector operations only (shuffles, convertvector). Going through scalar dword arrays here made the
+// optimizer (SLP) emit a wrong fp32 kernel -- it computed half of the outputs and duplicated them.
+template <int B> struct ChunkVec;
+template <> struct ChunkVec<16> { using type = rw_u32x4; };
+template <> struct ChunkVec<8> { using type = rw_u32x2; };
+
+template <typename T> __device__ inline f32x2_t pair_up(unsigned u);
+template <> __device__ inline f32x2_t pair_up<__half>(unsigned u) {
+    return __builtin_convertvector(__builtin_bit_cast(rw_f16x2, u), f32x2_t);
+}
+template <> __device__ inline f32x2_t pair_up<__hip_bfloat16>(unsigned u) {
+    return f32x2_t{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
+}
+template <typename T> __device__ inline unsigned pair_down(f32x2_t v);
+template <> __device__ inline unsigned pair_down<__half>(f32x2_t v) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, rw_f16x2)); // v_cvt_pk_f16_f32, RNE
+}
+template <> __device__ inline unsigned pair_down<__hip_bfloat16>(f32x2_t v) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, rw_bf16x2)); // v_cvt_pk_bf16_f32, RNE
+}
+
+template <typename T, int B> struct Chunk {
+    using U = typename ChunkVec<B>::type;
+    static constexpr int P = B / (2 * (int)sizeof(T)); // float2 pairs per chunk
+    __device__ static inline void up(U v, f32x2_t *dst) {
+        if constexpr (sizeof(T) == 4 && B == 16) {
+            const rw_f32x4 f = __builtin_bit_cast(rw_f32x4, v);
+            dst[0] = __builtin_shufflevector(f, f, 0, 1);
+            dst[1] = __builtin_shufflevector(f, f, 2, 3);
+        } else if constexpr (sizeof(T) == 4) {
+            dst[0] = __builtin_bit_cast(f32x2_t, v);
+        } else {
+#pragma unroll
+            for (int k = 0; k < P; ++k)
+                dst[k] = pair_up<T>(v[k]);
+        }
+    }
+    __device__ static inline U down(const f32x2_t *src) {
+        if constexpr (sizeof(T) == 4 && B == 16) {
+            return __builtin_bit_cast(U, __builtin_shufflevector(src[0], src[1], 0, 1, 2, 3));
+        } else if constexpr (sizeof(T) == 4) {
+            return __builtin_bit_cast(U, src[0]);
+        } else {
+            U r;
+#pragma unroll
+            for (int k = 0; k < P; ++k)
+                r[k] = pair_down<T>(src[k]);
+            return r;
+        }
+    }
+};
+
+template <int B, int CHUNKS>
+__device__ __forceinline__ void rows_load(typename ChunkVec<B>::type (&dst)[CHUNKS], const void *base, int nbytes, int voff0) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, nbytes, 0x00020000);
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+        if constexpr (B == 16)
+            dst[c] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff0 + c * 64 * B, 0, 0);
+        else
+            dst[c] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff0 + c * 64 * B, 0, 0);
+    }
+}
+template <int B, int CHUNKS>
+__device__ __forceinline__ void rows_store(const typename ChunkVec<B>::type (&src)[CHUNKS], void *base, int nbytes, int voff0) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, nbytes, 0x00020000);
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+        if constexpr (B == 16)
+            __builtin_amdgcn_raw_buffer_store_b128(src[c], rs, voff0 + c * 64 * B, 0, 0);
+        else
+            __builtin_amdgcn_raw_buffer_store_b64(src[c], rs, voff0 + c * 64 * B, 0, 0);
+    }
+}
+
+// 1 / sqrt(a): v_rsq_f32 (1 ulp) + one Newton step -> < 1 ulp, 4 instructions instead of the ~25 of 1.0f / sqrtf(a)
+__device__ inline float inv_sqrt(float a) {
+    const float y = __builtin_amdgcn_rsqf(a);
+    const float h = 0.5f * a * y;
+    return fmaf(y, fmaf(-h, y, 0.5f), y);
+}
+
+// ADD: the row is a + b (x2 = b), rounded to the storage type exactly as a separate Add kernel would store it, so
+// Norm(Add(a, b)) fused here equals the two-kernel chain bit for bit (this is the Add -> LayerNorm / RMSNorm fusion).
+template <typename T, int B, int CHUNKS, bool RMS, int ROWS, bool ADD>
+__global__ __launch_bounds__(256) void norm_rows_kernel(const T *__restrict__ x, const T *__restrict__ x2,
+                                                        const T *__restrict__ scale, const T *__restrict__ bias,
+                                                        T *__restrict__ y, long rows, int n, int scale_size,
+                                                        int bias_size, float eps) {
+    using CK = Chunk<T, B>;
+    using U = typename CK::U;
+    constexpr int PL = CK::P;          // float2 pairs in one chunk
+    constexpr int NP = PL * CHUNKS;    // pairs of one row held by a lane
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long ngroups = (rows + ROWS - 1) / ROWS;
+    const long stride = (long)gridDim.x * 4;
+    long g = (long)blockIdx.x * 4 + w;
+    if (g >= ngroups)
+        return;
+    const int row_bytes = n * (int)sizeof(T);
+    const int voff0 = lane * B;
+    const bool vlast = voff0 + (CHUNKS - 1) * 64 * B < row_bytes;
+    constexpr int R2 = ADD ? ROWS : 1;
+    U cur[ROWS][CHUNKS], nxt[ROWS][CHUNKS], cur2[R2][CHUNKS], nxt2[R2][CHUNKS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const long row = g * ROWS + r;
+        rows_load<B, CHUNKS>(cur[r], x + (row < rows ? row : rows - 1) * n, row_bytes, voff0);
+        if constexpr (ADD)
+            rows_load<B, CHUNKS>(cur2[r], x2 + (row < rows ? row : rows - 1) * n, row_bytes, voff0);
+    }
+    f32x2_t gs[NP], bs[NP];
+    {
+        U tmp[CHUNKS];
+        if (scale_size != 1) {
+            rows_load<B, CHUNKS>(tmp, scale, row_bytes, voff0);
+#pragma unroll
+            for (int c = 0; c < CHUNKS; ++c)
+                CK::up(tmp[c], &gs[c * PL]);
+        } else {
+            const float s0 = Elem<T>::ld(scale);
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+                gs[i] = f32x2_t{s0, s0};
+        }
+        if (bias != nullptr && bias_size != 1) {
+            rows_load<B, CHUNKS>(tmp, bias, row_bytes, voff0);
+#pragma unroll
+            for (int c = 0; c < CHUNKS; ++c)
+                CK::up(tmp[c], &bs[c * PL]);
+        } else {
+            const float b0 = bias != nullptr ? Elem<T>::ld(bias) : 0.f;
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+                bs[i] = f32x2_t{b0, b0};
+        }
+    }
+    const float fn = (float)n, inv_n = 1.0f / fn;
+    for (; g < ngroups; g += stride) {
+        const long gn = g + stride;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) { // prefetch; past the end the descriptor is empty: no traffic, no branch
+            const long row = gn * ROWS + r;
+            const bool live = gn < ngroups && row < rows;
+            rows_load<B, CHUNKS>(nxt[r], x + (live ? row : 0) * n, live ? row_bytes : 0, voff0);
+            if constexpr (ADD)
+                rows_load<B, CHUNKS>(nxt2[r], x2 + (live ? row : 0) * n, live ? row_bytes : 0, voff0);
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            f32x2_t xf[NP];
+#pragma unroll
+            for (int c = 0; c < CHUNKS; ++c)
+                CK::up(cur[r][c], &xf[c * PL]);
+            if constexpr (ADD) {
+                f32x2_t bf[NP];
+#pragma unroll
+                for (int c = 0; c < CHUNKS; ++c)
+                    CK::up(cur2[r][c], &bf[c * PL]);
+#pragma unroll
+                for (int i = 0; i < NP; ++i)
+                    xf[i] += bf[i];
+                if constexpr (sizeof(T) == 2) { // round the sum to the storage type, like the Add kernel's store
+#pragma unroll
+                    for (int i = 0; i < NP; ++i)
+                        xf[i] = pair_up<T>(pair_down<T>(xf[i]));
+                }
+            }
+            f32x2_t mu2 = {0.f, 0.f};
+            if (!RMS) {
+                f32x2_t s2 = xf[0];
+#pragma unroll
+                for (int i = 1; i < NP; ++i)
+                    s2 += xf[i]; // lanes past the row end hold 0
+                const float mu = wave_sum(s2.x + s2.y) / fn; // correctly rounded: integer-valued rows give exact means
+                mu2 = f32x2_t{mu, mu};
+            }
+            f32x2_t q2 = {0.f, 0.f}, ql = {0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                xf[i] -= mu2; // the centered value is what the output needs too
+                if (i < NP - PL)
+                    q2 = __builtin_elementwise_fma(xf[i], xf[i], q2);
+                else
+                    ql = __builtin_elementwise_fma(xf[i], xf[i], ql);
+            }
+            const float qlast = (RMS || vlast) ? ql.x + ql.y : 0.f; // padding lanes would add mu^2
+            const float rstd = inv_sqrt(fmaf(wave_sum(q2.x + q2.y + qlast), inv_n, eps));
+            const f32x2_t r2 = {rstd, rstd};
+            U out[CHUNKS];
+#pragma unroll
+            for (int c = 0; c < CHUNKS; ++c) {
+                f32x2_t o[PL];
+#pragma unroll
+                for (int k = 0; k < PL; ++k) // same roundings as norm_apply(): (x - mu) * rstd, then one fma
+                    o[k] = __builtin_elementwise_fma(xf[c * PL + k] * r2, gs[c * PL + k], bs[c * PL + k]);
+                out[c] = CK::down(o);
+            }
+            const long row = g * ROWS + r;
+            rows_store<B, CHUNKS>(out, y + (row < rows ? row : 0) * n, row < rows ? row_bytes : 0, voff0);
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (int c = 0; c < CHUNKS; ++c) {
+                cur[r][c] = nxt[r][c];
+                if constexpr (ADD)
+                    cur2[r][c] = nxt2[r][c];
+            }
+    }
+}
+
+
 // Long rows: block per row, row re-read from L2.
 template <typename T, bool RMS>
 __global__ __launch_bounds__(256) void norm_block_kernel(const T *__restrict__ x, const T *__restrict__ scale,
@@ -501,68 +760,6 @@ __global__ __launch_bounds__(256) void softmax_blockreg_kernel(const T *__restri
     }
 }
 
-// Add -> LayerNorm / RMSNorm in one pass (the residual join in front of every transformer normalisation):
-// y = norm(round_T(a + b)). The sum is rounded to the storage type before the statistics, exactly like the unfused
-// Add -> Norm chain, so the result equals it up to fp32 rounding ties of the final store. One wave per row, rows of up to 64 * VEC * CHUNKS elements,
-// 16-byte loads of both operands, grid-stride over rows.
-template <typename T, int CHUNKS, bool RMS>
-__global__ __launch_bounds__(256) void add_norm_wave_kernel(const T *__restrict__ a, const T *__restrict__ b,
-                                                            const T *__restrict__ scale, const T *__restrict__ bias,
-                                                            T *__restrict__ y, long rows, int n, int scale_size,
-                                                            int bias_size, float eps) {
-    constexpr int VEC = Elem<T>::VEC;
-    const int lane = threadIdx.x & 63;
-    const float fn = (float)n;
-    for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
-        RowRegs<T, CHUNKS> ra, rb;
-        load_row<T, CHUNKS, true>(a + row * n, n, lane, ra, 0.f);
-        load_row<T, CHUNKS, true>(b + row * n, n, lane, rb, 0.f);
-#pragma unroll
-        for (int c = 0; c < CHUNKS; ++c)
-#pragma unroll
-            for (int j = 0; j < VEC; ++j)
-                Elem<T>::st(&ra.c[c].v[j], Elem<T>::ld(&ra.c[c].v[j]) + Elem<T>::ld(&rb.c[c].v[j]));
-        float mu = 0.f;
-        if (!RMS) {
-            float s = 0.f;
-#pragma unroll
-            for (int c = 0; c < CHUNKS; ++c)
-#pragma unroll
-                for (int j = 0; j < VEC; ++j)
-                    s += Elem<T>::ld(&ra.c[c].v[j]);
-            mu = wave_sum(s) / fn;
-        }
-        float q = 0.f;
-#pragma unroll
-        for (int c = 0; c < CHUNKS; ++c)
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const int col = (c * 64 + lane) * VEC + j;
-                const float d = (col < n) ? Elem<T>::ld(&ra.c[c].v[j]) - mu : 0.f;
-                q = fmaf(d, d, q);
-            }
-        const float rstd = 1.0f / sqrtf(wave_sum(q) / fn + eps);
-#pragma unroll
-        for (int c = 0; c < CHUNKS; ++c) {
-            const int base = (c * 64 + lane) * VEC;
-            if (base < n) {
-                Pack<T, VEC> sc, bs;
-                if (scale_size != 1)
-                    sc = *reinterpret_cast<const Pack<T, VEC> *>(scale + base);
-                if (bias && bias_size != 1)
-                    bs = *reinterpret_cast<const Pack<T, VEC> *>(bias + base);
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) {
-                    const float gg = scale_size == 1 ? Elem<T>::ld(scale) : Elem<T>::ld(&sc.v[j]);
-                    const float bb = bias ? (bias_size == 1 ? Elem<T>::ld(bias) : Elem<T>::ld(&bs.v[j])) : 0.f;
-                    Elem<T>::st(&ra.c[c].v[j], norm_apply(Elem<T>::ld(&ra.c[c].v[j]), mu, rstd, gg, bb));
-                }
-            }
-        }
-        store_row<T, CHUNKS, true>(y + row * n, n, lane, ra);
-    }
-}
-
 static inline bool is_aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 // persistent grid: at most 8 blocks (32 waves) per CU
 static inline int env_int(const char *name, int dflt) {
@@ -573,6 +770,50 @@ static inline unsigned pgrid(int64_t blocks, int num_cu) {
     static const int per_cu = env_int("IROCM_ROWOPS_BLOCKS_PER_CU", 8); // tuning hook
     const int64_t cap = (int64_t)num_cu * per_cu;
     return (unsigned)(blocks < cap ? (blocks < 1 ? 1 : blocks) : cap);
+}
+
+// Launch of the fast row path (norm_rows_kernel); false when the rows do not qualify (unaligned, or > 4 KiB).
+template <typename T, bool RMS, bool ADD>
+static bool launch_norm_rows(infiniRocmRuntime_t rt, const T *x, const T *x2, const T *scale, const T *bias, T *y,
+                             int64_t outer, int64_t n, int64_t scale_size, int64_t bias_size, float eps) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int64_t row_bytes = n * (int64_t)sizeof(T);
+    const bool al = is_aligned16(x) && (!ADD || is_aligned16(x2)) && is_aligned16(y) && is_aligned16(scale) &&
+                    (bias == nullptr || is_aligned16(bias)) && (n % VEC == 0);
+    if (!al || row_bytes > 4096 || outer == 0)
+        return false;
+    // chunk width: the one that leaves the fewest idle lanes (768 f16 = 3 x 8 B, not 2 x 16 B with half a chunk idle)
+    const int c16 = (int)ceil_div(row_bytes, (int64_t)1024), c8 = (int)ceil_div(row_bytes, (int64_t)512);
+    const bool use8 = (c8 == 1 || c8 == 3) && (c8 * 512 - row_bytes) < (c16 * 1024 - row_bytes);
+    static const int rpw_env = env_int("IROCM_NORM_RPW", 0); // tuning hook
+    static const int per_cu = env_int("IROCM_NORM_BLOCKS_PER_CU", 4); // 16 persistent waves per CU, rows pipelined
+    const int rpw = (!ADD && rpw_env == 2) ? 2 : 1;
+    const int64_t blocks = ceil_div(outer, (int64_t)4 * rpw), cap = (int64_t)rt->num_cu * per_cu;
+    const dim3 grid((unsigned)(blocks < cap ? blocks : cap));
+#define ROWS_GO(B, C, R)                                                                                        \
+    hipLaunchKernelGGL((norm_rows_kernel<T, B, C, RMS, R, ADD>), grid, dim3(256), 0, rt->stream, x, x2, scale, bias, y, \
+                       (long)outer, (int)n, (int)scale_size, (int)bias_size, eps)
+#define ROWS_R(B, C)                                                                                            \
+    do {                                                                                                        \
+        if constexpr (!ADD) {                                                                                   \
+            if (rpw == 2) ROWS_GO(B, C, 2); else ROWS_GO(B, C, 1);                                               \
+        } else {                                                                                                \
+            ROWS_GO(B, C, 1);                                                                                   \
+        }                                                                                                       \
+    } while (0)
+    if (use8) {
+        if (c8 == 1) ROWS_R(8, 1); else ROWS_R(8, 3);
+    } else {
+        switch (c16) {
+        case 1: ROWS_R(16, 1); break;
+        case 2: ROWS_R(16, 2); break;
+        case 3: ROWS_R(16, 3); break;
+        default: ROWS_R(16, 4); break;
+        }
+    }
+#undef ROWS_R
+#undef ROWS_GO
+    return true;
 }
 
 template <typename T>
@@ -635,27 +876,20 @@ static int norm_dispatch(infiniRocmRuntime_t rt, const T *x, const T *scale, con
     const bool al = is_aligned16(x) && is_aligned16(y) && is_aligned16(scale) &&
                     (bias == nullptr || is_aligned16(bias)) && (n % VEC == 0);
     const int chunks = (int)ceil_div(n, (int64_t)64 * VEC);
-    const int64_t row_bytes = n * (int64_t)sizeof(T);
-    int rpw = (!al || outer < 4096) ? 1 : (row_bytes <= 1024 ? 4 : (row_bytes <= 3072 ? 2 : 1));
-    static const int rpw_env = env_int("IROCM_NORM_RPW", 0); // tuning hook
-    if (rpw_env && al)
-        rpw = rpw_env;
+    if (launch_norm_rows<T, RMS, false>(rt, x, (const T *)nullptr, scale, bias, y, outer, n, scale_size, bias_size, eps)) {
+        IROCM_LAUNCH_CHECK("norm");
+        return INFINI_ROCM_OK;
+    }
 #define NORM_GO(C, A, R)                                                                           \
     hipLaunchKernelGGL((norm_wave_kernel<T, C, A, RMS, R>), dim3(pgrid(ceil_div(outer, 4 * R), rt->num_cu)), \
                        dim3(256), 0, rt->stream, x, scale, bias, y, (long)outer, (int)n,           \
                        (int)scale_size, (int)bias_size, eps)
     if (chunks <= 1) {
-        if (!al) NORM_GO(1, false, 1);
-        else if (rpw == 4) NORM_GO(1, true, 4);
-        else if (rpw == 2) NORM_GO(1, true, 2);
-        else NORM_GO(1, true, 1);
+        NORM_GO(1, false, 1);
     } else if (chunks <= 2) {
-        if (!al) NORM_GO(2, false, 1);
-        else if (rpw == 4) NORM_GO(2, true, 4);
-        else if (rpw == 2) NORM_GO(2, true, 2);
-        else NORM_GO(2, true, 1);
+        NORM_GO(2, false, 1);
     } else if (chunks <= 4) {
-        if (al) NORM_GO(4, true, 1); else NORM_GO(4, false, 1);
+        NORM_GO(4, false, 1);
     } else {
         const unsigned g = (unsigned)(outer < 8192 ? outer : 8192);
         const int bch = (int)ceil_div(n, (int64_t)256 * VEC); // 16-byte chunks per thread of a block-resident row
@@ -679,20 +913,8 @@ static int norm_dispatch(infiniRocmRuntime_t rt, const T *x, const T *scale, con
 template <typename T, bool RMS>
 static int add_norm_dispatch(infiniRocmRuntime_t rt, const T *a, const T *b, const T *scale, const T *bias, T *y,
                              int64_t outer, int64_t n, int64_t scale_size, int64_t bias_size, float eps) {
-    constexpr int VEC = Elem<T>::VEC;
-    const bool al = is_aligned16(a) && is_aligned16(b) && is_aligned16(y) && is_aligned16(scale) &&
-                    (bias == nullptr || is_aligned16(bias)) && (n % VEC == 0);
-    const int chunks = (int)ceil_div(n, (int64_t)64 * VEC);
-    if (!al || chunks > 4)
-        return INFINI_ROCM_UNSUPPORTED;
-    const unsigned g = pgrid(ceil_div(outer, 4), rt->num_cu);
-#define AN(C)                                                                                                  \
-    hipLaunchKernelGGL((add_norm_wave_kernel<T, C, RMS>), dim3(g), dim3(256), 0, rt->stream, a, b, scale, bias, y, \
-                       (long)outer, (int)n, (int)scale_size, (int)bias_size, eps)
-    if (chunks <= 1) AN(1);
-    else if (chunks <= 2) AN(2);
-    else AN(4);
-#undef AN
+    if (!launch_norm_rows<T, RMS, true>(rt, a, b, scale, bias, y, outer, n, scale_size, bias_size, eps))
+        return INFINI_ROCM_UNSUPPORTED; // the caller falls back to Add + Norm
     IROCM_LAUNCH_CHECK("add_norm");
     return INFINI_ROCM_OK;
 }

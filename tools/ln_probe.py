@@ -9,7 +9,12 @@ from infinitensor_amd import RocmRuntime, ops
 from infinitensor_amd.runtime import Event
 
 rt = RocmRuntime(0)
-for rows, n in ((16384, 768), (262144, 768), (16384, 4096)):
+import os
+
+SHAPES = ((16384, 768), (262144, 768), (16384, 4096))
+if os.environ.get("LN_SHAPES"):  # e.g. LN_SHAPES=16384x768
+    SHAPES = tuple(tuple(int(v) for v in s.split("x")) for s in os.environ["LN_SHAPES"].split(","))
+for rows, n in SHAPES:
     for dt in (torch.float16, torch.float32):
         x = torch.randn(rows, n, device="cuda").to(dt)
         g = torch.randn(n, device="cuda").to(dt)
