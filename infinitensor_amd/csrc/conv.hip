@@ -22,6 +22,7 @@
 //   infini_rocm_matmul's LDS-DMA kernels by the dispatcher when the plane size allows 16-byte rows.
 // conv_direct32 (f32): one output per thread, serial fp32 fma over k in the oracle's order.
 #include "gemm_common.h"
+#include <type_traits>
 
 extern "C" int infini_rocm_matmul(infiniRocmRuntime_t rt, int dtype, const void *a, const void *b,
                                   const void *bias, void *c, int64_t batch, int64_t m, int64_t n,
@@ -81,6 +82,14 @@ template <typename Tr> __global__ __launch_bounds__(256) void conv_igemm16(ConvA
     const unsigned short *W = (const unsigned short *)p.w + (long)(g * p.fg) * p.kdim;
     const unsigned short *X = (const unsigned short *)p.x + ((long)img * p.c + (long)g * p.cg) * p.h * p.wd;
     const int RS = p.r * p.s;
+    // bias of the lane's four filter rows, loaded now: a 2-byte load issued in the epilogue puts an L2 round trip in front
+    // of the tile's stores (measured on conv_s1.hip: the epilogue, not the K loop, bounded the pointwise layers)
+    float bias_v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int fm = m0 + wm * 64 + i * 16 + (lane & 15);
+        bias_v[i] = (p.bias && fm < p.fg) ? Tr::to_f32(((const unsigned short *)p.bias)[g * p.fg + fm]) : 0.f;
+    }
 
     // ---- per-thread staging assignment --------------------------------------------------------
     // A: 128 rows x 32 k = 512 chunks of 8 k; thread t takes chunks t and t + 256: row = ch >> 2, kc = ch & 3
@@ -215,10 +224,13 @@ template <typename Tr> __global__ __launch_bounds__(256) void conv_igemm16(ConvA
     if (wide) {
         const int l15 = lane & 15, g4 = lane >> 4;
         const bool odd = g4 & 1;
+        // one copy per activation (a runtime switch per element leaves 64 scalar branches in the loop)
+        auto store_all = [&](auto actc) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(actc)::value;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int fm = m0 + wm * 64 + i * 16 + l15;
-            const float bv = bias ? Tr::to_f32(bias[g * p.fg + fm]) : 0.f;
+            const float bv = bias_v[i]; // loaded before the K loop
             const long rowoff = (long)fm * p.npix;
             const unsigned short *R = p.res ? (const unsigned short *)p.res + ((long)img * p.f + (long)g * p.fg) * p.npix : nullptr;
 #pragma unroll
@@ -237,8 +249,12 @@ template <typename Tr> __global__ __launch_bounds__(256) void conv_igemm16(ConvA
                         v[2] += Tr::to_f32((unsigned short)(rk[1] & 0xffff)); v[3] += Tr::to_f32((unsigned short)(rk[1] >> 16));
                     }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        v[r] = apply_act(v[r], p.act);
+                    for (int r = 0; r < 4; ++r) {
+                        if constexpr (ACT == 1)
+                            v[r] = v[r] > 0.f ? v[r] : 0.f;
+                        else if constexpr (ACT < 0)
+                            v[r] = apply_act(v[r], p.act);
+                    }
                     pk[t2][0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
                     pk[t2][1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
                 }
@@ -251,6 +267,13 @@ template <typename Tr> __global__ __launch_bounds__(256) void conv_igemm16(ConvA
                 *(u32x4_t *)(Y + rowoff + pix) = o;
             }
         }
+        };
+        if (p.act == 0)
+            store_all(std::integral_constant<int, 0>{});
+        else if (p.act == 1)
+            store_all(std::integral_constant<int, 1>{});
+        else
+            store_all(std::integral_constant<int, -1>{});
         return;
     }
 #pragma unroll
@@ -472,7 +495,13 @@ int infini_rocm_conv2d_res(infiniRocmRuntime_t rt, int dtype, const void *x, con
     // flight): C64->F256 108 vs 143 us, C256->F128 107 vs 137 us; from 28x28 down conv_s1 wins everywhere
     const bool big_plane_pointwise = r == 1 && s == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0 && groups == 1 &&
                                      p.npix >= 2048 && f >= 128 && c <= 256;
-    if (variant < 0 && (one_kstep || big_plane_pointwise))
+    // conv_pw_kernel (conv_s1.hip) candidates; IROCM_CONV_PW=2 (tuning hook) sends them there ahead of the two rules above
+    static const int pw_pref = getenv("IROCM_CONV_PW") ? atoi(getenv("IROCM_CONV_PW")) : 1;
+    const bool pw_shape = r == 1 && s == 1 && ph == 0 && pw == 0 && groups == 1 && c % 64 == 0 && c <= 256 && f > 64;
+    // measured (tools/conv_bench.py): with <= 128 input channels conv_pw wins everywhere (C64->F256 @56x56 64 vs 89 us generic,
+    // C128->F512 @28x28 44 vs 59 us conv_s1); at C = 256 its 100 KiB of LDS leaves one workgroup per CU and it loses
+    const bool pw_default = pw_pref >= 1 && pw_shape && c <= 128 && p.npix % 2 == 0 && sh == 1 && sw == 1;
+    if (variant < 0 && (one_kstep || big_plane_pointwise) && !(pw_default || (pw_pref == 2 && pw_shape)))
         goto generic;
     if (groups == 1 && variant != 1 && !(variant == 3 && pointwise_gemm) &&
         (variant == 2 || residual || !(pointwise_gemm && f >= 256 && c >= 256 && p.npix >= 512))) {

@@ -46,6 +46,7 @@ struct ConvS1Args {
     int act;
     int kdim, kpad;      // ROWTAP: C*R*S and its round-up to 32 (w is [F][kpad])
     int wide_epilogue;   // 16-byte stores where the plane allows (tuning hook IROCM_CONV_WIDE=0 turns it off)
+    int epi_probe;       // ablation hook, 0 in production
     unsigned x_bytes;    // bytes of everything behind x
     long plane_elems;    // elements of one phase plane set [n][c][h][wd]
     signed char slot[16]; // phase py*sw + px -> index of its plane set behind x
@@ -171,6 +172,211 @@ __global__ __launch_bounds__(256) void conv_repack_w_flat(const unsigned short *
         const int t = k / c, cc = k - t * c;
         o[i] = k < c * rs ? w[((long)ff * c + cc) * rs + t] : (unsigned short)0;
     }
+}
+
+// Epilogue of one 128 x 128 (WM = WN = 2) or 64 x 256 workgroup tile: + bias[f], optional residual, activation, NCHW store.
+// The accumulators hold filters on lanes (l15) and 4 consecutive pixel slots per lane (g4 * 4 + r).
+template <typename Tr>
+__device__ __forceinline__ void conv_tile_epilogue(const ConvS1Args &p, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn,
+                                                   int l15, int g4) {
+    unsigned short *Y = (unsigned short *)p.y;
+    const unsigned short *bias = (const unsigned short *)p.bias;
+    if (p.wide_epilogue == 9) { // ablation hook (IROCM_CONV_WIDE=9): keep the accumulators alive, store almost nothing
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (sacc == 123.456f)
+            Y[0] = 1;
+        return;
+    }
+    const bool vec_ok = (p.hw % 4 == 0) && ((((uintptr_t)p.y) & 7) == 0);
+    // Wide path (planes that are a multiple of 16 pixels, i.e. hwp == hw: 56x56, 28x28, ...): lane groups g4 / g4^1 swap
+    // halves of a pair of 16-pixel tiles so that every lane stores 8 consecutive pixels of one filter row with ONE
+    // 16-byte store (same exchange as the GEMM epilogue); wave-uniform condition, so the shuffles are convergent.
+    const bool wide = p.wide_epilogue && (p.hw % 16 == 0) && ((((uintptr_t)p.y) & 15) == 0) && (n0 + wn * 64 + 64 <= p.ncols) &&
+                      (m0 + wm * 64 + 64 <= p.f) && (!p.res || ((((uintptr_t)p.res) & 7) == 0));
+    if (wide) {
+        const bool odd = g4 & 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int fm = m0 + wm * 64 + i * 16 + l15;
+            const float bv = bias ? Tr::to_f32(bias[fm]) : 0.f;
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                unsigned pk[2][2];
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    const int col = n0 + wn * 64 + (jp * 2 + t2) * 16 + g4 * 4;
+                    const int im = col / p.hw, pix = col - im * p.hw; // hwp == hw here
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        v[r] = acc[i][jp * 2 + t2][r] + bv;
+                    if (p.res) {
+                        const u32x2_t rk = *(const u32x2_t *)((const unsigned short *)p.res + ((long)im * p.f + fm) * p.hw + pix);
+                        v[0] += Tr::to_f32((unsigned short)(rk[0] & 0xffff)); v[1] += Tr::to_f32((unsigned short)(rk[0] >> 16));
+                        v[2] += Tr::to_f32((unsigned short)(rk[1] & 0xffff)); v[3] += Tr::to_f32((unsigned short)(rk[1] >> 16));
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        v[r] = apply_act(v[r], p.act);
+                    pk[t2][0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
+                    pk[t2][1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
+                }
+                const unsigned s0 = odd ? pk[0][0] : pk[1][0], s1 = odd ? pk[0][1] : pk[1][1];
+                const unsigned r0 = (unsigned)__shfl_xor((int)s0, 16), r1 = (unsigned)__shfl_xor((int)s1, 16);
+                u32x4_t o;
+                if (odd) { o[0] = r0; o[1] = r1; o[2] = pk[1][0]; o[3] = pk[1][1]; }
+                else { o[0] = pk[0][0]; o[1] = pk[0][1]; o[2] = r0; o[3] = r1; }
+                const int col = n0 + wn * 64 + (jp * 2 + (odd ? 1 : 0)) * 16 + (g4 & ~1) * 4;
+                const int im = col / p.hw, pix = col - im * p.hw;
+                *(u32x4_t *)(Y + ((long)im * p.f + fm) * p.hw + pix) = o;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn * 64 + j * 16 + g4 * 4;
+        if (col >= p.ncols)
+            continue;
+        const int im = col / p.hwp, pix = col - im * p.hwp;
+        if (pix >= p.hw)
+            continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int fm = m0 + wm * 64 + i * 16 + l15;
+            if (fm >= p.f)
+                continue;
+            const float bv = bias ? Tr::to_f32(bias[fm]) : 0.f;
+            const long yoff = ((long)im * p.f + fm) * p.hw + pix;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                v[r] = acc[i][j][r] + bv;
+            if (p.res) {
+                const unsigned short *rp = (const unsigned short *)p.res + yoff;
+                if (vec_ok && pix + 3 < p.hw && ((((uintptr_t)p.res) & 7) == 0)) {
+                    const u32x2_t rk = *(const u32x2_t *)rp;
+                    v[0] += Tr::to_f32((unsigned short)(rk[0] & 0xffff)); v[1] += Tr::to_f32((unsigned short)(rk[0] >> 16));
+                    v[2] += Tr::to_f32((unsigned short)(rk[1] & 0xffff)); v[3] += Tr::to_f32((unsigned short)(rk[1] >> 16));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (pix + r < p.hw)
+                            v[r] += Tr::to_f32(rp[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                v[r] = apply_act(v[r], p.act);
+            unsigned short *dst = Y + yoff;
+            if (vec_ok && pix + 3 < p.hw) {
+                u32x2_t pk;
+                pk[0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
+                pk[1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
+                *(u32x2_t *)dst = pk;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (pix + r < p.hw)
+                        dst[r] = Tr::from_f32(v[r]);
+            }
+        }
+    }
+}
+
+// LDS-staged epilogue: measured on the pointwise layers, the direct stores above are what the convolutions wait for
+// (256->1024 @14x14: 26 us without the stores, 88 us with them; 128->512 @28x28: 23 vs 69 us) -- a wave store that
+// scatters 32- or 64-byte pieces over 16 filter rows moves < 1-2 TB/s. Here every wave first writes its 64 x 64 tile
+// (bias + activation applied, rounded) into a private [64][72]-element LDS image, then stores it row-wise: 8 lanes x 16
+// bytes = 128 contiguous bytes per filter row, 8 rows per instruction, one integer division per lane per tile.
+// `wbuf`: this wave's 9216 bytes. Needs an even plane size (dword-aligned runs); no residual input.
+constexpr int kEpiWaveBytes = 64 * 144;
+// The bias values of the lane's four filter rows (m0 + wm*64 + i*16 + l15) are loaded by the caller EARLY (a 2-byte
+// global load issued here would put an L2 round trip in front of every tile's stores).
+template <typename Tr>
+__device__ __forceinline__ void conv_load_bias(const ConvS1Args &p, int m0, int wm, int l15, float (&bv)[4]) {
+    const unsigned short *bias = (const unsigned short *)p.bias;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int fm = m0 + wm * 64 + i * 16 + l15;
+        bv[i] = (bias && fm < p.f) ? Tr::to_f32(bias[fm]) : 0.f;
+    }
+}
+
+template <typename Tr>
+__device__ __forceinline__ void conv_tile_epilogue_lds(const ConvS1Args &p, f32x4 (&acc)[4][4], const float (&bv)[4], int m0,
+                                                       int n0, int wm, int wn, int lane, char *wbuf) {
+    constexpr int ROWP = 144;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    // one copy of the packing loop per activation: a runtime switch per element keeps 64 scalar branches in the loop
+    auto stage = [&](auto actc) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[i][j][r] + bv[i];
+                    if constexpr (ACT == 1)
+                        v[r] = v[r] > 0.f ? v[r] : 0.f;
+                    else if constexpr (ACT < 0)
+                        v[r] = apply_act(v[r], p.act);
+                }
+                u32x2_t pk;
+                pk[0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
+                pk[1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
+                *(u32x2_t *)(wbuf + (i * 16 + l15) * ROWP + (j * 16 + g4 * 4) * 2) = pk;
+            }
+        }
+    };
+    if (p.act == 0)
+        stage(std::integral_constant<int, 0>{});
+    else if (p.act == 1)
+        stage(std::integral_constant<int, 1>{});
+    else
+        stage(std::integral_constant<int, -1>{});
+    __builtin_amdgcn_wave_barrier(); // same wave writes and reads: LDS operations of one wave complete in order
+    const int ch = lane & 7, rsub = lane >> 3;
+    const int col = n0 + wn * 64 + ch * 8;
+    const int im = col / p.hwp, pix = col - im * p.hwp;
+    const bool live = col < p.ncols && pix < p.hw;
+    const bool full = pix + 8 <= p.hw;
+    unsigned short *ybase = (unsigned short *)p.y + (long)im * p.f * p.hw + pix;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + rsub;
+        const int fm = m0 + wm * 64 + row;
+        const u32x4_t v = *(const u32x4_t *)(wbuf + row * ROWP + ch * 16);
+        if (p.epi_probe == 2) { // ablation hooks (IROCM_CONV_EPI_PROBE): 2 = no global stores
+            if (v[0] == 0x12345678u && v[3] == 0x9abcdef0u)
+                ((unsigned short *)p.y)[0] = 1;
+            continue;
+        }
+        if (p.epi_probe == 3 && it >= 4) // 3 = half of the rows
+            continue;
+        if (live && fm < p.f) {
+            unsigned short *dst = ybase + (long)fm * p.hw;
+            if (p.epi_probe == 4) // 4 = same pattern folded into 1 MiB (cache-resident destination)
+                dst = (unsigned short *)p.y + (((dst - (unsigned short *)p.y)) & 0x7ffff);
+            if (full) {
+                *(u32x4_t *)dst = v;
+            } else { // the last run of a plane whose size is not a multiple of 8
+                const int nv = p.hw - pix;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (e < nv)
+                        dst[e] = (unsigned short)(v[e >> 1] >> ((e & 1) * 16));
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
 }
 
 template <typename Tr, int WM, int WN, int BK, bool ROWTAP>
@@ -377,6 +583,8 @@ __global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void conv_s1_kernel(ConvS1
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bias_v[4]; // in flight during the whole K loop
+    conv_load_bias<Tr>(p, m0, wm, l15, bias_v);
 
     // per-lane LDS fragment offsets
     const int a_frag = ((wm * 64 + l15) * APITCH + g4 * 8) * 2; // + i*16*APITCH*2 + ks*64
@@ -448,103 +656,205 @@ __global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void conv_s1_kernel(ConvS1
     else
         sweep(std::false_type{});
 
-    // ---- epilogue ------------------------------------------------------------------------------------
-    unsigned short *Y = (unsigned short *)p.y;
-    const unsigned short *bias = (const unsigned short *)p.bias;
-    const bool vec_ok = (p.hw % 4 == 0) && ((((uintptr_t)p.y) & 7) == 0);
-    // Wide path (planes that are a multiple of 16 pixels, i.e. hwp == hw: 56x56, 28x28, ...): lane groups g4 / g4^1 swap
-    // halves of a pair of 16-pixel tiles so that every lane stores 8 consecutive pixels of one filter row with ONE
-    // 16-byte store (same exchange as the GEMM epilogue); wave-uniform condition, so the shuffles are convergent.
-    const bool wide = p.wide_epilogue && (p.hw % 16 == 0) && ((((uintptr_t)p.y) & 15) == 0) && (n0 + wn * 64 + 64 <= p.ncols) &&
-                      (m0 + wm * 64 + 64 <= p.f) && (!p.res || ((((uintptr_t)p.res) & 7) == 0));
-    if (wide) {
-        const bool odd = g4 & 1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int fm = m0 + wm * 64 + i * 16 + l15;
-            const float bv = bias ? Tr::to_f32(bias[fm]) : 0.f;
-#pragma unroll
-            for (int jp = 0; jp < 2; ++jp) {
-                unsigned pk[2][2];
-#pragma unroll
-                for (int t2 = 0; t2 < 2; ++t2) {
-                    const int col = n0 + wn * 64 + (jp * 2 + t2) * 16 + g4 * 4;
-                    const int im = col / p.hw, pix = col - im * p.hw; // hwp == hw here
-                    float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        v[r] = acc[i][jp * 2 + t2][r] + bv;
-                    if (p.res) {
-                        const u32x2_t rk = *(const u32x2_t *)((const unsigned short *)p.res + ((long)im * p.f + fm) * p.hw + pix);
-                        v[0] += Tr::to_f32((unsigned short)(rk[0] & 0xffff)); v[1] += Tr::to_f32((unsigned short)(rk[0] >> 16));
-                        v[2] += Tr::to_f32((unsigned short)(rk[1] & 0xffff)); v[3] += Tr::to_f32((unsigned short)(rk[1] >> 16));
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        v[r] = apply_act(v[r], p.act);
-                    pk[t2][0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
-                    pk[t2][1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
-                }
-                const unsigned s0 = odd ? pk[0][0] : pk[1][0], s1 = odd ? pk[0][1] : pk[1][1];
-                const unsigned r0 = (unsigned)__shfl_xor((int)s0, 16), r1 = (unsigned)__shfl_xor((int)s1, 16);
-                u32x4_t o;
-                if (odd) { o[0] = r0; o[1] = r1; o[2] = pk[1][0]; o[3] = pk[1][1]; }
-                else { o[0] = pk[0][0]; o[1] = pk[0][1]; o[2] = r0; o[3] = r1; }
-                const int col = n0 + wn * 64 + (jp * 2 + (odd ? 1 : 0)) * 16 + (g4 & ~1) * 4;
-                const int im = col / p.hw, pix = col - im * p.hw;
-                *(u32x4_t *)(Y + ((long)im * p.f + fm) * p.hw + pix) = o;
-            }
-        }
+    if (p.wide_epilogue == 1 && !p.res && (p.hw & 1) == 0) { // workgroup-uniform
+        __syncthreads(); // the K-loop's stages are dead: reuse them as the waves' staging images
+        conv_tile_epilogue_lds<Tr>(p, acc, bias_v, m0, n0, wm, wn, lane, smem + w * kEpiWaveBytes);
         return;
     }
+    conv_tile_epilogue<Tr>(p, acc, m0, n0, wm, wn, l15, g4);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pointwise (1x1, pad 0) convolutions with few input channels (C <= 256): ResNet's 64->256, 128->512, 256->1024
+// expansions and their siblings. With 1-4 K-steps per 128 x 128 tile the per-tile prologue (first-load latency) and the
+// epilogue of conv_s1_kernel are not hidden by anything and the X tile is re-fetched for every filter tile (measured:
+// 256->1024 @14x14 bs128 81 us against a ~12 us HBM floor). Here ONE workgroup owns a 128-slot column tile, keeps the
+// whole [C][128] input tile RESIDENT in LDS (read from HBM exactly once) and walks over all filter tiles: the weight
+// tile of the next K-step / next filter tile is in flight during the MFMAs and during the epilogue of the current tile,
+// so the pipeline never drains. Same fragment layouts, MFMA roles and epilogue as conv_s1_kernel<2, 2, 64>.
+// LDS: 2 x 18 KiB weight stages + C x 256 B (64 KiB at C = 256).
+// ------------------------------------------------------------------------------------------------
+// Workgroup barrier that orders LDS traffic only. __syncthreads() also drains vmcnt(0), i.e. waits for the output stores
+// of the tile just finished -- with one workgroup per CU that put the whole store latency on every filter tile.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <typename Tr, int NKB>
+__global__ __launch_bounds__(256, (NKB <= 2 ? 2 : 1)) void conv_pw_kernel(ConvS1Args p) {
+    constexpr int WN = 2, BK = 64, BM = 128, BN = 128, APITCH = BK + 8;
+    constexpr int A_BYTES = BM * APITCH * 2, ROWB = BN * 2, B_BYTES = BK * ROWB;
+    constexpr int NA = BM * (BK / 8) / 256; // 4
+    constexpr int CPR = BN / 8;             // 16 runs per k-row
+    constexpr int KSTEP = 256 / CPR;        // 16 k-rows per pass
+    constexpr int NB = BK / KSTEP;          // 4
+    extern __shared__ __attribute__((aligned(16))) char smem[]; // [ A block 0 .. NKB-1 | B block 0 .. NKB-1 ]
+    char *const bres = smem + NKB * A_BYTES;
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wm = w / WN, wn = w % WN;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    // neighbouring column tiles complete each other's cache lines (rows of 2 * hw bytes are rarely line aligned):
+    // keep them on one XCD, i.e. behind one L2
+    const int n0 = (int)xcd_remap(blockIdx.x, gridDim.x) * BN;
+    const unsigned short *Wp = (const unsigned short *)p.w; // [F][C]
+    const __amdgpu_buffer_rsrc_t xrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.x), 0, (int)p.x_bytes, 0x00020000);
+
+    int a_row[NA], a_kc[NA], a_lds[NA];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = n0 + wn * 64 + j * 16 + g4 * 4;
-        if (col >= p.ncols)
-            continue;
-        const int im = col / p.hwp, pix = col - im * p.hwp;
-        if (pix >= p.hw)
-            continue;
+    for (int i = 0; i < NA; ++i) {
+        const int ch = t + i * 256;
+        a_row[i] = ch / (BK / 8);
+        a_kc[i] = (ch % (BK / 8)) * 8;
+        a_lds[i] = (a_row[i] * APITCH + a_kc[i]) * 2;
+    }
+    const int cchunk = t % CPR, krow0 = t / CPR;
+    int col8 = n0 + cchunk * 8;
+    col8 = col8 < p.ncols ? col8 : 0; // slots past the last image: compute on column 0, never stored
+    const int img = col8 / p.hwp, pp = col8 - img * p.hwp;
+    // runs are dword aligned (hw even, pp % 8 == 0): the descriptor's range check zeroes whole dwords past the tensor,
+    // which can only be pad slots of the last row
+    const int b_base = (int)((((long)img * p.c + krow0) * p.hw + pp) * 2);
+    const int kstep_bytes = KSTEP * p.hw * 2, kblock_bytes = BK * p.hw * 2;
+    int b_lds[NB];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int fm = m0 + wm * 64 + i * 16 + l15;
-            if (fm >= p.f)
-                continue;
-            const float bv = bias ? Tr::to_f32(bias[fm]) : 0.f;
-            const long yoff = ((long)im * p.f + fm) * p.hw + pix;
-            float v[4];
+    for (int i = 0; i < NB; ++i) {
+        const int kr = krow0 + i * KSTEP;
+        b_lds[i] = kr * ROWB + ((cchunk ^ (f128::mn_f(kr) << 1)) * 16);
+    }
+    const int a_frag = ((wm * 64 + l15) * APITCH + g4 * 8) * 2;
+    int b_frag[2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                v[r] = acc[i][j][r] + bv;
-            if (p.res) {
-                const unsigned short *rp = (const unsigned short *)p.res + yoff;
-                if (vec_ok && pix + 3 < p.hw && ((((uintptr_t)p.res) & 7) == 0)) {
-                    const u32x2_t rk = *(const u32x2_t *)rp;
-                    v[0] += Tr::to_f32((unsigned short)(rk[0] & 0xffff)); v[1] += Tr::to_f32((unsigned short)(rk[0] >> 16));
-                    v[2] += Tr::to_f32((unsigned short)(rk[1] & 0xffff)); v[3] += Tr::to_f32((unsigned short)(rk[1] >> 16));
-                } else {
+    for (int hh = 0; hh < 2; ++hh)
+        b_frag[hh] = (g4 * 8 + hh * 4 + (l15 >> 2)) * ROWB + (l15 & 1) * 8;
+    const int mnf_lane[2] = {f128::mn_f(g4 * 8 + (l15 >> 2)), f128::mn_f(g4 * 8 + 4 + (l15 >> 2))};
+
+    // the input tile: all C rows, once
+    {
+        u32x4_t b_reg[NKB][NB];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (pix + r < p.hw)
-                            v[r] += Tr::to_f32(rp[r]);
-                }
-            }
+        for (int kt = 0; kt < NKB; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                v[r] = apply_act(v[r], p.act);
-            unsigned short *dst = Y + yoff;
-            if (vec_ok && pix + 3 < p.hw) {
-                u32x2_t pk;
-                pk[0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
-                pk[1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
-                *(u32x2_t *)dst = pk;
-            } else {
+            for (int i = 0; i < NB; ++i)
+                b_reg[kt][i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, b_base + kt * kblock_bytes + i * kstep_bytes, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (pix + r < p.hw)
-                        dst[r] = Tr::from_f32(v[r]);
-            }
+        for (int kt = 0; kt < NKB; ++kt)
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                *(u32x4_t *)(bres + kt * B_BYTES + b_lds[i]) = b_reg[kt][i];
+    }
+    // weights: the whole [128][C] tile of the NEXT filter tile is in flight during the MFMAs and the epilogue of the
+    // current one (one K-step of lookahead, ~0.3 us, cannot cover an L2 round trip; a tile can)
+    s16x8_t a_reg[NKB][NA];
+    auto load_tile_a = [&](int tm) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            int gm = tm * BM + a_row[i];
+            gm = gm < p.f ? gm : p.f - 1; // rows past F re-read the last filter; never stored
+            const unsigned short *src = Wp + (long)gm * p.c + a_kc[i];
+#pragma unroll
+            for (int kt = 0; kt < NKB; ++kt)
+                a_reg[kt][i] = *(const s16x8_t *)(src + kt * BK);
         }
+    };
+    auto store_tile_a = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int kt = 0; kt < NKB; ++kt)
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                *(s16x8_t *)(smem + kt * A_BYTES + a_lds[i]) = a_reg[kt][i];
+    };
+
+    f32x4 acc[4][4];
+    auto compute = [&](const char *astage, const char *bblk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            s16x8_t af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                af[i] = *(const s16x8_t *)(astage + a_frag + i * 16 * APITCH * 2 + ks * 64);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cblk = (wn * 64 + j * 16) >> 3;
+                s16x4_t h[2];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int c16 = (cblk + ((l15 >> 1) & 1)) ^ (mnf_lane[hh] << 1);
+                    const char *addr = bblk + ks * 32 * ROWB + b_frag[hh] + c16 * 16;
+                    h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t *)(addr));
+                }
+                bf[j] = s16x8_t{h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = Tr::mfma(bf[j], af[i], acc[i][j]);
+        }
+    };
+
+    const bool lds_epi = p.wide_epilogue == 1 && !p.res; // hw is even here
+    char *const epi = NKB >= 2 ? smem : bres + NKB * B_BYTES; // NKB == 1: 18 KiB of weights is too small, own region
+    float bias_v[4], bias_n[4];
+    load_tile_a(0);
+    conv_load_bias<Tr>(p, 0, wm, l15, bias_n);
+    store_tile_a();
+    __syncthreads();
+    for (int tm = 0; tm < p.tiles_m; ++tm) {
+        const bool has_next = tm + 1 < p.tiles_m;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            bias_v[i] = bias_n[i];
+        if (has_next) {
+            load_tile_a(tm + 1);
+            conv_load_bias<Tr>(p, (tm + 1) * BM, wm, l15, bias_n);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < NKB; ++kt)
+            compute(smem + kt * A_BYTES, bres + kt * B_BYTES);
+        if (lds_epi) {
+            if constexpr (NKB >= 2)
+                lds_barrier(); // the weight blocks are dead until store_tile_a: stage the output tile there
+            conv_tile_epilogue_lds<Tr>(p, acc, bias_v, tm * BM, n0, wm, wn, lane, epi + w * kEpiWaveBytes);
+        } else {
+            conv_tile_epilogue<Tr>(p, acc, tm * BM, n0, wm, wn, l15, g4);
+        }
+        if (has_next) {
+            lds_barrier(); // every wave is done reading this tile's weights (and its staging image)
+            store_tile_a();
+            lds_barrier();
+        }
+    }
+}
+
+template <typename Tr, int NKB> static int launch_pw_n(infiniRocmRuntime_t rt, ConvS1Args &p) {
+    constexpr int LDS = NKB * (128 * 72 * 2 + 64 * 256) + (NKB == 1 ? 4 * kEpiWaveBytes : 0);
+    auto kern = conv_pw_kernel<Tr, NKB>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        IROCM_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.tiles_n), dim3(256), LDS, rt->stream, p);
+    IROCM_LAUNCH_CHECK("conv_pw");
+    return INFINI_ROCM_OK;
+}
+template <typename Tr> static int launch_pw(infiniRocmRuntime_t rt, ConvS1Args &p) {
+    p.tiles_m = (int)ceil_div(p.f, 128);
+    p.tiles_n = (int)ceil_div(p.ncols, 128);
+    switch (p.c / 64) {
+    case 1: return launch_pw_n<Tr, 1>(rt, p);
+    case 2: return launch_pw_n<Tr, 2>(rt, p);
+    case 3: return launch_pw_n<Tr, 3>(rt, p);
+    default: return launch_pw_n<Tr, 4>(rt, p);
     }
 }
 
@@ -592,6 +902,8 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
     p.act = act;
     static const int wide = getenv("IROCM_CONV_WIDE") ? atoi(getenv("IROCM_CONV_WIDE")) : 1;
     p.wide_epilogue = wide;
+    static const int epi_probe = getenv("IROCM_CONV_EPI_PROBE") ? atoi(getenv("IROCM_CONV_EPI_PROBE")) : 0;
+    p.epi_probe = epi_probe;
     p.plane_elems = (long)n * c * p.hw;
     // phases read by some tap
     PhaseSplitArgs ps;
@@ -671,6 +983,9 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
         p.x = ps.o;
     }
     const bool bf = dtype == INFINI_DT_BF16;
+    static const int pw_on = getenv("IROCM_CONV_PW") ? atoi(getenv("IROCM_CONV_PW")) : 1; // tuning hook: 0 = off
+    if (pw_on && r == 1 && s == 1 && ph == 0 && pw == 0 && c % 64 == 0 && c <= (pw_on == 2 ? 256 : 128) && f > 64 && p.hw % 2 == 0)
+        return bf ? launch_pw<Bf16Traits>(rt, p) : launch_pw<F16Traits>(rt, p);
     if (rowtap)
         return bf ? launch_s1<Bf16Traits, 1, 4, 32, true>(rt, p) : launch_s1<F16Traits, 1, 4, 32, true>(rt, p);
     if (f <= 64)

@@ -75,6 +75,12 @@ S1_CONVS = [
     (4, 256, 14, 14, 64, 1, 1),   # pointwise, F <= 64 tile
     (1, 64, 56, 56, 64, 3, 3),    # ResNet stage-1 3x3
     (130, 64, 2, 2, 8, 3, 3),     # many tiny images per tile
+    # pointwise, C <= 256, F > 64: conv_pw_kernel (input tile resident in LDS, loop over filter tiles)
+    (3, 64, 8, 8, 256, 1, 1),      # one K-step per filter tile, two filter tiles, 1.5 column tiles
+    (2, 128, 14, 14, 200, 1, 1),   # two K-steps, ragged filter count, 196-pixel planes (pad slots, tile spans images)
+    (5, 256, 14, 14, 1024, 1, 1),  # ResNet 256 -> 1024 @14x14: four K-steps x eight filter tiles
+    (1, 192, 6, 5, 65, 1, 1),      # C = 192 (three K-steps), a single valid row in the second filter tile, tiny plane
+    (2, 256, 28, 28, 512, 1, 1, 2, 2, 1, 1),  # 1x1/2 down-sample: pointwise on the phase plane
     # strided: phase planes (conv_phase_split); n, c, h, w, f, r, s, sh, sw, dh, dw
     (3, 64, 14, 14, 96, 3, 3, 2, 2, 1, 1),    # ResNet 3x3/2 (all four phases)
     (2, 128, 28, 28, 256, 1, 1, 2, 2, 1, 1),  # ResNet 1x1/2 down-sample (one phase)
