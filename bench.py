@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="skip the ResNet-50 graph-latency row")
     ap.add_argument("--no-tp", action="store_true", help="skip the tensor-parallel block timing")
+    ap.add_argument("--secondary-timeout", type=float, default=420.0,
+                    help="seconds the secondary sections (TP block, graphs, CPU baseline, extras) may take before the "
+                         "headline line is printed without them and the process ends")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -406,57 +409,80 @@ def main() -> int:
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    tp_res = None
-    if not args.no_tp:
-        try:  # never let the secondary measurement take the headline line down
-            tp_res = tp_block(rt, ops, Event, world, rank, td if dist else None)
-        except Exception as e:  # noqa: BLE001
-            tp_res = {"error": repr(e)[:300]}
-
-    rn_res = None
-    if not args.no_graph:
-        try:
-            rn_res = graph_resnet50(local_rank, world, td if dist else None)
-        except BaseException as e:  # noqa: BLE001  (SystemExit when the plugin build is absent)
-            rn_res = {"error": repr(e)[:300]}
-
     flop_per_step = 2.0 * M * N * K
     value = world * args.steps * flop_per_step / elapsed / 1e12
     achieved = flop_per_step / kernel_s / 1e12
 
-    if rank == 0:
-        line = {
-            "metric": "bf16 MatMul 4096x4096x4096 throughput (GEMM TFLOP/s, % dense MFMA peak)",
-            "value": round(value, 2),
+    # The headline part of the line is complete here. Everything below is secondary (TP block, ResNet-50 graph, CPU
+    # baseline, extras): a watchdog prints the line with what has been gathered and ends the process if a secondary
+    # section stalls (e.g. a rank lost inside a collective), so the headline measurement always reaches the driver.
+    line = {
+        "metric": "bf16 MatMul 4096x4096x4096 throughput (GEMM TFLOP/s, % dense MFMA peak)",
+        "value": round(value, 2),
+        "unit": "TFLOP/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic (N(0,1) rounded to bf16, seeded)",
+        "config": {
+            "workload": "BASELINE configs[1]: one bf16 MatMul M=N=K=4096 per GPU, NN layout, fp32 accumulate, via infini_rocm_matmul",
+            "kernel_variant": ops.matmul_variants()[args.variant] if args.variant >= 0 else "heuristic",
+            "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"],
+            "clock_mhz": info["clock_mhz"],
+            "parallelism": f"{world} independent replicas (column-sharded GEMM has no collective)",
+        },
+        "roofline": {
+            "bound": "mfma",
+            "achieved": round(achieved, 2),
+            "peak": PEAK_BF16_TFLOPS,
             "unit": "TFLOP/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "bf16",
-            "data": "synthetic (N(0,1) rounded to bf16, seeded)",
-            "config": {
-                "workload": "BASELINE configs[1]: one bf16 MatMul M=N=K=4096 per GPU, NN layout, fp32 accumulate, via infini_rocm_matmul",
-                "kernel_variant": ops.matmul_variants()[args.variant] if args.variant >= 0 else "heuristic",
-                "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"],
-                "clock_mhz": info["clock_mhz"],
-                "parallelism": f"{world} independent replicas (column-sharded GEMM has no collective)",
-            },
-            "roofline": {
-                "bound": "mfma",
-                "achieved": round(achieved, 2),
-                "peak": PEAK_BF16_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                "traffic": pmc_traffic(),
-                "traffic_source": "profiles/r01_gemm256_v2_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel and shape; bytes per launch, FETCH_SIZE x2 per the gfx950 note)",
-                "kernel_us": round(kernel_s * 1e6, 3),
-                "peak_from_device": round(info["compute_units"] * 4096 * info["clock_mhz"] * 1e6 / 1e12, 1),
-            },
-        }
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+            "traffic": pmc_traffic(),
+            "traffic_source": "profiles/r01_gemm256_v2_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel and shape; bytes per launch, FETCH_SIZE x2 per the gfx950 note)",
+            "kernel_us": round(kernel_s * 1e6, 3),
+            "peak_from_device": round(info["compute_units"] * 4096 * info["clock_mhz"] * 1e6 / 1e12, 1),
+        },
+    }
+    import ctypes
+    import threading
+
+    printed = threading.Lock()
+
+    def emit(extra: dict | None = None) -> None:
+        if not printed.acquire(blocking=False):
+            return
+        if rank == 0:
+            if extra:
+                line.update(extra)
+            ctypes.CDLL(None).fflush(None)  # RCCL prints a version banner through C stdio: keep the JSON line last
+            print(json.dumps(line), flush=True)
+
+    def watchdog():
+        emit({"secondary_timeout_s": args.secondary_timeout})
+        os._exit(0)
+
+    wd = threading.Timer(args.secondary_timeout, watchdog)
+    wd.daemon = True
+    wd.start()
+
+    if not args.no_tp:
+        try:  # never let the secondary measurement take the headline line down
+            line["tp_block"] = tp_block(rt, ops, Event, world, rank, td if dist else None)
+        except Exception as e:  # noqa: BLE001
+            line["tp_block"] = {"error": repr(e)[:300]}
+
+    if not args.no_graph:
+        try:
+            line["graph_resnet50"] = graph_resnet50(local_rank, world, td if dist else None)
+        except BaseException as e:  # noqa: BLE001  (SystemExit when the plugin build is absent)
+            line["graph_resnet50"] = {"error": repr(e)[:300]}
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
                 cb = cpu_baseline_reference()
@@ -468,22 +494,16 @@ def main() -> int:
                 line["cpu_standin_mkl"] = cpu_standin_mkl()
             except Exception as e:
                 line["cpu_standin_mkl"] = {"error": repr(e)}
-        if tp_res is not None:
-            line["tp_block"] = tp_res
-        if rn_res is not None:
-            line["graph_resnet50"] = rn_res
         if world == 1 and not args.no_extras:
             try:
                 line["extras"] = extras(rt, ops, Event)
             except Exception as e:
                 line["extras"] = {"error": repr(e)}
-        import ctypes
-
-        ctypes.CDLL(None).fflush(None)  # RCCL prints a version banner through C stdio: keep the JSON line last
-        print(json.dumps(line), flush=True)
-    if dist:
+    emit()
+    if dist:  # the watchdog stays armed: a rank that never reaches this barrier must not hold the others
         td.barrier()
         td.destroy_process_group()
+    wd.cancel()
     return 0
 
 

@@ -48,3 +48,150 @@ def test_resnet50_logits_match_the_reference_cpu_backend(plugin_backend):
         assert np.abs(gotg - want).max() <= 1e-4 * scale
     finally:
         rocm.set_fusion(True)
+
+
+def _bert_oracle(feeds, batch, seq, layers, hidden, heads):
+    """fp64 restatement of tools/model_bench.py::build_bert over the very arrays fed to the graph (in creation
+    order), written with the pinned oracle ops (oracle/ref_ops.py)."""
+    from oracle import ref_ops as R
+
+    it = iter([np.asarray(a) for _, a in feeds])
+    nxt = lambda: next(it).astype(np.float64)
+    ids = next(it)
+    emb, pos, mask, scale = nxt(), nxt(), nxt(), nxt()
+    D = hidden // heads
+
+    def ln(t):
+        g, b = nxt(), nxt()
+        return R.layer_norm(t, g, b, 1e-12, 2)
+
+    def linear(t):
+        w, b = nxt(), nxt()
+        return R.matmul(t, w, b)
+
+    x = ln(R.gather(emb, ids, 0) + pos)
+    for _ in range(layers):
+        hd = lambda t: t.reshape(batch, seq, heads, D).transpose(0, 2, 1, 3)
+        q, k, v = hd(linear(x)), hd(linear(x)), hd(linear(x))
+        p = R.softmax(q @ k.transpose(0, 1, 3, 2) / scale + mask, 3)
+        ctx = (p @ v).transpose(0, 2, 1, 3).reshape(batch, seq, hidden)
+        x = ln(x + linear(ctx))
+        x = ln(x + linear(R.unary("gelu", linear(x))))
+    assert next(it, None) is None  # every fed array was consumed: the restatement walks the same graph
+    return x
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-4), ("f16", 3e-2)])
+def test_bert_encoder_end_to_end_vs_oracle(plugin_backend, dtype, tol):
+    """BASELINE config 4 on a small slice: embedding Gather (int64 ids) -> LayerNorm -> 2 encoder layers with the
+    decomposed attention chain (key-padding mask), Gelu FFN and residual LayerNorms, through the reference executor on
+    Device::ROCM — fused launches (attention, Add->LayerNorm), one kernel per operator, and hipGraph replay — against
+    the fp64 oracle. fp32: 1e-4 of the output scale (north_star); f16: storage rounding through 2 layers."""
+    from model_bench import Builder, build_bert
+
+    B = plugin_backend
+    batch, seq, layers, hidden, heads, ffn, vocab = 2, 128, 2, 128, 2, 512, 1000
+    rocm = B.RocmRuntime(0)
+    results = {}
+    want = None
+    try:
+        for mode in ("fused", "unfused", "hipgraph"):
+            rocm.set_fusion(mode != "unfused")
+            bl = Builder(B, rocm, dtype, seed=3)
+            out = build_bert(bl, batch, seq, layers, hidden, heads, ffn, vocab)
+            # key-padding mask: the last 17 keys of sequence 1 are masked out (additive -1e4 as exported BERT graphs do)
+            m = np.zeros((batch, 1, 1, seq), bl.np)
+            m[1, 0, 0, -17:] = -1e4
+            bl.feeds[3] = (bl.feeds[3][0], m)
+            bl.finish()
+            if mode == "hipgraph":
+                bl.h.run_with_hipgraph()
+                for t, a in bl.feeds:
+                    t.copyin_numpy(np.ascontiguousarray(a))
+                bl.h.run_with_hipgraph()
+            else:
+                before = rocm.fused_launch_count()
+                bl.h.run()
+                fused = rocm.fused_launch_count() - before
+                # per layer: two Add->LayerNorm launches, plus one attention launch where the fused kernel exists (f16/bf16)
+                floor = (3 if dtype == "f16" else 2) * layers
+                assert (fused >= floor) if mode == "fused" else (fused == 0), (mode, fused)
+            results[mode] = out.copyout_numpy().astype(np.float64).reshape(batch, seq, hidden)
+            if want is None:
+                want = _bert_oracle(bl.feeds, batch, seq, layers, hidden, heads)
+    finally:
+        rocm.set_fusion(True)
+    scale = np.abs(want).max()
+    for mode, got in results.items():
+        assert np.isfinite(got).all(), mode
+        assert np.abs(got - want).max() <= tol * scale, (mode, np.abs(got - want).max(), scale)
+    assert np.array_equal(results["fused"], results["hipgraph"])
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-4), ("f16", 3e-2)])
+def test_llama_block_through_reference_executor_vs_oracle(plugin_backend, dtype, tol):
+    """BASELINE config 5 at TP = 1 on a small slice, through the reference executor on Device::ROCM: RMSNorm -> q/k/v
+    MatMul -> RoPE -> head split -> causal attention chain -> o_proj -> AllReduceSum (1-rank RCCL communicator, the
+    operator parallel_opt.py inserts) -> residual -> RMSNorm -> gate/up/SiLU/Mul -> down -> AllReduceSum -> residual,
+    against the fp64 oracle of the same (rounded) operands: fp32 1e-4 of the output scale, f16 storage rounding."""
+    from oracle import ref_ops as R
+
+    B = plugin_backend
+    F32, U32 = {"f32": 1, "f16": 10}[dtype], 12
+    npdt = {"f32": np.float32, "f16": np.float16}[dtype]
+    Bt, S, NH, D, F = 2, 64, 2, 128, 384
+    H = NH * D
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((Bt, S, H)).astype(npdt)
+    W = {k: (rng.standard_normal((H, H)) / 16).astype(npdt) for k in "qkvo"}
+    Wg, Wu = ((rng.standard_normal((H, F)) / 16).astype(npdt) for _ in range(2))
+    Wd = (rng.standard_normal((F, H)) / 20).astype(npdt)
+    n1, n2 = (1 + 0.1 * rng.standard_normal(H)).astype(npdt), (1 + 0.1 * rng.standard_normal(H)).astype(npdt)
+    pos = np.tile(np.arange(S, dtype=np.uint32), (Bt, 1))
+    causal = np.triu(np.full((S, S), -1e4, npdt), 1).reshape(1, 1, S, S)
+    sc = np.array([np.sqrt(D)], npdt)
+    rocm = B.RocmRuntime(0)
+    rocm.init_comm("llama_block_test_" + dtype, 1, 0)
+    h = B.GraphHandler(rocm)
+    lin = B.ActType.Linear
+    feeds = []
+
+    def T(a, code=F32):
+        t = h.tensor(list(a.shape), code)
+        feeds.append((t, a))
+        return t
+
+    tx = T(x)
+    mm = lambda a, w: h.matmul(a, T(w), None, False, False, None, lin, "default")
+    tpos, tsc, tmask = T(pos, U32), T(sc), T(causal)
+    hn = h.RMSNorm(tx, T(n1), None)
+    heads = lambda t: h.transpose(h.reshape(t, None, [Bt, S, NH, D]), None, [0, 2, 1, 3])
+    q, k = heads(h.RoPE(tpos, mm(hn, W["q"]), None)), heads(h.RoPE(tpos, mm(hn, W["k"]), None))
+    v = heads(mm(hn, W["v"]))
+    s = h.add(h.div(h.matmul(q, k, None, False, True, None, lin, "default"), tsc, None), tmask, None)
+    ctx = h.matmul(h.softmax(s, None, 3), v, None, False, False, None, lin, "default")
+    ctx = h.reshape(h.transpose(ctx, None, [0, 2, 1, 3]), None, [Bt, S, H])
+    x1 = h.add(tx, h.allReduceSum(mm(ctx, W["o"]), None), None)
+    h2 = h.RMSNorm(x1, T(n2), None)
+    act = h.mul(h.silu(mm(h2, Wg), None), mm(h2, Wu), None)
+    out = h.add(x1, h.allReduceSum(mm(act, Wd), None), None)
+    h.data_malloc()
+    for t, a in feeds:
+        t.copyin_numpy(np.ascontiguousarray(a))
+    h.run()
+    got = out.copyout_numpy().astype(np.float64).reshape(Bt, S, H)
+
+    X = x.astype(np.float64)
+    W = {k: w.astype(np.float64) for k, w in W.items()}
+    Wg, Wu, Wd, n1, n2 = (a.astype(np.float64) for a in (Wg, Wu, Wd, n1, n2))
+    hd = lambda t: t.reshape(Bt, S, NH, D).transpose(0, 2, 1, 3)
+    hn_ = R.rms_norm(X, n1, 1e-5)
+    q_, k_ = hd(R.rope(pos, hn_ @ W["q"], D)), hd(R.rope(pos, hn_ @ W["k"], D))
+    v_ = hd(hn_ @ W["v"])
+    p_ = R.softmax(q_ @ k_.transpose(0, 1, 3, 2) / float(sc[0]) + causal.astype(np.float64), 3)
+    ctx_ = (p_ @ v_).transpose(0, 2, 1, 3).reshape(Bt, S, H)
+    x1_ = X + ctx_ @ W["o"]
+    h2_ = R.rms_norm(x1_, n2, 1e-5)
+    want = x1_ + (R.unary("silu", h2_ @ Wg) * (h2_ @ Wu)) @ Wd
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= tol * np.abs(want).max(), (np.abs(got - want).max(), np.abs(want).max())
