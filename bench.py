@@ -179,7 +179,7 @@ def graph_resnet50(local_rank: int, world: int, dist_mod) -> dict:
     sys.path.insert(0, str(REPO / "tools"))
     from model_bench import run_model
 
-    r = run_model("resnet50", local_rank, 128, iters=10)
+    r = run_model("resnet50", local_rank, 128, iters=10, tune=True)
     mm = run_model("matmul", local_rank, dtype="f16", iters=50)  # one-operator graph: executor overhead per launch
     ms = torch.tensor([r["hipgraph_ms"], r["eager_ms"]], device="cuda", dtype=torch.float64)
     if world > 1:
@@ -189,6 +189,8 @@ def graph_resnet50(local_rank: int, world: int, dist_mod) -> dict:
                         + ("on" if r["fusion"] else "off"),
             "hipgraph_ms": round(g, 3), "eager_ms": round(e, 3), "samples_per_s": round(world * 128 / g * 1e3, 0),
             "conv_gemm_TFLOPs_aggregate": round(world * r["gemm_conv_TFLOP"] / g * 1e3, 1), "ops": r["ops"], "finite": r["finite"],
+            # this rank's figures after the reference's h.tune() (MatMul / Conv choose their kernel by measurement)
+            "autotuned": {k: r[k] for k in ("tuned_hipgraph_ms", "tuned_eager_ms", "tune_seconds", "tuned_picks") if k in r},
             "matmul_4096_f16_via_executor": {"eager_ms_incl_sync": mm["eager_ms"], "hipgraph_ms_incl_sync": mm["hipgraph_ms"],
                                              "hipgraph_TFLOPs": mm["hipgraph_TFLOPs"]}}
 

@@ -73,6 +73,10 @@ PATCHES = [
      "        .def(\"set_fusion\", &RocmRuntimeObj::setFusion)\n"
      "        .def(\"get_fusion\", &RocmRuntimeObj::getFusion)\n"
      "        .def(\"fused_launch_count\", &RocmRuntimeObj::getFusedLaunchCount)\n"
+     "        .def_static(\"save_perf\", &RocmRuntimeObj::savePerfData)\n"
+     "        .def_static(\"load_perf\", &RocmRuntimeObj::loadPerfData)\n"
+     "        .def_static(\"clear_perf\", &RocmRuntimeObj::clearPerfData)\n"
+     "        .def_static(\"perf_size\", &RocmRuntimeObj::perfDataSize)\n"
      "        .def(\"init_comm\", &RocmRuntimeObj::initComm);\n"
      "#endif\n"
      "#ifdef USE_BANG\n    py::class_<BangRuntimeObj, std::shared_ptr<BangRuntimeObj>, RuntimeObj>("),
@@ -142,7 +146,7 @@ def build(verbose: bool = True) -> Path | None:
                     continue
                 rel = str(f.relative_to(REF))
                 srcs.append(patched.get(rel, f))
-        srcs.append(REPO / "oracle" / "shim" / "perf_engine_stub.cc")
+        # perf_engine.cc's replacement is plugin/src/rocm_perf.cc (JSON persistence written for json 3.1.1)
         srcs.extend(plugin_srcs)
         # every TU sees the patched runtime.h, so nothing can be shared with oracle/_ref's objects
         objdir = OUT / "obj"

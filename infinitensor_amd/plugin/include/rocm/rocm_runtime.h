@@ -56,6 +56,14 @@ class RocmRuntimeObj : public RuntimeObj {
     bool getFusion() const { return fusion; }
     size_t getFusedLaunchCount() const { return fusedCount; } // fused kernels launched so far (tests)
 
+    // the autotune cache: h.tune() fills the process-wide PerfEngine (MatMul / Conv pick among their kernel variants,
+    // rocm/rocm_perf.h); these persist it as JSON and bring it back (reference: PerfEngine::savePerfEngineData /
+    // loadPerfEngineData, src/core/perf_engine.cc:7-21 — not exported to Python there)
+    static void savePerfData(const string &path);
+    static void loadPerfData(const string &path);
+    static void clearPerfData();
+    static size_t perfDataSize();
+
     void initComm(const string &name, int worldSize, int rank) final;
     CommunicatorObj &getCommunicator() const final;
 
@@ -93,6 +101,7 @@ class RocmRuntimeObj : public RuntimeObj {
     // launches ops[i .. i+k) as one kernel when a fusion rule applies; returns k (0 = no rule)
     size_t tryLaunchFused(const OpVec &ops, size_t i) const;
     size_t tryLaunchFusedAttention(const OpVec &ops, size_t i) const;
+    int tunedVariant(const Operator &op) const; // kernel variant chosen by tune() for this operator's workload, or -1
     void tuneImpl(const Graph &graph, bool profiling) const;
     GraphState stateOf(const Graph &graph) const;
     void replay(CacheEntry &entry);

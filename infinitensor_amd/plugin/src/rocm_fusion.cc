@@ -25,7 +25,9 @@
 // Numerics: fp32 is bit-identical (same operations in the same order); f16 / bf16 round once instead of after
 // every op (a result at least as close to the exact value); Add -> Relu is bit-identical in every type.
 // INFINI_ROCM_FUSION=0 or RocmRuntimeObj::setFusion(false) restores one kernel per operator.
+#include "core/perf_engine.h"
 #include "operators/conv.h"
+#include "rocm/rocm_perf.h"
 #include <cstdlib>
 #include <string>
 #include "operators/element_wise.h"
@@ -158,6 +160,12 @@ size_t RocmRuntimeObj::tryLaunchFusedAttention(const OpVec &ops, size_t i) const
     return j + 1 - i;
 }
 
+int RocmRuntimeObj::tunedVariant(const Operator &op) const {
+    auto key = PerfEngine::Key{KernelAttrs{device, op->getOpType().underlying()}, op->getOpPerfKey()};
+    auto rec = std::dynamic_pointer_cast<RocmVariantPerfRecordObj>(PerfEngine::getInstance().getPerfData(key));
+    return rec ? rec->variant : -1;
+}
+
 size_t RocmRuntimeObj::tryLaunchFused(const OpVec &ops, size_t i) const {
     const Operator &op = ops[i];
     const auto type = op->getOpType();
@@ -221,6 +229,19 @@ size_t RocmRuntimeObj::tryLaunchFused(const OpVec &ops, size_t i) const {
                 continue;
             const auto [n, ch, h, wd, ff, r, s] = conv->getNCHWFRS();
             const auto [ph, pw, sh, sw, dh, dw] = conv->getPadStrideDilation();
+            // a tuned Conv (h.tune(): ConvRocm::tune) keeps its kernel choice when the tail is folded into it
+            struct VariantScope {
+                infiniRocmRuntime_t rt;
+                bool set;
+                VariantScope(infiniRocmRuntime_t rt, int v) : rt(rt), set(v >= 0) {
+                    if (set)
+                        ROCM_CALL(infini_rocm_conv2d_set_variant(rt, v));
+                }
+                ~VariantScope() {
+                    if (set)
+                        (void)infini_rocm_conv2d_set_variant(rt, -1);
+                }
+            } scope(rt, tunedVariant(op));
             ROCM_CALL(infini_rocm_conv2d_res(rt, x->getDTypeIndex(), x->getRawDataPtr<void *>(), w->getRawDataPtr<void *>(),
                                              c.bias ? c.bias->getRawDataPtr<void *>() : nullptr,
                                              c.res ? c.res->getRawDataPtr<void *>() : nullptr, c.last->getRawDataPtr<void *>(),

@@ -1,0 +1,83 @@
+// PerfEngine persistence + the ROCM perf-record types (see rocm/rocm_perf.h).
+//
+// The reference's src/core/perf_engine.cc needs nlohmann-json >= 3.2 (get_to); the only json on the build box is
+// 3.1.1, so this TU provides PerfEngine::savePerfEngineData / loadPerfEngineData itself, written against the 3.1 API
+// and producing the document the reference's serialisers produce:
+//   {"data": [ [ [[device, opType], {"hashType": h, "opType": t, "attrs": [..]}], {"type": id, "data": ..} ], .. ]}
+// (a std::map with a non-string key is an array of [key, value] pairs; a pair / tuple is an array).
+#include "rocm/rocm_perf.h"
+#include "core/perf_engine.h"
+#include <fstream>
+#include <sstream>
+
+namespace infini {
+
+void RocmVariantPerfRecordObj::to_json(json &j) {
+    j["type"] = recordType;
+    j["data"] = json::array({variant, time});
+}
+
+PerfRecord RocmVariantPerfRecordObj::from_json(const json &j) {
+    auto r = make_ref<RocmVariantPerfRecordObj>();
+    r->recordType = j["type"].get<int>();
+    r->variant = j["data"][0].get<int>();
+    r->time = j["data"][1].get<double>();
+    return r;
+}
+
+std::string perfEngineToJson() {
+    json entries = json::array();
+    for (const auto &[key, record] : PerfEngine::getInstance().get_data()) {
+        const auto &[attrs, perfKey] = key;
+        json jkey = json::array();
+        jkey.push_back(json::array({(int)std::get<0>(attrs), (int)std::get<1>(attrs)}));
+        json jperf;
+        jperf["hashType"] = perfKey.hash;
+        jperf["opType"] = perfKey.opType;
+        jperf["attrs"] = perfKey.attrs;
+        jkey.push_back(jperf);
+        json jrec;
+        record->to_json(jrec);
+        entries.push_back(json::array({jkey, jrec}));
+    }
+    json doc;
+    doc["data"] = entries;
+    return doc.dump();
+}
+
+void perfEngineFromJson(const std::string &text) {
+    const json doc = json::parse(text);
+    map<PerfEngine::Key, PerfRecord> data;
+    for (const auto &entry : doc.at("data")) {
+        const json &jkey = entry[0], &jrec = entry[1];
+        KernelAttrs attrs{(Device)jkey[0][0].get<int>(), (OpType::underlying_t)jkey[0][1].get<int>()};
+        OpPerfKey perfKey;
+        perfKey.hash = jkey[1].at("hashType").get<HashType>();
+        perfKey.opType = (OpType::underlying_t)jkey[1].at("opType").get<int>();
+        perfKey.attrs = jkey[1].at("attrs").get<vector<int>>();
+        const int type = jrec.at("type").get<int>();
+        data.emplace(PerfEngine::Key{attrs, perfKey}, PerfRecordRegistry::getInstance().getConstructor(type)(jrec));
+    }
+    PerfEngine::getInstance().set_data(data);
+}
+
+void PerfEngine::savePerfEngineData(std::string file_path) {
+    std::ofstream out(file_path, std::ios::out | std::ios::trunc | std::ios::binary);
+    IT_ASSERT(out.good(), "cannot write " + file_path);
+    out << perfEngineToJson() << std::endl;
+}
+
+void PerfEngine::loadPerfEngineData(std::string file_path) {
+    std::ifstream in(file_path, std::ios::in | std::ios::binary);
+    IT_ASSERT(in.good(), "cannot read " + file_path);
+    std::stringstream ss;
+    ss << in.rdbuf();
+    perfEngineFromJson(ss.str());
+}
+
+} // namespace infini
+
+// the macro opens namespace infini itself (kernel.h:197-205)
+REGISTER_CONSTRUCTOR(0, PerfRecordObj::from_json);
+REGISTER_CONSTRUCTOR(kRocmMatmulRecord, RocmVariantPerfRecordObj::from_json);
+REGISTER_CONSTRUCTOR(kRocmConvRecord, RocmVariantPerfRecordObj::from_json);

@@ -71,6 +71,11 @@ void RocmRuntimeObj::initComm(const string &name, int worldSize, int rank) {
     comm = std::make_unique<RcclCommunicatorObj>(worldSize, rank);
 }
 
+void RocmRuntimeObj::savePerfData(const string &path) { PerfEngine::getInstance().savePerfEngineData(path); }
+void RocmRuntimeObj::loadPerfData(const string &path) { PerfEngine::getInstance().loadPerfEngineData(path); }
+void RocmRuntimeObj::clearPerfData() { PerfEngine::getInstance().set_data({}); }
+size_t RocmRuntimeObj::perfDataSize() { return PerfEngine::getInstance().get_data().size(); }
+
 CommunicatorObj &RocmRuntimeObj::getCommunicator() const {
     IT_ASSERT(comm != nullptr, "communicator is not initialized (call init_comm)");
     return *comm;

@@ -505,3 +505,69 @@ def test_relu_maxpool_fusion_is_bit_exact(B, rocm):
         assert np.array_equal(got[True], got[False])
         want = R.pool2d(np.maximum(x.astype(np.float64), 0), "max", k, k, 1, 1, pad, pad, st, st, 0)
         assert np.array_equal(got[True].reshape(want.shape).astype(np.float64), want)
+
+
+def test_tune_selects_kernel_variants_and_keeps_results(B, rocm, tmp_path):
+    """h.tune() (reference: RuntimeObj::run(graph, tune = true)) on Device::ROCM: MatMul and Conv time their kernel
+    variants (RocmTunableKernel, the role of the cuBLAS / cuDNN algo sweep in matmul.cc:187-208 / conv.cc:176-244) and
+    leave type-3 / type-4 records in the PerfEngine; runs after that — eager, fused and hipGraph — launch the recorded
+    variant and agree with the untuned result (every variant accumulates in fp32) and with the oracle; the records
+    survive the JSON round trip."""
+    import json
+
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((4, 64, 28, 28)).astype(np.float16)
+    w = (rng.standard_normal((128, 64, 1, 1)) / 8).astype(np.float16)
+    w3 = (rng.standard_normal((128, 128, 3, 3)) / 34).astype(np.float16)
+    bs = rng.standard_normal((1, 128, 1, 1)).astype(np.float16)
+    a = rng.standard_normal((512, 768)).astype(np.float16)
+    m = (rng.standard_normal((768, 768)) / 28).astype(np.float16)
+    lin = B.ActType.Linear
+
+    def net(h, t):
+        y = h.relu(h.add(h.conv(t[0], t[1], None, 0, 0, 1, 1, 1, 1), t[3], None), None)
+        y = h.relu(h.add(h.conv(y, t[2], None, 1, 1, 1, 1, 1, 1), t[3], None), None)
+        return y, h.matmul(t[4], t[5], None, False, False, None, lin, "default")
+
+    ins = [(x.shape, F16, x), (w.shape, F16, w), (w3.shape, F16, w3), (bs.shape, F16, bs), (a.shape, F16, a), (m.shape, F16, m)]
+    B.RocmRuntime.clear_perf()
+    try:
+        h, (yc, ym) = build(B, rocm, net, ins)
+        h.run()
+        c0, m0 = get(yc).astype(np.float64), get(ym).astype(np.float64)
+        h.tune()
+        assert B.RocmRuntime.perf_size() >= 5  # 2 conv workloads, 1 matmul, add, relu
+        p = tmp_path / "perf.json"
+        B.RocmRuntime.save_perf(str(p))
+        recs = json.loads(p.read_text())["data"]
+        types = sorted(r["type"] for _, r in recs)
+        assert types.count(3) == 1 and types.count(4) == 2, types
+        for _, r in recs:
+            if r["type"] in (3, 4):
+                assert -1 <= r["data"][0] <= 7 and r["data"][1] > 0
+        results = []
+        for mode in ("eager", "hipgraph"):
+            hh, (yc2, ym2) = build(B, rocm, net, ins)
+            (hh.run_with_hipgraph if mode == "hipgraph" else hh.run)()
+            results.append((get(yc2).astype(np.float64), get(ym2).astype(np.float64)))
+        # force every non-default variant through the record path as well: same sums whatever tune() picked
+        for conv_v, mm_v in ((1, 0), (2, 1), (3, 6), (2, 7)):
+            forced = {"data": [[k, {"type": r["type"], "data": [conv_v if r["type"] == 4 else mm_v, r["data"][1]]}
+                                if r["type"] in (3, 4) else r] for k, r in recs]}
+            p.write_text(json.dumps(forced))
+            B.RocmRuntime.load_perf(str(p))
+            hh, (yc2, ym2) = build(B, rocm, net, ins)
+            hh.run()
+            results.append((get(yc2).astype(np.float64), get(ym2).astype(np.float64)))
+        X, W, W3, BS = (t.astype(np.float64) for t in (x, w, w3, bs))
+        y1 = np.maximum(R.conv2d(X, W, 0, 0, 1, 1, 1, 1) + BS, 0)
+        y1 = R.round_to(y1, "f16").astype(np.float64)
+        want_c = np.maximum(R.conv2d(y1, W3, 1, 1, 1, 1, 1, 1) + BS, 0)
+        want_m = a.astype(np.float64) @ m.astype(np.float64)
+        for c1, m1 in results:
+            assert np.allclose(c1.reshape(c0.shape), c0, rtol=2e-3, atol=2e-3)
+            assert np.allclose(m1.reshape(m0.shape), m0, rtol=2e-3, atol=2e-3)
+            assert np.allclose(c1.reshape(want_c.shape), want_c, rtol=4e-3, atol=4e-3)
+            assert np.allclose(m1.reshape(want_m.shape), want_m, rtol=4e-3, atol=4e-3)
+    finally:
+        B.RocmRuntime.clear_perf()

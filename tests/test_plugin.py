@@ -47,3 +47,53 @@ def test_native_cpu_path_unchanged(plugin_backend):
     w.copyin_float(list(map(float, range(10))))
     h.run()
     assert np.array_equal(np.array(y.copyout_float()), kat("test/kernels/cuda/test_cuda_matmul.cc", 65, "float"))
+
+
+def test_perf_engine_json_round_trip(plugin_backend, tmp_path):
+    """The autotune cache (plugin/src/rocm_perf.cc): records in the reference's PerfEngine document layout
+    (perf_engine.cc:23-45) — a ROCM MatMul variant record (type 3), a ROCM Conv variant record (type 4) and a plain
+    timing record (type 0) — load, count, save, and come back identical; then records produced by the reference's own
+    tune() on its CPU runtime survive a save / clear / load cycle."""
+    import json
+
+    R = plugin_backend.RocmRuntime
+    R.clear_perf()
+    assert R.perf_size() == 0
+    ROCM = 7  # enum class Device { CPU = 1, ..., ROCM } (build_plugin.py patch of include/core/runtime.h:35)
+    doc = {"data": [
+        [[[ROCM, 101], {"hashType": 1234567890123456789, "opType": 101, "attrs": [101, 1, 4096, 4096, 4096, 0, 0, 0]}],
+         {"type": 3, "data": [7, 0.104]}],
+        [[[ROCM, 30], {"hashType": 42, "opType": 30, "attrs": [30, 128, 64, 56, 56, 64, 3, 3, 1, 1, 1, 1, 1, 1, 0]}],
+         {"type": 4, "data": [2, 0.096]}],
+        [[[1, 5], {"hashType": 7, "opType": 5, "attrs": [5, 2, 3]}], {"type": 0, "data": 3}],
+    ]}
+    src = tmp_path / "perf_in.json"
+    src.write_text(json.dumps(doc))
+    R.load_perf(str(src))
+    assert R.perf_size() == 3
+    dst = tmp_path / "perf_out.json"
+    R.save_perf(str(dst))
+    back = json.loads(dst.read_text())
+    key = lambda e: (e[0][0][0], e[0][0][1], e[0][1]["hashType"])
+    assert sorted(back["data"], key=key) == sorted(doc["data"], key=key)
+
+    # records made by the reference's tune() itself
+    R.clear_perf()
+    b = plugin_backend
+    h = b.GraphHandler(b.cpu_runtime())
+    x, w = h.tensor([3, 5], 1), h.tensor([5, 2], 1)
+    h.relu(h.matmul(x, w, None, False, False, None, b.ActType.Linear, "default"), None)
+    h.data_malloc()
+    x.copyin_float([1.0] * 15)
+    w.copyin_float([1.0] * 10)
+    h.tune()
+    n = R.perf_size()
+    assert n == 2
+    R.save_perf(str(dst))
+    R.clear_perf()
+    assert R.perf_size() == 0
+    R.load_perf(str(dst))
+    assert R.perf_size() == n
+    R.clear_perf()
+    with pytest.raises(RuntimeError):
+        R.load_perf(str(tmp_path / "does_not_exist.json"))

@@ -168,7 +168,9 @@ def timed(fn, iters, warm=2):
 
 
 def run_model(model: str, device: int = 0, batch: int | None = None, seq: int = 512, layers: int = 12,
-              dtype: str = "f16", iters: int = 10) -> dict:
+              dtype: str = "f16", iters: int = 10, tune: bool = False) -> dict:
+    """tune=True additionally runs the reference's h.tune() (MatMul / Conv pick their kernel variant by measurement,
+    plugin/src/rocm_kernels.cc RocmTunableKernel) and times the graph again with the records in the PerfEngine."""
     B = load_backend()
     rt = B.RocmRuntime(device)
     bl = Builder(B, rt, dtype)
@@ -192,7 +194,28 @@ def run_model(model: str, device: int = 0, batch: int | None = None, seq: int = 
     eager = timed(bl.h.run, iters)
     graph = timed(bl.h.run_with_hipgraph, iters)
     y = out.copyout_numpy()
-    return {"model": name, "ops": nops, "fusion": bool(rt.get_fusion()), "fused_launches_per_run": int(fused), "gemm_conv_TFLOP": round(bl.flops / 1e12, 3),
+    tuned = {}
+    if tune:
+        import tempfile
+
+        t0 = time.perf_counter()
+        bl.h.tune()
+        tune_s = time.perf_counter() - t0
+        rt.clear_hip_graph_cache()  # the captured launches still carry the heuristic choices
+        te = timed(bl.h.run, iters)
+        tg = timed(bl.h.run_with_hipgraph, iters)
+        with tempfile.TemporaryDirectory() as d:
+            B.RocmRuntime.save_perf(d + "/perf.json")
+            recs = json.loads(open(d + "/perf.json").read())["data"]
+        picks = {}
+        for _, r in recs:
+            if r["type"] in (3, 4):
+                k = ("matmul" if r["type"] == 3 else "conv") + ":" + ("heuristic" if r["data"][0] < 0 else f"variant{r['data'][0]}")
+                picks[k] = picks.get(k, 0) + 1
+        y = out.copyout_numpy()
+        tuned = {"tuned_eager_ms": round(te, 3), "tuned_hipgraph_ms": round(tg, 3), "tune_seconds": round(tune_s, 2),
+                 "tuned_picks": picks}
+    return {**tuned, "model": name, "ops": nops, "fusion": bool(rt.get_fusion()), "fused_launches_per_run": int(fused), "gemm_conv_TFLOP": round(bl.flops / 1e12, 3),
             "eager_ms": round(eager, 3), "hipgraph_ms": round(graph, 3),
             "hipgraph_TFLOPs": round(bl.flops / graph / 1e9, 1), "batch": batch,
             "per_unit": f"{batch / graph * 1e3:.0f} samples/s", "finite": bool(np.isfinite(y.astype(np.float32)).all())}
@@ -206,8 +229,9 @@ def main():
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--tune", action="store_true", help="also time the graph after h.tune() (autotuned MatMul / Conv variants)")
     args = ap.parse_args()
-    print(json.dumps(run_model(args.model, 0, args.batch, args.seq, args.layers, args.dtype, args.iters)))
+    print(json.dumps(run_model(args.model, 0, args.batch, args.seq, args.layers, args.dtype, args.iters, args.tune)))
 
 
 if __name__ == "__main__":
