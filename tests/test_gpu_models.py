@@ -195,3 +195,31 @@ def test_llama_block_through_reference_executor_vs_oracle(plugin_backend, dtype,
     want = x1_ + (R.unary("silu", h2_ @ Wg) * (h2_ @ Wu)) @ Wd
     assert np.isfinite(got).all()
     assert np.abs(got - want).max() <= tol * np.abs(want).max(), (np.abs(got - want).max(), np.abs(want).max())
+
+
+def test_llama_block_tp_shards_sum_to_the_unsharded_block(plugin_backend):
+    """The tensor-parallel rewrite of config 5 (tools/model_bench.py::build_llama_block, rules of
+    examples/distributed/parallel_opt.py) checked on ONE GPU without a collective: the row-parallel partial sums of
+    rank 0 and rank 1 (world 2 and 4), each produced by that rank's sharded graph through the reference executor, add up
+    to the outputs of the unsharded graph — which is what AllReduceSum delivers at run time (fp32, 1e-4 of scale)."""
+    from model_bench import Builder, build_llama_block
+
+    B = plugin_backend
+    rocm = B.RocmRuntime(0)
+
+    def partials(world, rank):
+        bl = Builder(B, rocm, "f32", seed=4)
+        o, d = build_llama_block(bl, 2, 64, heads=4, head_dim=128, ffn=512, world=world, rank=rank, all_reduce=False)
+        bl.finish()
+        bl.h.run()
+        return o.copyout_numpy().astype(np.float64), d.copyout_numpy().astype(np.float64)
+
+    o_full, d_full = partials(1, 0)
+    assert np.isfinite(o_full).all() and np.abs(o_full).max() > 0 and np.abs(d_full).max() > 0
+    for world in (2, 4):
+        parts = [partials(world, r) for r in range(world)]
+        o_sum, d_sum = sum(p[0] for p in parts), sum(p[1] for p in parts)
+        assert np.abs(o_sum - o_full).max() <= 1e-4 * np.abs(o_full).max(), world
+        assert np.abs(d_sum - d_full).max() <= 1e-4 * np.abs(d_full).max(), world
+        # a single shard is NOT the answer (the test would be vacuous if sharding did nothing)
+        assert np.abs(parts[0][0] - o_full).max() > 1e-2 * np.abs(o_full).max()

@@ -5,6 +5,7 @@ MatMul + Add(bias), decomposed attention (MatMul, Div, Add(mask), Softmax, MatMu
 
   python tools/model_bench.py resnet50 [--batch 128] [--dtype f16]
   python tools/model_bench.py bert     [--batch 32] [--seq 512] [--layers 12]
+  python tools/model_bench.py llama    [--batch 4] [--seq 512]        (config 5 at TP = 1; TP > 1: tools/rocm_launch.py)
 
 Prints one JSON line per model: eager ms/run (host loop + launches + one sync) and hipGraph replay ms/run.
 Weights: N(0, sqrt(2/fan_in)) / N(0, 0.02), seed 0; inputs seeded. The parity of these graphs is
@@ -150,6 +151,53 @@ def build_bert(bl: Builder, batch: int, seq: int, layers: int, hidden: int = 768
     return x
 
 
+def build_llama_block(bl: Builder, batch: int, seq: int, heads: int = 32, head_dim: int = 128, ffn: int = 11008,
+                      world: int = 1, rank: int = 0, all_reduce: bool = True):
+    """BASELINE config 5: one Llama-7B-style decoder block, tensor-parallel over `world` ranks the way
+    examples/distributed/parallel_opt.py rewrites it — q/k/v/gate/up column-parallel (weight sharded on the last dim,
+    heads split), o_proj/down row-parallel (weight sharded on dim 0) followed by ONE AllReduceSum each
+    (parallel_opt.py:46-59,81-119,195-210). Every rank draws the same full weights (seeded) and keeps its shard
+    (infinitensor_amd/tp.py). Attention is the decomposed chain with an additive causal mask [1, 1, S, S].
+    all_reduce=False leaves the two partial sums un-reduced (their sum over ranks must equal the unsharded block:
+    tests/test_gpu_models.py)."""
+    from infinitensor_amd import tp
+
+    h, B = bl.h, bl.B
+    lin = B.ActType.Linear
+    H = heads * head_dim
+    nh = heads // world
+    T = batch * seq
+    x = bl.input((bl.rng.standard_normal((batch, seq, H))).astype(bl.np))
+    full = {n: (bl.rng.standard_normal(shape) * 0.02).astype(bl.np)
+            for n, shape in (("q", (H, H)), ("k", (H, H)), ("v", (H, H)), ("o", (H, H)), ("g", (H, ffn)), ("u", (H, ffn)), ("d", (ffn, H)))}
+    n1, n2 = (1 + 0.1 * bl.rng.standard_normal(H)).astype(bl.np), (1 + 0.1 * bl.rng.standard_normal(H)).astype(bl.np)
+    col = lambda n: bl.const(np.ascontiguousarray(tp.shard_column(full[n], world, rank)[0]))
+    row = lambda n: bl.const(np.ascontiguousarray(tp.shard_row(full[n], world, rank)))
+    pos = bl.const(np.tile(np.arange(seq, dtype=np.uint32), (batch, 1)), 12)
+    mask = bl.const(np.triu(np.full((seq, seq), -1e4, bl.np), 1).reshape(1, 1, seq, seq))
+    scale = bl.const(np.array([np.sqrt(head_dim)], bl.np))
+    mm = lambda a, w: h.matmul(a, w, None, False, False, None, lin, "default")
+    hd = lambda t: h.transpose(h.reshape(t, None, [batch, seq, nh, head_dim]), None, [0, 2, 1, 3])
+    hn = h.RMSNorm(x, bl.const(n1), None)
+    q, k = hd(h.RoPE(pos, mm(hn, col("q")), None)), hd(h.RoPE(pos, mm(hn, col("k")), None))
+    v = hd(mm(hn, col("v")))
+    s = h.add(h.div(h.matmul(q, k, None, False, True, None, lin, "default"), scale, None), mask, None)
+    ctx = h.matmul(h.softmax(s, None, 3), v, None, False, False, None, lin, "default")
+    ctx = h.reshape(h.transpose(ctx, None, [0, 2, 1, 3]), None, [batch, seq, nh * head_dim])
+    o = mm(ctx, row("o"))
+    if all_reduce:
+        o = h.allReduceSum(o, None)
+        x1 = h.add(x, o, None)
+    else:
+        x1 = x  # partial sums stay separate: the caller adds them up over the ranks
+    h2 = h.RMSNorm(x1, bl.const(n2), None)
+    d = mm(h.mul(h.silu(mm(h2, col("g")), None), mm(h2, col("u")), None), row("d"))
+    bl.flops += tp.llama_block_flops(T, H, ffn, world) + 4.0 * batch * nh * seq * seq * head_dim
+    if all_reduce:
+        return h.add(x1, h.allReduceSum(d, None), None)
+    return o, d
+
+
 def build_matmul(bl: Builder, n: int = 4096, trans_b: bool = False):
     """One n^3 MatMul as a one-operator graph: what a single launch costs through the reference executor."""
     a = bl.input((bl.rng.standard_normal((n, n))).astype(bl.np))
@@ -178,6 +226,11 @@ def run_model(model: str, device: int = 0, batch: int | None = None, seq: int = 
         batch = batch or 128
         out = build_resnet50(bl, batch)
         name = f"ResNet-50 bs{batch} {dtype}"
+    elif model == "llama":
+        batch = batch or 4
+        rt.init_comm("model_bench_llama", 1, 0)
+        out = build_llama_block(bl, batch, seq)
+        name = f"Llama-7B block bs{batch} seq{seq} {dtype} TP=1"
     elif model in ("matmul", "matmul_nt"):
         batch = 1
         out = build_matmul(bl, 4096, model == "matmul_nt")
@@ -223,7 +276,7 @@ def run_model(model: str, device: int = 0, batch: int | None = None, seq: int = 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("model", choices=["resnet50", "bert", "matmul", "matmul_nt"])
+    ap.add_argument("model", choices=["resnet50", "bert", "llama", "matmul", "matmul_nt"])
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--seq", type=int, default=512)
     ap.add_argument("--layers", type=int, default=12)
