@@ -48,6 +48,7 @@ struct ConvS1Args {
     int wide_epilogue;   // 16-byte stores where the plane allows (tuning hook IROCM_CONV_WIDE=0 turns it off)
     int epi_probe;       // ablation hook, 0 in production
     unsigned x_bytes;    // bytes of everything behind x
+    unsigned y_bytes;    // bytes of y (= bytes of the residual); 0 when they do not fit 32-bit buffer offsets
     long plane_elems;    // elements of one phase plane set [n][c][h][wd]
     signed char slot[16]; // phase py*sw + px -> index of its plane set behind x
 };
@@ -294,7 +295,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvS1Args &p, f32x4 (&
 // scatters 32- or 64-byte pieces over 16 filter rows moves < 1-2 TB/s. Here every wave first writes its 64 x 64 tile
 // (bias + activation applied, rounded) into a private [64][72]-element LDS image, then stores it row-wise: 8 lanes x 16
 // bytes = 128 contiguous bytes per filter row, 8 rows per instruction, one integer division per lane per tile.
-// `wbuf`: this wave's 9216 bytes. Needs an even plane size (dword-aligned runs); no residual input.
+// `wbuf`: this wave's 9216 bytes. Needs an even plane size (dword-aligned runs).
 constexpr int kEpiWaveBytes = 64 * 144;
 // The bias values of the lane's four filter rows (m0 + wm*64 + i*16 + l15) are loaded by the caller EARLY (a 2-byte
 // global load issued here would put an L2 round trip in front of every tile's stores).
@@ -313,6 +314,30 @@ __device__ __forceinline__ void conv_tile_epilogue_lds(const ConvS1Args &p, f32x
                                                        int n0, int wm, int wn, int lane, char *wbuf) {
     constexpr int ROWP = 144;
     const int l15 = lane & 15, g4 = lane >> 4;
+    // row-wise phase geometry: lane = (row sub-index, 16-byte chunk); one integer division per lane per tile
+    const int ch = lane & 7, rsub = lane >> 3;
+    const int col = n0 + wn * 64 + ch * 8;
+    const int im = col / p.hwp, pix = col - im * p.hwp;
+    const bool live = col < p.ncols && pix < p.hw;
+    const bool full = pix + 8 <= p.hw;
+    const long ybase_off = (long)im * p.f * p.hw + pix;
+    // Residual (y = act(conv + bias + residual), the join of a ResNet bottleneck): the lane's eight 16-byte runs are
+    // fetched HERE, ahead of the staging below, through a range-checked buffer descriptor (a run that ends a plane of
+    // hw % 8 != 0 pixels may reach past the tensor: those dwords read as zero and are never stored). They are added in
+    // the row-wise phase, so the residual moves in the same 128-byte row segments as the stores.
+    const bool has_res = p.res != nullptr;
+    u32x4_t rv[8];
+    if (has_res) {
+        const __amdgpu_buffer_rsrc_t rrs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.res), 0, (int)p.y_bytes, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            int fm = m0 + wm * 64 + it * 8 + rsub;
+            fm = fm < p.f ? fm : p.f - 1;
+            const long off = live ? (ybase_off + (long)fm * p.hw) * 2 : 0;
+            rv[it] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)off, 0, 0);
+        }
+    }
     // one copy of the packing loop per activation: a runtime switch per element keeps 64 scalar branches in the loop
     auto stage = [&](auto actc) __attribute__((always_inline)) {
         constexpr int ACT = decltype(actc)::value;
@@ -336,24 +361,34 @@ __device__ __forceinline__ void conv_tile_epilogue_lds(const ConvS1Args &p, f32x
             }
         }
     };
-    if (p.act == 0)
+    if (p.act == 0 || has_res) // with a residual the activation follows the add, in the row-wise phase
         stage(std::integral_constant<int, 0>{});
     else if (p.act == 1)
         stage(std::integral_constant<int, 1>{});
     else
         stage(std::integral_constant<int, -1>{});
     __builtin_amdgcn_wave_barrier(); // same wave writes and reads: LDS operations of one wave complete in order
-    const int ch = lane & 7, rsub = lane >> 3;
-    const int col = n0 + wn * 64 + ch * 8;
-    const int im = col / p.hwp, pix = col - im * p.hwp;
-    const bool live = col < p.ncols && pix < p.hw;
-    const bool full = pix + 8 <= p.hw;
-    unsigned short *ybase = (unsigned short *)p.y + (long)im * p.f * p.hw + pix;
+    unsigned short *ybase = (unsigned short *)p.y + ybase_off;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int row = it * 8 + rsub;
         const int fm = m0 + wm * 64 + row;
-        const u32x4_t v = *(const u32x4_t *)(wbuf + row * ROWP + ch * 16);
+        u32x4_t v = *(const u32x4_t *)(wbuf + row * ROWP + ch * 16);
+        if (has_res) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                float lo = Tr::to_f32((unsigned short)(v[d] & 0xffffu)) + Tr::to_f32((unsigned short)(rv[it][d] & 0xffffu));
+                float hi = Tr::to_f32((unsigned short)(v[d] >> 16)) + Tr::to_f32((unsigned short)(rv[it][d] >> 16));
+                if (p.act == 1) {
+                    lo = lo > 0.f ? lo : 0.f;
+                    hi = hi > 0.f ? hi : 0.f;
+                } else if (p.act != 0) {
+                    lo = apply_act(lo, p.act);
+                    hi = apply_act(hi, p.act);
+                }
+                v[d] = (unsigned)Tr::from_f32(lo) | ((unsigned)Tr::from_f32(hi) << 16);
+            }
+        }
         if (p.epi_probe == 2) { // ablation hooks (IROCM_CONV_EPI_PROBE): 2 = no global stores
             if (v[0] == 0x12345678u && v[3] == 0x9abcdef0u)
                 ((unsigned short *)p.y)[0] = 1;
@@ -656,7 +691,7 @@ __global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void conv_s1_kernel(ConvS1
     else
         sweep(std::false_type{});
 
-    if (p.wide_epilogue == 1 && !p.res && (p.hw & 1) == 0) { // workgroup-uniform
+    if (p.wide_epilogue == 1 && (!p.res || p.y_bytes) && (p.hw & 1) == 0) { // workgroup-uniform
         __syncthreads(); // the K-loop's stages are dead: reuse them as the waves' staging images
         conv_tile_epilogue_lds<Tr>(p, acc, bias_v, m0, n0, wm, wn, lane, smem + w * kEpiWaveBytes);
         return;
@@ -796,7 +831,7 @@ __global__ __launch_bounds__(256, (NKB <= 2 ? 2 : 1)) void conv_pw_kernel(ConvS1
         }
     };
 
-    const bool lds_epi = p.wide_epilogue == 1 && !p.res; // hw is even here
+    const bool lds_epi = p.wide_epilogue == 1 && (!p.res || p.y_bytes); // hw is even here
     char *const epi = NKB >= 2 ? smem : bres + NKB * B_BYTES; // NKB == 1: 18 KiB of weights is too small, own region
     float bias_v[4], bias_n[4];
     load_tile_a(0);
@@ -905,6 +940,10 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
     static const int epi_probe = getenv("IROCM_CONV_EPI_PROBE") ? atoi(getenv("IROCM_CONV_EPI_PROBE")) : 0;
     p.epi_probe = epi_probe;
     p.plane_elems = (long)n * c * p.hw;
+    {
+        const long yb = (long)n * f * p.hw * 2;
+        p.y_bytes = (yb < (1l << 31) - 64 && (((uintptr_t)res) & 3) == 0) ? (unsigned)yb : 0u; // else: the direct epilogue
+    }
     // phases read by some tap
     PhaseSplitArgs ps;
     ps.nslots = 0;

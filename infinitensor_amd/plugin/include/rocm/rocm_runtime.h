@@ -67,6 +67,12 @@ class RocmRuntimeObj : public RuntimeObj {
     void initComm(const string &name, int worldSize, int rank) final;
     CommunicatorObj &getCommunicator() const final;
 
+    // Output redirection for the "producer -> Reshape" fusion (rocm_fusion.cc): while set, the kernels of
+    // rocm_kernels.cc resolve `redirectTensor` to `redirectPtr` instead of the tensor's own buffer, so the producer
+    // writes straight into the Reshape's output and the copy (reference: CopyCuda, reshape.cc:4-13) is not launched.
+    static thread_local const TensorObj *redirectTensor;
+    static thread_local void *redirectPtr;
+
   private:
     struct TensorState {
         const void *tensor;
@@ -100,6 +106,9 @@ class RocmRuntimeObj : public RuntimeObj {
     void launchAll(const Graph &graph, bool validate) const;
     // launches ops[i .. i+k) as one kernel when a fusion rule applies; returns k (0 = no rule)
     size_t tryLaunchFused(const OpVec &ops, size_t i) const;
+    size_t tryLaunchFusedRules(const OpVec &ops, size_t i) const;
+    size_t tryLaunchIntoReshape(const OpVec &ops, size_t i) const;
+    void launchOne(const Operator &op) const; // one operator through KernelRegistry (+ its perf record, if tuned)
     size_t tryLaunchFusedAttention(const OpVec &ops, size_t i) const;
     int tunedVariant(const Operator &op) const; // kernel variant chosen by tune() for this operator's workload, or -1
     void tuneImpl(const Graph &graph, bool profiling) const;

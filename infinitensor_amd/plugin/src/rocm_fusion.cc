@@ -4,13 +4,15 @@
 //
 //   Conv -> Add(per-channel bias [1,F,1,1] / [F,1,1]) [-> Relu]   =>  conv2d(bias, act)        (onnx.py:159-190
 //   Conv -> Relu                                                   =>  conv2d(act)              emits these chains)
-//   Conv -> Add(bias) -> Add(identity) [-> Relu]                   =>  conv2d_res(bias, residual, act)   [opt-in:
-//        INFINI_ROCM_FUSE_RES=1; measured 1 % slower than conv + ADD_RELU on ResNet-50]
+//   Conv -> Add(bias) -> Add(identity) [-> Relu]                   =>  conv2d_res(bias, residual, act)   [f16 / bf16,
+//        even output planes: the residual moves in the LDS-staged epilogue's 128-byte rows; INFINI_ROCM_FUSE_RES=0|1]
 //   Add  -> Relu                                                   =>  binary(ADD_RELU)         (residual join)
 //   Relu -> MaxPool                                                =>  pool2d_relu              (ResNet stem)
 //   Add  -> LayerNormalization(last axis) | RMSNorm                =>  add_norm                 (transformer residual)
 //   Add(bias) -> Add(identity) [-> Relu]                           =>  bias_residual            (when the conv could not
 //        take the bias: its input's storage was recycled for the output)
+//   MatMul | Transpose | element-wise | Softmax | LayerNorm | Gather -> Reshape-family copy
+//                                                                  =>  the producer writes into the copy's output
 //   MatMul(Q, K^T) [-> Div|Mul(scalar)] [-> Add(mask)] -> Softmax(last axis) -> MatMul(P, V)
 //                                                                  =>  attention (csrc/attention.hip): the score
 //        matrix is never written; Q, K, V rank-4 [b, h, S, D] with D in {64, 128}, f16 / bf16, mask [b|1, 1, 1, Sk]
@@ -167,6 +169,53 @@ int RocmRuntimeObj::tunedVariant(const Operator &op) const {
 }
 
 size_t RocmRuntimeObj::tryLaunchFused(const OpVec &ops, size_t i) const {
+    if (const size_t used = tryLaunchFusedRules(ops, i))
+        return used;
+    return tryLaunchIntoReshape(ops, i);
+}
+
+// producer -> Reshape | Flatten | Identity | Squeeze | Unsqueeze: the reference runs these as a device memcpy
+// (CopyCuda, reshape.cc:4-21); here the producer writes straight into the copy's output buffer (BERT: the three
+// projections before the head split and the head merge, 48 copies of 25 MB per forward). The producer runs through its
+// normal kernel (and perf record) with its output tensor redirected, so nothing about its numerics changes.
+size_t RocmRuntimeObj::tryLaunchIntoReshape(const OpVec &ops, size_t i) const {
+    if (i + 1 >= ops.size())
+        return 0;
+    const Operator &op = ops[i], &next = ops[i + 1];
+    const auto nt = next->getOpType(), type = op->getOpType();
+    if (!(nt == OpType::Reshape || nt == OpType::Flatten || nt == OpType::Identity || nt == OpType::Squeeze ||
+          nt == OpType::Unsqueeze))
+        return 0;
+    // producers whose kernels only WRITE their output (no in-place state, no multi-output, no collectives)
+    if (!(type == OpType::MatMul || type == OpType::Transpose || type == OpType::Add || type == OpType::Sub ||
+          type == OpType::Mul || type == OpType::Div || type == OpType::Relu || type == OpType::Gelu ||
+          type == OpType::Silu || type == OpType::Sigmoid || type == OpType::Tanh || type == OpType::Softmax ||
+          type == OpType::LayerNormalization || type == OpType::RMSNorm || type == OpType::Gather))
+        return 0;
+    if (op->numOutputs() != 1 || next->numOutputs() != 1)
+        return 0;
+    const Tensor mid = op->getOutput(), out = next->getOutput();
+    if (next->getInputs(0) != mid || !soleConsumerIs(mid, next) || mid->getBytes() != out->getBytes() ||
+        !(mid->getDType() == out->getDType()))
+        return 0;
+    for (const auto &in : op->getInputs())
+        if (overlaps(out, in)) // the producer would overwrite what it is still reading
+            return 0;
+    struct Redirect {
+        Redirect(const TensorObj *t, void *p) {
+            RocmRuntimeObj::redirectTensor = t;
+            RocmRuntimeObj::redirectPtr = p;
+        }
+        ~Redirect() {
+            RocmRuntimeObj::redirectTensor = nullptr;
+            RocmRuntimeObj::redirectPtr = nullptr;
+        }
+    } redirect(mid.get(), out->getRawDataPtr<void *>());
+    launchOne(op);
+    return 2;
+}
+
+size_t RocmRuntimeObj::tryLaunchFusedRules(const OpVec &ops, size_t i) const {
     const Operator &op = ops[i];
     const auto type = op->getOpType();
     if (type == OpType::MatMul)
@@ -198,9 +247,15 @@ size_t RocmRuntimeObj::tryLaunchFused(const OpVec &ops, size_t i) const {
                 cands.push_back(cur);
             }
         }
-        // measured on ResNet-50 bs128: 6.46 ms with the residual in the conv epilogue vs 6.40 ms as conv + one ADD_RELU pass
-        // (the epilogue reads the residual in 32-byte row segments; the stand-alone pass streams at 6 TB/s) -> opt-in
-        static const bool fuseRes = std::getenv("INFINI_ROCM_FUSE_RES") && std::string(std::getenv("INFINI_ROCM_FUSE_RES")) == "1";
+        // The residual join rides in the conv epilogue where the LDS-staged epilogue serves it (conv_s1.hip: the residual
+        // is fetched in the same 128-byte row segments as the stores; even output planes, f16 / bf16). With the earlier
+        // direct epilogue (32-byte segments per filter row) the fused form was slower than conv + one ADD_RELU pass, which
+        // is still what odd planes (7x7) and fp32 get. INFINI_ROCM_FUSE_RES=0 / =1 forces it off / on for every shape.
+        static const int fuseResEnv = std::getenv("INFINI_ROCM_FUSE_RES") ? std::atoi(std::getenv("INFINI_ROCM_FUSE_RES")) : -1;
+        const auto &od = conv->getOutput()->getDims();
+        const bool fuseRes = fuseResEnv >= 0 ? fuseResEnv == 1
+                                             : (od.size() == 4 && ((long)od[2] * od[3]) % 2 == 0 && conv->getNumGroups() == 1 &&
+                                                !(x->getDType() == DataType::Float32) && !(x->getDType() == DataType::Double));
         if (fuseRes && cur.bias && nextIs(OpType::Add)) { // residual join: the tail of a ResNet bottleneck
             const Operator &add2 = ops[i + cur.used];
             const Tensor other = otherOf(add2);

@@ -60,7 +60,11 @@ static infiniRocmRuntime_t H(const RuntimeObj *ctx) {
     return c->handle();
 }
 static int DTI(const Tensor &t) { return t->getDTypeIndex(); }
-template <typename T = void> static T *P(const Tensor &t) { return t->getRawDataPtr<T *>(); }
+template <typename T = void> static T *P(const Tensor &t) {
+    if (t.get() == RocmRuntimeObj::redirectTensor) // producer -> Reshape fusion: write into the Reshape's output
+        return (T *)RocmRuntimeObj::redirectPtr;
+    return t->getRawDataPtr<T *>();
+}
 
 static std::vector<int64_t> dims64(const Shape &s) { return std::vector<int64_t>(s.begin(), s.end()); }
 // element strides of a dense tensor of `shape` viewed in `outShape` (0 where broadcast)

@@ -86,8 +86,6 @@ void RocmRuntimeObj::launchAll(const Graph &graph, bool validate) const {
     IT_ASSERT(graph != nullptr, "Cannot run a null graph");
     if (validate)
         graph->validateMemory();
-    const auto &registry = KernelRegistry::getInstance();
-    auto &perfEngine = PerfEngine::getInstance();
     const OpVec &ops = graph->getOperators();
     for (size_t i = 0; i < ops.size(); ++i) {
         const Operator &op = ops[i];
@@ -105,21 +103,28 @@ void RocmRuntimeObj::launchAll(const Graph &graph, bool validate) const {
                 continue;
             }
         }
-        auto attrs = KernelAttrs{device, op->getOpType().underlying()};
-        Kernel *kernel = registry.getKernel(attrs);
-        auto perfKey = PerfEngine::Key{attrs, op->getOpPerfKey()};
-        auto perfData = perfEngine.getPerfData(perfKey);
-        try {
-            if (perfData)
-                kernel->getComputeFunc(perfKey)(op, perfData, this);
-            else
-                kernel->compute(op, this);
-        } catch (Exception &e) {
-            e << " while launching " << op->toString();
-            throw;
-        }
+        launchOne(op);
     }
 }
+
+void RocmRuntimeObj::launchOne(const Operator &op) const {
+    auto attrs = KernelAttrs{device, op->getOpType().underlying()};
+    Kernel *kernel = KernelRegistry::getInstance().getKernel(attrs);
+    auto perfKey = PerfEngine::Key{attrs, op->getOpPerfKey()};
+    auto perfData = PerfEngine::getInstance().getPerfData(perfKey);
+    try {
+        if (perfData)
+            kernel->getComputeFunc(perfKey)(op, perfData, this);
+        else
+            kernel->compute(op, this);
+    } catch (Exception &e) {
+        e << " while launching " << op->toString();
+        throw;
+    }
+}
+
+thread_local const TensorObj *RocmRuntimeObj::redirectTensor = nullptr;
+thread_local void *RocmRuntimeObj::redirectPtr = nullptr;
 
 void RocmRuntimeObj::runWithoutSync(const Graph &graph) const {
     std::lock_guard<std::recursive_mutex> lock(executionMutex);

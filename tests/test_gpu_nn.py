@@ -269,7 +269,11 @@ def test_conv_transpose_reference_kats(rt):
 
 
 @pytest.mark.parametrize("dt", ["f32", "f16"])
-@pytest.mark.parametrize("cfg", [(2, 64, 14, 14, 128, 1, 1, 0, 1), (2, 32, 9, 9, 40, 3, 3, 1, 1), (1, 64, 8, 8, 256, 1, 1, 0, 2), (2, 3, 16, 16, 8, 7, 7, 3, 2)])
+@pytest.mark.parametrize("cfg", [(2, 64, 14, 14, 128, 1, 1, 0, 1), (2, 32, 9, 9, 40, 3, 3, 1, 1), (1, 64, 8, 8, 256, 1, 1, 0, 2), (2, 3, 16, 16, 8, 7, 7, 3, 2),
+                                 # the LDS-staged epilogue with a residual: conv_pw (C <= 128) and conv_s1, filter counts that
+                                 # leave partial tiles, planes of 196 pixels (a 4-pixel last run per row), several images
+                                 (3, 128, 14, 14, 200, 1, 1, 0, 1), (2, 64, 28, 28, 256, 1, 1, 0, 1), (3, 256, 14, 14, 320, 3, 3, 1, 1),
+                                 (2, 192, 6, 6, 72, 1, 1, 0, 1)])
 def test_conv_with_residual(rt, cfg, dt):
     """conv2d_res: act(conv + bias + residual) vs the oracle, on the conv_s1 / generic / fp32 paths."""
     n, c, h, w, f, r, s, pad, st = cfg
@@ -283,3 +287,26 @@ def test_conv_with_residual(rt, cfg, dt):
     want = np.maximum(base + R.round_to(b, dt).reshape(1, f, 1, 1) + R.round_to(res, dt), 0)
     tol = {"f32": 1e-4, "f16": 3e-3}[dt]
     assert np.allclose(host(y), want, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("act", [0, 1])
+def test_conv_residual_lds_epilogue_act_and_bf16(rt, dt, act):
+    """conv2d_res through the LDS-staged epilogue (even plane, conv_s1 3x3 and conv_pw 1x1): no activation / ReLU after
+    the residual add, f16 and bf16; the residual tensor is NOT the output buffer and stays untouched."""
+    rng = np.random.default_rng(77 + act)
+    for (n, c, h, f, r, pad) in ((3, 128, 14, 144, 1, 0), (2, 64, 12, 136, 3, 1)):
+        x = rng.standard_normal((n, c, h, h)).astype(np.float32)
+        wt = (rng.standard_normal((f, c, r, r)) / np.sqrt(c * r * r)).astype(np.float32)
+        b = rng.standard_normal((f,)).astype(np.float32)
+        base = R.conv2d(R.round_to(x, dt), R.round_to(wt, dt), pad, pad, 1, 1, 1, 1)
+        res = rng.standard_normal(base.shape).astype(np.float32)
+        dres = dev(res, TD[dt])
+        keep = dres.clone()
+        y = ops.conv2d(rt, dev(x, TD[dt]), dev(wt, TD[dt]), pad, pad, 1, 1, bias=dev(b, TD[dt]), act=act, residual=dres)
+        want = base + R.round_to(b, dt).reshape(1, f, 1, 1) + R.round_to(res, dt)
+        if act:
+            want = np.maximum(want, 0)
+        tol = {"f16": 3e-3, "bf16": 2.4e-2}[dt]
+        assert np.allclose(host(y), want, rtol=tol, atol=tol), (dt, act, c, np.abs(host(y) - want).max())
+        assert torch.equal(dres, keep)

@@ -47,6 +47,7 @@ def main():
     variants = [int(v) for v in args.variants.split(",")]
     totals = {v: 0.0 for v in variants}
     tot_flop = 0.0
+    tot_floor = 0.0
     table = [RESNET50[int(i)] for i in args.layers.split(",")] if args.layers else RESNET50
     for cnt, c, h, f, r, st, pad in table:
         x = torch.randn((args.batch, c, h, h), device="cuda").to(dt)
@@ -56,7 +57,12 @@ def main():
         y = torch.empty((args.batch, f, oh, oh), device="cuda", dtype=dt)
         flop = 2.0 * args.batch * f * oh * oh * c * r * r
         tot_flop += flop * cnt
-        line = f"x{cnt} C{c:<4d} {h:>3d}x{h:<3d} F{f:<4d} {r}x{r}/s{st} {flop / 1e9:8.2f} GF |"
+        # roofline floor of the layer: algorithmic bytes (input + weights + output, each once) at the 6.3 TB/s the guide
+        # measures as achievable, vs the FLOPs at the 2.15 PF the chip sustains at its ~2.05 GHz load clock
+        nbytes = 2.0 * (args.batch * c * h * h + f * c * r * r + args.batch * f * oh * oh)
+        floor_us = max(nbytes / 6.3e12, flop / 2.15e15) * 1e6
+        tot_floor += floor_us * cnt
+        line = f"x{cnt} C{c:<4d} {h:>3d}x{h:<3d} F{f:<4d} {r}x{r}/s{st} {flop / 1e9:8.2f} GF {nbytes / 1e6:7.1f} MB floor {floor_us:6.1f} us ({'hbm' if nbytes / 6.3e12 > flop / 2.15e15 else 'mfma'}) |"
         if os.environ.get("CONV_BENCH_PTRS"):
             print(f"x {x.data_ptr():#x}+{x.numel() * 2:#x} w {w.data_ptr():#x} b {b.data_ptr():#x} y {y.data_ptr():#x}+{y.numel() * 2:#x} "
                   f"ws {rt.workspace(1):#x}", flush=True)
@@ -73,9 +79,10 @@ def main():
             rt.sync()
             ms = rt.elapsed_ms(e0, e1) / args.iters
             totals[v] += ms * cnt
-            line += f" v{v}: {ms * 1e3:8.1f} us {flop / ms / 1e9:7.1f} TF |"
+            line += f" v{v}: {ms * 1e3:8.1f} us {flop / ms / 1e9:7.1f} TF x{ms * 1e3 / floor_us:4.1f} |"
         print(line, flush=True)
     ops.set_conv_variant(rt, -1)
+    print(f"network roofline floor: {tot_floor / 1e3:.3f} ms")
     print("network conv total: " + "  ".join(f"v{v}: {t:.3f} ms ({tot_flop / t / 1e9:.1f} TF/s)" for v, t in totals.items()))
 
 
