@@ -148,6 +148,16 @@ int infini_rocm_matmul(infiniRocmRuntime_t rt, int dtype, const void *a, const v
                        int trans_a, int trans_b, int64_t stride_a, int64_t stride_b,
                        int64_t bias_stride_b, int64_t bias_stride_m, int64_t bias_stride_n,
                        int act);
+/* MatMul whose result is stored head-split: the [m x n] block of every batch entry is written as
+ * [m / seq][n / head_dim][seq][head_dim], i.e. MatMul -> Reshape([B, S, H, D]) -> Transpose(0, 2, 1, 3) — the q / k / v
+ * projection of a transformer layer as ONNX exporters emit it (reference: matmul.cc + CopyCuda reshape.cc:4-13 +
+ * TransposeCuda transpose.cc:8-45, three launches) — in the GEMM's own epilogue. seq = head_dim = 0: plain MatMul.
+ * head_dim % 8 == 0, seq | m, head_dim | n. Same sums and rounding as infini_rocm_matmul. */
+int infini_rocm_matmul_headsplit(infiniRocmRuntime_t rt, int dtype, const void *a, const void *b,
+                                 const void *bias, void *c, int64_t batch, int64_t m, int64_t n, int64_t k,
+                                 int trans_a, int trans_b, int64_t stride_a, int64_t stride_b,
+                                 int64_t bias_stride_b, int64_t bias_stride_m, int64_t bias_stride_n,
+                                 int act, int64_t seq, int64_t head_dim);
 /* Select a specific GEMM kernel variant for the next matmul calls on this runtime
  * (-1 = heuristic). Used by tune() (reference: 24-algo sweep, matmul.cc:187-208) and by bench.py. */
 int infini_rocm_matmul_set_variant(infiniRocmRuntime_t rt, int variant);

@@ -81,6 +81,7 @@ def lib() -> C.CDLL:
     sig("infini_rocm_graph_launch", [vp, vp])
     sig("infini_rocm_graph_destroy", [vp])
     sig("infini_rocm_matmul", [vp, i32, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i64, i64, i64, i64, i64, i32])
+    sig("infini_rocm_matmul_headsplit", [vp, i32, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i64, i64, i64, i64, i64, i32, i64, i64])
     sig("infini_rocm_matmul_set_variant", [vp, i32])
     sig("infini_rocm_matmul_num_variants", [], i32)
     sig("infini_rocm_matmul_variant_name", [i32], C.c_char_p)

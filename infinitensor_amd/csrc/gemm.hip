@@ -100,7 +100,7 @@ template <typename Tr> __global__ __launch_bounds__(256) void gemm_generic16(Gem
                     if (bias)
                         v += Tr::to_f32(bias[(long)ib * p.bias_b + (long)row * p.bias_m + (long)col * p.bias_n]);
                     v = apply_act(v, p.act);
-                    C[(long)row * p.n + col] = Tr::from_f32(v);
+                    C[c_off(p, row, col)] = Tr::from_f32(v);
                 }
             }
 }
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void gemm_generic32(GemmArgs p) {
                     float v = acc[i][j][r];
                     if (bias)
                         v += bias[(long)ib * p.bias_b + (long)row * p.bias_m + (long)col * p.bias_n];
-                    C[(long)row * p.n + col] = apply_act(v, p.act);
+                    C[c_off(p, row, col)] = apply_act(v, p.act);
                 }
             }
 }
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void gemm_fast128(GemmArgs p) {
                 if (odd) { o[0] = r0; o[1] = r1; o[2] = pk[1][0]; o[3] = pk[1][1]; }
                 else { o[0] = pk[0][0]; o[1] = pk[0][1]; o[2] = r0; o[3] = r1; }
                 const int col = n0 + wn * 64 + (jp * 2 + (odd ? 1 : 0)) * 16 + (g4 & ~1) * 4;
-                *(u32x4_t *)(C + (long)row * p.n + col) = o;
+                *(u32x4_t *)(C + c_off(p, row, col)) = o;
             }
         }
     } else if (interior) {
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void gemm_fast128(GemmArgs p) {
                 u32x2_t pk;
                 pk[0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
                 pk[1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
-                *(u32x2_t *)(C + (long)row * p.n + col) = pk;
+                *(u32x2_t *)(C + c_off(p, row, col)) = pk;
             }
         }
     } else {
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void gemm_fast128(GemmArgs p) {
                     if (row < p.m && col + r < p.n) {
                         if (bias)
                             v += Tr::to_f32(bias[(long)ib * p.bias_b + (long)row * p.bias_m + (long)(col + r) * p.bias_n]);
-                        C[(long)row * p.n + col + r] = Tr::from_f32(apply_act(v, p.act));
+                        C[c_off(p, row, col + r)] = Tr::from_f32(apply_act(v, p.act));
                     }
                 }
             }
@@ -456,7 +456,23 @@ int infini_rocm_matmul(infiniRocmRuntime_t rt, int dtype, const void *a, const v
                        int trans_a, int trans_b, int64_t stride_a, int64_t stride_b,
                        int64_t bias_stride_b, int64_t bias_stride_m, int64_t bias_stride_n,
                        int act) {
+    return infini_rocm_matmul_headsplit(rt, dtype, a, b, bias, c, batch, m, n, k, trans_a, trans_b, stride_a, stride_b,
+                                        bias_stride_b, bias_stride_m, bias_stride_n, act, 0, 0);
+}
+
+int infini_rocm_matmul_headsplit(infiniRocmRuntime_t rt, int dtype, const void *a, const void *b,
+                                 const void *bias, void *c, int64_t batch, int64_t m, int64_t n, int64_t k,
+                                 int trans_a, int trans_b, int64_t stride_a, int64_t stride_b,
+                                 int64_t bias_stride_b, int64_t bias_stride_m, int64_t bias_stride_n,
+                                 int act, int64_t seq, int64_t head_dim) {
     IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG((seq == 0) == (head_dim == 0), "matmul: seq and head_dim go together");
+    if (head_dim) {
+        IROCM_CHECK_ARG(seq > 0 && head_dim > 0 && head_dim % 8 == 0 && m % seq == 0 && n % head_dim == 0 &&
+                            seq < (1ll << 31) && head_dim < (1ll << 31),
+                        "matmul: head split [m/%lld][n/%lld][%lld][%lld] does not tile m = %lld, n = %lld (head_dim %% 8 == 0)",
+                        (long long)seq, (long long)head_dim, (long long)seq, (long long)head_dim, (long long)m, (long long)n);
+    }
     IROCM_CHECK_ARG(dtype == INFINI_DT_F32 || dtype == INFINI_DT_F16 || dtype == INFINI_DT_BF16,
                     "matmul: unsupported dtype %s", dtype_name(dtype));
     IROCM_CHECK_ARG(batch >= 0 && m >= 0 && n >= 0 && k >= 0, "matmul: negative dimension");
@@ -479,6 +495,8 @@ int infini_rocm_matmul(infiniRocmRuntime_t rt, int dtype, const void *a, const v
     p.partial = nullptr;
     p.zeros = rt->zeros;
     p.epi16 = 1; // 16-byte epilogue stores (variant 2 forces the 8-byte epilogue for A/B runs)
+    p.hs_s = (int)seq;
+    p.hs_d = (int)head_dim;
     const bool akm = !trans_a, bkm = trans_b != 0;
 
     int variant = rt->matmul_variant;

@@ -364,7 +364,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                 if (odd) { o[0] = r0; o[1] = r1; o[2] = pk[1][0]; o[3] = pk[1][1]; }
                 else { o[0] = pk[0][0]; o[1] = pk[0][1]; o[2] = r0; o[3] = r1; }
                 const int col = n0 + wc * 64 + (jp * 2 + (odd ? 1 : 0)) * 16 + (g4 & ~1) * 4;
-                *(u32x4_t *)(C + (long)row * p.n + col) = o;
+                *(u32x4_t *)(C + c_off(p, row, col)) = o;
             }
         }
     } else if (interior) {
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                 u32x2_t pk;
                 pk[0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
                 pk[1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
-                *(u32x2_t *)(C + (long)row * p.n + col) = pk;
+                *(u32x2_t *)(C + c_off(p, row, col)) = pk;
             }
         }
     } else {
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                         float v = acc[i][j][r];
                         if (bias)
                             v += Tr::to_f32(bias[(long)ib * p.bias_b + (long)row * p.bias_m + (long)(col + r) * p.bias_n]);
-                        C[(long)row * p.n + col + r] = Tr::from_f32(apply_act(v, p.act));
+                        C[c_off(p, row, col + r)] = Tr::from_f32(apply_act(v, p.act));
                     }
                 }
             }
@@ -450,9 +450,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
             u32x2_t pk;
             pk[0] = (unsigned)o[0] | ((unsigned)o[1] << 16);
             pk[1] = (unsigned)o[2] | ((unsigned)o[3] << 16);
-            *(u32x2_t *)(C + e0) = pk;
+            *(u32x2_t *)(C + ib * mn + c_off(p, row, col)) = pk;
         } else {
-            C[e0] = o[0];
+            C[ib * mn + c_off(p, row, col)] = o[0];
         }
     }
 }

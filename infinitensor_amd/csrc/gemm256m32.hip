@@ -257,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void gemm256m32_kernel(GemmArgs p) {
                     u32x2_t pk;
                     pk[0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
                     pk[1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
-                    *(u32x2_t *)(C + (long)row * p.n + col) = pk;
+                    *(u32x2_t *)(C + c_off(p, row, col)) = pk;
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(512, 2) void gemm256m32_kernel(GemmArgs p) {
                             float x = v[r];
                             if (bias)
                                 x += Tr::to_f32(bias[(long)ib * p.bias_b + (long)row * p.bias_m + (long)(col + r) * p.bias_n]);
-                            C[(long)row * p.n + col + r] = Tr::from_f32(apply_act(x, p.act));
+                            C[c_off(p, row, col + r)] = Tr::from_f32(apply_act(x, p.act));
                         }
                     }
                 }

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(GemmArgs p) {
                 u32x2_t pk;
                 pk[0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
                 pk[1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
-                *(u32x2_t *)(C + (long)row * p.n + col) = pk;
+                *(u32x2_t *)(C + c_off(p, row, col)) = pk;
             });
         });
     } else {
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(GemmArgs p) {
                         float x = acc[i][j][r];
                         if (bias)
                             x += Tr::to_f32(bias[(long)ib * p.bias_b + (long)row * p.bias_m + (long)(col + r) * p.bias_n]);
-                        C[(long)row * p.n + col + r] = Tr::from_f32(apply_act(x, p.act));
+                        C[c_off(p, row, col + r)] = Tr::from_f32(apply_act(x, p.act));
                     }
                 }
             });

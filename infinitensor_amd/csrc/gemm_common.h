@@ -32,7 +32,19 @@ struct GemmArgs {
     float *partial;
     int epi16;         // gemm256: 16-byte stores in the epilogue (pair exchange between lane groups)
     const void *zeros; // >= 16 zero bytes in device memory: source of K-tail chunks past k (fast128)
+    // head-split store (0 = off): C[row][col] of one [m x n] problem goes to a [m / hs_s][n / hs_d][hs_s][hs_d] tensor,
+    // i.e. the MatMul -> Reshape([B, S, H, D]) -> Transpose(0, 2, 1, 3) chain of a transformer's q / k / v projections
+    // written by the GEMM itself. hs_d % 8 == 0 so a 16-byte store never straddles two heads.
+    int hs_s, hs_d;
 };
+
+// element offset of C(row, col) inside one batch's [m x n] block
+__device__ __forceinline__ long c_off(const GemmArgs &p, long row, long col) {
+    if (p.hs_d == 0)
+        return row * p.n + col;
+    const long b = row / p.hs_s, s = row - b * p.hs_s, h = col / p.hs_d, d = col - h * p.hs_d;
+    return ((b * (p.n / p.hs_d) + h) * p.hs_s + s) * p.hs_d + d;
+}
 
 // 16-bit element traits: how to feed v_mfma_f32_16x16x32_{bf16,f16} and convert on store.
 struct Bf16Traits {

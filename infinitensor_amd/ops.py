@@ -105,11 +105,13 @@ def broadcast_strides(shape: Sequence[int], out_shape: Sequence[int]) -> list[in
 # ------------------------------------------------------------------------------------------------
 def matmul(rt: RocmRuntime, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor | None = None,
            trans_a: bool = False, trans_b: bool = False, act: int = 0,
-           out: torch.Tensor | None = None) -> torch.Tensor:
+           out: torch.Tensor | None = None, head_split: tuple[int, int] | None = None) -> torch.Tensor:
     """C = op(A) op(B) (+bias) with the reference's batch-broadcast rule.
 
     Shape inference: src/operators/matmul.cc:26-49. Batch strides: zero when the operand is
     rank-2 or its broadcast batch is 1 (src/kernels/cuda/matmul.cc:124-137).
+    head_split = (seq, head_dim): the [m, n] result is stored as [m / seq, n / head_dim, seq, head_dim] — MatMul ->
+    Reshape([B, S, H, D]) -> Transpose(0, 2, 1, 3) in the GEMM epilogue (infini_rocm_matmul_headsplit).
     """
     sa, sb = list(a.shape), list(b.shape)
     if len(sa) < 2 or len(sb) < 2:
@@ -129,8 +131,15 @@ def matmul(rt: RocmRuntime, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor
         raise ValueError("only full or size-1 batch broadcast is supported (reference matmul.cc:124-137)")
     stride_a = 0 if (ba == 1 and batch > 1) else m * k
     stride_b = 0 if (bb == 1 and batch > 1) else n * k
+    seq = hd = 0
+    final_shape = out_shape
+    if head_split is not None:
+        seq, hd = (int(v) for v in head_split)
+        if seq <= 0 or hd <= 0 or m % seq or n % hd or hd % 8:
+            raise ValueError(f"head_split {head_split} does not tile m = {m}, n = {n} (head_dim % 8 == 0)")
+        final_shape = batch_shape + [m // seq, n // hd, seq, hd]
     if out is None:
-        out = torch.empty(out_shape, dtype=a.dtype, device=a.device)
+        out = torch.empty(final_shape, dtype=a.dtype, device=a.device)
     bs_b = bs_m = bs_n = 0
     if bias is not None:
         st = broadcast_strides(list(bias.shape), out_shape)
@@ -144,9 +153,9 @@ def matmul(rt: RocmRuntime, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor
             bs_b = math.prod(bias.shape[-2:]) if bias.dim() >= 2 else 0
             if list(bias.shape[:-2]) and math.prod(bias.shape[:-2]) != batch:
                 raise ValueError("partially-broadcast bias batch is not supported")
-    check(lib().infini_rocm_matmul(rt.handle, dtype_of(a), _ptr(a), _ptr(b), _ptr(bias), _ptr(out),
-                                   batch, m, n, k, int(trans_a), int(trans_b), stride_a, stride_b,
-                                   bs_b, bs_m, bs_n, int(act)))
+    check(lib().infini_rocm_matmul_headsplit(rt.handle, dtype_of(a), _ptr(a), _ptr(b), _ptr(bias), _ptr(out),
+                                             batch, m, n, k, int(trans_a), int(trans_b), stride_a, stride_b,
+                                             bs_b, bs_m, bs_n, int(act), seq, hd))
     return out
 
 

@@ -72,6 +72,9 @@ class RocmRuntimeObj : public RuntimeObj {
     // writes straight into the Reshape's output and the copy (reference: CopyCuda, reshape.cc:4-13) is not launched.
     static thread_local const TensorObj *redirectTensor;
     static thread_local void *redirectPtr;
+    // with a redirected MatMul: store the result head-split ([m / seq][n / headDim][seq][headDim]) — the
+    // MatMul -> Reshape -> Transpose(0, 2, 1, 3) fusion (infini_rocm_matmul_headsplit); 0 = plain store
+    static thread_local int redirectSeq, redirectHeadDim;
 
   private:
     struct TensorState {
@@ -108,6 +111,7 @@ class RocmRuntimeObj : public RuntimeObj {
     size_t tryLaunchFused(const OpVec &ops, size_t i) const;
     size_t tryLaunchFusedRules(const OpVec &ops, size_t i) const;
     size_t tryLaunchIntoReshape(const OpVec &ops, size_t i) const;
+    size_t tryLaunchHeadSplit(const OpVec &ops, size_t i) const;
     void launchOne(const Operator &op) const; // one operator through KernelRegistry (+ its perf record, if tuned)
     size_t tryLaunchFusedAttention(const OpVec &ops, size_t i) const;
     int tunedVariant(const Operator &op) const; // kernel variant chosen by tune() for this operator's workload, or -1

@@ -11,6 +11,8 @@
 //   Add  -> LayerNormalization(last axis) | RMSNorm                =>  add_norm                 (transformer residual)
 //   Add(bias) -> Add(identity) [-> Relu]                           =>  bias_residual            (when the conv could not
 //        take the bias: its input's storage was recycled for the output)
+//   MatMul(+bias) -> Reshape [B,S,H,D] -> Transpose(0,2,1,3)        =>  matmul_headsplit (the q / k / v head split in
+//        the GEMM epilogue; f16 / bf16)
 //   MatMul | Transpose | element-wise | Softmax | LayerNorm | Gather -> Reshape-family copy
 //                                                                  =>  the producer writes into the copy's output
 //   MatMul(Q, K^T) [-> Div|Mul(scalar)] [-> Add(mask)] -> Softmax(last axis) -> MatMul(P, V)
@@ -38,6 +40,7 @@
 #include "operators/matmul.h"
 #include "operators/pooling.h"
 #include "operators/softmax.h"
+#include "operators/transpose.h"
 #include "operators/unary.h"
 #include "rocm/rocm_runtime.h"
 
@@ -171,7 +174,56 @@ int RocmRuntimeObj::tunedVariant(const Operator &op) const {
 size_t RocmRuntimeObj::tryLaunchFused(const OpVec &ops, size_t i) const {
     if (const size_t used = tryLaunchFusedRules(ops, i))
         return used;
+    if (const size_t used = tryLaunchHeadSplit(ops, i))
+        return used;
     return tryLaunchIntoReshape(ops, i);
+}
+
+namespace {
+struct OutputRedirect { // RAII: the redirection never outlives one launch
+    OutputRedirect(const TensorObj *t, void *p, int seq = 0, int headDim = 0) {
+        RocmRuntimeObj::redirectTensor = t;
+        RocmRuntimeObj::redirectPtr = p;
+        RocmRuntimeObj::redirectSeq = seq;
+        RocmRuntimeObj::redirectHeadDim = headDim;
+    }
+    ~OutputRedirect() {
+        RocmRuntimeObj::redirectTensor = nullptr;
+        RocmRuntimeObj::redirectPtr = nullptr;
+        RocmRuntimeObj::redirectSeq = RocmRuntimeObj::redirectHeadDim = 0;
+    }
+};
+} // namespace
+
+// MatMul(+bias) [.., S, H*D] or [B*S, H*D] -> Reshape [B, S, H, D] -> Transpose(0, 2, 1, 3): the head split of a
+// transformer's q / k / v projections (three launches and two extra passes over the activation in the reference) as ONE
+// GEMM whose epilogue stores head-split (infini_rocm_matmul_headsplit). Same sums, same rounding: bit-identical.
+size_t RocmRuntimeObj::tryLaunchHeadSplit(const OpVec &ops, size_t i) const {
+    static const bool enabled = !(std::getenv("INFINI_ROCM_FUSE_HEADSPLIT") && std::atoi(std::getenv("INFINI_ROCM_FUSE_HEADSPLIT")) == 0);
+    if (!enabled || i + 2 >= ops.size() || ops[i]->getOpType() != OpType::MatMul ||
+        ops[i + 1]->getOpType() != OpType::Reshape || ops[i + 2]->getOpType() != OpType::Transpose)
+        return 0;
+    auto mm = as<MatmulObj>(ops[i]);
+    auto tr = as<TransposeObj>(ops[i + 2]);
+    const Tensor c = mm->getOutput(), r = ops[i + 1]->getOutput(), out = tr->getOutput();
+    if (ops[i + 1]->getInputs(0) != c || tr->getInputs(0) != r || !soleConsumerIs(c, ops[i + 1]) || !soleConsumerIs(r, ops[i + 2]))
+        return 0;
+    const auto &rd = r->getDims();
+    const auto perm = tr->getPermute();
+    if (rd.size() != 4 || perm.size() != 4 || perm[0] != 0 || perm[1] != 2 || perm[2] != 1 || perm[3] != 3)
+        return 0;
+    const auto [b, m, n, k] = mm->getBMNK();
+    const long B = rd[0], S = rd[1], Hh = rd[2], D = rd[3];
+    // the MatMul's rows are (batch, position), its columns (head, channel): [b x m] == [B x S] row-wise, n == H * D
+    if ((long)b * m != B * S || (long)n != Hh * D || m % S != 0 || D % 8 != 0 ||
+        !(c->getDType() == out->getDType()) || c->getBytes() != out->getBytes())
+        return 0;
+    for (const auto &in : mm->getInputs())
+        if (overlaps(out, in))
+            return 0;
+    OutputRedirect redirect(c.get(), out->getRawDataPtr<void *>(), (int)S, (int)D);
+    launchOne(ops[i]);
+    return 3;
 }
 
 // producer -> Reshape | Flatten | Identity | Squeeze | Unsqueeze: the reference runs these as a device memcpy
@@ -179,7 +231,8 @@ size_t RocmRuntimeObj::tryLaunchFused(const OpVec &ops, size_t i) const {
 // projections before the head split and the head merge, 48 copies of 25 MB per forward). The producer runs through its
 // normal kernel (and perf record) with its output tensor redirected, so nothing about its numerics changes.
 size_t RocmRuntimeObj::tryLaunchIntoReshape(const OpVec &ops, size_t i) const {
-    if (i + 1 >= ops.size())
+    static const bool enabled = !(std::getenv("INFINI_ROCM_FUSE_RESHAPE") && std::atoi(std::getenv("INFINI_ROCM_FUSE_RESHAPE")) == 0);
+    if (!enabled || i + 1 >= ops.size()) // INFINI_ROCM_FUSE_RESHAPE=0: A/B hook
         return 0;
     const Operator &op = ops[i], &next = ops[i + 1];
     const auto nt = next->getOpType(), type = op->getOpType();
@@ -201,16 +254,7 @@ size_t RocmRuntimeObj::tryLaunchIntoReshape(const OpVec &ops, size_t i) const {
     for (const auto &in : op->getInputs())
         if (overlaps(out, in)) // the producer would overwrite what it is still reading
             return 0;
-    struct Redirect {
-        Redirect(const TensorObj *t, void *p) {
-            RocmRuntimeObj::redirectTensor = t;
-            RocmRuntimeObj::redirectPtr = p;
-        }
-        ~Redirect() {
-            RocmRuntimeObj::redirectTensor = nullptr;
-            RocmRuntimeObj::redirectPtr = nullptr;
-        }
-    } redirect(mid.get(), out->getRawDataPtr<void *>());
+    OutputRedirect redirect(mid.get(), out->getRawDataPtr<void *>());
     launchOne(op);
     return 2;
 }

@@ -182,8 +182,12 @@ class MatmulRocm : public RocmTunableKernel {
             }
         }
         // `act` is ignored like in the reference CUDA kernel (matmul.cc never reads getAct())
-        ROCM_CALL(infini_rocm_matmul(H(ctx), DTI(A), P(A), P(B), bias, P(C), b, m, n, k, op->getTransA(),
-                                     op->getTransB(), strideA, strideB, bsb, bsm, bsn, 0));
+        // head-split store requested by the MatMul -> Reshape -> Transpose fusion for THIS op's output (rocm_fusion.cc)
+        const bool split = C.get() == RocmRuntimeObj::redirectTensor && RocmRuntimeObj::redirectHeadDim > 0;
+        ROCM_CALL(infini_rocm_matmul_headsplit(H(ctx), DTI(A), P(A), P(B), bias, P(C), b, m, n, k, op->getTransA(),
+                                               op->getTransB(), strideA, strideB, bsb, bsm, bsn, 0,
+                                               split ? RocmRuntimeObj::redirectSeq : 0,
+                                               split ? RocmRuntimeObj::redirectHeadDim : 0));
     }
 };
 REGISTER_KERNEL(Device::ROCM, OpType::MatMul, MatmulRocm, "Matmul_MFMA_ROCM");

@@ -174,3 +174,41 @@ def test_matmul_rejects_bad_arguments(rt):
     with pytest.raises(InfiniRocmError):  # the C ABI itself rejects an unsupported dtype, loudly
         from infinitensor_amd._lib import check
         check(lib().infini_rocm_matmul(rt.handle, 7, None, None, None, None, 1, 4, 4, 4, 0, 0, 16, 16, 0, 0, 0, 0))
+
+
+@pytest.mark.parametrize("variant", [-1, 0, 1, 6, 7])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("shape", [(1, 512, 768, 256, 128, 64), (2, 256, 512, 320, 128, 64), (1, 384, 200, 136, 96, 40),
+                                   (1, 1024, 1024, 1024, 256, 128)])
+def test_matmul_head_split_store_is_the_reshape_transpose_chain(rt, variant, dtype, shape):
+    """infini_rocm_matmul_headsplit: the [m, n] result stored as [m / S, n / D, S, D] equals MatMul -> Reshape([.., S, H, D])
+    -> Transpose(0, 2, 1, 3) of the plain call BIT FOR BIT (same kernel, same sums, only the store address differs), for
+    every kernel variant (generic, fast128, 256-tile, split-K), with a bias, ragged tiles and a batch."""
+    b, m, n, k, S, D = shape
+    rng = np.random.default_rng(m + n + k)
+    a = rng.standard_normal((b, m, k)).astype(np.float32)
+    w = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
+    bias = rng.standard_normal((n,)).astype(np.float32)
+    da, dw, db = dev(a, dtype), dev(w, dtype), dev(bias, dtype)
+    ops.set_matmul_variant(rt, variant)
+    try:
+        plain = ops.matmul(rt, da, dw, db)
+        split = ops.matmul(rt, da, dw, db, head_split=(S, D))
+    finally:
+        ops.set_matmul_variant(rt, -1)
+    assert tuple(split.shape) == (b, m // S, n // D, S, D)
+    want = plain.view(b, m // S, S, n // D, D).permute(0, 1, 3, 2, 4).contiguous()
+    assert torch.equal(split, want)
+    ref = R.matmul(R.round_to(a, {torch.float16: "f16", torch.bfloat16: "bf16", torch.float32: "f32"}[dtype]),
+                   R.round_to(w, {torch.float16: "f16", torch.bfloat16: "bf16", torch.float32: "f32"}[dtype]),
+                   R.round_to(bias, {torch.float16: "f16", torch.bfloat16: "bf16", torch.float32: "f32"}[dtype]))
+    tol = {torch.float16: 2e-3, torch.bfloat16: 1.6e-2, torch.float32: 1e-4}[dtype]
+    assert np.allclose(host(plain), ref, rtol=tol, atol=tol * 4)
+
+
+def test_matmul_head_split_rejects_bad_tilings(rt):
+    a, w = dev(np.ones((64, 32), np.float32), torch.float16), dev(np.ones((32, 48), np.float32), torch.float16)
+    with pytest.raises(ValueError):
+        ops.matmul(rt, a, w, head_split=(48, 16))  # 48 does not divide m = 64
+    with pytest.raises(ValueError):
+        ops.matmul(rt, a, w, head_split=(32, 12))  # head_dim % 8 != 0

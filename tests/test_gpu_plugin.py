@@ -634,3 +634,43 @@ def test_producer_writes_into_reshape_output(B, rocm):
     assert np.array_equal(got[("shared", True)], got[("shared", False)])
     assert np.allclose(got[("chain", True)].reshape(want_chain.shape), want_chain, rtol=1e-4, atol=1e-4)
     assert np.allclose(got[("shared", True)].reshape(want_shared.shape), want_shared, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("code,npdt", [(F16, np.float16), (F32, np.float32)])
+def test_head_split_fusion_is_bit_identical(B, rocm, code, npdt):
+    """MatMul(+bias) -> Reshape([B, S, H, D]) -> Transpose(0, 2, 1, 3) as one GEMM with a head-split store
+    (rocm_fusion.cc::tryLaunchHeadSplit): identical bits to the three-kernel chain, for a rank-2 and a rank-3 MatMul."""
+    rng = np.random.default_rng(41)
+    Bt, S, NH, D = 2, 64, 3, 32
+    w = (rng.standard_normal((NH * D, NH * D)) / 9).astype(npdt)
+    b = rng.standard_normal((NH * D,)).astype(npdt)
+    lin = B.ActType.Linear
+    for xshape in ((Bt * S, NH * D), (Bt, S, NH * D)):
+        x = rng.standard_normal(xshape).astype(npdt)
+
+        def fn(h, t):
+            y = h.matmul(t[0], t[1], None, False, False, t[2], lin, "default")
+            return h.transpose(h.reshape(y, None, [Bt, S, NH, D]), None, [0, 2, 1, 3])
+
+        got = {}
+        try:
+            for on in (True, False):
+                rocm.set_fusion(on)
+                h = B.GraphHandler(rocm)
+                ts = [h.tensor(list(a.shape), code) for a in (x, w, b)]
+                for t in ts:
+                    t.set_weight()
+                out = fn(h, ts)
+                h.data_malloc()
+                for t, a in zip(ts, (x, w, b)):
+                    put(t, a)
+                before = rocm.fused_launch_count()
+                h.run()
+                assert rocm.fused_launch_count() - before == (1 if on else 0)
+                got[on] = get(out)
+        finally:
+            rocm.set_fusion(True)
+        assert np.array_equal(got[True], got[False])
+        want = (x.astype(np.float64).reshape(Bt * S, NH * D) @ w.astype(np.float64) + b).reshape(Bt, S, NH, D).transpose(0, 2, 1, 3)
+        tol = 1e-4 if npdt is np.float32 else 4e-3
+        assert np.allclose(got[True].astype(np.float64).reshape(want.shape), want, rtol=tol, atol=tol)
