@@ -209,6 +209,14 @@ int infini_rocm_attention(infiniRocmRuntime_t rt, int dtype, const void *q, cons
                           int64_t head_dim, int64_t mask_group, const void *scale_dev, int scale_is_div,
                           float scale, int causal);
 
+/* The same attention with the result stored head-merged: out is [batch_heads / heads, seq_q, heads, head_dim], i.e. the
+ * Transpose(0, 2, 1, 3) -> Reshape([B, S, H * D]) a transformer layer applies to the context before its output projection
+ * (reference: TransposeCuda transpose.cc:8-45 + CopyCuda reshape.cc:4-13) done by the kernel's own store. heads = 0: plain. */
+int infini_rocm_attention_headmerge(infiniRocmRuntime_t rt, int dtype, const void *q, const void *k, const void *v,
+                                    const void *mask, void *out, int64_t batch_heads, int64_t seq_q, int64_t seq_k,
+                                    int64_t head_dim, int64_t mask_group, const void *scale_dev, int scale_is_div,
+                                    float scale, int causal, int64_t heads);
+
 /* AttentionKVCache: one decode step with in-place cache append (reference: attention_kvcache.cu:8-169).
  *   n = position_id[0] + 1; k_cache/v_cache[bh, n-1, :] = k/v[bh, :]; out[bh, :] = softmax(q . K[0:n]^T / sqrt(D)) V[0:n].
  * caches [batch_heads, max_seq, D]; q, k, v, out [batch_heads, D]; position_id: device I32 / U32 / I64 (element 0 is

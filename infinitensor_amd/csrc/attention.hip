@@ -30,6 +30,7 @@ struct AttnArgs {
     int scale_is_div; // effective scale = scale_value (0) or 1 / scale_value (1)
     float scale_imm;  // used when scale == nullptr
     int causal;
+    int o_heads;      // > 0: O is stored merged, [bh / o_heads][sq][o_heads][D] (Transpose(0,2,1,3) -> Reshape of the plain result)
 };
 
 // raw v_exp_f32 (exp2f() wraps it in a denormal range fix-up: 5 extra VALU instructions per score); results below
@@ -276,7 +277,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     }
 
     // ---- normalise and store: lane holds O[q = .. + l15][d = dt*16 + 4*g4 + r] ------------------------------
-    unsigned short *O = (unsigned short *)p.o + (long)bh * p.sq * D;
+    // plain: O[bh][q][D]; merged (o_heads = H): O[bh / H][q][bh % H][D] — the head merge a transformer layer applies next
+    const long o_row = p.o_heads ? (long)p.o_heads * D : (long)D;
+    unsigned short *O = (unsigned short *)p.o +
+                        (p.o_heads ? ((long)(bh / p.o_heads) * p.sq * p.o_heads + (bh % p.o_heads)) * D : (long)bh * p.sq * D);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         float l = l_run[nt];
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
             u32x2_t pk;
             pk[0] = (unsigned)Tr::from_f32(o[dt][nt][0] * inv) | ((unsigned)Tr::from_f32(o[dt][nt][1] * inv) << 16);
             pk[1] = (unsigned)Tr::from_f32(o[dt][nt][2] * inv) | ((unsigned)Tr::from_f32(o[dt][nt][3] * inv) << 16);
-            *(u32x2_t *)(O + (long)qi * D + dt * 16 + 4 * g4) = pk;
+            *(u32x2_t *)(O + (long)qi * o_row + dt * 16 + 4 * g4) = pk;
         }
     }
 }
@@ -324,7 +328,17 @@ extern "C" int infini_rocm_attention(infiniRocmRuntime_t rt, int dtype, const vo
                                      const void *mask, void *out, int64_t batch_heads, int64_t seq_q, int64_t seq_k,
                                      int64_t head_dim, int64_t mask_group, const void *scale_dev, int scale_is_div,
                                      float scale, int causal) {
+    return infini_rocm_attention_headmerge(rt, dtype, q, k, v, mask, out, batch_heads, seq_q, seq_k, head_dim, mask_group,
+                                           scale_dev, scale_is_div, scale, causal, 0);
+}
+
+extern "C" int infini_rocm_attention_headmerge(infiniRocmRuntime_t rt, int dtype, const void *q, const void *k, const void *v,
+                                               const void *mask, void *out, int64_t batch_heads, int64_t seq_q, int64_t seq_k,
+                                               int64_t head_dim, int64_t mask_group, const void *scale_dev, int scale_is_div,
+                                               float scale, int causal, int64_t heads) {
     IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(heads >= 0 && heads < 65536 && (heads == 0 || batch_heads % heads == 0),
+                    "attention: heads %lld does not divide batch_heads %lld", (long long)heads, (long long)batch_heads);
     IROCM_CHECK_ARG(dtype == INFINI_DT_F16 || dtype == INFINI_DT_BF16, "attention: f16 / bf16 only (got %s)", dtype_name(dtype));
     IROCM_CHECK_ARG(head_dim == 64 || head_dim == 128, "attention: head dim %lld not in {64, 128}", (long long)head_dim);
     IROCM_CHECK_ARG(batch_heads >= 0 && seq_q >= 0 && seq_k > 0 && batch_heads < 65536 && seq_q < (1ll << 31) && seq_k < (1ll << 31),
@@ -342,6 +356,7 @@ extern "C" int infini_rocm_attention(infiniRocmRuntime_t rt, int dtype, const vo
     p.scale_is_div = scale_is_div;
     p.scale_imm = scale;
     p.causal = causal;
+    p.o_heads = (int)heads;
     const bool bf = dtype == INFINI_DT_BF16;
     if (head_dim == 64)
         return bf ? launch_attn<Bf16Traits, 64, 4>(rt, p) : launch_attn<F16Traits, 64, 4>(rt, p);

@@ -219,27 +219,30 @@ def rms_norm(rt: RocmRuntime, x: torch.Tensor, weight: torch.Tensor, eps: float 
 
 def attention(rt: RocmRuntime, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float | torch.Tensor,
               mask: torch.Tensor | None = None, causal: bool = False, scale_is_div: bool = False,
-              out: torch.Tensor | None = None) -> torch.Tensor:
+              out: torch.Tensor | None = None, head_merge: int = 0) -> torch.Tensor:
     """softmax(scale * q k^T + mask) v over [..., S, D] (leading dims = batch x heads). `mask`: additive, shape
     [G, Sk] with G dividing the number of (batch, head) pairs (row g serves pairs g*BH/G .. (g+1)*BH/G - 1).
-    `scale`: a float, or a one-element device tensor (then multiply / divide per scale_is_div)."""
+    `scale`: a float, or a one-element device tensor (then multiply / divide per scale_is_div).
+    head_merge = H > 0: the result is stored as [BH / H, Sq, H, D] (Transpose(0, 2, 1, 3) of the plain [BH / H, H, Sq, D])."""
     if q.dim() < 3 or k.shape != v.shape or q.shape[:-2] != k.shape[:-2] or q.shape[-1] != k.shape[-1]:
         raise ValueError("attention expects q [..., Sq, D] and k, v [..., Sk, D]")
     bh = 1
     for d in q.shape[:-2]:
         bh *= d
     sq, sk, hd = q.shape[-2], k.shape[-2], q.shape[-1]
+    if head_merge and (head_merge < 0 or bh % head_merge):
+        raise ValueError(f"head_merge {head_merge} does not divide batch x heads = {bh}")
     if out is None:
-        out = torch.empty_like(q)
+        out = torch.empty((bh // head_merge, sq, head_merge, hd), dtype=q.dtype, device=q.device) if head_merge else torch.empty_like(q)
     group = 1
     if mask is not None:
         if mask.dim() != 2 or mask.shape[1] != sk or bh % mask.shape[0] != 0 or mask.dtype != q.dtype:
             raise ValueError("mask must be [G, Sk] of q's dtype with G dividing batch x heads")
         group = bh // mask.shape[0]
     dev_scale = scale if isinstance(scale, torch.Tensor) else None
-    check(lib().infini_rocm_attention(rt.handle, dtype_of(q), _ptr(q), _ptr(k), _ptr(v), _ptr(mask), _ptr(out), bh, sq, sk,
-                                      hd, group, _ptr(dev_scale), int(scale_is_div),
-                                      0.0 if dev_scale is not None else float(scale), int(causal)))
+    check(lib().infini_rocm_attention_headmerge(rt.handle, dtype_of(q), _ptr(q), _ptr(k), _ptr(v), _ptr(mask), _ptr(out), bh, sq, sk,
+                                                hd, group, _ptr(dev_scale), int(scale_is_div),
+                                                0.0 if dev_scale is not None else float(scale), int(causal), int(head_merge)))
     return out
 
 

@@ -17,7 +17,8 @@
 //                                                                  =>  the producer writes into the copy's output
 //   MatMul(Q, K^T) [-> Div|Mul(scalar)] [-> Add(mask)] -> Softmax(last axis) -> MatMul(P, V)
 //                                                                  =>  attention (csrc/attention.hip): the score
-//        matrix is never written; Q, K, V rank-4 [b, h, S, D] with D in {64, 128}, f16 / bf16, mask [b|1, 1, 1, Sk]
+//        matrix is never written; Q, K, V rank-4 [b, h, S, D] with D in {64, 128}, f16 / bf16, mask [b|1, 1, 1, Sk];
+//        a following Transpose(0,2,1,3) -> Reshape (the head merge) is folded into the kernel's store
 //
 // Conditions (checked every launch, nothing is cached across graph mutations):
 //   * the ops are CONSECUTIVE in the graph's operator order and each intermediate tensor has exactly one
@@ -145,24 +146,42 @@ size_t RocmRuntimeObj::tryLaunchFusedAttention(const OpVec &ops, size_t i) const
     if (mm2->getInputs(0) != cur || mm2->getTransA() || mm2->getTransB() || mm2->getBias() || mm2->getAct() != ActType::None ||
         v->getDims() != kd || !(v->getDType() == q->getDType()))
         return 0;
+    // Head merge: ctx [b, h, Sq, D] -> Transpose(0, 2, 1, 3) -> Reshape [b, Sq, h * D] (what every exported transformer
+    // does before the output projection) is folded into the kernel's store (infini_rocm_attention_headmerge).
+    Tensor dstT = out;
+    int64_t heads = 0;
+    size_t last = j;
+    static const bool mergeOn = !(std::getenv("INFINI_ROCM_FUSE_HEADMERGE") && std::atoi(std::getenv("INFINI_ROCM_FUSE_HEADMERGE")) == 0);
+    if (mergeOn && j + 2 < ops.size() && ops[j + 1]->getOpType() == OpType::Transpose && ops[j + 2]->getOpType() == OpType::Reshape &&
+        soleConsumerIs(out, ops[j + 1]) && soleConsumerIs(ops[j + 1]->getOutput(), ops[j + 2]) &&
+        ops[j + 2]->getInputs(0) == ops[j + 1]->getOutput()) {
+        const auto perm = as<TransposeObj>(ops[j + 1])->getPermute();
+        const Tensor r = ops[j + 2]->getOutput();
+        if (perm.size() == 4 && perm[0] == 0 && perm[1] == 2 && perm[2] == 1 && perm[3] == 3 && r->getBytes() == out->getBytes() &&
+            r->getDType() == out->getDType()) {
+            dstT = r;
+            heads = h;
+            last = j + 2;
+        }
+    }
     // O may sit exactly on Q (the planner likes to: Q is dead after the first MatMul and has O's size): a workgroup
-    // loads its query rows before the key sweep and writes the same rows of O after it. K / V are read by everyone.
-    // Any other overlap (K and V die after their MatMul too, and have O's size) is bridged through the workspace:
-    // O is [Sq, D] per head, the copy is small next to the score traffic the fusion removes.
-    const bool onQ = out->getRawDataPtr<void *>() == q->getRawDataPtr<void *>() && out->getDims() == qd;
-    const bool hazard = (overlaps(out, q) && !onQ) || overlaps(out, k) || overlaps(out, v) ||
-                        (mask && overlaps(out, mask)) || (scale && overlaps(out, scale));
-    void *dst = out->getRawDataPtr<void *>();
+    // loads its query rows before the key sweep and writes the same rows of O after it (plain layout only). K / V are
+    // read by everyone. Any other overlap (K and V die after their MatMul too, and have O's size) is bridged through the
+    // workspace: O is [Sq, D] per head, the copy is small next to the score traffic the fusion removes.
+    const bool onQ = heads == 0 && dstT->getRawDataPtr<void *>() == q->getRawDataPtr<void *>() && dstT->getDims() == qd;
+    const bool hazard = (overlaps(dstT, q) && !onQ) || overlaps(dstT, k) || overlaps(dstT, v) ||
+                        (mask && overlaps(dstT, mask)) || (scale && overlaps(dstT, scale));
+    void *dst = dstT->getRawDataPtr<void *>();
     if (hazard)
-        dst = getWorkspace(out->getBytes());
+        dst = getWorkspace(dstT->getBytes());
     const int64_t group = mask ? (mask->getDims()[0] == 1 ? (int64_t)b * h : h) : 1;
-    ROCM_CALL(infini_rocm_attention(rt, dt, q->getRawDataPtr<void *>(), k->getRawDataPtr<void *>(), v->getRawDataPtr<void *>(),
-                                    mask ? mask->getRawDataPtr<void *>() : nullptr, dst,
-                                    (int64_t)b * h, sq, sk, d, group, scale ? scale->getRawDataPtr<void *>() : nullptr,
-                                    isDiv ? 1 : 0, 1.0f, 0));
+    ROCM_CALL(infini_rocm_attention_headmerge(rt, dt, q->getRawDataPtr<void *>(), k->getRawDataPtr<void *>(),
+                                              v->getRawDataPtr<void *>(), mask ? mask->getRawDataPtr<void *>() : nullptr, dst,
+                                              (int64_t)b * h, sq, sk, d, group, scale ? scale->getRawDataPtr<void *>() : nullptr,
+                                              isDiv ? 1 : 0, 1.0f, 0, heads));
     if (hazard)
-        ROCM_CALL(infini_rocm_copy_inside(rt, out->getRawDataPtr<void *>(), dst, out->getBytes()));
-    return j + 1 - i;
+        ROCM_CALL(infini_rocm_copy_inside(rt, dstT->getRawDataPtr<void *>(), dst, dstT->getBytes()));
+    return last + 1 - i;
 }
 
 int RocmRuntimeObj::tunedVariant(const Operator &op) const {

@@ -102,3 +102,22 @@ def test_attention_kvcache_reference_kat(rt):
     y = ops.attention_kvcache(rt, torch.zeros(1, 1, 1, 128).cuda(), torch.zeros(1, 1, 1, 128).cuda(), one(1, 1, 1, 128),
                               one(1, 1, 1, 128), one(1, 1, 1, 128), torch.zeros(1, 1, dtype=torch.int32).cuda())
     assert R.equal_data(host(y).ravel(), kat("test/kernels/cuda/test_cuda_attention.cc", 36, "float"), 1e-6)
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("case", CASES)
+def test_attention_head_merge_store_is_the_transposed_result(rt, case, dt):
+    """infini_rocm_attention_headmerge: [B, Sq, H, D] output == Transpose(0, 2, 1, 3) of the plain [B, H, Sq, D] result, bit
+    for bit (same kernel, only the store address differs), over the ragged / masked / causal cases above."""
+    b, h, sq, sk, d, use_mask, causal = case
+    rng = np.random.default_rng(abs(hash(case)) % 2 ** 32)
+    qd, kd, vd = (dev(rng.standard_normal(s), TD[dt]) for s in ((b, h, sq, d), (b, h, sk, d), (b, h, sk, d)))
+    md = None
+    if use_mask:
+        m = np.where(rng.random((b, sk)) < 0.8, 0.0, -10000.0).astype(np.float32)
+        m[:, 0] = 0.0
+        md = dev(m, TD[dt])
+    plain = ops.attention(rt, qd, kd, vd, 1.0 / np.sqrt(d), md, causal)
+    merged = ops.attention(rt, qd, kd, vd, 1.0 / np.sqrt(d), md, causal, head_merge=h)
+    assert tuple(merged.shape) == (b, sq, h, d)
+    assert torch.equal(merged, plain.permute(0, 2, 1, 3).contiguous())
