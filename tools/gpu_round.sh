@@ -14,10 +14,12 @@ echo "smoke exit $?" | tee -a $O/smoke.log
 timeout 420 python bench.py > $O/bench.json 2> $O/bench.err
 echo "bench exit $? after $(( $(date +%s) - t0 )) s"
 timeout 240 python tools/model_bench.py bert --tune > $O/bert.json 2> $O/bert.err
+timeout 240 python tools/model_bench.py llama > $O/llama.json 2> $O/llama.err
+(cd $O && timeout 300 python $REPO/tools/rocm_launch.py --nproc_per_node 1 > rocm_launch.log 2>&1; echo "rocm_launch exit $?" >> rocm_launch.log)
 if [ -z "$NO_PROFILE" ]; then
   bash tools/profile_models.sh > $O/prof.log 2>&1
   mkdir -p $O/prof
   for f in $(find gpurun_out/prof_models -name "*kernel_stats.csv"); do cp $f $O/prof/; done
 fi
 echo "total $(( $(date +%s) - t0 )) s"
-tail -3 $O/pytest.log; tail -2 $O/smoke.log; cat $O/bench.json | cut -c1-1500; cat $O/bert.json | tail -1
+tail -3 $O/pytest.log; tail -2 $O/smoke.log; cat $O/bench.json | cut -c1-1500; grep model $O/bert.json; grep model $O/llama.json; grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" $O/rocm_launch.log | tail -6
