@@ -209,13 +209,17 @@ int infini_rocm_attention(infiniRocmRuntime_t rt, int dtype, const void *q, cons
                           int64_t head_dim, int64_t mask_group, const void *scale_dev, int scale_is_div,
                           float scale, int causal);
 
-/* The same attention with the result stored head-merged: out is [batch_heads / heads, seq_q, heads, head_dim], i.e. the
- * Transpose(0, 2, 1, 3) -> Reshape([B, S, H * D]) a transformer layer applies to the context before its output projection
- * (reference: TransposeCuda transpose.cc:8-45 + CopyCuda reshape.cc:4-13) done by the kernel's own store. heads = 0: plain. */
-int infini_rocm_attention_headmerge(infiniRocmRuntime_t rt, int dtype, const void *q, const void *k, const void *v,
-                                    const void *mask, void *out, int64_t batch_heads, int64_t seq_q, int64_t seq_k,
-                                    int64_t head_dim, int64_t mask_group, const void *scale_dev, int scale_is_div,
-                                    float scale, int causal, int64_t heads);
+/* The same attention with two extensions used by the runtime's fusion:
+ *   heads > 0: the result is stored head-merged, out = [batch_heads / heads, seq_q, heads, head_dim], i.e. the
+ *     Transpose(0, 2, 1, 3) -> Reshape([B, S, H * D]) a transformer layer applies to the context before its output
+ *     projection (reference: TransposeCuda transpose.cc:8-45 + CopyCuda reshape.cc:4-13) done by the kernel's own store;
+ *   mask_2d != 0: mask is a full additive mask [batch_heads / mask_group, seq_q, seq_k] (one row per query: a causal or
+ *     sliding-window mask passed as a tensor, as exported decoder graphs do) instead of one row per key sequence.
+ * heads = 0, mask_2d = 0: exactly infini_rocm_attention. */
+int infini_rocm_attention_ex(infiniRocmRuntime_t rt, int dtype, const void *q, const void *k, const void *v,
+                             const void *mask, void *out, int64_t batch_heads, int64_t seq_q, int64_t seq_k,
+                             int64_t head_dim, int64_t mask_group, const void *scale_dev, int scale_is_div,
+                             float scale, int causal, int64_t heads, int mask_2d);
 
 /* AttentionKVCache: one decode step with in-place cache append (reference: attention_kvcache.cu:8-169).
  *   n = position_id[0] + 1; k_cache/v_cache[bh, n-1, :] = k/v[bh, :]; out[bh, :] = softmax(q . K[0:n]^T / sqrt(D)) V[0:n].

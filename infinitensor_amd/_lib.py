@@ -90,7 +90,7 @@ def lib() -> C.CDLL:
     sig("infini_rocm_rms_norm", [vp, i32, vp, vp, vp, i64, i64, f32])
     sig("infini_rocm_conv2d_set_variant", [vp, i32])
     sig("infini_rocm_attention", [vp, i32, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, vp, i32, f32, i32])
-    sig("infini_rocm_attention_headmerge", [vp, i32, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, vp, i32, f32, i32, i64])
+    sig("infini_rocm_attention_ex", [vp, i32, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, vp, i32, f32, i32, i64, i32])
     sig("infini_rocm_attention_kvcache", [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i64, i64, i64])
     sig("infini_rocm_gather_elements", [vp, i32, i32, vp, vp, vp, i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), i32])
     sig("infini_rocm_resize", [vp, i32, vp, vp, i32, pi64, pi64, C.POINTER(C.c_float), C.POINTER(C.c_float), i32, i32, i32])

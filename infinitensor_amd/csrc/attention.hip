@@ -30,6 +30,7 @@ struct AttnArgs {
     int scale_is_div; // effective scale = scale_value (0) or 1 / scale_value (1)
     float scale_imm;  // used when scale == nullptr
     int causal;
+    int mask_rows;    // 0: mask is per key [G][sk]; sq: a full additive mask [G][sq][sk] (e.g. a causal mask passed as a tensor)
     int o_heads;      // > 0: O is stored merged, [bh / o_heads][sq][o_heads][D] (Transpose(0,2,1,3) -> Reshape of the plain result)
 };
 
@@ -38,7 +39,7 @@ struct AttnArgs {
 __device__ static inline float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // CAUSAL / MASK are compile-time so that the unmasked, non-causal sweep carries no select / compare per score.
-template <typename Tr, int D, int NT, bool CAUSAL, bool MASK>
+template <typename Tr, int D, int NT, bool CAUSAL, int MASK> // MASK: 0 none, 1 per key, 2 per (query, key)
 __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     constexpr int QW = NT * 16;              // query rows per wave
     constexpr int KT = 64;                   // keys per tile
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     const unsigned short *Q = (const unsigned short *)p.q + (long)bh * p.sq * D;
     const unsigned short *K = (const unsigned short *)p.k + (long)bh * p.sk * D;
     const unsigned short *V = (const unsigned short *)p.v + (long)bh * p.sk * D;
-    const unsigned short *M = p.mask ? (const unsigned short *)p.mask + (long)(bh / p.mask_group) * p.sk : nullptr;
+    const unsigned short *M = p.mask ? (const unsigned short *)p.mask + (long)(bh / p.mask_group) * p.sk * (MASK == 2 ? p.sq : 1) : nullptr;
 
     float scale = p.scale_imm;
     if (p.scale) {
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     }
     constexpr float LOG2E = 1.4426950408889634f;
     const float c = scale * LOG2E;
-    const bool mask_vec = MASK && (p.sk % 4 == 0) && ((((uintptr_t)p.mask) & 7) == 0);
+    const bool mask_vec = MASK != 0 && (p.sk % 4 == 0) && ((((uintptr_t)p.mask) & 7) == 0);
 
     // Q fragments (B operand: lane = query column l15, 8 consecutive d)
     s16x8_t qf[NT][KS];
@@ -154,7 +155,36 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
         // ---- scale, mask, online softmax (lane: query column l15, keys kbase + mt*16 + 4*g4 + r) -----
         // additive term per key (mask * log2 e, -inf past Sk): only when there is a mask or this is the ragged last tile
         const bool ragged = kbase + KT > p.sk; // wave-uniform
-        if constexpr (MASK) {
+        if constexpr (MASK == 2) {
+            // full additive mask: the lane's query column has its own mask row; 4 consecutive keys = one 8-byte load
+            const bool mvec = !ragged && mask_vec;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                int qr = q0 + nt * 16 + l15;
+                qr = qr < p.sq ? qr : p.sq - 1; // rows past Sq are computed on the last row and never stored
+                const unsigned short *Mr = M + (long)qr * p.sk;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int key = kbase + mt * 16 + 4 * g4;
+                    unsigned short mh[4] = {0, 0, 0, 0};
+                    if (mvec) {
+                        const u32x2_t mk = *(const u32x2_t *)(Mr + key);
+                        mh[0] = (unsigned short)(mk[0] & 0xffff); mh[1] = (unsigned short)(mk[0] >> 16);
+                        mh[2] = (unsigned short)(mk[1] & 0xffff); mh[3] = (unsigned short)(mk[1] >> 16);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (key + r < p.sk)
+                                mh[r] = Mr[key + r];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float mv = key + r < p.sk ? Tr::to_f32(mh[r]) * LOG2E : -INFINITY;
+                        s[mt][nt][r] = fmaf(s[mt][nt][r], c, mv);
+                    }
+                }
+            }
+        } else if constexpr (MASK == 1) {
             const bool mvec = !ragged && mask_vec; // 4 consecutive keys = one 8-byte load
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
@@ -300,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     }
 }
 
-template <typename Tr, int D, int NT, bool CAUSAL, bool MASK>
+template <typename Tr, int D, int NT, bool CAUSAL, int MASK>
 static int launch_attn2(infiniRocmRuntime_t rt, const AttnArgs &p) {
     constexpr int LDS = 2 * (64 * (D * 2 + 16) + 64 * (D * 2 + 32));
     auto kern = attention_kernel<Tr, D, NT, CAUSAL, MASK>;
@@ -315,9 +345,12 @@ static int launch_attn2(infiniRocmRuntime_t rt, const AttnArgs &p) {
     return INFINI_ROCM_OK;
 }
 template <typename Tr, int D, int NT> static int launch_attn(infiniRocmRuntime_t rt, const AttnArgs &p) {
+    const int mk = p.mask ? (p.mask_rows ? 2 : 1) : 0;
     if (p.causal)
-        return p.mask ? launch_attn2<Tr, D, NT, true, true>(rt, p) : launch_attn2<Tr, D, NT, true, false>(rt, p);
-    return p.mask ? launch_attn2<Tr, D, NT, false, true>(rt, p) : launch_attn2<Tr, D, NT, false, false>(rt, p);
+        return mk == 2 ? launch_attn2<Tr, D, NT, true, 2>(rt, p)
+                       : (mk == 1 ? launch_attn2<Tr, D, NT, true, 1>(rt, p) : launch_attn2<Tr, D, NT, true, 0>(rt, p));
+    return mk == 2 ? launch_attn2<Tr, D, NT, false, 2>(rt, p)
+                   : (mk == 1 ? launch_attn2<Tr, D, NT, false, 1>(rt, p) : launch_attn2<Tr, D, NT, false, 0>(rt, p));
 }
 
 } // namespace irocm
@@ -328,14 +361,14 @@ extern "C" int infini_rocm_attention(infiniRocmRuntime_t rt, int dtype, const vo
                                      const void *mask, void *out, int64_t batch_heads, int64_t seq_q, int64_t seq_k,
                                      int64_t head_dim, int64_t mask_group, const void *scale_dev, int scale_is_div,
                                      float scale, int causal) {
-    return infini_rocm_attention_headmerge(rt, dtype, q, k, v, mask, out, batch_heads, seq_q, seq_k, head_dim, mask_group,
-                                           scale_dev, scale_is_div, scale, causal, 0);
+    return infini_rocm_attention_ex(rt, dtype, q, k, v, mask, out, batch_heads, seq_q, seq_k, head_dim, mask_group,
+                                    scale_dev, scale_is_div, scale, causal, 0, 0);
 }
 
-extern "C" int infini_rocm_attention_headmerge(infiniRocmRuntime_t rt, int dtype, const void *q, const void *k, const void *v,
-                                               const void *mask, void *out, int64_t batch_heads, int64_t seq_q, int64_t seq_k,
-                                               int64_t head_dim, int64_t mask_group, const void *scale_dev, int scale_is_div,
-                                               float scale, int causal, int64_t heads) {
+extern "C" int infini_rocm_attention_ex(infiniRocmRuntime_t rt, int dtype, const void *q, const void *k, const void *v,
+                                        const void *mask, void *out, int64_t batch_heads, int64_t seq_q, int64_t seq_k,
+                                        int64_t head_dim, int64_t mask_group, const void *scale_dev, int scale_is_div,
+                                        float scale, int causal, int64_t heads, int mask_2d) {
     IROCM_CHECK_ARG(rt, "NULL runtime");
     IROCM_CHECK_ARG(heads >= 0 && heads < 65536 && (heads == 0 || batch_heads % heads == 0),
                     "attention: heads %lld does not divide batch_heads %lld", (long long)heads, (long long)batch_heads);
@@ -357,6 +390,7 @@ extern "C" int infini_rocm_attention_headmerge(infiniRocmRuntime_t rt, int dtype
     p.scale_imm = scale;
     p.causal = causal;
     p.o_heads = (int)heads;
+    p.mask_rows = (mask && mask_2d) ? (int)seq_q : 0;
     const bool bf = dtype == INFINI_DT_BF16;
     if (head_dim == 64)
         return bf ? launch_attn<Bf16Traits, 64, 4>(rt, p) : launch_attn<F16Traits, 64, 4>(rt, p);

@@ -221,7 +221,8 @@ def attention(rt: RocmRuntime, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor
               mask: torch.Tensor | None = None, causal: bool = False, scale_is_div: bool = False,
               out: torch.Tensor | None = None, head_merge: int = 0) -> torch.Tensor:
     """softmax(scale * q k^T + mask) v over [..., S, D] (leading dims = batch x heads). `mask`: additive, shape
-    [G, Sk] with G dividing the number of (batch, head) pairs (row g serves pairs g*BH/G .. (g+1)*BH/G - 1).
+    [G, Sk] (one row per key sequence) or [G, Sq, Sk] (one row per query: e.g. a causal mask passed as a tensor) with G
+    dividing the number of (batch, head) pairs (row g serves pairs g*BH/G .. (g+1)*BH/G - 1).
     `scale`: a float, or a one-element device tensor (then multiply / divide per scale_is_div).
     head_merge = H > 0: the result is stored as [BH / H, Sq, H, D] (Transpose(0, 2, 1, 3) of the plain [BH / H, H, Sq, D])."""
     if q.dim() < 3 or k.shape != v.shape or q.shape[:-2] != k.shape[:-2] or q.shape[-1] != k.shape[-1]:
@@ -235,14 +236,21 @@ def attention(rt: RocmRuntime, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor
     if out is None:
         out = torch.empty((bh // head_merge, sq, head_merge, hd), dtype=q.dtype, device=q.device) if head_merge else torch.empty_like(q)
     group = 1
+    mask_2d = 0
     if mask is not None:
-        if mask.dim() != 2 or mask.shape[1] != sk or bh % mask.shape[0] != 0 or mask.dtype != q.dtype:
-            raise ValueError("mask must be [G, Sk] of q's dtype with G dividing batch x heads")
+        if mask.dim() == 3:  # full additive mask [G, Sq, Sk]
+            if mask.shape[1] != sq:
+                raise ValueError("a rank-3 mask must be [G, Sq, Sk]")
+            mask_2d = 1
+        elif mask.dim() != 2:
+            raise ValueError("mask must be [G, Sk] or [G, Sq, Sk]")
+        if mask.shape[-1] != sk or bh % mask.shape[0] != 0 or mask.dtype != q.dtype:
+            raise ValueError("mask must be [G, Sk] / [G, Sq, Sk] of q's dtype with G dividing batch x heads")
         group = bh // mask.shape[0]
     dev_scale = scale if isinstance(scale, torch.Tensor) else None
-    check(lib().infini_rocm_attention_headmerge(rt.handle, dtype_of(q), _ptr(q), _ptr(k), _ptr(v), _ptr(mask), _ptr(out), bh, sq, sk,
-                                                hd, group, _ptr(dev_scale), int(scale_is_div),
-                                                0.0 if dev_scale is not None else float(scale), int(causal), int(head_merge)))
+    check(lib().infini_rocm_attention_ex(rt.handle, dtype_of(q), _ptr(q), _ptr(k), _ptr(v), _ptr(mask), _ptr(out), bh, sq, sk,
+                                         hd, group, _ptr(dev_scale), int(scale_is_div),
+                                         0.0 if dev_scale is not None else float(scale), int(causal), int(head_merge), mask_2d))
     return out
 
 

@@ -114,6 +114,7 @@ size_t RocmRuntimeObj::tryLaunchFusedAttention(const OpVec &ops, size_t i) const
         return 0;
     const int b = qd[0], h = qd[1], sq = qd[2], sk = kd[2], d = qd[3];
     Tensor cur = mm1->getOutput(), scale = nullptr, mask = nullptr;
+    bool mask2d = false;
     size_t j = i + 1;
     bool isDiv = false;
     auto next = [&](OpType t) { return j < ops.size() && ops[j]->getOpType() == t && soleConsumerIs(cur, ops[j]); };
@@ -130,10 +131,15 @@ size_t RocmRuntimeObj::tryLaunchFusedAttention(const OpVec &ops, size_t i) const
         const Tensor a0 = ops[j]->getInputs(0), a1 = ops[j]->getInputs(1);
         const Tensor other = a0 == cur ? a1 : a0;
         const auto &md = other->getDims();
-        if (other == cur || md.size() != 4 || (md[0] != b && md[0] != 1) || md[1] != 1 || md[2] != 1 || md[3] != sk ||
+        // key mask [b|1, 1, 1, Sk] (BERT padding) or a full additive mask [b|1, h|1, Sq, Sk] with the same grouping rule:
+        // heads may only broadcast when the batch does too or both are explicit ([1,1], [b,1], [b,h])
+        const bool keyMask = md.size() == 4 && md[1] == 1 && md[2] == 1;
+        const bool fullMask = md.size() == 4 && md[2] == sq && sq > 1 && (md[1] == 1 || (md[1] == h && md[0] == b));
+        if (other == cur || md.size() != 4 || (md[0] != b && md[0] != 1) || !(keyMask || fullMask) || md[3] != sk ||
             !(other->getDType() == q->getDType()))
             return 0;
         mask = other;
+        mask2d = !keyMask;
         cur = ops[j++]->getOutput();
     }
     if (!next(OpType::Softmax) || as<SoftmaxObj>(ops[j])->getAxis() != 3)
@@ -147,7 +153,7 @@ size_t RocmRuntimeObj::tryLaunchFusedAttention(const OpVec &ops, size_t i) const
         v->getDims() != kd || !(v->getDType() == q->getDType()))
         return 0;
     // Head merge: ctx [b, h, Sq, D] -> Transpose(0, 2, 1, 3) -> Reshape [b, Sq, h * D] (what every exported transformer
-    // does before the output projection) is folded into the kernel's store (infini_rocm_attention_headmerge).
+    // does before the output projection) is folded into the kernel's store (infini_rocm_attention_ex).
     Tensor dstT = out;
     int64_t heads = 0;
     size_t last = j;
@@ -174,11 +180,12 @@ size_t RocmRuntimeObj::tryLaunchFusedAttention(const OpVec &ops, size_t i) const
     void *dst = dstT->getRawDataPtr<void *>();
     if (hazard)
         dst = getWorkspace(dstT->getBytes());
-    const int64_t group = mask ? (mask->getDims()[0] == 1 ? (int64_t)b * h : h) : 1;
-    ROCM_CALL(infini_rocm_attention_headmerge(rt, dt, q->getRawDataPtr<void *>(), k->getRawDataPtr<void *>(),
+    // pairs (batch, head) served by one mask slab: [1,1,..] all of them, [b,1,..] the heads of a batch, [b,h,..] one
+    const int64_t group = !mask ? 1 : ((mask->getDims()[1] == h && h > 1) ? 1 : (mask->getDims()[0] == 1 ? (int64_t)b * h : h));
+    ROCM_CALL(infini_rocm_attention_ex(rt, dt, q->getRawDataPtr<void *>(), k->getRawDataPtr<void *>(),
                                               v->getRawDataPtr<void *>(), mask ? mask->getRawDataPtr<void *>() : nullptr, dst,
                                               (int64_t)b * h, sq, sk, d, group, scale ? scale->getRawDataPtr<void *>() : nullptr,
-                                              isDiv ? 1 : 0, 1.0f, 0, heads));
+                                       isDiv ? 1 : 0, 1.0f, 0, heads, mask2d ? 1 : 0));
     if (hazard)
         ROCM_CALL(infini_rocm_copy_inside(rt, dstT->getRawDataPtr<void *>(), dst, dstT->getBytes()));
     return last + 1 - i;
@@ -262,7 +269,7 @@ size_t RocmRuntimeObj::tryLaunchIntoReshape(const OpVec &ops, size_t i) const {
     if (!(type == OpType::MatMul || type == OpType::Transpose || type == OpType::Add || type == OpType::Sub ||
           type == OpType::Mul || type == OpType::Div || type == OpType::Relu || type == OpType::Gelu ||
           type == OpType::Silu || type == OpType::Sigmoid || type == OpType::Tanh || type == OpType::Softmax ||
-          type == OpType::LayerNormalization || type == OpType::RMSNorm || type == OpType::Gather))
+          type == OpType::LayerNormalization || type == OpType::RMSNorm || type == OpType::Gather || type == OpType::RoPE))
         return 0;
     if (op->numOutputs() != 1 || next->numOutputs() != 1)
         return 0;

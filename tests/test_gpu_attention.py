@@ -107,7 +107,7 @@ def test_attention_kvcache_reference_kat(rt):
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("case", CASES)
 def test_attention_head_merge_store_is_the_transposed_result(rt, case, dt):
-    """infini_rocm_attention_headmerge: [B, Sq, H, D] output == Transpose(0, 2, 1, 3) of the plain [B, H, Sq, D] result, bit
+    """infini_rocm_attention_ex(heads = H): [B, Sq, H, D] output == Transpose(0, 2, 1, 3) of the plain [B, H, Sq, D] result, bit
     for bit (same kernel, only the store address differs), over the ragged / masked / causal cases above."""
     b, h, sq, sk, d, use_mask, causal = case
     rng = np.random.default_rng(abs(hash(case)) % 2 ** 32)
@@ -121,3 +121,36 @@ def test_attention_head_merge_store_is_the_transposed_result(rt, case, dt):
     merged = ops.attention(rt, qd, kd, vd, 1.0 / np.sqrt(d), md, causal, head_merge=h)
     assert tuple(merged.shape) == (b, sq, h, d)
     assert torch.equal(merged, plain.permute(0, 2, 1, 3).contiguous())
+
+
+MASK2D_CASES = [
+    # b, h, sq, sk, d, mask batch dim, mask head dim
+    (2, 3, 128, 128, 64, 1, 1),     # one [Sq, Sk] mask for everything (a causal mask as a tensor)
+    (2, 2, 100, 77, 64, 2, 1),      # per batch entry, ragged tiles, Sk % 4 != 0 (element loads)
+    (2, 2, 64, 192, 128, 2, 2),     # per (batch, head)
+    (1, 4, 256, 256, 128, 1, 1),    # Llama head
+    (1, 3, 33, 36, 64, 1, 3),       # batch 1 with a per-head mask
+]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("case", MASK2D_CASES)
+def test_attention_full_additive_mask(rt, case, dt):
+    """mask [G, Sq, Sk] (one row per query; infini_rocm_attention_ex mask_2d): random additive biases plus a causal
+    pattern of large negatives, vs the oracle; and the causal-mask tensor reproduces the kernel's own causal option."""
+    b, h, sq, sk, d, mb, mh = case
+    rng = np.random.default_rng(abs(hash(case)) % 2 ** 32)
+    q, k, v = (rng.standard_normal(s).astype(np.float32) for s in ((b, h, sq, d), (b, h, sk, d), (b, h, sk, d)))
+    m = (0.5 * rng.standard_normal((mb, mh, sq, sk))).astype(np.float32)
+    m = np.where(np.tril(np.ones((sq, sk), dtype=bool), k=sk - sq), m, -10000.0).astype(np.float32)
+    m[..., 0] = np.minimum(m[..., 0], 0) * 0  # key 0 is always admissible: no fully masked row
+    scale = 1.0 / np.sqrt(d)
+    qd, kd, vd = dev(q, TD[dt]), dev(k, TD[dt]), dev(v, TD[dt])
+    y = ops.attention(rt, qd, kd, vd, scale, dev(m.reshape(mb * mh, sq, sk), TD[dt]))
+    want = R.attention(R.round_to(q, dt), R.round_to(k, dt), R.round_to(v, dt), scale, R.round_to(m, dt))
+    assert np.allclose(host(y), want, rtol=TOL[dt], atol=TOL[dt])
+    if sq == sk:
+        causal_tensor = np.triu(np.full((sq, sk), -10000.0, np.float32), 1)[None]
+        y_mask = ops.attention(rt, qd, kd, vd, scale, dev(causal_tensor, TD[dt]))
+        y_flag = ops.attention(rt, qd, kd, vd, scale, None, True)
+        assert np.allclose(host(y_mask), host(y_flag), rtol=TOL[dt], atol=TOL[dt])
