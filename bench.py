@@ -338,7 +338,7 @@ def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
 
 def pmc_traffic():
     """HBM-side bytes per GEMM launch from the committed PMC passes (tools/profile_gemm.sh); None if absent."""
-    p = REPO / "profiles" / "r01_gemm256_v2_pmc.json"
+    p = REPO / "profiles" / "r01_gemm256_v7_pmc.json"
     try:
         return float(json.loads(p.read_text())["traffic_bytes_per_launch"])
     except Exception:  # noqa: BLE001
@@ -445,7 +445,7 @@ def main() -> int:
             "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
             "traffic": pmc_traffic(),
-            "traffic_source": "profiles/r01_gemm256_v2_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel and shape; bytes per launch, FETCH_SIZE x2 per the gfx950 note)",
+            "traffic_source": "profiles/r01_gemm256_v7_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel and shape; bytes per launch, FETCH_SIZE x2 per the gfx950 note)",
             "kernel_us": round(kernel_s * 1e6, 3),
             "peak_from_device": round(info["compute_units"] * 4096 * info["clock_mhz"] * 1e6 / 1e12, 1),
         },
