@@ -242,9 +242,10 @@ def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
 
         h = ops.rms_norm(rt, x, n1, 1e-5)
         q, k = heads(rope(ops.matmul(rt, h, w_q))), heads(rope(ops.matmul(rt, h, w_k)))
-        v = heads(ops.matmul(rt, h, w_v))
-        ctx = ops.attention(rt, q, k, v, scale, scale_is_div=True)  # fused prefill attention (csrc/attention.hip)
-        ctx = ops.transpose(rt, ctx.view(Bt, heads_local, S, D), (0, 2, 1, 3)).view(T, heads_local * D)
+        # v: the head split is the GEMM's own store; the context: the head merge is the attention kernel's own store
+        # (what the runtime's fusion does to MatMul -> Reshape -> Transpose and to the chain's trailing Transpose -> Reshape)
+        v = ops.matmul(rt, h, w_v, head_split=(S, D)).view(Bt * heads_local, S, D)
+        ctx = ops.attention(rt, q, k, v, scale, scale_is_div=True, head_merge=heads_local).view(T, heads_local * D)
         o = ops.matmul(rt, ctx, w_o)
         if reduce:
             ops.all_reduce(rt, "sum", o, out=o)

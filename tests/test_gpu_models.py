@@ -224,3 +224,45 @@ def test_llama_block_tp_shards_sum_to_the_unsharded_block(plugin_backend):
         assert np.abs(d_sum - d_full).max() <= 1e-4 * np.abs(d_full).max(), world
         # a single shard is NOT the answer (the test would be vacuous if sharding did nothing)
         assert np.abs(parts[0][0] - o_full).max() > 1e-2 * np.abs(o_full).max()
+
+
+def test_resnet50_bs128_full_size_properties(plugin_backend):
+    """BASELINE config 3 at its full size (bs128, 224x224, fp16, fused launches + hipGraph), through size-independent
+    properties: the run is deterministic (two replays are bit-identical), every logit is finite, and the network is
+    batch-consistent — image i of the 128-batch produces the logits the same image produces in a 2-image batch built
+    with the same weights (different tile shapes and kernels per layer; fp16 tolerance)."""
+    from model_bench import Builder, build_resnet50
+
+    B = plugin_backend
+    rocm = B.RocmRuntime(0)
+
+    state = {}
+
+    def logits(batch, pick=None):
+        bl = Builder(B, rocm, "f16", seed=0)
+        out = build_resnet50(bl, batch)
+        idx = next(i for i, (t, a) in enumerate(bl.feeds) if a.ndim == 4 and a.shape[1] == 3 and a.shape[2] == 224)
+        if pick is None:
+            state["arrays"] = [a for _, a in bl.feeds]
+        else:  # the SAME weights as the 128-batch build (the builder draws the input first, so re-use its arrays) and two of its images
+            for i, (t, a) in enumerate(bl.feeds):
+                src = state["arrays"][i][pick] if i == idx else state["arrays"][i]
+                assert src.shape == a.shape
+                bl.feeds[i] = (t, np.ascontiguousarray(src))
+        bl.finish()
+        bl.h.run_with_hipgraph()
+        first = out.copyout_numpy().astype(np.float64).reshape(batch, 1000)
+        for t, a in bl.feeds:
+            t.copyin_numpy(np.ascontiguousarray(a))
+        bl.h.run_with_hipgraph()
+        second = out.copyout_numpy().astype(np.float64).reshape(batch, 1000)
+        return first, second
+
+    a1, a2 = logits(128)
+    assert np.isfinite(a1).all()
+    assert np.array_equal(a1, a2)
+    pick = [5, 77]
+    b1, _ = logits(2, pick)
+    scale = np.abs(a1).max()
+    assert np.abs(a1[pick] - b1).max() <= 2e-2 * scale, (np.abs(a1[pick] - b1).max(), scale)
+    assert (a1[pick].argmax(1) == b1.argmax(1)).all()

@@ -164,3 +164,30 @@ def test_add_norm_matches_the_chain(rt, shape, rms, dt):
     f, c = fused.float(), chain.float()
     assert torch.allclose(f, c, rtol=ulp, atol=ulp * 1e-2)
     assert (f != c).float().mean().item() < 1e-3
+
+
+@pytest.mark.parametrize("dt", ["f16", "f32"])
+def test_softmax_bert_full_size_properties(rt, dt):
+    """BASELINE config 4's softmax at its full size ([32, 12, 512, 512] = 196 608 rows of 512) through size-independent
+    properties: every row sums to 1, is non-negative and keeps the arg-max of its input; softmax(x + c) == softmax(x)
+    for a per-row constant; 64 sampled rows equal the oracle."""
+    import torch
+
+    tdt = {"f16": torch.float16, "f32": torch.float32}[dt]
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = (torch.randn(32, 12, 512, 512, device="cuda", generator=g) * 3).to(tdt)
+    y = ops.softmax(rt, x, 3)
+    rt.sync()
+    sums = y.float().sum(-1)
+    tol = 2e-3 if dt == "f16" else 1e-5
+    assert float((sums - 1).abs().max()) <= tol * 4
+    assert float(y.float().min()) >= 0
+    assert bool((y.float().argmax(-1) == x.float().argmax(-1)).float().mean() > 0.999)  # ties in f16 storage aside
+    if dt == "f32":
+        shift = torch.randn(32, 12, 512, 1, device="cuda", generator=g)
+        y2 = ops.softmax(rt, (x + shift).contiguous(), 3)
+        assert float((y2 - y).abs().max()) <= 2e-6
+    rows = np.random.default_rng(0).integers(0, 32 * 12 * 512, 64)
+    xs = x.view(-1, 512)[torch.from_numpy(rows).cuda()].float().cpu().numpy().astype(np.float64)
+    ys = y.view(-1, 512)[torch.from_numpy(rows).cuda()].float().cpu().numpy().astype(np.float64)
+    assert np.allclose(ys, R.softmax(xs, 1), rtol=tol, atol=tol)
