@@ -45,7 +45,7 @@ struct ConvS1Args {
     int tiles_m, tiles_n;
     int act;
     int kdim, kpad;      // ROWTAP: C*R*S and its round-up to 32 (w is [F][kpad])
-    int wide_epilogue;   // 16-byte stores where the plane allows (tuning hook IROCM_CONV_WIDE=0 turns it off)
+    int wide_epilogue;   // LDS-staged 16-byte-run epilogue: 0 off, 1 even planes only, 2 also odd planes (IROCM_CONV_WIDE)
     int epi_probe;       // ablation hook, 0 in production
     unsigned x_bytes;    // bytes of everything behind x
     unsigned y_bytes;    // bytes of y (= bytes of the residual); 0 when they do not fit 32-bit buffer offsets
@@ -691,7 +691,11 @@ __global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void conv_s1_kernel(ConvS1
     else
         sweep(std::false_type{});
 
-    if (p.wide_epilogue == 1 && (!p.res || p.y_bytes) && (p.hw & 1) == 0) { // workgroup-uniform
+    // even planes: dword-aligned runs (and the residual's buffer loads need them); odd planes (7x7): the rows start on
+    // 2-byte boundaries, plain global stores take that (unaligned access mode): wide_epilogue == 2, the default — measured on
+    // ResNet-50's 7x7 layers (bs128): 512->2048 67 -> 41 us, 2048->512 61 -> 46, 3x3 512 112 -> 97, 1024->2048/2 110 -> 83
+    if ((p.wide_epilogue == 1 && (!p.res || p.y_bytes) && (p.hw & 1) == 0) ||
+        (p.wide_epilogue == 2 && ((p.hw & 1) == 0 ? (!p.res || p.y_bytes) : !p.res))) { // workgroup-uniform
         __syncthreads(); // the K-loop's stages are dead: reuse them as the waves' staging images
         conv_tile_epilogue_lds<Tr>(p, acc, bias_v, m0, n0, wm, wn, lane, smem + w * kEpiWaveBytes);
         return;
@@ -831,7 +835,7 @@ __global__ __launch_bounds__(256, (NKB <= 2 ? 2 : 1)) void conv_pw_kernel(ConvS1
         }
     };
 
-    const bool lds_epi = p.wide_epilogue == 1 && (!p.res || p.y_bytes); // hw is even here
+    const bool lds_epi = p.wide_epilogue >= 1 && (!p.res || p.y_bytes); // hw is even here
     char *const epi = NKB >= 2 ? smem : bres + NKB * B_BYTES; // NKB == 1: 18 KiB of weights is too small, own region
     float bias_v[4], bias_n[4];
     load_tile_a(0);
@@ -935,7 +939,7 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
         return -1;
     p.ncols = n * p.hwp;
     p.act = act;
-    static const int wide = getenv("IROCM_CONV_WIDE") ? atoi(getenv("IROCM_CONV_WIDE")) : 1;
+    static const int wide = getenv("IROCM_CONV_WIDE") ? atoi(getenv("IROCM_CONV_WIDE")) : 2; // 0 off, 1 even planes only, 2 all
     p.wide_epilogue = wide;
     static const int epi_probe = getenv("IROCM_CONV_EPI_PROBE") ? atoi(getenv("IROCM_CONV_EPI_PROBE")) : 0;
     p.epi_probe = epi_probe;

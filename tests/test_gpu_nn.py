@@ -75,6 +75,10 @@ S1_CONVS = [
     (4, 256, 14, 14, 64, 1, 1),   # pointwise, F <= 64 tile
     (1, 64, 56, 56, 64, 3, 3),    # ResNet stage-1 3x3
     (130, 64, 2, 2, 8, 3, 3),     # many tiny images per tile
+    # ResNet stage-4 shapes: 7x7 planes (49 pixels: rows start on 2-byte boundaries, the LDS-staged epilogue stores them
+    # with unaligned 16-byte runs + a 1-pixel tail per row)
+    (4, 512, 7, 7, 2048, 1, 1), (3, 2048, 7, 7, 512, 1, 1), (2, 512, 7, 7, 512, 3, 3), (3, 512, 14, 14, 512, 3, 3, 2, 2, 1, 1),
+    (2, 64, 5, 3, 136, 1, 1),     # 15-pixel planes, ragged filter tile
     # pointwise, C <= 256, F > 64: conv_pw_kernel (input tile resident in LDS, loop over filter tiles)
     (3, 64, 8, 8, 256, 1, 1),      # one K-step per filter tile, two filter tiles, 1.5 column tiles
     (2, 128, 14, 14, 200, 1, 1),   # two K-steps, ragged filter count, 196-pixel planes (pad slots, tile spans images)
