@@ -490,11 +490,9 @@ int infini_rocm_conv2d_res(infiniRocmRuntime_t rt, int dtype, const void *x, con
     // ResNet-50 layer with tools/conv_bench.py)
     // a single K-step leaves nothing to pipeline: the small generic tile (more workgroups per CU) hides the latency better
     const bool one_kstep = (long)c * r * s <= 64 && f >= 128;
-    // measured per layer (tools/conv_bench.py, same box): on 56x56 planes the memory-bound pointwise layers with >= 128
-    // filters and <= 256 channels run 20-30 % faster on the small generic tile (6 workgroups per CU keep more bytes in
-    // flight): C64->F256 108 vs 143 us, C256->F128 107 vs 137 us; from 28x28 down conv_s1 wins everywhere
-    const bool big_plane_pointwise = r == 1 && s == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0 && groups == 1 &&
-                                     p.npix >= 2048 && f >= 128 && c <= 256;
+    // (an earlier rule sent 56x56 pointwise layers with >= 128 filters and <= 256 channels to the small generic tile; since the
+    // LDS-staged epilogue conv_s1 wins there too: C256->F128 @56x56 93 vs 112 us)
+    const bool big_plane_pointwise = false;
     // conv_pw_kernel (conv_s1.hip) candidates; IROCM_CONV_PW=2 (tuning hook) sends them there ahead of the two rules above
     static const int pw_pref = getenv("IROCM_CONV_PW") ? atoi(getenv("IROCM_CONV_PW")) : 1;
     const bool pw_shape = r == 1 && s == 1 && ph == 0 && pw == 0 && groups == 1 && c % 64 == 0 && c <= 256 && f > 64;
@@ -504,7 +502,9 @@ int infini_rocm_conv2d_res(infiniRocmRuntime_t rt, int dtype, const void *x, con
     if (variant < 0 && (one_kstep || big_plane_pointwise) && !(pw_default || (pw_pref == 2 && pw_shape)))
         goto generic;
     if (groups == 1 && variant != 1 && !(variant == 3 && pointwise_gemm) &&
-        (variant == 2 || residual || !(pointwise_gemm && f >= 256 && c >= 256 && p.npix >= 512))) {
+        // batched-GEMM route by default only for long-K pointwise layers on big planes: with K <= 512 its 256^2 tiles run 8
+        // K-tiles each and the per-tile prologue + epilogue dominates (C512->F256 @28x28: 88 us vs 66 us on conv_s1)
+        (variant == 2 || residual || !(pointwise_gemm && f >= 256 && c >= 1024 && p.npix >= 2048))) {
         const int st = launch_conv_s1(rt, dtype, x, w, bias, residual, y, (int)n, (int)c, (int)h, (int)wd, (int)f, (int)r, (int)s,
                                       ph, pw, sh, sw, dh, dw, p.oh, p.ow, act);
         if (st >= 0)
