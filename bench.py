@@ -181,6 +181,14 @@ def graph_resnet50(local_rank: int, world: int, dist_mod) -> dict:
 
     r = run_model("resnet50", local_rank, 128, iters=10, tune=True)
     mm = run_model("matmul", local_rank, dtype="f16", iters=50)  # one-operator graph: executor overhead per launch
+    other = {}
+    if world == 1:  # BASELINE configs 4 and 5 through the same drop-in path (rank-local figures, N = 1 only)
+        for key, model in (("bert_base_bs32_seq512_f16", "bert"), ("llama7b_block_2048tok_f16_tp1", "llama")):
+            try:
+                m = run_model(model, local_rank, iters=10)
+                other[key] = {k: m[k] for k in ("hipgraph_ms", "eager_ms", "hipgraph_TFLOPs", "ops", "fused_launches_per_run", "finite")}
+            except Exception as e:  # noqa: BLE001
+                other[key] = {"error": repr(e)[:200]}
     ms = torch.tensor([r["hipgraph_ms"], r["eager_ms"]], device="cuda", dtype=torch.float64)
     if world > 1:
         dist_mod.all_reduce(ms, op=dist_mod.ReduceOp.MAX)
@@ -192,7 +200,8 @@ def graph_resnet50(local_rank: int, world: int, dist_mod) -> dict:
             # this rank's figures after the reference's h.tune() (MatMul / Conv choose their kernel by measurement)
             "autotuned": {k: r[k] for k in ("tuned_hipgraph_ms", "tuned_eager_ms", "tune_seconds", "tuned_picks") if k in r},
             "matmul_4096_f16_via_executor": {"eager_ms_incl_sync": mm["eager_ms"], "hipgraph_ms_incl_sync": mm["hipgraph_ms"],
-                                             "hipgraph_TFLOPs": mm["hipgraph_TFLOPs"]}}
+                                             "hipgraph_TFLOPs": mm["hipgraph_TFLOPs"]},
+            **other}
 
 
 def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
