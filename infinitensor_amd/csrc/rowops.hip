@@ -171,12 +171,15 @@ __global__ __launch_bounds__(256) void softmax_wave_kernel(const T *__restrict__
             m = wave_max(m);
             float e[CHUNKS * VEC];
             float s = 0.f;
+            // 16-bit storage: e = 2^(x log2e - m log2e) as ONE fma + the raw v_exp_f32 (no denormal-range fix-up: a weight
+            // below 2^-126 is 0 in f16 / bf16 anyway); fp32 keeps expf (1e-6-class accuracy against the oracle)
+            const float ml2 = m * 1.4426950408889634f;
 #pragma unroll
             for (int c = 0; c < CHUNKS; ++c)
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
-                    const float d = Elem<T>::ld(&cur[r].c[c].v[j]) - m;
-                    const float ev = sizeof(T) == 4 ? expf(d) : __expf(d);
+                    const float xv = Elem<T>::ld(&cur[r].c[c].v[j]);
+                    const float ev = sizeof(T) == 4 ? expf(xv - m) : __builtin_amdgcn_exp2f(fmaf(xv, 1.4426950408889634f, -ml2));
                     e[c * VEC + j] = ev;
                     s += ev;
                 }
@@ -826,12 +829,14 @@ static int softmax_dispatch(infiniRocmRuntime_t rt, const T *x, T *y, int64_t ou
         const int chunks = (int)ceil_div(dimsize, per_chunk);
         // rows per wave: keep ~4 KiB of loads in flight per wave
         const int64_t row_bytes = dimsize * (int64_t)sizeof(T);
-        const int rpw = (!al || outer < 4096) ? 1 : (row_bytes <= 1024 ? 4 : (row_bytes <= 3072 ? 2 : 1));
+        static const int rpw8 = getenv("IROCM_SOFTMAX_RPW8") ? atoi(getenv("IROCM_SOFTMAX_RPW8")) : 0; // tuning hook
+        const int rpw = (!al || outer < 4096) ? 1 : (row_bytes <= 1024 ? (rpw8 ? 8 : 4) : (row_bytes <= 3072 ? 2 : 1));
 #define SM_GO(C, A, R)                                                                             \
     hipLaunchKernelGGL((softmax_wave_kernel<T, C, A, R>), dim3(pgrid(ceil_div(outer, 4 * R), rt->num_cu)), \
                        dim3(256), 0, rt->stream, x, y, (long)outer, (int)dimsize)
         if (chunks <= 1) {
             if (!al) SM_GO(1, false, 1);
+            else if (rpw == 8) SM_GO(1, true, 8);
             else if (rpw == 4) SM_GO(1, true, 4);
             else if (rpw == 2) SM_GO(1, true, 2);
             else SM_GO(1, true, 1);
