@@ -140,7 +140,8 @@ int infini_rocm_graph_destroy(infiniRocmGraph_t graph);
 /*   dtype F32: exact-f32 MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate.                       */
 /*   dtype F16 / BF16: v_mfma_f32_16x16x32_{f16,bf16}, fp32 accumulate, one rounding on store.  */
 /*   act: 0 none, 1 relu, 2 sigmoid, 3 tanh (reference ActType, include/core/common.h), 4 gelu  */
-/*   (erf form; used by the runtime's MatMul -> Gelu fusion); the                                */
+/*   (erf form, erff), 5 gelu with erf by Abramowitz-Stegun 7.1.26 (abs error 1.5e-7; what the  */
+/*   runtime's MatMul -> Gelu fusion uses for f16 / bf16 outputs); the                          */
 /*   reference CUDA kernel ignores it — the plugin passes 0 to stay op-for-op identical).       */
 /* ------------------------------------------------------------------------------------------ */
 int infini_rocm_matmul(infiniRocmRuntime_t rt, int dtype, const void *a, const void *b,

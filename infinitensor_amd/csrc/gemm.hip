@@ -478,7 +478,7 @@ int infini_rocm_matmul_headsplit(infiniRocmRuntime_t rt, int dtype, const void *
     IROCM_CHECK_ARG(batch >= 0 && m >= 0 && n >= 0 && k >= 0, "matmul: negative dimension");
     IROCM_CHECK_ARG(batch < 65536 && m < (1ll << 31) && n < (1ll << 31) && k < (1ll << 31),
                     "matmul: dimension too large");
-    IROCM_CHECK_ARG(act >= 0 && act <= 4, "matmul: bad act %d", act);
+    IROCM_CHECK_ARG(act >= 0 && act <= 5, "matmul: bad act %d", act);
     if (batch == 0 || m == 0 || n == 0)
         return INFINI_ROCM_OK;
     IROCM_CHECK_ARG(a && b && c, "matmul: NULL operand");

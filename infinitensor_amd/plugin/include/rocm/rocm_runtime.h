@@ -75,6 +75,8 @@ class RocmRuntimeObj : public RuntimeObj {
     // with a redirected MatMul: store the result head-split ([m / seq][n / headDim][seq][headDim]) — the
     // MatMul -> Reshape -> Transpose(0, 2, 1, 3) fusion (infini_rocm_matmul_headsplit); 0 = plain store
     static thread_local int redirectSeq, redirectHeadDim;
+    // with a redirected MatMul: activation applied in the GEMM epilogue (the MatMul -> Gelu fusion passes 5); 0 = none
+    static thread_local int redirectAct;
 
   private:
     struct TensorState {
@@ -112,6 +114,7 @@ class RocmRuntimeObj : public RuntimeObj {
     size_t tryLaunchFusedRules(const OpVec &ops, size_t i) const;
     size_t tryLaunchIntoReshape(const OpVec &ops, size_t i) const;
     size_t tryLaunchHeadSplit(const OpVec &ops, size_t i) const;
+    size_t tryLaunchMatmulGelu(const OpVec &ops, size_t i) const;
     void launchOne(const Operator &op) const; // one operator through KernelRegistry (+ its perf record, if tuned)
     size_t tryLaunchFusedAttention(const OpVec &ops, size_t i) const;
     int tunedVariant(const Operator &op) const; // kernel variant chosen by tune() for this operator's workload, or -1

@@ -13,6 +13,8 @@
 //        take the bias: its input's storage was recycled for the output)
 //   MatMul(+bias) -> Reshape [B,S,H,D] -> Transpose(0,2,1,3)        =>  matmul_headsplit (the q / k / v head split in
 //        the GEMM epilogue; f16 / bf16)
+//   MatMul(+bias) -> Gelu (f16 / bf16)                              =>  matmul(act = 5)  [opt-in, INFINI_ROCM_FUSE_GELU=1:
+//        measured slower than GEMM + the memory-bound Gelu pass]
 //   MatMul | Transpose | element-wise | Softmax | LayerNorm | Gather -> Reshape-family copy
 //                                                                  =>  the producer writes into the copy's output
 //   MatMul(Q, K^T) [-> Div|Mul(scalar)] [-> Add(mask)] -> Softmax(last axis) -> MatMul(P, V)
@@ -202,21 +204,24 @@ size_t RocmRuntimeObj::tryLaunchFused(const OpVec &ops, size_t i) const {
         return used;
     if (const size_t used = tryLaunchHeadSplit(ops, i))
         return used;
+    if (const size_t used = tryLaunchMatmulGelu(ops, i))
+        return used;
     return tryLaunchIntoReshape(ops, i);
 }
 
 namespace {
 struct OutputRedirect { // RAII: the redirection never outlives one launch
-    OutputRedirect(const TensorObj *t, void *p, int seq = 0, int headDim = 0) {
+    OutputRedirect(const TensorObj *t, void *p, int seq = 0, int headDim = 0, int act = 0) {
         RocmRuntimeObj::redirectTensor = t;
         RocmRuntimeObj::redirectPtr = p;
         RocmRuntimeObj::redirectSeq = seq;
         RocmRuntimeObj::redirectHeadDim = headDim;
+        RocmRuntimeObj::redirectAct = act;
     }
     ~OutputRedirect() {
         RocmRuntimeObj::redirectTensor = nullptr;
         RocmRuntimeObj::redirectPtr = nullptr;
-        RocmRuntimeObj::redirectSeq = RocmRuntimeObj::redirectHeadDim = 0;
+        RocmRuntimeObj::redirectSeq = RocmRuntimeObj::redirectHeadDim = RocmRuntimeObj::redirectAct = 0;
     }
 };
 } // namespace
@@ -250,6 +255,28 @@ size_t RocmRuntimeObj::tryLaunchHeadSplit(const OpVec &ops, size_t i) const {
     OutputRedirect redirect(c.get(), out->getRawDataPtr<void *>(), (int)S, (int)D);
     launchOne(ops[i]);
     return 3;
+}
+
+// MatMul(+bias) -> Gelu (BERT's FFN up-projection), f16 / bf16: the Gelu in the GEMM epilogue (act 5: erf by
+// Abramowitz-Stegun 7.1.26, ~20 VALU slots per element instead of erff's ~40). OPT-IN (INFINI_ROCM_FUSE_GELU=1): measured
+// on BERT-base bs32 seq512 it is SLOWER, 5.34 -> 5.68 ms — 50 M erf-class evaluations are ~40 us of pure VALU time on the
+// whole chip (an earlier erff version: +60 us), sitting exposed after the last K-tile, while the separate Gelu pass is a
+// 35 us memory-bound kernel. The erf form of Gelu is VALU-priced at about the cost of streaming the tensor once.
+size_t RocmRuntimeObj::tryLaunchMatmulGelu(const OpVec &ops, size_t i) const {
+    static const bool enabled = std::getenv("INFINI_ROCM_FUSE_GELU") && std::atoi(std::getenv("INFINI_ROCM_FUSE_GELU")) == 1;
+    if (!enabled || i + 1 >= ops.size() || ops[i]->getOpType() != OpType::MatMul || ops[i + 1]->getOpType() != OpType::Gelu)
+        return 0;
+    const Tensor c = ops[i]->getOutput(), out = ops[i + 1]->getOutput();
+    const int dt = c->getDTypeIndex();
+    if ((dt != INFINI_DT_F16 && dt != INFINI_DT_BF16) || ops[i + 1]->getInputs(0) != c || !soleConsumerIs(c, ops[i + 1]) ||
+        c->getBytes() != out->getBytes() || !(c->getDType() == out->getDType()))
+        return 0;
+    for (const auto &in : ops[i]->getInputs())
+        if (overlaps(out, in))
+            return 0;
+    OutputRedirect redirect(c.get(), out->getRawDataPtr<void *>(), 0, 0, 5);
+    launchOne(ops[i]);
+    return 2;
 }
 
 // producer -> Reshape | Flatten | Identity | Squeeze | Unsqueeze: the reference runs these as a device memcpy

@@ -183,9 +183,12 @@ class MatmulRocm : public RocmTunableKernel {
         }
         // `act` is ignored like in the reference CUDA kernel (matmul.cc never reads getAct())
         // head-split store requested by the MatMul -> Reshape -> Transpose fusion for THIS op's output (rocm_fusion.cc)
-        const bool split = C.get() == RocmRuntimeObj::redirectTensor && RocmRuntimeObj::redirectHeadDim > 0;
+        const bool redirected = C.get() == RocmRuntimeObj::redirectTensor;
+        const bool split = redirected && RocmRuntimeObj::redirectHeadDim > 0;
+        // `act` of the operator is ignored like in the reference CUDA kernel; a fused Gelu arrives through the redirect
         ROCM_CALL(infini_rocm_matmul_headsplit(H(ctx), DTI(A), P(A), P(B), bias, P(C), b, m, n, k, op->getTransA(),
-                                               op->getTransB(), strideA, strideB, bsb, bsm, bsn, 0,
+                                               op->getTransB(), strideA, strideB, bsb, bsm, bsn,
+                                               redirected ? RocmRuntimeObj::redirectAct : 0,
                                                split ? RocmRuntimeObj::redirectSeq : 0,
                                                split ? RocmRuntimeObj::redirectHeadDim : 0));
     }

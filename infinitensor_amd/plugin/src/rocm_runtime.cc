@@ -127,6 +127,7 @@ thread_local const TensorObj *RocmRuntimeObj::redirectTensor = nullptr;
 thread_local void *RocmRuntimeObj::redirectPtr = nullptr;
 thread_local int RocmRuntimeObj::redirectSeq = 0;
 thread_local int RocmRuntimeObj::redirectHeadDim = 0;
+thread_local int RocmRuntimeObj::redirectAct = 0;
 
 void RocmRuntimeObj::runWithoutSync(const Graph &graph) const {
     std::lock_guard<std::recursive_mutex> lock(executionMutex);

@@ -212,3 +212,27 @@ def test_matmul_head_split_rejects_bad_tilings(rt):
         ops.matmul(rt, a, w, head_split=(48, 16))  # 48 does not divide m = 64
     with pytest.raises(ValueError):
         ops.matmul(rt, a, w, head_split=(32, 12))  # head_dim % 8 != 0
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+@pytest.mark.parametrize("variant", [-1, 0, 1, 6, 7])
+def test_matmul_fast_gelu_epilogue(rt, dtype, tol, variant):
+    """act = 5: Gelu (erf form) in the GEMM epilogue with erf by Abramowitz-Stegun 7.1.26 (abs error 1.5e-7) vs the oracle's
+    exact Gelu of the fp64 product, over the whole input range incl. the negative tail (no cancellation in 1 + erf), and
+    against act = 4 (erff) to one output ulp."""
+    rng = np.random.default_rng(9)
+    a = (rng.standard_normal((512, 256)) * 1.5).astype(np.float32)
+    w = (rng.standard_normal((256, 768)) / 8).astype(np.float32)
+    bias = rng.standard_normal((768,)).astype(np.float32)
+    name = {torch.float16: "f16", torch.bfloat16: "bf16"}[dtype]
+    ops.set_matmul_variant(rt, variant)
+    try:
+        y5 = ops.matmul(rt, dev(a, dtype), dev(w, dtype), dev(bias, dtype), act=5)
+        y4 = ops.matmul(rt, dev(a, dtype), dev(w, dtype), dev(bias, dtype), act=4)
+    finally:
+        ops.set_matmul_variant(rt, -1)
+    pre = R.matmul(R.round_to(a, name), R.round_to(w, name), R.round_to(bias, name))
+    assert np.abs(pre).max() > 6 and pre.min() < -6  # the tails are exercised
+    want = R.unary("gelu", pre)
+    assert np.allclose(host(y5), want, rtol=tol, atol=tol)
+    assert np.allclose(host(y5), host(y4), rtol=tol, atol=tol / 4)
