@@ -1,6 +1,9 @@
 """The C-ABI library loads and exports every symbol include/infini_rocm.h declares (no GPU)."""
 import ctypes
 
+import pytest
+from conftest import REPO
+
 from infinitensor_amd import _lib
 
 
@@ -44,3 +47,20 @@ def test_no_oracle_import_in_product():
     for f in pkg.rglob("*.py"):
         txt = f.read_text()
         assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+
+
+def test_bench_has_no_cpu_fallback():
+    """bench.py on a box without a GPU must fail loudly: non-zero exit, no JSON line (the product path never routes
+    through the oracle or any CPU implementation)."""
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("has a GPU")
+    p = subprocess.run([sys.executable, str(REPO / "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode != 0
+    assert not any(line.startswith("{") for line in p.stdout.splitlines())
+    assert "GPU" in p.stderr
