@@ -332,13 +332,15 @@ def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
     gemm_shards = {
         "workload": "one bf16 4096^3 GEMM strong-scaled over %d GPUs" % world,
         "column_shard_ms": round(col_ms, 4), "column_shard_TFLOPs_aggregate": round(2.0 * G ** 3 / col_ms / 1e9, 1),
-        "k_shard_allreduce_ms": round(k_ms, 4), "k_shard_TFLOPs_aggregate": round(2.0 * G ** 3 / k_ms / 1e9, 1),
+        # a K shard needs world > 1 (at world 1 it is the plain GEMM and the all-reduce is an identity copy)
+        "k_shard_allreduce_ms": round(k_ms, 4) if world > 1 else None,
+        "k_shard_TFLOPs_aggregate": round(2.0 * G ** 3 / k_ms / 1e9, 1) if world > 1 else None,
     }
     return {
         "workload": "Llama-7B-style block (RMSNorm, q/k/v, RoPE, attention, o, RMSNorm, gate/up/SiLU, down), tokens 2048, fp16, TP=%d (2 all-reduces of 16 MiB)" % world,
         "ms_per_block": round(ms, 4),
         "gemm_TFLOPs_aggregate": round(tp.llama_block_flops(T, H, F, 1) / ms / 1e9, 1),
-        "allreduce_16MiB_ms": round(ar_ms, 4),
+        "allreduce_16MiB_ms": round(ar_ms, 4) if world > 1 else None,  # an identity copy at world 1: not a number
         "allreduce_busbw_GBs": round(2 * (world - 1) / world * nbytes / (ar_ms * 1e-3) / 1e9, 1) if world > 1 else None,
         "gemm_strong_scaling": gemm_shards,
         "max_abs_diff_vs_unsharded": tp_diff,
@@ -355,11 +357,43 @@ def pmc_traffic():
         return None
 
 
+def self_spawn(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in the environment — exactly what `python -m torch.distributed.run` would set) and relay
+    rank 0's output. Mirrors the reference launcher, which spawns its own workers
+    (examples/distributed/cuda/cuda_launch.py:110-130)."""
+    import socket
+    import subprocess
+
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(REPO / "bench.py"), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
 def main() -> int:
     args = parse()
     if args.cpu_baseline_worker:
         print(json.dumps(_cpu_baseline_worker()), flush=True)
         return 0
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_spawn(args)
     import torch
 
     from infinitensor_amd import RocmRuntime, ops
@@ -482,6 +516,19 @@ def main() -> int:
     wd.daemon = True
     wd.start()
 
+    try:  # the measured denominator: what the matrix pipes sustain on this chip with no memory traffic at all
+        sys.path.insert(0, str(REPO / "tools"))
+        from mfma_ceiling import mfma_ceiling
+
+        att = mfma_ceiling(rt, torch.bfloat16, iters=2000, reps=10, fill="normal")
+        line["roofline"]["attainable_peak"] = round(att, 1)
+        line["roofline"]["frac_of_attainable"] = round(achieved / att, 4)
+        line["roofline"]["attainable_peak_source"] = ("MFMA-only kernel (csrc/probe.hip: the GEMM's v_mfma_f32_16x16x32 stream, 8 waves "
+                                                      "per CU, N(0,1) bf16 operands, no memory / LDS instructions), same process")
+    except Exception as e:  # noqa: BLE001
+        line["roofline"]["attainable_peak"] = None
+        line["roofline"]["attainable_peak_error"] = repr(e)[:200]
+
     if not args.no_tp:
         try:  # never let the secondary measurement take the headline line down
             line["tp_block"] = tp_block(rt, ops, Event, world, rank, td if dist else None)
@@ -500,12 +547,20 @@ def main() -> int:
                 cb = cpu_baseline_reference()
             except Exception as e:  # keep the bench line even if the oracle module is missing
                 cb = {"error": repr(e)}
-            if cb is not None:
-                line["cpu_baseline"] = cb
             try:
-                line["cpu_standin_mkl"] = cpu_standin_mkl()
+                mkl = cpu_standin_mkl()
             except Exception as e:
-                line["cpu_standin_mkl"] = {"error": repr(e)}
+                mkl = {"error": repr(e)}
+            if cb is not None:
+                # top-level value / cores / kind / sample = the reference's own CPU kernel (the contract's fields);
+                # both CPU figures of BASELINE.md section 3 sit inside this one object, cores stated for each
+                cb = dict(cb)
+                cb["reference_1core"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample") if k in cb}
+                cb[f"mkl_standin_{mkl.get('cores', os.cpu_count())}core"] = mkl
+                cb["host_cores"] = os.cpu_count()
+                line["cpu_baseline"] = cb
+            else:
+                line["cpu_baseline"] = {"error": "oracle/_ref is not built", f"mkl_standin_{os.cpu_count()}core": mkl}
         if world == 1 and not args.no_extras:
             try:
                 line["extras"] = extras(rt, ops, Event)

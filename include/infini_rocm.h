@@ -113,6 +113,21 @@ int infini_rocm_memset(infiniRocmRuntime_t rt, void *dst, int value, size_t byte
 /* Scratch valid until the next call on the same runtime that asks for workspace
  * (reference: getWorkspace, include/cuda/cuda_runtime.h:85-88; grows on demand instead of 7 GiB). */
 int infini_rocm_workspace(infiniRocmRuntime_t rt, size_t bytes, void **ptr);
+/* Growing the workspace never frees the block it outgrows (hipGraph execs captured earlier still address it; the
+ * reference's fixed 7 GiB block never moves either): outgrown blocks are retired and stay allocated until
+ * _trim (call it only when no captured graph of this runtime is alive) or runtime destruction. Growth is also
+ * legal while the stream is capturing. _info reports the current size, the number of retired blocks and an epoch
+ * that changes whenever the current block does. */
+int infini_rocm_workspace_trim(infiniRocmRuntime_t rt);
+int infini_rocm_workspace_info(infiniRocmRuntime_t rt, size_t *bytes, size_t *retired_blocks, uint64_t *epoch);
+
+/* Diagnostics: one launch of the MFMA-only ceiling kernel (csrc/probe.hip) — the headline GEMM's MFMA stream (8 waves
+ * per workgroup, one workgroup per CU, v_mfma_f32_16x16x32 on 8 x 4 accumulator tiles) with no memory or LDS
+ * instruction in the loop, on the caller's operand data (>= 1.5 MiB of 16-bit values; sink >= compute_units * 512
+ * floats). *flop = FLOP of the launch. Timed with events it gives the matrix-pipe throughput the chip SUSTAINS under
+ * its power budget — the attainable denominator next to the nominal 2.5 PFLOP/s (bench.py roofline.attainable_peak). */
+int infini_rocm_probe_mfma_ceiling(infiniRocmRuntime_t rt, int dtype, const void *data, void *sink, int iters,
+                                   double *flop);
 
 /* Events on the runtime stream, for timing (reference: timeit, src/core/common.cc:7-22). */
 int infini_rocm_event_create(infiniRocmEvent_t *ev);
@@ -231,8 +246,9 @@ int infini_rocm_attention_kvcache(infiniRocmRuntime_t rt, int dtype, void *k_cac
                                   int64_t batch_heads, int64_t max_seq, int64_t head_dim);
 
 /* RoPE, rotate-half form (reference: _rope_kernel, src/kernels/cuda/rope.cu:6-31; glue rope.cc:8-33).
- * x, y: [tokens, dim_model] with dim_model a multiple of dim_head; pos: one position per token
- * (I32 / U32 / I64). The reference hard-codes dim_head = 128 and theta = 10000 and its launch covers a
+ * x, y: [tokens, dim_model]; a trailing partial head (dim_model % dim_head != 0) is accepted and its missing
+ * partner columns count as 0 (what test_cuda_rope.cc:17-31 relies on: dim_model 32, head dim 128); pos: one
+ * position per token (I32 / U32 / I64). The reference hard-codes dim_head = 128 and theta = 10000 and its launch covers a
  * single (batch, position) (rope.cu:85): here every token is rotated. */
 int infini_rocm_rope(infiniRocmRuntime_t rt, int dtype, int pos_dtype, const void *pos, const void *x,
                      void *y, int64_t tokens, int64_t dim_model, int64_t dim_head, float theta);
@@ -403,6 +419,13 @@ int infini_rocm_gather_elements(infiniRocmRuntime_t rt, int dtype, int index_dty
 int infini_rocm_where(infiniRocmRuntime_t rt, int dtype, const void *x, const void *y, const void *cond,
                       void *out, int ndim, const int64_t *shape, const int64_t *stride_x,
                       const int64_t *stride_y, const int64_t *stride_c);
+/* Same, with the condition read in `cond_dtype` (non-zero = true; -0.0 is false). The reference's CUDA Less writes
+ * bool BYTES into an output the graph declares with the operand dtype (element_wise.cu:101-131) and WhereCuda reads
+ * bytes; this backend's comparisons write whole elements (as the native-CPU kernels do), so the plugin's Where passes
+ * the condition tensor's dtype and a Less -> Where chain behaves the same on either convention. */
+int infini_rocm_where_ex(infiniRocmRuntime_t rt, int dtype, int cond_dtype, const void *x, const void *y,
+                         const void *cond, void *out, int ndim, const int64_t *shape, const int64_t *stride_x,
+                         const int64_t *stride_y, const int64_t *stride_c);
 /* Pad (constant 0) and Slice in one kernel, like the reference (PadSliceCudaCompute,
  * src/kernels/cuda/pad_slice.cc:4-45): out[i] = in[starts + i*steps] when inside `in`, else 0.
  * Slice: starts >= 0 (steps honoured — the reference CUDA kernel ignores them, pad_slice.cc:35-40);

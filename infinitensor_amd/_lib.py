@@ -71,6 +71,9 @@ def lib() -> C.CDLL:
     sig("infini_rocm_copy_inside", [vp, vp, vp, sz])
     sig("infini_rocm_memset", [vp, vp, i32, sz])
     sig("infini_rocm_workspace", [vp, sz, pvp])
+    sig("infini_rocm_workspace_trim", [vp])
+    sig("infini_rocm_workspace_info", [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(C.c_uint64)])
+    sig("infini_rocm_probe_mfma_ceiling", [vp, i32, vp, vp, i32, C.POINTER(C.c_double)])
     sig("infini_rocm_event_create", [pvp])
     sig("infini_rocm_event_destroy", [vp])
     sig("infini_rocm_event_record", [vp, vp])
@@ -111,6 +114,7 @@ def lib() -> C.CDLL:
     sig("infini_rocm_expand", [vp, i32, vp, vp, i32, pi64, pi64])
     sig("infini_rocm_gather", [vp, i32, i32, vp, vp, vp, i64, i64, i64, i64])
     sig("infini_rocm_where", [vp, i32, vp, vp, vp, vp, i32, pi64, pi64, pi64, pi64])
+    sig("infini_rocm_where_ex", [vp, i32, i32, vp, vp, vp, vp, i32, pi64, pi64, pi64, pi64])
     sig("infini_rocm_pad_slice", [vp, i32, vp, vp, i32, pi64, pi64, pi64, pi64, i32])
     sig("infini_rocm_strided_copy", [vp, vp, vp, i64, i64, i64, i64])
     sig("infini_rocm_comm_init", [vp, C.c_char_p, i32, i32])

@@ -334,11 +334,7 @@ template <typename Tr, int D, int NT, bool CAUSAL, int MASK>
 static int launch_attn2(infiniRocmRuntime_t rt, const AttnArgs &p) {
     constexpr int LDS = 2 * (64 * (D * 2 + 16) + 64 * (D * 2 + 32));
     auto kern = attention_kernel<Tr, D, NT, CAUSAL, MASK>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        IROCM_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_done = true;
-    }
+    IROCM_LDS_ATTR(kern, LDS, rt);
     dim3 grid((unsigned)ceil_div(p.sq, 4 * NT * 16), (unsigned)p.bh);
     hipLaunchKernelGGL(kern, grid, dim3(256), LDS, rt->stream, p);
     IROCM_LAUNCH_CHECK("attention");

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "infini_rocm.h"
 
@@ -77,6 +78,25 @@ inline const char *dtype_name(int dt) {
     }
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: one flag per (call site,
+// device), set under a lock, with the runtime's device made current first (a second RocmRuntime on another GPU of the
+// same process gets its own attribute call; launches below it then run with that device current).
+struct DeviceOnce {
+    std::mutex mu;
+    uint64_t done = 0;
+};
+#define IROCM_LDS_ATTR(kern, bytes, rt)                                                            \
+    do {                                                                                           \
+        static ::irocm::DeviceOnce _once;                                                          \
+        IROCM_HIP(hipSetDevice((rt)->device));                                                     \
+        std::lock_guard<std::mutex> _lk(_once.mu);                                                 \
+        const uint64_t _bit = 1ull << ((rt)->device & 63);                                         \
+        if (!(_once.done & _bit)) {                                                                \
+            IROCM_HIP(hipFuncSetAttribute((const void *)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+            _once.done |= _bit;                                                                    \
+        }                                                                                          \
+    } while (0)
+
 constexpr int kNumXcd = 8; // MI355X: 8 XCDs, block b is dispatched to XCD b % 8 (speed only)
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -90,6 +110,8 @@ struct infiniRocmRuntime {
     hipStream_t stream = nullptr; // the stream kernels launch on (own or adopted)
     void *workspace = nullptr;
     size_t workspace_bytes = 0;
+    std::vector<void *> retired;  // outgrown workspace blocks, kept alive for the graph execs that captured them
+    uint64_t workspace_epoch = 0; // bumped whenever `workspace` changes
     bool capturing = false;
     int matmul_variant = -1;
     int conv_variant = -1;

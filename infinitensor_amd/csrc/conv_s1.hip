@@ -877,11 +877,7 @@ __global__ __launch_bounds__(256, (NKB <= 2 ? 2 : 1)) void conv_pw_kernel(ConvS1
 template <typename Tr, int NKB> static int launch_pw_n(infiniRocmRuntime_t rt, ConvS1Args &p) {
     constexpr int LDS = NKB * (128 * 72 * 2 + 64 * 256) + (NKB == 1 ? 4 * kEpiWaveBytes : 0);
     auto kern = conv_pw_kernel<Tr, NKB>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        IROCM_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_done = true;
-    }
+    IROCM_LDS_ATTR(kern, LDS, rt);
     hipLaunchKernelGGL(kern, dim3((unsigned)p.tiles_n), dim3(256), LDS, rt->stream, p);
     IROCM_LAUNCH_CHECK("conv_pw");
     return INFINI_ROCM_OK;
@@ -906,11 +902,7 @@ static int launch_s1(infiniRocmRuntime_t rt, ConvS1Args &p) {
     const long blocks = (long)p.tiles_m * p.tiles_n;
     IROCM_CHECK_ARG(blocks < (1l << 31), "conv2d: too many tiles");
     auto kern = conv_s1_kernel<Tr, WM, WN, BK, ROWTAP>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        IROCM_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + (ROWTAP ? 16384 : 0)));
-        attr_done = true;
-    }
+    IROCM_LDS_ATTR(kern, LDS + (ROWTAP ? 16384 : 0), rt);
     const int lds = LDS + (ROWTAP ? p.kpad * 8 : 0); // + the per-k table
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, rt->stream, p);
     IROCM_LAUNCH_CHECK("conv_s1");

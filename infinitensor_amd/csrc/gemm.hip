@@ -16,7 +16,10 @@
 //       destination is lane-linear); M/N-major operands ([k][cols], the ONNX MatMul "NN" B and
 //       the transA A) are read with the gfx950 transpose read ds_read_b64_tr_b16, so no
 //       transposition pass is ever materialised.
-//   gemm_256 (gemm256.hip)         : 256x256x64 tile, 8 waves, deeper pipeline (headline shape).
+//   gemm_256 (gemm256.hip)         : 256x256x64 tile, 8 waves, staggered LOAD | COMPUTE schedule; one tile per
+//       workgroup, and the split-K form for few-tile / long-K shapes.
+//   gemm256p (gemm256p_kernel.h)   : the same inner loop as ONE persistent workgroup per CU walking its tiles through a
+//       flat K-tile pipeline (no cold prologue after the first tile, epilogues overlapped); tile widths 256 / 192 / 128.
 #include "gemm_common.h"
 #include <type_traits>
 
@@ -380,10 +383,13 @@ __global__ __launch_bounds__(256) void gemm_fast128(GemmArgs p) {
 }
 
 // implemented in gemm256.hip
-int launch_gemm256(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool a_kmajor, bool b_kmajor, int sched);
+int launch_gemm256(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool a_kmajor, bool b_kmajor);
 bool gemm256_supported(const GemmArgs &p, bool a_kmajor, bool b_kmajor);
-int launch_gemm256m32(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool a_kmajor, bool b_kmajor);
-int launch_gemm256w4(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool a_kmajor, bool b_kmajor);
+namespace g256p { // persistent multi-tile kernels, tile 256 x 64 NT (gemm256p_kernel.h)
+int launch_gemm256p_nt4(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool akm, bool bkm, int early_a);
+int launch_gemm256p_nt3(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool akm, bool bkm, int early_a);
+int launch_gemm256p_nt2(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool akm, bool bkm, int early_a);
+} // namespace g256p
 int launch_gemm256_splitk(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool a_kmajor, bool b_kmajor, int splits);
 
 template <typename Tr> static int launch_fast128(infiniRocmRuntime_t rt, GemmArgs p, bool akm, bool bkm) {
@@ -394,12 +400,7 @@ template <typename Tr> static int launch_fast128(infiniRocmRuntime_t rt, GemmArg
 #define IROCM_F128(AK, BK_)                                                                        \
     do {                                                                                           \
         auto kern = gemm_fast128<Tr, AK, BK_>;                                                     \
-        static bool attr_done = false;                                                             \
-        if (!attr_done) {                                                                          \
-            IROCM_HIP(hipFuncSetAttribute((const void *)kern,                                      \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
-            attr_done = true;                                                                      \
-        }                                                                                          \
+        IROCM_LDS_ATTR(kern, (int)lds, rt);                                                        \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, rt->stream, p);                       \
     } while (0)
     if (akm && bkm) IROCM_F128(true, true);
@@ -427,10 +428,19 @@ static bool fast128_supported(const GemmArgs &p, bool akm, bool bkm) {
     return true;
 }
 
-static const char *kVariantNames[] = {"generic64", "fast128_glds", "tile256_stagger", "tile256_pipelined", "tile256_mfma32",
-                                      "tile256_4wave", "tile256_splitk", "tile256_stagger_st16"};
-constexpr int kNumVariants = 8;
-constexpr int kDefault256 = 7; // schedule used by the heuristic (staggered + 16-byte epilogue stores)
+static const char *kVariantNames[] = {"generic64", "fast128_glds", "tile256", "tile256_splitk", "persist256", "persist192",
+                                      "persist128", "persist256_late_a", "persist192_late_a", "persist128_late_a"};
+constexpr int kNumVariants = 10;
+
+// Cost model of the persistent kernels (microseconds; calibrated on MI355X with tools/gemm_shapes.py): a workgroup
+// walks ceil(tiles / CUs) tiles of nk K-tiles each; a K-tile of a 256 x 64 NT tile costs kKt[NT]; the first tile's cold
+// prologue, the last tile's store tail and the launch are paid once.
+static double persist_cost(long m, long n, long k, long batch, int nt, int cus) {
+    static const double kKt[5] = {0, 0, 0.82, 1.12, 1.44};
+    const long tiles = ceil_div(m, 256) * ceil_div(n, 64 * nt) * batch;
+    const long waves = ceil_div(tiles, cus);
+    return (double)waves * ((double)(k / 64) * kKt[nt] + 0.5) + 11.0 + 0.9 * nt;
+}
 
 } // namespace irocm
 
@@ -494,7 +504,7 @@ int infini_rocm_matmul_headsplit(infiniRocmRuntime_t rt, int dtype, const void *
     p.splitk = 1;
     p.partial = nullptr;
     p.zeros = rt->zeros;
-    p.epi16 = 1; // 16-byte epilogue stores (variant 2 forces the 8-byte epilogue for A/B runs)
+    p.epi16 = 1; // 16-byte epilogue stores
     p.hs_s = (int)seq;
     p.hs_d = (int)head_dim;
     const bool akm = !trans_a, bkm = trans_b != 0;
@@ -513,11 +523,27 @@ int infini_rocm_matmul_headsplit(infiniRocmRuntime_t rt, int dtype, const void *
         if (splits > 16) splits = 16;
     }
     if (variant < 0) {
-        // heuristic: the 256^2 kernel wants at least ~one tile per CU; otherwise split-K; otherwise 128^2.
-        if (gemm256_supported(p, akm, bkm) && tiles256 >= rt->num_cu / 2 && splits < 2)
-            variant = kDefault256;
+        // heuristic: split-K when the 256^2 tiles cannot fill the CUs and K is long; otherwise the persistent kernel
+        // with the tile width the cost model likes best (it needs at least ~half a tile per CU); otherwise 128^2.
+        const bool ok256 = gemm256_supported(p, akm, bkm);
+        int best_nt = 0;
+        if (ok256 && splits < 2) {
+            double best = 1e30;
+            for (int nt = 4; nt >= 2; --nt) {
+                const long tiles = ceil_div(m, 256) * ceil_div(n, 64 * nt) * batch;
+                if (tiles * 2 < rt->num_cu)
+                    continue;
+                const double c = persist_cost(m, n, k, batch, nt, rt->num_cu);
+                if (c < best * 0.97) { // prefer the wider tile unless a narrower one is clearly cheaper
+                    best = c;
+                    best_nt = nt;
+                }
+            }
+        }
+        if (best_nt)
+            variant = 4 + (4 - best_nt);
         else if (splits >= 2)
-            variant = 6;
+            variant = 3;
         else if (fast128_supported(p, akm, bkm))
             variant = 1;
         else
@@ -528,18 +554,18 @@ int infini_rocm_matmul_headsplit(infiniRocmRuntime_t rt, int dtype, const void *
         variant = 0;
     }
 
-    if (variant == 7)
-        return launch_gemm256(rt, dtype, p, akm, bkm, 0);
-    if (variant == 2 && rt->matmul_variant == 2)
-        p.epi16 = 0; // explicitly requested: the plain staggered kernel
-    if (variant == 6)
+    if (variant >= 4) {
+        const int early_a = variant < 7;
+        switch ((variant - 4) % 3) {
+        case 0: return g256p::launch_gemm256p_nt4(rt, dtype, p, akm, bkm, early_a);
+        case 1: return g256p::launch_gemm256p_nt3(rt, dtype, p, akm, bkm, early_a);
+        default: return g256p::launch_gemm256p_nt2(rt, dtype, p, akm, bkm, early_a);
+        }
+    }
+    if (variant == 3)
         return launch_gemm256_splitk(rt, dtype, p, akm, bkm, splits < 2 ? 2 : splits);
-    if (variant == 5)
-        return launch_gemm256w4(rt, dtype, p, akm, bkm);
-    if (variant == 4)
-        return launch_gemm256m32(rt, dtype, p, akm, bkm);
-    if (variant >= 2)
-        return launch_gemm256(rt, dtype, p, akm, bkm, variant - 2);
+    if (variant == 2)
+        return launch_gemm256(rt, dtype, p, akm, bkm);
     if (variant == 1)
         return dtype == INFINI_DT_BF16 ? launch_fast128<Bf16Traits>(rt, p, akm, bkm)
                                        : launch_fast128<F16Traits>(rt, p, akm, bkm);

@@ -14,8 +14,7 @@
 //  * ds_reads are inline asm on purpose: hipcc drains vmcnt(0) before any LDS read it can see while an
 //    LDS-DMA is in flight (no alias info on the DMA), which would serialise the pipeline.
 //
-// Two schedules (template SCHED), selectable as matmul variants for within-run A/B:
-//  SCHED 0 "staggered": per K-tile 2 phases per wave, LOAD (ds_reads + DMA issue) | COMPUTE (32 MFMAs),
+// Schedule ("staggered"): per K-tile 2 phases per wave, LOAD (ds_reads + DMA issue) | COMPUTE (32 MFMAs),
 //    4 s_barriers per K-tile; the two wave rows run offset by one barrier interval and waves w / w+4 share
 //    a SIMD, so each SIMD always has one wave in COMPUTE. (The first version used 16-MFMA segments and
 //    8 barriers: 57 % MFMA-busy — each barrier + restart costs ~150 cycles of matrix-pipe idle.)
@@ -24,20 +23,17 @@
 //      was last read in L2(t-1) = -2/-1); DMA B(t+2) -> this buffer in L2(t) (B half last read in L1(t)
 //      = 0/1). Tile t+1 = {B issued L2(t-1), A issued L1(t)}; vmcnt(4) in L2(t) + the barrier ending
 //      interval 3 precede its first read at interval 4.
-//  SCHED 1 "pipelined": every wave software-pipelines its own stream: the ds_reads of the operand
-//    sub-tile needed by quadrant q+1 are issued BEFORE the 16 MFMAs of quadrant q (two A register sets,
-//    two B register sets), so the matrix pipe never waits on the wave's own LDS latency, and there is
-//    ONE s_barrier per K-tile (between quadrants 3 and 4): before it each wave has waited for its own
-//    DMA pieces of tile t+1 (vmcnt) and has retired all its LDS reads of tile t (the last ones, A1(t),
-//    were waited for before quadrant 3); after it tile t's buffer is dead (A1(t), B0/B1(t) live in
-//    registers) and is refilled with tile t+2 — a full K-tile of prefetch distance — and quadrant 4
-//    prefetches A0(t+1), B0(t+1) from the other buffer. B register sets swap roles every tile.
+// Alternatives that were built, measured slower and removed again (numbers in DESIGN.md's tuning log): a per-wave
+// software-pipelined schedule with one barrier per K-tile (spills), a v_mfma_f32_32x32x16 variant, a 4-wave
+// 128x128-wave-tile variant with AGPR accumulators, an 8-byte-store epilogue.
+// This one-shot kernel serves grids of at most one tile per CU and split-K; gemm256p_kernel.h is its persistent
+// multi-tile edition (same inner loop).
 #include "gemm256_common.h"
 
 namespace irocm {
 namespace g256 {
 
-template <typename Tr, bool A_KMAJOR, bool B_KMAJOR, int SCHED, bool SPLITK = false>
+template <typename Tr, bool A_KMAJOR, bool B_KMAJOR, bool SPLITK = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63;
@@ -186,119 +182,62 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 
-    if constexpr (SCHED == 0) {
-        // ======================= staggered LOAD | COMPUTE schedule ==================================
-        FA aq[4][2];
-        FB bq0[2][2], bq1[2][2];
-        auto ktile = [&](auto bufc, int kt) {
-            constexpr int buf = decltype(bufc)::value;
-            using OB = std::integral_constant<int, buf ^ 1>;
-            // L1
-            read_b(I0{}, bq0);
-            read_b(I1{}, bq1);
-            read_a(I0{}, aq);
-            if (kt + 1 < nk)
-                stage_a(buf ^ 1, kt + 1);
-            wait_lgkm0();
-            barrier();
-            // C1
-            __builtin_amdgcn_s_setprio(1);
-            compute(I0{}, I0{}, aq, bq0);
-            compute(I0{}, I1{}, aq, bq1);
-            __builtin_amdgcn_s_setprio(0);
-            barrier();
-            // L2
-            read_a(I1{}, aq);
-            flip_buf(OB{}); // every read of this tile is issued: next reads come from the other buffer
-            if (kt + 2 < nk) {
-                stage_b(buf, kt + 2);
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            wait_lgkm0();
-            barrier();
-            // C2
-            __builtin_amdgcn_s_setprio(1);
-            compute(I1{}, I1{}, aq, bq1);
-            compute(I1{}, I0{}, aq, bq0);
-            __builtin_amdgcn_s_setprio(0);
-            barrier();
-        };
-        stage_b(0, 0);
-        stage_a(0, 0);
-        if (nk > 1) {
-            stage_b(1, 1);
+    // ======================= staggered LOAD | COMPUTE schedule ==================================
+    FA aq[4][2];
+    FB bq0[2][2], bq1[2][2];
+    auto ktile = [&](auto bufc, int kt) {
+        constexpr int buf = decltype(bufc)::value;
+        using OB = std::integral_constant<int, buf ^ 1>;
+        // L1
+        read_b(I0{}, bq0);
+        read_b(I1{}, bq1);
+        read_a(I0{}, aq);
+        if (kt + 1 < nk)
+            stage_a(buf ^ 1, kt + 1);
+        wait_lgkm0();
+        barrier();
+        // C1
+        __builtin_amdgcn_s_setprio(1);
+        compute(I0{}, I0{}, aq, bq0);
+        compute(I0{}, I1{}, aq, bq1);
+        __builtin_amdgcn_s_setprio(0);
+        barrier();
+        // L2
+        read_a(I1{}, aq);
+        flip_buf(OB{}); // every read of this tile is issued: next reads come from the other buffer
+        if (kt + 2 < nk) {
+            stage_b(buf, kt + 2);
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        barrier();
-        if (wr == 1)
-            barrier(); // stagger: wave row 1 runs one barrier interval behind wave row 0
-        for (int kt = 0; kt < nk; kt += 2) {
-            ktile(I0{}, kt);
-            if (kt + 1 < nk)
-                ktile(I1{}, kt + 1);
-        }
-        if (wr == 0)
-            barrier(); // balance the stagger
-    } else {
-        // ======================= per-wave software-pipelined schedule ===============================
-        FA aqA[4][2], aqB[4][2]; // A0 set, A1 set
-        FB bqX[2][2], bqY[2][2]; // the two B sets swap roles (B0 / B1) every tile
-        // tile kt lives in buffer BUF; on entry aqA = A0(kt), b0 = B0(kt) are loaded and waited for.
-        auto ktile = [&](auto bufc, int kt, FB(&b0)[2][2], FB(&b1)[2][2]) {
-            constexpr int buf = decltype(bufc)::value;
-            using OB = std::integral_constant<int, buf ^ 1>;
-            const bool more = kt + 1 < nk;
-            // Q1: prefetch B1, compute (A0,B0)
-            read_b(I1{}, b1);
-            fence_sched();
-            compute(I0{}, I0{}, aqA, b0);
-            wait_lgkm0();
-            // Q2: prefetch A1, compute (A0,B1)
-            read_a(I1{}, aqB);
-            fence_sched();
-            compute(I0{}, I1{}, aqA, b1);
-            wait_lgkm0();
-            // Q3: compute (A1,B1); then the tile hand-off
-            flip_buf(OB{}); // all reads of this tile are issued
-            compute(I1{}, I1{}, aqB, b1);
-            fence_sched();
-            if (more) {
-                // own DMA pieces of tile kt+1 have landed (they were issued a full tile ago) ...
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                barrier(); // ... everybody's have, and everybody's LDS reads of tile kt have retired
-                if (kt + 2 < nk) { // refill this tile's buffer with tile kt+2
-                    stage_a(buf, kt + 2);
-                    stage_b(buf, kt + 2);
-                }
-                // Q4: prefetch A0, B0 of tile kt+1 (into the A0 set and the dead B1 set), compute (A1,B0)
-                read_b(I0{}, b1);
-                read_a(I0{}, aqA);
-                fence_sched();
-            }
-            compute(I1{}, I0{}, aqB, b0);
-            wait_lgkm0();
-        };
-        stage_a(0, 0);
-        stage_b(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        barrier();
-        if (nk > 1) {
-            stage_a(1, 1);
-            stage_b(1, 1);
-        }
-        read_b(I0{}, bqX);
-        read_a(I0{}, aqA);
         wait_lgkm0();
-        for (int kt = 0; kt < nk; kt += 2) {
-            ktile(I0{}, kt, bqX, bqY);
-            if (kt + 1 < nk)
-                ktile(I1{}, kt + 1, bqY, bqX);
-        }
+        barrier();
+        // C2
+        __builtin_amdgcn_s_setprio(1);
+        compute(I1{}, I1{}, aq, bq1);
+        compute(I1{}, I0{}, aq, bq0);
+        __builtin_amdgcn_s_setprio(0);
+        barrier();
+    };
+    stage_b(0, 0);
+    stage_a(0, 0);
+    if (nk > 1) {
+        stage_b(1, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    barrier();
+    if (wr == 1)
+        barrier(); // stagger: wave row 1 runs one barrier interval behind wave row 0
+    for (int kt = 0; kt < nk; kt += 2) {
+        ktile(I0{}, kt);
+        if (kt + 1 < nk)
+            ktile(I1{}, kt + 1);
+    }
+    if (wr == 0)
+        barrier(); // balance the stagger
 
     // ---- epilogue ------------------------------------------------------------------------------
     if constexpr (SPLITK) { // raw fp32 partial sums of this K slice; bias / activation / rounding in splitk_reduce
@@ -496,14 +435,8 @@ template <typename Tr> static int launch256_splitk(infiniRocmRuntime_t rt, GemmA
     const unsigned grid = (unsigned)p.tiles_m * p.tiles_n * p.batch * splits;
 #define IROCM_G256S(AK, BK_)                                                                       \
     do {                                                                                           \
-        auto kern = g256::gemm256_kernel<Tr, AK, BK_, 0, true>;                                    \
-        static bool attr_done = false;                                                             \
-        if (!attr_done) {                                                                          \
-            IROCM_HIP(hipFuncSetAttribute((const void *)kern,                                      \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize,              \
-                                          g256::LDS_BYTES));                                       \
-            attr_done = true;                                                                      \
-        }                                                                                          \
+        auto kern = g256::gemm256_kernel<Tr, AK, BK_, true>;                                    \
+        IROCM_LDS_ATTR(kern, g256::LDS_BYTES, rt);                                                 \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), g256::LDS_BYTES, rt->stream, p);           \
     } while (0)
     if (akm && bkm) IROCM_G256S(true, true);
@@ -525,20 +458,14 @@ int launch_gemm256_splitk(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, 
                                    : launch256_splitk<F16Traits>(rt, p, akm, bkm, splits);
 }
 
-template <typename Tr, int SCHED> static int launch256(infiniRocmRuntime_t rt, GemmArgs p, bool akm, bool bkm) {
+template <typename Tr> static int launch256(infiniRocmRuntime_t rt, GemmArgs p, bool akm, bool bkm) {
     p.tiles_m = (int)ceil_div(p.m, g256::BM);
     p.tiles_n = (int)ceil_div(p.n, g256::BN);
     const unsigned grid = (unsigned)p.tiles_m * p.tiles_n * p.batch;
 #define IROCM_G256(AK, BK_)                                                                        \
     do {                                                                                           \
-        auto kern = g256::gemm256_kernel<Tr, AK, BK_, SCHED>;                                      \
-        static bool attr_done = false;                                                             \
-        if (!attr_done) {                                                                          \
-            IROCM_HIP(hipFuncSetAttribute((const void *)kern,                                      \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize,              \
-                                          g256::LDS_BYTES));                                       \
-            attr_done = true;                                                                      \
-        }                                                                                          \
+        auto kern = g256::gemm256_kernel<Tr, AK, BK_>;                                      \
+        IROCM_LDS_ATTR(kern, g256::LDS_BYTES, rt);                                                 \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), g256::LDS_BYTES, rt->stream, p);           \
     } while (0)
     if (akm && bkm) IROCM_G256(true, true);
@@ -550,10 +477,8 @@ template <typename Tr, int SCHED> static int launch256(infiniRocmRuntime_t rt, G
     return INFINI_ROCM_OK;
 }
 
-int launch_gemm256(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool akm, bool bkm, int sched) {
-    if (sched == 0)
-        return dtype == INFINI_DT_BF16 ? launch256<Bf16Traits, 0>(rt, p, akm, bkm) : launch256<F16Traits, 0>(rt, p, akm, bkm);
-    return dtype == INFINI_DT_BF16 ? launch256<Bf16Traits, 1>(rt, p, akm, bkm) : launch256<F16Traits, 1>(rt, p, akm, bkm);
+int launch_gemm256(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool akm, bool bkm) {
+    return dtype == INFINI_DT_BF16 ? launch256<Bf16Traits>(rt, p, akm, bkm) : launch256<F16Traits>(rt, p, akm, bkm);
 }
 
 } // namespace irocm

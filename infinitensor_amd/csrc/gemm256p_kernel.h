@@ -1,0 +1,442 @@
+// gemm256p: the PERSISTENT, multi-tile edition of the staggered 256-row GEMM of gemm256.hip (SCHED 0).
+//
+// Why: a 256 x 256 x 64 workgroup pays ~14.5 us of fixed cost per output tile (cold first K-tiles ~5 us, the C store
+// tail ~7 us, launch ~2 us: tools/gemm_fixed_cost.py) around a main loop of 1.44 us per K-tile. One tile per workgroup
+// leaves that uncovered whenever K is short (BERT: 12 K-tiles) or a problem has several tiles per CU. Here ONE
+// workgroup per CU walks its tiles (tile ids blockIdx.x, + gridDim.x, ...) through ONE flat K-tile pipeline:
+//   * the LDS-DMA cursors run across tile boundaries (A one K-tile ahead, B two), so the next tile's first two K-tiles
+//     are in LDS before the current tile's last MFMA: no cold prologue after the first tile;
+//   * the epilogue of tile T is plain code between C2 of T's last K-tile and L1 of the next tile's first one — no
+//     barrier in it. The two wave rows stay staggered by one barrier interval, so while one wave of a SIMD converts and
+//     stores its 128 accumulators its partner is still issuing the last 32 MFMAs of T (or already the first 32 of
+//     T + 1); C stores are asynchronous and drain under the next tile's main loop. Only the LAST tile's store tail is
+//     exposed;
+//   * `early_a`: at a tile boundary the A DMA of the K-tile after next is issued BEFORE the C stores, and the L2 wait
+//     of the following K-tile counts the stores (vmcnt is an in-order counter on gfx950: waiting for a load issued
+//     after the stores would wait for the stores too) — the stores get one more K-tile to reach L2.
+// Tile width is a template parameter: NT = 4 / 3 / 2 MFMA column tiles per wave = 256 / 192 / 128 columns (8 waves as
+// 2 (M) x 4 (N); wave tile 128 x 16 NT), so N = 768 (BERT) tiles as 4 x 192 without a ragged last tile and small
+// grids can trade tile size for CU coverage. Everything else — LDS images, XOR swizzles, transpose reads, the
+// LOAD | COMPUTE stagger, counted vmcnt, inline-asm ds_reads — is gemm256.hip's; see the comments there.
+// N-major B with NT < 4 keeps the 512-byte-row LDS image and fetches 256 columns (the unused ones clamp to valid
+// memory): B is the small, L2-resident operand.
+#pragma once
+#include "gemm256_common.h"
+
+namespace irocm {
+namespace g256p {
+using namespace g256;
+
+template <int N> __device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// K-major operand of ROWS = 8 * 8 * CNT rows: 8 * CNT pieces of 8 rows; wave w issues pieces w*CNT .. w*CNT+CNT-1.
+template <int CNT>
+__device__ __forceinline__ void offs_k_n(unsigned (&off)[4], long ld, int row0, int rows, int w, int lane) {
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+        const int piece = w * CNT + i;
+        const int r = piece * 8 + (lane >> 3);
+        const int c_log = (lane & 7) ^ ((r >> 1) & 7);
+        int gr = row0 + r;
+        gr = gr < rows ? gr : rows - 1;
+        off[i] = (unsigned)(((long)gr * ld + c_log * 8) * 2);
+    }
+}
+template <int CNT>
+__device__ __forceinline__ void stage_n(const char *ubase, const unsigned (&off)[4], char *lds_oper, int w) {
+#pragma unroll
+    for (int i = 0; i < CNT; ++i)
+        __builtin_amdgcn_global_load_lds(IROCM_GLB_PTR(ubase + (unsigned long)off[i]),
+                                         IROCM_LDS_PTR(lds_oper + (w * CNT + i) * 1024), 16, 0, 0);
+}
+
+struct PArgs {
+    GemmArgs g;
+    int total_tiles; // tiles_m * tiles_n * batch
+    int early_a;     // issue the next A DMA before a tile's C stores (see above)
+};
+
+template <typename Tr, bool A_KMAJOR, bool B_KMAJOR, int NT>
+__global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
+    const GemmArgs &p = pa.g;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BN_ = 64 * NT;          // tile width
+    constexpr int NB = B_KMAJOR ? NT : 4; // B DMA pieces per wave and K-tile
+    constexpr int NJ1 = NT - 2;           // column tiles of B sub-tile 1 (sub-tile 0 always has two)
+    constexpr int NSTORE = 8 * ((NT + 1) / 2); // C stores per lane in the 16-byte epilogue
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = w >> 2, wc = w & 3;
+    const int l15 = lane & 15, g4 = lane >> 4;
+
+    const int nk = p.k / BK;
+    const int my_tiles = (pa.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total_kt = my_tiles * nk; // this workgroup's flat K-tile sequence
+    const unsigned per_batch = (unsigned)p.tiles_m * p.tiles_n;
+
+    // step s of this workgroup -> (batch, m0, n0). Linear tile ids keep the XCD of the workgroup (gridDim.x % 8 == 0
+    // whenever a workgroup has more than one tile), then the grouped raster of gemm256.hip.
+    auto decode = [&](int s, int &ib, int &m0, int &n0) {
+        unsigned wg = xcd_remap((unsigned)s * gridDim.x + blockIdx.x, (unsigned)pa.total_tiles);
+        ib = wg / per_batch;
+        wg -= ib * per_batch;
+        constexpr int GROUP_M = 8;
+        const unsigned per_group = GROUP_M * p.tiles_n;
+        const unsigned group = wg / per_group;
+        const int first_m = group * GROUP_M;
+        const int gsz = min(p.tiles_m - first_m, GROUP_M);
+        m0 = (first_m + (wg % per_group) % gsz) * BM;
+        n0 = ((wg % per_group) / gsz) * BN_;
+    };
+
+    const long lda = A_KMAJOR ? p.a_rs : p.a_cs;
+    const long ldb = B_KMAJOR ? p.b_cs : p.b_rs;
+    const long a_step = A_KMAJOR ? (long)BK * 2 : (long)BK * lda * 2; // bytes per K-tile (wave-uniform)
+    const long b_step = B_KMAJOR ? (long)BK * 2 : (long)BK * ldb * 2;
+
+    // ---- staging cursors: the next K-tile each operand will fetch, in flat order ------------------
+    unsigned a_off[4], b_off[4];
+    const char *a_base, *b_base;
+    int a_s = 0, a_kt = 0, a_G = 0; // tile step, K-tile inside it, flat index
+    int b_s = 0, b_kt = 0, b_G = 0;
+    auto set_a_tile = [&](int s) {
+        int ib, m0, n0;
+        decode(s, ib, m0, n0);
+        a_base = (const char *)((const unsigned short *)p.a + (long)ib * p.a_bs);
+        if constexpr (A_KMAJOR) offs_k(a_off, lda, m0, p.m, w, lane);
+        else offs_mn(a_off, lda, m0, p.m, w, lane);
+    };
+    auto set_b_tile = [&](int s) {
+        int ib, m0, n0;
+        decode(s, ib, m0, n0);
+        b_base = (const char *)((const unsigned short *)p.b + (long)ib * p.b_bs);
+        if constexpr (B_KMAJOR) offs_k_n<NT>(b_off, ldb, n0, p.n, w, lane);
+        else offs_mn(b_off, ldb, n0, p.n, w, lane);
+    };
+    auto stage_a_next = [&](int buf) {
+        stage4(a_base + (long)a_kt * a_step, a_off, smem + buf * BUF_BYTES, w);
+        ++a_G;
+        if (++a_kt == nk) {
+            a_kt = 0;
+            if (++a_s < my_tiles)
+                set_a_tile(a_s);
+        }
+    };
+    auto stage_b_next = [&](int buf) {
+        stage_n<NB>(b_base + (long)b_kt * b_step, b_off, smem + buf * BUF_BYTES + OPER_BYTES, w);
+        ++b_G;
+        if (++b_kt == nk) {
+            b_kt = 0;
+            if (++b_s < my_tiles)
+                set_b_tile(b_s);
+        }
+    };
+
+    // ---- per-lane LDS read addresses (gemm256.hip) ------------------------------------------------
+    const unsigned lds0 = (unsigned)(unsigned long)IROCM_LDS_PTR(smem);
+    const unsigned kmaj_lane = (unsigned)(l15 * 128 + (((g4 ^ (l15 >> 1)) & 3) | (((l15 >> 1) >> 2) << 2)) * 16);
+    unsigned a_k[2], b_k[2];
+    unsigned a_mn[8], b_mn[NT];
+    const int mnf = ((l15 >> 2) & 3) | ((g4 & 1) << 2);
+    const unsigned mn_lane = (unsigned)((g4 * 8 + (l15 >> 2)) * 512 + (l15 & 1) * 8);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        a_k[ks] = lds0 + wr * (128 * 128) + (kmaj_lane ^ (ks * 64));
+        b_k[ks] = lds0 + OPER_BYTES + wc * (16 * NT * 128) + (kmaj_lane ^ (ks * 64));
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c16 = ((l15 >> 1) & 1) | ((((wr * 8 + i) ^ mnf)) << 1);
+        a_mn[i] = lds0 + mn_lane + c16 * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int c16 = ((l15 >> 1) & 1) | ((((wc * NT + j) ^ mnf)) << 1);
+        b_mn[j] = lds0 + OPER_BYTES + mn_lane + c16 * 16;
+    }
+    auto flip_buf = [&](int d) { // d = +-BUF_BYTES: move the read addresses to the other K-tile buffer
+        if constexpr (A_KMAJOR) { a_k[0] += d; a_k[1] += d; }
+        else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a_mn[i] += d;
+        }
+        if constexpr (B_KMAJOR) { b_k[0] += d; b_k[1] += d; }
+        else {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b_mn[j] += d;
+        }
+    };
+
+    f32x4 acc[8][NT];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
+
+    using FA = Frag<A_KMAJOR>;
+    using FB = Frag<B_KMAJOR>;
+    auto read_a = [&](auto qc, FA(&aq)[4][2]) {
+        constexpr int q = decltype(qc)::value;
+        sfor<4>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            sfor<2>([&](auto kc) {
+                constexpr int ks = decltype(kc)::value;
+                if constexpr (A_KMAJOR) {
+                    aq[i][ks].v = lds_read_b128<(q * 4 + i) * 2048>(a_k[ks]);
+                } else {
+                    aq[i][ks].lo = lds_read_tr_b64<ks * 16384>(a_mn[q * 4 + i]);
+                    aq[i][ks].hi = lds_read_tr_b64<ks * 16384 + 2048>(a_mn[q * 4 + i]);
+                }
+            });
+        });
+    };
+    // B sub-tile q: column tiles q*2 .. q*2 + CNT - 1
+    auto read_b = [&](auto qc, auto cntc, FB(&bq)[2][2]) {
+        constexpr int q = decltype(qc)::value, CNT = decltype(cntc)::value;
+        sfor<CNT>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            sfor<2>([&](auto kc) {
+                constexpr int ks = decltype(kc)::value;
+                if constexpr (B_KMAJOR) {
+                    bq[j][ks].v = lds_read_b128<(q * 2 + j) * 2048>(b_k[ks]);
+                } else {
+                    bq[j][ks].lo = lds_read_tr_b64<ks * 16384>(b_mn[q * 2 + j]);
+                    bq[j][ks].hi = lds_read_tr_b64<ks * 16384 + 2048>(b_mn[q * 2 + j]);
+                }
+            });
+        });
+    };
+    auto compute = [&](auto qac, auto qbc, auto cntc, FA(&aq)[4][2], FB(&bq)[2][2]) {
+        constexpr int qa = decltype(qac)::value, qb = decltype(qbc)::value, CNT = decltype(cntc)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < CNT; ++j)
+                    acc[qa * 4 + i][qb * 2 + j] =
+                        Tr::mfma(bq[j][ks].get(), aq[i][ks].get(), acc[qa * 4 + i][qb * 2 + j]);
+    };
+
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using IJ1 = std::integral_constant<int, NJ1>;
+
+    // ---- epilogue of one tile --------------------------------------------------------------------
+    // returns true when exactly NSTORE vector stores per lane were issued (the 16-byte path)
+    auto epilogue = [&](int ib, int m0, int n0) -> bool {
+        unsigned short *C = (unsigned short *)p.c + (long)ib * p.m * p.n;
+        const unsigned short *bias = (const unsigned short *)p.bias;
+        const bool interior = (m0 + BM <= p.m) && (n0 + BN_ <= p.n) && (p.n % 4 == 0);
+        auto pack2 = [&](int i, int j, int row, unsigned (&pk)[2]) { // bias + activation + rounding of one 4-wide piece
+            const int col = n0 + wc * (16 * NT) + j * 16 + g4 * 4;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                v[r] = acc[i][j][r];
+            if (bias) {
+                const unsigned short *bp = bias + (long)ib * p.bias_b + (long)row * p.bias_m + (long)col * p.bias_n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r] += Tr::to_f32(bp[(long)r * p.bias_n]);
+            }
+            if (p.act) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r] = apply_act(v[r], p.act);
+            }
+            pk[0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
+            pk[1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
+        };
+        if (interior && p.epi16 && (p.n % 8 == 0) && ((((uintptr_t)p.c) & 15) == 0)) {
+            // 16-byte stores: lane groups g4 / g4^1 swap halves of a PAIR of column tiles (gemm256.hip); an odd last
+            // column tile (NT = 3) goes out as 8-byte stores
+            const bool odd = g4 & 1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = m0 + wr * 128 + i * 16 + l15;
+#pragma unroll
+                for (int jp = 0; jp < NT / 2; ++jp) {
+                    unsigned pk[2][2];
+                    pack2(i, jp * 2, row, pk[0]);
+                    pack2(i, jp * 2 + 1, row, pk[1]);
+                    const unsigned s0 = odd ? pk[0][0] : pk[1][0], s1 = odd ? pk[0][1] : pk[1][1];
+                    const unsigned r0 = (unsigned)__shfl_xor((int)s0, 16), r1 = (unsigned)__shfl_xor((int)s1, 16);
+                    u32x4_t o;
+                    if (odd) { o[0] = r0; o[1] = r1; o[2] = pk[1][0]; o[3] = pk[1][1]; }
+                    else { o[0] = pk[0][0]; o[1] = pk[0][1]; o[2] = r0; o[3] = r1; }
+                    const int col = n0 + wc * (16 * NT) + (jp * 2 + (odd ? 1 : 0)) * 16 + (g4 & ~1) * 4;
+                    *(u32x4_t *)(C + c_off(p, row, col)) = o;
+                }
+                if constexpr (NT % 2 == 1) {
+                    unsigned pk[2];
+                    pack2(i, NT - 1, row, pk);
+                    const int col = n0 + wc * (16 * NT) + (NT - 1) * 16 + g4 * 4;
+                    u32x2_t o2;
+                    o2[0] = pk[0]; o2[1] = pk[1];
+                    *(u32x2_t *)(C + c_off(p, row, col)) = o2;
+                }
+            }
+            return true;
+        }
+        if (interior) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = m0 + wr * 128 + i * 16 + l15;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    unsigned pk[2];
+                    pack2(i, j, row, pk);
+                    const int col = n0 + wc * (16 * NT) + j * 16 + g4 * 4;
+                    u32x2_t o2;
+                    o2[0] = pk[0]; o2[1] = pk[1];
+                    *(u32x2_t *)(C + c_off(p, row, col)) = o2;
+                }
+            }
+            return false;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = m0 + wr * 128 + i * 16 + l15;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int col = n0 + wc * (16 * NT) + j * 16 + g4 * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (row < p.m && col + r < p.n) {
+                        float v = acc[i][j][r];
+                        if (bias)
+                            v += Tr::to_f32(bias[(long)ib * p.bias_b + (long)row * p.bias_m + (long)(col + r) * p.bias_n]);
+                        C[c_off(p, row, col + r)] = Tr::from_f32(apply_act(v, p.act));
+                    }
+                }
+            }
+        }
+        return false;
+    };
+
+    // ---- the flat K-tile pipeline ------------------------------------------------------------------
+    FA aq[4][2];
+    FB bq0[2][2], bq1[2][2];
+    bool a_pre = false;    // the A DMA L1 would issue was already issued before the previous tile's C stores
+    bool st_pend = false;  // NSTORE C stores sit in the VM queue behind that A DMA: count them in the next L2 wait
+    auto ktile = [&](int buf) {
+        // L1
+        read_b(I0{}, I2{}, bq0);
+        if constexpr (NJ1 > 0) read_b(I1{}, IJ1{}, bq1);
+        read_a(I0{}, aq);
+        if (a_G < total_kt && !a_pre)
+            stage_a_next(buf ^ 1);
+        a_pre = false;
+        wait_lgkm0();
+        barrier();
+        // C1
+        __builtin_amdgcn_s_setprio(1);
+        compute(I0{}, I0{}, I2{}, aq, bq0);
+        if constexpr (NJ1 > 0) compute(I0{}, I1{}, IJ1{}, aq, bq1);
+        __builtin_amdgcn_s_setprio(0);
+        barrier();
+        // L2
+        read_a(I1{}, aq);
+        flip_buf(buf ? -BUF_BYTES : BUF_BYTES); // every read of this K-tile is issued
+        if (b_G < total_kt) {
+            stage_b_next(buf);
+            if (st_pend) wait_vm<NB + NSTORE>();
+            else wait_vm<NB>();
+        } else {
+            wait_vm<0>();
+        }
+        st_pend = false;
+        wait_lgkm0();
+        barrier();
+        // C2
+        __builtin_amdgcn_s_setprio(1);
+        if constexpr (NJ1 > 0) compute(I1{}, I1{}, IJ1{}, aq, bq1);
+        compute(I1{}, I0{}, I2{}, aq, bq0);
+        __builtin_amdgcn_s_setprio(0);
+        barrier();
+    };
+
+    int c_ib, c_m0, c_n0; // the tile being accumulated
+    decode(0, c_ib, c_m0, c_n0);
+    set_a_tile(0);
+    set_b_tile(0);
+    stage_b_next(0);
+    stage_a_next(0);
+    if (total_kt > 1) {
+        stage_b_next(1);
+        wait_vm<NB>();
+    } else {
+        wait_vm<0>();
+    }
+    barrier();
+    if (wr == 1)
+        barrier(); // stagger: wave row 1 runs one barrier interval behind wave row 0
+    int c_s = 0, kt_in = 0;
+    for (int G = 0; G < total_kt; ++G) {
+        const int buf = G & 1;
+        ktile(buf);
+        if (++kt_in == nk) { // this wave's part of tile c_s is complete
+            kt_in = 0;
+            const bool early = pa.early_a && a_G < total_kt;
+            if (early) {
+                stage_a_next(buf); // = L1 of the next K-tile, whose buffer is (G + 1) & 1; it stages into the other one
+                a_pre = true;
+            }
+            const bool counted = epilogue(c_ib, c_m0, c_n0);
+            st_pend = early && counted;
+            if (early && !counted)
+                a_pre = true; // still issued; the next L2 wait is simply conservative (waits for the stores)
+            if (++c_s < my_tiles) {
+                decode(c_s, c_ib, c_m0, c_n0);
+                zero_acc();
+            }
+        }
+    }
+    if (wr == 0)
+        barrier(); // balance the stagger
+}
+
+int launch_gemm256p_nt4(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool akm, bool bkm, int early_a);
+int launch_gemm256p_nt3(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool akm, bool bkm, int early_a);
+int launch_gemm256p_nt2(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool akm, bool bkm, int early_a);
+
+template <typename Tr, int NT> static int launch_p(infiniRocmRuntime_t rt, GemmArgs g, bool akm, bool bkm, int early_a) {
+    PArgs pa;
+    g.tiles_m = (int)ceil_div(g.m, BM);
+    g.tiles_n = (int)ceil_div(g.n, 64 * NT);
+    const long total = (long)g.tiles_m * g.tiles_n * g.batch;
+    if (total >= (1l << 31))
+        IROCM_FAIL(INFINI_ROCM_INVALID_ARGUMENT, "matmul: too many tiles");
+    pa.g = g;
+    pa.total_tiles = (int)total;
+    pa.early_a = early_a;
+    // one workgroup per CU walking its tiles; gridDim.x % 8 == 0 keeps every workgroup's tiles on its XCD's id range
+    unsigned grid = (unsigned)total;
+    const unsigned cus = (unsigned)(rt->num_cu >= 8 ? (rt->num_cu / 8) * 8 : rt->num_cu);
+    if (grid > cus)
+        grid = cus;
+#define IROCM_G256P(AK, BK_)                                                                       \
+    do {                                                                                           \
+        auto kern = gemm256p_kernel<Tr, AK, BK_, NT>;                                              \
+        IROCM_LDS_ATTR(kern, LDS_BYTES, rt);                                                       \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, rt->stream, pa);                \
+    } while (0)
+    if (akm && bkm) IROCM_G256P(true, true);
+    else if (akm && !bkm) IROCM_G256P(true, false);
+    else if (!akm && bkm) IROCM_G256P(false, true);
+    else IROCM_G256P(false, false);
+#undef IROCM_G256P
+    IROCM_LAUNCH_CHECK("gemm256p");
+    return INFINI_ROCM_OK;
+}
+
+} // namespace g256p
+} // namespace irocm

@@ -180,11 +180,22 @@ struct WhereArgs {
     long total;
 };
 
-template <int BYTES>
+// CB = bytes per condition element; SIGNMASK clears the sign bit of a floating-point condition (-0.0 is false).
+// The reference reads one byte per element (where.cu:4-19) because its CUDA Less writes bool bytes into a buffer the
+// graph declares with the operands' dtype; here comparisons write full elements (like the native-CPU kernels), so the
+// condition is read in ITS tensor's dtype and a Less(f32) -> Where chain works on both conventions.
+template <int CB> struct CondRaw;
+template <> struct CondRaw<1> { using t = uint8_t; };
+template <> struct CondRaw<2> { using t = uint16_t; };
+template <> struct CondRaw<4> { using t = uint32_t; };
+template <> struct CondRaw<8> { using t = uint64_t; };
+
+template <int BYTES, int CB>
 __global__ __launch_bounds__(256) void where_kernel(const void *__restrict__ x, const void *__restrict__ y,
-                                                    const uint8_t *__restrict__ c, void *__restrict__ out,
-                                                    WhereArgs p) {
+                                                    const void *__restrict__ cv, void *__restrict__ out,
+                                                    WhereArgs p, unsigned long long keep) {
     using R = typename Raw<BYTES>::t;
+    const typename CondRaw<CB>::t *c = (const typename CondRaw<CB>::t *)cv;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long)gridDim.x * 256) {
         long rem = i, ox = 0, oy = 0, oc = 0;
         for (int d = p.ndim - 1; d >= 0; --d) {
@@ -195,7 +206,7 @@ __global__ __launch_bounds__(256) void where_kernel(const void *__restrict__ x, 
             oc += id * p.sc[d];
             rem = q;
         }
-        ((R *)out)[i] = c[oc] ? ((const R *)x)[ox] : ((const R *)y)[oy];
+        ((R *)out)[i] = ((unsigned long long)c[oc] & keep) ? ((const R *)x)[ox] : ((const R *)y)[oy];
     }
 }
 
@@ -444,10 +455,15 @@ int infini_rocm_gather(infiniRocmRuntime_t rt, int dtype, int index_dtype, const
     return INFINI_ROCM_OK;
 }
 
-int infini_rocm_where(infiniRocmRuntime_t rt, int dtype, const void *x, const void *y, const void *cond,
-                      void *out, int ndim, const int64_t *shape, const int64_t *stride_x,
-                      const int64_t *stride_y, const int64_t *stride_c) {
+int infini_rocm_where_ex(infiniRocmRuntime_t rt, int dtype, int cond_dtype, const void *x, const void *y,
+                         const void *cond, void *out, int ndim, const int64_t *shape, const int64_t *stride_x,
+                         const int64_t *stride_y, const int64_t *stride_c) {
     IROCM_CHECK_ARG(rt, "NULL runtime");
+    const int cb = (int)dtype_size(cond_dtype);
+    IROCM_CHECK_ARG(cb == 1 || cb == 2 || cb == 4 || cb == 8, "where: unsupported condition dtype %s", dtype_name(cond_dtype));
+    const bool cfloat = cond_dtype == INFINI_DT_F16 || cond_dtype == INFINI_DT_BF16 || cond_dtype == INFINI_DT_F32 ||
+                        cond_dtype == INFINI_DT_F64;
+    const unsigned long long keep = cfloat ? ((cb == 8 ? ~0ull : ((1ull << (cb * 8)) - 1)) >> 1) : ~0ull;
     IROCM_CHECK_ARG(ndim >= 0 && ndim <= MD, "where: rank %d out of range", ndim);
     const int elem = (int)dtype_size(dtype);
     IROCM_CHECK_ARG(elem_ok(elem), "where: unsupported dtype %s", dtype_name(dtype));
@@ -482,14 +498,31 @@ int infini_rocm_where(infiniRocmRuntime_t rt, int dtype, const void *x, const vo
     }
     p.total = total;
     const unsigned g = grid_for(total, rt->num_cu);
-    switch (elem) {
-    case 1: hipLaunchKernelGGL(where_kernel<1>, dim3(g), dim3(256), 0, rt->stream, x, y, (const uint8_t *)cond, out, p); break;
-    case 2: hipLaunchKernelGGL(where_kernel<2>, dim3(g), dim3(256), 0, rt->stream, x, y, (const uint8_t *)cond, out, p); break;
-    case 4: hipLaunchKernelGGL(where_kernel<4>, dim3(g), dim3(256), 0, rt->stream, x, y, (const uint8_t *)cond, out, p); break;
-    default: hipLaunchKernelGGL(where_kernel<8>, dim3(g), dim3(256), 0, rt->stream, x, y, (const uint8_t *)cond, out, p); break;
+#define IROCM_WHERE(EB, CB_)                                                                      \
+    hipLaunchKernelGGL((where_kernel<EB, CB_>), dim3(g), dim3(256), 0, rt->stream, x, y, cond, out, p, keep)
+#define IROCM_WHERE_C(EB)                                                                         \
+    switch (cb) {                                                                                 \
+    case 1: IROCM_WHERE(EB, 1); break;                                                            \
+    case 2: IROCM_WHERE(EB, 2); break;                                                            \
+    case 4: IROCM_WHERE(EB, 4); break;                                                            \
+    default: IROCM_WHERE(EB, 8); break;                                                           \
     }
+    switch (elem) {
+    case 1: IROCM_WHERE_C(1); break;
+    case 2: IROCM_WHERE_C(2); break;
+    case 4: IROCM_WHERE_C(4); break;
+    default: IROCM_WHERE_C(8); break;
+    }
+#undef IROCM_WHERE_C
+#undef IROCM_WHERE
     IROCM_LAUNCH_CHECK("where");
     return INFINI_ROCM_OK;
+}
+
+int infini_rocm_where(infiniRocmRuntime_t rt, int dtype, const void *x, const void *y, const void *cond,
+                      void *out, int ndim, const int64_t *shape, const int64_t *stride_x,
+                      const int64_t *stride_y, const int64_t *stride_c) {
+    return infini_rocm_where_ex(rt, dtype, INFINI_DT_BOOL, x, y, cond, out, ndim, shape, stride_x, stride_y, stride_c);
 }
 
 int infini_rocm_pad_slice(infiniRocmRuntime_t rt, int dtype, const void *x, void *y, int ndim,

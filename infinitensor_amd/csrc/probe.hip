@@ -1,0 +1,73 @@
+// Diagnostics: the MFMA-only ceiling of this chip under ITS power budget.
+//
+// MI355X clocks to its power limit (MI355X_MICROARCH.md, "DVFS give-back"): the nominal dense bf16 peak (256 CUs x
+// 4096 FLOP/clk x 2.4 GHz = 2.5 PFLOP/s) is not what a matrix-pipe-saturating kernel on random data can reach. This
+// kernel issues the SAME MFMA stream as the headline GEMM (8 waves per workgroup = 2 per SIMD, 8 x 4 accumulator tiles
+// of v_mfma_f32_16x16x32 per wave, 12 distinct operand fragments of the caller's data, one workgroup per CU) with NO
+// memory or LDS instruction in the loop. Its TFLOP/s is the measured denominator for "how far is the GEMM from what the
+// matrix pipes can do at the clock the chip sustains" (bench.py: roofline.attainable_peak).
+#include "gemm_common.h"
+
+namespace irocm {
+
+template <typename Tr>
+__global__ __launch_bounds__(512, 2) void mfma_ceiling_kernel(const unsigned short *__restrict__ data, float *__restrict__ sink,
+                                                              int iters) {
+    const int t = threadIdx.x;
+    // 12 operand fragments per lane (8 A, 4 B), 16 bytes each, distinct per lane and per workgroup slot
+    const s16x8_t *src = (const s16x8_t *)data + ((size_t)(blockIdx.x & 15) * 512 + t) * 12;
+    s16x8_t a[8], b[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = src[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = src[8 + j];
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = Tr::mfma(b[j], a[(i + ks) & 7], acc[i][j]);
+        // keep the loop a loop (no cross-iteration folding), no memory traffic
+        asm volatile("" : "+v"(a[0]), "+v"(b[0]));
+    }
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            s += acc[i][j];
+    if (s[0] + s[1] + s[2] + s[3] == 123.456f) // practically never: keeps the accumulators live
+        sink[blockIdx.x * 512 + t] = s[0];
+}
+
+} // namespace irocm
+
+using namespace irocm;
+
+// data: >= 16 * 512 * 12 * 16 bytes (1.5 MiB) of 16-bit operands in device memory (random data = the realistic power
+// draw; zeros clock higher); sink: >= num_cu * 512 floats. Launches ONE kernel of num_cu workgroups x 512 threads that
+// issues iters * 64 MFMAs per wave; *flop receives the FLOP count of the launch (time it with events).
+extern "C" int infini_rocm_probe_mfma_ceiling(infiniRocmRuntime_t rt, int dtype, const void *data, void *sink, int iters,
+                                              double *flop) {
+    IROCM_CHECK_ARG(rt && data && sink && iters > 0, "probe: bad argument");
+    IROCM_CHECK_ARG(dtype == INFINI_DT_BF16 || dtype == INFINI_DT_F16, "probe: bf16 / f16 only");
+    const unsigned grid = (unsigned)rt->num_cu;
+    if (dtype == INFINI_DT_BF16)
+        hipLaunchKernelGGL(mfma_ceiling_kernel<Bf16Traits>, dim3(grid), dim3(512), 0, rt->stream, (const unsigned short *)data,
+                           (float *)sink, iters);
+    else
+        hipLaunchKernelGGL(mfma_ceiling_kernel<F16Traits>, dim3(grid), dim3(512), 0, rt->stream, (const unsigned short *)data,
+                           (float *)sink, iters);
+    IROCM_LAUNCH_CHECK("mfma_ceiling");
+    if (flop)
+        *flop = (double)grid * 8.0 * (double)iters * 64.0 * (2.0 * 16 * 16 * 32);
+    return INFINI_ROCM_OK;
+}

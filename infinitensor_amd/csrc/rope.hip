@@ -6,7 +6,8 @@
 // Deliberate deviations from the reference: the launch covers every (batch, position)
 // (the reference grid covers one: rope.cu:85); dim_head and theta are arguments (reference hard-codes 128 /
 // 10000: rope.cc:25); the partner element is never read outside its head (the reference test relies on an
-// out-of-bounds read returning 0: test_cuda_rope.cc:17-31 uses dim_model 32 < dim_head 128).
+// out-of-bounds read returning 0: test_cuda_rope.cc:17-31 uses dim_model 32 < dim_head 128 — a trailing partial
+// head is accepted here and its missing partner columns count as 0, which reproduces that test without the read).
 // One thread per (token, head, pair): one angle, one sincos, two outputs. fp32 math. HBM-bound:
 // 2 * numel * sizeof(T) bytes.
 #include "common.h"
@@ -32,19 +33,25 @@ __global__ __launch_bounds__(256) void rope_kernel(const P *__restrict__ pos, co
                                                    T *__restrict__ y, long tokens, int dim_model, int dim_head,
                                                    float neg2_log2theta_over_dh) {
     const int half = dim_head / 2;
-    const long pairs_per_token = dim_model / 2;
+    const int heads = (dim_model + dim_head - 1) / dim_head; // a trailing partial head is allowed
+    const long pairs_per_token = (long)heads * half;
     const long total = tokens * pairs_per_token;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long tok = i / pairs_per_token;
         const int pr = (int)(i - tok * pairs_per_token);
         const int head = pr / half, c = pr - head * half;
+        const int j0 = head * dim_head + c, j1 = j0 + half;
+        if (j0 >= dim_model)
+            continue;
         const float ang = (float)pos[tok] * exp2f((float)c * neg2_log2theta_over_dh);
         float sn, cs;
         sincosf(ang, &sn, &cs);
-        const long j = tok * dim_model + (long)head * dim_head + c;
-        const float a = RLd<T>::ld(x + j), b = RLd<T>::ld(x + j + half);
+        const long j = tok * dim_model + j0;
+        const bool pair = j1 < dim_model; // partner column beyond the row: treated as 0, never read
+        const float a = RLd<T>::ld(x + j), b = pair ? RLd<T>::ld(x + j + half) : 0.f;
         RLd<T>::st(y + j, a * cs - b * sn);
-        RLd<T>::st(y + j + half, b * cs + a * sn);
+        if (pair)
+            RLd<T>::st(y + j + half, b * cs + a * sn);
     }
 }
 
@@ -56,15 +63,13 @@ extern "C" int infini_rocm_rope(infiniRocmRuntime_t rt, int dtype, int pos_dtype
                                 void *y, int64_t tokens, int64_t dim_model, int64_t dim_head, float theta) {
     IROCM_CHECK_ARG(rt, "NULL runtime");
     IROCM_CHECK_ARG(tokens >= 0 && dim_model > 0 && dim_head > 0, "rope: bad extent");
-    IROCM_CHECK_ARG(dim_head % 2 == 0 && dim_model % dim_head == 0,
-                    "rope: dim_model %lld must be a multiple of the (even) head dim %lld", (long long)dim_model,
-                    (long long)dim_head);
+    IROCM_CHECK_ARG(dim_head % 2 == 0, "rope: head dim %lld must be even", (long long)dim_head);
     IROCM_CHECK_ARG(theta > 1.0f, "rope: theta must be > 1");
     if (tokens == 0)
         return INFINI_ROCM_OK;
     IROCM_CHECK_ARG(pos && x && y, "rope: NULL tensor");
     const float k = -2.0f * log2f(theta) / (float)dim_head;
-    const long total = tokens * (dim_model / 2);
+    const long total = tokens * (ceil_div(dim_model, dim_head) * (dim_head / 2));
     long g = ceil_div(total, 256);
     if (g > (long)rt->num_cu * 16) g = (long)rt->num_cu * 16;
 #define GO(T, P)                                                                                   \

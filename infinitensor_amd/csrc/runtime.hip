@@ -71,6 +71,8 @@ int infini_rocm_runtime_destroy(infiniRocmRuntime_t rt) {
     (void)infini_rocm_comm_destroy(rt);
     if (rt->workspace)
         (void)hipFree(rt->workspace);
+    for (void *p : rt->retired)
+        (void)hipFree(p);
     if (rt->zeros)
         (void)hipFree(rt->zeros);
     if (rt->own_stream)
@@ -175,26 +177,62 @@ int infini_rocm_memset(infiniRocmRuntime_t rt, void *dst, int value, size_t byte
     return INFINI_ROCM_OK;
 }
 
+// The scratch block never moves under a captured graph: growing allocates a NEW block and RETIRES the old one
+// (kept allocated — hipGraph execs captured earlier have its address baked into their kernel nodes; the reference
+// avoids the problem with one fixed 7 GiB block, cuda_runtime.h:85-88). Growth is legal during stream capture:
+// hipMalloc is issued under a thread-local Relaxed capture mode (the same guard torch's caching allocator uses), and
+// the launches already recorded keep pointing at the retired block, which stays valid. Retired blocks are released by
+// infini_rocm_workspace_trim (the plugin calls it when its graph cache is empty) and at runtime destruction.
 int infini_rocm_workspace(infiniRocmRuntime_t rt, size_t bytes, void **ptr) {
     IROCM_CHECK_ARG(rt && ptr, "NULL argument");
     if (bytes > rt->workspace_bytes) {
-        // Growing frees the old buffer: illegal while a capture is recording launches that use it.
-        if (rt->capturing)
-            IROCM_FAIL(INFINI_ROCM_CAPTURE_ERROR,
-                       "workspace must be pre-sized before graph capture (need %zu, have %zu)",
-                       bytes, rt->workspace_bytes);
         IROCM_HIP(hipSetDevice(rt->device));
-        if (rt->workspace) {
-            IROCM_HIP(hipStreamSynchronize(rt->stream));
-            IROCM_HIP(hipFree(rt->workspace));
-            rt->workspace = nullptr;
-            rt->workspace_bytes = 0;
+        // geometric growth bounds the retired total by the final size
+        size_t want = bytes > 2 * rt->workspace_bytes ? bytes : 2 * rt->workspace_bytes;
+        want = (want + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+        void *fresh = nullptr;
+        hipError_t e;
+        if (rt->capturing) {
+            hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+            IROCM_HIP(hipThreadExchangeStreamCaptureMode(&mode));
+            e = hipMalloc(&fresh, want);
+            (void)hipThreadExchangeStreamCaptureMode(&mode);
+        } else {
+            e = hipMalloc(&fresh, want);
         }
-        size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
-        IROCM_HIP(hipMalloc(&rt->workspace, want));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            IROCM_FAIL(e == hipErrorOutOfMemory ? INFINI_ROCM_OUT_OF_MEMORY : INFINI_ROCM_HIP_ERROR,
+                       "workspace: hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        }
+        if (rt->workspace)
+            rt->retired.push_back(rt->workspace);
+        rt->workspace = fresh;
         rt->workspace_bytes = want;
+        ++rt->workspace_epoch;
     }
     *ptr = rt->workspace;
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_workspace_trim(infiniRocmRuntime_t rt) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(!rt->capturing, "cannot trim the workspace while capturing");
+    if (rt->retired.empty())
+        return INFINI_ROCM_OK;
+    IROCM_HIP(hipSetDevice(rt->device));
+    IROCM_HIP(hipStreamSynchronize(rt->stream));
+    for (void *p : rt->retired)
+        (void)hipFree(p);
+    rt->retired.clear();
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_workspace_info(infiniRocmRuntime_t rt, size_t *bytes, size_t *retired_blocks, uint64_t *epoch) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    if (bytes) *bytes = rt->workspace_bytes;
+    if (retired_blocks) *retired_blocks = rt->retired.size();
+    if (epoch) *epoch = rt->workspace_epoch;
     return INFINI_ROCM_OK;
 }
 

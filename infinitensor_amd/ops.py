@@ -573,15 +573,13 @@ def resize(rt: RocmRuntime, x: torch.Tensor, out_shape: Sequence[int], scales: S
 def where(rt: RocmRuntime, x: torch.Tensor, y: torch.Tensor, cond: torch.Tensor,
           out: torch.Tensor | None = None) -> torch.Tensor:
     """cond ? x : y; operator input order x, y, cond (include/operators/where.h:9-34)."""
-    if cond.element_size() != 1:
-        raise TypeError("where condition must be a 1-byte type (bool / uint8)")
     oshape = infer_broadcast(infer_broadcast(list(x.shape), list(y.shape)), list(cond.shape))
     if out is None:
         out = torch.empty(oshape, dtype=x.dtype, device=x.device)
-    check(lib().infini_rocm_where(rt.handle, dtype_of(x), _ptr(x), _ptr(y), _ptr(cond), _ptr(out), len(oshape),
-                                  _i64arr(oshape), _i64arr(broadcast_strides(list(x.shape), oshape)),
-                                  _i64arr(broadcast_strides(list(y.shape), oshape)),
-                                  _i64arr(broadcast_strides(list(cond.shape), oshape))))
+    check(lib().infini_rocm_where_ex(rt.handle, dtype_of(x), dtype_of(cond), _ptr(x), _ptr(y), _ptr(cond), _ptr(out),
+                                     len(oshape), _i64arr(oshape), _i64arr(broadcast_strides(list(x.shape), oshape)),
+                                     _i64arr(broadcast_strides(list(y.shape), oshape)),
+                                     _i64arr(broadcast_strides(list(cond.shape), oshape))))
     return out
 
 

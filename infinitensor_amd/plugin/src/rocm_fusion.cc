@@ -115,6 +115,10 @@ size_t RocmRuntimeObj::tryLaunchFusedAttention(const OpVec &ops, size_t i) const
         (dt != INFINI_DT_F16 && dt != INFINI_DT_BF16) || !(k->getDType() == q->getDType()))
         return 0;
     const int b = qd[0], h = qd[1], sq = qd[2], sk = kd[2], d = qd[3];
+    // limits of infini_rocm_attention_ex (attention.hip): outside them the chain simply runs unfused
+    if ((int64_t)b * h >= 65536 || h >= 65536 || sk <= 0 || sq <= 0 ||
+        ((((uintptr_t)q->getRawDataPtr<void *>()) | ((uintptr_t)k->getRawDataPtr<void *>())) & 15) != 0)
+        return 0;
     Tensor cur = mm1->getOutput(), scale = nullptr, mask = nullptr;
     bool mask2d = false;
     size_t j = i + 1;
@@ -152,7 +156,8 @@ size_t RocmRuntimeObj::tryLaunchFusedAttention(const OpVec &ops, size_t i) const
     auto mm2 = as<MatmulObj>(ops[j]);
     const Tensor v = mm2->getInputs(1), out = mm2->getOutput();
     if (mm2->getInputs(0) != cur || mm2->getTransA() || mm2->getTransB() || mm2->getBias() || mm2->getAct() != ActType::None ||
-        v->getDims() != kd || !(v->getDType() == q->getDType()))
+        v->getDims() != kd || !(v->getDType() == q->getDType()) || (((uintptr_t)v->getRawDataPtr<void *>()) & 15) != 0 ||
+        (((uintptr_t)out->getRawDataPtr<void *>()) & 7) != 0)
         return 0;
     // Head merge: ctx [b, h, Sq, D] -> Transpose(0, 2, 1, 3) -> Reshape [b, Sq, h * D] (what every exported transformer
     // does before the output projection) is folded into the kernel's store (infini_rocm_attention_ex).

@@ -152,8 +152,8 @@ class RocmTunableKernel : public Kernel {
 // ---- MatMul (reference: matmulCublas, src/kernels/cuda/matmul.cc:66-209) --------------------------
 class MatmulRocm : public RocmTunableKernel {
     int setVariant(infiniRocmRuntime_t rt, int v) const override { return infini_rocm_matmul_set_variant(rt, v); }
-    // generic64, fast128 (LDS-DMA 128^2), tile256 split-K, tile256 staggered (gemm.hip kVariantNames)
-    std::vector<int> candidates() const override { return {0, 1, 6, 7}; }
+    // fast128 (LDS-DMA 128^2), tile256 one-shot, tile256 split-K, persistent 256 / 192 / 128 (gemm.hip kVariantNames)
+    std::vector<int> candidates() const override { return {1, 2, 3, 4, 5, 6}; }
     int recordType() const override { return kRocmMatmulRecord; }
     void launch(const Operator &_op, const RuntimeObj *ctx) const override {
         auto op = as<MatmulObj>(_op);
@@ -282,7 +282,8 @@ class RoPERocm : public RocmKernelWithoutConfig {
         const auto pos = op->getInputs(0), x = op->getInputs(1);
         const auto &d = x->getDims();
         IT_ASSERT(d.size() == 3 && pos->getDims().size() == 2 && d[1] == pos->getDims()[1]); // rope.cc:21-22
-        // head dim 128 and theta 1e4 are hard-coded by the reference (rope.cc:25, rope.cu:18)
+        // head dim 128 and theta 1e4 are hard-coded by the reference (rope.cc:25, rope.cu:18); a row narrower than one
+        // head (test_cuda_rope.cc: dim_model 32) is a partial head whose partner columns count as 0
         ROCM_CALL(infini_rocm_rope(H(ctx), DTI(x), DTI(pos), P(pos), P(x), P(op->getOutput()), (int64_t)d[0] * d[1],
                                    d[2], 128, 10000.0f));
     }
@@ -545,8 +546,9 @@ class WhereRocm : public RocmKernelWithoutConfig {
         auto shape = dims64(out->getDims());
         auto sx = bcastStrides(x->getDims(), out->getDims()), sy = bcastStrides(y->getDims(), out->getDims()),
              sc = bcastStrides(c->getDims(), out->getDims());
-        ROCM_CALL(infini_rocm_where(H(ctx), DTI(x), P(x), P(y), P(c), P(out), (int)shape.size(), shape.data(),
-                                    sx.data(), sy.data(), sc.data()));
+        // the condition is read in its own dtype: a 1-byte bool input, or the full-element 1/0 a comparison wrote
+        ROCM_CALL(infini_rocm_where_ex(H(ctx), DTI(x), DTI(c), P(x), P(y), P(c), P(out), (int)shape.size(),
+                                       shape.data(), sx.data(), sy.data(), sc.data()));
     }
 };
 REGISTER_KERNEL(Device::ROCM, OpType::Where, WhereRocm, "Where_ROCM");

@@ -18,6 +18,7 @@ void rocmCheck(int status, const char *what) {
 
 RocmRuntimeObj::RocmRuntimeObj(int deviceId, size_t hipGraphCacheCapacity)
     : RuntimeObj(Device::ROCM, deviceId), cacheCapacity(hipGraphCacheCapacity) {
+    IT_ASSERT(hipGraphCacheCapacity > 0, "hipGraph cache capacity must be greater than zero"); // cuda_runtime.cc:78
     ROCM_CALL(infini_rocm_runtime_create(deviceId, &rt));
     if (const char *e = std::getenv("INFINI_ROCM_FUSION"))
         fusion = std::string(e) != "0";
@@ -244,9 +245,16 @@ void RocmRuntimeObj::runWithHipGraph(const Graph &graph) {
     entry->owner = WRef<GraphObj>(graph);
     entry->state = std::move(state);
     entry->generation = generation;
-    // Kernels take scratch from the runtime workspace, which cannot grow while the stream records: if the first
-    // attempt fails, run the graph once eagerly (that sizes the workspace; results are the same) and capture again.
+    // Kernels take scratch from the runtime workspace. It may grow while the stream records (the C ABI retires the
+    // outgrown block instead of freeing it, so launches already recorded — and every graph exec captured earlier —
+    // keep valid addresses). The graph is never executed eagerly on behalf of a capture: a graph with collectives
+    // must issue the same RCCL calls on every rank whatever the state of each rank's workspace. Only if a capture
+    // fails AND the workspace block changed during it (a HIP build that refuses allocation under capture) is the
+    // capture repeated once, now with a workspace that is large enough; launches recorded into an aborted capture
+    // never execute.
     for (int attempt = 0;; ++attempt) {
+        uint64_t epochBefore = 0, epochAfter = 0;
+        ROCM_CALL(infini_rocm_workspace_info(rt, nullptr, nullptr, &epochBefore));
         ROCM_CALL(infini_rocm_graph_begin_capture(rt));
         try {
             launchAll(graph, false);
@@ -254,11 +262,10 @@ void RocmRuntimeObj::runWithHipGraph(const Graph &graph) {
             break;
         } catch (...) {
             infini_rocm_graph_abort_capture(rt);
-            if (attempt > 0)
+            infini_rocm_workspace_info(rt, nullptr, nullptr, &epochAfter);
+            if (attempt > 0 || epochAfter == epochBefore)
                 throw;
         }
-        launchAll(graph, false); // a genuine kernel error throws again here, outside any capture
-        sync();
     }
     IT_ASSERT(generation == graph->getCaptureGeneration(), "Graph changed while hipGraph capture was in progress");
     ROCM_CALL(infini_rocm_graph_launch(rt, entry->graph));
@@ -279,6 +286,8 @@ void RocmRuntimeObj::clearHipGraphCache() {
     std::lock_guard<std::recursive_mutex> executionLock(executionMutex);
     std::lock_guard<std::recursive_mutex> cacheLock(cacheMutex);
     cache.clear();
+    // no graph exec of this runtime is alive any more: scratch blocks retired by workspace growth can go
+    ROCM_CALL(infini_rocm_workspace_trim(rt));
 }
 size_t RocmRuntimeObj::getHipGraphCacheSize() const {
     std::lock_guard<std::recursive_mutex> lock(cacheMutex);

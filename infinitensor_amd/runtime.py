@@ -151,6 +151,16 @@ class RocmRuntime:
         check(lib().infini_rocm_workspace(self._h, nbytes, C.byref(p)))
         return p.value or 0
 
+    def workspace_info(self) -> dict:
+        """Current scratch size, number of retired (outgrown, still allocated) blocks and the block epoch."""
+        b, r, e = C.c_size_t(), C.c_size_t(), C.c_uint64()
+        check(lib().infini_rocm_workspace_info(self._h, C.byref(b), C.byref(r), C.byref(e)))
+        return {"bytes": b.value, "retired_blocks": r.value, "epoch": e.value}
+
+    def workspace_trim(self) -> None:
+        """Free retired scratch blocks (only when no captured graph of this runtime is alive)."""
+        check(lib().infini_rocm_workspace_trim(self._h))
+
     # -- timing -----------------------------------------------------------------------------
     def record(self, ev: Event) -> None:
         check(lib().infini_rocm_event_record(self._h, ev._h))

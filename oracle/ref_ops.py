@@ -380,8 +380,12 @@ def rope(pos: np.ndarray, x: np.ndarray, dim_head: int, theta: float = 10000.0) 
     jh = j % dim_head
     freq = theta ** (-(2.0 * (jh % half)) / dim_head)
     ang = P * freq
-    Xh = X.reshape(X.shape[:-1] + (dm // dim_head, dim_head))
-    rot = np.concatenate([-Xh[..., half:], Xh[..., :half]], axis=-1).reshape(X.shape)
+    # a trailing partial head (dm % dim_head != 0): its missing partner columns count as 0 — what the reference's own
+    # test relies on (test_cuda_rope.cc:17-31: dim_model 32, head dim 128, expected values are pure cosines)
+    pad = (-dm) % dim_head
+    Xp = np.concatenate([X, np.zeros(X.shape[:-1] + (pad,))], axis=-1) if pad else X
+    Xh = Xp.reshape(X.shape[:-1] + ((dm + pad) // dim_head, dim_head))
+    rot = np.concatenate([-Xh[..., half:], Xh[..., :half]], axis=-1).reshape(Xp.shape)[..., :dm]
     return X * np.cos(ang) + rot * np.sin(ang)
 
 

@@ -69,7 +69,7 @@ SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("shape", SHAPES)
@@ -92,6 +92,41 @@ def test_matmul_16bit_variants(rt, shape, ta, tb, dtype, variant):
     err = np.abs(got - want)
     bound = tol * np.abs(want) + tol * np.sqrt(k)
     assert (err <= bound).all(), f"max err {err.max()} at {np.unravel_index(err.argmax(), err.shape)}"
+
+
+@pytest.mark.parametrize("variant", [4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False)])
+@pytest.mark.parametrize("shape", [(1, 16384, 1536, 192), (1, 8192, 4096, 64), (1, 4104, 3080, 128), (3, 2048, 2560, 256),
+                                   (1, 16384, 768, 768)])
+def test_persistent_gemm_walks_several_tiles(rt, shape, ta, tb, variant):
+    """The persistent kernels with MORE tiles than CUs (a workgroup walks 2-4 tiles through one flat K-tile pipeline:
+    odd K-tile counts flip the LDS buffer parity between tiles, K = 64 lets the B cursor run two tiles ahead), ragged
+    edge tiles, a batch, a bias: sampled rows vs the fp64 oracle, the whole tensor vs the generic kernel (an independent
+    code path), and bit-identical repeats."""
+    b, m, n, k = shape
+    rng = np.random.default_rng(hash((shape, ta, tb)) % 2 ** 32)
+    a = rng.standard_normal((b, k, m) if ta else (b, m, k)).astype(np.float32)
+    bm = rng.standard_normal((n, k) if tb else (k, n)).astype(np.float32)
+    bias = rng.standard_normal((n,)).astype(np.float32)
+    ad, bd, biasd = dev(a, torch.bfloat16), dev(bm, torch.bfloat16), dev(bias, torch.bfloat16)
+    ops.set_matmul_variant(rt, variant)
+    try:
+        c1 = ops.matmul(rt, ad, bd, biasd, ta, tb)
+        c2 = ops.matmul(rt, ad, bd, biasd, ta, tb)
+        ops.set_matmul_variant(rt, 0)
+        c0 = ops.matmul(rt, ad, bd, biasd, ta, tb)
+    finally:
+        ops.set_matmul_variant(rt, -1)
+    assert torch.equal(c1, c2)
+    tol = 2 ** -7
+    d = (c1.float() - c0.float()).abs()
+    assert bool((d <= 2 * tol * c0.float().abs() + 2 * tol * np.sqrt(k)).all()), float(d.max())
+    rows = np.unique(np.concatenate([rng.choice(m, 24, replace=False), [0, 255, 256, m - 1]]))
+    ar = a[:, :, rows] if ta else a[:, rows, :]
+    want = R.matmul(R.round_to(ar, "bf16"), R.round_to(bm, "bf16"), R.round_to(bias, "bf16"), ta, tb)
+    got = host(c1)[:, rows, :]
+    err = np.abs(got - want)
+    assert (err <= tol * np.abs(want) + tol * np.sqrt(k)).all(), float(err.max())
 
 
 def test_matmul_splitk_heuristic_shapes(rt):
@@ -176,7 +211,7 @@ def test_matmul_rejects_bad_arguments(rt):
         check(lib().infini_rocm_matmul(rt.handle, 7, None, None, None, None, 1, 4, 4, 4, 0, 0, 16, 16, 0, 0, 0, 0))
 
 
-@pytest.mark.parametrize("variant", [-1, 0, 1, 6, 7])
+@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("shape", [(1, 512, 768, 256, 128, 64), (2, 256, 512, 320, 128, 64), (1, 384, 200, 136, 96, 40),
                                    (1, 1024, 1024, 1024, 256, 128)])
@@ -215,7 +250,7 @@ def test_matmul_head_split_rejects_bad_tilings(rt):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
-@pytest.mark.parametrize("variant", [-1, 0, 1, 6, 7])
+@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3, 4, 5, 6])
 def test_matmul_fast_gelu_epilogue(rt, dtype, tol, variant):
     """act = 5: Gelu (erf form) in the GEMM epilogue with erf by Abramowitz-Stegun 7.1.26 (abs error 1.5e-7) vs the oracle's
     exact Gelu of the fp64 product, over the whole input range incl. the negative tail (no cancellation in 1 + erf), and

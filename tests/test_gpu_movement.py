@@ -84,6 +84,24 @@ def test_where_mask_bit_exact(rt, dtype):
     assert np.array_equal(host(ops.where(rt, dev(x), dev(y), dev(c))), R.where(x, y, c))
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float16, np.float64, np.int32, np.int64])
+def test_less_feeds_where(rt, dtype):
+    """Less -> Where: the reference's CUDA Less writes bool BYTES into a buffer the graph declares with the operand
+    dtype and WhereCuda reads bytes (element_wise.cu:101-131, where.cu:4-19); this backend's comparisons write whole
+    elements (as the native-CPU kernels do), so Where reads the condition in ITS dtype (infini_rocm_where_ex, what
+    WhereRocm passes) and the chain gives the same answer; -0.0 counts as false."""
+    a, b = rnd((4, 1, 6), dtype, 1), rnd((1, 5, 6), dtype, 2)
+    x, y = rnd((4, 5, 6), dtype, 3), rnd((6,), dtype, 4)
+    c = ops.binary(rt, "less", dev(a), dev(b))
+    assert c.dtype == dev(a).dtype
+    got = host(ops.where(rt, dev(x), dev(y), c))
+    assert np.array_equal(got, np.where(a < b, x, np.broadcast_to(y, (4, 5, 6))))
+    if np.issubdtype(dtype, np.floating):
+        cz = np.array([0.0, -0.0, 1.0, -1.0, np.nan, 1e-30], dtype)
+        got = host(ops.where(rt, dev(np.ones(6, dtype)), dev(np.zeros(6, dtype)), dev(cz)))
+        assert np.array_equal(got, np.array([0, 0, 1, 1, 1, 1 if dtype != np.float16 else 0], dtype))
+
+
 def test_concat_split_slice_pad_expand_reference_kats(rt):
     t1 = R.incremental((2, 2, 3, 1))
     y = ops.concat(rt, [dev(t1), dev(R.ones((2, 2, 1, 1))), dev(R.ones((2, 2, 2, 1)))], 2)

@@ -1,0 +1,82 @@
+"""N > 1 on hardware: the RCCL path of SURVEY 8a row a11 / 8f-2 with one process per GPU.
+
+Collected everywhere, skipped on boxes with fewer GPUs than the case needs (the builder's `gpurun` boxes have one;
+the world-1 case runs there and keeps the worker script itself honest).
+Each case starts `world` workers (tests/_rccl_worker.py; RANK / WORLD_SIZE in the environment, file rendezvous in a
+temporary cwd like the reference's NcclCommunicatorObj) which run the reference's collective tests on Device::ROCM
+through both the C ABI and the reference executor + plugin:
+test/kernels/cuda/test_cuda_all_reduce.cc:38-106, test_cuda_all_gather.cc:38-50, test_cuda_broadcast.cc:41-55,
+test_cuda_sendrecv.cc:50-87 (worlds 3 and 4 there), test/cuda/test_nccl_comm.cc:37-52.
+Plus the 2-rank launcher check of examples/distributed/cuda/cuda_launch.py:70-76 (max-abs-diff of the tensor-parallel
+Llama block against the single-GPU result) and `bench.py --gpus 2` spawning its own ranks."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPO = Path(__file__).resolve().parent.parent
+NGPU = torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+def need(n):
+    return pytest.mark.skipif(NGPU < n, reason=f"needs {n} GPUs on one node (have {NGPU})")
+
+
+def launch(world: int, script: Path, cwd: Path, extra_args=(), timeout=600):
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script), *extra_args], env=env, cwd=cwd, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=timeout))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed (rc {p.returncode}):\n{se[-3000:]}"
+    return [so for so, _ in outs]
+
+
+@pytest.mark.parametrize("world", [1, pytest.param(2, marks=need(2)), pytest.param(3, marks=need(3)), pytest.param(4, marks=need(4)),
+                                   pytest.param(8, marks=need(8))])
+def test_rccl_collectives_match_the_reference_tests(world, tmp_path):
+    outs = launch(world, REPO / "tests" / "_rccl_worker.py", tmp_path)
+    for r, so in enumerate(outs):
+        res = json.loads([ln for ln in so.splitlines() if ln.startswith("RESULT ")][-1][7:])
+        assert res["rank"] == r and res["world"] == world
+        assert set(res["done"]) >= {"abi_all_reduce", "abi_all_gather", "abi_broadcast", "abi_send_recv",
+                                    "abi_all_reduce_hipgraph", "plugin_collectives", "plugin_all_reduce_hipgraph"}
+
+
+@need(2)
+def test_rocm_launch_two_ranks_match_single_gpu(tmp_path):
+    """cuda_launch.py:70-76: the sharded graph's output vs the single-GPU standard; fp16 tolerance."""
+    r = subprocess.run([sys.executable, str(REPO / "tools" / "rocm_launch.py"), "--nproc_per_node", "2", "--iters", "5"], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "TP=2" in line["workload"] and line["max_abs_diff_vs_single_gpu"] < 5e-2 and line["finite"]
+
+
+@need(2)
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` (no launcher): n_gpus 2, a real all-reduce bus bandwidth, TP parity."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--no-graph"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    tp = line["tp_block"]
+    assert tp["allreduce_busbw_GBs"] and tp["allreduce_busbw_GBs"] > 1.0
+    assert tp["max_abs_diff_vs_unsharded"] < 5e-2 and tp["finite"]

@@ -140,11 +140,24 @@ def test_rope_vs_oracle(rt, dt):
 
 
 def test_rope_reference_kat(rt):
-    """test_cuda_rope.cc:17-31 with the row zero-padded to one 128-wide head (see tests/test_oracle_nn.py)."""
+    """test_cuda_rope.cc:17-31: once with the row zero-padded to one 128-wide head, once at the reference's exact
+    shape {1, 1, 32} (head dim 128 > dim_model: a partial head whose partner columns count as 0)."""
     x = np.zeros((1, 1, 128), np.float32)
     x[..., :32] = 1
     y = ops.rope(rt, dev(np.array([[1]], np.int32)), dev(x), 128)
     assert R.equal_data(host(y)[0, 0, :32], kat("test/kernels/cuda/test_cuda_rope.cc", 29, "float"), 2e-6)
+    y = ops.rope(rt, dev(np.array([[1]], np.int32)), dev(np.ones((1, 1, 32), np.float32)), 128)
+    assert R.equal_data(host(y)[0, 0], kat("test/kernels/cuda/test_cuda_rope.cc", 29, "float"), 2e-6)
+
+
+def test_rope_partial_trailing_head(rt):
+    """dim_model = 2 full heads + 40 columns: full heads rotate normally, the partial head's columns whose partner
+    lies beyond the row keep x * cos."""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((1, 9, 2 * 64 + 40)).astype(np.float32)
+    pos = np.arange(9, dtype=np.int32)[None]
+    y = ops.rope(rt, dev(pos), dev(x), 64)
+    assert np.allclose(host(y), R.rope(pos, x, 64), rtol=1e-4, atol=1e-5)
 
 
 @pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])

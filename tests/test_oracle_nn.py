@@ -150,6 +150,9 @@ def test_rope_kat():
     x[..., :32] = 1.0
     y = R.rope(np.array([[1]]), x, 128)
     assert eq(y[0, 0, :32], kat(CU + "test_cuda_rope.cc", 29, "float"), 2e-6)
+    # the reference's exact shape {1, 1, 32}: a partial head whose partner columns count as 0
+    y = R.rope(np.array([[1]]), np.ones((1, 1, 32)), 128)
+    assert eq(y[0, 0], kat(CU + "test_cuda_rope.cc", 29, "float"), 2e-6)
 
 
 def test_attention_kvcache_kat():

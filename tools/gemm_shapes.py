@@ -1,5 +1,5 @@
 """GEMM time per kernel variant over the shapes of BASELINE configs 4 and 5 (BERT-base bs32 seq512 projections / FFN,
-Llama-7B block at 2048 tokens) and the headline 4096^3.  python tools/gemm_shapes.py [--dtype f16] [--variants -1,1,7,6]"""
+Llama-7B block at 2048 tokens) and the headline 4096^3.  python tools/gemm_shapes.py [--dtype f16] [--variants -1,1,2,3,4,5,6]"""
 import argparse
 import sys
 from pathlib import Path
@@ -18,7 +18,7 @@ SHAPES = [  # (name, m, n, k, bias)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--dtype", default="f16")
-ap.add_argument("--variants", default="-1,1,7,6")
+ap.add_argument("--variants", default="-1,1,2,3,4,5,6")
 ap.add_argument("--iters", type=int, default=50)
 args = ap.parse_args()
 dt = {"f16": torch.float16, "bf16": torch.bfloat16}[args.dtype]

@@ -1,0 +1,53 @@
+"""MFMA-only ceiling of this MI355X under its power budget (csrc/probe.hip): the headline GEMM's MFMA stream with no
+memory or LDS instruction in the loop, on N(0,1) operands (the realistic power draw) and on zeros (the chip clocks
+higher). Prints one JSON line.  python tools/mfma_ceiling.py [--dtype bf16] [--iters 4000] [--reps 20]"""
+import argparse
+import ctypes as C
+import json
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+
+from infinitensor_amd import RocmRuntime, lib
+from infinitensor_amd._lib import check
+from infinitensor_amd.runtime import Event
+
+
+def mfma_ceiling(rt, dtype=torch.bfloat16, iters=4000, reps=20, fill="normal") -> float:
+    """TFLOP/s of the MFMA-only kernel; average over `reps` back-to-back launches (HIP events on the runtime stream)."""
+    n = 16 * 512 * 12 * 8
+    data = (torch.randn(n, device="cuda") if fill == "normal" else torch.zeros(n, device="cuda")).to(dtype)
+    sink = torch.empty(rt.device_info()["compute_units"] * 512, device="cuda", dtype=torch.float32)
+    torch.cuda.synchronize()
+    code = 16 if dtype == torch.bfloat16 else 10
+    flop = C.c_double()
+
+    def launch():
+        check(lib().infini_rocm_probe_mfma_ceiling(rt.handle, code, C.c_void_p(data.data_ptr()), C.c_void_p(sink.data_ptr()),
+                                                   iters, C.byref(flop)))
+
+    for _ in range(3):
+        launch()
+    e0, e1 = Event(), Event()
+    rt.record(e0)
+    for _ in range(reps):
+        launch()
+    rt.record(e1)
+    s = rt.elapsed_ms(e0, e1) * 1e-3 / reps
+    return flop.value / s / 1e12
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--iters", type=int, default=4000)
+    ap.add_argument("--reps", type=int, default=20)
+    a = ap.parse_args()
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16}[a.dtype]
+    rt = RocmRuntime(0)
+    out = {"dtype": a.dtype, "iters": a.iters, "mfma_per_wave": a.iters * 64,
+           "random_TFLOPs": round(mfma_ceiling(rt, dt, a.iters, a.reps, "normal"), 1),
+           "zeros_TFLOPs": round(mfma_ceiling(rt, dt, a.iters, a.reps, "zeros"), 1), "nominal_peak_TFLOPs": 2500.0}
+    print(json.dumps(out))
