@@ -128,6 +128,12 @@ int infini_rocm_workspace_info(infiniRocmRuntime_t rt, size_t *bytes, size_t *re
  * its power budget — the attainable denominator next to the nominal 2.5 PFLOP/s (bench.py roofline.attainable_peak). */
 int infini_rocm_probe_mfma_ceiling(infiniRocmRuntime_t rt, int dtype, const void *data, void *sink, int iters,
                                    double *flop);
+/* Diagnostics: one launch of the persistent GEMM (bf16, row-major A [m,k] and B [k,n], no bias; tile_cols 256 or 192)
+ * built with s_memtime stamps at every wave's phase boundaries. trace: [min(tiles, compute_units)][8][128] uint64
+ * (0 = unused): slot 0 kernel entry, then per K-tile {L1 start, L2 start}, per tile {epilogue start, end}, last = after
+ * the final store drain. tools/gemm_timeline.py turns it into a per-phase table. */
+int infini_rocm_probe_gemm_timeline(infiniRocmRuntime_t rt, const void *a, const void *b, void *c, int64_t m, int64_t n,
+                                    int64_t k, int tile_cols, void *trace);
 
 /* Events on the runtime stream, for timing (reference: timeit, src/core/common.cc:7-22). */
 int infini_rocm_event_create(infiniRocmEvent_t *ev);

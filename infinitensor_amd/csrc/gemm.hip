@@ -386,9 +386,10 @@ __global__ __launch_bounds__(256) void gemm_fast128(GemmArgs p) {
 int launch_gemm256(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool a_kmajor, bool b_kmajor);
 bool gemm256_supported(const GemmArgs &p, bool a_kmajor, bool b_kmajor);
 namespace g256p { // persistent multi-tile kernels, tile 256 x 64 NT (gemm256p_kernel.h)
-int launch_gemm256p_nt4(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool akm, bool bkm, int early_a);
-int launch_gemm256p_nt3(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool akm, bool bkm, int early_a);
-int launch_gemm256p_nt2(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool akm, bool bkm, int early_a);
+int launch_gemm256p_nt4(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool akm, bool bkm);
+int launch_gemm256p_nt3(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool akm, bool bkm);
+int launch_gemm256p_nt2(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool akm, bool bkm);
+int launch_gemm256p_trace(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, int nt, unsigned long long *trace);
 } // namespace g256p
 int launch_gemm256_splitk(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool a_kmajor, bool b_kmajor, int splits);
 
@@ -429,17 +430,25 @@ static bool fast128_supported(const GemmArgs &p, bool akm, bool bkm) {
 }
 
 static const char *kVariantNames[] = {"generic64", "fast128_glds", "tile256", "tile256_splitk", "persist256", "persist192",
-                                      "persist128", "persist256_late_a", "persist192_late_a", "persist128_late_a"};
-constexpr int kNumVariants = 10;
+                                      "persist128"};
+constexpr int kNumVariants = 7;
 
-// Cost model of the persistent kernels (microseconds; calibrated on MI355X with tools/gemm_shapes.py): a workgroup
-// walks ceil(tiles / CUs) tiles of nk K-tiles each; a K-tile of a 256 x 64 NT tile costs kKt[NT]; the first tile's cold
-// prologue, the last tile's store tail and the launch are paid once.
+// Cost model behind the heuristic (microseconds; fitted to tools/gemm_shapes.py on MI355X, bf16 / f16, N(0,1) data).
+// A workgroup of the persistent kernel walks its tiles: a K-tile of a 256 x 64 NT tile costs kKt[NT]; every tile pays its
+// C store tail (a CU retires ~7 bytes / clk of stores: 128 KiB -> 9 us; gemm256p_kernel.h); launch + first prologue
+// ~3 us once. A last, partial wave of tiles is cheaper than a full one (fewer workgroups share L2 / HBM / power).
+static const double kKt[5] = {0, 0, 0.93, 1.13, 1.36};
+static const double kStoreTail[5] = {0, 0, 4.5, 6.7, 9.0};
 static double persist_cost(long m, long n, long k, long batch, int nt, int cus) {
-    static const double kKt[5] = {0, 0, 0.82, 1.12, 1.44};
     const long tiles = ceil_div(m, 256) * ceil_div(n, 64 * nt) * batch;
-    const long waves = ceil_div(tiles, cus);
-    return (double)waves * ((double)(k / 64) * kKt[nt] + 0.5) + 11.0 + 0.9 * nt;
+    const long full = tiles / cus;
+    const double frac = (double)(tiles - full * cus) / cus;
+    const double waves = (double)full + (frac > 0 ? (1.5 * frac < 1.0 ? 1.5 * frac : 1.0) : 0.0);
+    return waves * ((double)(k / 64) * kKt[nt] + kStoreTail[nt]) + 3.0;
+}
+// split-K: `splits` workgroups per 256^2 tile write fp32 partial planes, one reduce pass adds them
+static double splitk_cost(long m, long n, long k, long batch, int splits) {
+    return 3.0 + (double)(k / 64) / splits * kKt[4] + 12.0 + (double)batch * m * n * (4.0 * splits + 2.0) / 5.0e6;
 }
 
 } // namespace irocm
@@ -523,12 +532,11 @@ int infini_rocm_matmul_headsplit(infiniRocmRuntime_t rt, int dtype, const void *
         if (splits > 16) splits = 16;
     }
     if (variant < 0) {
-        // heuristic: split-K when the 256^2 tiles cannot fill the CUs and K is long; otherwise the persistent kernel
-        // with the tile width the cost model likes best (it needs at least ~half a tile per CU); otherwise 128^2.
+        // heuristic: the cheapest of {persistent 256 / 192 / 128-wide tiles, split-K} by the cost model when the 256-row
+        // kernels can serve the problem and it has at least ~half a tile per CU; otherwise 128^2 tiles; otherwise generic
         const bool ok256 = gemm256_supported(p, akm, bkm);
-        int best_nt = 0;
-        if (ok256 && splits < 2) {
-            double best = 1e30;
+        double best = 1e30;
+        if (ok256) {
             for (int nt = 4; nt >= 2; --nt) {
                 const long tiles = ceil_div(m, 256) * ceil_div(n, 64 * nt) * batch;
                 if (tiles * 2 < rt->num_cu)
@@ -536,32 +544,26 @@ int infini_rocm_matmul_headsplit(infiniRocmRuntime_t rt, int dtype, const void *
                 const double c = persist_cost(m, n, k, batch, nt, rt->num_cu);
                 if (c < best * 0.97) { // prefer the wider tile unless a narrower one is clearly cheaper
                     best = c;
-                    best_nt = nt;
+                    variant = 4 + (4 - nt);
                 }
             }
+            if (splits >= 2 && splitk_cost(m, n, k, batch, splits) < best * 0.97)
+                variant = 3;
         }
-        if (best_nt)
-            variant = 4 + (4 - best_nt);
-        else if (splits >= 2)
-            variant = 3;
-        else if (fast128_supported(p, akm, bkm))
-            variant = 1;
-        else
-            variant = 0;
+        if (variant < 0)
+            variant = fast128_supported(p, akm, bkm) ? 1 : 0;
     } else if (variant >= 2 && !gemm256_supported(p, akm, bkm)) {
         variant = fast128_supported(p, akm, bkm) ? 1 : 0;
     } else if (variant == 1 && !fast128_supported(p, akm, bkm)) {
         variant = 0;
     }
 
-    if (variant >= 4) {
-        const int early_a = variant < 7;
-        switch ((variant - 4) % 3) {
-        case 0: return g256p::launch_gemm256p_nt4(rt, dtype, p, akm, bkm, early_a);
-        case 1: return g256p::launch_gemm256p_nt3(rt, dtype, p, akm, bkm, early_a);
-        default: return g256p::launch_gemm256p_nt2(rt, dtype, p, akm, bkm, early_a);
-        }
-    }
+    if (variant == 4)
+        return g256p::launch_gemm256p_nt4(rt, dtype, p, akm, bkm);
+    if (variant == 5)
+        return g256p::launch_gemm256p_nt3(rt, dtype, p, akm, bkm);
+    if (variant == 6)
+        return g256p::launch_gemm256p_nt2(rt, dtype, p, akm, bkm);
     if (variant == 3)
         return launch_gemm256_splitk(rt, dtype, p, akm, bkm, splits < 2 ? 2 : splits);
     if (variant == 2)
@@ -581,6 +583,23 @@ int infini_rocm_matmul_headsplit(infiniRocmRuntime_t rt, int dtype, const void *
         hipLaunchKernelGGL(gemm_generic16<F16Traits>, grid, dim3(256), 0, rt->stream, p);
     IROCM_LAUNCH_CHECK("gemm_generic");
     return INFINI_ROCM_OK;
+}
+
+// Diagnostics: one launch of the persistent GEMM (bf16, NN, no bias) with every wave stamping s_memtime at its phase
+// boundaries; trace receives [min(tiles, CUs)][8][128] stamps (0 = unused slot): slot 0 kernel entry, then per K-tile
+// {L1 start, L2 start}, per tile {epilogue start, epilogue end}, last = after the final store drain.
+int infini_rocm_probe_gemm_timeline(infiniRocmRuntime_t rt, const void *a, const void *b, void *c, int64_t m, int64_t n,
+                                    int64_t k, int tile_cols, void *trace) {
+    IROCM_CHECK_ARG(rt && a && b && c && trace, "probe: NULL argument");
+    IROCM_CHECK_ARG(tile_cols == 256 || tile_cols == 192, "probe: tile_cols must be 256 or 192");
+    GemmArgs p;
+    memset(&p, 0, sizeof(p));
+    p.a = a; p.b = b; p.c = c;
+    p.m = (int)m; p.n = (int)n; p.k = (int)k; p.batch = 1;
+    p.a_rs = k; p.a_cs = 1; p.b_rs = n; p.b_cs = 1;
+    p.splitk = 1; p.epi16 = 1; p.zeros = rt->zeros;
+    IROCM_CHECK_ARG(gemm256_supported(p, true, false), "probe: shape not served by the 256-row kernels");
+    return g256p::launch_gemm256p_trace(rt, INFINI_DT_BF16, p, tile_cols / 64, (unsigned long long *)trace);
 }
 
 } // extern "C"

@@ -11,9 +11,18 @@
 //     stores its 128 accumulators its partner is still issuing the last 32 MFMAs of T (or already the first 32 of
 //     T + 1); C stores are asynchronous and drain under the next tile's main loop. Only the LAST tile's store tail is
 //     exposed;
-//   * `early_a`: at a tile boundary the A DMA of the K-tile after next is issued BEFORE the C stores, and the L2 wait
-//     of the following K-tile counts the stores (vmcnt is an in-order counter on gfx950: waiting for a load issued
-//     after the stores would wait for the stores too) — the stores get one more K-tile to reach L2.
+//     (A variant that issued the next A DMA before the C stores and counted the stores in the following vmcnt wait was
+//     built and removed: loads and stores retire through one counter but not in one order, so a counted wait behind
+//     stores proves nothing about older loads; every wait here is a plain vmcnt(N <= loads issued after the one needed),
+//     which is safe because loads retire in order among themselves.)
+// What the TRACE build measured (tools/gemm_timeline.py, 16384 x 3072 x 768, 3 tiles per workgroup): steady K-tile
+// ~3000 cycles; a tile's epilogue ~9400 cycles PER WAVE ROW = 18.7 k per tile: a CU retires C stores at ~7 bytes/clk
+// however they are shaped or timed (measured the same with 16 rows x 64 B and with 8 rows x 128 B per instruction, with
+// non-temporal stores, and with the workgroups started in 4 / 8 phases so that only a fraction of the CUs stores at a
+// time — all removed again), the storing waves sit in store issue meanwhile, and through the barriers so does the
+// workgroup. So what persistence buys per tile boundary is the prologue (~3 us) and the launch, not the store tail;
+// hiding that needs the packed tile parked in 64 more VGPRs (or in LDS) and trickled out under the next tile's main
+// loop — neither exists at 2 waves per SIMD with a 128 KiB K-tile ring.
 // Tile width is a template parameter: NT = 4 / 3 / 2 MFMA column tiles per wave = 256 / 192 / 128 columns (8 waves as
 // 2 (M) x 4 (N); wave tile 128 x 16 NT), so N = 768 (BERT) tiles as 4 x 192 without a ragged last tile and small
 // grids can trade tile size for CU coverage. Everything else — LDS images, XOR swizzles, transpose reads, the
@@ -55,17 +64,29 @@ __device__ __forceinline__ void stage_n(const char *ubase, const unsigned (&off)
 struct PArgs {
     GemmArgs g;
     int total_tiles; // tiles_m * tiles_n * batch
-    int early_a;     // issue the next A DMA before a tile's C stores (see above)
+    unsigned long long *trace; // TRACE instantiation only: [gridDim.x][8 waves][kTraceSlots] s_memtime stamps
 };
 
-template <typename Tr, bool A_KMAJOR, bool B_KMAJOR, int NT>
+constexpr int kTraceSlots = 128;
+
+// TRACE: every wave stamps s_memtime at phase boundaries into a private LDS strip behind the K-tile buffers (no VMEM
+// traffic, so the vmcnt bookkeeping is untouched) and dumps the strip at the end — tools/gemm_timeline.py.
+template <typename Tr, bool A_KMAJOR, bool B_KMAJOR, int NT, bool TRACE = false>
 __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     const GemmArgs &p = pa.g;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    int tslot = 0;
+    auto stamp = [&]() {
+        if constexpr (TRACE) {
+            const unsigned long long tm = __builtin_amdgcn_s_memtime();
+            if (tslot < kTraceSlots && (threadIdx.x & 63) == 0)
+                *(unsigned long long *)(smem + LDS_BYTES + (threadIdx.x >> 6) * (kTraceSlots * 8) + tslot * 8) = tm;
+            ++tslot;
+        }
+    };
     constexpr int BN_ = 64 * NT;          // tile width
     constexpr int NB = B_KMAJOR ? NT : 4; // B DMA pieces per wave and K-tile
     constexpr int NJ1 = NT - 2;           // column tiles of B sub-tile 1 (sub-tile 0 always has two)
-    constexpr int NSTORE = 8 * ((NT + 1) / 2); // C stores per lane in the 16-byte epilogue
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = w >> 2, wc = w & 3;
@@ -230,18 +251,46 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     using IJ1 = std::integral_constant<int, NJ1>;
 
     // ---- epilogue of one tile --------------------------------------------------------------------
-    // returns true when exactly NSTORE vector stores per lane were issued (the 16-byte path)
-    auto epilogue = [&](int ib, int m0, int n0) -> bool {
+    auto epilogue = [&](int ib, int m0, int n0) {
         unsigned short *C = (unsigned short *)p.c + (long)ib * p.m * p.n;
         const unsigned short *bias = (const unsigned short *)p.bias;
         const bool interior = (m0 + BM <= p.m) && (n0 + BN_ <= p.n) && (p.n % 4 == 0);
-        auto pack2 = [&](int i, int j, int row, unsigned (&pk)[2]) { // bias + activation + rounding of one 4-wide piece
+        // The usual bias is one row vector [n] (bias_m == 0, bias_n == 1): a lane's 4 NT bias values are fetched ONCE per
+        // tile (one 8-byte load per column tile) instead of once per accumulator element (128 scalar loads per lane,
+        // each followed by the compiler's vmcnt(0) — that also drained the DMA pipeline of the next tile).
+        const bool rowbias = bias && p.bias_m == 0 && p.bias_n == 1;
+        float bv[NT][4];
+        if (rowbias) {
+            const unsigned short *bb = bias + (long)ib * p.bias_b;
+            const bool al8 = ((((uintptr_t)bb) & 7) == 0);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int col = n0 + wc * (16 * NT) + j * 16 + g4 * 4;
+                if (al8 && col + 3 < p.n) {
+                    const u32x2_t q = *(const u32x2_t *)(bb + col);
+                    bv[j][0] = Tr::to_f32((unsigned short)(q[0] & 0xffff));
+                    bv[j][1] = Tr::to_f32((unsigned short)(q[0] >> 16));
+                    bv[j][2] = Tr::to_f32((unsigned short)(q[1] & 0xffff));
+                    bv[j][3] = Tr::to_f32((unsigned short)(q[1] >> 16));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        bv[j][r] = col + r < p.n ? Tr::to_f32(bb[col + r]) : 0.f;
+                }
+            }
+        }
+        auto pack2 = [&](int i, auto jc, int row, unsigned (&pk)[2]) { // bias + activation + rounding of one 4-wide piece
+            constexpr int j = decltype(jc)::value;
             const int col = n0 + wc * (16 * NT) + j * 16 + g4 * 4;
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 v[r] = acc[i][j][r];
-            if (bias) {
+            if (rowbias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r] += bv[j][r];
+            } else if (bias) {
                 const unsigned short *bp = bias + (long)ib * p.bias_b + (long)row * p.bias_m + (long)col * p.bias_n;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -262,45 +311,47 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int row = m0 + wr * 128 + i * 16 + l15;
-#pragma unroll
-                for (int jp = 0; jp < NT / 2; ++jp) {
+                sfor<NT / 2>([&](auto jpc) {
+                    constexpr int jp = decltype(jpc)::value;
                     unsigned pk[2][2];
-                    pack2(i, jp * 2, row, pk[0]);
-                    pack2(i, jp * 2 + 1, row, pk[1]);
-                    const unsigned s0 = odd ? pk[0][0] : pk[1][0], s1 = odd ? pk[0][1] : pk[1][1];
-                    const unsigned r0 = (unsigned)__shfl_xor((int)s0, 16), r1 = (unsigned)__shfl_xor((int)s1, 16);
+                    pack2(i, std::integral_constant<int, jp * 2>{}, row, pk[0]);
+                    pack2(i, std::integral_constant<int, jp * 2 + 1>{}, row, pk[1]);
+                    // v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of the second: even lanes end
+                    // with {own, right neighbour's} 4 + 4 columns of tile 2jp, odd lanes with {left neighbour's, own} of
+                    // tile 2jp + 1 — one VALU op per dword, no LDS round trip, no selects
+                    const u32x2_t t0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                    const u32x2_t t1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
                     u32x4_t o;
-                    if (odd) { o[0] = r0; o[1] = r1; o[2] = pk[1][0]; o[3] = pk[1][1]; }
-                    else { o[0] = pk[0][0]; o[1] = pk[0][1]; o[2] = r0; o[3] = r1; }
+                    o[0] = t0[0]; o[1] = t1[0]; o[2] = t0[1]; o[3] = t1[1];
                     const int col = n0 + wc * (16 * NT) + (jp * 2 + (odd ? 1 : 0)) * 16 + (g4 & ~1) * 4;
                     *(u32x4_t *)(C + c_off(p, row, col)) = o;
-                }
+                });
                 if constexpr (NT % 2 == 1) {
                     unsigned pk[2];
-                    pack2(i, NT - 1, row, pk);
+                    pack2(i, std::integral_constant<int, NT - 1>{}, row, pk);
                     const int col = n0 + wc * (16 * NT) + (NT - 1) * 16 + g4 * 4;
                     u32x2_t o2;
                     o2[0] = pk[0]; o2[1] = pk[1];
                     *(u32x2_t *)(C + c_off(p, row, col)) = o2;
                 }
             }
-            return true;
+            return;
         }
         if (interior) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int row = m0 + wr * 128 + i * 16 + l15;
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
+                sfor<NT>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
                     unsigned pk[2];
-                    pack2(i, j, row, pk);
+                    pack2(i, jc, row, pk);
                     const int col = n0 + wc * (16 * NT) + j * 16 + g4 * 4;
                     u32x2_t o2;
                     o2[0] = pk[0]; o2[1] = pk[1];
                     *(u32x2_t *)(C + c_off(p, row, col)) = o2;
-                }
+                });
             }
-            return false;
+            return;
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -319,22 +370,19 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
                 }
             }
         }
-        return false;
     };
 
     // ---- the flat K-tile pipeline ------------------------------------------------------------------
     FA aq[4][2];
     FB bq0[2][2], bq1[2][2];
-    bool a_pre = false;    // the A DMA L1 would issue was already issued before the previous tile's C stores
-    bool st_pend = false;  // NSTORE C stores sit in the VM queue behind that A DMA: count them in the next L2 wait
     auto ktile = [&](int buf) {
         // L1
+        stamp();
         read_b(I0{}, I2{}, bq0);
         if constexpr (NJ1 > 0) read_b(I1{}, IJ1{}, bq1);
         read_a(I0{}, aq);
-        if (a_G < total_kt && !a_pre)
+        if (a_G < total_kt)
             stage_a_next(buf ^ 1);
-        a_pre = false;
         wait_lgkm0();
         barrier();
         // C1
@@ -344,16 +392,15 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         __builtin_amdgcn_s_setprio(0);
         barrier();
         // L2
+        stamp();
         read_a(I1{}, aq);
         flip_buf(buf ? -BUF_BYTES : BUF_BYTES); // every read of this K-tile is issued
         if (b_G < total_kt) {
             stage_b_next(buf);
-            if (st_pend) wait_vm<NB + NSTORE>();
-            else wait_vm<NB>();
+            wait_vm<NB>(); // everything older than these NB loads has landed (C stores of a previous tile included)
         } else {
             wait_vm<0>();
         }
-        st_pend = false;
         wait_lgkm0();
         barrier();
         // C2
@@ -364,8 +411,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         barrier();
     };
 
-    int c_ib, c_m0, c_n0; // the tile being accumulated
-    decode(0, c_ib, c_m0, c_n0);
+    stamp();
     set_a_tile(0);
     set_b_tile(0);
     stage_b_next(0);
@@ -379,37 +425,43 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     barrier();
     if (wr == 1)
         barrier(); // stagger: wave row 1 runs one barrier interval behind wave row 0
-    int c_s = 0, kt_in = 0;
-    for (int G = 0; G < total_kt; ++G) {
-        const int buf = G & 1;
-        ktile(buf);
-        if (++kt_in == nk) { // this wave's part of tile c_s is complete
-            kt_in = 0;
-            const bool early = pa.early_a && a_G < total_kt;
-            if (early) {
-                stage_a_next(buf); // = L1 of the next K-tile, whose buffer is (G + 1) & 1; it stages into the other one
-                a_pre = true;
-            }
-            const bool counted = epilogue(c_ib, c_m0, c_n0);
-            st_pend = early && counted;
-            if (early && !counted)
-                a_pre = true; // still issued; the next L2 wait is simply conservative (waits for the stores)
-            if (++c_s < my_tiles) {
-                decode(c_s, c_ib, c_m0, c_n0);
-                zero_acc();
-            }
-        }
+    // Two nested loops over the SAME flat pipeline: the inner K loop stays a compact body with a short back edge (an
+    // epilogue inlined into one flat loop pushes the back edge beyond the +-128 KB reach of s_cbranch: every K-tile then
+    // pays s_getpc / s_setpc trampolines through cold code — measured 3-4 % slower than the one-shot kernel).
+    int G = 0;
+    for (int c_s = 0; c_s < my_tiles; ++c_s) {
+        int c_ib, c_m0, c_n0; // the tile being accumulated
+        decode(c_s, c_ib, c_m0, c_n0);
+        for (int kt = 0; kt < nk; ++kt, ++G)
+            ktile(G & 1);
+        stamp();
+        epilogue(c_ib, c_m0, c_n0); // this wave's part of tile c_s is complete; G = first K-tile of the next tile
+        if (c_s + 1 < my_tiles)
+            zero_acc();
+        stamp();
     }
     if (wr == 0)
         barrier(); // balance the stagger
+    if constexpr (TRACE) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        stamp();
+        __syncthreads();
+        for (int i = lane; i < kTraceSlots; i += 64)
+            pa.trace[((size_t)blockIdx.x * 8 + w) * kTraceSlots + i] =
+                i < tslot ? *(unsigned long long *)(smem + LDS_BYTES + w * (kTraceSlots * 8) + i * 8) : 0ull;
+    }
 }
 
-int launch_gemm256p_nt4(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool akm, bool bkm, int early_a);
-int launch_gemm256p_nt3(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool akm, bool bkm, int early_a);
-int launch_gemm256p_nt2(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool akm, bool bkm, int early_a);
+int launch_gemm256p_nt4(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool akm, bool bkm);
+int launch_gemm256p_trace(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, int nt, unsigned long long *trace);
+int launch_gemm256p_nt3(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool akm, bool bkm);
+int launch_gemm256p_nt2(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool akm, bool bkm);
 
-template <typename Tr, int NT> static int launch_p(infiniRocmRuntime_t rt, GemmArgs g, bool akm, bool bkm, int early_a) {
+template <typename Tr, int NT, bool TRACE = false>
+static int launch_p(infiniRocmRuntime_t rt, GemmArgs g, bool akm, bool bkm, unsigned long long *trace = nullptr) {
     PArgs pa;
+    pa.trace = trace;
+    constexpr int kLds = LDS_BYTES + (TRACE ? 8 * kTraceSlots * 8 : 0);
     g.tiles_m = (int)ceil_div(g.m, BM);
     g.tiles_n = (int)ceil_div(g.n, 64 * NT);
     const long total = (long)g.tiles_m * g.tiles_n * g.batch;
@@ -417,7 +469,6 @@ template <typename Tr, int NT> static int launch_p(infiniRocmRuntime_t rt, GemmA
         IROCM_FAIL(INFINI_ROCM_INVALID_ARGUMENT, "matmul: too many tiles");
     pa.g = g;
     pa.total_tiles = (int)total;
-    pa.early_a = early_a;
     // one workgroup per CU walking its tiles; gridDim.x % 8 == 0 keeps every workgroup's tiles on its XCD's id range
     unsigned grid = (unsigned)total;
     const unsigned cus = (unsigned)(rt->num_cu >= 8 ? (rt->num_cu / 8) * 8 : rt->num_cu);
@@ -425,14 +476,20 @@ template <typename Tr, int NT> static int launch_p(infiniRocmRuntime_t rt, GemmA
         grid = cus;
 #define IROCM_G256P(AK, BK_)                                                                       \
     do {                                                                                           \
-        auto kern = gemm256p_kernel<Tr, AK, BK_, NT>;                                              \
-        IROCM_LDS_ATTR(kern, LDS_BYTES, rt);                                                       \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, rt->stream, pa);                \
+        auto kern = gemm256p_kernel<Tr, AK, BK_, NT, TRACE>;                                       \
+        IROCM_LDS_ATTR(kern, kLds, rt);                                                            \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), kLds, rt->stream, pa);                     \
     } while (0)
-    if (akm && bkm) IROCM_G256P(true, true);
-    else if (akm && !bkm) IROCM_G256P(true, false);
-    else if (!akm && bkm) IROCM_G256P(false, true);
-    else IROCM_G256P(false, false);
+    if constexpr (TRACE) { // the timeline build exists for the ONNX "NN" layout only
+        if (!(akm && !bkm))
+            IROCM_FAIL(INFINI_ROCM_UNSUPPORTED, "gemm timeline: NN layout only");
+        IROCM_G256P(true, false);
+    } else {
+        if (akm && bkm) IROCM_G256P(true, true);
+        else if (akm && !bkm) IROCM_G256P(true, false);
+        else if (!akm && bkm) IROCM_G256P(false, true);
+        else IROCM_G256P(false, false);
+    }
 #undef IROCM_G256P
     IROCM_LAUNCH_CHECK("gemm256p");
     return INFINI_ROCM_OK;

@@ -5,9 +5,9 @@
 namespace irocm {
 namespace g256p {
 
-int launch_gemm256p_nt3(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool akm, bool bkm, int early_a) {
-    return dtype == INFINI_DT_BF16 ? launch_p<Bf16Traits, 3>(rt, p, akm, bkm, early_a)
-                                   : launch_p<F16Traits, 3>(rt, p, akm, bkm, early_a);
+int launch_gemm256p_nt3(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool akm, bool bkm) {
+    return dtype == INFINI_DT_BF16 ? launch_p<Bf16Traits, 3>(rt, p, akm, bkm)
+                                   : launch_p<F16Traits, 3>(rt, p, akm, bkm);
 }
 
 } // namespace g256p

@@ -94,7 +94,7 @@ def test_matmul_16bit_variants(rt, shape, ta, tb, dtype, variant):
     assert (err <= bound).all(), f"max err {err.max()} at {np.unravel_index(err.argmax(), err.shape)}"
 
 
-@pytest.mark.parametrize("variant", [4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", [4, 5, 6])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False)])
 @pytest.mark.parametrize("shape", [(1, 16384, 1536, 192), (1, 8192, 4096, 64), (1, 4104, 3080, 128), (3, 2048, 2560, 256),
                                    (1, 16384, 768, 768)])

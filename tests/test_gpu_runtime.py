@@ -99,14 +99,42 @@ def test_capture_errors_are_reported():
     r.begin_capture()
     with pytest.raises(InfiniRocmError):
         r.begin_capture()
-    with pytest.raises(InfiniRocmError):
-        r.workspace(1 << 30)  # growing the workspace inside a capture is refused
     r.abort_capture()
     x = torch.ones(16, device="cuda")
     torch.cuda.synchronize()
     y = ops.unary(r, "neg", x)  # the runtime is usable again after an aborted capture
     r.sync()
     assert float(y.sum()) == -16
+
+
+def test_workspace_grows_inside_a_capture_and_retires_old_blocks():
+    """Growing the scratch block is legal while the stream records (hipMalloc under a thread-local Relaxed capture
+    mode) and never frees the outgrown block: launches recorded earlier in the same capture, and graph execs captured
+    before, keep addressing live memory (csrc/runtime.hip; the reference's fixed 7 GiB block never moves either)."""
+    r = RocmRuntime(0)
+    p0 = r.workspace(1 << 20)
+    info0 = r.workspace_info()
+    assert info0["bytes"] >= 1 << 20 and info0["retired_blocks"] == 0
+    x = torch.arange(1024, device="cuda", dtype=torch.float32)
+    y = torch.zeros_like(x)
+    torch.cuda.synchronize()
+    r.begin_capture()
+    r.copy_inside(p0, x.data_ptr(), 4096)            # recorded against the first block
+    p1 = r.workspace(64 << 20)                        # grows inside the capture
+    r.copy_inside(y.data_ptr(), p0, 4096)            # still reads the (now retired) first block
+    g = r.end_capture()
+    info1 = r.workspace_info()
+    assert p1 != p0 and info1["retired_blocks"] == 1 and info1["epoch"] == info0["epoch"] + 1 and info1["bytes"] >= 64 << 20
+    for _ in range(3):
+        y.zero_()
+        torch.cuda.synchronize()
+        r.launch_graph(g)
+        r.sync()
+        assert torch.equal(y, x)
+    assert r.workspace(1 << 20) == p1  # no shrink
+    del g
+    r.workspace_trim()
+    assert r.workspace_info()["retired_blocks"] == 0
 
 
 def test_single_rank_communicator(tmp_path, monkeypatch):

@@ -9,5 +9,5 @@ tail -30 gpurun_out/r2a/pytest_main.log
 timeout 600 python -m pytest tests/test_gpu_matmul.py -m gpu -q --maxfail=10 -p no:cacheprovider -k "test_matmul_16bit_variants" > gpurun_out/r2a/pytest_variants.log 2>&1
 tail -5 gpurun_out/r2a/pytest_variants.log
 timeout 120 python tools/mfma_ceiling.py > gpurun_out/r2a/mfma_ceiling.json 2>&1; cat gpurun_out/r2a/mfma_ceiling.json
-timeout 300 python tools/gemm_shapes.py --dtype bf16 --variants -1,2,4,5,6,7,8,9 --iters 50 > gpurun_out/r2a/gemm_bf16.log 2>&1; cat gpurun_out/r2a/gemm_bf16.log
-timeout 300 python tools/gemm_shapes.py --dtype f16 --variants -1,1,2,3,4,5,6 --iters 50 > gpurun_out/r2a/gemm_f16.log 2>&1; cat gpurun_out/r2a/gemm_f16.log
+timeout 300 python tools/gemm_shapes.py --dtype bf16 --variants=-1,2,4,5,6,7,8,9 --iters 50 > gpurun_out/r2a/gemm_bf16.log 2>&1; cat gpurun_out/r2a/gemm_bf16.log
+timeout 300 python tools/gemm_shapes.py --dtype f16 --variants=-1,1,2,3,4,5,6 --iters 50 > gpurun_out/r2a/gemm_f16.log 2>&1; cat gpurun_out/r2a/gemm_f16.log
