@@ -130,35 +130,61 @@ def extras(rt, ops, Event) -> dict:
     out = {}
 
     def timeit(fn, iters=50, warm=5):
+        # These kernels last 10-300 us and this section runs after a CPU-only pause (the CPU baseline): a handful of
+        # warm-up launches leaves the chip at idle clocks (the round-1 driver run read 11.5 us for a LayerNorm that
+        # takes 8.5-9.4 us warm, profiles/r02_layernorm_sweep.txt). Warm up for >= 30 ms of back-to-back launches, then
+        # time >= 20 ms of them.
+        fn()
+        rt.sync()
+        e0, e1 = Event(), Event()
+        rt.record(e0)
         for _ in range(warm):
             fn()
-        e0, e1 = Event(), Event()
+        rt.record(e1)
+        per = max(rt.elapsed_ms(e0, e1) / warm, 1e-3)
+        for _ in range(int(30.0 / per) + 1):
+            fn()
+        iters = max(iters, int(20.0 / per) + 1)
         rt.record(e0)
         for _ in range(iters):
             fn()
         rt.record(e1)
         return rt.elapsed_ms(e0, e1) / iters * 1e-3
 
+    pmc = {}
+    try:  # HBM-side bytes per launch of these kernels (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, tools/profile_rowops.sh)
+        for r in json.loads((REPO / "profiles" / "r02_rowops_pmc.json").read_text())["rows"]:
+            pmc[(("softmax" if "softmax" in r["kernel"] else "layernorm"), r["shape"], r["dtype"])] = r
+    except Exception:  # noqa: BLE001
+        pass
+
+    def row(kind, shape, name, t, nbytes):
+        gbs = nbytes / t / 1e9
+        d = {"GB/s": round(gbs, 1), "frac_hbm_peak": round(gbs / PEAK_HBM_GBS, 4), "us": round(t * 1e6, 2)}
+        r = pmc.get((kind, shape, name))
+        if r:
+            d["traffic"] = r["fetch_bytes_x2"] + r["write_bytes"]
+            d["traffic_over_algorithmic"] = r["traffic_over_algorithmic"]
+            d["traffic_source"] = "profiles/r02_rowops_pmc.json"
+        return d
+
     for name, dt in (("f16", torch.float16), ("f32", torch.float32)):
         x = torch.randn(196608, 512, device="cuda").to(dt)
         y = torch.empty_like(x)
         t = timeit(lambda: ops.softmax(rt, x, 1, out=y))
-        gbs = 2 * x.numel() * x.element_size() / t / 1e9
-        out[f"softmax_196608x512_{name}"] = {"GB/s": round(gbs, 1), "frac_hbm_peak": round(gbs / PEAK_HBM_GBS, 4), "us": round(t * 1e6, 2)}
+        out[f"softmax_196608x512_{name}"] = row("softmax", "196608x512", name, t, 2 * x.numel() * x.element_size())
         del x, y
         x = torch.randn(16384, 768, device="cuda").to(dt)
         g = torch.randn(768, device="cuda").to(dt)
         b = torch.randn(768, device="cuda").to(dt)
         y = torch.empty_like(x)
         t = timeit(lambda: ops.layer_norm(rt, x, g, b, 1e-5, -1, out=y))
-        gbs = 2 * x.numel() * x.element_size() / t / 1e9
-        out[f"layernorm_16384x768_{name}"] = {"GB/s": round(gbs, 1), "frac_hbm_peak": round(gbs / PEAK_HBM_GBS, 4), "us": round(t * 1e6, 2)}
+        out[f"layernorm_16384x768_{name}"] = row("layernorm", "16384x768", name, t, 2 * x.numel() * x.element_size())
         # a larger LayerNorm (does not fit the 256 MiB Infinity Cache): 131072 x 768
         x = torch.randn(131072 * 2, 768, device="cuda").to(dt)
         y = torch.empty_like(x)
         t = timeit(lambda: ops.layer_norm(rt, x, g, b, 1e-5, -1, out=y), iters=20)
-        gbs = 2 * x.numel() * x.element_size() / t / 1e9
-        out[f"layernorm_262144x768_{name}"] = {"GB/s": round(gbs, 1), "frac_hbm_peak": round(gbs / PEAK_HBM_GBS, 4), "us": round(t * 1e6, 2)}
+        out[f"layernorm_262144x768_{name}"] = row("layernorm", "262144x768", name, t, 2 * x.numel() * x.element_size())
         del x, y
     # the headline GEMM in the other layouts / dtypes the reference's MatMul takes (transB = 1 is what ONNX Gemm exports)
     n = 4096
