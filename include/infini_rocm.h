@@ -357,9 +357,21 @@ int infini_rocm_conv_transpose2d(infiniRocmRuntime_t rt, int dtype, const void *
                                  int64_t s, int ph, int pw, int sh, int sw, int dh, int dw, int oph, int opw,
                                  int64_t groups, int act);
 /* Kernel choice for the next f16 / bf16 conv2d calls: -1 heuristic, 1 generic implicit GEMM only,
- * 2 tap-shifted implicit GEMM (conv_s1) for every unit-stride same-size shape, 3 batched-GEMM route for every
- * eligible pointwise shape. All variants compute the same sums (fp32 accumulate). Used by tune() and tests. */
+ * 2 the conv_s1.hip kernels (LDS-resident input patch for unit-stride "same" R x S, tap-shifted implicit GEMM
+ * otherwise) for every shape they serve, 3 batched-GEMM route for every eligible pointwise shape, 4 = 2 with the
+ * patch kernel off (the tap-shifted kernel everywhere: A/B). All variants compute the same sums (fp32 accumulate).
+ * Used by tune() and tests. */
 int infini_rocm_conv2d_set_variant(infiniRocmRuntime_t rt, int variant);
+/* Packed-weight cache. The f16 / bf16 conv kernels read their weights re-packed (FCRS -> [RS][F][C]); while `on` is set
+ * the next conv2d calls treat `w` as CONSTANT data: the packed image is built once, kept in a runtime-owned buffer keyed
+ * by (w, F, C, RS, layout) and reused by every later call — eager or captured (built on a side stream when the runtime
+ * stream is recording, so a hipGraph contains no pack node). An image is dropped when copy_from_cpu / copy_inside /
+ * memset / dealloc touch its source range (weight_cache_info's epoch then changes: whoever holds captured graphs of this
+ * runtime must drop them — the plugin does) or by weight_cache_clear. Off (default): re-packed per call in the workspace.
+ * The reference's cuDNN path has no per-call weight transform either (src/kernels/cuda/conv.cc:143-168). */
+int infini_rocm_conv2d_set_const_weights(infiniRocmRuntime_t rt, int on);
+int infini_rocm_weight_cache_info(infiniRocmRuntime_t rt, size_t *entries, size_t *bytes, uint64_t *epoch);
+int infini_rocm_weight_cache_clear(infiniRocmRuntime_t rt);
 
 /* ------------------------------------------------------------------------------------------ */
 /* ReduceSum / ReduceMean over arbitrary axes (reference: ReduceCudnnBase::compute,             */

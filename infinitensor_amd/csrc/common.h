@@ -115,12 +115,36 @@ struct infiniRocmRuntime {
     bool capturing = false;
     int matmul_variant = -1;
     int conv_variant = -1;
+    // conv weights declared constant by the caller: their re-packed images are cached (WCacheEntry) instead of rebuilt
+    int conv_const_weights = 0;
+    struct WCacheEntry {
+        const void *src;   // the operator's weight tensor (FCRS)
+        size_t src_bytes;
+        int f, c, rs, kind; // kind 0: [RS][F][C], 1: [F][Kpad]
+        void *packed;
+        size_t packed_bytes;
+    };
+    std::vector<WCacheEntry> wcache;
+    uint64_t wcache_epoch = 0;      // bumped whenever an entry is dropped (captured graphs may still address it)
+    hipStream_t side_stream = nullptr; // non-captured helper stream (packs weights while the main stream records)
     void *zeros = nullptr; // 256 zero bytes (K-tail source for the LDS-DMA GEMM staging)
     int num_cu = 256;
     void *comm = nullptr; // rcclComm_t, owned by comm.cc
     int comm_world = 1, comm_rank = 0;
     std::mutex mu;
 };
+
+namespace irocm {
+// packed-weight cache (runtime.hip)
+const void *wcache_lookup(infiniRocmRuntime *rt, const void *src, int f, int c, int rs, int kind);
+// allocates the packed buffer and tells on which stream to launch the pack kernel (the runtime stream, or the side stream
+// while the runtime stream is capturing); wcache_commit makes the image usable (waits for the side stream if it was used)
+int wcache_insert(infiniRocmRuntime *rt, const void *src, size_t src_bytes, int f, int c, int rs, int kind, size_t packed_bytes,
+                  void **packed, hipStream_t *stream);
+int wcache_commit(infiniRocmRuntime *rt, hipStream_t stream);
+// drops every entry whose SOURCE overlaps [ptr, ptr + bytes); the packed buffers are retired, not freed
+void wcache_invalidate(infiniRocmRuntime *rt, const void *ptr, size_t bytes);
+} // namespace irocm
 
 struct infiniRocmGraph {
     hipGraph_t graph = nullptr;

@@ -28,11 +28,13 @@
 //     Xp[py][px][n][c][OH][OW] = X[n][c][i*sh + py][j*sw + px] that some tap reads (1 of 4 for a 1x1/2, all 4 for a
 //     3x3/2); on a phase plane every tap is again a constant shift of a unit-stride same-size access, so the same
 //     kernel runs with a per-tap (plane, shift) pair. Needs OH == ceil(H / sh) and OW == ceil(W / sw).
-#include "gemm_common.h"
+#include "gemm256_common.h"
 #include <type_traits>
 #include <cstdlib>
 
 namespace irocm {
+
+template <int N> __device__ __forceinline__ void g256p_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 struct ConvS1Args {
     const void *x, *w, *bias; // x: input or its phase planes; w: [RS][F][C]
@@ -874,6 +876,318 @@ __global__ __launch_bounds__(256, (NKB <= 2 ? 2 : 1)) void conv_pw_kernel(ConvS1
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// conv_patch: unit-stride "same" R x S convolutions (the 3x3 layers) with the input patch RESIDENT in LDS.
+//
+// conv_s1_kernel re-fetches the B tile from L2 for every tap (nine times the input per 3x3 layer, through registers,
+// 2-byte-aligned 16-byte loads; rocprofv3 on 3x3 C256 14x14: MFMA busy 17 %). Here, per block of 32 channels, the
+// workgroup loads ONCE the input slots its 128 output slots can reach through any tap — [n0 - halo, n0 + 128 + halo),
+// halo = ph * W + pw rounded up to 8 — and all R*S taps are computed from that patch:
+//   global (NCHW rows, 16-byte runs of 8 slots) -> registers -> RAW image [32 k][slots] in LDS (512-byte rows, the
+//   GEMM's XOR swizzle) -> transposed INSIDE LDS by the gfx950 transpose read (2 x ds_read_b64_tr_b16 give a lane the 8
+//   consecutive channels of one slot) -> PM image [slot][32 k] (64-byte rows, chunk ^= ((slot >> 2) & 1) << 1:
+//   conflict-free for ds_read_b128 at every row offset). In PM a tap is a ROW offset ((r - ph) * W + (s - pw)): the B
+//   fragment of v_mfma_f32_16x16x32 for 16 slots is one aligned ds_read_b128 per lane whatever the tap, zero padding is
+//   a per-lane validity bit per (slot, tap) applied with v_cndmask (slots are flat pixel indices img * HWp + pix, as in
+//   conv_s1: a tap that leaves the image row / plane is masked, so what the neighbouring slots hold never matters).
+// Per tap one weight tile [128 f][32 c] (re-packed [RS][F][C]) arrives by LDS-DMA (global_load_lds_dwordx4): two stages of
+// THREE taps each (a filter row of a 3x3), fetched one step ahead; one barrier per three taps (48 MFMAs per wave): a first version staged it through registers one step
+// ahead like conv_s1_kernel and ran no faster than the tap-shifted kernel — with 16 MFMAs per step (256 cycles) the step
+// was bound by the L2 round trip of the weight loads, not by the B traffic the patch removes. The next channel block's
+// runs are in flight during the taps of the current one. 2 workgroups per CU (<= 64 KiB of LDS each). Same accumulator
+// layout and epilogues (LDS-staged row-wise stores, bias / residual / activation) as conv_s1_kernel<2, 2, *>.
+// ------------------------------------------------------------------------------------------------
+template <typename Tr, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_patch_kernel(ConvS1Args p, int halo8, int pslots) {
+    constexpr int BM = WM * 64, BN = WN * 64, BK = 32; // 4 waves of 64 x 64: <2, 2> = 128 f x 128 slots, <1, 4> = 64 f x 256 slots
+    constexpr int A_BYTES = BM * BK * 2;                     // weight tile: [BM f][32 c], 64-byte rows
+    constexpr int TPS = 3;                                   // taps per step (= per barrier): a filter row of a 3x3
+    constexpr int STAGE_BYTES = TPS * A_BYTES, NSTAGE = 2;   // two stages, each the tiles of TPS consecutive taps
+    constexpr int RAW_CH = WN == 4 ? 64 : 32;                // 16-byte chunks per RAW row (>= patch slots / 8)
+    constexpr int RAW_ROWB = RAW_CH * 16, RAW_BYTES = BK * RAW_ROWB; // [32 k][slots], fixed pitch
+    constexpr int NR = WN == 4 ? 6 : 4;                      // patch runs per thread per channel block
+    constexpr int NPA = BM / 64;                             // weight DMA pieces (16 rows x 64 B) per wave and tile
+    static_assert(WM * WN == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[]; // [A stages | RAW | PM]
+    char *const raw = smem + NSTAGE * STAGE_BYTES;
+    char *const pm = raw + RAW_BYTES;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = w / WN, wn = w % WN;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = wg % p.tiles_m, tn = wg / p.tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const unsigned short *Wp = (const unsigned short *)p.w;
+    const __amdgpu_buffer_rsrc_t xrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const int ncb = p.c / BK, ntaps = p.r * p.s;
+    const long tap_stride = (long)p.f * p.c;
+    const unsigned lds0 = (unsigned)(unsigned long)IROCM_LDS_PTR(smem);
+
+    // ---- weight tile by LDS-DMA: BM / 16 pieces of 16 rows x 64 B; wave w issues pieces NPA w ... The image is lane-linear
+    // (row = piece * 16 + lane / 4, 16-byte chunk lane % 4), so the chunk swizzle ((row >> 2) & 1) << 1 that makes the
+    // fragment reads conflict-free is applied to the global SOURCE chunk. ------------------------------------------
+    unsigned a_off[NPA]; // byte offset of this lane's 16 bytes inside one tap's [F][C] matrix (channel block 0)
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+        const int row = (w * NPA + i) * 16 + (lane >> 2);
+        const int c_src = (lane & 3) ^ (((row >> 2) & 1) << 1);
+        int gm = m0 + row;
+        gm = gm < p.f ? gm : p.f - 1; // rows past F re-read the last filter; never stored
+        a_off[i] = (unsigned)(((long)gm * p.c + c_src * 8) * 2);
+    }
+    // DMA cursor: the next step (channel block d_cb, taps TPS d_st ..) to fetch. Past the end it stays on the last one
+    // (re-fetched into a dead stage), a missing tap re-fetches the step's first: every wave always issues exactly NPA TPS DMA
+    // instructions per step, so the vmcnt counts below are uniform.
+    const int nst = (ntaps + TPS - 1) / TPS;
+    int d_cb = 0, d_st = 0;
+    auto dma_step = [&](int stage) __attribute__((always_inline)) {
+        const int t0 = TPS * d_st;
+        const unsigned off0 = (unsigned)(((long)t0 * tap_stride + d_cb * BK) * 2); // weights are < 4 GiB
+        char *dst = smem + stage * STAGE_BYTES + w * (NPA * 1024);
+#pragma unroll
+        for (int k = 0; k < TPS; ++k) {
+            const char *src = (const char *)Wp + off0 + (t0 + k < ntaps ? (unsigned)(k * tap_stride * 2) : 0u);
+#pragma unroll
+            for (int i = 0; i < NPA; ++i)
+                __builtin_amdgcn_global_load_lds(IROCM_GLB_PTR(src + (unsigned long)a_off[i]),
+                                                 IROCM_LDS_PTR(dst + k * A_BYTES + i * 1024), 16, 0, 0);
+        }
+        if (d_st + 1 < nst) ++d_st;
+        else if (d_cb + 1 < ncb) { d_st = 0; ++d_cb; }
+    };
+    // ---- patch runs: id = t + i*256 -> channel row id / rpr, slot run id % rpr ---------------------------
+    const int rpr = pslots / 8, nruns = BK * rpr;
+    const int pstart = n0 - halo8; // first slot of the patch (a multiple of 8, may be negative)
+    int p_voff[NR], p_lds[NR];
+    unsigned p_valid = 0;
+    bool risky_lane = false;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int id = t + i * 256;
+        const int kr = id / rpr, rc = id - kr * rpr;
+        const int slot0 = pstart + rc * 8;
+        int img = 0, pix = 0;
+        bool ok = id < nruns && slot0 >= 0 && slot0 < p.ncols;
+        if (ok) {
+            img = slot0 / p.hwp;
+            pix = slot0 - img * p.hwp;
+            ok = pix < p.hw;
+        }
+        p_voff[i] = (int)((((long)img * p.c + kr) * p.hw + pix) * 2);
+        p_lds[i] = id < nruns ? kr * RAW_ROWB + ((rc ^ (f128::mn_f(kr) << 1)) * 16) : -1;
+        if (ok) {
+            p_valid |= 1u << i;
+            // can the run end past the tensor in the LAST channel block? (only the last plane of an hw % 8 != 0 layer)
+            risky_lane = risky_lane || ((unsigned)(p_voff[i] + (ncb - 1) * BK * p.hw * 2) > p.x_bytes - 16);
+        }
+    }
+    const bool wg_risky = __syncthreads_or(risky_lane) != 0;
+    // ---- per-lane validity of (slot, tap) and PM row of the lane's slot for the four 16-slot blocks ------
+    int vm[4];
+    const int brow64 = (halo8 + wn * 64 + l15) * 64; // PM byte offset of the lane's slot in block j = 0 (j adds 1024)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int slot = n0 + wn * 64 + j * 16 + l15;
+        unsigned m = 0;
+        if (slot < p.ncols) {
+            const int img = slot / p.hwp, pix = slot - img * p.hwp;
+            if (pix < p.hw) {
+                const int oh = pix / p.wd, ow = pix - oh * p.wd;
+                for (int r_ = 0; r_ < p.r; ++r_)
+                    for (int s_ = 0; s_ < p.s; ++s_)
+                        if ((unsigned)(oh + r_ - p.ph) < (unsigned)p.in_h && (unsigned)(ow + s_ - p.pw) < (unsigned)p.in_w)
+                            m |= 1u << (r_ * p.s + s_);
+            }
+        }
+        vm[j] = (int)m;
+    }
+    // ---- LDS fragment offsets ----------------------------------------------------------------------------
+    // weight fragment of filter row wm*64 + i*16 + l15: chunk g4 of a 64-byte row, swizzled like the DMA source
+    const unsigned a_frag = lds0 + (unsigned)((wm * 64 + l15) * 64 + ((g4 ^ (((l15 >> 2) & 1) << 1)) * 16)); // + i * 1024
+    const unsigned pm0 = lds0 + NSTAGE * STAGE_BYTES + RAW_BYTES;
+    const int g4_16 = g4 * 16;
+    int t_frag[2]; // transposing pass: lane supplies k-row g4*8 + hh*4 + (l15 >> 2), 4 slots (l15 & 3) * 4 of the block
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+        t_frag[hh] = (g4 * 8 + hh * 4 + (l15 >> 2)) * RAW_ROWB + (l15 & 1) * 8;
+    const int mnf_lane[2] = {f128::mn_f(g4 * 8 + (l15 >> 2)), f128::mn_f(g4 * 8 + 4 + (l15 >> 2))};
+
+    u32x4_t p_reg[NR];
+    // SAFE = false: one 16-byte buffer load per run (runs that do not exist get an offset past the descriptor: zeros);
+    // SAFE = true (a live run of this workgroup may end past the tensor): such a run is fetched by element, because the
+    // descriptor's range check works on whole dwords of a possibly 2-byte-aligned run.
+    auto load_patch = [&](auto safec, int cb) __attribute__((always_inline)) {
+        constexpr bool SAFE = decltype(safec)::value;
+        const int cboff = cb * BK * p.hw * 2;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const bool ok = (p_valid >> i) & 1u;
+            const int voff = ok ? p_voff[i] + cboff : (int)0xfffffff0u;
+            if constexpr (SAFE) {
+                u32x4_t v = {0u, 0u, 0u, 0u};
+                if (ok) {
+                    if ((unsigned)voff <= p.x_bytes - 16) {
+                        v = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int eo = voff + 2 * j;
+                            const unsigned e = (unsigned)eo < p.x_bytes ? (unsigned)__builtin_amdgcn_raw_buffer_load_b16(xrs, eo, 0, 0) : 0u;
+                            v[j >> 1] |= e << ((j & 1) * 16);
+                        }
+                    }
+                }
+                p_reg[i] = v;
+            } else {
+                p_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, 0, 0);
+            }
+        }
+    };
+    auto store_patch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+            if (p_lds[i] >= 0)
+                *(u32x4_t *)(raw + p_lds[i]) = p_reg[i];
+    };
+    // RAW [k][slots] -> PM [slot][k]: wave w transposes the 16-slot blocks w, w + 4, ...
+    auto transpose = [&]() __attribute__((always_inline)) {
+        for (int sb = w; sb * 16 < pslots; sb += 4) {
+            s16x4_t h[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int c16 = (sb * 2 + ((l15 >> 1) & 1)) ^ (mnf_lane[hh] << 1);
+                const char *addr = raw + t_frag[hh] + c16 * 16;
+                h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t *)(addr));
+            }
+            const int row = sb * 16 + l15;
+            *(s16x8_t *)(pm + row * 64 + ((g4 ^ (((row >> 2) & 1) << 1)) * 16)) =
+                s16x8_t{h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bias_v[4];
+    conv_load_bias<Tr>(p, m0, wm, l15, bias_v);
+
+    // The fragment reads are inline asm (like gemm256.hip): hipcc knows nothing about what an LDS-DMA in flight writes
+    // and would drain vmcnt(0) in front of every LDS read it can see.
+    // One tap: 4 weight fragments + 4 slot fragments (blocks j are 16 rows = 1024 bytes apart and 16 rows never change
+    // (row >> 2) & 1: one address, four immediate offsets), validity as an all-ones / all-zeros word per (block, tap).
+    auto compute = [&](unsigned abase, int tap, int shift64) __attribute__((always_inline)) {
+        s16x8_t af[4];
+        u32x4_t bv[4];
+        af[0] = g256::lds_read_b128<0>(abase);
+        af[1] = g256::lds_read_b128<1024>(abase);
+        af[2] = g256::lds_read_b128<2048>(abase);
+        af[3] = g256::lds_read_b128<3072>(abase);
+        const int r64 = brow64 + shift64;
+        const unsigned baddr = pm0 + (unsigned)(r64 + (((r64 >> 3) & 32) ^ g4_16));
+        bv[0] = __builtin_bit_cast(u32x4_t, g256::lds_read_b128<0>(baddr));
+        bv[1] = __builtin_bit_cast(u32x4_t, g256::lds_read_b128<1024>(baddr));
+        bv[2] = __builtin_bit_cast(u32x4_t, g256::lds_read_b128<2048>(baddr));
+        bv[3] = __builtin_bit_cast(u32x4_t, g256::lds_read_b128<3072>(baddr));
+        g256::wait_lgkm0();
+        s16x8_t bf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned m = (unsigned)__builtin_amdgcn_sbfe(vm[j], tap, 1); // 0 or 0xffffffff
+            u32x4_t v = bv[j];
+            v[0] &= m; v[1] &= m; v[2] &= m; v[3] &= m;
+            bf[j] = __builtin_bit_cast(s16x8_t, v);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = Tr::mfma(bf[j], af[i], acc[i][j]);
+    };
+
+    auto sweep = [&](auto safec) __attribute__((always_inline)) {
+        load_patch(safec, 0);
+        dma_step(0);
+        store_patch(); // (the compiler waits for the runs here — and with them for the weight tiles)
+        __syncthreads();
+        transpose();
+        __syncthreads();
+        int stage = 0;
+        const int row64 = p.wd * 64;
+        for (int cb = 0; cb < ncb; ++cb) {
+            int sh64 = (-p.ph * p.wd - p.pw) * 64, ss = 0; // tap (0, 0)
+            auto next_tap = [&]() {
+                sh64 += 64;
+                if (++ss == p.s) { ss = 0; sh64 += row64 - p.s * 64; }
+            };
+            for (int st = 0; st < nst; ++st) {
+                // the tiles of the NEXT step, into the stage the previous step read (every wave is past that barrier);
+                // one step (TPS taps, >= 1 k cycles) covers their L2 round trip
+                dma_step(stage ^ 1);
+                if (st == 0) {
+                    // the next channel block's runs: in flight during the remaining taps (the last block re-reads itself)
+                    load_patch(safec, cb + 1 < ncb ? cb + 1 : cb);
+                }
+                const unsigned abase = a_frag + stage * STAGE_BYTES;
+#pragma unroll
+                for (int k = 0; k < TPS; ++k) {
+                    if (k == 0 || TPS * st + k < ntaps) {
+                        compute(abase + k * A_BYTES, TPS * st + k, sh64);
+                        next_tap();
+                    }
+                }
+                // my pieces of the next step's tiles have landed: every VMEM op — except the NR runs when they were issued
+                // after the tiles in this step. (SAFE issues a data-dependent number of loads for the runs: there the
+                // plain vmcnt(0) is the only count that is right for every wave.)
+                if (!decltype(safec)::value && st == 0) g256p_wait_vm<NR>();
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                g256::barrier();
+                stage ^= 1;
+            }
+            if (cb + 1 < ncb) {
+                store_patch();
+                __syncthreads();
+                transpose();
+                __syncthreads();
+            }
+        }
+    };
+    if (wg_risky)
+        sweep(std::true_type{});
+    else
+        sweep(std::false_type{});
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the tail's dead weight tiles must not land on the staging images
+    __syncthreads();
+    if ((p.wide_epilogue == 1 && (!p.res || p.y_bytes) && (p.hw & 1) == 0) ||
+        (p.wide_epilogue == 2 && ((p.hw & 1) == 0 ? (!p.res || p.y_bytes) : !p.res))) { // workgroup-uniform
+        conv_tile_epilogue_lds<Tr>(p, acc, bias_v, m0, n0, wm, wn, lane, smem + w * kEpiWaveBytes);
+        return;
+    }
+    conv_tile_epilogue<Tr>(p, acc, m0, n0, wm, wn, l15, g4);
+}
+
+template <typename Tr, int WM, int WN> static int launch_patch(infiniRocmRuntime_t rt, ConvS1Args &p, int halo8, int pslots) {
+    constexpr int BM = WM * 64, BN = WN * 64;
+    p.tiles_m = (int)ceil_div(p.f, BM);
+    p.tiles_n = (int)ceil_div(p.ncols, BN);
+    const long blocks = (long)p.tiles_m * p.tiles_n;
+    IROCM_CHECK_ARG(blocks < (1l << 31), "conv2d: too many tiles");
+    constexpr int fixed = 2 * 3 * (BM * 32 * 2) + 32 * (WN == 4 ? 1024 : 512); // weight stages + RAW
+    const int lds = fixed + pslots * 64;                                         // + PM (<= 80 KiB: two per CU)
+    auto kern = conv_patch_kernel<Tr, WM, WN>;
+    IROCM_LDS_ATTR(kern, fixed + (BN + 128) * 64, rt);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, rt->stream, p, halo8, pslots);
+    IROCM_LAUNCH_CHECK("conv_patch");
+    return INFINI_ROCM_OK;
+}
+
 template <typename Tr, int NKB> static int launch_pw_n(infiniRocmRuntime_t rt, ConvS1Args &p) {
     constexpr int LDS = NKB * (128 * 72 * 2 + 64 * 256) + (NKB == 1 ? 4 * kEpiWaveBytes : 0);
     auto kern = conv_pw_kernel<Tr, NKB>;
@@ -959,42 +1273,72 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
     if (x_bytes >= (1l << 31) - 64 || x_bytes < 64) // 32-bit buffer offsets; `x_bytes - 16` must not wrap
         return -1;
     p.x_bytes = (unsigned)x_bytes;
-    // workspace: [ re-packed weights | phase planes ]
+    // Re-packed weights: FCRS -> [RS][F][C] (or [F][Kpad] for ROWTAP). When the caller declared the weights constant
+    // (infini_rocm_conv2d_set_const_weights: the plugin does for graph weights / inputs no operator writes) the packed
+    // image is built ONCE, kept in a runtime-owned buffer keyed by (pointer, F, C, RS, layout) and dropped when anything
+    // is copied over the source range (runtime.hip) — the reference's cuDNN path has no per-call weight transform either
+    // (src/kernels/cuda/conv.cc:143-168). Otherwise it is rebuilt per call in the workspace: [ weights | phase planes ].
     p.kdim = c * r * s;
     p.kpad = (p.kdim + 31) & ~31;
     const size_t w_bytes = rowtap ? (((size_t)f * p.kpad * 2 + 255) & ~(size_t)255)
                                   : (r * s > 1 ? (((size_t)f * c * r * s * 2 + 255) & ~(size_t)255) : 0);
-    const size_t ws_bytes = w_bytes + (split ? (size_t)x_bytes : 0);
+    const bool cached = w_bytes && rt->conv_const_weights;
+    const void *packed = nullptr;
+    hipStream_t pack_stream = rt->stream; // (may be the legacy default stream, i.e. a null handle: never test it)
+    bool need_pack = w_bytes != 0;
+    if (cached) {
+        packed = wcache_lookup(rt, w, f, c, r * s, rowtap ? 1 : 0);
+        if (!packed) {
+            void *buf = nullptr;
+            int st = wcache_insert(rt, w, (size_t)f * c * r * s * 2, f, c, r * s, rowtap ? 1 : 0, w_bytes, &buf, &pack_stream);
+            if (st != INFINI_ROCM_OK)
+                return st;
+            packed = buf;
+        } else {
+            need_pack = false; // hit: nothing to launch
+        }
+    }
+    const size_t ws_w = cached ? 0 : w_bytes;
+    const size_t ws_bytes = ws_w + (split ? (size_t)x_bytes : 0);
     char *ws = nullptr;
     if (ws_bytes) {
         int st = infini_rocm_workspace(rt, ws_bytes, (void **)&ws);
         if (st != INFINI_ROCM_OK)
             return st;
     }
-    if (rowtap) { // FCRS -> [F][Kpad], k = tap * C + c
-        long g = ceil_div((long)f * p.kpad, 256);
-        if (g > 4096) g = 4096;
-        hipLaunchKernelGGL(conv_repack_w_flat, dim3((unsigned)g), dim3(256), 0, rt->stream, (const unsigned short *)w,
-                           (unsigned short *)ws, f, c, r * s, p.kpad);
-        IROCM_LAUNCH_CHECK("conv_repack_w_flat");
-        p.w = ws;
-    } else if (w_bytes) { // FCRS -> [RS][F][C]
-        long g = ceil_div((long)f * c * r * s, 256);
-        if (g > 4096) g = 4096;
-        hipLaunchKernelGGL(conv_repack_w, dim3((unsigned)g), dim3(256), 0, rt->stream, (const unsigned short *)w,
-                           (unsigned short *)ws, f, c, r * s);
-        IROCM_LAUNCH_CHECK("conv_repack_w");
-        p.w = ws;
+    unsigned short *wdst = cached ? (unsigned short *)const_cast<void *>(packed) : (unsigned short *)ws;
+    if (need_pack) {
+        if (rowtap) { // FCRS -> [F][Kpad], k = tap * C + c
+            long g = ceil_div((long)f * p.kpad, 256);
+            if (g > 4096) g = 4096;
+            hipLaunchKernelGGL(conv_repack_w_flat, dim3((unsigned)g), dim3(256), 0, pack_stream, (const unsigned short *)w, wdst, f,
+                               c, r * s, p.kpad);
+            IROCM_LAUNCH_CHECK("conv_repack_w_flat");
+        } else { // FCRS -> [RS][F][C]
+            long g = ceil_div((long)f * c * r * s, 256);
+            if (g > 4096) g = 4096;
+            hipLaunchKernelGGL(conv_repack_w, dim3((unsigned)g), dim3(256), 0, pack_stream, (const unsigned short *)w, wdst, f, c,
+                               r * s);
+            IROCM_LAUNCH_CHECK("conv_repack_w");
+        }
+        if (cached) {
+            int st = wcache_commit(rt, pack_stream);
+            if (st != INFINI_ROCM_OK)
+                return st;
+        }
     }
+    if (w_bytes)
+        p.w = wdst;
+    const size_t w_off = ws_w;
     if (split) {
         ps.x = (const unsigned short *)x;
-        ps.o = (unsigned short *)(ws + w_bytes);
+        ps.o = (unsigned short *)(ws + w_off);
         ps.planes = (long)n * c;
         ps.in_h = h; ps.in_w = wd; ps.oh = oh; ps.ow = ow; ps.sh = sh; ps.sw = sw;
         const long work2 = (long)n * c * 2 * oh * ((ow + 1) / 2);
         // vector kernels: 8 columns per thread when the row length allows (any phase set), else the quad kernel when all
         // four phases are wanted (3x3/2, 7x7/2); a 1x1/2 on odd-sized rows reads one phase and is faster element-wise
-        const bool v8ok = wd % 8 == 0 && (((uintptr_t)x) & 15) == 0 && (w_bytes % 8 == 0) && (p.plane_elems % 4 == 0);
+        const bool v8ok = wd % 8 == 0 && (((uintptr_t)x) & 15) == 0 && (w_off % 8 == 0) && (p.plane_elems % 4 == 0);
         if (sh == 2 && sw == 2 && (ps.nslots == 4 || v8ok) && work2 + (long)rt->num_cu * 32 * 256 < (1l << 31)) {
             PhaseSplit2Args a2;
             a2.x = ps.x; a2.o = ps.o; a2.planes = n * c; a2.in_h = h; a2.in_w = wd; a2.oh = oh; a2.ow = ow;
@@ -1023,6 +1367,18 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
         return bf ? launch_pw<Bf16Traits>(rt, p) : launch_pw<F16Traits>(rt, p);
     if (rowtap)
         return bf ? launch_s1<Bf16Traits, 1, 4, 32, true>(rt, p) : launch_s1<F16Traits, 1, 4, 32, true>(rt, p);
+    // unit-stride "same" R x S (the 3x3 layers): input patch resident in LDS, every tap an aligned row offset
+    static const int patch_on = getenv("IROCM_CONV_PATCH") ? atoi(getenv("IROCM_CONV_PATCH")) : 1; // tuning hook: 0 = off
+    if (patch_on && r * s > 1 && r * s <= 32 && !split && dh == 1 && dw == 1 && oh == h && ow == wd && 2 * ph == r - 1 &&
+        2 * pw == s - 1 && c % 32 == 0 && rt->conv_variant != 4) { // variant 4: the tap-shifted kernel (A/B)
+        const int halo8 = (ph * wd + pw + 7) & ~7;
+        // 128 f x 128 slots. (The 64 f x 256 slots form of the same kernel, <1, 4>, was measured on ResNet's C64 -> F64
+        // 56x56 layers — two channel blocks, 18 taps per workgroup: 119 us against 96 us for the tap-shifted kernel, whose
+        // 64 x 256 x 32 tile has no patch / transpose prologue to amortise — and is not instantiated.)
+        if (f > 64 && 2 * halo8 <= 128)
+            return bf ? launch_patch<Bf16Traits, 2, 2>(rt, p, halo8, 128 + 2 * halo8)
+                      : launch_patch<F16Traits, 2, 2>(rt, p, halo8, 128 + 2 * halo8);
+    }
     if (f <= 64)
         return bf ? launch_s1<Bf16Traits, 1, 4, 32>(rt, p) : launch_s1<F16Traits, 1, 4, 32>(rt, p);
     static const int cfg = getenv("IROCM_CONV_CFG") ? atoi(getenv("IROCM_CONV_CFG")) : 0; // tuning hook

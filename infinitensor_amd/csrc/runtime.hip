@@ -13,6 +13,69 @@ void set_error(const char *fmt, ...) {
 }
 } // namespace irocm
 
+namespace irocm {
+const void *wcache_lookup(infiniRocmRuntime *rt, const void *src, int f, int c, int rs, int kind) {
+    for (const auto &e : rt->wcache)
+        if (e.src == src && e.f == f && e.c == c && e.rs == rs && e.kind == kind)
+            return e.packed;
+    return nullptr;
+}
+int wcache_insert(infiniRocmRuntime *rt, const void *src, size_t src_bytes, int f, int c, int rs, int kind, size_t packed_bytes,
+                  void **packed, hipStream_t *stream) {
+    IROCM_HIP(hipSetDevice(rt->device));
+    void *buf = nullptr;
+    hipError_t e;
+    if (rt->capturing) { // allocation and the side stream are legal under a thread-local Relaxed capture mode
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+        IROCM_HIP(hipThreadExchangeStreamCaptureMode(&mode));
+        e = hipMalloc(&buf, packed_bytes);
+        if (e == hipSuccess && !rt->side_stream)
+            e = hipStreamCreateWithFlags(&rt->side_stream, hipStreamNonBlocking);
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
+    } else {
+        e = hipMalloc(&buf, packed_bytes);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (buf)
+            (void)hipFree(buf);
+        IROCM_FAIL(e == hipErrorOutOfMemory ? INFINI_ROCM_OUT_OF_MEMORY : INFINI_ROCM_HIP_ERROR,
+                   "weight cache: allocation of %zu bytes failed: %s", packed_bytes, hipGetErrorString(e));
+    }
+    rt->wcache.push_back({src, src_bytes, f, c, rs, kind, buf, packed_bytes});
+    *packed = buf;
+    *stream = rt->capturing ? rt->side_stream : rt->stream;
+    return INFINI_ROCM_OK;
+}
+int wcache_commit(infiniRocmRuntime *rt, hipStream_t stream) {
+    if (stream == rt->stream)
+        return INFINI_ROCM_OK; // same stream as the consumer: ordered
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    IROCM_HIP(hipThreadExchangeStreamCaptureMode(&mode));
+    const hipError_t e = hipStreamSynchronize(stream); // the captured graph must find the image complete at every replay
+    (void)hipThreadExchangeStreamCaptureMode(&mode);
+    if (e != hipSuccess)
+        IROCM_FAIL(INFINI_ROCM_HIP_ERROR, "weight cache: side stream failed: %s", hipGetErrorString(e));
+    return INFINI_ROCM_OK;
+}
+void wcache_invalidate(infiniRocmRuntime *rt, const void *ptr, size_t bytes) {
+    if (rt->wcache.empty() || !ptr || !bytes)
+        return;
+    const char *lo = (const char *)ptr, *hi = lo + bytes;
+    for (size_t i = 0; i < rt->wcache.size();) {
+        const auto &e = rt->wcache[i];
+        const char *slo = (const char *)e.src, *shi = slo + e.src_bytes;
+        if (slo < hi && lo < shi) {
+            rt->retired.push_back(e.packed); // a captured graph may still read it: released with the retired workspace blocks
+            rt->wcache.erase(rt->wcache.begin() + i);
+            ++rt->wcache_epoch;
+        } else {
+            ++i;
+        }
+    }
+}
+} // namespace irocm
+
 using namespace irocm;
 
 extern "C" int infini_rocm_comm_destroy(infiniRocmRuntime_t rt);
@@ -73,6 +136,10 @@ int infini_rocm_runtime_destroy(infiniRocmRuntime_t rt) {
         (void)hipFree(rt->workspace);
     for (void *p : rt->retired)
         (void)hipFree(p);
+    for (auto &e : rt->wcache)
+        (void)hipFree(e.packed);
+    if (rt->side_stream)
+        (void)hipStreamDestroy(rt->side_stream);
     if (rt->zeros)
         (void)hipFree(rt->zeros);
     if (rt->own_stream)
@@ -136,8 +203,17 @@ int infini_rocm_alloc(infiniRocmRuntime_t rt, size_t bytes, void **ptr) {
 
 int infini_rocm_dealloc(infiniRocmRuntime_t rt, void *ptr) {
     IROCM_CHECK_ARG(rt, "NULL runtime");
-    if (ptr)
+    if (ptr) {
+        if (!rt->wcache.empty()) { // the block's size is not known here: drop every image packed from inside it
+            hipDeviceptr_t base = nullptr;
+            size_t size = 0;
+            if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)ptr) == hipSuccess)
+                wcache_invalidate(rt, base, size);
+            else
+                (void)hipGetLastError();
+        }
         IROCM_HIP(hipFree(ptr));
+    }
     return INFINI_ROCM_OK;
 }
 
@@ -147,6 +223,7 @@ int infini_rocm_copy_from_cpu(infiniRocmRuntime_t rt, void *dst, const void *src
     IROCM_CHECK_ARG(rt, "NULL runtime");
     if (bytes == 0)
         return INFINI_ROCM_OK;
+    wcache_invalidate(rt, dst, bytes);
     IROCM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, rt->stream));
     IROCM_HIP(hipStreamSynchronize(rt->stream));
     return INFINI_ROCM_OK;
@@ -165,6 +242,7 @@ int infini_rocm_copy_inside(infiniRocmRuntime_t rt, void *dst, const void *src, 
     IROCM_CHECK_ARG(rt, "NULL runtime");
     if (bytes == 0 || dst == src)
         return INFINI_ROCM_OK;
+    wcache_invalidate(rt, dst, bytes);
     IROCM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, rt->stream));
     return INFINI_ROCM_OK;
 }
@@ -173,6 +251,7 @@ int infini_rocm_memset(infiniRocmRuntime_t rt, void *dst, int value, size_t byte
     IROCM_CHECK_ARG(rt, "NULL runtime");
     if (bytes == 0)
         return INFINI_ROCM_OK;
+    wcache_invalidate(rt, dst, bytes);
     IROCM_HIP(hipMemsetAsync(dst, value, bytes, rt->stream));
     return INFINI_ROCM_OK;
 }
@@ -225,6 +304,33 @@ int infini_rocm_workspace_trim(infiniRocmRuntime_t rt) {
     for (void *p : rt->retired)
         (void)hipFree(p);
     rt->retired.clear();
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_conv2d_set_const_weights(infiniRocmRuntime_t rt, int on) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    rt->conv_const_weights = on ? 1 : 0;
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_weight_cache_info(infiniRocmRuntime_t rt, size_t *entries, size_t *bytes, uint64_t *epoch) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    size_t b = 0;
+    for (const auto &e : rt->wcache)
+        b += e.packed_bytes;
+    if (entries) *entries = rt->wcache.size();
+    if (bytes) *bytes = b;
+    if (epoch) *epoch = rt->wcache_epoch;
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_weight_cache_clear(infiniRocmRuntime_t rt) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    for (auto &e : rt->wcache) {
+        rt->retired.push_back(e.packed);
+        ++rt->wcache_epoch;
+    }
+    rt->wcache.clear();
     return INFINI_ROCM_OK;
 }
 

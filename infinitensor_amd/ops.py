@@ -163,6 +163,19 @@ def set_matmul_variant(rt: RocmRuntime, variant: int) -> None:
     check(lib().infini_rocm_matmul_set_variant(rt.handle, int(variant)))
 
 
+def set_conv_const_weights(rt: RocmRuntime, on: bool) -> None:
+    """While on, conv2d treats its weights as constant data and caches their re-packed image (infini_rocm.h)."""
+    check(lib().infini_rocm_conv2d_set_const_weights(rt.handle, 1 if on else 0))
+
+
+def weight_cache_info(rt: RocmRuntime) -> dict:
+    import ctypes as C
+
+    n, b, e = C.c_size_t(), C.c_size_t(), C.c_uint64()
+    check(lib().infini_rocm_weight_cache_info(rt.handle, C.byref(n), C.byref(b), C.byref(e)))
+    return {"entries": n.value, "bytes": b.value, "epoch": e.value}
+
+
 def set_conv_variant(rt: RocmRuntime, variant: int) -> None:
     """-1 heuristic, 1 generic implicit GEMM, 2 conv_s1 wherever eligible, 3 batched-GEMM route for pointwise."""
     check(lib().infini_rocm_conv2d_set_variant(rt.handle, int(variant)))

@@ -8,6 +8,7 @@
 #pragma once
 #include "core/communicator.h"
 #include "core/runtime.h"
+#include "core/tensor.h"
 #include "infini_rocm.h"
 #include <list>
 #include <memory>
@@ -121,6 +122,8 @@ class RocmRuntimeObj : public RuntimeObj {
     void tuneImpl(const Graph &graph, bool profiling) const;
     GraphState stateOf(const Graph &graph) const;
     void replay(CacheEntry &entry);
+    // a host copy dropped a packed weight image that captured graphs may read: forget every capture
+    void dropCapturesIfWeightsChanged(uint64_t epochBefore) const;
 
     infiniRocmRuntime_t rt = nullptr;
     std::unique_ptr<CommunicatorObj> comm;
@@ -131,6 +134,23 @@ class RocmRuntimeObj : public RuntimeObj {
     Cache cache; // most recently used first
     mutable std::recursive_mutex executionMutex;
     mutable std::recursive_mutex cacheMutex;
+};
+
+// While alive: the conv kernels treat the weight tensor as constant data and keep its re-packed image in the runtime's
+// packed-weight cache (infini_rocm_conv2d_set_const_weights). Only for weights no operator of the graph writes (graph
+// weights / inputs: getSource() == nullptr) — whatever the host copies over them goes through copyBlobFromCPU /
+// copyBlobInsideRuntime, which drop the stale image (and, in RocmRuntimeObj, the captured graphs that read it).
+struct ConstWeightsScope {
+    infiniRocmRuntime_t rt;
+    bool on;
+    ConstWeightsScope(infiniRocmRuntime_t rt, const Tensor &w) : rt(rt), on(w->getSource() == nullptr) {
+        if (on)
+            (void)infini_rocm_conv2d_set_const_weights(rt, 1);
+    }
+    ~ConstWeightsScope() {
+        if (on)
+            (void)infini_rocm_conv2d_set_const_weights(rt, 0);
+    }
 };
 
 // Throw infini::Exception with the C ABI's message when a call fails

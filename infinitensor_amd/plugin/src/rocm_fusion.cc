@@ -399,6 +399,7 @@ size_t RocmRuntimeObj::tryLaunchFusedRules(const OpVec &ops, size_t i) const {
                         (void)infini_rocm_conv2d_set_variant(rt, -1);
                 }
             } scope(rt, tunedVariant(op));
+            ConstWeightsScope constWeights(rt, w); // graph weights: pack once, cache (rocm_runtime.h)
             ROCM_CALL(infini_rocm_conv2d_res(rt, x->getDTypeIndex(), x->getRawDataPtr<void *>(), w->getRawDataPtr<void *>(),
                                              c.bias ? c.bias->getRawDataPtr<void *>() : nullptr,
                                              c.res ? c.res->getRawDataPtr<void *>() : nullptr, c.last->getRawDataPtr<void *>(),

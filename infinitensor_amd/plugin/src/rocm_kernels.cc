@@ -199,12 +199,13 @@ REGISTER_KERNEL(Device::ROCM, OpType::MatMul, MatmulRocm, "Matmul_MFMA_ROCM");
 class ConvRocm : public RocmTunableKernel {
     int setVariant(infiniRocmRuntime_t rt, int v) const override { return infini_rocm_conv2d_set_variant(rt, v); }
     // generic implicit GEMM, tap-shifted implicit GEMM (conv_s1), batched-GEMM route for pointwise shapes (infini_rocm.h)
-    std::vector<int> candidates() const override { return {1, 2, 3}; }
+    std::vector<int> candidates() const override { return {1, 2, 3, 4}; }
     int recordType() const override { return kRocmConvRecord; }
     void launch(const Operator &_op, const RuntimeObj *ctx) const override {
         auto op = as<ConvObj>(_op);
         const auto [n, c, h, w, f, r, s] = op->getNCHWFRS();
         const auto [ph, pw, sh, sw, dh, dw] = op->getPadStrideDilation();
+        ConstWeightsScope constWeights(H(ctx), op->getInputs(1)); // graph weights: pack once, cache (rocm_runtime.h)
         ROCM_CALL(infini_rocm_conv2d(H(ctx), DTI(op->getInputs(0)), P(op->getInputs(0)), P(op->getInputs(1)),
                                      nullptr, P(op->getOutput()), n, c, h, w, f, r, s, ph, pw, sh, sw, dh, dw,
                                      op->getNumGroups(), 0));

@@ -46,14 +46,31 @@ void *RocmRuntimeObj::alloc(size_t size) {
     return p;
 }
 void RocmRuntimeObj::dealloc(void *ptr) { ROCM_CALL(infini_rocm_dealloc(rt, ptr)); }
+static uint64_t weightEpoch(infiniRocmRuntime_t rt) {
+    uint64_t e = 0;
+    (void)infini_rocm_weight_cache_info(rt, nullptr, nullptr, &e);
+    return e;
+}
+void RocmRuntimeObj::dropCapturesIfWeightsChanged(uint64_t epochBefore) const {
+    if (weightEpoch(rt) == epochBefore)
+        return;
+    // the copy went over a conv weight whose packed image was cached: captured graphs still address the old image
+    auto *self = const_cast<RocmRuntimeObj *>(this);
+    std::lock_guard<std::recursive_mutex> cacheLock(cacheMutex);
+    self->cache.clear();
+}
 void RocmRuntimeObj::copyBlobFromCPU(void *dst, const void *src, size_t bytes) const {
+    const uint64_t e0 = weightEpoch(rt);
     ROCM_CALL(infini_rocm_copy_from_cpu(rt, dst, src, bytes));
+    dropCapturesIfWeightsChanged(e0);
 }
 void RocmRuntimeObj::copyBlobToCPU(void *dst, const void *src, size_t bytes) const {
     ROCM_CALL(infini_rocm_copy_to_cpu(rt, dst, src, bytes));
 }
 void RocmRuntimeObj::copyBlobInsideRuntime(void *dst, const void *src, size_t bytes) const {
+    const uint64_t e0 = weightEpoch(rt);
     ROCM_CALL(infini_rocm_copy_inside(rt, dst, src, bytes));
+    dropCapturesIfWeightsChanged(e0);
     ROCM_CALL(infini_rocm_runtime_sync(rt)); // reference semantics: cudaMemcpy D2D is synchronous
 }
 void *RocmRuntimeObj::getWorkspace(size_t size) const {

@@ -79,6 +79,13 @@ S1_CONVS = [
     # with unaligned 16-byte runs + a 1-pixel tail per row)
     (4, 512, 7, 7, 2048, 1, 1), (3, 2048, 7, 7, 512, 1, 1), (2, 512, 7, 7, 512, 3, 3), (3, 512, 14, 14, 512, 3, 3, 2, 2, 1, 1),
     (2, 64, 5, 3, 136, 1, 1),     # 15-pixel planes, ragged filter tile
+    # conv_patch_kernel (unit-stride "same" R x S, C % 32 == 0, F > 64: input patch resident in LDS, taps = row offsets)
+    (2, 128, 56, 56, 128, 3, 3),  # W = 56: halo 57 -> 64, the largest patch (256 slots)
+    (9, 256, 7, 7, 136, 3, 3),    # 49-pixel planes, tiles span 2-3 images, ragged filter count, the tensor ends mid-run
+    (1, 32, 60, 60, 65, 3, 3),    # one channel block, W = 60, a single valid row in the second filter tile
+    (2, 64, 64, 64, 128, 3, 3),   # W = 64: the patch would need 272 slots -> the tap-shifted kernel
+    (3, 160, 9, 11, 100, 3, 1),   # 3 x 1 window, 5 channel blocks, 99-pixel planes
+    (2, 64, 28, 28, 512, 3, 3),   # four filter tiles share each patch position
     # pointwise, C <= 256, F > 64: conv_pw_kernel (input tile resident in LDS, loop over filter tiles)
     (3, 64, 8, 8, 256, 1, 1),      # one K-step per filter tile, two filter tiles, 1.5 column tiles
     (2, 128, 14, 14, 200, 1, 1),   # two K-steps, ragged filter count, 196-pixel planes (pad slots, tile spans images)
@@ -124,6 +131,59 @@ def test_conv_s1_vs_oracle_and_generic_kernel(rt, cfg, dt):
     assert np.allclose(host(y), want, rtol=tol, atol=tol)
     # same products, fp32 accumulation in a different order: the two kernels agree to rounding of the output type
     assert np.allclose(host(y), host(yg), rtol=tol, atol=tol)
+
+
+def test_conv_packed_weight_cache(rt):
+    """Constant weights are re-packed ONCE (runtime-owned image keyed by pointer / shape), reused by eager calls and by a
+    captured graph (packed on a side stream while the runtime stream records: no pack node in the graph), and dropped
+    when the host copies new values over the weight tensor."""
+    from infinitensor_amd import RocmRuntime
+
+    r = RocmRuntime(0)
+    rng = np.random.default_rng(3)
+    x = dev(rng.standard_normal((2, 64, 14, 14)).astype(np.float32), torch.float16)
+    w1 = (rng.standard_normal((128, 64, 3, 3)) / 24).astype(np.float16)
+    w2 = (rng.standard_normal((128, 64, 3, 3)) / 24).astype(np.float16)
+    w = torch.from_numpy(w1).cuda()
+    torch.cuda.synchronize()
+    y_plain = ops.conv2d(r, x, w, 1, 1)
+    r.sync()
+    assert ops.weight_cache_info(r)["entries"] == 0
+    ops.set_conv_const_weights(r, True)
+    try:
+        ya = ops.conv2d(r, x, w, 1, 1)
+        yb = ops.conv2d(r, x, w, 1, 1)
+        r.sync()
+        info = ops.weight_cache_info(r)
+        assert info["entries"] == 1 and info["bytes"] >= w.numel() * 2
+        assert torch.equal(ya, y_plain) and torch.equal(yb, y_plain)
+        # a second weight tensor is packed INSIDE a capture (cold cache): the graph replays against the cached image
+        wb = torch.from_numpy(w2).cuda()
+        yc = torch.empty_like(y_plain)
+        torch.cuda.synchronize()
+        r.begin_capture()
+        ops.conv2d(r, x, wb, 1, 1, out=yc)
+        g = r.end_capture()
+        assert ops.weight_cache_info(r)["entries"] == 2
+        for _ in range(2):
+            yc.zero_()
+            torch.cuda.synchronize()
+            r.launch_graph(g)
+            r.sync()
+            want = R.conv2d(host(x).astype(np.float64), w2.astype(np.float64), 1, 1, 1, 1, 1, 1)
+            assert np.allclose(host(yc), want, rtol=2e-3, atol=2e-3)
+        # new VALUES in the first weight tensor through the runtime's copy: its image is dropped, the next call re-packs
+        e0 = ops.weight_cache_info(r)["epoch"]
+        src = np.ascontiguousarray(w2)
+        r.copy_from_cpu(w.data_ptr(), src.ctypes.data, src.nbytes)
+        info = ops.weight_cache_info(r)
+        assert info["entries"] == 1 and info["epoch"] == e0 + 1
+        yd = ops.conv2d(r, x, w, 1, 1)
+        r.sync()
+        assert ops.weight_cache_info(r)["entries"] == 2
+        assert np.allclose(host(yd), want, rtol=2e-3, atol=2e-3) and not torch.equal(yd, y_plain)
+    finally:
+        ops.set_conv_const_weights(r, False)
 
 
 def test_conv_s1_zero_padding_is_exact(rt):

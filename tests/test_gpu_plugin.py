@@ -957,3 +957,37 @@ def test_replay_survives_workspace_growth_by_a_later_graph(B):
         assert np.array_equal(get(o1), o1_before)
     assert rt.hip_graph_capture_count() == 2
     assert np.allclose(get(o1).astype(np.float64).reshape(w1.shape), w1, rtol=3e-3, atol=3e-3)
+
+
+def test_conv_weights_are_packed_once_and_repacked_after_copyin(B):
+    """Graph weights (no producing operator) are re-packed once: after the first run the packed image is cached, a
+    hipGraph capture holds no pack kernel, and copying new weights in drops the image AND the captures that read it
+    (the replay after the copy-in re-captures and sees the new weights; the reference's cuDNN path has no weight
+    transform to go stale, src/kernels/cuda/conv.cc:143-168)."""
+    rt = B.RocmRuntime(0)
+    rng = np.random.default_rng(17)
+    x = rng.standard_normal((2, 64, 12, 12)).astype(np.float16)
+    w1 = (rng.standard_normal((128, 64, 3, 3)) / 24).astype(np.float16)
+    w2 = (rng.standard_normal((128, 64, 3, 3)) / 24).astype(np.float16)
+    h = B.GraphHandler(rt)
+    tx, tw = h.tensor([2, 64, 12, 12], F16), h.tensor([128, 64, 3, 3], F16)
+    out = h.relu(h.conv(tx, tw, None, 1, 1, 1, 1, 1, 1), None)
+    h.data_malloc()
+    put(tx, x)
+    put(tw, w1)
+    want1 = np.maximum(R.conv2d(x.astype(np.float64), w1.astype(np.float64), 1, 1, 1, 1, 1, 1), 0)
+    want2 = np.maximum(R.conv2d(x.astype(np.float64), w2.astype(np.float64), 1, 1, 1, 1, 1, 1), 0)
+    h.run_with_hipgraph()
+    assert np.allclose(get(out).astype(np.float64).reshape(want1.shape), want1, rtol=3e-3, atol=3e-3)
+    put(tx, x)  # activations are re-fed before every run (the planner may place the output on the dead input): no recapture
+    h.run_with_hipgraph()
+    assert rt.hip_graph_capture_count() == 1
+    assert np.allclose(get(out).astype(np.float64).reshape(want1.shape), want1, rtol=3e-3, atol=3e-3)
+    put(tx, x)
+    put(tw, w2)  # weights: the packed image is stale -> dropped together with the capture
+    h.run_with_hipgraph()
+    assert rt.hip_graph_capture_count() == 2
+    assert np.allclose(get(out).astype(np.float64).reshape(want2.shape), want2, rtol=3e-3, atol=3e-3)
+    put(tx, x)
+    h.run()
+    assert np.allclose(get(out).astype(np.float64).reshape(want2.shape), want2, rtol=3e-3, atol=3e-3)
