@@ -376,7 +376,7 @@ def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
 
 def pmc_traffic():
     """HBM-side bytes per GEMM launch from the committed PMC passes (tools/profile_gemm.sh); None if absent."""
-    p = REPO / "profiles" / "r01_gemm256_v7_pmc.json"
+    p = REPO / "profiles" / "r02_gemm256p_pmc.json"
     try:
         return float(json.loads(p.read_text())["traffic_bytes_per_launch"])
     except Exception:  # noqa: BLE001
@@ -462,19 +462,35 @@ def main() -> int:
             td.barrier()
 
     e0, e1 = Event(), Event()
+    # one event after every launch (<= 1000 steps): the per-launch spread shows burst vs sustained clocks (the chip
+    # throttles after ~20 back-to-back launches); an event record costs well under a microsecond of stream time
+    marks = [Event() for _ in range(args.steps)] if args.steps <= 1000 else []
     barrier()
     torch.cuda.synchronize()
     rt.sync()
     t0 = time.perf_counter()
     rt.record(e0)
-    for _ in range(args.steps):
+    for i in range(args.steps):
         step()
+        if marks:
+            rt.record(marks[i])
     rt.record(e1)
     rt.sync()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_s = rt.elapsed_ms(e0, e1) * 1e-3 / args.steps  # avg launch duration from HIP events
+    per_launch = None
+    if marks:
+        prev, durs = e0, []
+        for m in marks:
+            durs.append(rt.elapsed_ms(prev, m) * 1e3)
+            prev = m
+        durs_sorted = sorted(durs)
+        per_launch = {"min": round(durs_sorted[0], 2), "median": round(durs_sorted[len(durs) // 2], 2),
+                      "mean": round(sum(durs) / len(durs), 2), "max": round(durs_sorted[-1], 2),
+                      "first10_mean": round(sum(durs[:10]) / min(10, len(durs)), 2),
+                      "last10_mean": round(sum(durs[-10:]) / min(10, len(durs)), 2)}
 
     if dist:
         tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
@@ -515,8 +531,9 @@ def main() -> int:
             "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
             "traffic": pmc_traffic(),
-            "traffic_source": "profiles/r01_gemm256_v7_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel and shape; bytes per launch, FETCH_SIZE x2 per the gfx950 note)",
+            "traffic_source": "profiles/r02_gemm256p_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel and shape; bytes per launch, FETCH_SIZE x2 per the gfx950 note)",
             "kernel_us": round(kernel_s * 1e6, 3),
+            "kernel_us_per_launch": per_launch,
             "peak_from_device": round(info["compute_units"] * 4096 * info["clock_mhz"] * 1e6 / 1e12, 1),
         },
     }

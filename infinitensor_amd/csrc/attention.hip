@@ -19,6 +19,7 @@
 //     optional causal masking (bottom-right aligned: key > query + Sk - Sq -> -inf). Keys past Sk are -inf. Fully masked rows produce 0.
 //   * scale comes from device memory (the graph's scalar constant), multiply or divide — the launch stays capturable.
 #include "gemm_common.h"
+#include <cstdlib>
 
 namespace irocm {
 
@@ -388,7 +389,11 @@ extern "C" int infini_rocm_attention_ex(infiniRocmRuntime_t rt, int dtype, const
     p.o_heads = (int)heads;
     p.mask_rows = (mask && mask_2d) ? (int)seq_q : 0;
     const bool bf = dtype == INFINI_DT_BF16;
-    if (head_dim == 64)
+    if (head_dim == 64) {
+        static const int nt_env = getenv("IROCM_ATTN_NT") ? atoi(getenv("IROCM_ATTN_NT")) : 0; // tuning hook
+        if (nt_env == 2)
+            return bf ? launch_attn<Bf16Traits, 64, 2>(rt, p) : launch_attn<F16Traits, 64, 2>(rt, p);
         return bf ? launch_attn<Bf16Traits, 64, 4>(rt, p) : launch_attn<F16Traits, 64, 4>(rt, p);
+    }
     return bf ? launch_attn<Bf16Traits, 128, 2>(rt, p) : launch_attn<F16Traits, 128, 2>(rt, p);
 }

@@ -157,7 +157,11 @@ def test_matmul_fp32(rt, shape, ta, tb):
     c = ops.matmul(rt, dev(a), dev(bm), None, ta, tb)
     want = R.matmul(a, bm, None, ta, tb)
     got = host(c)
-    assert np.allclose(got, want, rtol=1e-4, atol=1e-4 * np.sqrt(k) * 0.1)
+    # north_star: fp32 within 1e-4 RELATIVE of the CPU oracle — asserted as a pure relative bound wherever |c| >= 1 ...
+    big = np.abs(want) >= 1.0
+    assert (np.abs(got - want)[big] <= 1e-4 * np.abs(want)[big]).all(), np.abs((got - want)[big] / want[big]).max()
+    # ... and near zero (cancellation: |c| < 1 while sum |a b| ~ k / 3) as a small absolute bound
+    assert (np.abs(got - want)[~big] <= 2e-5).all(), np.abs((got - want)[~big]).max()
 
 
 def test_matmul_bias_broadcast_forms(rt):

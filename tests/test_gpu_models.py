@@ -266,3 +266,70 @@ def test_resnet50_bs128_full_size_properties(plugin_backend):
     scale = np.abs(a1).max()
     assert np.abs(a1[pick] - b1).max() <= 2e-2 * scale, (np.abs(a1[pick] - b1).max(), scale)
     assert (a1[pick].argmax(1) == b1.argmax(1)).all()
+
+
+def test_bert_base_one_full_width_layer_vs_oracle(plugin_backend):
+    """BASELINE config 4 at FULL width — hidden 768, 12 heads of 64, FFN 3072, seq 512 — one encoder layer, batch 1,
+    through the reference executor on Device::ROCM (fused attention, head-split GEMMs, Add->LayerNorm, persistent GEMM
+    tiles of 192 columns for N = 768) against the fp64 oracle: the shapes every kernel of the BERT-base bench runs at."""
+    from model_bench import Builder, build_bert
+
+    B = plugin_backend
+    batch, seq, layers, hidden, heads, ffn, vocab = 1, 512, 1, 768, 12, 3072, 2000
+    rocm = B.RocmRuntime(0)
+    for dtype, tol in (("f16", 3e-2), ("f32", 1e-4)):
+        bl = Builder(B, rocm, dtype, seed=5)
+        out = build_bert(bl, batch, seq, layers, hidden, heads, ffn, vocab)
+        m = np.zeros((batch, 1, 1, seq), bl.np)
+        m[0, 0, 0, -40:] = -1e4
+        bl.feeds[3] = (bl.feeds[3][0], m)
+        bl.finish()
+        bl.h.run()
+        got = out.copyout_numpy().astype(np.float64).reshape(batch, seq, hidden)
+        want = _bert_oracle(bl.feeds, batch, seq, layers, hidden, heads)
+        scale = np.abs(want).max()
+        assert np.isfinite(got).all()
+        assert np.abs(got - want).max() <= tol * scale, (dtype, np.abs(got - want).max(), scale)
+
+
+@pytest.mark.parametrize("layer", ["stem", "bottleneck56"])
+def test_resnet50_full_size_layers_vs_oracle(rt, layer):
+    """BASELINE config 3 at FULL spatial size, N = 2: the 7x7/2 stem on 224x224 (+ bias + ReLU) and one 56x56 bottleneck
+    (1x1 64->64, 3x3 64->64, 1x1 64->256, each + bias + ReLU, the residual join) through the C ABI in f16 against the
+    fp64 oracle (the end-to-end ResNet test compares with the reference CPU backend at 32x32 only)."""
+    import torch
+
+    from infinitensor_amd import ops
+    from oracle import ref_ops as R
+
+    rng = np.random.default_rng(11)
+    h16 = lambda a: torch.from_numpy(a.astype(np.float16)).cuda()
+    r16 = lambda a: a.astype(np.float16).astype(np.float64)
+    if layer == "stem":
+        x = rng.random((2, 3, 224, 224)).astype(np.float32)
+        w = (rng.standard_normal((64, 3, 7, 7)) * np.sqrt(2 / 147)).astype(np.float32)
+        b = (rng.standard_normal(64) * 0.1).astype(np.float32)
+        y = ops.conv2d(rt, h16(x), h16(w), 3, 3, 2, 2, bias=h16(b), act=1)
+        want = np.maximum(R.conv2d(r16(x), r16(w), 3, 3, 2, 2, 1, 1) + r16(b).reshape(1, 64, 1, 1), 0)
+        got = y.float().cpu().numpy().astype(np.float64)
+        assert got.shape == want.shape == (2, 64, 112, 112)
+        assert np.allclose(got, want, rtol=3e-3, atol=3e-3), np.abs(got - want).max()
+        return
+    x = rng.standard_normal((2, 256, 56, 56)).astype(np.float32)
+    shapes = [(64, 256, 1), (64, 64, 3), (256, 64, 1)]
+    ws = [(rng.standard_normal((f, c, k, k)) * np.sqrt(2 / (c * k * k))).astype(np.float32) for f, c, k in shapes]
+    bs = [(rng.standard_normal(f) * 0.1).astype(np.float32) for f, _, _ in shapes]
+    t = h16(x)
+    ref = r16(x)
+    for i, ((f, c, k), w, b) in enumerate(zip(shapes, ws, bs)):
+        last = i == 2
+        t = ops.conv2d(rt, t, h16(w), k // 2, k // 2, 1, 1, bias=h16(b), act=0 if last else 1)
+        ref = R.conv2d(ref, r16(w), k // 2, k // 2, 1, 1, 1, 1) + r16(b).reshape(1, f, 1, 1)
+        if not last:
+            ref = np.maximum(ref, 0)
+        ref = ref.astype(np.float16).astype(np.float64)  # every operator stores f16
+    out = ops.unary(rt, "relu", ops.binary(rt, "add", t, h16(x)))
+    want = np.maximum((ref + r16(x)).astype(np.float16).astype(np.float64), 0)
+    got = out.float().cpu().numpy().astype(np.float64)
+    assert got.shape == want.shape == (2, 256, 56, 56)
+    assert np.allclose(got, want, rtol=4e-3, atol=8e-3), np.abs(got - want).max()

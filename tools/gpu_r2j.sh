@@ -1,0 +1,10 @@
+#!/bin/bash
+# round-2 final visit: everything gpu_round.sh does + the PMC passes of the persistent GEMM and the patch conv
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+rm -rf gpurun_out/round gpurun_out/prof_models
+bash tools/gpu_round.sh > gpurun_out/round_stdout.log 2>&1
+tail -14 gpurun_out/round_stdout.log | cut -c1-1500
+bash tools/profile_gemm.sh 4 > gpurun_out/prof_gemm.log 2>&1; tail -3 gpurun_out/prof_gemm.log | cut -c1-1200
+bash tools/profile_cmd.sh conv_patch patch -- python tools/conv_bench.py --layers 16 --variants=-1 --iters 5 > gpurun_out/prof_patch.log 2>&1; tail -12 gpurun_out/prof_patch.log
+timeout 200 python tools/conv_bench.py --variants=-1 --iters 20 > gpurun_out/conv_layers.log 2>&1; tail -3 gpurun_out/conv_layers.log
