@@ -391,6 +391,12 @@ int infini_rocm_batch_norm(infiniRocmRuntime_t rt, int dtype, const void *x, con
 /* MaxPool / AveragePool 2-D, NCHW (reference: poolingCudnn, src/kernels/cuda/pooling.cc:6-95;      */
 /*   output size src/operators/pooling.cc:17-35). kind: 0 max, 1 average. Average divides by kh*kw   */
 /*   (COUNT_INCLUDE_PADDING, pooling.cc:86-90); max ignores padding. Dilation is honoured (ONNX);     */
+/* LRN across channels, ONNX semantics (reference operator src/operators/lrn.cc; its only kernel is Cambricon's,
+ * src/kernels/bang/lrn.cc:6-56, and no test pins values: the oracle is the ONNX definition). x, y: [n, c, inner];
+ * y = x / (bias + alpha / size * sum of x^2 over channels [c - floor((size-1)/2), c + ceil((size-1)/2)])^beta. f32/f16/bf16. */
+int infini_rocm_lrn(infiniRocmRuntime_t rt, int dtype, const void *x, void *y, int64_t n, int64_t c, int64_t inner,
+                    int size, float alpha, float beta, float bias);
+
 /*   cuDNN ignores it.                                                                               */
 int infini_rocm_pool2d(infiniRocmRuntime_t rt, int kind, int dtype, const void *x, void *y, int64_t n,
                        int64_t c, int64_t h, int64_t w, int kh, int kw, int dh, int dw, int ph, int pw,

@@ -284,6 +284,34 @@ __global__ __launch_bounds__(256) void global_avgpool_kernel(const T *__restrict
         LdSt<T>::st(y + plane, s / (float)hw);
 }
 
+// ---- LRN across channels (ONNX LRN; reference operator: src/operators/lrn.cc, only a Cambricon kernel exists,
+// src/kernels/bang/lrn.cc:6-56): y[n,c,p] = x[n,c,p] / (bias + alpha / size * sum_{i in window(c)} x[n,i,p]^2)^beta,
+// window(c) = [c - floor((size-1)/2), c + ceil((size-1)/2)] clipped to [0, C). One thread per (n, 4 consecutive pixels)
+// walks the channels with the window's squares in a running fp32 sum that is RE-SUMMED (not slid) every step: exact and
+// order-stable; the re-reads of the window hit L1 / L2 (neighbouring threads share the lines). HBM-bound.
+template <typename T>
+__global__ __launch_bounds__(256) void lrn_kernel(const T *__restrict__ x, T *__restrict__ y, long n, int c, long inner, int size,
+                                                  float alpha_over_size, float beta, float bias) {
+    const int lo = (size - 1) / 2, hi = size - 1 - lo;
+    const long total = n * inner;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long img = i / inner, pix = i - img * inner;
+        const T *xp = x + img * c * inner + pix;
+        T *yp = y + img * c * inner + pix;
+        for (int ch = 0; ch < c; ++ch) {
+            const int a = ch - lo < 0 ? 0 : ch - lo, b = ch + hi >= c ? c - 1 : ch + hi;
+            float sq = 0.f;
+            for (int k = a; k <= b; ++k) {
+                const float v = LdSt<T>::ld(xp + (long)k * inner);
+                sq = fmaf(v, v, sq);
+            }
+            const float d = fmaf(alpha_over_size, sq, bias);
+            // d^-beta = exp2(-beta * log2 d); d > 0 for every legal attribute set (bias > 0 or data != 0)
+            LdSt<T>::st(yp + (long)ch * inner, LdSt<T>::ld(xp + (long)ch * inner) * exp2f(-beta * log2f(d)));
+        }
+    }
+}
+
 } // namespace irocm
 
 using namespace irocm;
@@ -332,6 +360,30 @@ int infini_rocm_batch_norm(infiniRocmRuntime_t rt, int dtype, const void *x, con
     }
 #undef GO
     IROCM_LAUNCH_CHECK("batch_norm");
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_lrn(infiniRocmRuntime_t rt, int dtype, const void *x, void *y, int64_t n, int64_t c, int64_t inner,
+                    int size, float alpha, float beta, float bias) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(n >= 0 && c > 0 && inner >= 0 && c < (1ll << 31), "lrn: bad extent");
+    IROCM_CHECK_ARG(size >= 1, "lrn: size must be >= 1");
+    if (n == 0 || inner == 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(x && y, "lrn: NULL tensor");
+    long g = ceil_div(n * inner, 256);
+    if (g > (long)rt->num_cu * 32) g = (long)rt->num_cu * 32;
+#define GO(T)                                                                                      \
+    hipLaunchKernelGGL((lrn_kernel<T>), dim3((unsigned)g), dim3(256), 0, rt->stream, (const T *)x, (T *)y, (long)n, (int)c,   \
+                       (long)inner, size, alpha / (float)size, beta, bias)
+    switch (dtype) {
+    case INFINI_DT_F32: GO(float); break;
+    case INFINI_DT_F16: GO(__half); break;
+    case INFINI_DT_BF16: GO(__hip_bfloat16); break;
+    default: IROCM_FAIL(INFINI_ROCM_UNSUPPORTED, "lrn: unsupported dtype %s", dtype_name(dtype));
+    }
+#undef GO
+    IROCM_LAUNCH_CHECK("lrn");
     return INFINI_ROCM_OK;
 }
 

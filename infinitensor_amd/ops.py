@@ -163,6 +163,20 @@ def set_matmul_variant(rt: RocmRuntime, variant: int) -> None:
     check(lib().infini_rocm_matmul_set_variant(rt.handle, int(variant)))
 
 
+def lrn(rt: RocmRuntime, x: torch.Tensor, size: int, alpha: float = 1e-4, beta: float = 0.75, bias: float = 1.0,
+        out: torch.Tensor | None = None) -> torch.Tensor:
+    """ONNX LRN across dim 1 of x [N, C, ...] (operators/lrn.h)."""
+    if x.dim() < 2:
+        raise ValueError("lrn expects [N, C, ...]")
+    if out is None:
+        out = torch.empty_like(x)
+    n, c = x.shape[0], x.shape[1]
+    inner = x.numel() // max(1, n * c)
+    check(lib().infini_rocm_lrn(rt.handle, dtype_of(x), _ptr(x), _ptr(out), n, c, inner, int(size), float(alpha), float(beta),
+                                float(bias)))
+    return out
+
+
 def set_conv_const_weights(rt: RocmRuntime, on: bool) -> None:
     """While on, conv2d treats its weights as constant data and caches their re-packed image (infini_rocm.h)."""
     check(lib().infini_rocm_conv2d_set_const_weights(rt.handle, 1 if on else 0))

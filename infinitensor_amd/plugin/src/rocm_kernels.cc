@@ -16,6 +16,7 @@
 #include "operators/extend.h"
 #include "operators/gather.h"
 #include "operators/layer_norm.h"
+#include "operators/lrn.h"
 #include "operators/matmul.h"
 #include "operators/pad.h"
 #include "operators/pooling.h"
@@ -225,6 +226,19 @@ class ConvTransposed2dRocm : public RocmKernelWithoutConfig {
     }
 };
 REGISTER_KERNEL(Device::ROCM, OpType::ConvTranspose, ConvTransposed2dRocm, "ConvTranspose_Direct_ROCM");
+
+// ---- LRN (ONNX semantics; the reference has the operator and a Cambricon kernel only, src/kernels/bang/lrn.cc) --------
+class LRNRocm : public RocmKernelWithoutConfig {
+    void compute(const Operator &_op, const RuntimeObj *ctx) const override {
+        auto op = as<LRNObj>(_op);
+        const auto &d = op->getInputs(0)->getDims();
+        IT_ASSERT(d.size() >= 2, "LRN expects [N, C, ...]");
+        const auto [alpha, beta, bias] = op->getAlphaBetaBias();
+        ROCM_CALL(infini_rocm_lrn(H(ctx), DTI(op->getInputs(0)), P(op->getInputs(0)), P(op->getOutput()), d[0], d[1],
+                                  prod(d, 2, d.size()), op->getSize(), alpha, beta, bias));
+    }
+};
+REGISTER_KERNEL(Device::ROCM, OpType::LRN, LRNRocm, "LRN_ROCM");
 
 // ---- Softmax / LayerNorm / RMSNorm ------------------------------------------------------------------
 class SoftmaxRocm : public RocmKernelWithoutConfig {

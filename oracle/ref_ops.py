@@ -389,6 +389,21 @@ def rope(pos: np.ndarray, x: np.ndarray, dim_head: int, theta: float = 10000.0) 
     return X * np.cos(ang) + rot * np.sin(ang)
 
 
+# LRN across channels — ONNX LRN-13 (reference operator: src/operators/lrn.cc; front-end onnx.py:1101-1115 passes alpha, beta,
+# bias, size through; the only kernel in the reference is Cambricon's cnnlLrn_v2, src/kernels/bang/lrn.cc:6-56, and no reference
+# test asserts LRN values: PARITY UNPINNED for this op — the oracle is the ONNX operator definition).
+def lrn(x: np.ndarray, size: int, alpha: float = 1e-4, beta: float = 0.75, bias: float = 1.0) -> np.ndarray:
+    X = np.asarray(x, dtype=np.float64)
+    C = X.shape[1]
+    sq = X * X
+    out = np.empty_like(X)
+    lo, hi = (size - 1) // 2, size - 1 - (size - 1) // 2
+    for c in range(C):
+        a, b = max(0, c - lo), min(C - 1, c + hi)
+        out[:, c] = X[:, c] / (bias + alpha / size * sq[:, a:b + 1].sum(axis=1)) ** beta
+    return out
+
+
 # Scaled-dot-product attention = the unfused chain MatMul -> Div/Mul -> (+mask) -> Softmax -> MatMul
 def attention(q, k, v, scale: float, mask=None, causal: bool = False) -> np.ndarray:
     Q, K, V = (np.asarray(t, dtype=np.float64) for t in (q, k, v))

@@ -133,6 +133,23 @@ def test_conv_s1_vs_oracle_and_generic_kernel(rt, cfg, dt):
     assert np.allclose(host(y), host(yg), rtol=tol, atol=tol)
 
 
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+def test_lrn_vs_oracle(rt, dt):
+    """ONNX LRN across channels: hand-computed case + random shapes vs the oracle (window clipped at both channel ends,
+    odd and even sizes, size > C)."""
+    x = np.array([1.0, 2.0, 3.0], np.float32).reshape(1, 3, 1, 1)
+    y = host(ops.lrn(rt, dev(x, TD[dt]), 3, alpha=3.0, beta=1.0, bias=1.0))
+    # windows {1,2}, {1,2,3}, {2,3}: 1 / (1 + 5), 2 / (1 + 14), 3 / (1 + 13)
+    tol = {"f32": 1e-6, "f16": 1e-3, "bf16": 8e-3}[dt]
+    assert np.allclose(y.ravel(), [1 / 6, 2 / 15, 3 / 14], rtol=tol, atol=tol)
+    rng = np.random.default_rng(4)
+    for shape, size in (((2, 7, 3, 5), 5), ((1, 16, 9), 4), ((3, 2, 4, 4), 9), ((2, 96, 13, 13), 5)):
+        xs = (rng.standard_normal(shape) * 2).astype(np.float32)
+        got = host(ops.lrn(rt, dev(xs, TD[dt]), size, alpha=1e-2, beta=0.75, bias=2.0))
+        want = R.lrn(R.round_to(xs, dt), size, 1e-2, 0.75, 2.0)
+        assert np.allclose(got, want, rtol=max(tol, 2e-6) * 4, atol=max(tol, 2e-6) * 4)
+
+
 def test_conv_packed_weight_cache(rt):
     """Constant weights are re-packed ONCE (runtime-owned image keyed by pointer / shape), reused by eager calls and by a
     captured graph (packed on a side stream while the runtime stream records: no pack node in the graph), and dropped

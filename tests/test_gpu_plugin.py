@@ -252,8 +252,8 @@ def test_missing_kernel_is_a_loud_error(B, rocm):
     h = B.GraphHandler(rocm)
     x = h.tensor([2, 3, 4, 4], F32)
     h.resize(x, None, None, h.tensor([4], I64), None, None, [2, 3, 8, 8], "nearest", "floor", "half_pixel") if False else None
-    # LRN has no ROCM kernel registered: running it must raise, not silently fall back
-    y = h.lrn(x, None, 0.1, 0.75, 1.0, 3)
+    # InstanceNormalization has no ROCM kernel registered: running it must raise, not silently fall back
+    y = h.instanceNormalization(x, None, h.tensor([3], F32), h.tensor([3], F32), 1e-5)
     h.data_malloc()
     put(x, np.ones((2, 3, 4, 4), np.float32))
     with pytest.raises(RuntimeError):
@@ -895,14 +895,14 @@ def test_hipgraph_two_runtimes_run_concurrently(B):
 
 def test_hipgraph_recovers_after_capture_failure(B):
     """test_cudagraph.cc:281-304: a graph whose operator cannot be launched (the reference registers a kernel that
-    synchronises inside capture; here LRN, which has no Device::ROCM kernel, throws inside the capture) fails loudly,
+    synchronises inside capture; here InstanceNormalization, which has no Device::ROCM kernel, throws inside the capture) fails loudly,
     leaves the cache and the stream usable, and an earlier capture still replays."""
     rt = B.RocmRuntime(0)
     valid = _GraphFixture(B, rt, 2)
     valid.run(_inc(2))
     h = B.GraphHandler(rt)
     x = h.tensor([2, 3, 4, 4], F32)
-    h.lrn(x, None, 0.1, 0.75, 1.0, 3)
+    h.instanceNormalization(x, None, h.tensor([3], F32), h.tensor([3], F32), 1e-5)
     h.data_malloc()
     put(x, np.ones((2, 3, 4, 4), np.float32))
     with pytest.raises(RuntimeError):
@@ -991,3 +991,17 @@ def test_conv_weights_are_packed_once_and_repacked_after_copyin(B):
     put(tx, x)
     h.run()
     assert np.allclose(get(out).astype(np.float64).reshape(want2.shape), want2, rtol=3e-3, atol=3e-3)
+
+
+@pytest.mark.parametrize("code,npdt,tol", [(F32, np.float32, 1e-5), (F16, np.float16, 2e-3)])
+def test_lrn_through_reference_executor(B, rocm, code, npdt, tol):
+    """h.lrn on Device::ROCM (ONNX LRN semantics; the reference ships the operator, the ONNX import / export of its four
+    attributes — pyinfinitensor/tests/test_onnxstub.py:407-428 — and a Cambricon kernel only) vs the oracle, AlexNet-style
+    attributes and an even window."""
+    rng = np.random.default_rng(9)
+    x = (rng.standard_normal((2, 11, 5, 7)) * 3).astype(npdt)
+    for size, alpha, beta, bias in ((5, 1e-4, 0.75, 2.0), (4, 0.5, 0.5, 1.0), (1, 2.0, 1.0, 0.5), (31, 1e-2, 0.75, 1.0)):
+        h, out = build(B, rocm, lambda hd, t: hd.lrn(t[0], None, alpha, beta, bias, size), [(x.shape, code, x)])
+        h.run()
+        want = R.lrn(x.astype(np.float64), size, alpha, beta, bias)
+        assert np.allclose(get(out).astype(np.float64).reshape(want.shape), want, rtol=tol, atol=tol), (size, alpha)

@@ -195,3 +195,14 @@ def test_conv_transpose_kats():
     assert eq(y.ravel(), kat(CT, 87, "float"))
     y = R.conv_transpose2d(R.incremental((1, 2, 3, 3)), R.incremental((2, 2, 3, 3)))
     assert eq(y.ravel(), kat(CT, 129, "float"))
+
+
+def test_lrn_oracle_definition():
+    """LRN: no reference test asserts values (parity unpinned; oracle/ref_ops.py says so) — the restatement is checked
+    against the ONNX definition worked by hand: windows clipped at the channel ends, even sizes extend one further up."""
+    x = np.array([1.0, 2.0, 3.0, 4.0]).reshape(1, 4, 1, 1)
+    y = R.lrn(x, 3, alpha=3.0, beta=1.0, bias=1.0).ravel()
+    assert np.allclose(y, [1 / (1 + 5), 2 / (1 + 14), 3 / (1 + 29), 4 / (1 + 25)])
+    y = R.lrn(x, 2, alpha=2.0, beta=0.5, bias=0.0).ravel()  # window [c, c + 1]
+    assert np.allclose(y, [1 / np.sqrt(5), 2 / np.sqrt(13), 3 / np.sqrt(25), 4 / np.sqrt(16)])
+    assert np.allclose(R.lrn(x, 1, alpha=1.0, beta=1.0, bias=0.0).ravel(), 1 / x.ravel())
