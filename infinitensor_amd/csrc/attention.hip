@@ -15,11 +15,11 @@
 //     so the row statistics, the rescale of O and the final 1/l are per-lane scalars and P never touches LDS.
 //   * K / V tiles: register-staged double buffering (global loads of tile t+1 fly during the MFMAs of tile t), LDS images
 //     padded to conflict-free pitches (K: D*2 + 16 B for ds_read_b128, V: D*2 + 32 B for the transpose reads).
-//   * mask: additive, one value per (batch-group, key) broadcast over the query rows (the BERT [B,1,1,S] padding mask);
+//   * mask: additive, one value per (batch-group, key) broadcast over the query rows (the BERT [B,1,1,S] padding mask) —
+//     its 64 values per key tile ride with the K / V tile into LDS as fp32 (x log2 e, -inf past Sk);
 //     optional causal masking (bottom-right aligned: key > query + Sk - Sq -> -inf). Keys past Sk are -inf. Fully masked rows produce 0.
 //   * scale comes from device memory (the graph's scalar constant), multiply or divide — the launch stays capturable.
 #include "gemm_common.h"
-#include <cstdlib>
 
 namespace irocm {
 
@@ -41,7 +41,7 @@ __device__ static inline float fast_exp2(float x) { return __builtin_amdgcn_exp2
 
 // CAUSAL / MASK are compile-time so that the unmasked, non-causal sweep carries no select / compare per score.
 template <typename Tr, int D, int NT, bool CAUSAL, int MASK> // MASK: 0 none, 1 per key, 2 per (query, key)
-__global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, (NT == 2 && D == 64) ? 3 : 2) void attention_kernel(AttnArgs p) {
     constexpr int QW = NT * 16;              // query rows per wave
     constexpr int KT = 64;                   // keys per tile
     constexpr int KP = D * 2 + 16;           // K image pitch (bytes)
@@ -90,6 +90,13 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
         st_col[i] = (ch % (D / 8)) * 8;
     }
     s16x8_t kreg[NCH], vreg[NCH];
+    // MASK == 1 (one additive value per key): the tile's 64 values travel with the K / V tile — wave 0 fetches them with the
+    // next tile's operands and leaves them in LDS as fp32, already times log2 e and -inf past Sk, so a tile reads its 16
+    // values per lane with four ds_read_b128 and spends no global load, convert or compare on the mask. (A load issued
+    // inside the tile is waited for with vmcnt(0) right after the S product — hipcc cannot count across the branches of a
+    // guarded load — and that wait also drains the K / V prefetch: the masked BERT shape ran 61 us against 53 us unmasked.)
+    unsigned short mreg = 0;
+    int mkey = 0;
     auto load_tile = [&](int kbase) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
@@ -98,14 +105,25 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
             kreg[i] = *(const s16x8_t *)(K + (long)kr * D + st_col[i]);
             vreg[i] = *(const s16x8_t *)(V + (long)kr * D + st_col[i]);
         }
+        if constexpr (MASK == 1) {
+            if (t < KT) {
+                mkey = kbase + t;
+                mreg = M[mkey < p.sk ? mkey : p.sk - 1];
+            }
+        }
     };
-    auto store_tile = [&](char *stage) {
+    auto store_tile = [&](char *stage, float *mstrip) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             *(s16x8_t *)(stage + st_row[i] * KP + st_col[i] * 2) = kreg[i];
             *(s16x8_t *)(stage + K_BYTES + st_row[i] * VP + st_col[i] * 2) = vreg[i];
         }
+        if constexpr (MASK == 1) {
+            if (t < KT)
+                mstrip[t] = mkey < p.sk ? Tr::to_f32(mreg) * LOG2E : -INFINITY;
+        }
     };
+    float *const mstrips = (float *)(smem + 2 * STAGE); // 2 x KT floats (MASK == 1 only)
 
     f32x4 o[DT][NT];
 #pragma unroll
@@ -128,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     }
 
     load_tile(0);
-    store_tile(smem);
+    store_tile(smem, mstrips);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const char *cur = smem + (kt & 1) * STAGE;
@@ -186,28 +204,15 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
                 }
             }
         } else if constexpr (MASK == 1) {
-            const bool mvec = !ragged && mask_vec; // 4 consecutive keys = one 8-byte load
+            const float *mstrip = mstrips + (kt & 1) * KT;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                const int key = kbase + mt * 16 + 4 * g4;
-                unsigned short mh[4] = {0, 0, 0, 0};
-                if (mvec) {
-                    const u32x2_t mk = *(const u32x2_t *)(M + key);
-                    mh[0] = (unsigned short)(mk[0] & 0xffff); mh[1] = (unsigned short)(mk[0] >> 16);
-                    mh[2] = (unsigned short)(mk[1] & 0xffff); mh[3] = (unsigned short)(mk[1] >> 16);
-                } else {
+                const f32x4 mv = *(const f32x4 *)(mstrip + mt * 16 + 4 * g4);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (key + r < p.sk)
-                            mh[r] = M[key + r];
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float mv = key + r < p.sk ? Tr::to_f32(mh[r]) * LOG2E : -INFINITY;
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        s[mt][nt][r] = fmaf(s[mt][nt][r], c, mv);
-                }
+                        s[mt][nt][r] = fmaf(s[mt][nt][r], c, mv[r]);
             }
         } else {
 #pragma unroll
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
                     o[dt][nt] = Tr::mfma(vf, pf[nt][kk], o[dt][nt]);
             }
         if (kt + 1 < nkt)
-            store_tile(smem + ((kt + 1) & 1) * STAGE);
+            store_tile(smem + ((kt + 1) & 1) * STAGE, mstrips + ((kt + 1) & 1) * KT);
         __syncthreads();
     }
 
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
 
 template <typename Tr, int D, int NT, bool CAUSAL, int MASK>
 static int launch_attn2(infiniRocmRuntime_t rt, const AttnArgs &p) {
-    constexpr int LDS = 2 * (64 * (D * 2 + 16) + 64 * (D * 2 + 32));
+    constexpr int LDS = 2 * (64 * (D * 2 + 16) + 64 * (D * 2 + 32)) + (MASK == 1 ? 2 * 64 * 4 : 0);
     auto kern = attention_kernel<Tr, D, NT, CAUSAL, MASK>;
     IROCM_LDS_ATTR(kern, LDS, rt);
     dim3 grid((unsigned)ceil_div(p.sq, 4 * NT * 16), (unsigned)p.bh);
@@ -389,11 +394,11 @@ extern "C" int infini_rocm_attention_ex(infiniRocmRuntime_t rt, int dtype, const
     p.o_heads = (int)heads;
     p.mask_rows = (mask && mask_2d) ? (int)seq_q : 0;
     const bool bf = dtype == INFINI_DT_BF16;
-    if (head_dim == 64) {
-        static const int nt_env = getenv("IROCM_ATTN_NT") ? atoi(getenv("IROCM_ATTN_NT")) : 0; // tuning hook
-        if (nt_env == 2)
-            return bf ? launch_attn<Bf16Traits, 64, 2>(rt, p) : launch_attn<F16Traits, 64, 2>(rt, p);
-        return bf ? launch_attn<Bf16Traits, 64, 4>(rt, p) : launch_attn<F16Traits, 64, 4>(rt, p);
-    }
+    // NT = 2 (32 query rows per wave, 128 per workgroup) for both head sizes. At D = 64 that is 153-168 VGPRs = 3 waves per
+    // SIMD and, on BERT's 384 x 512 problem, 1536 workgroups = exactly two rounds of the chip's 768 slots; the 64-row
+    // variant (256 VGPRs, 2 waves per SIMD, 768 workgroups on 512 slots) measured 52.9 / 62.9 us (plain / masked) against
+    // 49.5 / 50.6 us for this one, and 171 vs 162 us at S = 2048.
+    if (head_dim == 64)
+        return bf ? launch_attn<Bf16Traits, 64, 2>(rt, p) : launch_attn<F16Traits, 64, 2>(rt, p);
     return bf ? launch_attn<Bf16Traits, 128, 2>(rt, p) : launch_attn<F16Traits, 128, 2>(rt, p);
 }

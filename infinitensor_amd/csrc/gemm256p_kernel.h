@@ -71,7 +71,7 @@ constexpr int kTraceSlots = 128;
 
 // TRACE: every wave stamps s_memtime at phase boundaries into a private LDS strip behind the K-tile buffers (no VMEM
 // traffic, so the vmcnt bookkeeping is untouched) and dumps the strip at the end — tools/gemm_timeline.py.
-template <typename Tr, bool A_KMAJOR, bool B_KMAJOR, int NT, bool TRACE = false>
+template <typename Tr, bool A_KMAJOR, bool B_KMAJOR, int NT, bool TRACE = false, bool GELU = false>
 __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     const GemmArgs &p = pa.g;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -296,7 +296,14 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
                 for (int r = 0; r < 4; ++r)
                     v[r] += Tr::to_f32(bp[(long)r * p.bias_n]);
             }
-            if (p.act) {
+            if constexpr (GELU) {
+                // act 5 as a compile-time epilogue: apply_act's run-time switch, unrolled over the tile's 128 values per
+                // lane, carries every activation's code (erff, tanhf ...) 128 times — an instruction stream far beyond
+                // the I-cache (measured: BERT's FFN1 +85 us per launch with the switch)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r] = gelu_erf_as(v[r]);
+            } else if (p.act) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     v[r] = apply_act(v[r], p.act);
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
                         float v = acc[i][j][r];
                         if (bias)
                             v += Tr::to_f32(bias[(long)ib * p.bias_b + (long)row * p.bias_m + (long)(col + r) * p.bias_n]);
-                        C[c_off(p, row, col + r)] = Tr::from_f32(apply_act(v, p.act));
+                        C[c_off(p, row, col + r)] = Tr::from_f32(GELU ? gelu_erf_as(v) : apply_act(v, p.act));
                     }
                 }
             }
@@ -484,6 +491,10 @@ static int launch_p(infiniRocmRuntime_t rt, GemmArgs g, bool akm, bool bkm, unsi
         if (!(akm && !bkm))
             IROCM_FAIL(INFINI_ROCM_UNSUPPORTED, "gemm timeline: NN layout only");
         IROCM_G256P(true, false);
+    } else if (g.act == 5 && akm && !bkm) { // MatMul -> Gelu fusion (rocm_fusion.cc): the ONNX "NN" layout only
+        auto kern = gemm256p_kernel<Tr, true, false, NT, false, true>;
+        IROCM_LDS_ATTR(kern, kLds, rt);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), kLds, rt->stream, pa);
     } else {
         if (akm && bkm) IROCM_G256P(true, true);
         else if (akm && !bkm) IROCM_G256P(true, false);

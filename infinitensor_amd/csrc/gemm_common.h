@@ -77,6 +77,20 @@ struct F16Traits {
     }
 };
 
+// Gelu (erf form, unary.cu) with erf by Abramowitz-Stegun 7.1.26 (abs error <= 1.5e-7, far below a 16-bit output's
+// rounding): ~18 VALU slots instead of erff's ~40, so it can ride in a GEMM epilogue. 1 +- erf is formed without
+// cancellation: 1 - erf(z) = poly(t) e^{-z^2}.
+__device__ static inline float gelu_erf_as(float v) {
+    const float z = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float q = fmaf(1.061405429f, t, -1.453152027f);
+    q = fmaf(q, t, 1.421413741f);
+    q = fmaf(q, t, -0.284496736f);
+    q = fmaf(q, t, 0.254829592f);
+    const float c = q * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z); // 1 - erf(z), z >= 0
+    return 0.5f * v * (v >= 0.f ? 2.0f - c : c);
+}
+
 // Fused epilogue activation (reference ActType: include/core/common.h — None/Relu/Sigmoid/Tanh).
 __device__ static inline float apply_act(float v, int act) {
     switch (act) {
@@ -84,18 +98,7 @@ __device__ static inline float apply_act(float v, int act) {
     case 2: return 1.f / (1.f + __expf(-v));
     case 3: return tanhf(v);
     case 4: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); // Gelu (erf form, unary.cu) — fusion only
-    case 5: { // Gelu (erf form) with erf by Abramowitz-Stegun 7.1.26 (abs error <= 1.5e-7, far below a 16-bit output's
-              // rounding): ~16 VALU slots instead of erff's ~40, so it can ride in a GEMM epilogue. 1 +- erf is formed
-              // without cancellation: 1 - erf(z) = poly(t) e^{-z^2}.
-        const float z = fabsf(v) * 0.70710678118654752440f;
-        const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-        float q = fmaf(1.061405429f, t, -1.453152027f);
-        q = fmaf(q, t, 1.421413741f);
-        q = fmaf(q, t, -0.284496736f);
-        q = fmaf(q, t, 0.254829592f);
-        const float c = q * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z); // 1 - erf(z), z >= 0
-        return 0.5f * v * (v >= 0.f ? 2.0f - c : c);
-    }
+    case 5: return gelu_erf_as(v);
     default: return v;
     }
 }

@@ -13,8 +13,7 @@
 //        take the bias: its input's storage was recycled for the output)
 //   MatMul(+bias) -> Reshape [B,S,H,D] -> Transpose(0,2,1,3)        =>  matmul_headsplit (the q / k / v head split in
 //        the GEMM epilogue; f16 / bf16)
-//   MatMul(+bias) -> Gelu (f16 / bf16)                              =>  matmul(act = 5)  [opt-in, INFINI_ROCM_FUSE_GELU=1:
-//        measured slower than GEMM + the memory-bound Gelu pass]
+//   MatMul(+bias) -> Gelu (f16 / bf16)                              =>  matmul(act = 5): Gelu in the GEMM epilogue
 //   MatMul | Transpose | element-wise | Softmax | LayerNorm | Gather -> Reshape-family copy
 //                                                                  =>  the producer writes into the copy's output
 //   MatMul(Q, K^T) [-> Div|Mul(scalar)] [-> Add(mask)] -> Softmax(last axis) -> MatMul(P, V)
@@ -35,6 +34,7 @@
 #include "core/perf_engine.h"
 #include "operators/conv.h"
 #include "rocm/rocm_perf.h"
+#include <cstdio>
 #include <cstdlib>
 #include <string>
 #include "operators/element_wise.h"
@@ -263,12 +263,14 @@ size_t RocmRuntimeObj::tryLaunchHeadSplit(const OpVec &ops, size_t i) const {
 }
 
 // MatMul(+bias) -> Gelu (BERT's FFN up-projection), f16 / bf16: the Gelu in the GEMM epilogue (act 5: erf by
-// Abramowitz-Stegun 7.1.26, ~20 VALU slots per element instead of erff's ~40). OPT-IN (INFINI_ROCM_FUSE_GELU=1): measured
-// on BERT-base bs32 seq512 it is SLOWER, 5.34 -> 5.68 ms — 50 M erf-class evaluations are ~40 us of pure VALU time on the
-// whole chip (an earlier erff version: +60 us), sitting exposed after the last K-tile, while the separate Gelu pass is a
-// 35 us memory-bound kernel. The erf form of Gelu is VALU-priced at about the cost of streaming the tensor once.
+// Abramowitz-Stegun 7.1.26, ~18 VALU slots per element instead of erff's ~40). On by default (INFINI_ROCM_FUSE_GELU=0: A/B
+// hook). BERT-base bs32 seq512: 5.07 -> 4.73 ms — the separate Gelu pass is a 36.7 us memory-bound kernel per layer, the
+// erf evaluations cost the persistent GEMM's store-bound epilogue ~9 us. (Round 1 measured this fusion SLOWER, 5.34 ->
+// 5.68 ms, and kept it opt-in: the epilogue selected the activation with a run-time switch that the unrolled tile epilogue
+// replicated 128 times, erff and tanhf included; the persistent kernel now has a compile-time Gelu instantiation,
+// gemm256p_kernel.h.)
 size_t RocmRuntimeObj::tryLaunchMatmulGelu(const OpVec &ops, size_t i) const {
-    static const bool enabled = std::getenv("INFINI_ROCM_FUSE_GELU") && std::atoi(std::getenv("INFINI_ROCM_FUSE_GELU")) == 1;
+    static const bool enabled = !(std::getenv("INFINI_ROCM_FUSE_GELU") && std::atoi(std::getenv("INFINI_ROCM_FUSE_GELU")) == 0);
     if (!enabled || i + 1 >= ops.size() || ops[i]->getOpType() != OpType::MatMul || ops[i + 1]->getOpType() != OpType::Gelu)
         return 0;
     const Tensor c = ops[i]->getOutput(), out = ops[i + 1]->getOutput();
@@ -375,8 +377,13 @@ size_t RocmRuntimeObj::tryLaunchFusedRules(const OpVec &ops, size_t i) const {
             cands.push_back(cur);
         }
         // longest chain whose output buffer is safe to write while the conv still reads its inputs
+        static const bool fusionLog = std::getenv("INFINI_ROCM_FUSION_LOG") != nullptr; // diagnostics: which chain each conv got
         for (auto it = cands.rbegin(); it != cands.rend(); ++it) {
             const Cand &c = *it;
+            if (fusionLog)
+                fprintf(stderr, "[fusion] conv#%zu [%d,%d,%d,%d]: chain %zu (bias %d res %d act %d) out-on-x %d out-on-w %d out-on-res %d\n", i,
+                        (int)od[0], (int)od[1], (int)od[2], (int)od[3], c.used, c.bias != nullptr, c.res != nullptr, c.act,
+                        (int)overlaps(c.last, x), (int)overlaps(c.last, w), (int)(c.res && overlaps(c.last, c.res)));
             // the residual is read at exactly the position that is written: it may be the output buffer itself
             const bool resHazard = c.res && overlaps(c.last, c.res) &&
                                    !(c.res->getRawDataPtr<void *>() == c.last->getRawDataPtr<void *>() &&

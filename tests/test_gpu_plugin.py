@@ -318,6 +318,38 @@ def test_fusion_is_invisible(B, rocm, code, npdt):
         assert np.allclose(got[True], want, rtol=4e-3, atol=4e-3)
 
 
+def test_matmul_gelu_fusion(B, rocm):
+    """MatMul(+bias) -> Gelu (BERT's FFN up-projection): one GEMM launch with the Gelu in its epilogue (rocm_fusion.cc,
+    gemm256p_kernel.h's compile-time instantiation at a persistent-kernel size, the run-time act elsewhere) vs two kernels
+    vs the fp64 oracle. f32 is not fused (the matcher is f16 / bf16 only)."""
+    rng = np.random.default_rng(33)
+    for (m, k, n) in ((1024, 256, 1536), (96, 64, 80)):
+        ins = [((m, k), F16, (rng.standard_normal((m, k)) * 1.5).astype(np.float16)),
+               ((k, n), F16, (rng.standard_normal((k, n)) / 8).astype(np.float16)),
+               ((n,), F16, rng.standard_normal((n,)).astype(np.float16))]
+        def fn(h, t):
+            for x in t:  # weights live outside the planner's recycled arena: the Gelu output cannot land on a dead operand
+                x.set_weight()  # (in which case the matcher rightly refuses: the GEMM would overwrite what it still reads)
+            return h.gelu(h.matmul(t[0], t[1], None, False, False, t[2], B.ActType.Linear, "default"), None)
+
+        got = {}
+        try:
+            for on in (True, False):
+                rocm.set_fusion(on)
+                h, out = build(B, rocm, fn, ins)
+                before = rocm.fused_launch_count()
+                h.run()
+                assert (rocm.fused_launch_count() - before == 1) == on
+                got[on] = get(out).astype(np.float64)
+        finally:
+            rocm.set_fusion(True)
+        a, w, bias = [x.astype(np.float64) for _, _, x in ins]
+        want = R.unary("gelu", a @ w + bias)
+        assert np.abs(a @ w + bias).max() > 6  # both tails of erf
+        assert np.allclose(got[True], want, rtol=2e-3, atol=2e-3)
+        assert np.allclose(got[True], got[False], rtol=2e-3, atol=2e-3)
+
+
 def test_fusion_keeps_tensors_that_someone_else_reads(B, rocm):
     """The conv output feeds the bias-add AND a second consumer: it must be materialised (no fusion across it)."""
     rng = np.random.default_rng(12)
