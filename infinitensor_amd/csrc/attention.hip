@@ -16,7 +16,8 @@
 //   * K / V tiles: register-staged double buffering (global loads of tile t+1 fly during the MFMAs of tile t), LDS images
 //     padded to conflict-free pitches (K: D*2 + 16 B for ds_read_b128, V: D*2 + 32 B for the transpose reads).
 //   * mask: additive, one value per (batch-group, key) broadcast over the query rows (the BERT [B,1,1,S] padding mask) —
-//     its 64 values per key tile ride with the K / V tile into LDS as fp32 (x log2 e, -inf past Sk);
+//     its 64 values per key tile ride with the K / V tile into LDS as fp32 (/ scale, -inf past Sk) and enter the score
+//     MFMAs as their C operand; the scale itself is applied inside the exponent's fma;
 //     optional causal masking (bottom-right aligned: key > query + Sk - Sq -> -inf). Keys past Sk are -inf. Fully masked rows produce 0.
 //   * scale comes from device memory (the graph's scalar constant), multiply or divide — the launch stays capturable.
 #include "gemm_common.h"
@@ -67,7 +68,13 @@ __global__ __launch_bounds__(256, (NT == 2 && D == 64) ? 3 : 2) void attention_k
         scale = p.scale_is_div ? 1.0f / sv : sv;
     }
     constexpr float LOG2E = 1.4426950408889634f;
-    const float c = scale * LOG2E;
+    // The scores stay in raw q.k units ("S' units") until the exponent: S' = K Q^T + mask / scale is what the MFMA chain
+    // produces (the additive term is its C operand), and P = exp2(S' c - m' c) is one fma per score. That needs c > 0 for
+    // the running maximum to commute with the scale: the sign of a negative scale goes into Q (exact), a zero scale zeroes Q.
+    const bool neg_q = scale < 0.f, zero_q = scale == 0.f;
+    const float sabs = zero_q ? 1.0f : fabsf(scale);
+    const float c = sabs * LOG2E;
+    const float inv_scale = 1.0f / sabs; // additive mask (natural-log units) -> S' units
     const bool mask_vec = MASK != 0 && (p.sk % 4 == 0) && ((((uintptr_t)p.mask) & 7) == 0);
 
     // Q fragments (B operand: lane = query column l15, 8 consecutive d)
@@ -80,6 +87,15 @@ __global__ __launch_bounds__(256, (NT == 2 && D == 64) ? 3 : 2) void attention_k
         for (int ks = 0; ks < KS; ++ks)
             qf[nt][ks] = *(const s16x8_t *)(Q + (long)qr * D + ks * 32 + g4 * 8);
     }
+    if (neg_q || zero_q) { // wave-uniform, never in a transformer graph (scale = 1 / sqrt(D))
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    qf[nt][ks][e] = zero_q ? (short)0 : (short)(qf[nt][ks][e] ^ (short)0x8000);
+    }
 
     // staging assignment
     int st_row[NCH], st_col[NCH];
@@ -90,13 +106,13 @@ __global__ __launch_bounds__(256, (NT == 2 && D == 64) ? 3 : 2) void attention_k
         st_col[i] = (ch % (D / 8)) * 8;
     }
     s16x8_t kreg[NCH], vreg[NCH];
-    // MASK == 1 (one additive value per key): the tile's 64 values travel with the K / V tile — wave 0 fetches them with the
-    // next tile's operands and leaves them in LDS as fp32, already times log2 e and -inf past Sk, so a tile reads its 16
-    // values per lane with four ds_read_b128 and spends no global load, convert or compare on the mask. (A load issued
-    // inside the tile is waited for with vmcnt(0) right after the S product — hipcc cannot count across the branches of a
-    // guarded load — and that wait also drains the K / V prefetch: the masked BERT shape ran 61 us against 53 us unmasked.)
+    // The additive term of a key tile — MASK == 1: mask[key] / scale, otherwise 0; -inf for keys past Sk — travels with the
+    // K / V tile: wave 0 fetches the mask values with the next tile's operands and leaves the 64 terms in LDS as fp32, and a
+    // tile reads its 16 per lane with four ds_read_b128 as the C operands of its first MFMAs: no global load, convert,
+    // compare or accumulator clear inside the tile. (A mask load issued inside the tile is waited for with vmcnt(0) right
+    // after the S product — hipcc cannot count across the branches of a guarded load — and that wait also drains the K / V
+    // prefetch: the masked BERT shape ran 61 us against 53 us unmasked.)
     unsigned short mreg = 0;
-    int mkey = 0;
     auto load_tile = [&](int kbase) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
@@ -106,24 +122,20 @@ __global__ __launch_bounds__(256, (NT == 2 && D == 64) ? 3 : 2) void attention_k
             vreg[i] = *(const s16x8_t *)(V + (long)kr * D + st_col[i]);
         }
         if constexpr (MASK == 1) {
-            if (t < KT) {
-                mkey = kbase + t;
-                mreg = M[mkey < p.sk ? mkey : p.sk - 1];
-            }
+            if (t < KT)
+                mreg = M[kbase + t < p.sk ? kbase + t : p.sk - 1];
         }
     };
-    auto store_tile = [&](char *stage, float *mstrip) {
+    auto store_tile = [&](char *stage, float *mstrip, int kbase) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             *(s16x8_t *)(stage + st_row[i] * KP + st_col[i] * 2) = kreg[i];
             *(s16x8_t *)(stage + K_BYTES + st_row[i] * VP + st_col[i] * 2) = vreg[i];
         }
-        if constexpr (MASK == 1) {
-            if (t < KT)
-                mstrip[t] = mkey < p.sk ? Tr::to_f32(mreg) * LOG2E : -INFINITY;
-        }
+        if (t < KT)
+            mstrip[t] = kbase + t < p.sk ? (MASK == 1 ? Tr::to_f32(mreg) * inv_scale : 0.f) : -INFINITY;
     };
-    float *const mstrips = (float *)(smem + 2 * STAGE); // 2 x KT floats (MASK == 1 only)
+    float *const mstrips = (float *)(smem + 2 * STAGE); // 2 x KT floats
 
     f32x4 o[DT][NT];
 #pragma unroll
@@ -131,7 +143,7 @@ __global__ __launch_bounds__(256, (NT == 2 && D == 64) ? 3 : 2) void attention_k
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
             o[dt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run[NT], l_run[NT]; // running max (log2 units, reduced over the 4 lanes of a column) and per-lane partial sum
+    float m_run[NT], l_run[NT]; // running max (S' units, reduced over the 4 lanes of a column) and per-lane partial sum
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         m_run[nt] = -INFINITY;
@@ -146,7 +158,7 @@ __global__ __launch_bounds__(256, (NT == 2 && D == 64) ? 3 : 2) void attention_k
     }
 
     load_tile(0);
-    store_tile(smem, mstrips);
+    store_tile(smem, mstrips, 0);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const char *cur = smem + (kt & 1) * STAGE;
@@ -154,7 +166,8 @@ __global__ __launch_bounds__(256, (NT == 2 && D == 64) ? 3 : 2) void attention_k
         if (kt + 1 < nkt)
             load_tile(kbase + KT);
 
-        // ---- S^T = K Q^T : 4 key sub-tiles x NT query tiles ------------------------------------------
+        // ---- S'^T = K Q^T + term : 4 key sub-tiles x NT query tiles (lane: query column l15, keys kbase + mt*16 + 4*g4 + r)
+        const float *mstrip = mstrips + (kt & 1) * KT;
         f32x4 s[4][NT];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
@@ -162,20 +175,19 @@ __global__ __launch_bounds__(256, (NT == 2 && D == 64) ? 3 : 2) void attention_k
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
                 kf[ks] = *(const s16x8_t *)(cur + (mt * 16 + l15) * KP + (ks * 32 + g4 * 8) * 2);
+            const f32x4 term = *(const f32x4 *)(mstrip + mt * 16 + 4 * g4);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                f32x4 a = term;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
                     a = Tr::mfma(kf[ks], qf[nt][ks], a);
                 s[mt][nt] = a;
             }
         }
-        // ---- scale, mask, online softmax (lane: query column l15, keys kbase + mt*16 + 4*g4 + r) -----
-        // additive term per key (mask * log2 e, -inf past Sk): only when there is a mask or this is the ragged last tile
-        const bool ragged = kbase + KT > p.sk; // wave-uniform
         if constexpr (MASK == 2) {
             // full additive mask: the lane's query column has its own mask row; 4 consecutive keys = one 8-byte load
+            const bool ragged = kbase + KT > p.sk; // wave-uniform
             const bool mvec = !ragged && mask_vec;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -197,39 +209,9 @@ __global__ __launch_bounds__(256, (NT == 2 && D == 64) ? 3 : 2) void attention_k
                                 mh[r] = Mr[key + r];
                     }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float mv = key + r < p.sk ? Tr::to_f32(mh[r]) * LOG2E : -INFINITY;
-                        s[mt][nt][r] = fmaf(s[mt][nt][r], c, mv);
-                    }
-                }
-            }
-        } else if constexpr (MASK == 1) {
-            const float *mstrip = mstrips + (kt & 1) * KT;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const f32x4 mv = *(const f32x4 *)(mstrip + mt * 16 + 4 * g4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        s[mt][nt][r] = fmaf(s[mt][nt][r], c, mv[r]);
-            }
-        } else {
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    s[mt][nt] *= c;
-            if (ragged) {
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (kbase + mt * 16 + 4 * g4 + r >= p.sk) {
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
-                                s[mt][nt][r] = -INFINITY;
-                        }
+                        s[mt][nt][r] = fmaf(Tr::to_f32(mh[r]), inv_scale, s[mt][nt][r]); // keys past Sk are -inf already
+                }
             }
         }
         if (CAUSAL) {
@@ -256,14 +238,15 @@ __global__ __launch_bounds__(256, (NT == 2 && D == 64) ? 3 : 2) void attention_k
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float m_new = fmaxf(m_run[nt], mx);
             const float m_use = m_new == -INFINITY ? 0.f : m_new;
-            const float alpha = fast_exp2(m_run[nt] - m_use);
+            const float alpha = fast_exp2((m_run[nt] - m_use) * c);
+            const float nmc = -m_use * c;
             m_run[nt] = m_new;
             float ps = 0.f;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = fast_exp2(s[mt][nt][r] - m_use);
+                    const float e = fast_exp2(fmaf(s[mt][nt][r], c, nmc));
                     s[mt][nt][r] = e;
                     ps += e;
                 }
@@ -308,7 +291,7 @@ __global__ __launch_bounds__(256, (NT == 2 && D == 64) ? 3 : 2) void attention_k
                     o[dt][nt] = Tr::mfma(vf, pf[nt][kk], o[dt][nt]);
             }
         if (kt + 1 < nkt)
-            store_tile(smem + ((kt + 1) & 1) * STAGE, mstrips + ((kt + 1) & 1) * KT);
+            store_tile(smem + ((kt + 1) & 1) * STAGE, mstrips + ((kt + 1) & 1) * KT, kbase + KT);
         __syncthreads();
     }
 
@@ -338,7 +321,7 @@ __global__ __launch_bounds__(256, (NT == 2 && D == 64) ? 3 : 2) void attention_k
 
 template <typename Tr, int D, int NT, bool CAUSAL, int MASK>
 static int launch_attn2(infiniRocmRuntime_t rt, const AttnArgs &p) {
-    constexpr int LDS = 2 * (64 * (D * 2 + 16) + 64 * (D * 2 + 32)) + (MASK == 1 ? 2 * 64 * 4 : 0);
+    constexpr int LDS = 2 * (64 * (D * 2 + 16) + 64 * (D * 2 + 32)) + 2 * 64 * 4;
     auto kern = attention_kernel<Tr, D, NT, CAUSAL, MASK>;
     IROCM_LDS_ATTR(kern, LDS, rt);
     dim3 grid((unsigned)ceil_div(p.sq, 4 * NT * 16), (unsigned)p.bh);

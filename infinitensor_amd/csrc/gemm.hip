@@ -87,25 +87,39 @@ template <typename Tr> __global__ __launch_bounds__(256) void gemm_generic16(Gem
                 acc[i][j] = Tr::mfma(af[i], bf[j], acc[i][j]);
         __syncthreads();
     }
-    // C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
-    unsigned short *C = (unsigned short *)p.c + (long)ib * p.m * p.n;
-    const unsigned short *bias = (const unsigned short *)p.bias;
+    // one copy of the epilogue per activation class (0 none, 1 relu, 5 A-S Gelu, -1 = p.act at run time): see gemm256p_kernel.h
+    auto epilogue = [&](auto actc) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(actc)::value;
+        auto act1 = [&](float v) {
+            if constexpr (ACT == 1) return v > 0.f ? v : 0.f;
+            else if constexpr (ACT == 5) return gelu_erf_as(v);
+            else if constexpr (ACT < 0) return apply_act(v, p.act);
+            else return v;
+        };
+        // C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+        unsigned short *C = (unsigned short *)p.c + (long)ib * p.m * p.n;
+        const unsigned short *bias = (const unsigned short *)p.bias;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
-                const int col = n0 + wn * 32 + j * 16 + (lane & 15);
-                if (row < p.m && col < p.n) {
-                    float v = acc[i][j][r];
-                    if (bias)
-                        v += Tr::to_f32(bias[(long)ib * p.bias_b + (long)row * p.bias_m + (long)col * p.bias_n]);
-                    v = apply_act(v, p.act);
-                    C[c_off(p, row, col)] = Tr::from_f32(v);
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
+                    const int col = n0 + wn * 32 + j * 16 + (lane & 15);
+                    if (row < p.m && col < p.n) {
+                        float v = acc[i][j][r];
+                        if (bias)
+                            v += Tr::to_f32(bias[(long)ib * p.bias_b + (long)row * p.bias_m + (long)col * p.bias_n]);
+                        v = act1(v);
+                        C[c_off(p, row, col)] = Tr::from_f32(v);
+                    }
                 }
-            }
+    };
+    if (p.act == 0) epilogue(std::integral_constant<int, 0>{});
+    else if (p.act == 1) epilogue(std::integral_constant<int, 1>{});
+    else if (p.act == 5) epilogue(std::integral_constant<int, 5>{});
+    else epilogue(std::integral_constant<int, -1>{});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -284,102 +298,112 @@ __global__ __launch_bounds__(256) void gemm_fast128(GemmArgs p) {
             step(std::integral_constant<int, 1>{}, kt + 1);
     }
 
-    unsigned short *C = (unsigned short *)p.c + (long)ib * p.m * p.n;
-    const unsigned short *bias = (const unsigned short *)p.bias;
-    const bool interior = (m0 + BM <= p.m) && (n0 + BN <= p.n) && (p.n % 4 == 0);
-    if (interior && (p.n % 8 == 0) && ((((uintptr_t)p.c) & 15) == 0)) {
-        // 16-byte stores by swapping half tiles between lane groups g4 / g4^1 (same exchange as gemm256.hip)
-        const int l15 = lane & 15, g4 = lane >> 4;
-        const bool odd = g4 & 1;
+    // one copy of the epilogue per activation class (0 none, 1 relu, 5 A-S Gelu, -1 = p.act at run time): see gemm256p_kernel.h
+    auto epilogue = [&](auto actc) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(actc)::value;
+        auto act1 = [&](float v) {
+            if constexpr (ACT == 1) return v > 0.f ? v : 0.f;
+            else if constexpr (ACT == 5) return gelu_erf_as(v);
+            else if constexpr (ACT < 0) return apply_act(v, p.act);
+            else return v;
+        };
+        unsigned short *C = (unsigned short *)p.c + (long)ib * p.m * p.n;
+        const unsigned short *bias = (const unsigned short *)p.bias;
+        const bool interior = (m0 + BM <= p.m) && (n0 + BN <= p.n) && (p.n % 4 == 0);
+        if (interior && (p.n % 8 == 0) && ((((uintptr_t)p.c) & 15) == 0)) {
+            // 16-byte stores by swapping half tiles between lane groups g4 / g4^1 (same exchange as gemm256.hip)
+            const int l15 = lane & 15, g4 = lane >> 4;
+            const bool odd = g4 & 1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = m0 + wm * 64 + i * 16 + l15;
+            for (int i = 0; i < 4; ++i) {
+                const int row = m0 + wm * 64 + i * 16 + l15;
 #pragma unroll
-            for (int jp = 0; jp < 2; ++jp) {
-                unsigned pk[2][2];
+                for (int jp = 0; jp < 2; ++jp) {
+                    unsigned pk[2][2];
 #pragma unroll
-                for (int t2 = 0; t2 < 2; ++t2) {
-                    const int col = n0 + wn * 64 + (jp * 2 + t2) * 16 + g4 * 4;
+                    for (int t2 = 0; t2 < 2; ++t2) {
+                        const int col = n0 + wn * 64 + (jp * 2 + t2) * 16 + g4 * 4;
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            v[r] = acc[i][jp * 2 + t2][r];
+                        if (bias) {
+                            const unsigned short *bp = bias + (long)ib * p.bias_b + (long)row * p.bias_m + (long)col * p.bias_n;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                v[r] += Tr::to_f32(bp[(long)r * p.bias_n]);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            v[r] = act1(v[r]);
+                        pk[t2][0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
+                        pk[t2][1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
+                    }
+                    const unsigned s0 = odd ? pk[0][0] : pk[1][0], s1 = odd ? pk[0][1] : pk[1][1];
+                    const unsigned r0 = (unsigned)__shfl_xor((int)s0, 16), r1 = (unsigned)__shfl_xor((int)s1, 16);
+                    u32x4_t o;
+                    if (odd) { o[0] = r0; o[1] = r1; o[2] = pk[1][0]; o[3] = pk[1][1]; }
+                    else { o[0] = pk[0][0]; o[1] = pk[0][1]; o[2] = r0; o[3] = r1; }
+                    const int col = n0 + wn * 64 + (jp * 2 + (odd ? 1 : 0)) * 16 + (g4 & ~1) * 4;
+                    *(u32x4_t *)(C + c_off(p, row, col)) = o;
+                }
+            }
+        } else if (interior) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = m0 + wm * 64 + i * 16 + (lane & 15);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        v[r] = acc[i][jp * 2 + t2][r];
+                        v[r] = acc[i][j][r];
                     if (bias) {
                         const unsigned short *bp = bias + (long)ib * p.bias_b + (long)row * p.bias_m + (long)col * p.bias_n;
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             v[r] += Tr::to_f32(bp[(long)r * p.bias_n]);
                     }
-                    if (p.act) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            v[r] = apply_act(v[r], p.act);
-                    }
-                    pk[t2][0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
-                    pk[t2][1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
-                }
-                const unsigned s0 = odd ? pk[0][0] : pk[1][0], s1 = odd ? pk[0][1] : pk[1][1];
-                const unsigned r0 = (unsigned)__shfl_xor((int)s0, 16), r1 = (unsigned)__shfl_xor((int)s1, 16);
-                u32x4_t o;
-                if (odd) { o[0] = r0; o[1] = r1; o[2] = pk[1][0]; o[3] = pk[1][1]; }
-                else { o[0] = pk[0][0]; o[1] = pk[0][1]; o[2] = r0; o[3] = r1; }
-                const int col = n0 + wn * 64 + (jp * 2 + (odd ? 1 : 0)) * 16 + (g4 & ~1) * 4;
-                *(u32x4_t *)(C + c_off(p, row, col)) = o;
-            }
-        }
-    } else if (interior) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = m0 + wm * 64 + i * 16 + (lane & 15);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int col = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    v[r] = acc[i][j][r];
-                if (bias) {
-                    const unsigned short *bp = bias + (long)ib * p.bias_b + (long)row * p.bias_m + (long)col * p.bias_n;
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        v[r] += Tr::to_f32(bp[(long)r * p.bias_n]);
+                        v[r] = act1(v[r]);
+                    u32x2_t pk;
+                    pk[0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
+                    pk[1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
+                    *(u32x2_t *)(C + c_off(p, row, col)) = pk;
                 }
-                if (p.act) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        v[r] = apply_act(v[r], p.act);
-                }
-                u32x2_t pk;
-                pk[0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
-                pk[1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
-                *(u32x2_t *)(C + c_off(p, row, col)) = pk;
             }
-        }
-    } else {
-        for (int i = 0; i < 4; ++i) {
-            const int row = m0 + wm * 64 + i * 16 + (lane & 15);
-            for (int j = 0; j < 4; ++j) {
-                const int col = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-                for (int r = 0; r < 4; ++r) {
-                    // select the register with a static index (runtime-indexed vectors go to scratch)
-                    float v = 0.f;
+        } else {
+            for (int i = 0; i < 4; ++i) {
+                const int row = m0 + wm * 64 + i * 16 + (lane & 15);
+                for (int j = 0; j < 4; ++j) {
+                    const int col = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+                    for (int r = 0; r < 4; ++r) {
+                        // select the register with a static index (runtime-indexed vectors go to scratch)
+                        float v = 0.f;
 #pragma unroll
-                    for (int ii = 0; ii < 4; ++ii)
+                        for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj)
+                            for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                            for (int rr = 0; rr < 4; ++rr)
-                                if (ii == i && jj == j && rr == r)
-                                    v = acc[ii][jj][rr];
-                    if (row < p.m && col + r < p.n) {
-                        if (bias)
-                            v += Tr::to_f32(bias[(long)ib * p.bias_b + (long)row * p.bias_m + (long)(col + r) * p.bias_n]);
-                        C[c_off(p, row, col + r)] = Tr::from_f32(apply_act(v, p.act));
+                                for (int rr = 0; rr < 4; ++rr)
+                                    if (ii == i && jj == j && rr == r)
+                                        v = acc[ii][jj][rr];
+                        if (row < p.m && col + r < p.n) {
+                            if (bias)
+                                v += Tr::to_f32(bias[(long)ib * p.bias_b + (long)row * p.bias_m + (long)(col + r) * p.bias_n]);
+                            C[c_off(p, row, col + r)] = Tr::from_f32(act1(v));
+                        }
                     }
                 }
             }
         }
-    }
+    };
+    if (p.act == 0) epilogue(std::integral_constant<int, 0>{});
+    else if (p.act == 1) epilogue(std::integral_constant<int, 1>{});
+    else if (p.act == 5) epilogue(std::integral_constant<int, 5>{});
+    else epilogue(std::integral_constant<int, -1>{});
 }
 
 // implemented in gemm256.hip
@@ -435,10 +459,10 @@ constexpr int kNumVariants = 7;
 
 // Cost model behind the heuristic (microseconds; fitted to tools/gemm_shapes.py on MI355X, bf16 / f16, N(0,1) data).
 // A workgroup of the persistent kernel walks its tiles: a K-tile of a 256 x 64 NT tile costs kKt[NT]; every tile pays its
-// C store tail (a CU retires ~7 bytes / clk of stores: 128 KiB -> 9 us; gemm256p_kernel.h); launch + first prologue
-// ~3 us once. A last, partial wave of tiles is cheaper than a full one (fewer workgroups share L2 / HBM / power).
-static const double kKt[5] = {0, 0, 0.93, 1.13, 1.36};
-static const double kStoreTail[5] = {0, 0, 4.5, 6.7, 9.0};
+// tile boundary (both wave rows' epilogues side by side, ~10.5 k cycles, + the pipeline restart; gemm256p_kernel.h); launch +
+// first prologue ~3 us once. Re-fitted after the epilogues were de-serialised (profiles/r02_gemm_shapes_bf16.txt). A last, partial wave of tiles is cheaper than a full one (fewer workgroups share L2 / HBM / power).
+static const double kKt[5] = {0, 0, 0.91, 1.10, 1.40};
+static const double kStoreTail[5] = {0, 0, 5.4, 7.0, 7.5};
 static double persist_cost(long m, long n, long k, long batch, int nt, int cus) {
     const long tiles = ceil_div(m, 256) * ceil_div(n, 64 * nt) * batch;
     const long full = tiles / cus;
@@ -558,6 +582,8 @@ int infini_rocm_matmul_headsplit(infiniRocmRuntime_t rt, int dtype, const void *
         variant = 0;
     }
 
+    if (variant >= 4 && !(act == 0 || act == 1 || act == 5))
+        variant = 2; // sigmoid / tanh / erff-Gelu epilogues live in the one-shot kernel only (gemm256p_kernel.h)
     if (variant == 4)
         return g256p::launch_gemm256p_nt4(rt, dtype, p, akm, bkm);
     if (variant == 5)

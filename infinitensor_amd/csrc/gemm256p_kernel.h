@@ -71,7 +71,7 @@ constexpr int kTraceSlots = 128;
 
 // TRACE: every wave stamps s_memtime at phase boundaries into a private LDS strip behind the K-tile buffers (no VMEM
 // traffic, so the vmcnt bookkeeping is untouched) and dumps the strip at the end — tools/gemm_timeline.py.
-template <typename Tr, bool A_KMAJOR, bool B_KMAJOR, int NT, bool TRACE = false, bool GELU = false>
+template <typename Tr, bool A_KMAJOR, bool B_KMAJOR, int NT, bool TRACE = false>
 __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     const GemmArgs &p = pa.g;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -251,7 +251,18 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     using IJ1 = std::integral_constant<int, NJ1>;
 
     // ---- epilogue of one tile --------------------------------------------------------------------
-    auto epilogue = [&](int ib, int m0, int n0) {
+    // ACT is the activation as a compile-time value (0 none, 1 relu, 5 Gelu with erf by Abramowitz-Stegun), one copy of the
+    // epilogue each: apply_act's run-time switch, replicated for each of a lane's 128 accumulators, put ~1600 instructions
+    // (erff, tanhf, expf bodies) between two stores — with the Gelu selected at run time BERT's FFN1 launch cost +85 us.
+    // Sigmoid / tanh / erff-Gelu are served by the one-shot kernel (gemm.hip routes them; a run-time copy here beside the
+    // three spills 528 bytes per lane).
+    auto epilogue = [&](auto actc, int ib, int m0, int n0) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(actc)::value;
+        auto act1 = [&](float v) {
+            if constexpr (ACT == 1) return v > 0.f ? v : 0.f;
+            else if constexpr (ACT == 5) return gelu_erf_as(v);
+            else return v;
+        };
         unsigned short *C = (unsigned short *)p.c + (long)ib * p.m * p.n;
         const unsigned short *bias = (const unsigned short *)p.bias;
         const bool interior = (m0 + BM <= p.m) && (n0 + BN_ <= p.n) && (p.n % 4 == 0);
@@ -296,18 +307,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
                 for (int r = 0; r < 4; ++r)
                     v[r] += Tr::to_f32(bp[(long)r * p.bias_n]);
             }
-            if constexpr (GELU) {
-                // act 5 as a compile-time epilogue: apply_act's run-time switch, unrolled over the tile's 128 values per
-                // lane, carries every activation's code (erff, tanhf ...) 128 times — an instruction stream far beyond
-                // the I-cache (measured: BERT's FFN1 +85 us per launch with the switch)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    v[r] = gelu_erf_as(v[r]);
-            } else if (p.act) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    v[r] = apply_act(v[r], p.act);
-            }
+            for (int r = 0; r < 4; ++r)
+                v[r] = act1(v[r]);
             pk[0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
             pk[1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
         };
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
                         float v = acc[i][j][r];
                         if (bias)
                             v += Tr::to_f32(bias[(long)ib * p.bias_b + (long)row * p.bias_m + (long)(col + r) * p.bias_n]);
-                        C[c_off(p, row, col + r)] = Tr::from_f32(GELU ? gelu_erf_as(v) : apply_act(v, p.act));
+                        C[c_off(p, row, col + r)] = Tr::from_f32(act1(v));
                     }
                 }
             }
@@ -442,9 +444,21 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         for (int kt = 0; kt < nk; ++kt, ++G)
             ktile(G & 1);
         stamp();
-        epilogue(c_ib, c_m0, c_n0); // this wave's part of tile c_s is complete; G = first K-tile of the next tile
+        // Wave row 0 reaches here one barrier interval before row 1. Without the two barriers below the rows' epilogues
+        // serialise: row 1's last (short) compute interval lasts as long as row 0's epilogue, and row 0's first compute of
+        // the next tile as long as row 1's — 2 x 9.4 k cycles per tile boundary in the timeline (tools/gemm_timeline.py).
+        // Row 0 waits out row 1's last compute, both rows run their epilogues side by side (10-11 k cycles for both), row 1
+        // falls back one interval.
+        if (wr == 0)
+            barrier();
+        // this wave's part of tile c_s is complete; G = first K-tile of the next tile
+        if (p.act == 0) epilogue(std::integral_constant<int, 0>{}, c_ib, c_m0, c_n0);
+        else if (p.act == 1) epilogue(std::integral_constant<int, 1>{}, c_ib, c_m0, c_n0);
+        else epilogue(std::integral_constant<int, 5>{}, c_ib, c_m0, c_n0); // launch_p admits act 0, 1, 5 only
         if (c_s + 1 < my_tiles)
             zero_acc();
+        if (wr == 1)
+            barrier();
         stamp();
     }
     if (wr == 0)
@@ -469,6 +483,8 @@ static int launch_p(infiniRocmRuntime_t rt, GemmArgs g, bool akm, bool bkm, unsi
     PArgs pa;
     pa.trace = trace;
     constexpr int kLds = LDS_BYTES + (TRACE ? 8 * kTraceSlots * 8 : 0);
+    if (!(g.act == 0 || g.act == 1 || g.act == 5))
+        IROCM_FAIL(INFINI_ROCM_UNSUPPORTED, "gemm256p: activation %d is not served by the persistent kernels", g.act);
     g.tiles_m = (int)ceil_div(g.m, BM);
     g.tiles_n = (int)ceil_div(g.n, 64 * NT);
     const long total = (long)g.tiles_m * g.tiles_n * g.batch;
@@ -491,10 +507,6 @@ static int launch_p(infiniRocmRuntime_t rt, GemmArgs g, bool akm, bool bkm, unsi
         if (!(akm && !bkm))
             IROCM_FAIL(INFINI_ROCM_UNSUPPORTED, "gemm timeline: NN layout only");
         IROCM_G256P(true, false);
-    } else if (g.act == 5 && akm && !bkm) { // MatMul -> Gelu fusion (rocm_fusion.cc): the ONNX "NN" layout only
-        auto kern = gemm256p_kernel<Tr, true, false, NT, false, true>;
-        IROCM_LDS_ATTR(kern, kLds, rt);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), kLds, rt->stream, pa);
     } else {
         if (akm && bkm) IROCM_G256P(true, true);
         else if (akm && !bkm) IROCM_G256P(true, false);
