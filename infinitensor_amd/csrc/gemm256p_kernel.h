@@ -6,23 +6,21 @@
 // workgroup per CU walks its tiles (tile ids blockIdx.x, + gridDim.x, ...) through ONE flat K-tile pipeline:
 //   * the LDS-DMA cursors run across tile boundaries (A one K-tile ahead, B two), so the next tile's first two K-tiles
 //     are in LDS before the current tile's last MFMA: no cold prologue after the first tile;
-//   * the epilogue of tile T is plain code between C2 of T's last K-tile and L1 of the next tile's first one — no
-//     barrier in it. The two wave rows stay staggered by one barrier interval, so while one wave of a SIMD converts and
-//     stores its 128 accumulators its partner is still issuing the last 32 MFMAs of T (or already the first 32 of
-//     T + 1); C stores are asynchronous and drain under the next tile's main loop. Only the LAST tile's store tail is
-//     exposed;
+//   * the epilogue of tile T sits between C2 of T's last K-tile and L1 of the next tile's first one; C stores are
+//     asynchronous and drain under the next tile's main loop. The two wave rows run their epilogues SIDE BY SIDE: row 0,
+//     which is one barrier interval ahead (the LOAD | COMPUTE stagger), first waits out row 1's last compute interval and
+//     row 1 falls back one interval after its own epilogue (two extra barriers per tile, see the tile loop).
 //     (A variant that issued the next A DMA before the C stores and counted the stores in the following vmcnt wait was
 //     built and removed: loads and stores retire through one counter but not in one order, so a counted wait behind
 //     stores proves nothing about older loads; every wait here is a plain vmcnt(N <= loads issued after the one needed),
 //     which is safe because loads retire in order among themselves.)
 // What the TRACE build measured (tools/gemm_timeline.py, 16384 x 3072 x 768, 3 tiles per workgroup): steady K-tile
-// ~3000 cycles; a tile's epilogue ~9400 cycles PER WAVE ROW = 18.7 k per tile: a CU retires C stores at ~7 bytes/clk
-// however they are shaped or timed (measured the same with 16 rows x 64 B and with 8 rows x 128 B per instruction, with
-// non-temporal stores, and with the workgroups started in 4 / 8 phases so that only a fraction of the CUs stores at a
-// time — all removed again), the storing waves sit in store issue meanwhile, and through the barriers so does the
-// workgroup. So what persistence buys per tile boundary is the prologue (~3 us) and the launch, not the store tail;
-// hiding that needs the packed tile parked in 64 more VGPRs (or in LDS) and trickled out under the next tile's main
-// loop — neither exists at 2 waves per SIMD with a 128 KiB K-tile ring.
+// ~3000 cycles (2048 of them MFMA issue); a wave row's epilogue ~9400 cycles. In the first version the epilogue had no
+// barrier in it, and the workgroup-wide barriers of the K-tiles around it serialised the rows: row 1's last (short)
+// compute interval lasted as long as row 0's epilogue and row 0's first interval of the next tile as long as row 1's,
+// 18.7 k cycles per tile boundary — misread at first as a per-CU store limit of 7 bytes / clk (and "confirmed" by
+// experiments that could not move it: 8 rows x 128 B instead of 16 x 64 B per store, non-temporal stores, workgroups
+// started in phases; all removed). Side by side both rows finish in ~10.5 k cycles: DESIGN.md, "Follow-up".
 // Tile width is a template parameter: NT = 4 / 3 / 2 MFMA column tiles per wave = 256 / 192 / 128 columns (8 waves as
 // 2 (M) x 4 (N); wave tile 128 x 16 NT), so N = 768 (BERT) tiles as 4 x 192 without a ragged last tile and small
 // grids can trade tile size for CU coverage. Everything else — LDS images, XOR swizzles, transpose reads, the
