@@ -56,6 +56,7 @@ class RocmRuntimeObj : public RuntimeObj {
     void setFusion(bool on);
     bool getFusion() const { return fusion; }
     size_t getFusedLaunchCount() const { return fusedCount; } // fused kernels launched so far (tests)
+    size_t getBridgedInputCount() const { return bridgedCount; } // fused convs that read a workspace copy of their input
 
     // the autotune cache: h.tune() fills the process-wide PerfEngine (MatMul / Conv pick among their kernel variants,
     // rocm/rocm_perf.h); these persist it as JSON and bring it back (reference: PerfEngine::savePerfEngineData /
@@ -131,6 +132,7 @@ class RocmRuntimeObj : public RuntimeObj {
     size_t captureCount = 0;
     bool fusion = true;
     mutable size_t fusedCount = 0;
+    mutable size_t bridgedCount = 0;
     Cache cache; // most recently used first
     mutable std::recursive_mutex executionMutex;
     mutable std::recursive_mutex cacheMutex;

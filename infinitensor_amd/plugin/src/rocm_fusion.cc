@@ -388,11 +388,31 @@ size_t RocmRuntimeObj::tryLaunchFusedRules(const OpVec &ops, size_t i) const {
             const bool resHazard = c.res && overlaps(c.last, c.res) &&
                                    !(c.res->getRawDataPtr<void *>() == c.last->getRawDataPtr<void *>() &&
                                      c.res->getDims() == c.last->getDims());
-            if (!(c.last->getDType() == x->getDType()) || overlaps(c.last, x) || overlaps(c.last, w) ||
-                (c.bias && overlaps(c.last, c.bias)) || resHazard)
-                continue;
             const auto [n, ch, h, wd, ff, r, s] = conv->getNCHWFRS();
             const auto [ph, pw, sh, sw, dh, dw] = conv->getPadStrideDilation();
+            // The planner likes to put the chain's output on the conv's own input (dead after the conv in the unfused
+            // graph). When that input is small next to the output — the 64 -> 256 expansions of ResNet's first stage: 51 MB
+            // in, 205 MB out — the conv reads a copy of it from the workspace instead of giving up the tail: one 2 x 51 MB
+            // copy instead of a lone 2 x 205 MB ReLU / bias pass. Unit-stride only (a strided conv keeps its phase planes
+            // at the workspace base, a long-K pointwise layer may run as a split-K GEMM with partial planes there); the
+            // copy sits behind the conv's own packed-weight area.
+            const bool onX = overlaps(c.last, x);
+            static const bool bridgeOn = !(std::getenv("INFINI_ROCM_BRIDGE_X") && std::atoi(std::getenv("INFINI_ROCM_BRIDGE_X")) == 0);
+            const bool bridgeX = bridgeOn && onX && sh == 1 && sw == 1 && conv->getNumGroups() == 1 && ch < 1024 &&
+                                 (size_t)x->getBytes() * 3 <= (size_t)c.last->getBytes();
+            if (!(c.last->getDType() == x->getDType()) || (onX && !bridgeX) || overlaps(c.last, w) ||
+                (c.bias && overlaps(c.last, c.bias)) || resHazard)
+                continue;
+            const void *xptr = x->getRawDataPtr<void *>();
+            if (bridgeX) {
+                const size_t wArea = (((size_t)ff * ch * r * s * 2 + 4096) + 255) & ~(size_t)255;
+                char *ws = (char *)getWorkspace(wArea + x->getBytes());
+                ROCM_CALL(infini_rocm_copy_inside(rt, ws + wArea, xptr, x->getBytes()));
+                xptr = ws + wArea;
+                ++bridgedCount;
+                if (fusionLog)
+                    fprintf(stderr, "[fusion] conv#%zu: input bridged through the workspace (%zu bytes)\n", i, (size_t)x->getBytes());
+            }
             // a tuned Conv (h.tune(): ConvRocm::tune) keeps its kernel choice when the tail is folded into it
             struct VariantScope {
                 infiniRocmRuntime_t rt;
@@ -407,7 +427,7 @@ size_t RocmRuntimeObj::tryLaunchFusedRules(const OpVec &ops, size_t i) const {
                 }
             } scope(rt, tunedVariant(op));
             ConstWeightsScope constWeights(rt, w); // graph weights: pack once, cache (rocm_runtime.h)
-            ROCM_CALL(infini_rocm_conv2d_res(rt, x->getDTypeIndex(), x->getRawDataPtr<void *>(), w->getRawDataPtr<void *>(),
+            ROCM_CALL(infini_rocm_conv2d_res(rt, x->getDTypeIndex(), xptr, w->getRawDataPtr<void *>(),
                                              c.bias ? c.bias->getRawDataPtr<void *>() : nullptr,
                                              c.res ? c.res->getRawDataPtr<void *>() : nullptr, c.last->getRawDataPtr<void *>(),
                                              n, ch, h, wd, ff, r, s, ph, pw, sh, sw, dh, dw, conv->getNumGroups(), c.act));

@@ -261,6 +261,9 @@ def test_resnet50_bs128_full_size_properties(plugin_backend):
     a1, a2 = logits(128)
     assert np.isfinite(a1).all()
     assert np.array_equal(a1, a2)
+    # the 64 -> 256 expansions of the first stage: the planner puts the fused chain's output on the conv's (small) input,
+    # the conv then reads a workspace copy of it (rocm_fusion.cc) — exercised here, checked by the batch consistency below
+    assert rocm.bridged_input_count() >= 1
     pick = [5, 77]
     b1, _ = logits(2, pick)
     scale = np.abs(a1).max()
