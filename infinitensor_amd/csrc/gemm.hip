@@ -460,14 +460,16 @@ constexpr int kNumVariants = 7;
 // Cost model behind the heuristic (microseconds; fitted to tools/gemm_shapes.py on MI355X, bf16 / f16, N(0,1) data).
 // A workgroup of the persistent kernel walks its tiles: a K-tile of a 256 x 64 NT tile costs kKt[NT]; every tile pays its
 // tile boundary (both wave rows' epilogues side by side, ~10.5 k cycles, + the pipeline restart; gemm256p_kernel.h); launch +
-// first prologue ~3 us once. Re-fitted after the epilogues were de-serialised (profiles/r02_gemm_shapes_bf16.txt). A last, partial wave of tiles is cheaper than a full one (fewer workgroups share L2 / HBM / power).
+// first prologue ~3 us once. Re-fitted after the epilogues were de-serialised (profiles/r02_gemm_shapes_bf16.txt).
 static const double kKt[5] = {0, 0, 0.91, 1.10, 1.40};
 static const double kStoreTail[5] = {0, 0, 5.4, 7.0, 7.5};
 static double persist_cost(long m, long n, long k, long batch, int nt, int cus) {
     const long tiles = ceil_div(m, 256) * ceil_div(n, 64 * nt) * batch;
     const long full = tiles / cus;
     const double frac = (double)(tiles - full * cus) / cus;
-    const double waves = (double)full + (frac > 0 ? (1.5 * frac < 1.0 ? 1.5 * frac : 1.0) : 0.0);
+    // a partial last round still costs most of a tile time (every workgroup's tile takes what it takes; only the shared
+    // L2 / HBM / power budget is lighter): 0.55 + 0.5 frac of a full round fits the sweep from frac = 0.25 to 0.8
+    const double waves = (double)full + (frac > 0 ? (0.55 + 0.5 * frac < 1.0 ? 0.55 + 0.5 * frac : 1.0) : 0.0);
     return waves * ((double)(k / 64) * kKt[nt] + kStoreTail[nt]) + 3.0;
 }
 // split-K: `splits` workgroups per 256^2 tile write fp32 partial planes, one reduce pass adds them

@@ -53,6 +53,37 @@ def test_attention_vs_oracle(rt, case, dt):
     assert np.allclose(host(y), want, rtol=TOL[dt], atol=TOL[dt])
 
 
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("scale", [-0.125, 0.0, 3.0])
+@pytest.mark.parametrize("d,causal,use_mask", [(64, False, True), (128, True, False), (64, True, True)])
+def test_attention_scale_sign_and_zero(rt, dt, scale, d, causal, use_mask):
+    """The kernel keeps the scores in q.k units and applies the scale inside the exponent, which needs a positive factor:
+    the sign of a negative scale goes into Q, a zero scale zeroes Q (attention.hip). Same result as the oracle's
+    softmax(scale * Q K^T + mask) V for every sign, also through a device-memory scale used as a divisor."""
+    rng = np.random.default_rng(17)
+    b, h, sq, sk = 2, 2, 70, 150
+    q = rng.standard_normal((b, h, sq, d)).astype(np.float32)
+    k = rng.standard_normal((b, h, sk, d)).astype(np.float32)
+    v = rng.standard_normal((b, h, sk, d)).astype(np.float32)
+    mask = None
+    if use_mask:
+        mask = np.where(rng.random((b, sk)) < 0.8, 0.0, -10000.0).astype(np.float32)
+        mask[:, 0] = 0.0
+    qd, kd, vd = dev(q, TD[dt]), dev(k, TD[dt]), dev(v, TD[dt])
+    md = dev(mask, TD[dt]) if use_mask else None
+    want = R.attention(R.round_to(q, dt), R.round_to(k, dt), R.round_to(v, dt), scale,
+                       None if mask is None else R.round_to(mask, dt)[:, None, None, :], causal)
+    y = ops.attention(rt, qd, kd, vd, scale, md, causal)
+    assert np.allclose(host(y), want, rtol=TOL[dt], atol=TOL[dt])
+    if scale != 0.0:  # the graph's Div(scalar) form: scale = 1 / value held in device memory
+        inv = torch.tensor([1.0 / scale], dtype=TD[dt]).cuda()
+        eff = 1.0 / float(inv.float().item())  # the 16-bit rounding of the constant is part of the graph
+        want_div = R.attention(R.round_to(q, dt), R.round_to(k, dt), R.round_to(v, dt), eff,
+                               None if mask is None else R.round_to(mask, dt)[:, None, None, :], causal)
+        y2 = ops.attention(rt, qd, kd, vd, inv, md, causal, scale_is_div=True)
+        assert np.allclose(host(y2), want_div, rtol=TOL[dt], atol=TOL[dt])
+
+
 def test_attention_equals_the_unfused_chain(rt):
     """Same graph as BERT emits: MatMul(q, k^T) -> Div(sqrt d) -> Add(mask) -> Softmax -> MatMul(p, v), scale taken
     from device memory as the graph's scalar constant."""

@@ -708,6 +708,48 @@ def test_head_split_fusion_is_bit_identical(B, rocm, code, npdt):
         assert np.allclose(got[True].astype(np.float64).reshape(want.shape), want, rtol=tol, atol=tol)
 
 
+def test_grouped_qkv_head_split_is_bit_identical(B, rocm):
+    """Three head-split projections of ONE activation (q, k, v) whose weights / biases / outputs sit at a uniform spacing
+    run as one grouped GEMM launch (rocm_fusion.cc::tryLaunchHeadSplit: group index = batch index, zero A stride) —
+    identical bits to nine kernels; a fourth consumer of the activation (a different width) stays outside the group."""
+    rng = np.random.default_rng(43)
+    Bt, S, NH, D = 2, 128, 4, 64
+    hid = NH * D
+    x = rng.standard_normal((Bt, S, hid)).astype(np.float16)
+    ws = [(rng.standard_normal((hid, hid)) / 16).astype(np.float16) for _ in range(3)]
+    bs = [rng.standard_normal((hid,)).astype(np.float16) for _ in range(3)]
+    arrays = [x]
+    for w, b in zip(ws, bs):  # a layer's parameters in creation order: w_q, b_q, w_k, b_k, w_v, b_v
+        arrays += [w, b]
+    lin = B.ActType.Linear
+    got, launches = {}, {}
+    try:
+        for on in (True, False):
+            rocm.set_fusion(on)
+            h = B.GraphHandler(rocm)
+            ts = [h.tensor(list(a.shape), F16) for a in arrays]
+            for t in ts:
+                t.set_weight()
+            outs = []
+            for j in range(3):
+                y = h.matmul(ts[0], ts[1 + 2 * j], None, False, False, ts[2 + 2 * j], lin, "default")
+                outs.append(h.transpose(h.reshape(y, None, [Bt, S, NH, D]), None, [0, 2, 1, 3]))
+            h.data_malloc()
+            for t, a in zip(ts, arrays):
+                put(t, a)
+            before = rocm.fused_launch_count()
+            h.run()
+            launches[on] = rocm.fused_launch_count() - before
+            got[on] = [get(o) for o in outs]
+    finally:
+        rocm.set_fusion(True)
+    assert launches[False] == 0 and launches[True] in (1, 2, 3)  # 1 = all three grouped (the planner's layout permitting)
+    for j in range(3):
+        assert np.array_equal(got[True][j], got[False][j])
+        want = (x.astype(np.float64).reshape(Bt * S, hid) @ ws[j].astype(np.float64) + bs[j]).reshape(Bt, S, NH, D).transpose(0, 2, 1, 3)
+        assert np.allclose(got[True][j].astype(np.float64), want, rtol=4e-3, atol=4e-3)
+
+
 # ---- hipGraph cache: the remaining cases of test/cuda/test_cudagraph.cc, through backend.RocmRuntime -----------------
 class _GraphFixture:
     """CudaGraphFixture of test_cudagraph.cc:29-72: input [batch, 2] @ identity weight [2, 2] -> Relu."""
