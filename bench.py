@@ -36,7 +36,10 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    # default warm-up: 300 launches = 30 ms. The chip needs ~150 back-to-back launches (15 ms) to clock up from idle — measured
+    # per launch: 124, 112, 107, 105, 102, 101, 100.6 ... 99.6 us per 25-launch window, flat at 99.5-100 us from launch ~200 to
+    # 600 (profiles/r02_launch_series.txt) — and a 20-launch warm-up put that ramp inside the timed region (109.7 us mean).
+    ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--variant", type=int, default=-1, help="GEMM kernel variant (-1 = heuristic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
@@ -462,8 +465,8 @@ def main() -> int:
             td.barrier()
 
     e0, e1 = Event(), Event()
-    # one event after every launch (<= 1000 steps): the per-launch spread shows burst vs sustained clocks (the chip
-    # throttles after ~20 back-to-back launches); an event record costs well under a microsecond of stream time
+    # one event after every launch (<= 1000 steps): the per-launch spread shows the clock state over the run (the chip ramps
+    # UP over its first ~150 launches from idle and then holds); an event record costs well under a microsecond of stream time
     marks = [Event() for _ in range(args.steps)] if args.steps <= 1000 else []
     barrier()
     torch.cuda.synchronize()
