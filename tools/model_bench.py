@@ -206,9 +206,12 @@ def build_matmul(bl: Builder, n: int = 4096, trans_b: bool = False):
     return bl.h.matmul(a, w, None, False, trans_b, None, bl.B.ActType.Linear, "default")
 
 
-def timed(fn, iters, warm=2):
-    for _ in range(warm):
+def timed(fn, iters, warm_ms=40.0):
+    # warm by time, not by count: the chip clocks up for ~15 ms from idle (profiles/r02_launch_series.txt)
+    t0, n = time.perf_counter(), 0
+    while n < 2 or (time.perf_counter() - t0) * 1e3 < warm_ms:
         fn()
+        n += 1
     t0 = time.perf_counter()
     for _ in range(iters):
         fn()
