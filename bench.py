@@ -465,9 +465,6 @@ def main() -> int:
             td.barrier()
 
     e0, e1 = Event(), Event()
-    # one event after every launch (<= 1000 steps): the per-launch spread shows the clock state over the run (the chip ramps
-    # UP over its first ~150 launches from idle and then holds); an event record costs well under a microsecond of stream time
-    marks = [Event() for _ in range(args.steps)] if args.steps <= 1000 else []
     barrier()
     torch.cuda.synchronize()
     rt.sync()
@@ -475,17 +472,27 @@ def main() -> int:
     rt.record(e0)
     for i in range(args.steps):
         step()
-        if marks:
-            rt.record(marks[i])
     rt.record(e1)
     rt.sync()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_s = rt.elapsed_ms(e0, e1) * 1e-3 / args.steps  # avg launch duration from HIP events
+    kernel_s = rt.elapsed_ms(e0, e1) * 1e-3 / args.steps  # avg launch duration from HIP events over the timed region
+    # Per-launch spread, from a SECOND pass of the same launches with an event after every one (<= 1000 steps): it shows
+    # the clock state over a run (the chip ramps UP over its first ~150 launches from idle and then holds). Kept out of the
+    # timed region: every event record is a marker packet between two dispatches and costs 2-6 us of queue time per launch
+    # (measured: 101.6 us per launch with the markers against 95.7 us kernel duration in the rocprofv3 trace of the same run;
+    # 96.8 against 94.8 us on another box).
     per_launch = None
-    if marks:
-        prev, durs = e0, []
+    if args.steps <= 1000:
+        marks = [Event() for _ in range(args.steps)]
+        m0 = Event()
+        rt.record(m0)
+        for i in range(args.steps):
+            step()
+            rt.record(marks[i])
+        rt.sync()
+        prev, durs = m0, []
         for m in marks:
             durs.append(rt.elapsed_ms(prev, m) * 1e3)
             prev = m
@@ -493,7 +500,8 @@ def main() -> int:
         per_launch = {"min": round(durs_sorted[0], 2), "median": round(durs_sorted[len(durs) // 2], 2),
                       "mean": round(sum(durs) / len(durs), 2), "max": round(durs_sorted[-1], 2),
                       "first10_mean": round(sum(durs[:10]) / min(10, len(durs)), 2),
-                      "last10_mean": round(sum(durs[-10:]) / min(10, len(durs)), 2)}
+                      "last10_mean": round(sum(durs[-10:]) / min(10, len(durs)), 2),
+                      "note": "second pass, one event record after every launch (each adds 2-6 us of queue time)"}
 
     if dist:
         tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)

@@ -8,5 +8,23 @@ for m in "resnet50 --batch 128 --iters 3" "bert --batch 32 --seq 512 --iters 3";
   name=$(echo $m | cut -d' ' -f1)
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -o $name -- python $REPO/tools/model_bench.py $m > $OUT/$name.log 2>&1
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python $REPO/bench.py --no-cpu-baseline --no-extras --no-graph --no-tp --steps 50 --warmup 5 > $OUT/bench.log 2>&1
+# the SAME headline command bench.py runs by default (300 warm-up + 200 timed launches); the secondary sections are switched off
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python $REPO/bench.py --no-cpu-baseline --no-extras --no-graph --no-tp > $OUT/bench.log 2>&1
+python3 - <<PY
+import csv, glob, json
+rows = []
+for f in glob.glob("$OUT/bench/**/*kernel_trace.csv", recursive=True):
+    rows += [r for r in csv.DictReader(open(f)) if "gemm256p_kernel" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+# launch order: 300 warm-up, 200 timed, then whatever later sections add (none with the flags above)
+timed = d[300:500] if len(d) >= 500 else d
+out = {"command": "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-extras --no-graph --no-tp",
+       "kernel": rows[0]["Kernel_Name"] if rows else None, "launches": len(d),
+       "us_mean_all": sum(d) / max(1, len(d)), "us_mean_timed_200": sum(timed) / max(1, len(timed)),
+       "us_min_timed": min(timed) if timed else None, "us_max_timed": max(timed) if timed else None,
+       "us_mean_first_100_warmup": sum(d[:100]) / max(1, len(d[:100]))}
+json.dump(out, open("$OUT/bench_trace_summary.json", "w"), indent=1)
+print(json.dumps(out))
+PY
 for f in $(find $OUT -name "*kernel_stats.csv"); do echo "== $f"; head -14 $f | cut -c1-230; done
