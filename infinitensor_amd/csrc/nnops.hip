@@ -284,6 +284,35 @@ __global__ __launch_bounds__(256) void global_avgpool_kernel(const T *__restrict
         LdSt<T>::st(y + plane, s / (float)hw);
 }
 
+// Global average pool over SMALL planes (ResNet's 7 x 7 head: 49 elements = 98 bytes per plane): a wave per plane moves one
+// 2-byte load per lane and ran at 0.8 TB/s (26 MB in 32 us). Here a workgroup owns 256 consecutive planes = one contiguous
+// slab: coalesced 16-byte loads into LDS, then one thread per plane sums its hw elements from LDS in index order (fp32).
+typedef unsigned int pool_u32x4_t __attribute__((ext_vector_type(4)));
+template <typename T>
+__global__ __launch_bounds__(256) void global_avgpool_small_kernel(const T *__restrict__ x, T *__restrict__ y, long planes, int hw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const long p0 = (long)blockIdx.x * 256;
+    const long np = planes - p0 < 256 ? planes - p0 : 256;
+    const long bytes = np * hw * (long)sizeof(T); // the slab starts 16-byte aligned: 256 * hw * sizeof(T) per workgroup
+    const char *src = (const char *)(x + p0 * hw);
+    for (long o = (long)threadIdx.x * 16; o < bytes; o += 256 * 16) {
+        if (o + 16 <= bytes) {
+            *(pool_u32x4_t *)(smem + o) = *(const pool_u32x4_t *)(src + o);
+        } else {
+            for (long b = o; b < bytes; b += sizeof(T))
+                *(T *)(smem + b) = *(const T *)(src + b);
+        }
+    }
+    __syncthreads();
+    if ((long)threadIdx.x < np) {
+        const T *pl = (const T *)smem + (long)threadIdx.x * hw;
+        float s = 0.f;
+        for (int i = 0; i < hw; ++i)
+            s += LdSt<T>::ld(pl + i);
+        LdSt<T>::st(y + p0 + threadIdx.x, s / (float)hw);
+    }
+}
+
 // ---- LRN across channels (ONNX LRN; reference operator: src/operators/lrn.cc, only a Cambricon kernel exists,
 // src/kernels/bang/lrn.cc:6-56): y[n,c,p] = x[n,c,p] / (bias + alpha / size * sum_{i in window(c)} x[n,i,p]^2)^beta,
 // window(c) = [c - floor((size-1)/2), c + ceil((size-1)/2)] clipped to [0, C). One thread per (n, 4 consecutive pixels)
@@ -439,7 +468,11 @@ int infini_rocm_pool2d_relu(infiniRocmRuntime_t rt, int kind, int dtype, const v
         return INFINI_ROCM_OK;
     }
 #define GO(T)                                                                                      \
-    if (global_avg)                                                                                \
+    if (global_avg && (long)h * w * (long)sizeof(T) * 256 <= 64 * 1024 && ((((uintptr_t)x) & 15) == 0))  \
+        hipLaunchKernelGGL((global_avgpool_small_kernel<T>), dim3((unsigned)ceil_div(n * c, 256)), \
+                           dim3(256), (size_t)(h * w) * sizeof(T) * 256, rt->stream, (const T *)x, \
+                           (T *)y, (long)(n * c), (int)(h * w));                                   \
+    else if (global_avg)                                                                           \
         hipLaunchKernelGGL((global_avgpool_kernel<T>), dim3((unsigned)ceil_div(n * c, 4)),         \
                            dim3(256), 0, rt->stream, (const T *)x, (T *)y, (long)(n * c),          \
                            (long)(h * w));                                                         \

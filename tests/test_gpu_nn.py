@@ -301,7 +301,9 @@ def test_pooling_reference_kats(rt):
 @pytest.mark.parametrize("dt", ["f32", "f16"])
 @pytest.mark.parametrize("cfg", [((2, 64, 112, 112), 3, 3, 1, 1, 1, 1, 2, 2, 0), ((2, 2048, 7, 7), 7, 7, 1, 1, 0, 0, 1, 1, 0),
                                  ((1, 3, 10, 9), 2, 3, 2, 1, 1, 0, 1, 2, 1), ((2, 5, 8), 1, 3, 1, 1, 0, 1, 1, 2, 0),
-                                 ((3, 5, 9, 16), 3, 3, 1, 1, 1, 1, 2, 2, 0)])  # odd height on the specialised 3x3/2 max-pool kernel
+                                 ((3, 5, 9, 16), 3, 3, 1, 1, 1, 1, 2, 2, 0),  # odd height on the specialised 3x3/2 max-pool kernel
+                                 ((3, 100, 7, 7), 7, 7, 1, 1, 0, 0, 1, 1, 0),  # global pools: 300 planes = a ragged last slab of
+                                 ((1, 513, 5, 3), 5, 3, 1, 1, 0, 0, 1, 1, 0)])  # the small-plane kernel; odd plane sizes
 def test_pooling_vs_oracle(rt, cfg, dt):
     shape, kh, kw, dh, dw, ph, pw, sh, sw, ceil = cfg
     rng = np.random.default_rng(29)
