@@ -180,6 +180,10 @@ int infini_rocm_matmul_headsplit(infiniRocmRuntime_t rt, int dtype, const void *
                                  int trans_a, int trans_b, int64_t stride_a, int64_t stride_b,
                                  int64_t bias_stride_b, int64_t bias_stride_m, int64_t bias_stride_n,
                                  int act, int64_t seq, int64_t head_dim);
+/* May a matmul of this extent take the runtime workspace (split-K partial planes) under the current variant setting?
+ * A caller that parks an operand of the NEXT matmul in the workspace (rocm_fusion.cc: the fused attention's output
+ * feeding the output projection) asks first. *may = 1 is conservative: split-K is possible, not certain. */
+int infini_rocm_matmul_may_use_workspace(infiniRocmRuntime_t rt, int64_t batch, int64_t m, int64_t n, int *may);
 /* Select a specific GEMM kernel variant for the next matmul calls on this runtime
  * (-1 = heuristic). Used by tune() (reference: 24-algo sweep, matmul.cc:187-208) and by bench.py. */
 int infini_rocm_matmul_set_variant(infiniRocmRuntime_t rt, int variant);

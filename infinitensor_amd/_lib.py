@@ -87,6 +87,7 @@ def lib() -> C.CDLL:
     sig("infini_rocm_matmul", [vp, i32, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i64, i64, i64, i64, i64, i32])
     sig("infini_rocm_matmul_headsplit", [vp, i32, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i64, i64, i64, i64, i64, i32, i64, i64])
     sig("infini_rocm_matmul_set_variant", [vp, i32])
+    sig("infini_rocm_matmul_may_use_workspace", [vp, i64, i64, i64, C.POINTER(C.c_int)])
     sig("infini_rocm_matmul_num_variants", [], i32)
     sig("infini_rocm_matmul_variant_name", [i32], C.c_char_p)
     sig("infini_rocm_softmax", [vp, i32, vp, vp, i64, i64, i64])

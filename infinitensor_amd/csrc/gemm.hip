@@ -496,6 +496,18 @@ int infini_rocm_matmul_set_variant(infiniRocmRuntime_t rt, int variant) {
     return INFINI_ROCM_OK;
 }
 
+// split-K (the only MatMul path that takes the runtime workspace: fp32 partial planes) needs few enough 256^2 tiles
+static bool splitk_possible(infiniRocmRuntime_t rt, int64_t m, int64_t n, int64_t batch) {
+    const long tiles256 = ceil_div(m, 256) * ceil_div(n, 256) * batch;
+    return tiles256 * 2 <= rt->num_cu + rt->num_cu / 4;
+}
+
+int infini_rocm_matmul_may_use_workspace(infiniRocmRuntime_t rt, int64_t batch, int64_t m, int64_t n, int *may) {
+    IROCM_CHECK_ARG(rt && may, "NULL argument");
+    *may = (rt->matmul_variant == 3 || splitk_possible(rt, m, n, batch)) ? 1 : 0;
+    return INFINI_ROCM_OK;
+}
+
 int infini_rocm_matmul(infiniRocmRuntime_t rt, int dtype, const void *a, const void *b,
                        const void *bias, void *c, int64_t batch, int64_t m, int64_t n, int64_t k,
                        int trans_a, int trans_b, int64_t stride_a, int64_t stride_b,
@@ -551,7 +563,7 @@ int infini_rocm_matmul_headsplit(infiniRocmRuntime_t rt, int dtype, const void *
     // slice still runs >= 8 K-tiles (the fp32 partial planes cost 8 bytes per output element and slice)
     const long tiles256 = ceil_div(m, 256) * ceil_div(n, 256) * batch;
     int splits = 1;
-    if (gemm256_supported(p, akm, bkm) && tiles256 * 2 <= rt->num_cu + rt->num_cu / 4) {
+    if (gemm256_supported(p, akm, bkm) && splitk_possible(rt, m, n, batch)) {
         splits = (int)(rt->num_cu / tiles256);
         const int max_by_k = (int)(k / (8 * 64));
         if (splits > max_by_k) splits = max_by_k;

@@ -104,6 +104,23 @@ std::vector<int64_t> strides64(const Shape &shape, const Shape &outShape) {
 }
 } // namespace
 
+namespace {
+struct OutputRedirect { // RAII: the redirection never outlives one launch
+    OutputRedirect(const TensorObj *t, void *p, int seq = 0, int headDim = 0, int act = 0) {
+        RocmRuntimeObj::redirectTensor = t;
+        RocmRuntimeObj::redirectPtr = p;
+        RocmRuntimeObj::redirectSeq = seq;
+        RocmRuntimeObj::redirectHeadDim = headDim;
+        RocmRuntimeObj::redirectAct = act;
+    }
+    ~OutputRedirect() {
+        RocmRuntimeObj::redirectTensor = nullptr;
+        RocmRuntimeObj::redirectPtr = nullptr;
+        RocmRuntimeObj::redirectSeq = RocmRuntimeObj::redirectHeadDim = RocmRuntimeObj::redirectAct = 0;
+    }
+};
+} // namespace
+
 size_t RocmRuntimeObj::tryLaunchFusedAttention(const OpVec &ops, size_t i) const {
     auto mm1 = as<MatmulObj>(ops[i]);
     if (mm1->getTransA() || !mm1->getTransB() || mm1->getBias() || mm1->getAct() != ActType::None)
@@ -193,8 +210,35 @@ size_t RocmRuntimeObj::tryLaunchFusedAttention(const OpVec &ops, size_t i) const
                                               v->getRawDataPtr<void *>(), mask ? mask->getRawDataPtr<void *>() : nullptr, dst,
                                               (int64_t)b * h, sq, sk, d, group, scale ? scale->getRawDataPtr<void *>() : nullptr,
                                        isDiv ? 1 : 0, 1.0f, 0, heads, mask2d ? 1 : 0));
-    if (hazard)
+    if (hazard) {
+        // The bridged result usually feeds exactly one operator, the output projection, which is next in the list: let
+        // that MatMul read its A operand straight from the workspace (input redirect through P(), rocm_kernels.cc) instead
+        // of copying 25 MB per BERT layer to a tensor nobody else reads. Only a plain MatMul that cannot itself take the
+        // workspace (split-K partial planes) and that no other launch-time rule would pick up.
+        static const bool feedOn = !(std::getenv("INFINI_ROCM_FEED_NEXT") && std::atoi(std::getenv("INFINI_ROCM_FEED_NEXT")) == 0);
+        const size_t nx = last + 1;
+        if (feedOn && nx < ops.size() && ops[nx]->getOpType() == OpType::MatMul && soleConsumerIs(dstT, ops[nx])) {
+            auto mmn = as<MatmulObj>(ops[nx]);
+            const auto [nb, nm, nn, nk] = mmn->getBMNK();
+            int mayWs = 1;
+            ROCM_CALL(infini_rocm_matmul_may_use_workspace(rt, nb, nm, nn, &mayWs));
+            bool onlyA = mmn->getInputs(0) == dstT;
+            for (size_t q = 1; q < mmn->getInputs().size(); ++q)
+                onlyA = onlyA && mmn->getInputs(q) != dstT;
+            bool otherRule = false; // head split / Gelu / copy elision would want the single redirect slot themselves
+            if (nx + 1 < ops.size()) {
+                const auto t2 = ops[nx + 1]->getOpType();
+                otherRule = t2 == OpType::Reshape || t2 == OpType::Flatten || t2 == OpType::Identity || t2 == OpType::Squeeze ||
+                            t2 == OpType::Unsqueeze || t2 == OpType::Gelu;
+            }
+            if (!mayWs && onlyA && !otherRule && tunedVariant(ops[nx]) != 3 && !overlaps(mmn->getOutput(), dstT)) {
+                OutputRedirect feed(dstT.get(), dst);
+                launchOne(ops[nx]);
+                return last + 2 - i;
+            }
+        }
         ROCM_CALL(infini_rocm_copy_inside(rt, dstT->getRawDataPtr<void *>(), dst, dstT->getBytes()));
+    }
     return last + 1 - i;
 }
 
@@ -214,22 +258,6 @@ size_t RocmRuntimeObj::tryLaunchFused(const OpVec &ops, size_t i) const {
     return tryLaunchIntoReshape(ops, i);
 }
 
-namespace {
-struct OutputRedirect { // RAII: the redirection never outlives one launch
-    OutputRedirect(const TensorObj *t, void *p, int seq = 0, int headDim = 0, int act = 0) {
-        RocmRuntimeObj::redirectTensor = t;
-        RocmRuntimeObj::redirectPtr = p;
-        RocmRuntimeObj::redirectSeq = seq;
-        RocmRuntimeObj::redirectHeadDim = headDim;
-        RocmRuntimeObj::redirectAct = act;
-    }
-    ~OutputRedirect() {
-        RocmRuntimeObj::redirectTensor = nullptr;
-        RocmRuntimeObj::redirectPtr = nullptr;
-        RocmRuntimeObj::redirectSeq = RocmRuntimeObj::redirectHeadDim = RocmRuntimeObj::redirectAct = 0;
-    }
-};
-} // namespace
 
 // MatMul(+bias) [.., S, H*D] or [B*S, H*D] -> Reshape [B, S, H, D] -> Transpose(0, 2, 1, 3): the head split of a
 // transformer's q / k / v projections (three launches and two extra passes over the activation in the reference) as ONE

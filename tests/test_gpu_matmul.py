@@ -275,3 +275,28 @@ def test_matmul_fast_gelu_epilogue(rt, dtype, tol, variant):
     want = R.unary("gelu", pre)
     assert np.allclose(host(y5), want, rtol=tol, atol=tol)
     assert np.allclose(host(y5), host(y4), rtol=tol, atol=tol / 4)
+
+
+def test_matmul_workspace_hint(rt):
+    """infini_rocm_matmul_may_use_workspace: split-K (the only MatMul path that takes the runtime workspace) is possible
+    only below ~0.6 tiles of 256^2 per CU, or when variant 3 is forced (rocm_fusion.cc parks an operand of the next MatMul
+    in the workspace only when the answer is 0)."""
+    import ctypes as C
+
+    from infinitensor_amd import lib
+    from infinitensor_amd._lib import check
+
+    def may(batch, m, n):
+        out = C.c_int(-1)
+        check(lib().infini_rocm_matmul_may_use_workspace(rt.handle, batch, m, n, C.byref(out)))
+        return out.value
+
+    assert may(1, 128, 1000) == 1        # ResNet's classifier: 4 tiles
+    assert may(1, 2048, 4096) == 1       # 128 tiles: the Llama down projection runs split-K
+    assert may(32, 512, 768) == 0        # BERT's output projection: 192 tiles of 256^2 ... plus batch: no split-K
+    assert may(1, 16384, 3072) == 0
+    ops.set_matmul_variant(rt, 3)
+    try:
+        assert may(1, 16384, 3072) == 1  # forced split-K
+    finally:
+        ops.set_matmul_variant(rt, -1)
