@@ -180,6 +180,15 @@ int infini_rocm_matmul_headsplit(infiniRocmRuntime_t rt, int dtype, const void *
                                  int trans_a, int trans_b, int64_t stride_a, int64_t stride_b,
                                  int64_t bias_stride_b, int64_t bias_stride_m, int64_t bias_stride_n,
                                  int act, int64_t seq, int64_t head_dim);
+/* The same with an explicit element stride between the batches' [m x n] output blocks (stride_c; 0 = m * n, i.e. exactly
+ * infini_rocm_matmul_headsplit): lets a caller run several MatMuls of ONE left operand that write separate tensors as one
+ * launch — batch index = member, stride_a = 0, stride_b / bias_stride_b / stride_c = the (uniform) distances between the
+ * members' weights / biases / outputs (rocm_fusion.cc: gate + up, q + k + v of a decoder block). */
+int infini_rocm_matmul_grouped(infiniRocmRuntime_t rt, int dtype, const void *a, const void *b,
+                               const void *bias, void *c, int64_t batch, int64_t m, int64_t n, int64_t k,
+                               int trans_a, int trans_b, int64_t stride_a, int64_t stride_b, int64_t stride_c,
+                               int64_t bias_stride_b, int64_t bias_stride_m, int64_t bias_stride_n,
+                               int act, int64_t seq, int64_t head_dim);
 /* May a matmul of this extent take the runtime workspace (split-K partial planes) under the current variant setting?
  * A caller that parks an operand of the NEXT matmul in the workspace (rocm_fusion.cc: the fused attention's output
  * feeding the output projection) asks first. *may = 1 is conservative: split-K is possible, not certain. */

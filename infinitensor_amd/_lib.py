@@ -86,6 +86,7 @@ def lib() -> C.CDLL:
     sig("infini_rocm_graph_destroy", [vp])
     sig("infini_rocm_matmul", [vp, i32, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i64, i64, i64, i64, i64, i32])
     sig("infini_rocm_matmul_headsplit", [vp, i32, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i64, i64, i64, i64, i64, i32, i64, i64])
+    sig("infini_rocm_matmul_grouped", [vp, i32, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i64, i64, i64, i64, i64, i64, i32, i64, i64])
     sig("infini_rocm_matmul_set_variant", [vp, i32])
     sig("infini_rocm_matmul_may_use_workspace", [vp, i64, i64, i64, C.POINTER(C.c_int)])
     sig("infini_rocm_matmul_num_variants", [], i32)

@@ -97,7 +97,7 @@ template <typename Tr> __global__ __launch_bounds__(256) void gemm_generic16(Gem
             else return v;
         };
         // C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
-        unsigned short *C = (unsigned short *)p.c + (long)ib * p.m * p.n;
+        unsigned short *C = (unsigned short *)p.c + (long)ib * p.c_bs;
         const unsigned short *bias = (const unsigned short *)p.bias;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void gemm_generic32(GemmArgs p) {
         }
         __syncthreads();
     }
-    float *C = (float *)p.c + (long)ib * p.m * p.n;
+    float *C = (float *)p.c + (long)ib * p.c_bs;
     const float *bias = (const float *)p.bias;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void gemm_fast128(GemmArgs p) {
             else if constexpr (ACT < 0) return apply_act(v, p.act);
             else return v;
         };
-        unsigned short *C = (unsigned short *)p.c + (long)ib * p.m * p.n;
+        unsigned short *C = (unsigned short *)p.c + (long)ib * p.c_bs;
         const unsigned short *bias = (const unsigned short *)p.bias;
         const bool interior = (m0 + BM <= p.m) && (n0 + BN <= p.n) && (p.n % 4 == 0);
         if (interior && (p.n % 8 == 0) && ((((uintptr_t)p.c) & 15) == 0)) {
@@ -522,7 +522,19 @@ int infini_rocm_matmul_headsplit(infiniRocmRuntime_t rt, int dtype, const void *
                                  int trans_a, int trans_b, int64_t stride_a, int64_t stride_b,
                                  int64_t bias_stride_b, int64_t bias_stride_m, int64_t bias_stride_n,
                                  int act, int64_t seq, int64_t head_dim) {
+    return infini_rocm_matmul_grouped(rt, dtype, a, b, bias, c, batch, m, n, k, trans_a, trans_b, stride_a, stride_b, 0,
+                                      bias_stride_b, bias_stride_m, bias_stride_n, act, seq, head_dim);
+}
+
+int infini_rocm_matmul_grouped(infiniRocmRuntime_t rt, int dtype, const void *a, const void *b,
+                               const void *bias, void *c, int64_t batch, int64_t m, int64_t n, int64_t k,
+                               int trans_a, int trans_b, int64_t stride_a, int64_t stride_b, int64_t stride_c,
+                               int64_t bias_stride_b, int64_t bias_stride_m, int64_t bias_stride_n,
+                               int act, int64_t seq, int64_t head_dim) {
     IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(stride_c == 0 || stride_c >= m * n || stride_c <= -(m * n) || batch <= 1,
+                    "matmul: output blocks of %lld elements overlap at a batch stride of %lld", (long long)(m * n), (long long)stride_c);
+    IROCM_CHECK_ARG(stride_c % 8 == 0, "matmul: the output batch stride must be a multiple of 8 elements (16-byte stores)");
     IROCM_CHECK_ARG((seq == 0) == (head_dim == 0), "matmul: seq and head_dim go together");
     if (head_dim) {
         IROCM_CHECK_ARG(seq > 0 && head_dim > 0 && head_dim % 8 == 0 && m % seq == 0 && n % head_dim == 0 &&
@@ -546,6 +558,7 @@ int infini_rocm_matmul_headsplit(infiniRocmRuntime_t rt, int dtype, const void *
     p.a_rs = trans_a ? 1 : k; p.a_cs = trans_a ? m : 1; p.a_bs = stride_a;
     p.b_rs = trans_b ? 1 : n; p.b_cs = trans_b ? k : 1; p.b_bs = stride_b;
     p.bias_b = bias_stride_b; p.bias_m = bias_stride_m; p.bias_n = bias_stride_n;
+    p.c_bs = stride_c ? stride_c : m * n;
     p.act = act;
     p.tiles_m = p.tiles_n = 0;
     p.splitk = 1;
@@ -596,8 +609,9 @@ int infini_rocm_matmul_headsplit(infiniRocmRuntime_t rt, int dtype, const void *
         variant = 0;
     }
 
-    if (variant >= 4 && !(act == 0 || act == 1 || act == 5))
-        variant = 2; // sigmoid / tanh / erff-Gelu epilogues live in the one-shot kernel only (gemm256p_kernel.h)
+    // sigmoid / tanh / erff-Gelu epilogues and biases other than one row vector live in the one-shot kernel (gemm256p_kernel.h)
+    if (variant >= 4 && (!(act == 0 || act == 1 || act == 5) || (p.bias && !(p.bias_m == 0 && p.bias_n == 1))))
+        variant = 2;
     if (variant == 4)
         return g256p::launch_gemm256p_nt4(rt, dtype, p, akm, bkm);
     if (variant == 5)

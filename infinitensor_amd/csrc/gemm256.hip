@@ -261,7 +261,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         }
         return;
     }
-    unsigned short *C = (unsigned short *)p.c + (long)ib * p.m * p.n;
+    unsigned short *C = (unsigned short *)p.c + (long)ib * p.c_bs;
     const unsigned short *bias = (const unsigned short *)p.bias;
     const bool interior = (m0 + BM <= p.m) && (n0 + BN <= p.n) && (p.n % 4 == 0);
     if (interior && p.epi16 && (p.n % 8 == 0) && ((((uintptr_t)p.c) & 15) == 0)) {
@@ -389,9 +389,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p) {
             u32x2_t pk;
             pk[0] = (unsigned)o[0] | ((unsigned)o[1] << 16);
             pk[1] = (unsigned)o[2] | ((unsigned)o[3] << 16);
-            *(u32x2_t *)(C + ib * mn + c_off(p, row, col)) = pk;
+            *(u32x2_t *)(C + ib * p.c_bs + c_off(p, row, col)) = pk;
         } else {
-            C[ib * mn + c_off(p, row, col)] = o[0];
+            C[ib * p.c_bs + c_off(p, row, col)] = o[0];
         }
     }
 }

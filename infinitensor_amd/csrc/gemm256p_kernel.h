@@ -261,14 +261,22 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
             else if constexpr (ACT == 5) return gelu_erf_as(v);
             else return v;
         };
-        unsigned short *C = (unsigned short *)p.c + (long)ib * p.m * p.n;
+        unsigned short *C = (unsigned short *)p.c + (long)ib * p.c_bs;
         const unsigned short *bias = (const unsigned short *)p.bias;
         const bool interior = (m0 + BM <= p.m) && (n0 + BN_ <= p.n) && (p.n % 4 == 0);
-        // The usual bias is one row vector [n] (bias_m == 0, bias_n == 1): a lane's 4 NT bias values are fetched ONCE per
-        // tile (one 8-byte load per column tile) instead of once per accumulator element (128 scalar loads per lane,
-        // each followed by the compiler's vmcnt(0) — that also drained the DMA pipeline of the next tile).
-        const bool rowbias = bias && p.bias_m == 0 && p.bias_n == 1;
+        // Bias: none or ONE row vector [n] (bias_m == 0, bias_n == 1; launch_p admits nothing else): a lane's 4 NT values are
+        // fetched ONCE per tile (one 8-byte load per column tile) instead of once per accumulator element (128 scalar loads
+        // per lane, each followed by the compiler's vmcnt(0) — that also drained the DMA pipeline of the next tile). The
+        // general forms (column vectors, full matrices) live in the one-shot kernel: their strides cost this kernel four
+        // scalar registers it does not have — at 106 SGPRs ONE more 64-bit argument (the output batch stride) tipped the
+        // 256-column build into 408-468 bytes of scratch per lane and 76 -> 116 us on BERT's FFN1.
+        const bool rowbias = bias != nullptr;
         float bv[NT][4];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                bv[j][r] = 0.f;
         if (rowbias) {
             const unsigned short *bb = bias + (long)ib * p.bias_b;
             const bool al8 = ((((uintptr_t)bb) & 7) == 0);
@@ -295,19 +303,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 v[r] = acc[i][j][r];
-            if (rowbias) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    v[r] += bv[j][r];
-            } else if (bias) {
-                const unsigned short *bp = bias + (long)ib * p.bias_b + (long)row * p.bias_m + (long)col * p.bias_n;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    v[r] += Tr::to_f32(bp[(long)r * p.bias_n]);
-            }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                v[r] = act1(v[r]);
+                v[r] = act1(v[r] + bv[j][r]);
             pk[0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
             pk[1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
         };
@@ -369,10 +367,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (row < p.m && col + r < p.n) {
-                        float v = acc[i][j][r];
-                        if (bias)
-                            v += Tr::to_f32(bias[(long)ib * p.bias_b + (long)row * p.bias_m + (long)(col + r) * p.bias_n]);
-                        C[c_off(p, row, col + r)] = Tr::from_f32(act1(v));
+                        C[c_off(p, row, col + r)] = Tr::from_f32(act1(acc[i][j][r] + bv[j][r]));
                     }
                 }
             }
@@ -481,8 +476,8 @@ static int launch_p(infiniRocmRuntime_t rt, GemmArgs g, bool akm, bool bkm, unsi
     PArgs pa;
     pa.trace = trace;
     constexpr int kLds = LDS_BYTES + (TRACE ? 8 * kTraceSlots * 8 : 0);
-    if (!(g.act == 0 || g.act == 1 || g.act == 5))
-        IROCM_FAIL(INFINI_ROCM_UNSUPPORTED, "gemm256p: activation %d is not served by the persistent kernels", g.act);
+    if (!(g.act == 0 || g.act == 1 || g.act == 5) || (g.bias && !(g.bias_m == 0 && g.bias_n == 1)))
+        IROCM_FAIL(INFINI_ROCM_UNSUPPORTED, "gemm256p: activation %d / this bias layout is not served by the persistent kernels", g.act);
     g.tiles_m = (int)ceil_div(g.m, BM);
     g.tiles_n = (int)ceil_div(g.n, 64 * NT);
     const long total = (long)g.tiles_m * g.tiles_n * g.batch;

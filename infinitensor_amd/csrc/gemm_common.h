@@ -24,6 +24,7 @@ struct GemmArgs {
     long a_rs, a_cs, a_bs;
     long b_rs, b_cs, b_bs;
     long bias_b, bias_m, bias_n;
+    long c_bs; // element stride between the batches' [m x n] output blocks (m * n unless the caller groups separate tensors)
     int act;
     int tiles_m, tiles_n;
     // split-K (gemm256 only): `splitk` workgroups share one output tile, each sums a slice of K into its own fp32

@@ -195,6 +195,35 @@ def set_conv_variant(rt: RocmRuntime, variant: int) -> None:
     check(lib().infini_rocm_conv2d_set_variant(rt.handle, int(variant)))
 
 
+def matmul_grouped(rt: RocmRuntime, a: torch.Tensor, ws: list, outs: list, biases: list | None = None, act: int = 0) -> list:
+    """Several MatMuls of ONE left operand `a` [m, k] with separate weights `ws[j]` [k, n] (and row biases [n]) into separate
+    outputs `outs[j]` [m, n], as one launch: batch index = member, zero A stride. The members' weights, biases and outputs
+    must sit at uniform distances in memory (infini_rocm_matmul_grouped); raises ValueError otherwise."""
+    g = len(ws)
+    if g < 1 or len(outs) != g or (biases is not None and len(biases) != g):
+        raise ValueError("matmul_grouped: one weight, output (and bias) per member")
+    m, k = a.shape
+    n = ws[0].shape[1]
+    es = a.element_size()
+
+    def stride(ts):
+        if g == 1:
+            return 0
+        d = ts[1].data_ptr() - ts[0].data_ptr()
+        if d % es or any(t.data_ptr() - ts[0].data_ptr() != j * d for j, t in enumerate(ts)):
+            raise ValueError("matmul_grouped: members are not uniformly spaced in memory")
+        return d // es
+
+    for w, o in zip(ws, outs):
+        if tuple(w.shape) != (k, n) or tuple(o.shape) != (m, n) or w.dtype != a.dtype or o.dtype != a.dtype:
+            raise ValueError("matmul_grouped: members must share shapes and dtype")
+    sb, sc = stride(ws), stride(outs)
+    sbias = stride(biases) if biases is not None else 0
+    check(lib().infini_rocm_matmul_grouped(rt.handle, dtype_of(a), _ptr(a), _ptr(ws[0]), _ptr(biases[0]) if biases is not None else None,
+                                           _ptr(outs[0]), g, m, n, k, 0, 0, 0, sb, sc, sbias, 0, 1 if biases is not None else 0, int(act), 0, 0))
+    return outs
+
+
 def matmul_variants() -> list[str]:
     n = lib().infini_rocm_matmul_num_variants()
     return [lib().infini_rocm_matmul_variant_name(i).decode() for i in range(n)]

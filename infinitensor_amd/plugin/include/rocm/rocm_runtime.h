@@ -6,6 +6,7 @@
 // capture/replay cache keyed by the graph's capture state (same invalidation rules as the reference's
 // CUDA-graph cache, cuda_runtime.cc:210-426).
 #pragma once
+#include <vector>
 #include "core/communicator.h"
 #include "core/runtime.h"
 #include "core/tensor.h"
@@ -113,6 +114,7 @@ class RocmRuntimeObj : public RuntimeObj {
     void launchAll(const Graph &graph, bool validate) const;
     // launches ops[i .. i+k) as one kernel when a fusion rule applies; returns k (0 = no rule)
     size_t tryLaunchFused(const OpVec &ops, size_t i) const;
+    size_t tryLaunchGroupedMatmul(const OpVec &ops, size_t i) const;
     size_t tryLaunchFusedRules(const OpVec &ops, size_t i) const;
     size_t tryLaunchIntoReshape(const OpVec &ops, size_t i) const;
     size_t tryLaunchHeadSplit(const OpVec &ops, size_t i) const;
@@ -133,6 +135,7 @@ class RocmRuntimeObj : public RuntimeObj {
     bool fusion = true;
     mutable size_t fusedCount = 0;
     mutable size_t bridgedCount = 0;
+    mutable std::vector<char> launchedAhead; // per launchAll: operators a grouped launch already ran out of order
     Cache cache; // most recently used first
     mutable std::recursive_mutex executionMutex;
     mutable std::recursive_mutex cacheMutex;

@@ -105,8 +105,11 @@ void RocmRuntimeObj::launchAll(const Graph &graph, bool validate) const {
     if (validate)
         graph->validateMemory();
     const OpVec &ops = graph->getOperators();
+    launchedAhead.assign(ops.size(), 0);
     for (size_t i = 0; i < ops.size(); ++i) {
         const Operator &op = ops[i];
+        if (launchedAhead[i]) // ran as a member of an earlier grouped launch (rocm_fusion.cc::tryLaunchGroupedMatmul)
+            continue;
         if (fusion) {
             size_t fused = 0;
             try {

@@ -300,3 +300,34 @@ def test_matmul_workspace_hint(rt):
         assert may(1, 16384, 3072) == 1  # forced split-K
     finally:
         ops.set_matmul_variant(rt, -1)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+@pytest.mark.parametrize("variant", [-1, 2, 4, 5, 6])
+def test_matmul_grouped_members_at_a_stride(rt, dtype, tol, variant):
+    """infini_rocm_matmul_grouped: three MatMuls of one activation whose weights / biases / OUTPUTS are separate tensors at
+    uniform distances (carved out of slabs with gaps) run as one launch; every member equals its own plain matmul bit for
+    bit (same kernel, same sums), and the gaps between the outputs stay untouched."""
+    rng = np.random.default_rng(61)
+    m, k, n, g = 640, 256, 384, 3
+    a = dev(rng.standard_normal((m, k)).astype(np.float32), dtype)
+    wslab = dev((rng.standard_normal((g, k * n + 64)) / 16).astype(np.float32), dtype)
+    bslab = dev(rng.standard_normal((g, n + 8)).astype(np.float32), dtype)
+    oslab = torch.full((g, m * n + 128), 7.0, dtype=dtype, device="cuda")
+    ws = [wslab[j, : k * n].view(k, n) for j in range(g)]
+    bs = [bslab[j, :n] for j in range(g)]
+    outs = [oslab[j, : m * n].view(m, n) for j in range(g)]
+    ops.set_matmul_variant(rt, variant)
+    try:
+        ops.matmul_grouped(rt, a, ws, outs, bs, act=1)
+        singles = [ops.matmul(rt, a, ws[j], bs[j], act=1) for j in range(g)]
+    finally:
+        ops.set_matmul_variant(rt, -1)
+    rt.sync()
+    for j in range(g):
+        assert torch.equal(outs[j], singles[j]), j
+        want = np.maximum(R.matmul(host(a), host(ws[j]), host(bs[j])), 0)
+        assert np.allclose(host(outs[j]), want, rtol=tol, atol=tol)
+        assert torch.all(oslab[j, m * n:] == 7.0).item()  # the gap behind every member
+    with pytest.raises(ValueError):
+        ops.matmul_grouped(rt, a, [ws[0], ws[2], ws[1]], outs, bs)  # not a uniform progression

@@ -750,6 +750,54 @@ def test_grouped_qkv_head_split_is_bit_identical(B, rocm):
         assert np.allclose(got[True][j].astype(np.float64), want, rtol=4e-3, atol=4e-3)
 
 
+def test_grouped_plain_matmuls_are_hoisted_safely(B, rocm):
+    """A decoder block's gate / up pattern — mm_g, Silu, mm_u, Mul — and three projections ahead of element-wise ops: the
+    MatMuls of one activation run as ONE grouped launch, the later members ahead of their place in the list
+    (rocm_fusion.cc::tryLaunchGroupedMatmul). Identical bits to the per-operator run; the operators that were jumped over
+    still see their own inputs."""
+    rng = np.random.default_rng(47)
+    T, H, Fd = 512, 256, 768
+    x = rng.standard_normal((T, H)).astype(np.float16)
+    wg, wu = [(rng.standard_normal((H, Fd)) / 16).astype(np.float16) for _ in range(2)]
+    wq, wk, wv = [(rng.standard_normal((H, H)) / 16).astype(np.float16) for _ in range(3)]
+    arrays = [x, wg, wu, wq, wk, wv]
+    lin = B.ActType.Linear
+    got, launches = {}, {}
+    try:
+        for on in (True, False):
+            rocm.set_fusion(on)
+            h = B.GraphHandler(rocm)
+            ts = [h.tensor(list(a.shape), F16) for a in arrays]
+            for t in ts[1:]:
+                t.set_weight()
+            mm = lambda a, w: h.matmul(a, w, None, False, False, None, lin, "default")
+            xin = h.relu(ts[0], None)  # the shared activation is itself an intermediate
+            # The raw products stay alive to the end of the graph (they are outputs too): otherwise the planner hands mm_g's
+            # buffer to mm_u as soon as Silu has read it, and the rule rightly refuses to run mm_u ahead of Silu.
+            g_raw = mm(xin, ts[1])
+            gated = h.mul(h.silu(g_raw, None), mm(xin, ts[2]), None)
+            q_raw, k_raw = mm(xin, ts[3]), mm(xin, ts[4])
+            q, k, v = h.neg(q_raw, None), h.abs(k_raw, None), h.sigmoid(mm(xin, ts[5]), None)
+            outs = [gated, q, k, v, g_raw, q_raw, k_raw]
+            h.data_malloc()
+            for t, a in zip(ts, arrays):
+                put(t, a)
+            before = rocm.fused_launch_count()
+            h.run()
+            launches[on] = rocm.fused_launch_count() - before
+            got[on] = [get(o) for o in outs]
+    finally:
+        rocm.set_fusion(True)
+    assert launches[False] == 0 and launches[True] >= 1  # at least the gate / up pair (two members always sit "uniformly")
+    for a, b in zip(got[True], got[False]):
+        assert np.array_equal(a, b)
+    xr = np.maximum(x.astype(np.float64), 0)
+    silu = lambda t: t / (1 + np.exp(-t))
+    r16 = lambda t: t.astype(np.float16).astype(np.float64)
+    want = r16(silu(r16(xr @ wg.astype(np.float64)))) * r16(xr @ wu.astype(np.float64))
+    assert np.allclose(got[True][0].astype(np.float64), want, rtol=6e-3, atol=6e-3)
+
+
 # ---- hipGraph cache: the remaining cases of test/cuda/test_cudagraph.cc, through backend.RocmRuntime -----------------
 class _GraphFixture:
     """CudaGraphFixture of test_cudagraph.cc:29-72: input [batch, 2] @ identity weight [2, 2] -> Relu."""
