@@ -82,14 +82,19 @@ struct F16Traits {
 // rounding): ~18 VALU slots instead of erff's ~40, so it can ride in a GEMM epilogue. 1 +- erf is formed without
 // cancellation: 1 - erf(z) = poly(t) e^{-z^2}.
 __device__ static inline float gelu_erf_as(float v) {
-    const float z = fabsf(v) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    // 0.5 v (1 + erf(v / sqrt 2)) = max(v, 0) - 0.5 |v| c  with  c = 1 - erf(|v| / sqrt 2) = poly(t) t e^{-v^2 / 2}: one form for
+    // both signs, the two scale factors folded into constants
+    // (p / sqrt 2; sqrt(log2 e / 2) so that exp2 takes -(k |v|)^2 directly): 14 plain VALU + rcp + exp2 per element.
+    // |v| is clamped at 1e4 (c is exactly 0 long before) so that +inf gives inf, not inf * 0; the relu part carries a NaN.
+    const float a = fminf(fabsf(v), 1.0e4f);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, a, 1.0f));
     float q = fmaf(1.061405429f, t, -1.453152027f);
     q = fmaf(q, t, 1.421413741f);
     q = fmaf(q, t, -0.284496736f);
     q = fmaf(q, t, 0.254829592f);
-    const float c = q * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z); // 1 - erf(z), z >= 0
-    return 0.5f * v * (v >= 0.f ? 2.0f - c : c);
+    const float zz = a * 0.84932180028801904272f; // sqrt(log2(e) / 2)
+    const float c = (q * t) * __builtin_amdgcn_exp2f(-(zz * zz));
+    return fmaf(-0.5f, a * c, v < 0.f ? 0.f : v);
 }
 
 // Fused epilogue activation (reference ActType: include/core/common.h — None/Relu/Sigmoid/Tanh).
