@@ -13,7 +13,8 @@ from infinitensor_amd import RocmRuntime, ops
 
 rt = RocmRuntime(0)
 rt.use_torch_stream()
-rng = np.random.default_rng(77)
+import os
+rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "77")))
 n_conv = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 n_attn = int(sys.argv[2]) if len(sys.argv) > 2 else 80
 bad = 0

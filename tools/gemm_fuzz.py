@@ -11,7 +11,8 @@ from infinitensor_amd import RocmRuntime, ops
 
 rt = RocmRuntime(0)
 rt.use_torch_stream()
-rng = np.random.default_rng(2024)
+import os
+rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "2024")))
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 ACT = {0: lambda x: x, 1: torch.relu, 2: torch.sigmoid, 3: torch.tanh, 4: lambda x: torch.nn.functional.gelu(x),
        5: lambda x: torch.nn.functional.gelu(x)}
