@@ -181,7 +181,8 @@ int infini_rocm_matmul_headsplit(infiniRocmRuntime_t rt, int dtype, const void *
                                  int64_t bias_stride_b, int64_t bias_stride_m, int64_t bias_stride_n,
                                  int act, int64_t seq, int64_t head_dim);
 /* The same with an explicit element stride between the batches' [m x n] output blocks (stride_c; 0 = m * n, i.e. exactly
- * infini_rocm_matmul_headsplit): lets a caller run several MatMuls of ONE left operand that write separate tensors as one
+ * infini_rocm_matmul_headsplit). Replaces several matmulCublas calls (src/kernels/cuda/matmul.cc:67-174, one per MatMul
+ * operator) that share their left operand: lets a caller run several MatMuls of ONE left operand that write separate tensors as one
  * launch — batch index = member, stride_a = 0, stride_b / bias_stride_b / stride_c = the (uniform) distances between the
  * members' weights / biases / outputs (rocm_fusion.cc: gate + up, q + k + v of a decoder block). */
 int infini_rocm_matmul_grouped(infiniRocmRuntime_t rt, int dtype, const void *a, const void *b,
