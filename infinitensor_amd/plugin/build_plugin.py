@@ -74,6 +74,7 @@ PATCHES = [
      "        .def(\"get_fusion\", &RocmRuntimeObj::getFusion)\n"
      "        .def(\"fused_launch_count\", &RocmRuntimeObj::getFusedLaunchCount)\n"
      "        .def(\"bridged_input_count\", &RocmRuntimeObj::getBridgedInputCount)\n"
+     "        .def(\"parked_member_count\", &RocmRuntimeObj::getParkedMemberCount)\n"
      "        .def_static(\"save_perf\", &RocmRuntimeObj::savePerfData)\n"
      "        .def_static(\"load_perf\", &RocmRuntimeObj::loadPerfData)\n"
      "        .def_static(\"clear_perf\", &RocmRuntimeObj::clearPerfData)\n"

@@ -6,6 +6,7 @@
 // capture/replay cache keyed by the graph's capture state (same invalidation rules as the reference's
 // CUDA-graph cache, cuda_runtime.cc:210-426).
 #pragma once
+#include <map>
 #include <vector>
 #include "core/communicator.h"
 #include "core/runtime.h"
@@ -58,6 +59,7 @@ class RocmRuntimeObj : public RuntimeObj {
     bool getFusion() const { return fusion; }
     size_t getFusedLaunchCount() const { return fusedCount; } // fused kernels launched so far (tests)
     size_t getBridgedInputCount() const { return bridgedCount; } // fused convs that read a workspace copy of their input
+    size_t getParkedMemberCount() const { return parkedCount; }   // grouped MatMul members whose result was parked in the workspace
 
     // the autotune cache: h.tune() fills the process-wide PerfEngine (MatMul / Conv pick among their kernel variants,
     // rocm/rocm_perf.h); these persist it as JSON and bring it back (reference: PerfEngine::savePerfEngineData /
@@ -115,6 +117,7 @@ class RocmRuntimeObj : public RuntimeObj {
     // launches ops[i .. i+k) as one kernel when a fusion rule applies; returns k (0 = no rule)
     size_t tryLaunchFused(const OpVec &ops, size_t i) const;
     size_t tryLaunchGroupedMatmul(const OpVec &ops, size_t i) const;
+    void launchWithInputRedirect(const Operator &op, const TensorObj *t, void *ptr) const;
     size_t tryLaunchFusedRules(const OpVec &ops, size_t i) const;
     size_t tryLaunchIntoReshape(const OpVec &ops, size_t i) const;
     size_t tryLaunchHeadSplit(const OpVec &ops, size_t i) const;
@@ -136,6 +139,14 @@ class RocmRuntimeObj : public RuntimeObj {
     mutable size_t fusedCount = 0;
     mutable size_t bridgedCount = 0;
     mutable std::vector<char> launchedAhead; // per launchAll: operators a grouped launch already ran out of order
+    // per launchAll: operator index -> (tensor, pointer): this operator reads `tensor` from `pointer` (a result a grouped launch
+    // parked in the workspace because the tensor's own buffer was still in use when the group ran); launched without fusion
+    struct ParkedFeed {
+        const TensorObj *tensor;
+        void *ptr;
+    };
+    mutable std::map<size_t, ParkedFeed> parkedFeeds;
+    mutable size_t parkedCount = 0;
     Cache cache; // most recently used first
     mutable std::recursive_mutex executionMutex;
     mutable std::recursive_mutex cacheMutex;

@@ -121,6 +121,11 @@ struct OutputRedirect { // RAII: the redirection never outlives one launch
 };
 } // namespace
 
+void RocmRuntimeObj::launchWithInputRedirect(const Operator &op, const TensorObj *t, void *ptr) const {
+    OutputRedirect feed(t, ptr); // P(t) resolves to ptr for the duration of this one launch (rocm_kernels.cc)
+    launchOne(op);
+}
+
 size_t RocmRuntimeObj::tryLaunchFusedAttention(const OpVec &ops, size_t i) const {
     auto mm1 = as<MatmulObj>(ops[i]);
     if (mm1->getTransA() || !mm1->getTransB() || mm1->getBias() || mm1->getAct() != ActType::None)
@@ -457,6 +462,13 @@ size_t RocmRuntimeObj::tryLaunchGroupedMatmul(const OpVec &ops, size_t i) const 
     };
     touch(ops[i]);
     std::vector<Tensor> producedBetween; // outputs of the jumped-over operators
+    size_t parkAt = 0;                   // index of the member whose result goes to the workspace (0: none)
+    auto wsQuiet = [](const Operator &o) { // kernels that never take the runtime workspace
+        const auto t = o->getOpType();
+        return t.isUnary() || t == OpType::Silu || t == OpType::Add || t == OpType::Sub || t == OpType::Mul || t == OpType::Div ||
+               t == OpType::RoPE || t == OpType::Reshape || t == OpType::Flatten || t == OpType::Identity || t == OpType::Squeeze ||
+               t == OpType::Unsqueeze || t == OpType::Transpose;
+    };
     constexpr size_t kWindow = 12;
     for (size_t j = i + 1; j < ops.size() && j <= i + kWindow && members.size() < 4; ++j) {
         bool member = false;
@@ -468,15 +480,39 @@ size_t RocmRuntimeObj::tryLaunchGroupedMatmul(const OpVec &ops, size_t i) const 
                      mjm == m0 && nj == n0 && kj == k0 && (bj_t != nullptr) == (bias0 != nullptr) &&
                      mj->getOutput()->getDims() == mm0->getOutput()->getDims();
             const Tensor outj = mj->getOutput();
-            for (size_t q = 0; member && q < touched.size(); ++q)
-                member = !overlaps(outj, touched[q]);
+            bool clear = true; // the member's own output buffer is free at the group's position
+            for (size_t q = 0; member && clear && q < touched.size(); ++q)
+                clear = !overlaps(outj, touched[q]);
             for (size_t q = 0; member && q < producedBetween.size(); ++q)
                 for (const auto &in : mj->getInputs())
                     member = member && !overlaps(producedBetween[q], in);
+            // The planner usually recycles: mm_u's output sits where mm_g's was (dead once Silu has read it). Then the member's
+            // result is PARKED in the workspace and its one consumer — the very next operator, an element-wise / RoPE kernel —
+            // reads it from there (parkedFeeds). Two-member groups only (member = batch index needs ONE output stride), nothing
+            // between the group and that consumer may use the workspace, and the grouped MatMul itself must not (split-K).
+            if (member && !clear) {
+                int mayWs = 1;
+                const auto [gb, gm, gn, gk] = mj->getBMNK();
+                ROCM_CALL(infini_rocm_matmul_may_use_workspace(rt, 2, (int64_t)gb * gm, gn, &mayWs));
+                bool quiet = members.size() == 1 && parkAt == 0 && !mayWs && j + 1 < ops.size() && soleConsumerIs(outj, ops[j + 1]) &&
+                             wsQuiet(ops[j + 1]) && tunedVariant(ops[j + 1]) < 0;
+                for (size_t b = i + 1; quiet && b < j; ++b)
+                    quiet = wsQuiet(ops[b]);
+                int uses = 0;
+                if (quiet)
+                    for (const auto &in : ops[j + 1]->getInputs())
+                        uses += in == outj;
+                if (quiet && uses == 1)
+                    parkAt = j;
+                else
+                    member = false;
+            }
         }
         touch(ops[j]);
         if (member) {
             members.push_back(j);
+            if (parkAt == j)
+                break; // a parked member closes the group
         } else {
             for (const auto &t : ops[j]->getOutputs())
                 producedBetween.push_back(t);
@@ -502,10 +538,21 @@ size_t RocmRuntimeObj::tryLaunchGroupedMatmul(const OpVec &ops, size_t i) const 
     };
     size_t cnt = members.size();
     intptr_t dw = 0, db = 0, dc = 0;
-    while (cnt >= 2 && !uniform(cnt, dw, db, dc))
-        --cnt;
-    if (cnt < 2)
-        return 0;
+    void *park = nullptr;
+    if (parkAt) { // exactly two members: the second one's result goes to the workspace
+        park = getWorkspace((size_t)cBytes);
+        auto W1 = as<MatmulObj>(ops[members[1]])->getInputs(1);
+        dw = addr(W1) - addr(w0);
+        db = bias0 ? addr(as<MatmulObj>(ops[members[1]])->getInputs(2)) - addr(bias0) : 0;
+        dc = (intptr_t)park - addr(mm0->getOutput());
+        if (cnt != 2 || dw % 16 != 0 || db % es != 0 || dc % 16 != 0 || (dc < cBytes && dc > -cBytes))
+            return 0;
+    } else {
+        while (cnt >= 2 && !uniform(cnt, dw, db, dc))
+            --cnt;
+        if (cnt < 2)
+            return 0;
+    }
     // rows: the batch folds into m when the weight is shared (rank-2 w) and A is dense
     const int64_t rows = (int64_t)b0 * m0;
     if (std::getenv("INFINI_ROCM_FUSION_LOG"))
@@ -517,6 +564,10 @@ size_t RocmRuntimeObj::tryLaunchGroupedMatmul(const OpVec &ops, size_t i) const 
                                          mm0->getTransB() ? 1 : 0, /*strideA*/ 0, dw / es, dc / es, db / es, 0, bias0 ? 1 : 0, 0, 0, 0));
     for (size_t q = 1; q < cnt; ++q)
         launchedAhead[members[q]] = 1;
+    if (parkAt) {
+        parkedFeeds[parkAt + 1] = ParkedFeed{ops[parkAt]->getOutput().get(), park};
+        ++parkedCount;
+    }
     return 1;
 }
 

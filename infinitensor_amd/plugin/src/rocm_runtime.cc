@@ -106,10 +106,15 @@ void RocmRuntimeObj::launchAll(const Graph &graph, bool validate) const {
         graph->validateMemory();
     const OpVec &ops = graph->getOperators();
     launchedAhead.assign(ops.size(), 0);
+    parkedFeeds.clear();
     for (size_t i = 0; i < ops.size(); ++i) {
         const Operator &op = ops[i];
         if (launchedAhead[i]) // ran as a member of an earlier grouped launch (rocm_fusion.cc::tryLaunchGroupedMatmul)
             continue;
+        if (auto it = parkedFeeds.find(i); it != parkedFeeds.end()) { // reads a parked group result: plain launch, input redirected
+            launchWithInputRedirect(op, it->second.tensor, it->second.ptr);
+            continue;
+        }
         if (fusion) {
             size_t fused = 0;
             try {

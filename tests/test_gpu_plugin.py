@@ -798,6 +798,56 @@ def test_grouped_plain_matmuls_are_hoisted_safely(B, rocm):
     assert np.allclose(got[True][0].astype(np.float64), want, rtol=6e-3, atol=6e-3)
 
 
+def test_grouped_matmul_member_parked_in_the_workspace(B, rocm):
+    """The same gate / up and q / k patterns as a real graph has them: the raw products are NOT kept alive, so the planner puts
+    mm_u's output where mm_g's was (dead once Silu has read it). The group still runs as one launch: the second member's
+    result is parked in the workspace and its one consumer (Mul / Abs, the next operator) reads it from there
+    (`parked_member_count`). Identical bits to the per-operator run."""
+    rng = np.random.default_rng(53)
+    T, H, Fd = 4096, 256, 2816  # big enough that the grouped GEMM cannot be a split-K one (which would want the workspace itself)
+    x = rng.standard_normal((T, H)).astype(np.float16)
+    wg, wu = [(rng.standard_normal((H, Fd)) / 16).astype(np.float16) for _ in range(2)]
+    wq, wk = [(rng.standard_normal((H, Fd)) / 16).astype(np.float16) for _ in range(2)]
+    arrays = [x, wg, wu, wq, wk]
+    lin = B.ActType.Linear
+    got, parked = {}, {}
+    try:
+        for on in (True, False):
+            rocm.set_fusion(on)
+            h = B.GraphHandler(rocm)
+            ts = [h.tensor(list(a.shape), F16) for a in arrays]
+            for t in ts[1:]:
+                t.set_weight()
+            mm = lambda a, w: h.matmul(a, w, None, False, False, None, lin, "default")
+            xin = h.relu(ts[0], None)
+            gated = h.mul(h.silu(mm(xin, ts[1]), None), mm(xin, ts[2]), None)
+            q, k = h.neg(mm(xin, ts[3]), None), h.abs(mm(xin, ts[4]), None)
+            qk = h.add(q, k, None)
+            outs = [gated, qk]
+            h.data_malloc()
+            for t, a in zip(ts, arrays):
+                put(t, a)
+            before = rocm.parked_member_count()
+            h.run()
+            first = [get(o) for o in outs]
+            put(ts[0], x)  # the planner recycles the input's buffer: feed it again before the second run
+            h.run_with_hipgraph()  # the parked pointer is part of the captured graph
+            parked[on] = rocm.parked_member_count() - before
+            got[on] = [get(o) for o in outs]
+            for a, b in zip(first, got[on]):
+                assert np.array_equal(a, b)
+    finally:
+        rocm.set_fusion(True)
+    assert parked[False] == 0
+    for a, b in zip(got[True], got[False]):
+        assert np.array_equal(a, b)
+    xr = np.maximum(x.astype(np.float64), 0)
+    r16 = lambda t: t.astype(np.float16).astype(np.float64)
+    want = r16(-r16(xr @ wq.astype(np.float64))) + r16(np.abs(r16(xr @ wk.astype(np.float64))))
+    assert np.allclose(got[True][1].astype(np.float64), want, rtol=6e-3, atol=6e-3)
+    assert parked[True] >= 1  # the planner recycles mm_g's buffer for mm_u here: the parked path is what ran
+
+
 # ---- hipGraph cache: the remaining cases of test/cuda/test_cudagraph.cc, through backend.RocmRuntime -----------------
 class _GraphFixture:
     """CudaGraphFixture of test_cudagraph.cc:29-72: input [batch, 2] @ identity weight [2, 2] -> Relu."""
