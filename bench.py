@@ -292,7 +292,7 @@ def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
         x1 = ops.binary(rt, "add", x, o)
         h2 = ops.rms_norm(rt, x1, n2, 1e-5)
         gu = ops.matmul(rt, h2, w_gu)  # gate and up projections grouped the same way (330 -> 286 us at TP = 1)
-        a = ops.binary(rt, "mul", ops.unary(rt, "silu", gu[0]), gu[1])
+        a = ops.silu_mul(rt, gu[0], gu[1])  # Silu -> Mul as one pass (bit-identical to the two kernels)
         d = ops.matmul(rt, a, w_d)
         if reduce:
             ops.all_reduce(rt, "sum", d, out=d)

@@ -338,6 +338,11 @@ typedef enum {
 int infini_rocm_unary(infiniRocmRuntime_t rt, int op, int dtype, const void *x, void *y,
                       int64_t n, float p0, float p1);
 
+/* y = silu(a) * b over n elements, same shape (a gated MLP's Silu -> Mul pair, reference: unary.cu silu + element_wise.cu mul,
+ * two launches and one extra pass over the tensor). The Silu value is rounded to the tensor's dtype before the product:
+ * bit-identical to the two-kernel chain. Operands 16-byte aligned; y may alias a or b. */
+int infini_rocm_silu_mul(infiniRocmRuntime_t rt, int dtype, const void *a, const void *b, void *y, int64_t n);
+
 /* Cast between dtypes (reference: CastCuda, src/kernels/cuda/unary.cc:30-68, 5 of the 26
  * CastTypes; here any pair of {F32,F16,BF16,F64,I8,U8,I16,I32,I64,U32,BOOL}). Float->int
  * truncates toward zero like a C cast (reference cast kernel: `(T)x`). */

@@ -111,6 +111,7 @@ def lib() -> C.CDLL:
     sig("infini_rocm_rope", [vp, i32, i32, vp, vp, vp, i64, i64, i64, f32])
     sig("infini_rocm_binary", [vp, i32, i32, vp, vp, vp, i32, pi64, pi64, pi64])
     sig("infini_rocm_unary", [vp, i32, i32, vp, vp, i64, f32, f32])
+    sig("infini_rocm_silu_mul", [vp, i32, vp, vp, vp, i64])
     sig("infini_rocm_cast", [vp, i32, i32, vp, vp, i64])
     sig("infini_rocm_conv2d", [vp, i32, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, i64, i32])
     sig("infini_rocm_reduce", [vp, i32, i32, vp, vp, i32, pi64, C.POINTER(i32)])

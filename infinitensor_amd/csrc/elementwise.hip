@@ -356,6 +356,39 @@ __global__ __launch_bounds__(256) void unary_kernel_unaligned(const T *__restric
         Cvt<T>::store(y + i, un_op<OP>((float)Cvt<T>::load(x + i), p0, p1));
 }
 
+// y = silu(a) * b (a gated MLP's Silu -> Mul pair as one pass): the Silu value is rounded to T before the product, exactly as
+// the separate Silu kernel would have stored it, so the result is bit-identical to the two-kernel chain.
+template <typename T>
+__global__ __launch_bounds__(256) void silu_mul_kernel(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ y, long n) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const long nvec = n / VEC;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
+        const VecT<T, VEC> ta = reinterpret_cast<const VecT<T, VEC> *>(a)[v], tb = reinterpret_cast<const VecT<T, VEC> *>(b)[v];
+        VecT<T, VEC> o;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            T s_;
+            Cvt<T>::store(&s_, un_op<INFINI_UN_SILU>((float)Cvt<T>::load(&ta.v[j]), 0.f, 0.f));
+            Cvt<T>::store(&o.v[j], (float)Cvt<T>::load(&s_) * (float)Cvt<T>::load(&tb.v[j]));
+        }
+        reinterpret_cast<VecT<T, VEC> *>(y)[v] = o;
+    }
+    const long tail0 = nvec * VEC;
+    if (blockIdx.x == 0 && tail0 + threadIdx.x < n) {
+        T s_;
+        Cvt<T>::store(&s_, un_op<INFINI_UN_SILU>((float)Cvt<T>::load(a + tail0 + threadIdx.x), 0.f, 0.f));
+        Cvt<T>::store(y + tail0 + threadIdx.x, (float)Cvt<T>::load(&s_) * (float)Cvt<T>::load(b + tail0 + threadIdx.x));
+    }
+}
+
+template <typename T> static int silu_mul_launch(infiniRocmRuntime_t rt, const void *a, const void *b, void *y, int64_t n) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const unsigned grid = capped_grid(ceil_div(n, VEC), rt->num_cu);
+    hipLaunchKernelGGL((silu_mul_kernel<T>), dim3(grid), dim3(256), 0, rt->stream, (const T *)a, (const T *)b, (T *)y, (long)n);
+    IROCM_LAUNCH_CHECK("silu_mul");
+    return INFINI_ROCM_OK;
+}
+
 template <typename T, int OP>
 static int unary_launch(infiniRocmRuntime_t rt, const void *x, void *y, int64_t n, float p0, float p1) {
     constexpr int VEC = 16 / (int)sizeof(T);
@@ -511,6 +544,22 @@ int infini_rocm_unary(infiniRocmRuntime_t rt, int op, int dtype, const void *x, 
     case INFINI_DT_BF16: return unary_op_dispatch<__hip_bfloat16>(rt, op, x, y, n, p0, p1);
     default:
         IROCM_FAIL(INFINI_ROCM_UNSUPPORTED, "unary: unsupported dtype %s", dtype_name(dtype));
+    }
+}
+
+int infini_rocm_silu_mul(infiniRocmRuntime_t rt, int dtype, const void *a, const void *b, void *y, int64_t n) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(n >= 0, "silu_mul: negative size");
+    if (n == 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(a && b && y, "silu_mul: NULL tensor");
+    IROCM_CHECK_ARG((((uintptr_t)a | (uintptr_t)b | (uintptr_t)y) & 15) == 0, "silu_mul: operands must be 16-byte aligned");
+    switch (dtype) {
+    case INFINI_DT_F32: return silu_mul_launch<float>(rt, a, b, y, n);
+    case INFINI_DT_F16: return silu_mul_launch<__half>(rt, a, b, y, n);
+    case INFINI_DT_BF16: return silu_mul_launch<__hip_bfloat16>(rt, a, b, y, n);
+    default:
+        IROCM_FAIL(INFINI_ROCM_UNSUPPORTED, "silu_mul: unsupported dtype %s", dtype_name(dtype));
     }
 }
 

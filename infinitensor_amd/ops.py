@@ -407,6 +407,16 @@ def unary(rt: RocmRuntime, op: str, x: torch.Tensor, p0: float = float("nan"), p
     return out
 
 
+def silu_mul(rt: RocmRuntime, a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """silu(a) * b in one pass (the Silu -> Mul pair of a gated MLP); bit-identical to unary("silu") followed by binary("mul")."""
+    if a.shape != b.shape or a.dtype != b.dtype:
+        raise ValueError("silu_mul: operands must share shape and dtype")
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib().infini_rocm_silu_mul(rt.handle, dtype_of(a), _ptr(a), _ptr(b), _ptr(out), a.numel()))
+    return out
+
+
 def cast(rt: RocmRuntime, x: torch.Tensor, dst: torch.dtype, out: torch.Tensor | None = None) -> torch.Tensor:
     if out is None:
         out = torch.empty(x.shape, dtype=dst, device=x.device)

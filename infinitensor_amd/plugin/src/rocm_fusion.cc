@@ -720,6 +720,39 @@ size_t RocmRuntimeObj::tryLaunchFusedRules(const OpVec &ops, size_t i) const {
         }
         return 0;
     }
+    // Silu(a) -> Mul(., b): the gate of a gated MLP as one pass (infini_rocm_silu_mul; bit-identical: the Silu value is rounded
+    // as its own kernel would have stored it). Operators between the two that a grouped launch already ran (the up projection,
+    // rocm_fusion.cc::tryLaunchGroupedMatmul) are skipped over; b may be a result parked in the workspace by that launch.
+    if (type == OpType::Silu) {
+        static const bool swigluOn = !(std::getenv("INFINI_ROCM_FUSE_SWIGLU") && std::atoi(std::getenv("INFINI_ROCM_FUSE_SWIGLU")) == 0);
+        size_t m = i + 1;
+        while (m < ops.size() && launchedAhead[m])
+            ++m;
+        if (swigluOn && m < ops.size() && ops[m]->getOpType() == OpType::Mul && soleConsumerIs(op->getOutput(), ops[m])) {
+            const Tensor a = op->getInputs(0), sOut = op->getOutput(), out = ops[m]->getOutput();
+            const Tensor m0 = ops[m]->getInputs(0), m1 = ops[m]->getInputs(1);
+            const Tensor b = m0 == sOut ? m1 : m0;
+            const int dt = a->getDTypeIndex();
+            auto safe = [&](const Tensor &u) { // element-wise: exactly in place is fine, a partial overlap is not
+                return !overlaps(out, u) || (u->getRawDataPtr<void *>() == out->getRawDataPtr<void *>() && u->getDims() == out->getDims());
+            };
+            const void *bp = b->getRawDataPtr<void *>();
+            auto pf = parkedFeeds.find(m);
+            const bool bParked = pf != parkedFeeds.end() && pf->second.tensor == b.get();
+            if (bParked)
+                bp = pf->second.ptr;
+            if (b != sOut && (m0 == sOut) != (m1 == sOut) && (dt == INFINI_DT_F16 || dt == INFINI_DT_BF16 || dt == INFINI_DT_F32) &&
+                a->getDims() == out->getDims() && b->getDims() == out->getDims() && b->getDType() == a->getDType() &&
+                out->getDType() == a->getDType() && safe(a) && (bParked || safe(b)) &&
+                (((uintptr_t)a->getRawDataPtr<void *>() | (uintptr_t)bp | (uintptr_t)out->getRawDataPtr<void *>()) & 15) == 0 &&
+                (pf == parkedFeeds.end() || bParked)) {
+                ROCM_CALL(infini_rocm_silu_mul(rt, dt, a->getRawDataPtr<void *>(), bp, out->getRawDataPtr<void *>(), (int64_t)out->size()));
+                if (bParked)
+                    parkedFeeds.erase(pf);
+                return m - i + 1; // everything in between already ran
+            }
+        }
+    }
     // Relu -> MaxPool: max and relu commute (bit-identical); the stem of every ResNet
     if (type == OpType::Relu && i + 1 < ops.size() && ops[i + 1]->getOpType() == OpType::MaxPool &&
         soleConsumerIs(op->getOutput(), ops[i + 1])) {

@@ -169,3 +169,27 @@ def test_bias_residual_is_bit_identical_to_the_chain(rt, shape, relu, dt):
     if relu:
         chain = ops.unary(rt, "relu", chain)
     assert torch.equal(fused, chain)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("n", [1, 7, 4096, 100003])
+def test_silu_mul_equals_the_two_kernel_chain(rt, dt, n):
+    """infini_rocm_silu_mul (the Silu -> Mul pair of a gated MLP as one pass): bit-identical to unary(silu) -> binary(mul),
+    also in place on either operand, and against the fp64 formula."""
+    g = torch.Generator().manual_seed(n)
+    a = (torch.randn(n, generator=g) * 3).to(dt).cuda()
+    b = torch.randn(n, generator=g).to(dt).cuda()
+    chain = ops.binary(rt, "mul", ops.unary(rt, "silu", a), b)
+    fused = ops.silu_mul(rt, a, b)
+    rt.sync()
+    assert torch.equal(fused, chain)
+    a64, b64 = a.double().cpu(), b.double().cpu()
+    want = a64 / (1 + torch.exp(-a64)) * b64
+    tol = {torch.float32: 1e-5, torch.float16: 3e-3, torch.bfloat16: 2e-2}[dt]
+    assert torch.allclose(fused.double().cpu(), want, rtol=tol, atol=tol)
+    a2 = a.clone()
+    ops.silu_mul(rt, a2, b, out=a2)
+    b2 = b.clone()
+    ops.silu_mul(rt, a, b2, out=b2)
+    rt.sync()
+    assert torch.equal(a2, chain) and torch.equal(b2, chain)
