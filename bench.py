@@ -275,15 +275,15 @@ def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
         def heads(t):  # [T, heads_local*D] -> [Bt*heads_local, S, D]
             return ops.transpose(rt, t.view(Bt, S, heads_local, D), (0, 2, 1, 3)).view(Bt * heads_local, S, D)
 
-        def rope(t):  # rotary embedding per head (head dim 128, theta 1e4: rope.cc:25)
-            return ops.rope(rt, pos, t.view(Bt, S, heads_local * D), D).view(T, heads_local * D)
+        def rope_heads(t):  # rotary embedding per head (head dim 128, theta 1e4: rope.cc:25) with the head split as its store
+            return ops.rope(rt, pos, t.view(Bt, S, heads_local * D), D, head_split=True).view(Bt * heads_local, S, D)
 
         h = ops.rms_norm(rt, x, n1, 1e-5)
         # q, k, v projections of the same activations as ONE grouped launch (batch index = projection, zero A stride: the
         # three weight shards are stacked once at set-up): 3 x 128 tiles of 256^2 leave half the chip idle per launch,
         # 384 tiles in one persistent launch do not (measured 215 -> 169 us at TP = 1)
         qkv = ops.matmul(rt, h, w_qkv)
-        q, k = heads(rope(qkv[0])), heads(rope(qkv[1]))
+        q, k = rope_heads(qkv[0]), rope_heads(qkv[1])
         v = heads(qkv[2])
         ctx = ops.attention(rt, q, k, v, scale, scale_is_div=True, head_merge=heads_local).view(T, heads_local * D)
         o = ops.matmul(rt, ctx, w_o)

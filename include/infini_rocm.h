@@ -272,6 +272,11 @@ int infini_rocm_attention_kvcache(infiniRocmRuntime_t rt, int dtype, void *k_cac
  * single (batch, position) (rope.cu:85): here every token is rotated. */
 int infini_rocm_rope(infiniRocmRuntime_t rt, int dtype, int pos_dtype, const void *pos, const void *x,
                      void *y, int64_t tokens, int64_t dim_model, int64_t dim_head, float theta);
+/* RoPE with a head-split store: token (b, s), head h, column c goes to y[b][h][s][c] — RoPE -> Reshape([B, S, H, D]) ->
+ * Transpose(0, 2, 1, 3) (rope.cu, reshape.cc, transpose.cc: three launches) as one pass. seq = S (0: exactly infini_rocm_rope);
+ * tokens % seq == 0, dim_model % dim_head == 0, x != y. */
+int infini_rocm_rope_headsplit(infiniRocmRuntime_t rt, int dtype, int pos_dtype, const void *pos, const void *x,
+                               void *y, int64_t tokens, int64_t dim_model, int64_t dim_head, float theta, int64_t seq);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Binary element-wise with numpy broadcasting                                                  */

@@ -109,6 +109,7 @@ def lib() -> C.CDLL:
     sig("infini_rocm_add_norm", [vp, i32, i32, vp, vp, vp, vp, vp, i64, i64, i64, i64, f32])
     sig("infini_rocm_pool2d_relu", [vp, i32, i32, vp, vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32])
     sig("infini_rocm_rope", [vp, i32, i32, vp, vp, vp, i64, i64, i64, f32])
+    sig("infini_rocm_rope_headsplit", [vp, i32, i32, vp, vp, vp, i64, i64, i64, f32, i64])
     sig("infini_rocm_binary", [vp, i32, i32, vp, vp, vp, i32, pi64, pi64, pi64])
     sig("infini_rocm_unary", [vp, i32, i32, vp, vp, i64, f32, f32])
     sig("infini_rocm_silu_mul", [vp, i32, vp, vp, vp, i64])

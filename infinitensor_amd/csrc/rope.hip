@@ -31,7 +31,7 @@ template <> struct RLd<__hip_bfloat16> {
 template <typename T, typename P>
 __global__ __launch_bounds__(256) void rope_kernel(const P *__restrict__ pos, const T *__restrict__ x,
                                                    T *__restrict__ y, long tokens, int dim_model, int dim_head,
-                                                   float neg2_log2theta_over_dh) {
+                                                   float neg2_log2theta_over_dh, int hs_seq) {
     const int half = dim_head / 2;
     const int heads = (dim_model + dim_head - 1) / dim_head; // a trailing partial head is allowed
     const long pairs_per_token = (long)heads * half;
@@ -49,9 +49,12 @@ __global__ __launch_bounds__(256) void rope_kernel(const P *__restrict__ pos, co
         const long j = tok * dim_model + j0;
         const bool pair = j1 < dim_model; // partner column beyond the row: treated as 0, never read
         const float a = RLd<T>::ld(x + j), b = pair ? RLd<T>::ld(x + j + half) : 0.f;
-        RLd<T>::st(y + j, a * cs - b * sn);
+        // hs_seq > 0: head-split store, token (b, s) head h column c -> y[b][h][s][c] (the Reshape([B, S, H, D]) ->
+        // Transpose(0, 2, 1, 3) a decoder applies next); dim_model % dim_head == 0 then
+        const long jo = hs_seq ? (((tok / hs_seq) * heads + head) * hs_seq + tok % hs_seq) * dim_head + c : j;
+        RLd<T>::st(y + jo, a * cs - b * sn);
         if (pair)
-            RLd<T>::st(y + j + half, b * cs + a * sn);
+            RLd<T>::st(y + jo + half, b * cs + a * sn);
     }
 }
 
@@ -61,7 +64,16 @@ using namespace irocm;
 
 extern "C" int infini_rocm_rope(infiniRocmRuntime_t rt, int dtype, int pos_dtype, const void *pos, const void *x,
                                 void *y, int64_t tokens, int64_t dim_model, int64_t dim_head, float theta) {
+    return infini_rocm_rope_headsplit(rt, dtype, pos_dtype, pos, x, y, tokens, dim_model, dim_head, theta, 0);
+}
+
+extern "C" int infini_rocm_rope_headsplit(infiniRocmRuntime_t rt, int dtype, int pos_dtype, const void *pos, const void *x,
+                                          void *y, int64_t tokens, int64_t dim_model, int64_t dim_head, float theta,
+                                          int64_t seq) {
     IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(seq >= 0 && seq < (1ll << 31), "rope: bad sequence length");
+    IROCM_CHECK_ARG(seq == 0 || (tokens % seq == 0 && dim_model % dim_head == 0 && x != y),
+                    "rope: the head-split store needs tokens %% seq == 0, whole heads and separate buffers");
     IROCM_CHECK_ARG(tokens >= 0 && dim_model > 0 && dim_head > 0, "rope: bad extent");
     IROCM_CHECK_ARG(dim_head % 2 == 0, "rope: head dim %lld must be even", (long long)dim_head);
     IROCM_CHECK_ARG(theta > 1.0f, "rope: theta must be > 1");
@@ -75,7 +87,7 @@ extern "C" int infini_rocm_rope(infiniRocmRuntime_t rt, int dtype, int pos_dtype
 #define GO(T, P)                                                                                   \
     hipLaunchKernelGGL((rope_kernel<T, P>), dim3((unsigned)g), dim3(256), 0, rt->stream,           \
                        (const P *)pos, (const T *)x, (T *)y, (long)tokens, (int)dim_model,         \
-                       (int)dim_head, k)
+                       (int)dim_head, k, (int)seq)
 #define GOP(T)                                                                                     \
     switch (pos_dtype) {                                                                           \
     case INFINI_DT_I32: GO(T, int32_t); break;                                                     \

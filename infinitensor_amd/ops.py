@@ -341,10 +341,18 @@ def add_layer_norm(rt: RocmRuntime, a: torch.Tensor, b: torch.Tensor, scale: tor
 
 
 def rope(rt: RocmRuntime, pos: torch.Tensor, x: torch.Tensor, dim_head: int = 128, theta: float = 10000.0,
-         out: torch.Tensor | None = None) -> torch.Tensor:
+         out: torch.Tensor | None = None, head_split: bool = False) -> torch.Tensor:
     """RoPE(pos [B, S], x [B, S, dim_model]) (operators/rope.h; dim_head 128 / theta 1e4 as rope.cc:25)."""
     if x.dim() != 3 or pos.dim() != 2 or tuple(pos.shape) != tuple(x.shape[:2]):
         raise ValueError("rope expects pos [B, S] and x [B, S, dim_model]")  # reference: IT_ASSERT(nDims == 3 ...)
+    if head_split:  # the result as [B, H, S, D]: RoPE -> Reshape([B, S, H, D]) -> Transpose(0, 2, 1, 3) in one pass
+        if x.shape[2] % dim_head:
+            raise ValueError("rope: head_split needs whole heads")
+        if out is None:
+            out = torch.empty((x.shape[0], x.shape[2] // dim_head, x.shape[1], dim_head), dtype=x.dtype, device=x.device)
+        check(lib().infini_rocm_rope_headsplit(rt.handle, dtype_of(x), dtype_of(pos), _ptr(pos), _ptr(x), _ptr(out),
+                                               x.shape[0] * x.shape[1], x.shape[2], int(dim_head), float(theta), x.shape[1]))
+        return out
     if out is None:
         out = torch.empty_like(x)
     check(lib().infini_rocm_rope(rt.handle, dtype_of(x), dtype_of(pos), _ptr(pos), _ptr(x), _ptr(out),

@@ -117,6 +117,7 @@ class RocmRuntimeObj : public RuntimeObj {
     // launches ops[i .. i+k) as one kernel when a fusion rule applies; returns k (0 = no rule)
     size_t tryLaunchFused(const OpVec &ops, size_t i) const;
     size_t tryLaunchGroupedMatmul(const OpVec &ops, size_t i) const;
+    size_t tryLaunchRopeHeadSplit(const OpVec &ops, size_t i) const;
     void launchWithInputRedirect(const Operator &op, const TensorObj *t, void *ptr) const;
     size_t tryLaunchFusedRules(const OpVec &ops, size_t i) const;
     size_t tryLaunchIntoReshape(const OpVec &ops, size_t i) const;

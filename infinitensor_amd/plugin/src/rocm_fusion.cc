@@ -262,6 +262,8 @@ size_t RocmRuntimeObj::tryLaunchFused(const OpVec &ops, size_t i) const {
         return used;
     if (const size_t used = tryLaunchGroupedMatmul(ops, i))
         return used;
+    if (const size_t used = tryLaunchRopeHeadSplit(ops, i))
+        return used;
     return tryLaunchIntoReshape(ops, i);
 }
 
@@ -569,6 +571,44 @@ size_t RocmRuntimeObj::tryLaunchGroupedMatmul(const OpVec &ops, size_t i) const 
         ++parkedCount;
     }
     return 1;
+}
+
+// RoPE -> Reshape([B, S, H, D]) -> Transpose(0, 2, 1, 3): the rotary embedding of a decoder's q / k followed by their head split
+// (rope.cu, reshape.cc, transpose.cc: three launches, two extra passes) as one pass with a head-split store
+// (infini_rocm_rope_headsplit). Head dim 128 / theta 1e4 as the reference hard-codes them (rope.cc:25). The input may be a
+// grouped MatMul's result parked in the workspace (parkedFeeds): this rule resolves it itself, launchAll tries it first.
+size_t RocmRuntimeObj::tryLaunchRopeHeadSplit(const OpVec &ops, size_t i) const {
+    static const bool enabled = !(std::getenv("INFINI_ROCM_FUSE_ROPE_SPLIT") && std::atoi(std::getenv("INFINI_ROCM_FUSE_ROPE_SPLIT")) == 0);
+    if (!enabled || i + 2 >= ops.size() || ops[i]->getOpType() != OpType::RoPE || ops[i + 1]->getOpType() != OpType::Reshape ||
+        ops[i + 2]->getOpType() != OpType::Transpose || launchedAhead[i + 1] || launchedAhead[i + 2])
+        return 0;
+    const Tensor pos = ops[i]->getInputs(0), x = ops[i]->getInputs(1), y = ops[i]->getOutput();
+    const Tensor r = ops[i + 1]->getOutput(), out = ops[i + 2]->getOutput();
+    auto tr = as<TransposeObj>(ops[i + 2]);
+    if (ops[i + 1]->getInputs(0) != y || tr->getInputs(0) != r || !soleConsumerIs(y, ops[i + 1]) || !soleConsumerIs(r, ops[i + 2]))
+        return 0;
+    const auto &xd = x->getDims(), &rd = r->getDims();
+    const auto perm = tr->getPermute();
+    if (xd.size() != 3 || rd.size() != 4 || perm.size() != 4 || perm[0] != 0 || perm[1] != 2 || perm[2] != 1 || perm[3] != 3 ||
+        rd[0] != xd[0] || rd[1] != xd[1] || rd[3] != 128 || (long)rd[2] * rd[3] != xd[2] || pos->getDims().size() != 2 ||
+        pos->getDims()[1] != xd[1] || !(out->getDType() == x->getDType()) || out->getBytes() != x->getBytes())
+        return 0;
+    const void *xp = x->getRawDataPtr<void *>();
+    auto pf = parkedFeeds.find(i);
+    if (pf != parkedFeeds.end()) {
+        if (pf->second.tensor != x.get())
+            return 0;
+        xp = pf->second.ptr; // the tensor's own buffer holds something else right now: only the parked copy counts
+    } else if (overlaps(out, x)) {
+        return 0;
+    }
+    if (overlaps(out, pos))
+        return 0;
+    ROCM_CALL(infini_rocm_rope_headsplit(rt, x->getDTypeIndex(), pos->getDTypeIndex(), pos->getRawDataPtr<void *>(), xp,
+                                         out->getRawDataPtr<void *>(), (int64_t)xd[0] * xd[1], xd[2], 128, 10000.0f, xd[1]));
+    if (pf != parkedFeeds.end())
+        parkedFeeds.erase(pf);
+    return 3;
 }
 
 // producer -> Reshape | Flatten | Identity | Squeeze | Unsqueeze: the reference runs these as a device memcpy

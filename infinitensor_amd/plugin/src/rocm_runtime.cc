@@ -111,8 +111,15 @@ void RocmRuntimeObj::launchAll(const Graph &graph, bool validate) const {
         const Operator &op = ops[i];
         if (launchedAhead[i]) // ran as a member of an earlier grouped launch (rocm_fusion.cc::tryLaunchGroupedMatmul)
             continue;
-        if (auto it = parkedFeeds.find(i); it != parkedFeeds.end()) { // reads a parked group result: plain launch, input redirected
-            launchWithInputRedirect(op, it->second.tensor, it->second.ptr);
+        if (auto it = parkedFeeds.find(i); it != parkedFeeds.end()) { // reads a parked group result
+            if (fusion) { // the one rule that knows about parked operands itself
+                if (const size_t used = tryLaunchRopeHeadSplit(ops, i)) {
+                    ++fusedCount;
+                    i += used - 1;
+                    continue;
+                }
+            }
+            launchWithInputRedirect(op, it->second.tensor, it->second.ptr); // plain launch, input redirected
             continue;
         }
         if (fusion) {

@@ -204,3 +204,18 @@ def test_softmax_bert_full_size_properties(rt, dt):
     xs = x.view(-1, 512)[torch.from_numpy(rows).cuda()].float().cpu().numpy().astype(np.float64)
     ys = y.view(-1, 512)[torch.from_numpy(rows).cuda()].float().cpu().numpy().astype(np.float64)
     assert np.allclose(ys, R.softmax(xs, 1), rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16, torch.bfloat16])
+def test_rope_head_split_store_is_the_transposed_result(rt, dt):
+    """infini_rocm_rope_headsplit: RoPE -> Reshape([B, S, H, D]) -> Transpose(0, 2, 1, 3) as one pass — the same bits as the
+    plain RoPE followed by the two movement ops."""
+    g = torch.Generator().manual_seed(5)
+    B_, S, H, D = 2, 37, 3, 128
+    x = torch.randn(B_, S, H * D, generator=g).to(dt).cuda()
+    pos = torch.arange(S, dtype=torch.int32).repeat(B_, 1).cuda()
+    plain = ops.rope(rt, pos, x, D)
+    want = ops.transpose(rt, plain.view(B_, S, H, D), (0, 2, 1, 3))
+    got = ops.rope(rt, pos, x, D, head_split=True)
+    rt.sync()
+    assert tuple(got.shape) == (B_, H, S, D) and torch.equal(got, want)
