@@ -1,0 +1,44 @@
+"""Short runs of the randomised sweeps under tools/ (the long runs are in DESIGN.md): C-ABI kernels against torch references,
+and the launch-time fusion rules against the per-operator run through the reference executor."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = Path(__file__).resolve().parent.parent
+
+
+def _run(script, args, env=None, timeout=600):
+    e = dict(os.environ, FUZZ_SEED="4242", **(env or {}))
+    r = subprocess.run([sys.executable, str(REPO / "tools" / script), *args], cwd=REPO, env=e, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    return r.stdout
+
+
+def test_matmul_random_shapes_vs_torch():
+    assert "120/120 cases ok" in _run("gemm_fuzz.py", ["120"])
+
+
+def test_conv_and_attention_random_shapes_vs_torch():
+    out = _run("conv_attn_fuzz.py", ["60", "50"])
+    assert "conv: 0 failures" in out and "attention: 0 failures" in out
+
+
+def test_rowops_random_shapes_vs_torch():
+    assert "270/270 cases ok" in _run("rowops_fuzz.py", ["270"])
+
+
+def test_fusion_rules_are_bit_identical_on_random_graphs():
+    """MatMul grouping / hoisting / parking, head splits, Silu -> Mul, RoPE head split, copy elision: fusion on == fusion off,
+    bit for bit (the Gelu epilogue rounds once by design and is switched off for this comparison)."""
+    pytest.importorskip("conftest").load_backend_module() or pytest.skip("plugin build missing")
+    out = _run("fusion_fuzz.py", ["24"], {"INFINI_ROCM_FUSE_GELU": "0"})
+    assert "24/24 graphs bit-identical" in out
+
+
+def test_conv_fusion_agrees_on_random_resnet_blocks():
+    pytest.importorskip("conftest").load_backend_module() or pytest.skip("plugin build missing")
+    assert "16/16 graphs agree" in _run("conv_fusion_fuzz.py", ["16"])
