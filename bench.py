@@ -40,6 +40,11 @@ def parse():
     # per launch: 124, 112, 107, 105, 102, 101, 100.6 ... 99.6 us per 25-launch window, flat at 99.5-100 us from launch ~200 to
     # 600 (profiles/r02_launch_series.txt) — and a 20-launch warm-up put that ramp inside the timed region (109.7 us mean).
     ap.add_argument("--warmup", type=int, default=300)
+    # Independent of --warmup: back-to-back launches for at least this long before the W warm-up steps, so that a caller who
+    # asks for a handful of warm-up steps (the driver: 5) still times the chip at the clocks it holds, not inside its
+    # 15 ms ramp from idle. The line reports it (`prewarm_ms`, `prewarm_launches`) next to a COLD figure taken before it
+    # (`roofline.cold20`: the first 20 launches on an idle chip).
+    ap.add_argument("--prewarm-ms", type=float, default=40.0)
     ap.add_argument("--variant", type=int, default=-1, help="GEMM kernel variant (-1 = heuristic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
@@ -212,18 +217,24 @@ def graph_resnet50(local_rank: int, world: int, dist_mod) -> dict:
     mm = run_model("matmul", local_rank, dtype="f16", iters=50)  # one-operator graph: executor overhead per launch
     other = {}
     if world == 1:  # BASELINE configs 4 and 5 through the same drop-in path (rank-local figures, N = 1 only)
-        for key, model in (("bert_base_bs32_seq512_f16", "bert"), ("llama7b_block_2048tok_f16_tp1", "llama")):
+        # every graph is built in the form and operator order pyinfinitensor/onnx.py emits (tools/model_bench.py); the
+        # decomposed row additionally lowers LayerNorm / Gelu to the primitive operators of an opset < 17 export
+        for key, model, kw in (("bert_base_bs32_seq512_f16", "bert", {}),
+                               ("bert_base_bs32_seq512_f16_decomposed_ln_gelu", "bert", {"decomposed": True}),
+                               ("llama7b_block_2048tok_f16_tp1", "llama", {})):
             try:
-                m = run_model(model, local_rank, iters=10)
-                other[key] = {k: m[k] for k in ("hipgraph_ms", "eager_ms", "hipgraph_TFLOPs", "ops", "fused_launches_per_run", "finite")}
+                m = run_model(model, local_rank, iters=10, **kw)
+                other[key] = {k: m[k] for k in ("lowering", "hipgraph_ms", "eager_ms", "hipgraph_TFLOPs", "ops", "fused_launches_per_run", "finite")}
             except Exception as e:  # noqa: BLE001
                 other[key] = {"error": repr(e)[:200]}
     ms = torch.tensor([r["hipgraph_ms"], r["eager_ms"]], device="cuda", dtype=torch.float64)
     if world > 1:
         dist_mod.all_reduce(ms, op=dist_mod.ReduceOp.MAX)
     g, e = (float(v) for v in ms.tolist())
-    return {"workload": f"ResNet-50 bs128 fp16 per GPU x {world} replicas, reference executor + ROCM plugin, launch-time fusion "
+    return {"workload": f"ResNet-50 bs128 fp16 per GPU x {world} replicas, reference executor + ROCM plugin, graph in the "
+                        f"front-end's lowering ({r['lowering']}: conv -> reshape(bias) -> add), launch planning "
                         + ("on" if r["fusion"] else "off"),
+            "fused_launches_per_run": r["fused_launches_per_run"],
             "hipgraph_ms": round(g, 3), "eager_ms": round(e, 3), "samples_per_s": round(world * 128 / g * 1e3, 0),
             "conv_gemm_TFLOPs_aggregate": round(world * r["gemm_conv_TFLOP"] / g * 1e3, 1), "ops": r["ops"], "finite": r["finite"],
             # this rank's figures after the reference's h.tune() (MatMul / Conv choose their kernel by measurement)
@@ -384,13 +395,28 @@ def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
     }
 
 
-def pmc_traffic():
-    """HBM-side bytes per GEMM launch from the committed PMC passes (tools/profile_gemm.sh); None if absent."""
-    p = REPO / "profiles" / "r02_gemm256p_pmc.json"
-    try:
-        return float(json.loads(p.read_text())["traffic_bytes_per_launch"])
-    except Exception:  # noqa: BLE001
-        return None
+def pmc_traffic(launched: str) -> dict:
+    """HBM-side bytes per GEMM launch from the committed PMC passes (tools/profile_gemm.sh: rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE of the same shape; FETCH_SIZE x2 per the gfx950 note). The counter file names the kernel variant it was
+    taken from; a file from ANOTHER variant than the one this run launched is refused (traffic: null) instead of silently
+    going stale when the kernel changes."""
+    for name in ("r03_gemm256p_pmc.json", "r02_gemm256p_pmc.json"):
+        p = REPO / "profiles" / name
+        try:
+            d = json.loads(p.read_text())
+        except Exception:  # noqa: BLE001
+            continue
+        try:
+            from infinitensor_amd import ops
+
+            file_variant = d.get("variant_name") or ops.matmul_variants()[int(d["variant"])]
+        except Exception:  # noqa: BLE001
+            file_variant = None
+        src = f"profiles/{name} (variant {file_variant})"
+        if file_variant != launched:
+            return {"traffic": None, "traffic_source": f"{src} REFUSED: this run launched {launched}"}
+        return {"traffic": float(d["traffic_bytes_per_launch"]), "traffic_source": src}
+    return {"traffic": None, "traffic_source": "no counter file under profiles/"}
 
 
 def self_spawn(args) -> int:
@@ -463,6 +489,25 @@ def main() -> int:
     def step():
         ops.matmul(rt, a, b, out=c)
 
+    # cold figure: the first 20 launches on a chip that has been idle since the allocations above
+    rt.sync()
+    ec0, ec1 = Event(), Event()
+    rt.record(ec0)
+    for _ in range(20):
+        step()
+    rt.record(ec1)
+    rt.sync()
+    cold_us = rt.elapsed_ms(ec0, ec1) * 1e3 / 20
+    kernel_variant_launched = ops.matmul_last_variant(rt)
+    # time-based pre-warm (not part of --warmup, stated in the line)
+    prewarm_launches = 0
+    t_pw = time.perf_counter()
+    while (time.perf_counter() - t_pw) * 1e3 < args.prewarm_ms:
+        for _ in range(16):
+            step()
+        prewarm_launches += 16
+        rt.sync()
+    prewarm_ms = (time.perf_counter() - t_pw) * 1e3
     for _ in range(args.warmup):
         step()
     rt.sync()
@@ -529,6 +574,8 @@ def main() -> int:
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        "prewarm_ms": round(prewarm_ms, 1),
+        "prewarm_launches": prewarm_launches,
         "ms_per_step": round(elapsed / args.steps * 1e3, 5),
         "higher_is_better": True,
         "scaling": "weak",
@@ -538,6 +585,7 @@ def main() -> int:
         "config": {
             "workload": "BASELINE configs[1]: one bf16 MatMul M=N=K=4096 per GPU, NN layout, fp32 accumulate, via infini_rocm_matmul",
             "kernel_variant": ops.matmul_variants()[args.variant] if args.variant >= 0 else "heuristic",
+            "kernel_variant_launched": kernel_variant_launched,
             "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"],
             "clock_mhz": info["clock_mhz"],
             "parallelism": f"{world} independent replicas (column-sharded GEMM has no collective)",
@@ -548,9 +596,11 @@ def main() -> int:
             "peak": PEAK_BF16_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-            "traffic": pmc_traffic(),
-            "traffic_source": "profiles/r02_gemm256p_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel and shape; bytes per launch, FETCH_SIZE x2 per the gfx950 note)",
+            **pmc_traffic(kernel_variant_launched),
             "kernel_us": round(kernel_s * 1e6, 3),
+            # the same kernel on an idle chip: first 20 launches after the allocations, before any warm-up
+            "cold20": {"kernel_us": round(cold_us, 3), "achieved": round(flop_per_step / (cold_us * 1e-6) / 1e12, 2),
+                       "frac": round(flop_per_step / (cold_us * 1e-6) / 1e12 / PEAK_BF16_TFLOPS, 4)},
             "kernel_us_per_launch": per_launch,
             "peak_from_device": round(info["compute_units"] * 4096 * info["clock_mhz"] * 1e6 / 1e12, 1),
         },

@@ -199,6 +199,10 @@ int infini_rocm_matmul_may_use_workspace(infiniRocmRuntime_t rt, int64_t batch, 
 int infini_rocm_matmul_set_variant(infiniRocmRuntime_t rt, int variant);
 int infini_rocm_matmul_num_variants(void);
 const char *infini_rocm_matmul_variant_name(int variant);
+/* The variant the most recent matmul call on this runtime actually launched (-1 before the first): what the heuristic /
+ * the forced setting resolved to for that shape. Measurement tools stamp their records with it (bench.py refuses counter
+ * files taken from another kernel). */
+int infini_rocm_matmul_last_variant(infiniRocmRuntime_t rt, int *variant);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Softmax along one axis (reference: softmax_kernel, src/kernels/cuda/softmax.cu:242-404;      */
@@ -230,6 +234,13 @@ int infini_rocm_rms_norm(infiniRocmRuntime_t rt, int dtype, const void *x, const
 int infini_rocm_add_norm(infiniRocmRuntime_t rt, int dtype, int rms, const void *a, const void *b, const void *scale,
                          const void *bias, void *y, int64_t outer, int64_t norm_size, int64_t scale_size,
                          int64_t bias_size, float eps);
+/* y = LayerNorm / RMSNorm of ((a + pre) + b) with `pre` ONE row of norm_size elements (NULL: add_norm): the chain
+ * MatMul -> Add(bias) -> Add(residual) -> LayerNormalization the reference's ONNX front-end emits for a transformer's
+ * output projections (pyinfinitensor/onnx.py:280-290 imports MatMul without bias; element_wise.cc, layer_norm.cc) when the
+ * bias could not ride in the GEMM epilogue. Both sums are rounded to the storage type like their own Add kernels. */
+int infini_rocm_bias_add_norm(infiniRocmRuntime_t rt, int dtype, int rms, const void *a, const void *pre, const void *b,
+                              const void *scale, const void *bias, void *y, int64_t outer, int64_t norm_size,
+                              int64_t scale_size, int64_t bias_size, float eps);
 
 /* Fused prefill attention  O = softmax(scale * Q K^T + mask) V  per (batch x head); f16 / bf16, head dim 64 or 128.
  * Replaces the chain MatMul(Q, K^T) -> Div/Mul(scalar) -> Add(mask) -> Softmax -> MatMul(P, V) of the reference graph

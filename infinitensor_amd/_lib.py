@@ -88,6 +88,7 @@ def lib() -> C.CDLL:
     sig("infini_rocm_matmul_headsplit", [vp, i32, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i64, i64, i64, i64, i64, i32, i64, i64])
     sig("infini_rocm_matmul_grouped", [vp, i32, vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i64, i64, i64, i64, i64, i64, i32, i64, i64])
     sig("infini_rocm_matmul_set_variant", [vp, i32])
+    sig("infini_rocm_matmul_last_variant", [vp, C.POINTER(C.c_int)])
     sig("infini_rocm_matmul_may_use_workspace", [vp, i64, i64, i64, C.POINTER(C.c_int)])
     sig("infini_rocm_matmul_num_variants", [], i32)
     sig("infini_rocm_matmul_variant_name", [i32], C.c_char_p)
@@ -107,6 +108,7 @@ def lib() -> C.CDLL:
     sig("infini_rocm_conv2d_res", [vp, i32, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, i64, i32])
     sig("infini_rocm_bias_residual", [vp, i32, vp, vp, vp, vp, i64, i64, i64, i32])
     sig("infini_rocm_add_norm", [vp, i32, i32, vp, vp, vp, vp, vp, i64, i64, i64, i64, f32])
+    sig("infini_rocm_bias_add_norm", [vp, i32, i32, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, f32])
     sig("infini_rocm_pool2d_relu", [vp, i32, i32, vp, vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32])
     sig("infini_rocm_rope", [vp, i32, i32, vp, vp, vp, i64, i64, i64, f32])
     sig("infini_rocm_rope_headsplit", [vp, i32, i32, vp, vp, vp, i64, i64, i64, f32, i64])

@@ -114,6 +114,7 @@ struct infiniRocmRuntime {
     uint64_t workspace_epoch = 0; // bumped whenever `workspace` changes
     bool capturing = false;
     int matmul_variant = -1;
+    int last_matmul_variant = -1; // the variant the most recent matmul call actually launched
     int conv_variant = -1;
     // conv weights declared constant by the caller: their re-packed images are cached (WCacheEntry) instead of rebuilt
     int conv_const_weights = 0;
@@ -142,6 +143,8 @@ const void *wcache_lookup(infiniRocmRuntime *rt, const void *src, int f, int c, 
 int wcache_insert(infiniRocmRuntime *rt, const void *src, size_t src_bytes, int f, int c, int rs, int kind, size_t packed_bytes,
                   void **packed, hipStream_t *stream);
 int wcache_commit(infiniRocmRuntime *rt, hipStream_t stream);
+// removes the entry whose packed image is `packed` (a pack that failed after wcache_insert); the buffer is retired
+void wcache_forget(infiniRocmRuntime *rt, const void *packed);
 // drops every entry whose SOURCE overlaps [ptr, ptr + bytes); the packed buffers are retired, not freed
 void wcache_invalidate(infiniRocmRuntime *rt, const void *ptr, size_t bytes);
 } // namespace irocm

@@ -1308,23 +1308,34 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
     }
     unsigned short *wdst = cached ? (unsigned short *)const_cast<void *>(packed) : (unsigned short *)ws;
     if (need_pack) {
+        // a cache entry published by wcache_insert above must not outlive a failed pack: the next conv with the same key
+        // would hit it and read an uninitialised image
+        auto fail_pack = [&](const char *what, hipError_t e) {
+            if (cached)
+                wcache_forget(rt, packed);
+            IROCM_FAIL(INFINI_ROCM_HIP_ERROR, "launch of %s failed: %s", what, hipGetErrorString(e));
+        };
         if (rowtap) { // FCRS -> [F][Kpad], k = tap * C + c
             long g = ceil_div((long)f * p.kpad, 256);
             if (g > 4096) g = 4096;
             hipLaunchKernelGGL(conv_repack_w_flat, dim3((unsigned)g), dim3(256), 0, pack_stream, (const unsigned short *)w, wdst, f,
                                c, r * s, p.kpad);
-            IROCM_LAUNCH_CHECK("conv_repack_w_flat");
+            if (hipError_t e = hipGetLastError(); e != hipSuccess)
+                return fail_pack("conv_repack_w_flat", e);
         } else { // FCRS -> [RS][F][C]
             long g = ceil_div((long)f * c * r * s, 256);
             if (g > 4096) g = 4096;
             hipLaunchKernelGGL(conv_repack_w, dim3((unsigned)g), dim3(256), 0, pack_stream, (const unsigned short *)w, wdst, f, c,
                                r * s);
-            IROCM_LAUNCH_CHECK("conv_repack_w");
+            if (hipError_t e = hipGetLastError(); e != hipSuccess)
+                return fail_pack("conv_repack_w", e);
         }
         if (cached) {
             int st = wcache_commit(rt, pack_stream);
-            if (st != INFINI_ROCM_OK)
+            if (st != INFINI_ROCM_OK) {
+                wcache_forget(rt, packed);
                 return st;
+            }
         }
     }
     if (w_bytes)

@@ -489,6 +489,12 @@ const char *infini_rocm_matmul_variant_name(int v) {
     return (v >= 0 && v < kNumVariants) ? kVariantNames[v] : "invalid";
 }
 
+int infini_rocm_matmul_last_variant(infiniRocmRuntime_t rt, int *variant) {
+    IROCM_CHECK_ARG(rt && variant, "NULL argument");
+    *variant = rt->last_matmul_variant;
+    return INFINI_ROCM_OK;
+}
+
 int infini_rocm_matmul_set_variant(infiniRocmRuntime_t rt, int variant) {
     IROCM_CHECK_ARG(rt, "NULL runtime");
     IROCM_CHECK_ARG(variant >= -1 && variant < kNumVariants, "variant %d out of range", variant);
@@ -612,6 +618,7 @@ int infini_rocm_matmul_grouped(infiniRocmRuntime_t rt, int dtype, const void *a,
     // sigmoid / tanh / erff-Gelu epilogues and biases other than one row vector live in the one-shot kernel (gemm256p_kernel.h)
     if (variant >= 4 && (!(act == 0 || act == 1 || act == 5) || (p.bias && !(p.bias_m == 0 && p.bias_n == 1))))
         variant = 2;
+    rt->last_matmul_variant = variant;
     if (variant == 4)
         return g256p::launch_gemm256p_nt4(rt, dtype, p, akm, bkm);
     if (variant == 5)

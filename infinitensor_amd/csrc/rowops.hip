@@ -455,10 +455,14 @@ __device__ inline float inv_sqrt(float a) {
     return fmaf(y, fmaf(-h, y, 0.5f), y);
 }
 
-// ADD: the row is a + b (x2 = b), rounded to the storage type exactly as a separate Add kernel would store it, so
+// ADD = 1: the row is a + b (x2 = b), rounded to the storage type exactly as a separate Add kernel would store it, so
 // Norm(Add(a, b)) fused here equals the two-kernel chain bit for bit (this is the Add -> LayerNorm / RMSNorm fusion).
-template <typename T, int B, int CHUNKS, bool RMS, int ROWS, bool ADD>
+// ADD = 2: the row is (a + pre) + b with `pre` one row vector of n elements (the bias of the linear layer that produced
+// a: MatMul -> Add(bias) -> Add(residual) -> Norm as the ONNX front-end emits a transformer's output projections), each
+// sum rounded like its own Add kernel would have stored it.
+template <typename T, int B, int CHUNKS, bool RMS, int ROWS, int ADD>
 __global__ __launch_bounds__(256) void norm_rows_kernel(const T *__restrict__ x, const T *__restrict__ x2,
+                                                        const T *__restrict__ pre,
                                                         const T *__restrict__ scale, const T *__restrict__ bias,
                                                         T *__restrict__ y, long rows, int n, int scale_size,
                                                         int bias_size, float eps) {
@@ -485,9 +489,15 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const T *__restrict__ x,
         if constexpr (ADD)
             rows_load<B, CHUNKS>(cur2[r], x2 + (row < rows ? row : rows - 1) * n, row_bytes, voff0);
     }
-    f32x2_t gs[NP], bs[NP];
+    f32x2_t gs[NP], bs[NP], ps[ADD == 2 ? NP : 1];
     {
         U tmp[CHUNKS];
+        if constexpr (ADD == 2) {
+            rows_load<B, CHUNKS>(tmp, pre, row_bytes, voff0);
+#pragma unroll
+            for (int c = 0; c < CHUNKS; ++c)
+                CK::up(tmp[c], &ps[c * PL]);
+        }
         if (scale_size != 1) {
             rows_load<B, CHUNKS>(tmp, scale, row_bytes, voff0);
 #pragma unroll
@@ -528,6 +538,16 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const T *__restrict__ x,
 #pragma unroll
             for (int c = 0; c < CHUNKS; ++c)
                 CK::up(cur[r][c], &xf[c * PL]);
+            if constexpr (ADD == 2) {
+#pragma unroll
+                for (int i = 0; i < NP; ++i)
+                    xf[i] += ps[i];
+                if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                    for (int i = 0; i < NP; ++i)
+                        xf[i] = pair_up<T>(pair_down<T>(xf[i]));
+                }
+            }
             if constexpr (ADD) {
                 f32x2_t bf[NP];
 #pragma unroll
@@ -776,13 +796,13 @@ static inline unsigned pgrid(int64_t blocks, int num_cu) {
 }
 
 // Launch of the fast row path (norm_rows_kernel); false when the rows do not qualify (unaligned, or > 4 KiB).
-template <typename T, bool RMS, bool ADD>
-static bool launch_norm_rows(infiniRocmRuntime_t rt, const T *x, const T *x2, const T *scale, const T *bias, T *y,
+template <typename T, bool RMS, int ADD>
+static bool launch_norm_rows(infiniRocmRuntime_t rt, const T *x, const T *x2, const T *pre, const T *scale, const T *bias, T *y,
                              int64_t outer, int64_t n, int64_t scale_size, int64_t bias_size, float eps) {
     constexpr int VEC = Elem<T>::VEC;
     const int64_t row_bytes = n * (int64_t)sizeof(T);
-    const bool al = is_aligned16(x) && (!ADD || is_aligned16(x2)) && is_aligned16(y) && is_aligned16(scale) &&
-                    (bias == nullptr || is_aligned16(bias)) && (n % VEC == 0);
+    const bool al = is_aligned16(x) && (!ADD || is_aligned16(x2)) && (ADD != 2 || is_aligned16(pre)) && is_aligned16(y) &&
+                    is_aligned16(scale) && (bias == nullptr || is_aligned16(bias)) && (n % VEC == 0);
     if (!al || row_bytes > 4096 || outer == 0)
         return false;
     // chunk width: the one that leaves the fewest idle lanes (768 f16 = 3 x 8 B, not 2 x 16 B with half a chunk idle)
@@ -794,7 +814,7 @@ static bool launch_norm_rows(infiniRocmRuntime_t rt, const T *x, const T *x2, co
     const int64_t blocks = ceil_div(outer, (int64_t)4 * rpw), cap = (int64_t)rt->num_cu * per_cu;
     const dim3 grid((unsigned)(blocks < cap ? blocks : cap));
 #define ROWS_GO(B, C, R)                                                                                        \
-    hipLaunchKernelGGL((norm_rows_kernel<T, B, C, RMS, R, ADD>), grid, dim3(256), 0, rt->stream, x, x2, scale, bias, y, \
+    hipLaunchKernelGGL((norm_rows_kernel<T, B, C, RMS, R, ADD>), grid, dim3(256), 0, rt->stream, x, x2, pre, scale, bias, y, \
                        (long)outer, (int)n, (int)scale_size, (int)bias_size, eps)
 #define ROWS_R(B, C)                                                                                            \
     do {                                                                                                        \
@@ -881,7 +901,7 @@ static int norm_dispatch(infiniRocmRuntime_t rt, const T *x, const T *scale, con
     const bool al = is_aligned16(x) && is_aligned16(y) && is_aligned16(scale) &&
                     (bias == nullptr || is_aligned16(bias)) && (n % VEC == 0);
     const int chunks = (int)ceil_div(n, (int64_t)64 * VEC);
-    if (launch_norm_rows<T, RMS, false>(rt, x, (const T *)nullptr, scale, bias, y, outer, n, scale_size, bias_size, eps)) {
+    if (launch_norm_rows<T, RMS, 0>(rt, x, (const T *)nullptr, (const T *)nullptr, scale, bias, y, outer, n, scale_size, bias_size, eps)) {
         IROCM_LAUNCH_CHECK("norm");
         return INFINI_ROCM_OK;
     }
@@ -916,9 +936,11 @@ static int norm_dispatch(infiniRocmRuntime_t rt, const T *x, const T *scale, con
 
 // Returns INFINI_ROCM_UNSUPPORTED (without setting an error) when the shape is outside the fused kernel's reach.
 template <typename T, bool RMS>
-static int add_norm_dispatch(infiniRocmRuntime_t rt, const T *a, const T *b, const T *scale, const T *bias, T *y,
+static int add_norm_dispatch(infiniRocmRuntime_t rt, const T *a, const T *b, const T *pre, const T *scale, const T *bias, T *y,
                              int64_t outer, int64_t n, int64_t scale_size, int64_t bias_size, float eps) {
-    if (!launch_norm_rows<T, RMS, true>(rt, a, b, scale, bias, y, outer, n, scale_size, bias_size, eps))
+    const bool ok = pre ? launch_norm_rows<T, RMS, 2>(rt, a, b, pre, scale, bias, y, outer, n, scale_size, bias_size, eps)
+                        : launch_norm_rows<T, RMS, 1>(rt, a, b, pre, scale, bias, y, outer, n, scale_size, bias_size, eps);
+    if (!ok)
         return INFINI_ROCM_UNSUPPORTED; // the caller falls back to Add + Norm
     IROCM_LAUNCH_CHECK("add_norm");
     return INFINI_ROCM_OK;
@@ -987,6 +1009,12 @@ int infini_rocm_layer_norm(infiniRocmRuntime_t rt, int dtype, const void *x, con
 int infini_rocm_add_norm(infiniRocmRuntime_t rt, int dtype, int rms, const void *a, const void *b, const void *scale,
                          const void *bias, void *y, int64_t outer, int64_t norm_size, int64_t scale_size,
                          int64_t bias_size, float eps) {
+    return infini_rocm_bias_add_norm(rt, dtype, rms, a, nullptr, b, scale, bias, y, outer, norm_size, scale_size, bias_size, eps);
+}
+
+int infini_rocm_bias_add_norm(infiniRocmRuntime_t rt, int dtype, int rms, const void *a, const void *pre, const void *b,
+                              const void *scale, const void *bias, void *y, int64_t outer, int64_t norm_size,
+                              int64_t scale_size, int64_t bias_size, float eps) {
     IROCM_CHECK_ARG(rt, "NULL runtime");
     IROCM_CHECK_ARG(outer >= 0 && norm_size >= 0 && norm_size < (1ll << 31), "add_norm: bad extent");
     if (outer == 0 || norm_size == 0)
@@ -996,10 +1024,10 @@ int infini_rocm_add_norm(infiniRocmRuntime_t rt, int dtype, int rms, const void 
     IROCM_CHECK_ARG(bias == nullptr || bias_size == 1 || bias_size == norm_size, "add_norm: bad bias size");
     int st = INFINI_ROCM_UNSUPPORTED;
 #define GO(T)                                                                                                   \
-    st = rms ? add_norm_dispatch<T, true>(rt, (const T *)a, (const T *)b, (const T *)scale, (const T *)bias, (T *)y, \
-                                          outer, norm_size, scale_size, bias_size, eps)                        \
-             : add_norm_dispatch<T, false>(rt, (const T *)a, (const T *)b, (const T *)scale, (const T *)bias, (T *)y, \
-                                           outer, norm_size, scale_size, bias_size, eps)
+    st = rms ? add_norm_dispatch<T, true>(rt, (const T *)a, (const T *)b, (const T *)pre, (const T *)scale, (const T *)bias, \
+                                          (T *)y, outer, norm_size, scale_size, bias_size, eps)                \
+             : add_norm_dispatch<T, false>(rt, (const T *)a, (const T *)b, (const T *)pre, (const T *)scale, (const T *)bias, \
+                                           (T *)y, outer, norm_size, scale_size, bias_size, eps)
     switch (dtype) {
     case INFINI_DT_F32: GO(float); break;
     case INFINI_DT_F16: GO(__half); break;
@@ -1009,8 +1037,14 @@ int infini_rocm_add_norm(infiniRocmRuntime_t rt, int dtype, int rms, const void 
 #undef GO
     if (st != INFINI_ROCM_UNSUPPORTED)
         return st;
-    // outside the fused kernel's reach (long or unaligned rows): the two-kernel chain, in place over y
-    const int64_t shape[2] = {outer, norm_size}, str[2] = {norm_size, 1};
+    // outside the fused kernel's reach (long or unaligned rows): the operator chain, in place over y
+    const int64_t shape[2] = {outer, norm_size}, str[2] = {norm_size, 1}, rowstr[2] = {0, 1};
+    if (pre) {
+        st = infini_rocm_binary(rt, INFINI_BIN_ADD, dtype, a, pre, y, 2, shape, str, rowstr);
+        if (st != INFINI_ROCM_OK)
+            return st;
+        a = y;
+    }
     st = infini_rocm_binary(rt, INFINI_BIN_ADD, dtype, a, b, y, 2, shape, str, str);
     if (st != INFINI_ROCM_OK)
         return st;

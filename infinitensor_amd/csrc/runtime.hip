@@ -58,6 +58,15 @@ int wcache_commit(infiniRocmRuntime *rt, hipStream_t stream) {
         IROCM_FAIL(INFINI_ROCM_HIP_ERROR, "weight cache: side stream failed: %s", hipGetErrorString(e));
     return INFINI_ROCM_OK;
 }
+void wcache_forget(infiniRocmRuntime *rt, const void *packed) {
+    for (size_t i = 0; i < rt->wcache.size(); ++i)
+        if (rt->wcache[i].packed == packed) {
+            rt->retired.push_back(rt->wcache[i].packed);
+            rt->wcache.erase(rt->wcache.begin() + i);
+            ++rt->wcache_epoch;
+            return;
+        }
+}
 void wcache_invalidate(infiniRocmRuntime *rt, const void *ptr, size_t bytes) {
     if (rt->wcache.empty() || !ptr || !bytes)
         return;
@@ -380,6 +389,9 @@ int infini_rocm_event_elapsed_ms(infiniRocmEvent_t start, infiniRocmEvent_t stop
 int infini_rocm_graph_begin_capture(infiniRocmRuntime_t rt) {
     IROCM_CHECK_ARG(rt, "NULL runtime");
     IROCM_CHECK_ARG(!rt->capturing, "capture already active");
+    // Work already queued on the stream (asynchronous memset / copy_inside of a raw C-ABI caller) must be complete before
+    // anything recorded here runs on the side stream (the conv weight pack of a capture is NOT ordered after the stream).
+    IROCM_HIP(hipStreamSynchronize(rt->stream));
     // ThreadLocal mode, like the reference (cuda_runtime.cc:259-266): other threads/runtimes
     // may keep using the device while this stream records.
     IROCM_HIP(hipStreamBeginCapture(rt->stream, hipStreamCaptureModeThreadLocal));

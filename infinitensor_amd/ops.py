@@ -163,6 +163,15 @@ def set_matmul_variant(rt: RocmRuntime, variant: int) -> None:
     check(lib().infini_rocm_matmul_set_variant(rt.handle, int(variant)))
 
 
+def matmul_last_variant(rt: RocmRuntime) -> str:
+    """Name of the GEMM kernel variant the most recent matmul on this runtime launched ("none" before the first)."""
+    import ctypes as C
+
+    v = C.c_int(-1)
+    check(lib().infini_rocm_matmul_last_variant(rt.handle, C.byref(v)))
+    return lib().infini_rocm_matmul_variant_name(v.value).decode() if v.value >= 0 else "none"
+
+
 def lrn(rt: RocmRuntime, x: torch.Tensor, size: int, alpha: float = 1e-4, beta: float = 0.75, bias: float = 1.0,
         out: torch.Tensor | None = None) -> torch.Tensor:
     """ONNX LRN across dim 1 of x [N, C, ...] (operators/lrn.h)."""
@@ -328,15 +337,20 @@ def attention_kvcache(rt: RocmRuntime, k_cache: torch.Tensor, v_cache: torch.Ten
 
 
 def add_layer_norm(rt: RocmRuntime, a: torch.Tensor, b: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor | None,
-                   eps: float, rms: bool = False, out: torch.Tensor | None = None) -> torch.Tensor:
-    """LayerNorm (or RMSNorm) over the last dim of a + b in one pass (the sum is rounded like the chain's)."""
+                   eps: float, rms: bool = False, out: torch.Tensor | None = None, pre: torch.Tensor | None = None) -> torch.Tensor:
+    """LayerNorm (or RMSNorm) over the last dim of a + b in one pass (the sum is rounded like the chain's). `pre`: one row
+    of n elements added to a first — (a + pre) + b, the MatMul -> Add(bias) -> Add(residual) -> Norm chain of the ONNX
+    front-end (infini_rocm_bias_add_norm)."""
     if a.shape != b.shape or a.dtype != b.dtype:
         raise ValueError("add_layer_norm: operands must match")
     n = a.shape[-1]
+    if pre is not None and (pre.numel() != n or pre.dtype != a.dtype):
+        raise ValueError("add_layer_norm: pre must be one row of the normalised size")
     if out is None:
         out = torch.empty_like(a)
-    check(lib().infini_rocm_add_norm(rt.handle, dtype_of(a), int(rms), _ptr(a), _ptr(b), _ptr(scale), _ptr(bias), _ptr(out),
-                                     a.numel() // n, n, scale.numel(), bias.numel() if bias is not None else 0, float(eps)))
+    check(lib().infini_rocm_bias_add_norm(rt.handle, dtype_of(a), int(rms), _ptr(a), _ptr(pre), _ptr(b), _ptr(scale), _ptr(bias),
+                                          _ptr(out), a.numel() // n, n, scale.numel(), bias.numel() if bias is not None else 0,
+                                          float(eps)))
     return out
 
 

@@ -51,7 +51,9 @@ PATCHES = [
     ("include/core/graph_handler.h",
      "#ifdef USE_CUDA\n    inline void run_with_cudagraph() {",
      "#ifdef USE_ROCM\n    inline void run_with_hipgraph() {\n"
-     "        (as<RocmRuntimeObj>(g->getRuntime()))->runWithHipGraph(g);\n    }\n#endif\n"
+     "        (as<RocmRuntimeObj>(g->getRuntime()))->runWithHipGraph(g);\n    }\n"
+     "    inline std::vector<std::string> rocm_fusion_plan() {\n"
+     "        return RocmRuntimeObj::describeFusionPlan(g);\n    }\n#endif\n"
      "#ifdef USE_CUDA\n    inline void run_with_cudagraph() {"),
     ("include/core/graph_handler.h",
      "#include \"core/graph.h\"",
@@ -86,7 +88,8 @@ PATCHES = [
      "        .def(\"run\", &Handler::run, policy::automatic)\n",
      "        .def(\"run\", &Handler::run, policy::automatic)\n"
      "#ifdef USE_ROCM\n        .def(\"run_with_hipgraph\", &Handler::run_with_hipgraph,\n"
-     "             policy::automatic)\n#endif\n"),
+     "             policy::automatic)\n"
+     "        .def(\"rocm_fusion_plan\", &Handler::rocm_fusion_plan)\n#endif\n"),
 ]
 
 

@@ -12,9 +12,11 @@
 #include "core/runtime.h"
 #include "core/tensor.h"
 #include "infini_rocm.h"
+#include <functional>
 #include <list>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <unordered_map>
 
 namespace infini {
@@ -72,16 +74,36 @@ class RocmRuntimeObj : public RuntimeObj {
     void initComm(const string &name, int worldSize, int rank) final;
     CommunicatorObj &getCommunicator() const final;
 
-    // Output redirection for the "producer -> Reshape" fusion (rocm_fusion.cc): while set, the kernels of
-    // rocm_kernels.cc resolve `redirectTensor` to `redirectPtr` instead of the tensor's own buffer, so the producer
-    // writes straight into the Reshape's output and the copy (reference: CopyCuda, reshape.cc:4-13) is not launched.
-    static thread_local const TensorObj *redirectTensor;
-    static thread_local void *redirectPtr;
-    // with a redirected MatMul: store the result head-split ([m / seq][n / headDim][seq][headDim]) — the
-    // MatMul -> Reshape -> Transpose(0, 2, 1, 3) fusion (infini_rocm_matmul_headsplit); 0 = plain store
-    static thread_local int redirectSeq, redirectHeadDim;
-    // with a redirected MatMul: activation applied in the GEMM epilogue (the MatMul -> Gelu fusion passes 5); 0 = none
-    static thread_local int redirectAct;
+    // Per-launch overrides a planned (fused) launch hands to the kernels of rocm_kernels.cc (thread-local, set by an RAII
+    // scope around ONE launchOne / C-ABI call, never alive across launches):
+    //  * tensor[i] -> ptr[i]: P(t) resolves these tensors to the given pointers instead of their own buffers — a producer
+    //    writing straight into a Reshape's output (reference: CopyCuda, reshape.cc:4-13, not launched), or an operator
+    //    reading a result that a previous launch left in the workspace;
+    //  * for the MatMul `matmul`: a folded Add(bias) (`biasPtr`: a row vector of n elements), an activation in the GEMM
+    //    epilogue (`act`, 5 = Gelu) and a head-split store ([m / seq][n / headDim][seq][headDim]: the
+    //    MatMul -> Reshape -> Transpose(0, 2, 1, 3) chain, infini_rocm_matmul_headsplit); 0 = plain.
+    struct LaunchOverrides {
+        const TensorObj *tensor[2] = {nullptr, nullptr};
+        void *ptr[2] = {nullptr, nullptr};
+        const OperatorObj *matmul = nullptr;
+        const void *biasPtr = nullptr;
+        int act = 0, seq = 0, headDim = 0;
+    };
+    static thread_local LaunchOverrides overrides;
+
+    // One entry of a launch plan (src/rocm_fusion.cc): the operators `members` (positions in the graph's operator order)
+    // run as ONE launch sequence `run` at position `slot`.
+    struct PlanItem {
+        size_t slot = 0;
+        std::vector<size_t> members;
+        std::string what;           // "conv+bias+relu", "matmul+bias+headsplit x3", ... ("" = the operator's own kernel)
+        std::function<void()> run;  // empty: nothing to launch (the operators were absorbed by another item)
+        bool fused = false;
+    };
+    using LaunchPlan = std::vector<PlanItem>;
+    // What launchAll would do for `graph` (any runtime: on a non-ROCM runtime nothing can be launched, the plan is only
+    // described) — one line per item: "<slot> <what> [members]". Tests and tools/plan_dump.py read it.
+    static std::vector<std::string> describeFusionPlan(const Graph &graph);
 
   private:
     struct TensorState {
@@ -113,19 +135,15 @@ class RocmRuntimeObj : public RuntimeObj {
     };
     using Cache = std::list<std::unique_ptr<CacheEntry>>;
 
+    friend class FusionPlanner; // src/rocm_fusion.cc
     void launchAll(const Graph &graph, bool validate) const;
-    // launches ops[i .. i+k) as one kernel when a fusion rule applies; returns k (0 = no rule)
-    size_t tryLaunchFused(const OpVec &ops, size_t i) const;
-    size_t tryLaunchGroupedMatmul(const OpVec &ops, size_t i) const;
-    size_t tryLaunchRopeHeadSplit(const OpVec &ops, size_t i) const;
-    void launchWithInputRedirect(const Operator &op, const TensorObj *t, void *ptr) const;
-    size_t tryLaunchFusedRules(const OpVec &ops, size_t i) const;
-    size_t tryLaunchIntoReshape(const OpVec &ops, size_t i) const;
-    size_t tryLaunchHeadSplit(const OpVec &ops, size_t i) const;
-    size_t tryLaunchMatmulGelu(const OpVec &ops, size_t i) const;
+    // the launch plan of a graph: which operators run fused, where (src/rocm_fusion.cc); fusion off = one item per operator
+    LaunchPlan buildPlan(const Graph &graph) const;
+    void executePlan(const LaunchPlan &plan, const OpVec &ops) const;
     void launchOne(const Operator &op) const; // one operator through KernelRegistry (+ its perf record, if tuned)
-    size_t tryLaunchFusedAttention(const OpVec &ops, size_t i) const;
-    int tunedVariant(const Operator &op) const; // kernel variant chosen by tune() for this operator's workload, or -1
+    // a host write went over [ptr, ptr + bytes): scalar constants the planner read from there are stale (returns whether
+    // any were — captured graphs embed plans that were decided on those values)
+    bool forgetScalars(const void *ptr, size_t bytes) const;
     void tuneImpl(const Graph &graph, bool profiling) const;
     GraphState stateOf(const Graph &graph) const;
     void replay(CacheEntry &entry);
@@ -139,15 +157,10 @@ class RocmRuntimeObj : public RuntimeObj {
     bool fusion = true;
     mutable size_t fusedCount = 0;
     mutable size_t bridgedCount = 0;
-    mutable std::vector<char> launchedAhead; // per launchAll: operators a grouped launch already ran out of order
-    // per launchAll: operator index -> (tensor, pointer): this operator reads `tensor` from `pointer` (a result a grouped launch
-    // parked in the workspace because the tensor's own buffer was still in use when the group ran); launched without fusion
-    struct ParkedFeed {
-        const TensorObj *tensor;
-        void *ptr;
-    };
-    mutable std::map<size_t, ParkedFeed> parkedFeeds;
     mutable size_t parkedCount = 0;
+    // values of one-element constant tensors (weights no operator writes) the planner looked at — Pow's exponent, the
+    // sqrt(2) / 0.5 / 1 of a decomposed Gelu, LayerNorm's epsilon — keyed by device address; dropped by host writes
+    mutable std::map<const void *, std::pair<size_t, double>> scalarCache;
     Cache cache; // most recently used first
     mutable std::recursive_mutex executionMutex;
     mutable std::recursive_mutex cacheMutex;

@@ -1,77 +1,119 @@
-// Launch-time operator fusion for Device::ROCM: the reference executes one kernel per operator
-// (cuda_runtime.cc:136-170); on MI355X the element-wise tails of a convolution are pure HBM traffic, so the
-// runtime folds them into the producing kernel's epilogue when that cannot be observed:
+// Launch planning for Device::ROCM. The reference executes one kernel per operator (cuda_runtime.cc:136-170); on
+// MI355X the element-wise tails of a convolution / GEMM are pure HBM traffic, so before a graph is launched the runtime
+// PLANS it: operators that can run as one kernel become one plan item, everything else stays one item per operator.
+// The plan is then executed item by item (rocm_runtime.cc::executePlan); nothing of the graph is modified.
 //
-//   Conv -> Add(per-channel bias [1,F,1,1] / [F,1,1]) [-> Relu]   =>  conv2d(bias, act)        (onnx.py:159-190
-//   Conv -> Relu                                                   =>  conv2d(act)              emits these chains)
-//   Conv -> Add(bias) -> Add(identity) [-> Relu]                   =>  conv2d_res(bias, residual, act)   [f16 / bf16,
-//        even output planes: the residual moves in the LDS-staged epilogue's 128-byte rows; INFINI_ROCM_FUSE_RES=0|1]
-//   Add  -> Relu                                                   =>  binary(ADD_RELU)         (residual join)
-//   Relu -> MaxPool                                                =>  pool2d_relu              (ResNet stem)
-//   Add  -> LayerNormalization(last axis) | RMSNorm                =>  add_norm                 (transformer residual)
-//   Add(bias) -> Add(identity) [-> Relu]                           =>  bias_residual            (when the conv could not
-//        take the bias: its input's storage was recycled for the output)
-//   MatMul(+bias) -> Reshape [B,S,H,D] -> Transpose(0,2,1,3)        =>  matmul_headsplit (the q / k / v head split in
-//        the GEMM epilogue; f16 / bf16)
-//   MatMul(+bias) -> Gelu (f16 / bf16)                              =>  matmul(act = 5): Gelu in the GEMM epilogue
-//   MatMul | Transpose | element-wise | Softmax | LayerNorm | Gather -> Reshape-family copy
-//                                                                  =>  the producer writes into the copy's output
-//   MatMul(Q, K^T) [-> Div|Mul(scalar)] [-> Add(mask)] -> Softmax(last axis) -> MatMul(P, V)
-//                                                                  =>  attention (csrc/attention.hip): the score
-//        matrix is never written; Q, K, V rank-4 [b, h, S, D] with D in {64, 128}, f16 / bf16, mask [b|1, 1, 1, Sk];
-//        a following Transpose(0,2,1,3) -> Reshape (the head merge) is folded into the kernel's store
+// The chains are matched on the graph the reference's ONNX front-end actually builds (pyinfinitensor/onnx.py), i.e.
+//   * a Conv's bias arrives as   Conv -> Reshape(bias, [1, F, 1, 1]) -> Add           (onnx.py:159-190)
+//   * a linear layer as          MatMul(x, W) [no bias, no transpose] -> Add(bias)    (onnx.py:280-290; only Gemm,
+//     :291-311, carries bias / transposes)
+//   * Q.K^T as                   Transpose(K) -> MatMul(Q, K^T)
+//   * opset < 17 LayerNorm as    ReduceMean, Sub, Pow, ReduceMean, Add, Sqrt, Div, Mul, Add    (nine operators)
+//   * opset < 20 Gelu as         Div, Erf, Add, Mul, Mul
+// and in whatever operator order the exporter chose: a matcher follows the CONSUMER of the chain's tensor, not the next
+// operator in the list (the front-end's Reshape of a conv bias sits between the Conv and its Add; a transformer's q
+// projection is issued before k and v but reshaped after them).
 //
-// Conditions (checked every launch, nothing is cached across graph mutations):
-//   * the ops are CONSECUTIVE in the graph's operator order and each intermediate tensor has exactly one
-//     consumer (so it is not a graph output and nobody else reads it);
-//   * the buffer of the final tensor does not overlap an input of the fused kernel — the memory planner reuses
-//     dead tensors' storage, and the fused kernel writes the final tensor earlier than the unfused chain would
-//     (exception: Add -> Relu exactly in place over a same-extent input, which is index-wise safe);
-//   * same dtype throughout. Intermediate tensors are simply not materialised.
-// Numerics: fp32 is bit-identical (same operations in the same order); f16 / bf16 round once instead of after
-// every op (a result at least as close to the exact value); Add -> Relu is bit-identical in every type.
+// Rules (every intermediate tensor has exactly one consumer and is not a graph output; same dtype throughout):
+//   Conv -> Add(per-channel bias) [-> Add(identity)] [-> Relu]     =>  conv2d_res(bias, residual, act)
+//   MatMul [-> Add(row bias)] [-> Gelu] [-> Reshape [B,S,H,D] -> Transpose(0,2,1,3)  |  -> Reshape-family copy]
+//                                                                  =>  one GEMM: bias / Gelu in the epilogue, head-split
+//        or redirected store; two or three such projections of ONE activation (q, k, v) => one grouped launch
+//   [Transpose(K)] -> MatMul(Q, K^T) [-> Div|Mul(scalar)] [-> Add(mask)] -> Softmax(last axis) -> MatMul(P, V)
+//        [-> Transpose(0,2,1,3) -> Reshape]                        =>  attention (csrc/attention.hip): the score matrix is
+//        never written. K^T may be MatMul's transB, a Transpose(0,1,3,2) of the head-split K (absorbed: the kernel
+//        reads K), or a Transpose(0,2,3,1) of K's [B,S,H,D] view (the producer stores K head-major instead)
+//   ReduceMean, Sub, Pow(2), ReduceMean, Add(eps), Sqrt, Div, Mul(gamma), Add(beta)   =>  layer_norm  (one pass)
+//   Div(x, sqrt 2), Erf, Add(1), Mul(x, .), Mul(., 0.5)  (any operand order)          =>  Gelu (unary kernel or epilogue)
+//   Add -> LayerNormalization(last axis) | RMSNorm | decomposed LayerNorm             =>  add_norm
+//   Add(bias) -> Add(identity) [-> Relu]  =>  bias_residual;     Add -> Relu  =>  binary(ADD_RELU)
+//   Relu -> MaxPool  =>  pool2d_relu;     Silu(a) -> Mul(., b)  =>  silu_mul;     RoPE -> Reshape -> Transpose  =>  rope_headsplit
+//   producer -> Reshape-family copy       =>  the producer writes into the copy's output
+//   plain MatMuls of one activation a few operators apart (gate / up) => one grouped launch (run AHEAD of their place)
+//   Reshape-family operators on a weight (the conv bias Reshape)  =>  not launched: a reshape does not change the bytes,
+//        the consumer reads the weight itself
+//
+// When a fused item runs. An item made of operators at positions p0 < p1 < ... < pk runs at pk (it "sinks"): its final
+// tensor is written exactly when the unfused graph would write it, so the memory planner's reuse of dead storage stays
+// valid for everything else. What moves is the time the item READS the inputs of its earlier members; the planner proves
+// for each such tensor that no operator between its original reader and pk writes memory overlapping it (`survives`) —
+// else the chain is cut before that member. Results of earlier members that ARE materialised later than planned (k and v
+// of a grouped q / k / v launch) must have no reader in between (`unreadUntil`). The one rule that runs operators AHEAD of
+// their place (grouped gate / up) checks the opposite: the early write must not land on anything the jumped-over
+// operators — or a sunk item's late reads — still use.
+// In-kernel hazards: the final buffer must not overlap an input of the fused kernel (exception: element-wise kernels
+// exactly in place over a same-extent input).
+// Numerics: fp32 chains run the same operations in the same order (bit-identical); f16 / bf16 round once instead of after
+// every operator; the decomposed LayerNorm / Gelu forms compute in fp32 what the nine / five operators round per step.
 // INFINI_ROCM_FUSION=0 or RocmRuntimeObj::setFusion(false) restores one kernel per operator.
 #include "core/perf_engine.h"
 #include "operators/conv.h"
-#include "rocm/rocm_perf.h"
-#include <cstdio>
-#include <cstdlib>
-#include <string>
 #include "operators/element_wise.h"
 #include "operators/layer_norm.h"
-#include "operators/rms_norm.h"
 #include "operators/matmul.h"
 #include "operators/pooling.h"
+#include "operators/reduce.h"
+#include "operators/rms_norm.h"
 #include "operators/softmax.h"
 #include "operators/transpose.h"
 #include "operators/unary.h"
+#include "rocm/rocm_perf.h"
 #include "rocm/rocm_runtime.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <optional>
+#include <string>
+#include <unordered_map>
 
 namespace infini {
 
+thread_local RocmRuntimeObj::LaunchOverrides RocmRuntimeObj::overrides;
+
 namespace {
+using PlanItem = RocmRuntimeObj::PlanItem;
+using LaunchPlan = RocmRuntimeObj::LaunchPlan;
+
+struct OverrideScope { // RAII: overrides never outlive one launch
+    OverrideScope() { RocmRuntimeObj::overrides = RocmRuntimeObj::LaunchOverrides(); }
+    ~OverrideScope() { RocmRuntimeObj::overrides = RocmRuntimeObj::LaunchOverrides(); }
+    void redirect(const TensorObj *t, void *p) {
+        auto &o = RocmRuntimeObj::overrides;
+        const int s = o.tensor[0] ? 1 : 0;
+        IT_ASSERT(o.tensor[s] == nullptr, "more than two tensor overrides in one launch");
+        o.tensor[s] = t;
+        o.ptr[s] = p;
+    }
+};
+
+bool envOn(const char *name) { // default on; NAME=0 is the A/B hook
+    const char *e = std::getenv(name);
+    return !(e && std::atoi(e) == 0);
+}
+uintptr_t addrOf(const Tensor &t) { return reinterpret_cast<uintptr_t>(t->getRawDataPtr<void *>()); }
 bool overlaps(const Tensor &a, const Tensor &b) {
-    const auto pa = reinterpret_cast<uintptr_t>(a->getRawDataPtr<void *>());
-    const auto pb = reinterpret_cast<uintptr_t>(b->getRawDataPtr<void *>());
+    const auto pa = addrOf(a), pb = addrOf(b);
     return pa < pb + b->getBytes() && pb < pa + a->getBytes();
 }
-// `t` is consumed only by `next`, which directly follows in the operator order
-bool soleConsumerIs(const Tensor &t, const Operator &next) {
-    const auto targets = t->getTargets();
-    return targets.size() == 1 && targets[0] == next;
+bool samePlace(const Tensor &a, const Tensor &b) { return addrOf(a) == addrOf(b) && a->getDims() == b->getDims(); }
+bool isCopyLike(OpType t) {
+    return t == OpType::Reshape || t == OpType::Flatten || t == OpType::Identity || t == OpType::Squeeze || t == OpType::Unsqueeze;
 }
-bool isChannelBias(const Tensor &b, int f) {
-    const auto &d = b->getDims();
+bool isChannelBias(const Shape &d, int f) {
     if (d.size() == 4)
         return d[0] == 1 && d[1] == f && d[2] == 1 && d[3] == 1;
     if (d.size() == 3)
         return d[0] == f && d[1] == 1 && d[2] == 1;
     return false;
 }
-// `b` is a per-channel bias of a tensor with dims `d` ([N, C, ...]): [1, C, 1, ...] or [C, 1, ...]
-bool isChannelBiasOf(const Tensor &b, const Shape &d) {
-    const auto &bd = b->getDims();
-    if ((int64_t)b->size() != d[1])
+// `bd` is a per-channel bias of a tensor with dims `d` ([N, C, ...]): [1, C, 1, ...] or [C, 1, ...]
+bool isChannelBiasOf(const Shape &bd, const Shape &d) {
+    int64_t sz = 1;
+    for (int v : bd)
+        sz *= v;
+    if (d.size() < 2 || sz != d[1])
         return false;
     if (bd.size() == d.size()) {
         for (size_t i = 0; i < bd.size(); ++i)
@@ -86,6 +128,15 @@ bool isChannelBiasOf(const Tensor &b, const Shape &d) {
         return true;
     }
     return false;
+}
+// `bd` broadcasts to one row of n elements: [n], [1, n], [1, 1, n], ...
+bool isRowVector(const Shape &bd, int n) {
+    if (bd.empty() || bd.back() != n)
+        return false;
+    for (size_t i = 0; i + 1 < bd.size(); ++i)
+        if (bd[i] != 1)
+            return false;
+    return true;
 }
 std::vector<int64_t> strides64(const Shape &shape, const Shape &outShape) {
     const int r = shape.size(), ro = outShape.size();
@@ -102,577 +153,1348 @@ std::vector<int64_t> strides64(const Shape &shape, const Shape &outShape) {
     }
     return out;
 }
-} // namespace
-
-namespace {
-struct OutputRedirect { // RAII: the redirection never outlives one launch
-    OutputRedirect(const TensorObj *t, void *p, int seq = 0, int headDim = 0, int act = 0) {
-        RocmRuntimeObj::redirectTensor = t;
-        RocmRuntimeObj::redirectPtr = p;
-        RocmRuntimeObj::redirectSeq = seq;
-        RocmRuntimeObj::redirectHeadDim = headDim;
-        RocmRuntimeObj::redirectAct = act;
-    }
-    ~OutputRedirect() {
-        RocmRuntimeObj::redirectTensor = nullptr;
-        RocmRuntimeObj::redirectPtr = nullptr;
-        RocmRuntimeObj::redirectSeq = RocmRuntimeObj::redirectHeadDim = RocmRuntimeObj::redirectAct = 0;
-    }
-};
-} // namespace
-
-void RocmRuntimeObj::launchWithInputRedirect(const Operator &op, const TensorObj *t, void *ptr) const {
-    OutputRedirect feed(t, ptr); // P(t) resolves to ptr for the duration of this one launch (rocm_kernels.cc)
-    launchOne(op);
+bool isHalf(int dt) { return dt == INFINI_DT_F16 || dt == INFINI_DT_BF16; }
+bool permIs(const std::vector<int> &p, int a, int b, int c, int d) {
+    return p.size() == 4 && p[0] == a && p[1] == b && p[2] == c && p[3] == d;
 }
+double halfToDouble(uint16_t h) {
+    const int s = h >> 15, e = (h >> 10) & 31, m = h & 1023;
+    double v = e == 0 ? std::ldexp((double)m, -24) : (e == 31 ? (m ? NAN : INFINITY) : std::ldexp((double)(m | 1024), e - 25));
+    return s ? -v : v;
+}
+} // namespace
 
-size_t RocmRuntimeObj::tryLaunchFusedAttention(const OpVec &ops, size_t i) const {
-    auto mm1 = as<MatmulObj>(ops[i]);
-    if (mm1->getTransA() || !mm1->getTransB() || mm1->getBias() || mm1->getAct() != ActType::None)
-        return 0;
-    const Tensor q = mm1->getInputs(0), k = mm1->getInputs(1);
-    const auto &qd = q->getDims(), &kd = k->getDims();
-    const int dt = q->getDTypeIndex();
-    if (qd.size() != 4 || kd.size() != 4 || qd[0] != kd[0] || qd[1] != kd[1] || qd[3] != kd[3] || (qd[3] != 64 && qd[3] != 128) ||
-        (dt != INFINI_DT_F16 && dt != INFINI_DT_BF16) || !(k->getDType() == q->getDType()))
-        return 0;
-    const int b = qd[0], h = qd[1], sq = qd[2], sk = kd[2], d = qd[3];
-    // limits of infini_rocm_attention_ex (attention.hip): outside them the chain simply runs unfused
-    if ((int64_t)b * h >= 65536 || h >= 65536 || sk <= 0 || sq <= 0 ||
-        ((((uintptr_t)q->getRawDataPtr<void *>()) | ((uintptr_t)k->getRawDataPtr<void *>())) & 15) != 0)
-        return 0;
-    Tensor cur = mm1->getOutput(), scale = nullptr, mask = nullptr;
-    bool mask2d = false;
-    size_t j = i + 1;
-    bool isDiv = false;
-    auto next = [&](OpType t) { return j < ops.size() && ops[j]->getOpType() == t && soleConsumerIs(cur, ops[j]); };
-    if (next(OpType::Div) || next(OpType::Mul)) {
-        const Tensor a0 = ops[j]->getInputs(0), a1 = ops[j]->getInputs(1);
-        isDiv = ops[j]->getOpType() == OpType::Div;
-        const Tensor other = a0 == cur ? a1 : a0;
-        if (other == cur || other->size() != 1 || !(other->getDType() == q->getDType()) || (isDiv && a0 != cur))
-            return 0;
-        scale = other;
-        cur = ops[j++]->getOutput();
+class FusionPlanner {
+  public:
+    FusionPlanner(const RocmRuntimeObj *R, const OpVec &ops, bool fusion)
+        : R(R), rt(R ? R->handle() : nullptr), ops(ops), n(ops.size()), fusion(fusion), claimed(ops.size(), 0),
+          writeAt(ops.size(), -1), log(std::getenv("INFINI_ROCM_FUSION_LOG") != nullptr) {
+        posOf.reserve(n * 2);
+        for (size_t i = 0; i < n; ++i)
+            posOf[ops[i].get()] = i;
     }
-    if (next(OpType::Add)) {
-        const Tensor a0 = ops[j]->getInputs(0), a1 = ops[j]->getInputs(1);
-        const Tensor other = a0 == cur ? a1 : a0;
-        const auto &md = other->getDims();
-        // key mask [b|1, 1, 1, Sk] (BERT padding) or a full additive mask [b|1, h|1, Sq, Sk] with the same grouping rule:
-        // heads may only broadcast when the batch does too or both are explicit ([1,1], [b,1], [b,h])
-        const bool keyMask = md.size() == 4 && md[1] == 1 && md[2] == 1;
-        const bool fullMask = md.size() == 4 && md[2] == sq && sq > 1 && (md[1] == 1 || (md[1] == h && md[0] == b));
-        if (other == cur || md.size() != 4 || (md[0] != b && md[0] != 1) || !(keyMask || fullMask) || md[3] != sk ||
-            !(other->getDType() == q->getDType()))
-            return 0;
-        mask = other;
-        mask2d = !keyMask;
-        cur = ops[j++]->getOutput();
-    }
-    if (!next(OpType::Softmax) || as<SoftmaxObj>(ops[j])->getAxis() != 3)
-        return 0;
-    cur = ops[j++]->getOutput();
-    if (!next(OpType::MatMul))
-        return 0;
-    auto mm2 = as<MatmulObj>(ops[j]);
-    const Tensor v = mm2->getInputs(1), out = mm2->getOutput();
-    if (mm2->getInputs(0) != cur || mm2->getTransA() || mm2->getTransB() || mm2->getBias() || mm2->getAct() != ActType::None ||
-        v->getDims() != kd || !(v->getDType() == q->getDType()) || (((uintptr_t)v->getRawDataPtr<void *>()) & 15) != 0 ||
-        (((uintptr_t)out->getRawDataPtr<void *>()) & 7) != 0)
-        return 0;
-    // Head merge: ctx [b, h, Sq, D] -> Transpose(0, 2, 1, 3) -> Reshape [b, Sq, h * D] (what every exported transformer
-    // does before the output projection) is folded into the kernel's store (infini_rocm_attention_ex).
-    Tensor dstT = out;
-    int64_t heads = 0;
-    size_t last = j;
-    static const bool mergeOn = !(std::getenv("INFINI_ROCM_FUSE_HEADMERGE") && std::atoi(std::getenv("INFINI_ROCM_FUSE_HEADMERGE")) == 0);
-    if (mergeOn && j + 2 < ops.size() && ops[j + 1]->getOpType() == OpType::Transpose && ops[j + 2]->getOpType() == OpType::Reshape &&
-        soleConsumerIs(out, ops[j + 1]) && soleConsumerIs(ops[j + 1]->getOutput(), ops[j + 2]) &&
-        ops[j + 2]->getInputs(0) == ops[j + 1]->getOutput()) {
-        const auto perm = as<TransposeObj>(ops[j + 1])->getPermute();
-        const Tensor r = ops[j + 2]->getOutput();
-        if (perm.size() == 4 && perm[0] == 0 && perm[1] == 2 && perm[2] == 1 && perm[3] == 3 && r->getBytes() == out->getBytes() &&
-            r->getDType() == out->getDType()) {
-            dstT = r;
-            heads = h;
-            last = j + 2;
-        }
-    }
-    // O may sit exactly on Q (the planner likes to: Q is dead after the first MatMul and has O's size): a workgroup
-    // loads its query rows before the key sweep and writes the same rows of O after it (plain layout only). K / V are
-    // read by everyone. Any other overlap (K and V die after their MatMul too, and have O's size) is bridged through the
-    // workspace: O is [Sq, D] per head, the copy is small next to the score traffic the fusion removes.
-    const bool onQ = heads == 0 && dstT->getRawDataPtr<void *>() == q->getRawDataPtr<void *>() && dstT->getDims() == qd;
-    const bool hazard = (overlaps(dstT, q) && !onQ) || overlaps(dstT, k) || overlaps(dstT, v) ||
-                        (mask && overlaps(dstT, mask)) || (scale && overlaps(dstT, scale));
-    void *dst = dstT->getRawDataPtr<void *>();
-    if (hazard)
-        dst = getWorkspace(dstT->getBytes());
-    // pairs (batch, head) served by one mask slab: [1,1,..] all of them, [b,1,..] the heads of a batch, [b,h,..] one
-    const int64_t group = !mask ? 1 : ((mask->getDims()[1] == h && h > 1) ? 1 : (mask->getDims()[0] == 1 ? (int64_t)b * h : h));
-    ROCM_CALL(infini_rocm_attention_ex(rt, dt, q->getRawDataPtr<void *>(), k->getRawDataPtr<void *>(),
-                                              v->getRawDataPtr<void *>(), mask ? mask->getRawDataPtr<void *>() : nullptr, dst,
-                                              (int64_t)b * h, sq, sk, d, group, scale ? scale->getRawDataPtr<void *>() : nullptr,
-                                       isDiv ? 1 : 0, 1.0f, 0, heads, mask2d ? 1 : 0));
-    if (hazard) {
-        // The bridged result usually feeds exactly one operator, the output projection, which is next in the list: let
-        // that MatMul read its A operand straight from the workspace (input redirect through P(), rocm_kernels.cc) instead
-        // of copying 25 MB per BERT layer to a tensor nobody else reads. Only a plain MatMul that cannot itself take the
-        // workspace (split-K partial planes) and that no other launch-time rule would pick up.
-        static const bool feedOn = !(std::getenv("INFINI_ROCM_FEED_NEXT") && std::atoi(std::getenv("INFINI_ROCM_FEED_NEXT")) == 0);
-        const size_t nx = last + 1;
-        if (feedOn && nx < ops.size() && ops[nx]->getOpType() == OpType::MatMul && soleConsumerIs(dstT, ops[nx])) {
-            auto mmn = as<MatmulObj>(ops[nx]);
-            const auto [nb, nm, nn, nk] = mmn->getBMNK();
-            int mayWs = 1;
-            ROCM_CALL(infini_rocm_matmul_may_use_workspace(rt, nb, nm, nn, &mayWs));
-            bool onlyA = mmn->getInputs(0) == dstT;
-            for (size_t q = 1; q < mmn->getInputs().size(); ++q)
-                onlyA = onlyA && mmn->getInputs(q) != dstT;
-            bool otherRule = false; // head split / Gelu / copy elision would want the single redirect slot themselves
-            if (nx + 1 < ops.size()) {
-                const auto t2 = ops[nx + 1]->getOpType();
-                otherRule = t2 == OpType::Reshape || t2 == OpType::Flatten || t2 == OpType::Identity || t2 == OpType::Squeeze ||
-                            t2 == OpType::Unsqueeze || t2 == OpType::Gelu;
+
+    LaunchPlan run() {
+        for (size_t i = 0; i < n; ++i) {
+            if (claimed[i])
+                continue;
+            bool done = false;
+            if (auto pk = parked.find(i); pk != parked.end()) {
+                done = fusion && planParkedConsumer(i, pk->second);
+                if (!done) { // plain launch, the parked operand read from the workspace
+                    const ParkedFeed pf = pk->second;
+                    const Operator op = ops[i];
+                    const RocmRuntimeObj *r = R;
+                    emit(i, {i}, "", false, [r, op, pf] {
+                        OverrideScope s;
+                        s.redirect(pf.tensor, r->getWorkspace(pf.bytes));
+                        r->launchOne(op);
+                    });
+                    done = true;
+                }
             }
-            if (!mayWs && onlyA && !otherRule && tunedVariant(ops[nx]) != 3 && !overlaps(mmn->getOutput(), dstT)) {
-                OutputRedirect feed(dstT.get(), dst);
-                launchOne(ops[nx]);
-                return last + 2 - i;
+            if (!done && fusion)
+                done = tryRules(i);
+            if (!done) {
+                const Operator op = ops[i];
+                const RocmRuntimeObj *r = R;
+                emit(i, {i}, "", false, [r, op] { r->launchOne(op); });
             }
         }
-        ROCM_CALL(infini_rocm_copy_inside(rt, dstT->getRawDataPtr<void *>(), dst, dstT->getBytes()));
+        std::stable_sort(items.begin(), items.end(), [](const PlanItem &a, const PlanItem &b) { return a.slot < b.slot; });
+        return std::move(items);
     }
-    return last + 1 - i;
-}
 
-int RocmRuntimeObj::tunedVariant(const Operator &op) const {
-    auto key = PerfEngine::Key{KernelAttrs{device, op->getOpType().underlying()}, op->getOpPerfKey()};
-    auto rec = std::dynamic_pointer_cast<RocmVariantPerfRecordObj>(PerfEngine::getInstance().getPerfData(key));
-    return rec ? rec->variant : -1;
-}
+  private:
+    const RocmRuntimeObj *R; // nullptr: dry run (describeFusionPlan on a non-ROCM runtime)
+    infiniRocmRuntime_t rt;
+    const OpVec &ops;
+    const size_t n;
+    const bool fusion;
+    std::vector<char> claimed;
+    // for a claimed operator: the slot at which ITS output tensor is really written (-1: never — an intermediate that is
+    // not materialised, a grouped result parked in the workspace)
+    std::vector<long> writeAt;
+    std::unordered_map<const OperatorObj *, size_t> posOf;
+    LaunchPlan items;
+    const bool log;
+    struct LateRead { // a sunk item reads `t` at `to` instead of `from`
+        size_t from, to;
+        Tensor t;
+    };
+    std::vector<LateRead> lateReads;
+    struct ParkedFeed { // the operator at the key position reads `tensor` from the workspace (getWorkspace(bytes))
+        const TensorObj *tensor;
+        size_t bytes;
+    };
+    std::map<size_t, ParkedFeed> parked;
 
-size_t RocmRuntimeObj::tryLaunchFused(const OpVec &ops, size_t i) const {
-    if (const size_t used = tryLaunchFusedRules(ops, i))
-        return used;
-    if (const size_t used = tryLaunchHeadSplit(ops, i))
-        return used;
-    if (const size_t used = tryLaunchMatmulGelu(ops, i))
-        return used;
-    if (const size_t used = tryLaunchGroupedMatmul(ops, i))
-        return used;
-    if (const size_t used = tryLaunchRopeHeadSplit(ops, i))
-        return used;
-    return tryLaunchIntoReshape(ops, i);
-}
-
-
-// MatMul(+bias) [.., S, H*D] or [B*S, H*D] -> Reshape [B, S, H, D] -> Transpose(0, 2, 1, 3): the head split of a
-// transformer's q / k / v projections (three launches and two extra passes over the activation in the reference) as ONE
-// GEMM whose epilogue stores head-split (infini_rocm_matmul_headsplit). Same sums, same rounding: bit-identical.
-//
-// Two or three such chains in a row that read the SAME activations (q, k, v) become ONE grouped launch when their weights,
-// biases and outputs happen to sit at a uniform spacing in memory (the reference's allocator hands out a layer's weights
-// back to back, and the three head-split outputs are the same size): the group index is the GEMM's batch index with a zero
-// A stride. One launch walks 3 x 256 tiles per CU-set instead of three launches of one tile per CU each paying the pipeline
-// prologue and the launch gap (BERT-base: 3 x 25 us -> ~62 us per layer). Same kernels, same sums: bit-identical.
-namespace {
-struct HeadSplitChain {
-    std::shared_ptr<MatmulObj> mm;
-    Tensor out;
-    long S = 0, D = 0, rows = 0; // rows = b * m: the GEMM's row count with the batch folded in
-    int n = 0, k = 0;
-};
-bool matchHeadSplit(const OpVec &ops, size_t i, HeadSplitChain &h) {
-    if (i + 2 >= ops.size() || ops[i]->getOpType() != OpType::MatMul || ops[i + 1]->getOpType() != OpType::Reshape ||
-        ops[i + 2]->getOpType() != OpType::Transpose)
-        return false;
-    auto mm = as<MatmulObj>(ops[i]);
-    auto tr = as<TransposeObj>(ops[i + 2]);
-    const Tensor c = mm->getOutput(), r = ops[i + 1]->getOutput(), out = tr->getOutput();
-    if (ops[i + 1]->getInputs(0) != c || tr->getInputs(0) != r || !soleConsumerIs(c, ops[i + 1]) || !soleConsumerIs(r, ops[i + 2]))
-        return false;
-    const auto &rd = r->getDims();
-    const auto perm = tr->getPermute();
-    if (rd.size() != 4 || perm.size() != 4 || perm[0] != 0 || perm[1] != 2 || perm[2] != 1 || perm[3] != 3)
-        return false;
-    const auto [b, m, n, k] = mm->getBMNK();
-    const long B = rd[0], S = rd[1], Hh = rd[2], D = rd[3];
-    // the MatMul's rows are (batch, position), its columns (head, channel): [b x m] == [B x S] row-wise, n == H * D
-    if ((long)b * m != B * S || (long)n != Hh * D || m % S != 0 || D % 8 != 0 ||
-        !(c->getDType() == out->getDType()) || c->getBytes() != out->getBytes())
-        return false;
-    for (const auto &in : mm->getInputs())
-        if (overlaps(out, in))
-            return false;
-    h.mm = mm;
-    h.out = out;
-    h.S = S;
-    h.D = D;
-    h.rows = (long)b * m;
-    h.n = n;
-    h.k = k;
-    return true;
-}
-} // namespace
-
-size_t RocmRuntimeObj::tryLaunchHeadSplit(const OpVec &ops, size_t i) const {
-    static const bool enabled = !(std::getenv("INFINI_ROCM_FUSE_HEADSPLIT") && std::atoi(std::getenv("INFINI_ROCM_FUSE_HEADSPLIT")) == 0);
-    HeadSplitChain h0;
-    if (!enabled || !matchHeadSplit(ops, i, h0))
-        return 0;
-    // ---- grouped q / k / v ------------------------------------------------------------------------------
-    static const bool groupOn = !(std::getenv("INFINI_ROCM_GROUP_QKV") && std::atoi(std::getenv("INFINI_ROCM_GROUP_QKV")) == 0);
-    const auto &mm0 = h0.mm;
-    const Tensor a0 = mm0->getInputs(0), w0 = mm0->getInputs(1);
-    const Tensor bias0 = mm0->numInputs() == 3 ? mm0->getInputs(2) : nullptr;
-    const int dt = a0->getDTypeIndex();
-    const bool groupable = groupOn && (dt == INFINI_DT_F16 || dt == INFINI_DT_BF16) && !mm0->getTransA() && !mm0->getTransB() &&
-                           w0->getRank() == 2 && tunedVariant(ops[i]) < 0 &&
-                           (!bias0 || (bias0->getRank() == 1 && (int)bias0->size() == h0.n));
-    if (groupable) {
-        std::vector<HeadSplitChain> g{h0};
-        while (g.size() < 4) {
-            HeadSplitChain hn;
-            if (!matchHeadSplit(ops, i + 3 * g.size(), hn))
+    // ---- graph helpers -----------------------------------------------------------------------------------------
+    size_t pos(const Operator &op) const { return posOf.at(op.get()); }
+    // the one operator that reads `t` (nullptr: several readers, none, or a graph output that must exist in memory)
+    Operator onlyUser(const Tensor &t) const {
+        if (t->isOutput())
+            return nullptr;
+        const auto tg = t->getTargets();
+        if (tg.size() != 1)
+            return nullptr;
+        auto it = posOf.find(tg[0].get());
+        if (it == posOf.end() || claimed[it->second])
+            return nullptr;
+        return tg[0];
+    }
+    Operator userOfType(const Tensor &t, OpType type, size_t after) const {
+        Operator u = onlyUser(t);
+        if (!u || !(u->getOpType() == type) || pos(u) <= after)
+            return nullptr;
+        return u;
+    }
+    // memory no operator ever writes and the planner never recycles: graph weights and inputs (dataMalloc, graph.cc: weights
+    // live in their own region, inputs / outputs are "not reused later"). A tensor the user created without marking it is
+    // recycled after its last reader like any intermediate.
+    static bool persistent(const Tensor &t) { return !t->getSource() && (t->isWeight() || t->isInput()); }
+    static Tensor otherOf(const Operator &o, const Tensor &t) { return o->getInputs(0) == t ? o->getInputs(1) : o->getInputs(0); }
+    static bool usesOnce(const Operator &o, const Tensor &t) {
+        int c = 0;
+        for (const auto &in : o->getInputs())
+            c += in == t;
+        return c == 1;
+    }
+    // `t` seen through Reshape-family operators down to a tensor no operator writes (a weight / graph input): a reshape
+    // does not change the bytes, so the consumer can read the root at any time. Returns the root (or nullptr) and the
+    // positions of the copy operators that become dead when this consumer was their chain's only reader.
+    Tensor aliasRoot(const Tensor &t, std::vector<size_t> &dead) const {
+        Tensor cur = t;
+        std::vector<size_t> via;
+        bool sole = true;
+        while (true) {
+            Operator src = cur->getSource();
+            if (!src)
                 break;
-            const auto &mn = hn.mm;
-            const Tensor wn = mn->getInputs(1), bn = mn->numInputs() == 3 ? mn->getInputs(2) : nullptr;
-            if (mn->getInputs(0) != a0 || mn->getTransA() || mn->getTransB() || wn->getDims() != w0->getDims() ||
-                !(wn->getDType() == w0->getDType()) || (bn != nullptr) != (bias0 != nullptr) ||
-                (bn && bn->getDims() != bias0->getDims()) || hn.S != h0.S || hn.D != h0.D || hn.rows != h0.rows || hn.n != h0.n ||
-                hn.k != h0.k || tunedVariant(ops[i + 3 * g.size()]) >= 0)
-                break;
-            g.push_back(hn);
+            if (!isCopyLike(src->getOpType()) || src->getInputs(0)->getBytes() != cur->getBytes())
+                return nullptr;
+            auto it = posOf.find(src.get());
+            if (it == posOf.end())
+                return nullptr;
+            sole = sole && cur->getTargets().size() == 1 && !cur->isOutput() && !claimed[it->second];
+            if (sole)
+                via.push_back(it->second);
+            cur = src->getInputs(0);
         }
-        auto addr = [](const Tensor &t) { return (intptr_t)t->getRawDataPtr<void *>(); };
-        // uniform spacing of weights / biases, outputs back to back (C of group j = C + j * rows * n)
-        auto uniform = [&](size_t cnt) {
-            const intptr_t dw = addr(g[1].mm->getInputs(1)) - addr(w0);
-            const intptr_t db = bias0 ? addr(g[1].mm->getInputs(2)) - addr(bias0) : 0;
-            const intptr_t dc = (intptr_t)h0.out->getBytes();
-            if (dw % 16 != 0 || db % 2 != 0)
+        if (cur == t || !persistent(cur))
+            return nullptr;
+        dead = via;
+        return cur;
+    }
+    // memory `t` occupies is not written by any operator at a position in (from, to) other than `members`
+    bool survives(const Tensor &t, size_t from, size_t to, const std::vector<size_t> &members) const {
+        if (persistent(t) || from >= to)
+            return true; // weights / graph inputs: no operator writes them, the planner never recycles them
+        for (size_t p = from + 1; p < to; ++p) {
+            if (std::find(members.begin(), members.end(), p) != members.end())
+                continue;
+            // an operator some item already owns writes when (and if) that item says so; an unclaimed one at its own place
+            if (claimed[p] && !(writeAt[p] > (long)from && writeAt[p] < (long)to))
+                continue;
+            for (const auto &o : ops[p]->getOutputs())
+                if (o && overlaps(o, t))
+                    return false;
+            if (ops[p]->getOpType() == OpType::AttentionKVCache) // appends to its cache inputs in place
+                for (int q = 0; q < 2; ++q)
+                    if (overlaps(ops[p]->getInputs(q), t))
+                        return false;
+        }
+        return true;
+    }
+    // nobody outside `members` reads `t` before position `to`
+    bool unreadUntil(const Tensor &t, size_t to, const std::vector<size_t> &members) const {
+        for (const auto &u : t->getTargets()) {
+            auto it = posOf.find(u.get());
+            if (it == posOf.end())
                 return false;
-            for (size_t j = 1; j < cnt; ++j) {
-                if (addr(g[j].mm->getInputs(1)) - addr(w0) != (intptr_t)j * dw)
+            if (it->second < to && std::find(members.begin(), members.end(), it->second) == members.end())
+                return false;
+        }
+        return true;
+    }
+    struct Read {
+        Tensor t;
+        size_t at; // position of the member that reads it in the unfused graph
+    };
+    bool readsSurvive(const std::vector<Read> &reads, size_t slot, const std::vector<size_t> &members) const {
+        for (const auto &r : reads)
+            if (!survives(r.t, r.at, slot, members))
+                return false;
+        return true;
+    }
+    void noteLateReads(const std::vector<Read> &reads, size_t slot) {
+        for (const auto &r : reads)
+            if (r.at < slot && !persistent(r.t))
+                lateReads.push_back({r.at, slot, r.t});
+    }
+    // 16-byte alignment of device addresses; a dry run on another runtime's arena assumes the ROCM arena's 256-byte alignment
+    bool al16(uintptr_t v) const { return !R || (v & 15) == 0; }
+    int tunedVariant(const Operator &op) const {
+        auto key = PerfEngine::Key{KernelAttrs{Device::ROCM, op->getOpType().underlying()}, op->getOpPerfKey()};
+        auto rec = std::dynamic_pointer_cast<RocmVariantPerfRecordObj>(PerfEngine::getInstance().getPerfData(key));
+        return rec ? rec->variant : -1;
+    }
+    bool mayUseWorkspace(int64_t b, int64_t m, int64_t nn) const {
+        if (!rt)
+            return false;
+        int may = 1;
+        ROCM_CALL(infini_rocm_matmul_may_use_workspace(rt, b, m, nn, &may));
+        return may != 0;
+    }
+    // value of a one-element constant (a tensor no operator writes)
+    bool scalarOf(const Tensor &t, double &v) const {
+        if (t->size() != 1 || !persistent(t) || !t->hasData())
+            return false;
+        const void *p = t->getRawDataPtr<void *>();
+        if (R) {
+            auto it = R->scalarCache.find(p);
+            if (it != R->scalarCache.end() && it->second.first == t->getBytes()) {
+                v = it->second.second;
+                return true;
+            }
+        }
+        unsigned char buf[8] = {0};
+        const size_t bytes = t->getBytes();
+        if (bytes > 8)
+            return false;
+        t->getRuntime()->copyBlobToCPU(buf, p, bytes);
+        const int dt = t->getDTypeIndex();
+        if (dt == INFINI_DT_F32) {
+            float f;
+            std::memcpy(&f, buf, 4);
+            v = f;
+        } else if (dt == INFINI_DT_F64) {
+            std::memcpy(&v, buf, 8);
+        } else if (dt == INFINI_DT_F16) {
+            uint16_t h;
+            std::memcpy(&h, buf, 2);
+            v = halfToDouble(h);
+        } else if (dt == INFINI_DT_BF16) {
+            uint32_t u = 0;
+            std::memcpy(((char *)&u) + 2, buf, 2);
+            float f;
+            std::memcpy(&f, &u, 4);
+            v = f;
+        } else {
+            return false;
+        }
+        if (R)
+            R->scalarCache[p] = {bytes, v};
+        return true;
+    }
+    bool scalarNear(const Tensor &t, double want, double rel) const {
+        double v;
+        return scalarOf(t, v) && std::fabs(v - want) <= rel * std::fabs(want);
+    }
+
+    // writers: the members whose own output tensors the item materialises (default: the last member)
+    void emit(size_t slot, std::vector<size_t> members, std::string what, bool fused, std::function<void()> fn,
+              std::vector<size_t> writers = {}) {
+        for (size_t m : members) {
+            claimed[m] = 1;
+            writeAt[m] = -1;
+        }
+        if (writers.empty() && !members.empty())
+            writers.push_back(*std::max_element(members.begin(), members.end()));
+        for (size_t w : writers)
+            writeAt[w] = (long)slot;
+        if (log && fused) {
+            std::string ms;
+            for (size_t m : members)
+                ms += (ms.empty() ? "" : ",") + std::to_string(m);
+            fprintf(stderr, "[fusion] @%zu %s [%s]\n", slot, what.c_str(), ms.c_str());
+        }
+        PlanItem it;
+        it.slot = slot;
+        it.members = std::move(members);
+        it.what = std::move(what);
+        it.fused = fused;
+        it.run = std::move(fn);
+        items.push_back(std::move(it));
+    }
+
+    bool tryRules(size_t i) {
+        const auto type = ops[i]->getOpType();
+        if (type == OpType::MatMul)
+            return planAttentionAt(i) || planMatmul(i) || planGroupedAhead(i);
+        if (type == OpType::Transpose)
+            return planAttentionFromTranspose(i) || planIntoCopy(i);
+        if (type == OpType::Conv)
+            return planConv(i);
+        if (type == OpType::Silu && planSiluMul(i))
+            return true;
+        if (type == OpType::Relu && planReluPool(i))
+            return true;
+        if (type == OpType::ReduceMean && planLayerNormDecomposed(i))
+            return true;
+        if ((type == OpType::Div || type == OpType::Mul) && planGeluDecomposed(i))
+            return true;
+        if (type == OpType::Add && (planAddNorm(i) || planBiasResidual(i) || planAddRelu(i)))
+            return true;
+        if (type == OpType::RoPE && planRopeHeadSplit(i, nullptr))
+            return true;
+        return planIntoCopy(i);
+    }
+
+    // ============================================================================================================
+    // decomposed LayerNorm:  m = ReduceMean(x, last axis, keepdims); d = Sub(x, m); v = ReduceMean(Pow(d, 2) | Mul(d, d));
+    //                        y = Div(d, Sqrt(Add(v, eps))) [* gamma] [+ beta]
+    // ============================================================================================================
+    struct NormMatch {
+        std::vector<size_t> members; // ascending
+        Tensor x, gamma, beta, out;
+        double eps = 0;
+        size_t first = 0, last = 0;
+    };
+    // `x` is read by exactly ReduceMean and Sub (the head of the pattern); extra readers of x are allowed when
+    // `allowOtherReaders` (x stays a materialised tensor then)
+    bool matchLayerNormDecomposed(const Tensor &x, NormMatch &m) const {
+        static const bool on = envOn("INFINI_ROCM_FUSE_DECOMPOSED");
+        if (!on)
+            return false;
+        Operator mean = nullptr, sub = nullptr;
+        for (const auto &u : x->getTargets()) {
+            auto it = posOf.find(u.get());
+            if (it == posOf.end() || claimed[it->second])
+                continue;
+            if (u->getOpType() == OpType::ReduceMean && !mean)
+                mean = u;
+            else if (u->getOpType() == OpType::Sub && u->getInputs(0) == x && !sub)
+                sub = u;
+        }
+        if (!mean || !sub)
+            return false;
+        const auto &xd = x->getDims();
+        const int rank = xd.size();
+        auto lastAxisMean = [&](const Operator &o) {
+            auto r = as<ReduceBaseObj>(o);
+            return r->getKeepDims() && r->getAxes().size() == 1 && *r->getAxes().begin() == rank - 1;
+        };
+        if (rank < 1 || !lastAxisMean(mean))
+            return false;
+        const Tensor mu = mean->getOutput(), d = sub->getOutput();
+        if (sub->getInputs(1) != mu || mu->isOutput() || mu->getTargets().size() != 1 || d->isOutput() || d->getDims() != xd)
+            return false;
+        // d feeds the variance branch (Pow(d, 2) or Mul(d, d)) and the final Div
+        Operator sq = nullptr, div = nullptr;
+        const auto dt = d->getTargets();
+        for (const auto &u : dt) {
+            if (claimed[pos(u)])
+                return false;
+            if (u->getOpType() == OpType::Pow && u->getInputs(0) == d)
+                sq = u;
+            else if (u->getOpType() == OpType::Mul && u->getInputs(0) == d && u->getInputs(1) == d)
+                sq = u;
+            else if (u->getOpType() == OpType::Div && u->getInputs(0) == d)
+                div = u;
+            else
+                return false;
+        }
+        if (!sq || !div || (sq->getOpType() == OpType::Pow ? dt.size() != 2 : dt.size() != 3))
+            return false;
+        if (sq->getOpType() == OpType::Pow && !scalarNear(sq->getInputs(1), 2.0, 1e-6))
+            return false;
+        Operator mean2 = userOfType(sq->getOutput(), OpType::ReduceMean, pos(sq));
+        if (!mean2 || !lastAxisMean(mean2))
+            return false;
+        Operator addEps = userOfType(mean2->getOutput(), OpType::Add, pos(mean2));
+        if (!addEps)
+            return false;
+        double eps;
+        if (!scalarOf(otherOf(addEps, mean2->getOutput()), eps) || !(eps >= 0) || eps > 1e-2)
+            return false;
+        Operator sqrt = userOfType(addEps->getOutput(), OpType::Sqrt, pos(addEps));
+        if (!sqrt || div->getInputs(1) != sqrt->getOutput() || sqrt->getOutput()->getTargets().size() != 1 ||
+            sqrt->getOutput()->isOutput() || pos(div) < pos(sqrt))
+            return false;
+        m.members = {pos(mean), pos(sub), pos(sq), pos(mean2), pos(addEps), pos(sqrt), pos(div)};
+        m.x = x;
+        m.eps = eps;
+        m.gamma = m.beta = nullptr;
+        Tensor cur = div->getOutput();
+        size_t lastPos = pos(div);
+        const int nlast = xd.back();
+        if (Operator mul = userOfType(cur, OpType::Mul, lastPos)) {
+            const Tensor g = otherOf(mul, cur);
+            if (g != cur && persistent(g) && isRowVector(g->getDims(), nlast) && g->getDType() == x->getDType() &&
+                mul->getOutput()->getDims() == xd) {
+                m.gamma = g;
+                m.members.push_back(pos(mul));
+                cur = mul->getOutput();
+                lastPos = pos(mul);
+                if (Operator add = userOfType(cur, OpType::Add, lastPos)) {
+                    const Tensor b = otherOf(add, cur);
+                    if (b != cur && persistent(b) && isRowVector(b->getDims(), nlast) && b->getDType() == x->getDType() &&
+                        add->getOutput()->getDims() == xd) {
+                        m.beta = b;
+                        m.members.push_back(pos(add));
+                        cur = add->getOutput();
+                    }
+                }
+            }
+        }
+        if (!m.gamma)
+            return false; // the kernels take a scale vector; a bare normalisation is not worth a special case
+        std::sort(m.members.begin(), m.members.end());
+        m.first = m.members.front();
+        m.last = m.members.back();
+        m.out = cur;
+        if (!(cur->getDType() == x->getDType()))
+            return false;
+        return true;
+    }
+
+    bool planLayerNormDecomposed(size_t i) {
+        const Tensor x = ops[i]->getInputs(0);
+        NormMatch m;
+        if (!matchLayerNormDecomposed(x, m) || m.first != i)
+            return false;
+        if (!readsSurvive({{x, m.first}}, m.last, m.members))
+            return false;
+        if (overlaps(m.out, x) && !samePlace(m.out, x))
+            return false;
+        if (overlaps(m.out, m.gamma) || (m.beta && overlaps(m.out, m.beta)))
+            return false;
+        noteLateReads({{x, m.first}}, m.last);
+        const RocmRuntimeObj *r = R;
+        const Tensor xx = x, g = m.gamma, b = m.beta, out = m.out;
+        const int64_t nn = x->getDims().back(), outer = (int64_t)x->size() / nn;
+        const float eps = (float)m.eps;
+        emit(m.last, m.members, "layer_norm(decomposed)", true, [r, xx, g, b, out, nn, outer, eps] {
+            ROCM_CALL(infini_rocm_layer_norm(r->handle(), xx->getDTypeIndex(), xx->getRawDataPtr<void *>(), g->getRawDataPtr<void *>(),
+                                             b ? b->getRawDataPtr<void *>() : nullptr, out->getRawDataPtr<void *>(), outer, nn,
+                                             (int64_t)g->size(), b ? (int64_t)b->size() : 0, eps));
+        });
+        return true;
+    }
+
+    // ============================================================================================================
+    // decomposed Gelu:  y = 0.5 * x * (1 + erf(x / sqrt 2)) as  Div(x, 1.41421) | Mul(x, 0.70711) -> Erf -> Add(1) ->
+    //                   Mul(x, .) -> Mul(., 0.5)      (or Mul(x, 0.5) first, then Mul with the (1 + erf) branch)
+    // ============================================================================================================
+    struct GeluMatch {
+        std::vector<size_t> members;
+        Tensor x, out;
+        size_t first = 0, last = 0;
+    };
+    bool matchGeluDecomposed(const Tensor &x, GeluMatch &m) const {
+        static const bool on = envOn("INFINI_ROCM_FUSE_DECOMPOSED");
+        if (!on)
+            return false;
+        const auto tg = x->getTargets();
+        if (tg.size() != 2 || x->isOutput())
+            return false;
+        for (int a = 0; a < 2; ++a) {
+            const Operator scale = tg[a], other = tg[1 - a];
+            if (claimed[pos(scale)] || claimed[pos(other)])
+                return false;
+            // scale: x / sqrt(2) or x * (1 / sqrt(2))
+            bool isScale = false;
+            if (scale->getOpType() == OpType::Div && scale->getInputs(0) == x)
+                isScale = scalarNear(scale->getInputs(1), 1.4142135623730951, 2e-3);
+            else if (scale->getOpType() == OpType::Mul && usesOnce(scale, x))
+                isScale = scalarNear(otherOf(scale, x), 0.7071067811865476, 2e-3);
+            if (!isScale)
+                continue;
+            Operator erf = userOfType(scale->getOutput(), OpType::Erf, pos(scale));
+            if (!erf)
+                continue;
+            Operator add1 = userOfType(erf->getOutput(), OpType::Add, pos(erf));
+            if (!add1 || !scalarNear(otherOf(add1, erf->getOutput()), 1.0, 1e-6))
+                continue;
+            const Tensor onePlus = add1->getOutput();
+            // x's second reader multiplies x with (1 + erf) or with 0.5
+            if (!(other->getOpType() == OpType::Mul) || !usesOnce(other, x))
+                continue;
+            const Tensor o2 = otherOf(other, x);
+            Operator final = nullptr;
+            if (o2 == onePlus && onlyUser(onePlus) == other && pos(other) > pos(add1)) {
+                // Mul(x, 1 + erf) -> Mul(., 0.5)
+                Operator half = userOfType(other->getOutput(), OpType::Mul, pos(other));
+                if (!half || !scalarNear(otherOf(half, other->getOutput()), 0.5, 1e-6))
+                    continue;
+                final = half;
+                m.members = {pos(scale), pos(erf), pos(add1), pos(other), pos(half)};
+            } else if (scalarNear(o2, 0.5, 1e-6)) {
+                // Mul(x, 0.5) -> Mul(., 1 + erf)
+                Operator prod = userOfType(other->getOutput(), OpType::Mul, pos(other));
+                if (!prod || otherOf(prod, other->getOutput()) != onePlus || onlyUser(onePlus) != prod || pos(prod) < pos(add1))
+                    continue;
+                final = prod;
+                m.members = {pos(scale), pos(erf), pos(add1), pos(other), pos(prod)};
+            } else {
+                continue;
+            }
+            const Tensor out = final->getOutput();
+            if (out->getDims() != x->getDims() || !(out->getDType() == x->getDType()))
+                continue;
+            std::sort(m.members.begin(), m.members.end());
+            m.first = m.members.front();
+            m.last = m.members.back();
+            m.x = x;
+            m.out = out;
+            return true;
+        }
+        return false;
+    }
+    bool planGeluDecomposed(size_t i) {
+        for (const auto &x : ops[i]->getInputs()) {
+            GeluMatch m;
+            if (x->size() <= 1 || !matchGeluDecomposed(x, m) || m.first != i)
+                continue;
+            if (!readsSurvive({{x, m.first}}, m.last, m.members) || (overlaps(m.out, x) && !samePlace(m.out, x)))
+                continue;
+            noteLateReads({{x, m.first}}, m.last);
+            const RocmRuntimeObj *r = R;
+            const Tensor xx = x, out = m.out;
+            emit(m.last, m.members, "gelu(decomposed)", true, [r, xx, out] {
+                ROCM_CALL(infini_rocm_unary(r->handle(), INFINI_UN_GELU, xx->getDTypeIndex(), xx->getRawDataPtr<void *>(),
+                                            out->getRawDataPtr<void *>(), out->size(), NAN, NAN));
+            });
+            return true;
+        }
+        return false;
+    }
+
+    // ============================================================================================================
+    // attention
+    // ============================================================================================================
+    struct AttnPlan {
+        std::vector<size_t> members;
+        std::vector<Read> reads;
+        Tensor q, kbuf, v, mask, scale, dstT, out;
+        int b = 0, h = 0, sq = 0, sk = 0, d = 0, dt = 0;
+        bool isDiv = false, mask2d = false;
+        int64_t heads = 0;
+        size_t last = 0;
+    };
+    // mm1 at `i`. `kAs`: a tensor whose BUFFER will hold K as [b, h, Sk, D] when the attention runs although the graph
+    // says otherwise (its producer stores K head-major on our behalf), or nullptr. `absorbed`: a Transpose(0, 1, 3, 2)
+    // in front of mm1 that is not launched (position, or SIZE_MAX).
+    bool matchAttention(size_t i, const Tensor &kAs, size_t absorbed, AttnPlan &a) const {
+        static const bool on = envOn("INFINI_ROCM_FUSE_ATTENTION");
+        if (!on || claimed[i])
+            return false;
+        auto mm1 = as<MatmulObj>(ops[i]);
+        if (mm1->getTransA() || mm1->getBias() || mm1->getAct() != ActType::None)
+            return false;
+        const Tensor q = mm1->getInputs(0), kx = mm1->getInputs(1);
+        Tensor kbuf;
+        Shape kd;
+        size_t kReadAt = i;
+        if (mm1->getTransB()) {
+            kbuf = kx;
+            kd = kx->getDims();
+        } else if (kAs && kAs == kx) {
+            kbuf = kx;
+            const auto &x = kx->getDims(); // [b, h, D, Sk] as the graph sees it
+            if (x.size() != 4)
+                return false;
+            kd = {x[0], x[1], x[3], x[2]};
+        } else if (absorbed != SIZE_MAX) {
+            kbuf = ops[absorbed]->getInputs(0);
+            kd = kbuf->getDims();
+            kReadAt = absorbed;
+            if (ops[absorbed]->getOutput() != kx)
+                return false;
+        } else {
+            return false;
+        }
+        const auto &qd = q->getDims();
+        const int dt = q->getDTypeIndex();
+        if (qd.size() != 4 || kd.size() != 4 || qd[0] != kd[0] || qd[1] != kd[1] || qd[3] != kd[3] || (qd[3] != 64 && qd[3] != 128) ||
+            !isHalf(dt) || !(kx->getDType() == q->getDType()))
+            return false;
+        const int b = qd[0], h = qd[1], sq = qd[2], sk = kd[2], d = qd[3];
+        // limits of infini_rocm_attention_ex (attention.hip): outside them the chain simply runs unfused
+        if ((int64_t)b * h >= 65536 || h >= 65536 || sk <= 0 || sq <= 0 || !al16(addrOf(q) | addrOf(kbuf)))
+            return false;
+        a = AttnPlan();
+        a.members = {i};
+        if (absorbed != SIZE_MAX)
+            a.members.push_back(absorbed);
+        a.reads = {{q, i}, {kbuf, kReadAt}};
+        Tensor cur = mm1->getOutput();
+        size_t at = i;
+        auto step = [&](const Operator &u) {
+            a.members.push_back(pos(u));
+            at = pos(u);
+            cur = u->getOutput();
+        };
+        Operator u = onlyUser(cur);
+        if (u && pos(u) > at && (u->getOpType() == OpType::Div || u->getOpType() == OpType::Mul)) {
+            const Tensor a0 = u->getInputs(0), a1 = u->getInputs(1);
+            a.isDiv = u->getOpType() == OpType::Div;
+            const Tensor other = a0 == cur ? a1 : a0;
+            if (other == cur || other->size() != 1 || !(other->getDType() == q->getDType()) || (a.isDiv && a0 != cur))
+                return false;
+            a.scale = other;
+            a.reads.push_back({other, pos(u)});
+            step(u);
+            u = onlyUser(cur);
+        }
+        if (u && pos(u) > at && u->getOpType() == OpType::Add) {
+            const Tensor other = otherOf(u, cur);
+            const auto &md = other->getDims();
+            // key mask [b|1, 1, 1, Sk] (BERT padding) or a full additive mask [b|1, h|1, Sq, Sk] with the same grouping rule:
+            // heads may only broadcast when the batch does too or both are explicit ([1,1], [b,1], [b,h])
+            const bool keyMask = md.size() == 4 && md[1] == 1 && md[2] == 1;
+            const bool fullMask = md.size() == 4 && md[2] == sq && sq > 1 && (md[1] == 1 || (md[1] == h && md[0] == b));
+            if (other == cur || md.size() != 4 || (md[0] != b && md[0] != 1) || !(keyMask || fullMask) || md[3] != sk ||
+                !(other->getDType() == q->getDType()))
+                return false;
+            a.mask = other;
+            a.mask2d = !keyMask;
+            a.reads.push_back({other, pos(u)});
+            step(u);
+            u = onlyUser(cur);
+        }
+        if (!u || pos(u) <= at || !(u->getOpType() == OpType::Softmax) || as<SoftmaxObj>(u)->getAxis() != 3)
+            return false;
+        step(u);
+        u = onlyUser(cur);
+        if (!u || pos(u) <= at || !(u->getOpType() == OpType::MatMul))
+            return false;
+        auto mm2 = as<MatmulObj>(u);
+        const Tensor v = mm2->getInputs(1), out = mm2->getOutput();
+        if (mm2->getInputs(0) != cur || mm2->getTransA() || mm2->getTransB() || mm2->getBias() || mm2->getAct() != ActType::None ||
+            v->getDims() != kd || !(v->getDType() == q->getDType()) || !al16(addrOf(v)) || !al16(addrOf(out) << 1))
+            return false;
+        a.reads.push_back({v, pos(u)});
+        step(u);
+        // Head merge: ctx [b, h, Sq, D] -> Transpose(0, 2, 1, 3) -> Reshape [b, Sq, h * D] (what every exported transformer
+        // does before the output projection) is folded into the kernel's store (infini_rocm_attention_ex).
+        a.dstT = out;
+        a.heads = 0;
+        static const bool mergeOn = envOn("INFINI_ROCM_FUSE_HEADMERGE");
+        if (mergeOn) {
+            Operator tr = userOfType(out, OpType::Transpose, at);
+            if (tr && permIs(as<TransposeObj>(tr)->getPermute(), 0, 2, 1, 3)) {
+                Operator rs = userOfType(tr->getOutput(), OpType::Reshape, pos(tr));
+                if (rs && rs->getOutput()->getBytes() == out->getBytes() && rs->getOutput()->getDType() == out->getDType()) {
+                    a.members.push_back(pos(tr));
+                    a.members.push_back(pos(rs));
+                    a.dstT = rs->getOutput();
+                    a.heads = h;
+                    at = pos(rs);
+                }
+            }
+        }
+        std::sort(a.members.begin(), a.members.end());
+        a.last = a.members.back();
+        a.q = q, a.kbuf = kbuf, a.v = v, a.out = out;
+        a.b = b, a.h = h, a.sq = sq, a.sk = sk, a.d = d, a.dt = dt;
+        if (!readsSurvive(a.reads, a.last, a.members))
+            return false;
+        return true;
+    }
+
+    struct MMChain;
+    void commitAttention(const AttnPlan &a) {
+        // O may sit exactly on Q (the planner likes to: Q is dead after the first MatMul and has O's size): a workgroup
+        // loads its query rows before the key sweep and writes the same rows of O after it (plain layout only). K / V are
+        // read by everyone. Any other overlap (K and V die after their MatMul too, and have O's size) is bridged through the
+        // workspace: O is [Sq, D] per head, the copy is small next to the score traffic the fusion removes.
+        const bool onQ = a.heads == 0 && addrOf(a.dstT) == addrOf(a.q) && a.dstT->getDims() == a.q->getDims();
+        const bool hazard = (overlaps(a.dstT, a.q) && !onQ) || overlaps(a.dstT, a.kbuf) || overlaps(a.dstT, a.v) ||
+                            (a.mask && overlaps(a.dstT, a.mask)) || (a.scale && overlaps(a.dstT, a.scale));
+        // pairs (batch, head) served by one mask slab: [1,1,..] all of them, [b,1,..] the heads of a batch, [b,h,..] one
+        const int64_t group = !a.mask ? 1 : ((a.mask->getDims()[1] == a.h && a.h > 1) ? 1 : (a.mask->getDims()[0] == 1 ? (int64_t)a.b * a.h : a.h));
+        noteLateReads(a.reads, a.last);
+        const RocmRuntimeObj *r = R;
+        const AttnPlan ap = a;
+        auto attn = [r, ap, group](void *dst) {
+            ROCM_CALL(infini_rocm_attention_ex(r->handle(), ap.dt, ap.q->getRawDataPtr<void *>(), ap.kbuf->getRawDataPtr<void *>(),
+                                               ap.v->getRawDataPtr<void *>(), ap.mask ? ap.mask->getRawDataPtr<void *>() : nullptr, dst,
+                                               (int64_t)ap.b * ap.h, ap.sq, ap.sk, ap.d, group,
+                                               ap.scale ? ap.scale->getRawDataPtr<void *>() : nullptr, ap.isDiv ? 1 : 0, 1.0f, 0, ap.heads,
+                                               ap.mask2d ? 1 : 0));
+        };
+        if (!hazard) {
+            emit(a.last, a.members, "attention", true, [attn, ap] { attn(ap.dstT->getRawDataPtr<void *>()); });
+            return;
+        }
+        // The bridged result usually feeds exactly one operator, the output projection, right behind the chain: let that
+        // MatMul (with whatever the MatMul rule folds into it: bias, ...) read its A operand straight from the workspace
+        // instead of copying 25 MB per BERT layer to a tensor nobody else reads. Only a MatMul that cannot itself take
+        // the workspace (split-K partial planes).
+        static const bool feedOn = envOn("INFINI_ROCM_FEED_NEXT");
+        const size_t bytes = a.dstT->getBytes();
+        // claim the attention first so that the consumer's chain cannot pick its members
+        std::vector<size_t> members = a.members;
+        for (size_t m : members)
+            claimed[m] = 1;
+        Operator nx = feedOn ? onlyUser(a.dstT) : nullptr;
+        if (nx && nx->getOpType() == OpType::MatMul && pos(nx) == a.last + 1) {
+            auto mmn = as<MatmulObj>(nx);
+            const auto [nb, nm, nn, nk] = mmn->getBMNK();
+            bool onlyA = mmn->getInputs(0) == a.dstT;
+            for (size_t q = 1; q < mmn->getInputs().size(); ++q)
+                onlyA = onlyA && mmn->getInputs(q) != a.dstT;
+            if (!mayUseWorkspace(nb, nm, nn) && onlyA && tunedVariant(nx) != 3) {
+                MMChain ch = buildMatmulChain(pos(nx), /*contiguousOnly*/ true, a.dstT);
+                if (ch.ok && !ch.attn) {
+                    std::vector<size_t> all = members;
+                    all.insert(all.end(), ch.members.begin(), ch.members.end());
+                    noteLateReads(ch.reads, ch.slot);
+                    auto chainRun = chainLaunch(ch, a.dstT.get(), bytes);
+                    emit(ch.slot, all, "attention(bridged)>" + ch.what, true, [r, attn, chainRun, bytes] {
+                        attn(r->getWorkspace(bytes));
+                        chainRun();
+                    });
+                    return;
+                }
+            }
+        }
+        emit(a.last, members, "attention(bridged)+copy", true, [r, attn, ap, bytes] {
+            void *ws = r->getWorkspace(bytes);
+            attn(ws);
+            ROCM_CALL(infini_rocm_copy_inside(r->handle(), ap.dstT->getRawDataPtr<void *>(), ws, bytes));
+        });
+    }
+
+    bool planAttentionAt(size_t i) {
+        AttnPlan a;
+        if (!matchAttention(i, nullptr, SIZE_MAX, a))
+            return false;
+        commitAttention(a);
+        return true;
+    }
+    // Transpose in front of Q.K^T. perm (0, 1, 3, 2) on the head-split K: absorbed, the kernel reads K itself.
+    // perm (0, 2, 3, 1) on K's [B, S, H, D] view (two exporter transposes merged): run it as (0, 2, 1, 3) into the same
+    // buffer — K head-major is what the kernel wants — unless K's producer already did (planMatmul handles that case).
+    bool planAttentionFromTranspose(size_t i) {
+        auto tr = as<TransposeObj>(ops[i]);
+        const Tensor kx = tr->getOutput();
+        Operator mm = onlyUser(kx);
+        if (!mm || !(mm->getOpType() == OpType::MatMul) || pos(mm) <= i || mm->getInputs(1) != kx || mm->getInputs(0) == kx)
+            return false;
+        const auto perm = tr->getPermute();
+        AttnPlan a;
+        if (permIs(perm, 0, 1, 3, 2)) {
+            if (!matchAttention(pos(mm), nullptr, i, a))
+                return false;
+            commitAttention(a);
+            return true;
+        }
+        if (permIs(perm, 0, 2, 3, 1)) {
+            if (!matchAttention(pos(mm), kx, SIZE_MAX, a))
+                return false;
+            const Tensor in = tr->getInputs(0);
+            if (overlaps(in, kx))
+                return false;
+            const RocmRuntimeObj *r = R;
+            emit(i, {i}, "transpose(K head-major)", true, [r, in, kx] {
+                const auto &d = in->getDims();
+                const int64_t shape[4] = {d[0], d[1], d[2], d[3]};
+                const int p[4] = {0, 2, 1, 3};
+                ROCM_CALL(infini_rocm_transpose(r->handle(), in->getDTypeIndex(), in->getRawDataPtr<void *>(), kx->getRawDataPtr<void *>(), 4,
+                                                shape, p));
+            });
+            commitAttention(a);
+            return true;
+        }
+        return false;
+    }
+
+    // ============================================================================================================
+    // MatMul chains
+    // ============================================================================================================
+    struct MMChain {
+        bool ok = false;
+        std::shared_ptr<MatmulObj> mm;
+        size_t head = 0, slot = 0;
+        std::vector<size_t> members; // ascending, with the dead alias operators
+        std::vector<Read> reads;
+        Tensor bias;                 // folded Add operand (read through biasSrc)
+        Tensor biasSrc;              // tensor whose buffer is passed (the alias root, or `bias` itself)
+        int act = 0;                 // 5: Gelu in the epilogue
+        int store = 0;               // 0 plain, 1 head split, 2 redirected into a Reshape-family copy's output
+        bool kHeadMajor = false;     // store 1 into the buffer of a Transpose(0, 2, 3, 1) output (read by an attention)
+        Tensor out;                  // tensor whose buffer receives the result
+        long S = 0, D = 0, rows = 0;
+        int n = 0, k = 0;
+        std::optional<AttnPlan> attn; // committed together with the chain (kHeadMajor)
+        std::string what;
+    };
+
+    // The longest fusable chain headed by the MatMul at `i` (ok = false: nothing to fold — not even a redirect).
+    // contiguousOnly: every member must directly follow the previous one (dead alias operators aside).
+    // fedA: the MatMul's A operand is read from the workspace, not from its own buffer (the caller bridged it there), so the
+    // chain's output may sit on that buffer.
+    MMChain buildMatmulChain(size_t i, bool contiguousOnly, const Tensor &fedA = nullptr) {
+        MMChain best;
+        if (claimed[i] || !(ops[i]->getOpType() == OpType::MatMul))
+            return best;
+        auto mm = as<MatmulObj>(ops[i]);
+        const auto [b, m, nn, kk] = mm->getBMNK();
+        const Tensor A = mm->getInputs(0), W = mm->getInputs(1), C = mm->getOutput();
+        const int dt = A->getDTypeIndex();
+        MMChain c;
+        c.mm = mm;
+        c.head = i;
+        c.members = {i};
+        c.reads = {{W, i}};
+        if (!(fedA && fedA == A))
+            c.reads.push_back({A, i});
+        if (mm->numInputs() == 3)
+            c.reads.push_back({mm->getInputs(2), i});
+        c.out = C;
+        c.n = nn, c.k = kk;
+        c.rows = (long)b * m;
+        c.slot = i;
+        c.what = "matmul";
+        // a candidate is valid when the reads of its earlier members survive until its slot and its output buffer does
+        // not overlap what the GEMM reads
+        auto valid = [&](const MMChain &x) {
+            if (contiguousOnly) {
+                for (size_t q = 1; q < x.members.size(); ++q)
+                    if (x.members[q] != x.members[q - 1] + 1)
+                        return false;
+            }
+            if (!readsSurvive(x.reads, x.slot, x.members))
+                return false;
+            for (const auto &rd : x.reads)
+                if (overlaps(x.out, rd.t))
                     return false;
-                if (bias0 && addr(g[j].mm->getInputs(2)) - addr(bias0) != (intptr_t)j * db)
+            if (x.biasSrc && overlaps(x.out, x.biasSrc))
+                return false;
+            return true;
+        };
+        auto add = [&](MMChain &x, size_t p) {
+            x.members.push_back(p);
+            std::sort(x.members.begin(), x.members.end());
+            x.slot = std::max(x.slot, p);
+        };
+        Tensor cur = C;
+        size_t at = i;
+        // 1. Add(row bias)
+        static const bool biasOn = envOn("INFINI_ROCM_FUSE_MATMUL_BIAS");
+        if (biasOn && mm->numInputs() == 2) {
+            if (Operator u = userOfType(cur, OpType::Add, at)) {
+                const Tensor other = otherOf(u, cur);
+                std::vector<size_t> dead;
+                if (other != cur && isRowVector(other->getDims(), nn) && other->getDType() == C->getDType() &&
+                    u->getOutput()->getDims() == C->getDims()) {
+                    MMChain x = c;
+                    const Tensor root = aliasRoot(other, dead);
+                    x.bias = other;
+                    x.biasSrc = root ? root : other;
+                    for (size_t dp : dead)
+                        add(x, dp);
+                    add(x, pos(u));
+                    if (!root)
+                        x.reads.push_back({other, pos(u)});
+                    x.out = u->getOutput();
+                    x.what += "+bias";
+                    if (valid(x)) {
+                        c = x;
+                        best = c;
+                        best.ok = true;
+                        cur = c.out;
+                        at = pos(u);
+                    }
+                }
+            }
+        }
+        // 2. Gelu (single operator or the five-operator form) in the epilogue, f16 / bf16
+        static const bool geluOn = envOn("INFINI_ROCM_FUSE_GELU");
+        if (geluOn && isHalf(dt) && cur == c.out) {
+            MMChain x = c;
+            bool got = false;
+            if (Operator u = userOfType(cur, OpType::Gelu, at)) {
+                add(x, pos(u));
+                x.out = u->getOutput();
+                got = true;
+            } else {
+                GeluMatch g;
+                if (matchGeluDecomposed(cur, g) && g.first > at) {
+                    for (size_t p : g.members)
+                        add(x, p);
+                    x.out = g.out;
+                    got = true;
+                }
+            }
+            if (got && x.out->getBytes() == cur->getBytes() && x.out->getDType() == cur->getDType()) {
+                x.act = 5;
+                x.what += "+gelu";
+                if (valid(x)) {
+                    c = x;
+                    best = c;
+                    best.ok = true;
+                    cur = c.out;
+                    at = c.slot;
+                }
+            }
+        }
+        // 3. the store: head split, K head-major for an attention, or straight into a Reshape-family copy's output
+        static const bool splitOn = envOn("INFINI_ROCM_FUSE_HEADSPLIT"), copyOn = envOn("INFINI_ROCM_FUSE_RESHAPE");
+        if (Operator rs = onlyUser(cur); rs && pos(rs) > at && isCopyLike(rs->getOpType()) && rs->getInputs(0) == cur &&
+                                        rs->getOutput()->getBytes() == cur->getBytes() && rs->getOutput()->getDType() == cur->getDType()) {
+            const Tensor r = rs->getOutput();
+            const auto &rd = r->getDims();
+            bool split = false;
+            if (splitOn && rs->getOpType() == OpType::Reshape && rd.size() == 4 && c.act == 0) {
+                if (Operator tr = userOfType(r, OpType::Transpose, pos(rs))) {
+                    const auto perm = as<TransposeObj>(tr)->getPermute();
+                    const long B = rd[0], S = rd[1], Hh = rd[2], D = rd[3];
+                    // the MatMul's rows are (batch, position), its columns (head, channel): [b x m] == [B x S] row-wise, n == H * D
+                    const bool shapeOK = (long)b * m == B * S && (long)nn == Hh * D && m % S == 0 && D % 8 == 0 &&
+                                         tr->getOutput()->getDType() == cur->getDType() && tr->getOutput()->getBytes() == cur->getBytes();
+                    if (shapeOK && (permIs(perm, 0, 2, 1, 3) || permIs(perm, 0, 2, 3, 1))) {
+                        MMChain x = c;
+                        add(x, pos(rs));
+                        add(x, pos(tr));
+                        x.out = tr->getOutput();
+                        x.store = 1;
+                        x.S = S, x.D = D;
+                        x.what += "+headsplit";
+                        bool okx = true;
+                        if (permIs(perm, 0, 2, 3, 1)) { // only as the K of a fused attention
+                            okx = false;
+                            Operator mm1 = onlyUser(x.out);
+                            if (mm1 && mm1->getOpType() == OpType::MatMul && mm1->getInputs(1) == x.out && mm1->getInputs(0) != x.out &&
+                                pos(mm1) > pos(tr)) {
+                                // members of this chain must look claimed to the attention matcher
+                                for (size_t p : x.members)
+                                    claimed[p] = 1;
+                                AttnPlan ap;
+                                okx = matchAttention(pos(mm1), x.out, SIZE_MAX, ap);
+                                for (size_t p : x.members)
+                                    claimed[p] = 0;
+                                if (okx) {
+                                    x.attn = ap;
+                                    x.kHeadMajor = true;
+                                    x.what += "(K for attention)";
+                                }
+                            }
+                        }
+                        if (okx && valid(x)) {
+                            c = x;
+                            best = c;
+                            best.ok = true;
+                            split = true;
+                        }
+                    }
+                }
+            }
+            if (!split && copyOn) {
+                MMChain x = c;
+                add(x, pos(rs));
+                x.out = r;
+                x.store = 2;
+                x.what += ">reshape";
+                if (valid(x)) {
+                    c = x;
+                    best = c;
+                    best.ok = true;
+                }
+            }
+        }
+        if (!best.ok && contiguousOnly) { // the caller launches the bare MatMul through the chain machinery (input redirect)
+            best = c;
+            best.ok = true;
+        }
+        return best;
+    }
+
+    // the launch of one chain; feedT != nullptr: the MatMul reads `feedT` from the workspace (getWorkspace(feedBytes))
+    std::function<void()> chainLaunch(const MMChain &c, const TensorObj *feedT, size_t feedBytes) const {
+        const RocmRuntimeObj *r = R;
+        const MMChain cc = c;
+        const Operator op = ops[c.head];
+        return [r, cc, op, feedT, feedBytes] {
+            OverrideScope s;
+            auto &o = RocmRuntimeObj::overrides;
+            o.matmul = op.get();
+            if (cc.biasSrc)
+                o.biasPtr = cc.biasSrc->getRawDataPtr<void *>();
+            o.act = cc.act;
+            if (cc.store == 1) {
+                o.seq = (int)cc.S;
+                o.headDim = (int)cc.D;
+            }
+            if (cc.out != cc.mm->getOutput())
+                s.redirect(cc.mm->getOutput().get(), cc.out->getRawDataPtr<void *>());
+            if (feedT)
+                s.redirect(feedT, r->getWorkspace(feedBytes));
+            r->launchOne(op);
+        };
+    }
+
+    void commitChain(const MMChain &c) {
+        noteLateReads(c.reads, c.slot);
+        emit(c.slot, c.members, c.what, true, chainLaunch(c, nullptr, 0));
+        if (c.attn)
+            commitAttention(*c.attn);
+    }
+
+    // MatMul at `i`: its chain, and — for head-split chains — the sibling projections of the same activation (q, k, v) as
+    // ONE grouped launch when their weights / biases / outputs sit at uniform distances (the group index is the GEMM's
+    // batch index with a zero A stride; BERT-base: 3 x 25 us -> ~62 us per layer). Same kernels, same sums: bit-identical.
+    bool planMatmul(size_t i) {
+        MMChain h0 = buildMatmulChain(i, false);
+        if (!h0.ok)
+            return false;
+        static const bool groupOn = envOn("INFINI_ROCM_GROUP_QKV");
+        const auto &mm0 = h0.mm;
+        const Tensor a0 = mm0->getInputs(0), w0 = mm0->getInputs(1);
+        const int dt = a0->getDTypeIndex();
+        auto biasOf = [](const MMChain &c) -> Tensor { return c.biasSrc ? c.biasSrc : (c.mm->numInputs() == 3 ? c.mm->getInputs(2) : nullptr); };
+        const Tensor bias0 = biasOf(h0);
+        const bool groupable = groupOn && h0.store == 1 && h0.act == 0 && isHalf(dt) && !mm0->getTransA() && !mm0->getTransB() &&
+                               w0->getRank() == 2 && tunedVariant(ops[i]) < 0 &&
+                               (!bias0 || ((int)bias0->size() == h0.n && isRowVector(bias0->getDims(), h0.n)));
+        if (groupable) {
+            std::vector<MMChain> g{h0};
+            // siblings: other unclaimed MatMuls reading a0 as their A operand, in operator order
+            std::vector<size_t> sib;
+            for (const auto &u : a0->getTargets()) {
+                auto it = posOf.find(u.get());
+                if (it == posOf.end() || it->second == i || claimed[it->second] || !(u->getOpType() == OpType::MatMul) ||
+                    u->getInputs(0) != a0)
+                    continue;
+                sib.push_back(it->second);
+            }
+            std::sort(sib.begin(), sib.end());
+            sib.erase(std::unique(sib.begin(), sib.end()), sib.end());
+            // members of the group so far must look claimed while the next chain is built (the K chain's attention matcher)
+            for (size_t j : sib) {
+                if (g.size() >= 4)
+                    break;
+                if (j < i)
+                    continue;
+                MMChain hn = buildMatmulChain(j, false);
+                if (!hn.ok || hn.store != 1 || hn.act != 0)
+                    continue;
+                const auto &mn = hn.mm;
+                const Tensor wn = mn->getInputs(1), bn = biasOf(hn);
+                if (mn->getTransA() || mn->getTransB() || wn->getDims() != w0->getDims() || !(wn->getDType() == w0->getDType()) ||
+                    (bn != nullptr) != (bias0 != nullptr) || (bn && bn->size() != bias0->size()) || hn.S != h0.S || hn.D != h0.D ||
+                    hn.rows != h0.rows || hn.n != h0.n || hn.k != h0.k || tunedVariant(ops[j]) >= 0)
+                    continue;
+                // chains must not share members (cannot, but an attention committed with one must not claim another's)
+                g.push_back(hn);
+            }
+            if (g.size() >= 2 && commitGroup(g, a0))
+                return true;
+        }
+        commitChain(h0);
+        return true;
+    }
+
+    // One grouped launch for head-split projections g (same activation). The launch runs at the LAST member's slot; the
+    // group index walks the members in the order of their OUTPUT addresses, so weights / biases must be uniformly spaced in
+    // that same order. Members that cannot be arranged so are left out (they run on their own).
+    bool commitGroup(std::vector<MMChain> g, const Tensor &a0) {
+        auto biasOf = [](const MMChain &c) -> Tensor { return c.biasSrc ? c.biasSrc : (c.mm->numInputs() == 3 ? c.mm->getInputs(2) : nullptr); };
+        std::sort(g.begin(), g.end(), [](const MMChain &x, const MMChain &y) { return addrOf(x.out) < addrOf(y.out); });
+        const intptr_t es = (intptr_t)a0->getDType().getSize();
+        const intptr_t cBytes = (intptr_t)g[0].out->getBytes();
+        auto uniform = [&](const std::vector<MMChain> &s) {
+            const intptr_t dw = (intptr_t)addrOf(s[1].mm->getInputs(1)) - (intptr_t)addrOf(s[0].mm->getInputs(1));
+            const Tensor b0 = biasOf(s[0]);
+            const intptr_t db = b0 ? (intptr_t)addrOf(biasOf(s[1])) - (intptr_t)addrOf(b0) : 0;
+            if (dw % 16 != 0 || db % es != 0)
+                return false;
+            for (size_t j = 1; j < s.size(); ++j) {
+                if ((intptr_t)addrOf(s[j].mm->getInputs(1)) - (intptr_t)addrOf(s[0].mm->getInputs(1)) != (intptr_t)j * dw)
                     return false;
-                if (addr(g[j].out) - addr(h0.out) != (intptr_t)j * dc)
+                if (b0 && (intptr_t)addrOf(biasOf(s[j])) - (intptr_t)addrOf(b0) != (intptr_t)j * db)
+                    return false;
+                if ((intptr_t)addrOf(s[j].out) - (intptr_t)addrOf(s[0].out) != (intptr_t)j * cBytes)
                     return false;
             }
             return true;
         };
-        size_t cnt = g.size();
-        while (cnt >= 2 && !uniform(cnt))
-            --cnt;
-        // no output may land on anything a later group member still reads
-        bool safe = cnt >= 2;
-        for (size_t j = 0; safe && j < cnt; ++j)
-            for (size_t l = 0; safe && l < cnt; ++l)
-                for (const auto &in : g[l].mm->getInputs())
-                    if (overlaps(g[j].out, in))
-                        safe = false;
-        if (safe) {
-            const size_t es = a0->getDType().getSize();
-            const int64_t strideB = (addr(g[1].mm->getInputs(1)) - addr(w0)) / (intptr_t)es;
-            const int64_t strideBias = bias0 ? (addr(g[1].mm->getInputs(2)) - addr(bias0)) / (intptr_t)es : 0;
-            if (std::getenv("INFINI_ROCM_FUSION_LOG"))
-                fprintf(stderr, "[fusion] headsplit#%zu: %zu projections of one activation grouped into one launch\n", i, cnt);
-            ROCM_CALL(infini_rocm_matmul_headsplit(rt, dt, a0->getRawDataPtr<void *>(), w0->getRawDataPtr<void *>(),
-                                                   bias0 ? bias0->getRawDataPtr<void *>() : nullptr,
-                                                   h0.out->getRawDataPtr<void *>(), (int64_t)cnt, h0.rows, h0.n, h0.k, 0, 0,
-                                                   /*strideA*/ 0, strideB, strideBias, 0, bias0 ? 1 : 0, 0, h0.S, h0.D));
-            return 3 * cnt;
+        // the longest run of address-adjacent members that is uniform
+        std::vector<MMChain> pick;
+        for (size_t lo = 0; lo < g.size() && pick.size() < 2; ++lo)
+            for (size_t hi = g.size(); hi >= lo + 2; --hi) {
+                std::vector<MMChain> s(g.begin() + lo, g.begin() + hi);
+                if (uniform(s)) {
+                    pick = s;
+                    break;
+                }
+            }
+        if (pick.size() < 2)
+            return false;
+        size_t slot = 0;
+        std::vector<size_t> members;
+        std::vector<Read> reads;
+        for (const auto &c : pick) {
+            slot = std::max(slot, c.slot);
+            members.insert(members.end(), c.members.begin(), c.members.end());
+            reads.insert(reads.end(), c.reads.begin(), c.reads.end());
         }
-    }
-    OutputRedirect redirect(mm0->getOutput().get(), h0.out->getRawDataPtr<void *>(), (int)h0.S, (int)h0.D);
-    launchOne(ops[i]);
-    return 3;
-}
-
-// MatMul(+bias) -> Gelu (BERT's FFN up-projection), f16 / bf16: the Gelu in the GEMM epilogue (act 5: erf by
-// Abramowitz-Stegun 7.1.26, ~18 VALU slots per element instead of erff's ~40). On by default (INFINI_ROCM_FUSE_GELU=0: A/B
-// hook). BERT-base bs32 seq512: 5.07 -> 4.73 ms — the separate Gelu pass is a 36.7 us memory-bound kernel per layer, the
-// erf evaluations cost the persistent GEMM's store-bound epilogue ~9 us. (Round 1 measured this fusion SLOWER, 5.34 ->
-// 5.68 ms, and kept it opt-in: the epilogue selected the activation with a run-time switch that the unrolled tile epilogue
-// replicated 128 times, erff and tanhf included; the persistent kernel now has a compile-time Gelu instantiation,
-// gemm256p_kernel.h.)
-size_t RocmRuntimeObj::tryLaunchMatmulGelu(const OpVec &ops, size_t i) const {
-    static const bool enabled = !(std::getenv("INFINI_ROCM_FUSE_GELU") && std::atoi(std::getenv("INFINI_ROCM_FUSE_GELU")) == 0);
-    if (!enabled || i + 1 >= ops.size() || ops[i]->getOpType() != OpType::MatMul || ops[i + 1]->getOpType() != OpType::Gelu)
-        return 0;
-    const Tensor c = ops[i]->getOutput(), out = ops[i + 1]->getOutput();
-    const int dt = c->getDTypeIndex();
-    if ((dt != INFINI_DT_F16 && dt != INFINI_DT_BF16) || ops[i + 1]->getInputs(0) != c || !soleConsumerIs(c, ops[i + 1]) ||
-        c->getBytes() != out->getBytes() || !(c->getDType() == out->getDType()))
-        return 0;
-    for (const auto &in : ops[i]->getInputs())
-        if (overlaps(out, in))
-            return 0;
-    OutputRedirect redirect(c.get(), out->getRawDataPtr<void *>(), 0, 0, 5);
-    launchOne(ops[i]);
-    return 2;
-}
-
-// Plain MatMuls that multiply the SAME activations by different weights (a decoder block's gate and up projections; q and k
-// ahead of their RoPE) are a few operators apart in the list: mm_g, Silu, mm_u, Mul. Each alone leaves the chip part empty
-// (Llama-7B at 2048 tokens: 128 or 344 tiles of 256^2 on 256 CUs); as ONE grouped launch (infini_rocm_matmul_grouped: batch
-// index = member, zero A stride, the members' weights / outputs at their own uniform distances) they fill it: q + k + v
-// 215 -> 169 us, gate + up 330 -> 286 us through the C ABI. A later member runs EARLIER than its place in the list, so:
-//   * none of the operators it jumps over may produce (or overwrite) anything it reads;
-//   * its output buffer — which the planner handed out for the member's own position — must not overlap anything those
-//     operators (or the group) read or write;
-//   * a member that another rule wants (head split, Gelu epilogue, copy elision) is left to that rule.
-// Members are marked in `launchedAhead` and skipped when the loop reaches them. INFINI_ROCM_GROUP_MATMUL=0 switches it off.
-size_t RocmRuntimeObj::tryLaunchGroupedMatmul(const OpVec &ops, size_t i) const {
-    static const bool enabled = !(std::getenv("INFINI_ROCM_GROUP_MATMUL") && std::atoi(std::getenv("INFINI_ROCM_GROUP_MATMUL")) == 0);
-    if (!enabled || ops[i]->getOpType() != OpType::MatMul)
-        return 0;
-    auto eligible = [&](size_t j) -> bool {
-        if (ops[j]->getOpType() != OpType::MatMul || launchedAhead[j] || tunedVariant(ops[j]) >= 0)
+        std::sort(members.begin(), members.end());
+        if (std::adjacent_find(members.begin(), members.end()) != members.end())
             return false;
-        auto mm = as<MatmulObj>(ops[j]);
-        const Tensor a = mm->getInputs(0), w = mm->getInputs(1);
-        const int dt = a->getDTypeIndex();
-        if ((dt != INFINI_DT_F16 && dt != INFINI_DT_BF16) || mm->getTransA() || w->getRank() != 2 || !(w->getDType() == a->getDType()))
+        if (!readsSurvive(reads, slot, members))
             return false;
-        if (mm->numInputs() == 3 && !(mm->getInputs(2)->getRank() == 1 && (int)mm->getInputs(2)->size() == w->getDims()[mm->getTransB() ? 0 : 1]))
-            return false;
-        if (j + 1 < ops.size()) { // someone else's pattern
-            const auto t2 = ops[j + 1]->getOpType();
-            if ((t2 == OpType::Reshape || t2 == OpType::Flatten || t2 == OpType::Identity || t2 == OpType::Squeeze ||
-                 t2 == OpType::Unsqueeze || t2 == OpType::Gelu) && soleConsumerIs(mm->getOutput(), ops[j + 1]))
+        for (const auto &c : pick) {
+            // results written later than planned must have no reader in between; no output may land on an input
+            if (c.slot < slot) {
+                std::vector<size_t> allowed = members;
+                if (c.attn)
+                    allowed.insert(allowed.end(), c.attn->members.begin(), c.attn->members.end());
+                if (!unreadUntil(c.out, slot + 1, allowed))
+                    return false;
+                // an attention committed with this member must run after the group
+                if (c.attn && c.attn->last < slot)
+                    return false;
+            }
+            for (const auto &rd : reads)
+                if (overlaps(c.out, rd.t))
+                    return false;
+            if (Tensor bs = biasOf(c); bs && overlaps(c.out, bs))
                 return false;
         }
-        return true;
-    };
-    if (!eligible(i))
-        return 0;
-    auto mm0 = as<MatmulObj>(ops[i]);
-    const Tensor a0 = mm0->getInputs(0), w0 = mm0->getInputs(1);
-    const Tensor bias0 = mm0->numInputs() == 3 ? mm0->getInputs(2) : nullptr;
-    const auto [b0, m0, n0, k0] = mm0->getBMNK();
-    std::vector<size_t> members{i};
-    std::vector<Tensor> touched; // everything the group and the operators it jumps over read or write
-    auto touch = [&](const Operator &o) {
-        for (const auto &t : o->getInputs())
-            touched.push_back(t);
-        for (const auto &t : o->getOutputs())
-            touched.push_back(t);
-    };
-    touch(ops[i]);
-    std::vector<Tensor> producedBetween; // outputs of the jumped-over operators
-    size_t parkAt = 0;                   // index of the member whose result goes to the workspace (0: none)
-    auto wsQuiet = [](const Operator &o) { // kernels that never take the runtime workspace
-        const auto t = o->getOpType();
-        return t.isUnary() || t == OpType::Silu || t == OpType::Add || t == OpType::Sub || t == OpType::Mul || t == OpType::Div ||
-               t == OpType::RoPE || t == OpType::Reshape || t == OpType::Flatten || t == OpType::Identity || t == OpType::Squeeze ||
-               t == OpType::Unsqueeze || t == OpType::Transpose;
-    };
-    constexpr size_t kWindow = 12;
-    for (size_t j = i + 1; j < ops.size() && j <= i + kWindow && members.size() < 4; ++j) {
-        bool member = false;
-        if (eligible(j)) {
-            auto mj = as<MatmulObj>(ops[j]);
-            const auto [bj, mjm, nj, kj] = mj->getBMNK();
-            const Tensor wj = mj->getInputs(1), bj_t = mj->numInputs() == 3 ? mj->getInputs(2) : nullptr;
-            member = mj->getInputs(0) == a0 && mj->getTransB() == mm0->getTransB() && wj->getDims() == w0->getDims() && bj == b0 &&
-                     mjm == m0 && nj == n0 && kj == k0 && (bj_t != nullptr) == (bias0 != nullptr) &&
-                     mj->getOutput()->getDims() == mm0->getOutput()->getDims();
-            const Tensor outj = mj->getOutput();
-            bool clear = true; // the member's own output buffer is free at the group's position
-            for (size_t q = 0; member && clear && q < touched.size(); ++q)
-                clear = !overlaps(outj, touched[q]);
-            for (size_t q = 0; member && q < producedBetween.size(); ++q)
-                for (const auto &in : mj->getInputs())
-                    member = member && !overlaps(producedBetween[q], in);
-            // The planner usually recycles: mm_u's output sits where mm_g's was (dead once Silu has read it). Then the member's
-            // result is PARKED in the workspace and its one consumer — the very next operator, an element-wise / RoPE kernel —
-            // reads it from there (parkedFeeds). Two-member groups only (member = batch index needs ONE output stride), nothing
-            // between the group and that consumer may use the workspace, and the grouped MatMul itself must not (split-K).
-            if (member && !clear) {
-                int mayWs = 1;
-                const auto [gb, gm, gn, gk] = mj->getBMNK();
-                ROCM_CALL(infini_rocm_matmul_may_use_workspace(rt, 2, (int64_t)gb * gm, gn, &mayWs));
-                bool quiet = members.size() == 1 && parkAt == 0 && !mayWs && j + 1 < ops.size() && soleConsumerIs(outj, ops[j + 1]) &&
-                             wsQuiet(ops[j + 1]) && tunedVariant(ops[j + 1]) < 0;
-                for (size_t b = i + 1; quiet && b < j; ++b)
-                    quiet = wsQuiet(ops[b]);
-                int uses = 0;
-                if (quiet)
-                    for (const auto &in : ops[j + 1]->getInputs())
-                        uses += in == outj;
-                if (quiet && uses == 1)
-                    parkAt = j;
-                else
-                    member = false;
+        // a member whose output buffer is still in use by someone else before `slot`? No: the buffer is the member's own
+        // from its planned position on; only members planned AFTER... all members' slots are <= slot, so every output
+        // buffer is live at `slot`.
+        noteLateReads(reads, slot);
+        const RocmRuntimeObj *r = R;
+        const Tensor w0 = pick[0].mm->getInputs(1), bias0 = biasOf(pick[0]), out0 = pick[0].out;
+        const int64_t strideB = ((intptr_t)addrOf(pick[1].mm->getInputs(1)) - (intptr_t)addrOf(w0)) / es;
+        const int64_t strideBias = bias0 ? ((intptr_t)addrOf(biasOf(pick[1])) - (intptr_t)addrOf(bias0)) / es : 0;
+        const int64_t cnt = pick.size(), rows = pick[0].rows, S = pick[0].S, D = pick[0].D;
+        const int nn = pick[0].n, kk = pick[0].k, dt = a0->getDTypeIndex();
+        const Tensor A = a0;
+        std::vector<size_t> writers;
+        for (const auto &c : pick)
+            writers.push_back(c.members.back());
+        emit(slot, members, pick[0].what + " x" + std::to_string(cnt) + " (grouped)", true,
+             [r, A, w0, bias0, out0, cnt, rows, nn, kk, strideB, strideBias, S, D, dt] {
+                 ROCM_CALL(infini_rocm_matmul_headsplit(r->handle(), dt, A->getRawDataPtr<void *>(), w0->getRawDataPtr<void *>(),
+                                                        bias0 ? bias0->getRawDataPtr<void *>() : nullptr, out0->getRawDataPtr<void *>(), cnt,
+                                                        rows, nn, kk, 0, 0, /*strideA*/ 0, strideB, strideBias, 0, bias0 ? 1 : 0, 0, S, D));
+             },
+             writers);
+        for (const auto &c : pick)
+            if (c.attn)
+                commitAttention(*c.attn);
+        // members left out run on their own
+        for (const auto &c : g) {
+            bool in = false;
+            for (const auto &p : pick)
+                in = in || p.head == c.head;
+            if (!in && !claimed[c.head]) {
+                bool free = true;
+                for (size_t m : c.members)
+                    free = free && !claimed[m];
+                if (free && (!c.attn || !claimed[c.attn->members[0]]))
+                    commitChain(c);
             }
         }
-        touch(ops[j]);
-        if (member) {
-            members.push_back(j);
-            if (parkAt == j)
-                break; // a parked member closes the group
-        } else {
-            for (const auto &t : ops[j]->getOutputs())
-                producedBetween.push_back(t);
-        }
-    }
-    auto addr = [](const Tensor &t) { return (intptr_t)t->getRawDataPtr<void *>(); };
-    const intptr_t es = (intptr_t)a0->getDType().getSize();
-    const intptr_t cBytes = (intptr_t)mm0->getOutput()->getBytes();
-    auto uniform = [&](size_t cnt, intptr_t &dw, intptr_t &db, intptr_t &dc) {
-        auto W = [&](size_t q) { return as<MatmulObj>(ops[members[q]])->getInputs(1); };
-        auto Bi = [&](size_t q) { return as<MatmulObj>(ops[members[q]])->getInputs(2); };
-        auto O = [&](size_t q) { return ops[members[q]]->getOutput(); };
-        dw = addr(W(1)) - addr(w0);
-        db = bias0 ? addr(Bi(1)) - addr(bias0) : 0;
-        dc = addr(O(1)) - addr(O(0));
-        if (dw % 16 != 0 || db % es != 0 || dc % 16 != 0 || (dc < cBytes && dc > -cBytes))
-            return false;
-        for (size_t q = 2; q < cnt; ++q)
-            if (addr(W(q)) - addr(w0) != (intptr_t)q * dw || (bias0 && addr(Bi(q)) - addr(bias0) != (intptr_t)q * db) ||
-                addr(O(q)) - addr(O(0)) != (intptr_t)q * dc)
-                return false;
         return true;
-    };
-    size_t cnt = members.size();
-    intptr_t dw = 0, db = 0, dc = 0;
-    void *park = nullptr;
-    if (parkAt) { // exactly two members: the second one's result goes to the workspace
-        park = getWorkspace((size_t)cBytes);
-        auto W1 = as<MatmulObj>(ops[members[1]])->getInputs(1);
-        dw = addr(W1) - addr(w0);
-        db = bias0 ? addr(as<MatmulObj>(ops[members[1]])->getInputs(2)) - addr(bias0) : 0;
-        dc = (intptr_t)park - addr(mm0->getOutput());
-        if (cnt != 2 || dw % 16 != 0 || db % es != 0 || dc % 16 != 0 || (dc < cBytes && dc > -cBytes))
-            return 0;
-    } else {
-        while (cnt >= 2 && !uniform(cnt, dw, db, dc))
-            --cnt;
+    }
+
+    // Plain MatMuls that multiply the SAME activations by different weights (a decoder block's gate and up projections; q and k
+    // ahead of their RoPE) are a few operators apart in the list: mm_g, Silu, mm_u, Mul. Each alone leaves the chip part empty
+    // (Llama-7B at 2048 tokens: 128 or 344 tiles of 256^2 on 256 CUs); as ONE grouped launch (infini_rocm_matmul_grouped: batch
+    // index = member, zero A stride, the members' weights / outputs at their own uniform distances) they fill it: q + k + v
+    // 215 -> 169 us, gate + up 330 -> 286 us through the C ABI. A later member runs EARLIER than its place in the list, so:
+    //   * none of the operators it jumps over may produce (or overwrite) anything it reads;
+    //   * its output buffer — which the planner handed out for the member's own position — must not overlap anything those
+    //     operators (or the group, or a sunk item's late reads) read or write;
+    //   * a member that another rule wants (head split, Gelu epilogue, bias fold, copy elision) is left to that rule.
+    // INFINI_ROCM_GROUP_MATMUL=0 switches it off.
+    bool planGroupedAhead(size_t i) {
+        static const bool enabled = envOn("INFINI_ROCM_GROUP_MATMUL");
+        if (!enabled)
+            return false;
+        auto eligible = [&](size_t j) -> bool {
+            if (!(ops[j]->getOpType() == OpType::MatMul) || claimed[j] || tunedVariant(ops[j]) >= 0)
+                return false;
+            auto mm = as<MatmulObj>(ops[j]);
+            const Tensor a = mm->getInputs(0), w = mm->getInputs(1);
+            const int dt = a->getDTypeIndex();
+            if (!isHalf(dt) || mm->getTransA() || w->getRank() != 2 || !(w->getDType() == a->getDType()))
+                return false;
+            if (mm->numInputs() == 3 && !(mm->getInputs(2)->getRank() == 1 && (int)mm->getInputs(2)->size() == w->getDims()[mm->getTransB() ? 0 : 1]))
+                return false;
+            MMChain other = buildMatmulChain(j, false); // someone else's pattern
+            return !other.ok;
+        };
+        if (!eligible(i))
+            return false;
+        auto mm0 = as<MatmulObj>(ops[i]);
+        const Tensor a0 = mm0->getInputs(0), w0 = mm0->getInputs(1);
+        const Tensor bias0 = mm0->numInputs() == 3 ? mm0->getInputs(2) : nullptr;
+        const auto [b0, m0, n0, k0] = mm0->getBMNK();
+        std::vector<size_t> members{i};
+        std::vector<Tensor> touched; // everything the group and the operators it jumps over read or write
+        auto touch = [&](const Operator &o) {
+            for (const auto &t : o->getInputs())
+                touched.push_back(t);
+            for (const auto &t : o->getOutputs())
+                touched.push_back(t);
+        };
+        touch(ops[i]);
+        std::vector<Tensor> producedBetween; // outputs of the jumped-over operators
+        size_t parkAt = 0;                   // index of the member whose result goes to the workspace (0: none)
+        auto wsQuiet = [](const Operator &o) { // kernels that never take the runtime workspace
+            const auto t = o->getOpType();
+            return t.isUnary() || t == OpType::Silu || t == OpType::Add || t == OpType::Sub || t == OpType::Mul || t == OpType::Div ||
+                   t == OpType::RoPE || isCopyLike(t) || t == OpType::Transpose;
+        };
+        constexpr size_t kWindow = 12;
+        for (size_t j = i + 1; j < n && j <= i + kWindow && members.size() < 4; ++j) {
+            bool member = false;
+            if (eligible(j)) {
+                auto mj = as<MatmulObj>(ops[j]);
+                const auto [bj, mjm, nj, kj] = mj->getBMNK();
+                const Tensor wj = mj->getInputs(1), bj_t = mj->numInputs() == 3 ? mj->getInputs(2) : nullptr;
+                member = mj->getInputs(0) == a0 && mj->getTransB() == mm0->getTransB() && wj->getDims() == w0->getDims() && bj == b0 &&
+                         mjm == m0 && nj == n0 && kj == k0 && (bj_t != nullptr) == (bias0 != nullptr) &&
+                         mj->getOutput()->getDims() == mm0->getOutput()->getDims();
+                const Tensor outj = mj->getOutput();
+                bool clear = true; // the member's own output buffer is free at the group's position
+                for (size_t q = 0; member && clear && q < touched.size(); ++q)
+                    clear = !overlaps(outj, touched[q]);
+                for (const auto &lr : lateReads) // a sunk item still reads this memory later than the graph says
+                    if (member && clear && lr.to > i && lr.from < j && overlaps(outj, lr.t))
+                        clear = false;
+                for (size_t q = 0; member && q < producedBetween.size(); ++q)
+                    for (const auto &in : mj->getInputs())
+                        member = member && !overlaps(producedBetween[q], in);
+                // The planner usually recycles: mm_u's output sits where mm_g's was (dead once Silu has read it). Then the member's
+                // result is PARKED in the workspace and its one consumer — the very next operator, an element-wise / RoPE kernel —
+                // reads it from there. Two-member groups only (member = batch index needs ONE output stride), nothing
+                // between the group and that consumer may use the workspace, and the grouped MatMul itself must not (split-K).
+                if (member && !clear) {
+                    const auto [gb, gm, gn, gk] = mj->getBMNK();
+                    bool quiet = members.size() == 1 && parkAt == 0 && !mayUseWorkspace(2, (int64_t)gb * gm, gn) && j + 1 < n &&
+                                 onlyUser(outj) == ops[j + 1] && wsQuiet(ops[j + 1]) && tunedVariant(ops[j + 1]) < 0;
+                    for (size_t bq = i + 1; quiet && bq < j; ++bq)
+                        quiet = wsQuiet(ops[bq]) && !claimed[bq];
+                    if (quiet && usesOnce(ops[j + 1], outj))
+                        parkAt = j;
+                    else
+                        member = false;
+                }
+            }
+            if (claimed[j] && !member) // an operator another item already owns: its real run time is not its position
+                break;
+            touch(ops[j]);
+            if (member) {
+                members.push_back(j);
+                if (parkAt == j)
+                    break; // a parked member closes the group
+            } else {
+                for (const auto &t : ops[j]->getOutputs())
+                    producedBetween.push_back(t);
+            }
+        }
+        auto addr = [](const Tensor &t) { return (intptr_t)addrOf(t); };
+        const intptr_t es = (intptr_t)a0->getDType().getSize();
+        const intptr_t cBytes = (intptr_t)mm0->getOutput()->getBytes();
+        auto Wt = [&](size_t q) { return as<MatmulObj>(ops[members[q]])->getInputs(1); };
+        auto Bi = [&](size_t q) { return as<MatmulObj>(ops[members[q]])->getInputs(2); };
+        auto Ot = [&](size_t q) { return ops[members[q]]->getOutput(); };
+        auto uniform = [&](size_t cnt, intptr_t &dw, intptr_t &db, intptr_t &dc) {
+            dw = addr(Wt(1)) - addr(w0);
+            db = bias0 ? addr(Bi(1)) - addr(bias0) : 0;
+            dc = addr(Ot(1)) - addr(Ot(0));
+            if (dw % 16 != 0 || db % es != 0 || dc % 16 != 0 || (dc < cBytes && dc > -cBytes))
+                return false;
+            for (size_t q = 2; q < cnt; ++q)
+                if (addr(Wt(q)) - addr(w0) != (intptr_t)q * dw || (bias0 && addr(Bi(q)) - addr(bias0) != (intptr_t)q * db) ||
+                    addr(Ot(q)) - addr(Ot(0)) != (intptr_t)q * dc)
+                    return false;
+            return true;
+        };
+        size_t cnt = members.size();
         if (cnt < 2)
-            return 0;
+            return false;
+        intptr_t dw = 0, db = 0, dc = 0;
+        if (parkAt) { // exactly two members: the second one's result goes to the workspace
+            dw = addr(Wt(1)) - addr(w0);
+            db = bias0 ? addr(Bi(1)) - addr(bias0) : 0;
+            if (cnt != 2 || dw % 16 != 0 || db % es != 0)
+                return false;
+        } else {
+            while (cnt >= 2 && !uniform(cnt, dw, db, dc))
+                --cnt;
+            if (cnt < 2)
+                return false;
+        }
+        // rows: the batch folds into m when the weight is shared (rank-2 w) and A is dense
+        const int64_t rows = (int64_t)b0 * m0;
+        const RocmRuntimeObj *r = R;
+        const Tensor A = a0, W = w0, Bs = bias0, O = mm0->getOutput();
+        const int tb = mm0->getTransB() ? 1 : 0, dt = a0->getDTypeIndex();
+        const int64_t n64 = n0, k64 = k0;
+        const bool park = parkAt != 0;
+        std::vector<size_t> mem(members.begin(), members.begin() + cnt);
+        emit(i, mem, "matmul x" + std::to_string(cnt) + " (grouped ahead" + (park ? ", parked)" : ")"), true,
+             [r, A, W, Bs, O, cnt, rows, n64, k64, tb, dw, db, dc, es, dt, park, cBytes] {
+                 intptr_t dcv = dc;
+                 if (park) {
+                     void *p = r->getWorkspace((size_t)cBytes);
+                     dcv = (intptr_t)p - (intptr_t)O->getRawDataPtr<void *>();
+                     IT_ASSERT(dcv % 16 == 0 && !(dcv < cBytes && dcv > -cBytes), "parked GEMM output collides with the group's own");
+                     ++r->parkedCount;
+                 }
+                 ROCM_CALL(infini_rocm_matmul_grouped(r->handle(), dt, A->getRawDataPtr<void *>(), W->getRawDataPtr<void *>(),
+                                                      Bs ? Bs->getRawDataPtr<void *>() : nullptr, O->getRawDataPtr<void *>(), (int64_t)cnt,
+                                                      rows, n64, k64, 0, tb, /*strideA*/ 0, dw / es, dcv / es, db / es, 0, Bs ? 1 : 0, 0, 0, 0));
+             },
+             park ? std::vector<size_t>{i} : mem);
+        if (parkAt)
+            parked[parkAt + 1] = ParkedFeed{ops[parkAt]->getOutput().get(), (size_t)cBytes};
+        return true;
     }
-    // rows: the batch folds into m when the weight is shared (rank-2 w) and A is dense
-    const int64_t rows = (int64_t)b0 * m0;
-    if (std::getenv("INFINI_ROCM_FUSION_LOG"))
-        fprintf(stderr, "[fusion] matmul#%zu: %zu MatMuls of one activation grouped into one launch (members up to #%zu)\n", i, cnt,
-                members[cnt - 1]);
-    ROCM_CALL(infini_rocm_matmul_grouped(rt, a0->getDTypeIndex(), a0->getRawDataPtr<void *>(), w0->getRawDataPtr<void *>(),
-                                         bias0 ? bias0->getRawDataPtr<void *>() : nullptr,
-                                         mm0->getOutput()->getRawDataPtr<void *>(), (int64_t)cnt, rows, n0, k0, 0,
-                                         mm0->getTransB() ? 1 : 0, /*strideA*/ 0, dw / es, dc / es, db / es, 0, bias0 ? 1 : 0, 0, 0, 0));
-    for (size_t q = 1; q < cnt; ++q)
-        launchedAhead[members[q]] = 1;
-    if (parkAt) {
-        parkedFeeds[parkAt + 1] = ParkedFeed{ops[parkAt]->getOutput().get(), park};
-        ++parkedCount;
+
+    // the operator at `i` reads a parked group result: rules that know how to (RoPE head split, Silu-Mul reach it themselves)
+    bool planParkedConsumer(size_t i, const ParkedFeed &pf) {
+        if (ops[i]->getOpType() == OpType::RoPE)
+            return planRopeHeadSplit(i, &pf);
+        return false;
     }
-    return 1;
-}
 
-// RoPE -> Reshape([B, S, H, D]) -> Transpose(0, 2, 1, 3): the rotary embedding of a decoder's q / k followed by their head split
-// (rope.cu, reshape.cc, transpose.cc: three launches, two extra passes) as one pass with a head-split store
-// (infini_rocm_rope_headsplit). Head dim 128 / theta 1e4 as the reference hard-codes them (rope.cc:25). The input may be a
-// grouped MatMul's result parked in the workspace (parkedFeeds): this rule resolves it itself, launchAll tries it first.
-size_t RocmRuntimeObj::tryLaunchRopeHeadSplit(const OpVec &ops, size_t i) const {
-    static const bool enabled = !(std::getenv("INFINI_ROCM_FUSE_ROPE_SPLIT") && std::atoi(std::getenv("INFINI_ROCM_FUSE_ROPE_SPLIT")) == 0);
-    if (!enabled || i + 2 >= ops.size() || ops[i]->getOpType() != OpType::RoPE || ops[i + 1]->getOpType() != OpType::Reshape ||
-        ops[i + 2]->getOpType() != OpType::Transpose || launchedAhead[i + 1] || launchedAhead[i + 2])
-        return 0;
-    const Tensor pos = ops[i]->getInputs(0), x = ops[i]->getInputs(1), y = ops[i]->getOutput();
-    const Tensor r = ops[i + 1]->getOutput(), out = ops[i + 2]->getOutput();
-    auto tr = as<TransposeObj>(ops[i + 2]);
-    if (ops[i + 1]->getInputs(0) != y || tr->getInputs(0) != r || !soleConsumerIs(y, ops[i + 1]) || !soleConsumerIs(r, ops[i + 2]))
-        return 0;
-    const auto &xd = x->getDims(), &rd = r->getDims();
-    const auto perm = tr->getPermute();
-    if (xd.size() != 3 || rd.size() != 4 || perm.size() != 4 || perm[0] != 0 || perm[1] != 2 || perm[2] != 1 || perm[3] != 3 ||
-        rd[0] != xd[0] || rd[1] != xd[1] || rd[3] != 128 || (long)rd[2] * rd[3] != xd[2] || pos->getDims().size() != 2 ||
-        pos->getDims()[1] != xd[1] || !(out->getDType() == x->getDType()) || out->getBytes() != x->getBytes())
-        return 0;
-    const void *xp = x->getRawDataPtr<void *>();
-    auto pf = parkedFeeds.find(i);
-    if (pf != parkedFeeds.end()) {
-        if (pf->second.tensor != x.get())
-            return 0;
-        xp = pf->second.ptr; // the tensor's own buffer holds something else right now: only the parked copy counts
-    } else if (overlaps(out, x)) {
-        return 0;
-    }
-    if (overlaps(out, pos))
-        return 0;
-    ROCM_CALL(infini_rocm_rope_headsplit(rt, x->getDTypeIndex(), pos->getDTypeIndex(), pos->getRawDataPtr<void *>(), xp,
-                                         out->getRawDataPtr<void *>(), (int64_t)xd[0] * xd[1], xd[2], 128, 10000.0f, xd[1]));
-    if (pf != parkedFeeds.end())
-        parkedFeeds.erase(pf);
-    return 3;
-}
-
-// producer -> Reshape | Flatten | Identity | Squeeze | Unsqueeze: the reference runs these as a device memcpy
-// (CopyCuda, reshape.cc:4-21); here the producer writes straight into the copy's output buffer (BERT: the three
-// projections before the head split and the head merge, 48 copies of 25 MB per forward). The producer runs through its
-// normal kernel (and perf record) with its output tensor redirected, so nothing about its numerics changes.
-size_t RocmRuntimeObj::tryLaunchIntoReshape(const OpVec &ops, size_t i) const {
-    static const bool enabled = !(std::getenv("INFINI_ROCM_FUSE_RESHAPE") && std::atoi(std::getenv("INFINI_ROCM_FUSE_RESHAPE")) == 0);
-    if (!enabled || i + 1 >= ops.size()) // INFINI_ROCM_FUSE_RESHAPE=0: A/B hook
-        return 0;
-    const Operator &op = ops[i], &next = ops[i + 1];
-    const auto nt = next->getOpType(), type = op->getOpType();
-    if (!(nt == OpType::Reshape || nt == OpType::Flatten || nt == OpType::Identity || nt == OpType::Squeeze ||
-          nt == OpType::Unsqueeze))
-        return 0;
-    // producers whose kernels only WRITE their output (no in-place state, no multi-output, no collectives)
-    if (!(type == OpType::MatMul || type == OpType::Transpose || type == OpType::Add || type == OpType::Sub ||
-          type == OpType::Mul || type == OpType::Div || type == OpType::Relu || type == OpType::Gelu ||
-          type == OpType::Silu || type == OpType::Sigmoid || type == OpType::Tanh || type == OpType::Softmax ||
-          type == OpType::LayerNormalization || type == OpType::RMSNorm || type == OpType::Gather || type == OpType::RoPE))
-        return 0;
-    if (op->numOutputs() != 1 || next->numOutputs() != 1)
-        return 0;
-    const Tensor mid = op->getOutput(), out = next->getOutput();
-    if (next->getInputs(0) != mid || !soleConsumerIs(mid, next) || mid->getBytes() != out->getBytes() ||
-        !(mid->getDType() == out->getDType()))
-        return 0;
-    for (const auto &in : op->getInputs())
-        if (overlaps(out, in)) // the producer would overwrite what it is still reading
-            return 0;
-    OutputRedirect redirect(mid.get(), out->getRawDataPtr<void *>());
-    launchOne(op);
-    return 2;
-}
-
-size_t RocmRuntimeObj::tryLaunchFusedRules(const OpVec &ops, size_t i) const {
-    const Operator &op = ops[i];
-    const auto type = op->getOpType();
-    if (type == OpType::MatMul)
-        return tryLaunchFusedAttention(ops, i);
-    if (type == OpType::Conv) {
-        auto conv = as<ConvObj>(op);
+    // ============================================================================================================
+    // Conv chains
+    // ============================================================================================================
+    bool planConv(size_t i) {
+        auto conv = as<ConvObj>(ops[i]);
         const Tensor x = conv->getInputs(0), w = conv->getInputs(1);
-        const int f = conv->getOutput()->getDims()[1];
+        const auto &od = conv->getOutput()->getDims();
+        const int f = od[1];
         // candidate chains, each one op longer than the previous: conv [+ bias] [+ residual] [+ relu]
         struct Cand {
-            size_t used;
-            Tensor last, bias, res;
+            std::vector<size_t> members;
+            std::vector<Read> reads;
+            Tensor last, biasSrc, res;
             int act;
+            size_t slot;
         };
         std::vector<Cand> cands;
-        Cand cur{1, conv->getOutput(), nullptr, nullptr, 0};
-        auto nextIs = [&](OpType t) {
-            return i + cur.used < ops.size() && ops[i + cur.used]->getOpType() == t && soleConsumerIs(cur.last, ops[i + cur.used]);
+        Cand cur{{i}, {{x, i}, {w, i}}, conv->getOutput(), nullptr, nullptr, 0, i};
+        auto add = [&](Cand &c, size_t p) {
+            c.members.push_back(p);
+            std::sort(c.members.begin(), c.members.end());
+            c.slot = std::max(c.slot, p);
         };
-        auto otherOf = [&](const Operator &o) { return o->getInputs(0) == cur.last ? o->getInputs(1) : o->getInputs(0); };
-        if (nextIs(OpType::Add)) {
-            const Operator &add = ops[i + cur.used];
-            const Tensor other = otherOf(add);
-            if (other != cur.last && isChannelBias(other, f) && other->getDType() == cur.last->getDType() &&
-                add->getOutput()->getDims() == cur.last->getDims()) {
-                cur.bias = other;
-                cur.last = add->getOutput();
-                ++cur.used;
+        if (Operator u = userOfType(cur.last, OpType::Add, cur.slot)) {
+            const Tensor other = otherOf(u, cur.last);
+            if (other != cur.last && isChannelBias(other->getDims(), f) && other->getDType() == cur.last->getDType() &&
+                u->getOutput()->getDims() == cur.last->getDims()) {
+                std::vector<size_t> dead;
+                const Tensor root = aliasRoot(other, dead); // the front-end's Reshape(bias, [1, F, 1, 1]): read the weight itself
+                cur.biasSrc = root ? root : other;
+                for (size_t dp : dead)
+                    add(cur, dp);
+                if (!root)
+                    cur.reads.push_back({other, pos(u)});
+                add(cur, pos(u));
+                cur.last = u->getOutput();
                 cands.push_back(cur);
             }
         }
@@ -681,220 +1503,461 @@ size_t RocmRuntimeObj::tryLaunchFusedRules(const OpVec &ops, size_t i) const {
         // direct epilogue (32-byte segments per filter row) the fused form was slower than conv + one ADD_RELU pass, which
         // is still what odd planes (7x7) and fp32 get. INFINI_ROCM_FUSE_RES=0 / =1 forces it off / on for every shape.
         static const int fuseResEnv = std::getenv("INFINI_ROCM_FUSE_RES") ? std::atoi(std::getenv("INFINI_ROCM_FUSE_RES")) : -1;
-        const auto &od = conv->getOutput()->getDims();
         const bool fuseRes = fuseResEnv >= 0 ? fuseResEnv == 1
                                              : (od.size() == 4 && ((long)od[2] * od[3]) % 2 == 0 && conv->getNumGroups() == 1 &&
                                                 !(x->getDType() == DataType::Float32) && !(x->getDType() == DataType::Double));
-        if (fuseRes && cur.bias && nextIs(OpType::Add)) { // residual join: the tail of a ResNet bottleneck
-            const Operator &add2 = ops[i + cur.used];
-            const Tensor other = otherOf(add2);
-            if (other != cur.last && other->getDims() == cur.last->getDims() && other->getDType() == cur.last->getDType()) {
-                cur.res = other;
-                cur.last = add2->getOutput();
-                ++cur.used;
-                cands.push_back(cur);
+        if (fuseRes && cur.biasSrc) { // residual join: the tail of a ResNet bottleneck
+            if (Operator u = userOfType(cur.last, OpType::Add, cur.slot)) {
+                const Tensor other = otherOf(u, cur.last);
+                if (other != cur.last && other->getDims() == cur.last->getDims() && other->getDType() == cur.last->getDType()) {
+                    cur.res = other;
+                    cur.reads.push_back({other, pos(u)});
+                    add(cur, pos(u));
+                    cur.last = u->getOutput();
+                    cands.push_back(cur);
+                }
             }
         }
-        if (nextIs(OpType::Relu)) {
+        if (Operator u = userOfType(cur.last, OpType::Relu, cur.slot)) {
             cur.act = 1;
-            cur.last = ops[i + cur.used]->getOutput();
-            ++cur.used;
+            add(cur, pos(u));
+            cur.last = u->getOutput();
             cands.push_back(cur);
         }
         // longest chain whose output buffer is safe to write while the conv still reads its inputs
-        static const bool fusionLog = std::getenv("INFINI_ROCM_FUSION_LOG") != nullptr; // diagnostics: which chain each conv got
+        const auto [nb, ch, hh, wd, ff, rr, ss] = conv->getNCHWFRS();
+        const auto [ph, pw, sh, sw, dh, dw] = conv->getPadStrideDilation();
         for (auto it = cands.rbegin(); it != cands.rend(); ++it) {
             const Cand &c = *it;
-            if (fusionLog)
+            if (log)
                 fprintf(stderr, "[fusion] conv#%zu [%d,%d,%d,%d]: chain %zu (bias %d res %d act %d) out-on-x %d out-on-w %d out-on-res %d\n", i,
-                        (int)od[0], (int)od[1], (int)od[2], (int)od[3], c.used, c.bias != nullptr, c.res != nullptr, c.act,
+                        (int)od[0], (int)od[1], (int)od[2], (int)od[3], c.members.size(), c.biasSrc != nullptr, c.res != nullptr, c.act,
                         (int)overlaps(c.last, x), (int)overlaps(c.last, w), (int)(c.res && overlaps(c.last, c.res)));
+            if (!readsSurvive(c.reads, c.slot, c.members))
+                continue;
             // the residual is read at exactly the position that is written: it may be the output buffer itself
-            const bool resHazard = c.res && overlaps(c.last, c.res) &&
-                                   !(c.res->getRawDataPtr<void *>() == c.last->getRawDataPtr<void *>() &&
-                                     c.res->getDims() == c.last->getDims());
-            const auto [n, ch, h, wd, ff, r, s] = conv->getNCHWFRS();
-            const auto [ph, pw, sh, sw, dh, dw] = conv->getPadStrideDilation();
+            const bool resHazard = c.res && overlaps(c.last, c.res) && !samePlace(c.res, c.last);
             // The planner likes to put the chain's output on the conv's own input (dead after the conv in the unfused
             // graph). When that input is small next to the output — the 64 -> 256 expansions of ResNet's first stage: 51 MB
             // in, 205 MB out — the conv reads a copy of it from the workspace instead of giving up the tail: one 2 x 51 MB
             // copy instead of a lone 2 x 205 MB ReLU / bias pass. Unit-stride only (a strided conv keeps its phase planes
             // at the workspace base, a long-K pointwise layer may run as a split-K GEMM with partial planes there); the
-            // copy sits behind the conv's own packed-weight area.
+            // copy sits behind the conv's own packed-weight area (sized like conv_s1.hip sizes it: [F][roundup32(C R S)] for
+            // channel counts that are not multiples of 32).
             const bool onX = overlaps(c.last, x);
-            static const bool bridgeOn = !(std::getenv("INFINI_ROCM_BRIDGE_X") && std::atoi(std::getenv("INFINI_ROCM_BRIDGE_X")) == 0);
-            const bool bridgeX = bridgeOn && onX && sh == 1 && sw == 1 && conv->getNumGroups() == 1 && ch < 1024 &&
+            static const bool bridgeOn = envOn("INFINI_ROCM_BRIDGE_X");
+            const bool bridgeX = bridgeOn && onX && sh == 1 && sw == 1 && conv->getNumGroups() == 1 && ch < 1024 && ch % 32 == 0 &&
                                  (size_t)x->getBytes() * 3 <= (size_t)c.last->getBytes();
             if (!(c.last->getDType() == x->getDType()) || (onX && !bridgeX) || overlaps(c.last, w) ||
-                (c.bias && overlaps(c.last, c.bias)) || resHazard)
+                (c.biasSrc && overlaps(c.last, c.biasSrc)) || resHazard)
                 continue;
-            const void *xptr = x->getRawDataPtr<void *>();
-            if (bridgeX) {
-                const size_t wArea = (((size_t)ff * ch * r * s * 2 + 4096) + 255) & ~(size_t)255;
-                char *ws = (char *)getWorkspace(wArea + x->getBytes());
-                ROCM_CALL(infini_rocm_copy_inside(rt, ws + wArea, xptr, x->getBytes()));
-                xptr = ws + wArea;
-                ++bridgedCount;
-                if (fusionLog)
-                    fprintf(stderr, "[fusion] conv#%zu: input bridged through the workspace (%zu bytes)\n", i, (size_t)x->getBytes());
-            }
-            // a tuned Conv (h.tune(): ConvRocm::tune) keeps its kernel choice when the tail is folded into it
-            struct VariantScope {
-                infiniRocmRuntime_t rt;
-                bool set;
-                VariantScope(infiniRocmRuntime_t rt, int v) : rt(rt), set(v >= 0) {
-                    if (set)
-                        ROCM_CALL(infini_rocm_conv2d_set_variant(rt, v));
+            noteLateReads(c.reads, c.slot);
+            const RocmRuntimeObj *r = R;
+            const Operator op = ops[i];
+            const Tensor X = x, Wt = w, Bs = c.biasSrc, Rs = c.res, Out = c.last;
+            const int act = c.act, groups = conv->getNumGroups();
+            const int variant = tunedVariant(op);
+            const int n_ = nb, c_ = ch, h_ = hh, w_ = wd, f_ = ff, r_ = rr, s_ = ss, ph_ = ph, pw_ = pw, sh_ = sh, sw_ = sw, dh_ = dh, dw_ = dw;
+            const bool lg = log;
+            const size_t idx = i;
+            std::string what = std::string("conv") + (c.biasSrc ? "+bias" : "") + (c.res ? "+res" : "") + (c.act ? "+relu" : "") +
+                               (bridgeX ? " (x bridged)" : "");
+            emit(c.slot, c.members, what, true, [=] {
+                const void *xptr = X->getRawDataPtr<void *>();
+                if (bridgeX) {
+                    const size_t kpad = ((size_t)c_ * r_ * s_ + 31) & ~(size_t)31;
+                    const size_t wArea = ((std::max((size_t)f_ * c_ * r_ * s_, (size_t)f_ * kpad) * 2 + 4096) + 255) & ~(size_t)255;
+                    char *ws = (char *)r->getWorkspace(wArea + X->getBytes());
+                    ROCM_CALL(infini_rocm_copy_inside(r->handle(), ws + wArea, xptr, X->getBytes()));
+                    xptr = ws + wArea;
+                    ++r->bridgedCount;
+                    if (lg)
+                        fprintf(stderr, "[fusion] conv#%zu: input bridged through the workspace (%zu bytes)\n", idx, (size_t)X->getBytes());
                 }
-                ~VariantScope() {
-                    if (set)
-                        (void)infini_rocm_conv2d_set_variant(rt, -1);
-                }
-            } scope(rt, tunedVariant(op));
-            ConstWeightsScope constWeights(rt, w); // graph weights: pack once, cache (rocm_runtime.h)
-            ROCM_CALL(infini_rocm_conv2d_res(rt, x->getDTypeIndex(), xptr, w->getRawDataPtr<void *>(),
-                                             c.bias ? c.bias->getRawDataPtr<void *>() : nullptr,
-                                             c.res ? c.res->getRawDataPtr<void *>() : nullptr, c.last->getRawDataPtr<void *>(),
-                                             n, ch, h, wd, ff, r, s, ph, pw, sh, sw, dh, dw, conv->getNumGroups(), c.act));
-            return c.used;
+                // a tuned Conv (h.tune(): ConvRocm::tune) keeps its kernel choice when the tail is folded into it
+                struct VariantScope {
+                    infiniRocmRuntime_t rt;
+                    bool set;
+                    VariantScope(infiniRocmRuntime_t rt, int v) : rt(rt), set(v >= 0) {
+                        if (set)
+                            ROCM_CALL(infini_rocm_conv2d_set_variant(rt, v));
+                    }
+                    ~VariantScope() {
+                        if (set)
+                            (void)infini_rocm_conv2d_set_variant(rt, -1);
+                    }
+                } scope(r->handle(), variant);
+                ConstWeightsScope constWeights(r->handle(), Wt); // graph weights: pack once, cache (rocm_runtime.h)
+                ROCM_CALL(infini_rocm_conv2d_res(r->handle(), X->getDTypeIndex(), xptr, Wt->getRawDataPtr<void *>(),
+                                                 Bs ? Bs->getRawDataPtr<void *>() : nullptr, Rs ? Rs->getRawDataPtr<void *>() : nullptr,
+                                                 Out->getRawDataPtr<void *>(), n_, c_, h_, w_, f_, r_, s_, ph_, pw_, sh_, sw_, dh_, dw_, groups,
+                                                 act));
+            });
+            return true;
         }
-        return 0;
+        return false;
     }
+
+    // ============================================================================================================
+    // element-wise / normalisation pairs
+    // ============================================================================================================
     // Silu(a) -> Mul(., b): the gate of a gated MLP as one pass (infini_rocm_silu_mul; bit-identical: the Silu value is rounded
-    // as its own kernel would have stored it). Operators between the two that a grouped launch already ran (the up projection,
-    // rocm_fusion.cc::tryLaunchGroupedMatmul) are skipped over; b may be a result parked in the workspace by that launch.
-    if (type == OpType::Silu) {
-        static const bool swigluOn = !(std::getenv("INFINI_ROCM_FUSE_SWIGLU") && std::atoi(std::getenv("INFINI_ROCM_FUSE_SWIGLU")) == 0);
-        size_t m = i + 1;
-        while (m < ops.size() && launchedAhead[m])
-            ++m;
-        if (swigluOn && m < ops.size() && ops[m]->getOpType() == OpType::Mul && soleConsumerIs(op->getOutput(), ops[m])) {
-            const Tensor a = op->getInputs(0), sOut = op->getOutput(), out = ops[m]->getOutput();
-            const Tensor m0 = ops[m]->getInputs(0), m1 = ops[m]->getInputs(1);
-            const Tensor b = m0 == sOut ? m1 : m0;
-            const int dt = a->getDTypeIndex();
-            auto safe = [&](const Tensor &u) { // element-wise: exactly in place is fine, a partial overlap is not
-                return !overlaps(out, u) || (u->getRawDataPtr<void *>() == out->getRawDataPtr<void *>() && u->getDims() == out->getDims());
-            };
-            const void *bp = b->getRawDataPtr<void *>();
-            auto pf = parkedFeeds.find(m);
-            const bool bParked = pf != parkedFeeds.end() && pf->second.tensor == b.get();
-            if (bParked)
-                bp = pf->second.ptr;
-            if (b != sOut && (m0 == sOut) != (m1 == sOut) && (dt == INFINI_DT_F16 || dt == INFINI_DT_BF16 || dt == INFINI_DT_F32) &&
-                a->getDims() == out->getDims() && b->getDims() == out->getDims() && b->getDType() == a->getDType() &&
-                out->getDType() == a->getDType() && safe(a) && (bParked || safe(b)) &&
-                (((uintptr_t)a->getRawDataPtr<void *>() | (uintptr_t)bp | (uintptr_t)out->getRawDataPtr<void *>()) & 15) == 0 &&
-                (pf == parkedFeeds.end() || bParked)) {
-                ROCM_CALL(infini_rocm_silu_mul(rt, dt, a->getRawDataPtr<void *>(), bp, out->getRawDataPtr<void *>(), (int64_t)out->size()));
-                if (bParked)
-                    parkedFeeds.erase(pf);
-                return m - i + 1; // everything in between already ran
-            }
-        }
+    // as its own kernel would have stored it). Operators between the two that a grouped launch already ran (the up projection)
+    // are simply not in the way; b may be a result parked in the workspace by that launch.
+    bool planSiluMul(size_t i) {
+        static const bool on = envOn("INFINI_ROCM_FUSE_SWIGLU");
+        const Operator op = ops[i];
+        Operator mul = on ? userOfType(op->getOutput(), OpType::Mul, i) : nullptr;
+        if (!mul)
+            return false;
+        const size_t m = pos(mul);
+        const Tensor a = op->getInputs(0), sOut = op->getOutput(), out = mul->getOutput();
+        if (!usesOnce(mul, sOut))
+            return false;
+        const Tensor b = otherOf(mul, sOut);
+        const int dt = a->getDTypeIndex();
+        auto safe = [&](const Tensor &u) { return !overlaps(out, u) || samePlace(u, out); }; // element-wise: exactly in place is fine
+        auto pf = parked.find(m);
+        const bool bParked = pf != parked.end() && pf->second.tensor == b.get();
+        if (pf != parked.end() && !bParked)
+            return false;
+        if (!(b != sOut && (isHalf(dt) || dt == INFINI_DT_F32) && a->getDims() == out->getDims() && b->getDims() == out->getDims() &&
+              b->getDType() == a->getDType() && out->getDType() == a->getDType() && safe(a) && (bParked || safe(b)) &&
+              al16(addrOf(a) | addrOf(out) | (bParked ? 0 : addrOf(b)))))
+            return false;
+        std::vector<size_t> members{i, m};
+        std::vector<Read> reads{{a, i}};
+        if (!readsSurvive(reads, m, members))
+            return false;
+        noteLateReads(reads, m);
+        const RocmRuntimeObj *r = R;
+        const size_t pbytes = bParked ? pf->second.bytes : 0;
+        if (bParked)
+            parked.erase(pf);
+        emit(m, members, bParked ? "silu_mul(parked b)" : "silu_mul", true, [r, a, b, out, dt, bParked, pbytes] {
+            const void *bp = bParked ? r->getWorkspace(pbytes) : b->getRawDataPtr<void *>();
+            ROCM_CALL(infini_rocm_silu_mul(r->handle(), dt, a->getRawDataPtr<void *>(), bp, out->getRawDataPtr<void *>(), (int64_t)out->size()));
+        });
+        return true;
     }
+
     // Relu -> MaxPool: max and relu commute (bit-identical); the stem of every ResNet
-    if (type == OpType::Relu && i + 1 < ops.size() && ops[i + 1]->getOpType() == OpType::MaxPool &&
-        soleConsumerIs(op->getOutput(), ops[i + 1])) {
-        auto pool = as<PoolingObj>(ops[i + 1]);
+    bool planReluPool(size_t i) {
+        const Operator op = ops[i];
+        Operator pl = userOfType(op->getOutput(), OpType::MaxPool, i);
+        if (!pl)
+            return false;
+        auto pool = as<PoolingObj>(pl);
         const Tensor x = op->getInputs(0), out = pool->getOutput();
-        if (!overlaps(out, x)) {
-            const auto [n, c, h, w, kh, kw] = pool->getNCHWRS();
-            const auto [ph, pw, sh, sw, dh, dw] = pool->getPadStrideDilation();
-            ROCM_CALL(infini_rocm_pool2d_relu(rt, 0, x->getDTypeIndex(), x->getRawDataPtr<void *>(), out->getRawDataPtr<void *>(),
-                                              n, c, h, w, kh, kw, dh, dw, ph, pw, sh, sw, pool->getCeilMode(), 1));
-            return 2;
-        }
+        std::vector<size_t> members{i, pos(pl)};
+        if (overlaps(out, x) || !readsSurvive({{x, i}}, pos(pl), members))
+            return false;
+        noteLateReads({{x, i}}, pos(pl));
+        const auto [nb, c, h, w, kh, kw] = pool->getNCHWRS();
+        const auto [ph, pw, sh, sw, dh, dw] = pool->getPadStrideDilation();
+        const int ceil = pool->getCeilMode();
+        const RocmRuntimeObj *r = R;
+        const int n_ = nb, c_ = c, h_ = h, w_ = w, kh_ = kh, kw_ = kw, ph_ = ph, pw_ = pw, sh_ = sh, sw_ = sw, dh_ = dh, dw_ = dw;
+        emit(pos(pl), members, "relu+maxpool", true, [=] {
+            ROCM_CALL(infini_rocm_pool2d_relu(r->handle(), 0, x->getDTypeIndex(), x->getRawDataPtr<void *>(), out->getRawDataPtr<void *>(), n_,
+                                              c_, h_, w_, kh_, kw_, dh_, dw_, ph_, pw_, sh_, sw_, ceil, 1));
+        });
+        return true;
     }
-    // Add(a, b) (same extents) -> LayerNormalization over the last axis / RMSNorm: one pass
-    if (type == OpType::Add && i + 1 < ops.size() && soleConsumerIs(op->getOutput(), ops[i + 1]) &&
-        (ops[i + 1]->getOpType() == OpType::LayerNormalization || ops[i + 1]->getOpType() == OpType::RMSNorm)) {
-        const Operator &nrm = ops[i + 1];
-        const Tensor a = op->getInputs(0), b = op->getInputs(1), t = op->getOutput(), out = nrm->getOutput();
-        const auto &td = t->getDims();
-        const bool rms = nrm->getOpType() == OpType::RMSNorm;
-        bool ok = a->getDims() == td && b->getDims() == td && a->getDType() == b->getDType() && nrm->getInputs(0) == t;
+
+    // Add(a, b) (same extents) -> LayerNormalization over the last axis / RMSNorm / the nine-operator LayerNorm: one pass.
+    // Also Add(a, row bias) -> Add(., b) -> Norm: a linear layer's bias that could not ride in the GEMM epilogue (the
+    // memory planner likes to put the bias Add's output on the MatMul's dead A operand) joins the residual add and the
+    // normalisation instead (infini_rocm_bias_add_norm).
+    bool planAddNorm(size_t i) {
+        const Operator op = ops[i];
+        Tensor a = op->getInputs(0), b = op->getInputs(1), t = op->getOutput(), pre = nullptr;
+        const Shape td = t->getDims();
+        if (!(a->getDType() == b->getDType()) || t->isOutput() || td.empty())
+            return false;
+        std::vector<size_t> members{i};
+        std::vector<Read> reads;
+        size_t sumAt = i; // position of the Add whose result is normalised
+        if (!(a->getDims() == td && b->getDims() == td)) {
+            static const bool on = envOn("INFINI_ROCM_FUSE_BIAS_NORM");
+            const bool aRow = isRowVector(a->getDims(), td.back()), bRow = isRowVector(b->getDims(), td.back());
+            const Tensor full = aRow ? b : a, row = aRow ? a : b;
+            if (!on || aRow == bRow || full->getDims() != td || (int)td.size() < 2)
+                return false;
+            Operator add2 = userOfType(t, OpType::Add, i);
+            if (!add2)
+                return false;
+            const Tensor res = otherOf(add2, t);
+            if (res == t || res->getDims() != td || !(res->getDType() == t->getDType()) || add2->getOutput()->getDims() != td ||
+                add2->getOutput()->isOutput())
+                return false;
+            std::vector<size_t> dead;
+            const Tensor root = aliasRoot(row, dead);
+            pre = root ? root : row;
+            for (size_t dp : dead)
+                if (dp > i)
+                    members.push_back(dp);
+            if (!root)
+                reads.push_back({row, i});
+            members.push_back(pos(add2));
+            reads.push_back({full, i});
+            reads.push_back({res, pos(add2)});
+            a = full;
+            b = res;
+            t = add2->getOutput();
+            sumAt = pos(add2);
+        } else {
+            reads = {{a, i}, {b, i}};
+        }
+        Tensor scale, bias, out;
         float eps = 1e-5f; // RMSNorm: hard-coded in the reference (rms_norm.cu:46)
-        Tensor scale = nrm->getInputs(1), bias = nullptr;
-        if (ok && !rms) {
-            auto ln = as<LayerNormObj>(nrm);
-            ok = ln->getAxis() == (int)td.size() - 1;
-            eps = ln->getEps();
-            if (ln->numInputs() == 3)
-                bias = ln->getInputs(2);
-        }
-        if (ok) {
-            auto hazard = [&](const Tensor &u) { // row-wise in place over an operand of identical extent is safe
-                const bool inPlace = u->getRawDataPtr<void *>() == out->getRawDataPtr<void *>() && u->getDims() == td;
-                return overlaps(out, u) && !inPlace;
-            };
-            if (!hazard(a) && !hazard(b) && !overlaps(out, scale) && !(bias && overlaps(out, bias))) {
-                const int64_t n = td.back(), outer = (int64_t)t->size() / n;
-                ROCM_CALL(infini_rocm_add_norm(rt, t->getDTypeIndex(), rms ? 1 : 0, a->getRawDataPtr<void *>(),
-                                               b->getRawDataPtr<void *>(), scale->getRawDataPtr<void *>(),
-                                               bias ? bias->getRawDataPtr<void *>() : nullptr, out->getRawDataPtr<void *>(),
-                                               outer, n, (int64_t)scale->size(), bias ? (int64_t)bias->size() : 0, eps));
-                return 2;
+        bool rms = false;
+        size_t slot = sumAt;
+        std::string what = pre ? "bias+" : "";
+        Operator nrm = onlyUser(t);
+        if (nrm && pos(nrm) > sumAt && (nrm->getOpType() == OpType::LayerNormalization || nrm->getOpType() == OpType::RMSNorm) &&
+            nrm->getInputs(0) == t) {
+            rms = nrm->getOpType() == OpType::RMSNorm;
+            scale = nrm->getInputs(1);
+            if (!rms) {
+                auto ln = as<LayerNormObj>(nrm);
+                if (ln->getAxis() != (int)td.size() - 1)
+                    return false;
+                eps = ln->getEps();
+                if (ln->numInputs() == 3)
+                    bias = ln->getInputs(2);
             }
+            out = nrm->getOutput();
+            members.push_back(pos(nrm));
+            slot = pos(nrm);
+            what += rms ? "add+rmsnorm" : "add+layernorm";
+        } else {
+            NormMatch m;
+            if (!matchLayerNormDecomposed(t, m) || t->getTargets().size() != 2 || m.first < sumAt)
+                return false;
+            scale = m.gamma;
+            bias = m.beta;
+            eps = (float)m.eps;
+            out = m.out;
+            members.insert(members.end(), m.members.begin(), m.members.end());
+            slot = m.last;
+            what += "add+layernorm(decomposed)";
         }
+        std::sort(members.begin(), members.end());
+        auto hazard = [&](const Tensor &u) { return overlaps(out, u) && !samePlace(u, out); }; // row-wise in place is safe
+        if (hazard(a) || hazard(b) || overlaps(out, scale) || (bias && overlaps(out, bias)) || (pre && overlaps(out, pre)) ||
+            !(out->getDType() == t->getDType()))
+            return false;
+        if (!readsSurvive(reads, slot, members))
+            return false;
+        noteLateReads(reads, slot);
+        const int64_t nn = td.back(), outer = (int64_t)t->size() / nn;
+        const RocmRuntimeObj *r = R;
+        const int dt = t->getDTypeIndex();
+        emit(slot, members, what, true, [r, a, b, pre, scale, bias, out, outer, nn, eps, rms, dt] {
+            ROCM_CALL(infini_rocm_bias_add_norm(r->handle(), dt, rms ? 1 : 0, a->getRawDataPtr<void *>(),
+                                                pre ? pre->getRawDataPtr<void *>() : nullptr, b->getRawDataPtr<void *>(),
+                                                scale->getRawDataPtr<void *>(), bias ? bias->getRawDataPtr<void *>() : nullptr,
+                                                out->getRawDataPtr<void *>(), outer, nn, (int64_t)scale->size(),
+                                                bias ? (int64_t)bias->size() : 0, eps));
+        });
+        return true;
     }
+
     // Add(x, per-channel bias) -> Add(., identity) [-> Relu]: the bottleneck tail when the bias could not ride in the conv
-    if (type == OpType::Add && i + 1 < ops.size() && ops[i + 1]->getOpType() == OpType::Add &&
-        soleConsumerIs(op->getOutput(), ops[i + 1])) {
+    bool planBiasResidual(size_t i) {
+        const Operator op = ops[i];
         const Tensor t = op->getOutput();
         const Tensor a0 = op->getInputs(0), a1 = op->getInputs(1);
         const auto &td = t->getDims();
-        Tensor xin = nullptr, bias = nullptr;
-        if (td.size() >= 2 && isChannelBiasOf(a1, td) && a0->getDims() == td) { xin = a0; bias = a1; }
-        else if (td.size() >= 2 && isChannelBiasOf(a0, td) && a1->getDims() == td) { xin = a1; bias = a0; }
-        if (xin) {
-            const Operator &add2 = ops[i + 1];
-            const Tensor res = add2->getInputs(0) == t ? add2->getInputs(1) : add2->getInputs(0);
-            Tensor out = add2->getOutput();
-            size_t used = 2;
-            int relu = 0;
-            if (res != t && res->getDims() == td && res->getDType() == t->getDType() && bias->getDType() == t->getDType()) {
-                if (i + 2 < ops.size() && ops[i + 2]->getOpType() == OpType::Relu && soleConsumerIs(out, ops[i + 2])) {
-                    out = ops[i + 2]->getOutput();
-                    relu = 1;
-                    used = 3;
-                }
-                auto hazard = [&](const Tensor &u) {
-                    const bool inPlace = u->getRawDataPtr<void *>() == out->getRawDataPtr<void *>() && u->getDims() == td;
-                    return overlaps(out, u) && !inPlace;
-                };
-                if (!hazard(xin) && !hazard(res) && !overlaps(out, bias)) {
-                    int64_t inner = 1;
-                    for (size_t d = 2; d < td.size(); ++d)
-                        inner *= td[d];
-                    ROCM_CALL(infini_rocm_bias_residual(rt, t->getDTypeIndex(), xin->getRawDataPtr<void *>(),
-                                                        bias->getRawDataPtr<void *>(), res->getRawDataPtr<void *>(),
-                                                        out->getRawDataPtr<void *>(), td[0], td[1], inner, relu));
-                    return used;
-                }
-            }
+        Operator add2 = userOfType(t, OpType::Add, i);
+        if (!add2 || td.size() < 2)
+            return false;
+        Tensor xin = nullptr, biasT = nullptr;
+        if (isChannelBiasOf(a1->getDims(), td) && a0->getDims() == td) { xin = a0; biasT = a1; }
+        else if (isChannelBiasOf(a0->getDims(), td) && a1->getDims() == td) { xin = a1; biasT = a0; }
+        if (!xin)
+            return false;
+        std::vector<size_t> members{i}, dead;
+        const Tensor root = aliasRoot(biasT, dead);
+        const Tensor biasSrc = root ? root : biasT;
+        for (size_t dp : dead)
+            if (dp > i) // an alias operator in front of the chain's head already ran (or will): leave it alone
+                members.push_back(dp);
+        const Tensor res = otherOf(add2, t);
+        Tensor out = add2->getOutput();
+        members.push_back(pos(add2));
+        size_t slot = pos(add2);
+        int relu = 0;
+        if (!(res != t && res->getDims() == td && res->getDType() == t->getDType() && biasT->getDType() == t->getDType()))
+            return false;
+        if (Operator rl = userOfType(out, OpType::Relu, slot)) {
+            out = rl->getOutput();
+            relu = 1;
+            members.push_back(pos(rl));
+            slot = pos(rl);
         }
+        auto hazard = [&](const Tensor &u) { return overlaps(out, u) && !samePlace(u, out); };
+        if (hazard(xin) || hazard(res) || overlaps(out, biasSrc))
+            return false;
+        std::sort(members.begin(), members.end());
+        std::vector<Read> reads{{xin, i}, {res, pos(add2)}};
+        if (!root)
+            reads.push_back({biasT, i});
+        if (!readsSurvive(reads, slot, members))
+            return false;
+        noteLateReads(reads, slot);
+        int64_t inner = 1;
+        for (size_t d = 2; d < td.size(); ++d)
+            inner *= td[d];
+        const RocmRuntimeObj *r = R;
+        const int dt = t->getDTypeIndex();
+        const int64_t d0 = td[0], d1 = td[1];
+        emit(slot, members, relu ? "bias+res+relu" : "bias+res", true, [r, xin, biasSrc, res, out, d0, d1, inner, relu, dt] {
+            ROCM_CALL(infini_rocm_bias_residual(r->handle(), dt, xin->getRawDataPtr<void *>(), biasSrc->getRawDataPtr<void *>(),
+                                                res->getRawDataPtr<void *>(), out->getRawDataPtr<void *>(), d0, d1, inner, relu));
+        });
+        return true;
     }
-    if (type == OpType::Add && i + 1 < ops.size() && ops[i + 1]->getOpType() == OpType::Relu &&
-        soleConsumerIs(op->getOutput(), ops[i + 1])) {
-        const Tensor a = op->getInputs(0), b = op->getInputs(1), out = ops[i + 1]->getOutput();
-        const auto &od = op->getOutput()->getDims();
+
+    bool planAddRelu(size_t i) {
+        const Operator op = ops[i];
+        Operator rl = userOfType(op->getOutput(), OpType::Relu, i);
+        if (!rl)
+            return false;
+        const Tensor a = op->getInputs(0), b = op->getInputs(1), out = rl->getOutput();
+        const Shape od = op->getOutput()->getDims();
         // element-wise with identical extents may run exactly in place (the planner likes to give the Relu output the
         // storage of a dead Add input); any other overlap is a hazard
-        auto hazard = [&](const Tensor &t) {
-            const bool inPlace = t->getRawDataPtr<void *>() == out->getRawDataPtr<void *>() && t->getDims() == od;
-            return overlaps(out, t) && !inPlace;
-        };
+        auto hazard = [&](const Tensor &t) { return overlaps(out, t) && !(addrOf(t) == addrOf(out) && t->getDims() == od); };
         if (!(a->getDType() == b->getDType()) || hazard(a) || hazard(b))
-            return 0;
-        const auto shape = std::vector<int64_t>(od.begin(), od.end());
-        const auto sa = strides64(a->getDims(), od), sb = strides64(b->getDims(), od);
-        ROCM_CALL(infini_rocm_binary(rt, INFINI_BIN_ADD_RELU, a->getDTypeIndex(), a->getRawDataPtr<void *>(),
-                                     b->getRawDataPtr<void *>(), out->getRawDataPtr<void *>(), (int)shape.size(),
-                                     shape.data(), sa.data(), sb.data()));
-        return 2;
+            return false;
+        std::vector<size_t> members{i, pos(rl)};
+        std::vector<Read> reads{{a, i}, {b, i}};
+        if (!readsSurvive(reads, pos(rl), members))
+            return false;
+        noteLateReads(reads, pos(rl));
+        const RocmRuntimeObj *r = R;
+        emit(pos(rl), members, "add+relu", true, [r, a, b, out, od] {
+            const auto shape = std::vector<int64_t>(od.begin(), od.end());
+            const auto sa = strides64(a->getDims(), od), sb = strides64(b->getDims(), od);
+            ROCM_CALL(infini_rocm_binary(r->handle(), INFINI_BIN_ADD_RELU, a->getDTypeIndex(), a->getRawDataPtr<void *>(),
+                                         b->getRawDataPtr<void *>(), out->getRawDataPtr<void *>(), (int)shape.size(), shape.data(), sa.data(),
+                                         sb.data()));
+        });
+        return true;
     }
-    return 0;
+
+    // RoPE -> Reshape([B, S, H, D]) -> Transpose(0, 2, 1, 3): the rotary embedding of a decoder's q / k followed by their head split
+    // (rope.cu, reshape.cc, transpose.cc: three launches, two extra passes) as one pass with a head-split store
+    // (infini_rocm_rope_headsplit). Head dim 128 / theta 1e4 as the reference hard-codes them (rope.cc:25). The input may be a
+    // grouped MatMul's result parked in the workspace.
+    bool planRopeHeadSplit(size_t i, const ParkedFeed *pf) {
+        static const bool on = envOn("INFINI_ROCM_FUSE_ROPE_SPLIT");
+        if (!on)
+            return false;
+        const Operator op = ops[i];
+        const Tensor posT = op->getInputs(0), x = op->getInputs(1), y = op->getOutput();
+        Operator rs = userOfType(y, OpType::Reshape, i);
+        Operator tr = rs ? userOfType(rs->getOutput(), OpType::Transpose, pos(rs)) : nullptr;
+        if (!tr)
+            return false;
+        const Tensor r4 = rs->getOutput(), out = tr->getOutput();
+        const auto &xd = x->getDims(), &rd = r4->getDims();
+        if (xd.size() != 3 || rd.size() != 4 || !permIs(as<TransposeObj>(tr)->getPermute(), 0, 2, 1, 3) || rd[0] != xd[0] || rd[1] != xd[1] ||
+            rd[3] != 128 || (long)rd[2] * rd[3] != xd[2] || posT->getDims().size() != 2 || posT->getDims()[1] != xd[1] ||
+            !(out->getDType() == x->getDType()) || out->getBytes() != x->getBytes())
+            return false;
+        if (pf && pf->tensor != x.get())
+            return false;
+        if ((!pf && overlaps(out, x)) || overlaps(out, posT))
+            return false;
+        std::vector<size_t> members{i, pos(rs), pos(tr)};
+        const size_t slot = pos(tr);
+        std::vector<Read> reads{{posT, i}};
+        if (!pf)
+            reads.push_back({x, i});
+        else if (slot != i + 2)
+            return false; // the parked copy lives in the workspace: nothing may run in between
+        if (!readsSurvive(reads, slot, members))
+            return false;
+        noteLateReads(reads, slot);
+        const RocmRuntimeObj *r = R;
+        const bool isParked = pf != nullptr;
+        const size_t pbytes = pf ? pf->bytes : 0;
+        const int64_t rows = (int64_t)xd[0] * xd[1], width = xd[2], seq = xd[1];
+        if (pf)
+            parked.erase(i);
+        emit(slot, members, isParked ? "rope+headsplit(parked x)" : "rope+headsplit", true, [r, x, posT, out, rows, width, seq, isParked, pbytes] {
+            const void *xp = isParked ? r->getWorkspace(pbytes) : x->getRawDataPtr<void *>();
+            ROCM_CALL(infini_rocm_rope_headsplit(r->handle(), x->getDTypeIndex(), posT->getDTypeIndex(), posT->getRawDataPtr<void *>(), xp,
+                                                 out->getRawDataPtr<void *>(), rows, width, 128, 10000.0f, seq));
+        });
+        return true;
+    }
+
+    // producer -> Reshape | Flatten | Identity | Squeeze | Unsqueeze: the reference runs these as a device memcpy
+    // (CopyCuda, reshape.cc:4-21); here the producer writes straight into the copy's output buffer. The producer runs through
+    // its normal kernel (and perf record) with its output tensor redirected, so nothing about its numerics changes. A copy of
+    // a weight / graph input whose every reader was folded is handled by the readers (aliasRoot), not here.
+    bool planIntoCopy(size_t i) {
+        static const bool on = envOn("INFINI_ROCM_FUSE_RESHAPE");
+        const Operator op = ops[i];
+        const auto type = op->getOpType();
+        // producers whose kernels only WRITE their output (no in-place state, no multi-output, no collectives)
+        if (!on || !(type == OpType::MatMul || type == OpType::Transpose || type == OpType::Add || type == OpType::Sub || type == OpType::Mul ||
+                     type == OpType::Div || type == OpType::Relu || type == OpType::Gelu || type == OpType::Silu || type == OpType::Sigmoid ||
+                     type == OpType::Tanh || type == OpType::Softmax || type == OpType::LayerNormalization || type == OpType::RMSNorm ||
+                     type == OpType::Gather || type == OpType::RoPE))
+            return false;
+        if (op->numOutputs() != 1)
+            return false;
+        const Tensor mid = op->getOutput();
+        Operator next = onlyUser(mid);
+        if (!next || pos(next) <= i || !isCopyLike(next->getOpType()) || next->numOutputs() != 1 || next->getInputs(0) != mid)
+            return false;
+        const Tensor out = next->getOutput();
+        if (mid->getBytes() != out->getBytes() || !(mid->getDType() == out->getDType()))
+            return false;
+        std::vector<Read> reads;
+        for (const auto &in : op->getInputs()) {
+            if (overlaps(out, in)) // the producer would overwrite what it is still reading
+                return false;
+            reads.push_back({in, i});
+        }
+        std::vector<size_t> members{i, pos(next)};
+        if (!readsSurvive(reads, pos(next), members))
+            return false;
+        noteLateReads(reads, pos(next));
+        const RocmRuntimeObj *r = R;
+        emit(pos(next), members, ">reshape", true, [r, op, mid, out] {
+            OverrideScope s;
+            s.redirect(mid.get(), out->getRawDataPtr<void *>());
+            r->launchOne(op);
+        });
+        return true;
+    }
+};
+
+RocmRuntimeObj::LaunchPlan RocmRuntimeObj::buildPlan(const Graph &graph) const {
+    FusionPlanner planner(this, graph->getOperators(), fusion);
+    return planner.run();
+}
+
+std::vector<std::string> RocmRuntimeObj::describeFusionPlan(const Graph &graph) {
+    IT_ASSERT(graph != nullptr);
+    graph->validateMemory();
+    auto self = std::dynamic_pointer_cast<RocmRuntimeObj>(graph->getRuntime());
+    static const bool envFusion = !(std::getenv("INFINI_ROCM_FUSION") && std::string(std::getenv("INFINI_ROCM_FUSION")) == "0");
+    FusionPlanner planner(self.get(), graph->getOperators(), self ? self->fusion : envFusion);
+    std::vector<std::string> out;
+    for (const auto &it : planner.run()) {
+        std::string s = std::to_string(it.slot) + " " + (it.fused ? it.what : std::string("op")) + " [";
+        for (size_t q = 0; q < it.members.size(); ++q)
+            s += (q ? "," : "") + std::to_string(it.members[q]);
+        out.push_back(s + "]");
+    }
+    return out;
 }
 
 } // namespace infini

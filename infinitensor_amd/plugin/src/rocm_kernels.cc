@@ -62,8 +62,13 @@ static infiniRocmRuntime_t H(const RuntimeObj *ctx) {
 }
 static int DTI(const Tensor &t) { return t->getDTypeIndex(); }
 template <typename T = void> static T *P(const Tensor &t) {
-    if (t.get() == RocmRuntimeObj::redirectTensor) // producer -> Reshape fusion: write into the Reshape's output
-        return (T *)RocmRuntimeObj::redirectPtr;
+    // a planned launch may point a tensor somewhere else for this one call (RocmRuntimeObj::LaunchOverrides): a producer
+    // writing into a Reshape's output, an operand left in the workspace by the previous launch
+    const auto &ov = RocmRuntimeObj::overrides;
+    if (ov.tensor[0] && t.get() == ov.tensor[0])
+        return (T *)ov.ptr[0];
+    if (ov.tensor[1] && t.get() == ov.tensor[1])
+        return (T *)ov.ptr[1];
     return t->getRawDataPtr<T *>();
 }
 
@@ -182,16 +187,21 @@ class MatmulRocm : public RocmTunableKernel {
                 bsb = (int64_t)bt->getDims()[bt->getRank() - 2] * bt->getDims()[bt->getRank() - 1];
             }
         }
-        // `act` is ignored like in the reference CUDA kernel (matmul.cc never reads getAct())
-        // head-split store requested by the MatMul -> Reshape -> Transpose fusion for THIS op's output (rocm_fusion.cc)
-        const bool redirected = C.get() == RocmRuntimeObj::redirectTensor;
-        const bool split = redirected && RocmRuntimeObj::redirectHeadDim > 0;
-        // `act` of the operator is ignored like in the reference CUDA kernel; a fused Gelu arrives through the redirect
+        // `act` of the operator is ignored like in the reference CUDA kernel (matmul.cc never reads getAct()). What the
+        // launch plan folded into THIS MatMul arrives through the overrides (rocm_fusion.cc): the row bias of a following
+        // Add (onnx.py:280-290 imports MatMul without bias), a Gelu, a head-split store.
+        const auto &ov = RocmRuntimeObj::overrides;
+        const bool mine = ov.matmul == _op.get();
+        if (mine && ov.biasPtr) {
+            IT_ASSERT(bias == nullptr, "a bias was folded into a MatMul that has its own");
+            bias = ov.biasPtr;
+            bsb = bsm = 0;
+            bsn = 1;
+        }
+        const bool split = mine && ov.headDim > 0;
         ROCM_CALL(infini_rocm_matmul_headsplit(H(ctx), DTI(A), P(A), P(B), bias, P(C), b, m, n, k, op->getTransA(),
-                                               op->getTransB(), strideA, strideB, bsb, bsm, bsn,
-                                               redirected ? RocmRuntimeObj::redirectAct : 0,
-                                               split ? RocmRuntimeObj::redirectSeq : 0,
-                                               split ? RocmRuntimeObj::redirectHeadDim : 0));
+                                               op->getTransB(), strideA, strideB, bsb, bsm, bsn, mine ? ov.act : 0,
+                                               split ? ov.seq : 0, split ? ov.headDim : 0));
     }
 };
 REGISTER_KERNEL(Device::ROCM, OpType::MatMul, MatmulRocm, "Matmul_MFMA_ROCM");

@@ -7,21 +7,48 @@
 // (a std::map with a non-string key is an array of [key, value] pairs; a pair / tuple is an array).
 #include "rocm/rocm_perf.h"
 #include "core/perf_engine.h"
+#include "infini_rocm.h"
 #include <fstream>
 #include <sstream>
 
 namespace infini {
 
+// Variant numbers are an implementation detail of the library (they were renumbered between rounds): a record carries
+// the variant's NAME and is resolved by name on load. A record without a name (an older file), with an unknown name or —
+// for Conv, whose variants have no names — outside the current range falls back to the heuristic (-1) instead of making
+// every such operator throw at launch.
+static const char *kConvVariantNames[] = {"heuristic0", "generic", "conv_s1", "batched_gemm", "conv_s1_nopatch"};
+
+static std::string variantName(int recordType, int v) {
+    if (v < 0)
+        return "heuristic";
+    if (recordType == kRocmMatmulRecord)
+        return infini_rocm_matmul_variant_name(v);
+    return (v <= 4) ? kConvVariantNames[v] : "invalid";
+}
+
 void RocmVariantPerfRecordObj::to_json(json &j) {
     j["type"] = recordType;
-    j["data"] = json::array({variant, time});
+    j["data"] = json::array({json(variant), json(time), json(variantName(recordType, variant))});
 }
 
 PerfRecord RocmVariantPerfRecordObj::from_json(const json &j) {
     auto r = make_ref<RocmVariantPerfRecordObj>();
     r->recordType = j["type"].get<int>();
-    r->variant = j["data"][0].get<int>();
     r->time = j["data"][1].get<double>();
+    r->variant = -1;
+    if (j["data"].size() >= 3) {
+        const std::string name = j["data"][2].get<std::string>();
+        for (int v = 0; v < 64; ++v) {
+            const std::string cand = variantName(r->recordType, v);
+            if (cand == "invalid")
+                break;
+            if (cand == name) {
+                r->variant = v;
+                break;
+            }
+        }
+    }
     return r;
 }
 

@@ -58,11 +58,34 @@ void RocmRuntimeObj::dropCapturesIfWeightsChanged(uint64_t epochBefore) const {
     auto *self = const_cast<RocmRuntimeObj *>(this);
     std::lock_guard<std::recursive_mutex> cacheLock(cacheMutex);
     self->cache.clear();
+    // no graph exec of this runtime is alive any more: the dropped image (and outgrown scratch blocks) can be freed now —
+    // a workload that re-uploads a weight every run would otherwise retire one image per run until the device is full
+    (void)infini_rocm_workspace_trim(rt);
+}
+bool RocmRuntimeObj::forgetScalars(const void *ptr, size_t bytes) const {
+    if (scalarCache.empty())
+        return false;
+    bool any = false;
+    const char *lo = (const char *)ptr, *hi = lo + bytes;
+    for (auto it = scalarCache.begin(); it != scalarCache.end();) {
+        const char *p = (const char *)it->first;
+        if (p < hi && lo < p + it->second.first) {
+            it = scalarCache.erase(it);
+            any = true;
+        } else {
+            ++it;
+        }
+    }
+    return any;
 }
 void RocmRuntimeObj::copyBlobFromCPU(void *dst, const void *src, size_t bytes) const {
     const uint64_t e0 = weightEpoch(rt);
     ROCM_CALL(infini_rocm_copy_from_cpu(rt, dst, src, bytes));
     dropCapturesIfWeightsChanged(e0);
+    if (forgetScalars(dst, bytes)) { // a constant a launch plan was decided on (Pow's exponent, a Gelu's sqrt 2): re-plan
+        std::lock_guard<std::recursive_mutex> cacheLock(cacheMutex);
+        const_cast<RocmRuntimeObj *>(this)->cache.clear();
+    }
 }
 void RocmRuntimeObj::copyBlobToCPU(void *dst, const void *src, size_t bytes) const {
     ROCM_CALL(infini_rocm_copy_to_cpu(rt, dst, src, bytes));
@@ -71,6 +94,10 @@ void RocmRuntimeObj::copyBlobInsideRuntime(void *dst, const void *src, size_t by
     const uint64_t e0 = weightEpoch(rt);
     ROCM_CALL(infini_rocm_copy_inside(rt, dst, src, bytes));
     dropCapturesIfWeightsChanged(e0);
+    if (forgetScalars(dst, bytes)) {
+        std::lock_guard<std::recursive_mutex> cacheLock(cacheMutex);
+        const_cast<RocmRuntimeObj *>(this)->cache.clear();
+    }
     ROCM_CALL(infini_rocm_runtime_sync(rt)); // reference semantics: cudaMemcpy D2D is synchronous
 }
 void *RocmRuntimeObj::getWorkspace(size_t size) const {
@@ -99,44 +126,27 @@ CommunicatorObj &RocmRuntimeObj::getCommunicator() const {
     return *comm;
 }
 
-// ---- the hot loop: one Kernel::compute per operator, asynchronously on the runtime stream -------
+// ---- the hot loop: the launch plan (rocm_fusion.cc), item by item, asynchronously on the runtime stream -----
 void RocmRuntimeObj::launchAll(const Graph &graph, bool validate) const {
     IT_ASSERT(graph != nullptr, "Cannot run a null graph");
     if (validate)
         graph->validateMemory();
-    const OpVec &ops = graph->getOperators();
-    launchedAhead.assign(ops.size(), 0);
-    parkedFeeds.clear();
-    for (size_t i = 0; i < ops.size(); ++i) {
-        const Operator &op = ops[i];
-        if (launchedAhead[i]) // ran as a member of an earlier grouped launch (rocm_fusion.cc::tryLaunchGroupedMatmul)
+    executePlan(buildPlan(graph), graph->getOperators());
+}
+
+void RocmRuntimeObj::executePlan(const LaunchPlan &plan, const OpVec &ops) const {
+    for (const auto &item : plan) {
+        if (!item.run)
             continue;
-        if (auto it = parkedFeeds.find(i); it != parkedFeeds.end()) { // reads a parked group result
-            if (fusion) { // the one rule that knows about parked operands itself
-                if (const size_t used = tryLaunchRopeHeadSplit(ops, i)) {
-                    ++fusedCount;
-                    i += used - 1;
-                    continue;
-                }
-            }
-            launchWithInputRedirect(op, it->second.tensor, it->second.ptr); // plain launch, input redirected
-            continue;
+        try {
+            item.run();
+        } catch (Exception &e) {
+            if (item.fused)
+                e << " while launching (fused: " << item.what << ") " << ops[item.members.front()]->toString();
+            throw;
         }
-        if (fusion) {
-            size_t fused = 0;
-            try {
-                fused = tryLaunchFused(ops, i);
-            } catch (Exception &e) {
-                e << " while launching (fused) " << op->toString();
-                throw;
-            }
-            if (fused) {
-                ++fusedCount;
-                i += fused - 1;
-                continue;
-            }
-        }
-        launchOne(op);
+        if (item.fused)
+            ++fusedCount;
     }
 }
 
@@ -155,12 +165,6 @@ void RocmRuntimeObj::launchOne(const Operator &op) const {
         throw;
     }
 }
-
-thread_local const TensorObj *RocmRuntimeObj::redirectTensor = nullptr;
-thread_local void *RocmRuntimeObj::redirectPtr = nullptr;
-thread_local int RocmRuntimeObj::redirectSeq = 0;
-thread_local int RocmRuntimeObj::redirectHeadDim = 0;
-thread_local int RocmRuntimeObj::redirectAct = 0;
 
 void RocmRuntimeObj::runWithoutSync(const Graph &graph) const {
     std::lock_guard<std::recursive_mutex> lock(executionMutex);
@@ -284,12 +288,15 @@ void RocmRuntimeObj::runWithHipGraph(const Graph &graph) {
     // fails AND the workspace block changed during it (a HIP build that refuses allocation under capture) is the
     // capture repeated once, now with a workspace that is large enough; launches recorded into an aborted capture
     // never execute.
+    // The plan is made BEFORE the stream records: the planner may read one-element constants back from the device
+    // (a decomposed Gelu's sqrt 2, LayerNorm's epsilon), which a recording stream cannot serve.
+    const LaunchPlan plan = buildPlan(graph);
     for (int attempt = 0;; ++attempt) {
         uint64_t epochBefore = 0, epochAfter = 0;
         ROCM_CALL(infini_rocm_workspace_info(rt, nullptr, nullptr, &epochBefore));
         ROCM_CALL(infini_rocm_graph_begin_capture(rt));
         try {
-            launchAll(graph, false);
+            executePlan(plan, graph->getOperators());
             ROCM_CALL(infini_rocm_graph_end_capture(rt, &entry->graph));
             break;
         } catch (...) {

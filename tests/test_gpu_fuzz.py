@@ -42,3 +42,10 @@ def test_fusion_rules_are_bit_identical_on_random_graphs():
 def test_conv_fusion_agrees_on_random_resnet_blocks():
     pytest.importorskip("conftest").load_backend_module() or pytest.skip("plugin build missing")
     assert "16/16 graphs agree" in _run("conv_fusion_fuzz.py", ["16"])
+
+
+def test_onnx_form_transformer_blocks_agree_with_planning_on_and_off():
+    """Transformer blocks in the form and operator order the ONNX front-end emits (MatMul -> Add(bias), interleaved q / k / v,
+    Transpose(K), decomposed LayerNorm / Gelu): launch planning on == off within 16-bit rounding, both == the fp64 oracle."""
+    pytest.importorskip("conftest").load_backend_module() or pytest.skip("plugin build missing")
+    assert "24/24 graphs agree" in _run("onnx_form_fuzz.py", ["24"])

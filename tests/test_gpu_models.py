@@ -50,20 +50,28 @@ def test_resnet50_logits_match_the_reference_cpu_backend(plugin_backend):
         rocm.set_fusion(True)
 
 
-def _bert_oracle(feeds, batch, seq, layers, hidden, heads):
+LOWERINGS = {"onnx": {}, "onnx-merged-kt": {"merged_kt": True}, "onnx-decomposed": {"decomposed": True}, "idealised": {"frontend": False}}
+
+
+def _bert_oracle(feeds, batch, seq, layers, hidden, heads, decomposed=False):
     """fp64 restatement of tools/model_bench.py::build_bert over the very arrays fed to the graph (in creation
-    order), written with the pinned oracle ops (oracle/ref_ops.py)."""
+    order), written with the pinned oracle ops (oracle/ref_ops.py). Every lowering of the builder computes this function."""
     from oracle import ref_ops as R
 
     it = iter([np.asarray(a) for _, a in feeds])
     nxt = lambda: next(it).astype(np.float64)
     ids = next(it)
     emb, pos, mask, scale = nxt(), nxt(), nxt(), nxt()
+    eps = 1e-12
+    if decomposed:  # the constants of the primitive-operator forms: 2, 1, 0.5, sqrt 2, epsilon (as stored)
+        two, one, half, sqrt2, epsa = nxt(), nxt(), nxt(), nxt(), nxt()
+        assert two[0] == 2 and one[0] == 1 and half[0] == 0.5 and abs(sqrt2[0] - 2 ** 0.5) < 1e-3
+        eps = float(epsa[0])
     D = hidden // heads
 
     def ln(t):
         g, b = nxt(), nxt()
-        return R.layer_norm(t, g, b, 1e-12, 2)
+        return R.layer_norm(t, g, b, eps, 2)
 
     def linear(t):
         w, b = nxt(), nxt()
@@ -81,12 +89,15 @@ def _bert_oracle(feeds, batch, seq, layers, hidden, heads):
     return x
 
 
+@pytest.mark.parametrize("lowering", list(LOWERINGS))
 @pytest.mark.parametrize("dtype,tol", [("f32", 1e-4), ("f16", 3e-2)])
-def test_bert_encoder_end_to_end_vs_oracle(plugin_backend, dtype, tol):
+def test_bert_encoder_end_to_end_vs_oracle(plugin_backend, dtype, tol, lowering):
     """BASELINE config 4 on a small slice: embedding Gather (int64 ids) -> LayerNorm -> 2 encoder layers with the
     decomposed attention chain (key-padding mask), Gelu FFN and residual LayerNorms, through the reference executor on
-    Device::ROCM — fused launches (attention, Add->LayerNorm), one kernel per operator, and hipGraph replay — against
-    the fp64 oracle. fp32: 1e-4 of the output scale (north_star); f16: storage rounding through 2 layers."""
+    Device::ROCM — planned launches, one kernel per operator, and hipGraph replay — against the fp64 oracle, in every
+    lowering: the form and operator order pyinfinitensor/onnx.py emits (MatMul + Add(bias), Transpose(K), q reshaped after
+    k / v), the same with K's transposes merged, with LayerNorm / Gelu decomposed into opset < 17 primitives, and the
+    idealised round-1/2 form. fp32: 1e-4 of the output scale (north_star); f16: storage rounding through 2 layers."""
     from model_bench import Builder, build_bert
 
     B = plugin_backend
@@ -98,7 +109,7 @@ def test_bert_encoder_end_to_end_vs_oracle(plugin_backend, dtype, tol):
         for mode in ("fused", "unfused", "hipgraph"):
             rocm.set_fusion(mode != "unfused")
             bl = Builder(B, rocm, dtype, seed=3)
-            out = build_bert(bl, batch, seq, layers, hidden, heads, ffn, vocab)
+            out = build_bert(bl, batch, seq, layers, hidden, heads, ffn, vocab, **LOWERINGS[lowering])
             # key-padding mask: the last 17 keys of sequence 1 are masked out (additive -1e4 as exported BERT graphs do)
             m = np.zeros((batch, 1, 1, seq), bl.np)
             m[1, 0, 0, -17:] = -1e4
@@ -118,9 +129,13 @@ def test_bert_encoder_end_to_end_vs_oracle(plugin_backend, dtype, tol):
                 # grouped launch for q, k, v in f16 / bf16 when the planner's layout allows it
                 floor = (4 if dtype == "f16" else 5) * layers
                 assert (fused >= floor) if mode == "fused" else (fused == 0), (mode, fused)
+                if mode == "fused":  # no operator of an encoder layer is left to run alone except (fp32) Gelu / the attention chain
+                    plan = bl.h.rocm_fusion_plan()
+                    alone = sum(1 for p in plan if " op [" in p)
+                    assert alone <= (5 + layers * 2 if dtype == "f16" else 5 + layers * 10), (alone, plan)
             results[mode] = out.copyout_numpy().astype(np.float64).reshape(batch, seq, hidden)
             if want is None:
-                want = _bert_oracle(bl.feeds, batch, seq, layers, hidden, heads)
+                want = _bert_oracle(bl.feeds, batch, seq, layers, hidden, heads, decomposed="decomposed" in lowering)
     finally:
         rocm.set_fusion(True)
     scale = np.abs(want).max()
@@ -130,8 +145,9 @@ def test_bert_encoder_end_to_end_vs_oracle(plugin_backend, dtype, tol):
     assert np.array_equal(results["fused"], results["hipgraph"])
 
 
+@pytest.mark.parametrize("kt", ["transpose", "transB"])
 @pytest.mark.parametrize("dtype,tol", [("f32", 1e-4), ("f16", 3e-2)])
-def test_llama_block_through_reference_executor_vs_oracle(plugin_backend, dtype, tol):
+def test_llama_block_through_reference_executor_vs_oracle(plugin_backend, dtype, tol, kt):
     """BASELINE config 5 at TP = 1 on a small slice, through the reference executor on Device::ROCM: RMSNorm -> q/k/v
     MatMul -> RoPE -> head split -> causal attention chain -> o_proj -> AllReduceSum (1-rank RCCL communicator, the
     operator parallel_opt.py inserts) -> residual -> RMSNorm -> gate/up/SiLU/Mul -> down -> AllReduceSum -> residual,
@@ -153,7 +169,7 @@ def test_llama_block_through_reference_executor_vs_oracle(plugin_backend, dtype,
     causal = np.triu(np.full((S, S), -1e4, npdt), 1).reshape(1, 1, S, S)
     sc = np.array([np.sqrt(D)], npdt)
     rocm = B.RocmRuntime(0)
-    rocm.init_comm("llama_block_test_" + dtype, 1, 0)
+    rocm.init_comm("llama_block_test_" + dtype + kt, 1, 0)
     h = B.GraphHandler(rocm)
     lin = B.ActType.Linear
     feeds = []
@@ -170,7 +186,11 @@ def test_llama_block_through_reference_executor_vs_oracle(plugin_backend, dtype,
     heads = lambda t: h.transpose(h.reshape(t, None, [Bt, S, NH, D]), None, [0, 2, 1, 3])
     q, k = heads(h.RoPE(tpos, mm(hn, W["q"]), None)), heads(h.RoPE(tpos, mm(hn, W["k"]), None))
     v = heads(mm(hn, W["v"]))
-    s = h.add(h.div(h.matmul(q, k, None, False, True, None, lin, "default"), tsc, None), tmask, None)
+    if kt == "transpose":  # Q.K^T as the ONNX front-end imports it: Transpose(K) -> MatMul (onnx.py:280-290: no transB)
+        qk = h.matmul(q, h.transpose(k, None, [0, 1, 3, 2]), None, False, False, None, lin, "default")
+    else:
+        qk = h.matmul(q, k, None, False, True, None, lin, "default")
+    s = h.add(h.div(qk, tsc, None), tmask, None)
     ctx = h.matmul(h.softmax(s, None, 3), v, None, False, False, None, lin, "default")
     ctx = h.reshape(h.transpose(ctx, None, [0, 2, 1, 3]), None, [Bt, S, H])
     x1 = h.add(tx, h.allReduceSum(mm(ctx, W["o"]), None), None)
@@ -281,19 +301,20 @@ def test_bert_base_one_full_width_layer_vs_oracle(plugin_backend):
     B = plugin_backend
     batch, seq, layers, hidden, heads, ffn, vocab = 1, 512, 1, 768, 12, 3072, 2000
     rocm = B.RocmRuntime(0)
-    for dtype, tol in (("f16", 3e-2), ("f32", 1e-4)):
-        bl = Builder(B, rocm, dtype, seed=5)
-        out = build_bert(bl, batch, seq, layers, hidden, heads, ffn, vocab)
-        m = np.zeros((batch, 1, 1, seq), bl.np)
-        m[0, 0, 0, -40:] = -1e4
-        bl.feeds[3] = (bl.feeds[3][0], m)
-        bl.finish()
-        bl.h.run()
-        got = out.copyout_numpy().astype(np.float64).reshape(batch, seq, hidden)
-        want = _bert_oracle(bl.feeds, batch, seq, layers, hidden, heads)
-        scale = np.abs(want).max()
-        assert np.isfinite(got).all()
-        assert np.abs(got - want).max() <= tol * scale, (dtype, np.abs(got - want).max(), scale)
+    for lowering in ("onnx", "onnx-decomposed"):
+        for dtype, tol in (("f16", 3e-2), ("f32", 1e-4)):
+            bl = Builder(B, rocm, dtype, seed=5)
+            out = build_bert(bl, batch, seq, layers, hidden, heads, ffn, vocab, **LOWERINGS[lowering])
+            m = np.zeros((batch, 1, 1, seq), bl.np)
+            m[0, 0, 0, -40:] = -1e4
+            bl.feeds[3] = (bl.feeds[3][0], m)
+            bl.finish()
+            bl.h.run()
+            got = out.copyout_numpy().astype(np.float64).reshape(batch, seq, hidden)
+            want = _bert_oracle(bl.feeds, batch, seq, layers, hidden, heads, decomposed="decomposed" in lowering)
+            scale = np.abs(want).max()
+            assert np.isfinite(got).all()
+            assert np.abs(got - want).max() <= tol * scale, (lowering, dtype, np.abs(got - want).max(), scale)
 
 
 @pytest.mark.parametrize("layer", ["stem", "bottleneck56"])

@@ -19,9 +19,12 @@ def B(plugin_backend):
     return plugin_backend
 
 
+PLAN_ONLY = bool(__import__("os").environ.get("IROCM_TEST_PLAN_ONLY"))  # debugging aid: print the launch plans on a GPU-less box
+
+
 @pytest.fixture(scope="module")
 def rocm(B):
-    return B.RocmRuntime(0)
+    return None if PLAN_ONLY else B.RocmRuntime(0)
 
 
 def put(t, a):
@@ -1177,3 +1180,264 @@ def test_lrn_through_reference_executor(B, rocm, code, npdt, tol):
         h.run()
         want = R.lrn(x.astype(np.float64), size, alpha, beta, bias)
         assert np.allclose(get(out).astype(np.float64).reshape(want.shape), want, rtol=tol, atol=tol), (size, alpha)
+
+
+# ---- the chains in the form the ONNX front-end emits them (pyinfinitensor/onnx.py) -----------------------------------------
+def _on_off(B, rocm, fn, ins, hipgraph=False):
+    """Runs the graph with launch planning on and off; returns ({on: output as fp64}, {on: fused launches}, plan lines)."""
+    got, fused, plan = {}, {}, None
+    if PLAN_ONLY:
+        h, _ = build(B, B.cpu_runtime(), fn, ins)
+        print("\n".join(h.rocm_fusion_plan()))
+        pytest.skip("plan only")
+    try:
+        for on in (True, False):
+            rocm.set_fusion(on)
+            h, out = build(B, rocm, fn, ins)
+            if on:
+                plan = h.rocm_fusion_plan()
+            before = rocm.fused_launch_count()
+            if hipgraph:
+                h.run_with_hipgraph()
+            else:
+                h.run()
+            fused[on] = rocm.fused_launch_count() - before
+            got[on] = get(out).astype(np.float64)
+    finally:
+        rocm.set_fusion(True)
+    return got, fused, plan
+
+
+def _weights(t):
+    t[0].set_input()  # the graph input: never recycled by the memory planner (graph.cc dataMalloc)
+    for x in t[1:]:   # everything else is an initializer of the ONNX graph
+        x.set_weight()
+
+
+@pytest.mark.parametrize("code,npdt,tol", [(F32, np.float32, 1e-4), (F16, np.float16, 4e-3)])
+def test_front_end_conv_bias_reshape_chain_is_one_launch(B, rocm, code, npdt, tol):
+    """onnx.py:159-190 lowers a Conv with bias to conv -> reshape(bias, [1, F, 1, 1]) -> add; the operator order is
+    [Conv, Reshape, Add, Relu]. Planned as ONE launch (the Reshape of a weight is not launched: the epilogue reads the
+    weight), equal to the four-kernel run and to the oracle."""
+    rng = np.random.default_rng(41)
+    c, f = 32, 48
+    ins = [((2, c, 10, 12), code, rng.standard_normal((2, c, 10, 12)).astype(npdt)),
+           ((f, c, 3, 3), code, (rng.standard_normal((f, c, 3, 3)) / 17).astype(npdt)),
+           ((f,), code, rng.standard_normal((f,)).astype(npdt))]
+
+    def fn(h, t):
+        _weights(t)
+        y = h.conv(t[0], t[1], None, 1, 1, 1, 1, 1, 1)
+        return h.relu(h.add(y, h.reshape(t[2], None, [1, f, 1, 1]), None), None)
+
+    got, fused, plan = _on_off(B, rocm, fn, ins)
+    assert fused == {True: 1, False: 0} and plan == ["3 conv+bias+relu [0,1,2,3]"], (fused, plan)
+    x, w, b = (a.astype(np.float64) for _, _, a in ins)
+    want = np.maximum(R.conv2d(x, w, 1, 1, 1, 1, 1, 1) + b.reshape(1, f, 1, 1), 0).reshape(got[True].shape)
+    if code == F32:
+        assert np.array_equal(got[True], got[False])
+    for on in (True, False):
+        assert np.allclose(got[on], want, rtol=tol, atol=tol), (on, np.abs(got[on] - want).max())
+
+
+@pytest.mark.parametrize("bias_first", [True, False])
+@pytest.mark.parametrize("tail", ["none", "gelu", "gelu5", "headsplit", "reshape"])
+def test_front_end_matmul_add_bias_chains(B, rocm, bias_first, tail):
+    """onnx.py:280-290 imports MatMul with no bias: a linear layer is MatMul -> Add(bias) (the exporter puts the bias first).
+    The Add folds into the GEMM epilogue, and with it whatever follows: Gelu (one operator or the five-operator opset < 20
+    form), the Reshape -> Transpose head split, a Reshape. One launch each; within f16 rounding of the per-operator run and
+    of the fp64 oracle (the fused GEMM rounds once where the chain rounds after every operator)."""
+    rng = np.random.default_rng(42)
+    Bt, S, NH, D, K = 2, 128, 2, 64, 192
+    N = NH * D
+    ins = [((Bt, S, K), F16, rng.standard_normal((Bt, S, K)).astype(np.float16)),
+           ((K, N), F16, (rng.standard_normal((K, N)) / 8).astype(np.float16)),
+           ((N,), F16, rng.standard_normal((N,)).astype(np.float16)),
+           ((1,), F16, np.array([np.sqrt(2.0)], np.float16)), ((1,), F16, np.array([1.0], np.float16)),
+           ((1,), F16, np.array([0.5], np.float16))]
+
+    def fn(h, t):
+        _weights(t)
+        mm = h.matmul(t[0], t[1], None, False, False, None, B.ActType.Linear, "default")
+        y = h.add(t[2], mm, None) if bias_first else h.add(mm, t[2], None)
+        if tail == "gelu":
+            y = h.gelu(y, None)
+        elif tail == "gelu5":
+            y = h.mul(h.mul(y, h.add(h.erf(h.div(y, t[3], None), None), t[4], None), None), t[5], None)
+        elif tail == "headsplit":
+            y = h.transpose(h.reshape(y, None, [Bt, S, NH, D]), None, [0, 2, 1, 3])
+        elif tail == "reshape":
+            y = h.reshape(y, None, [Bt * S, N])
+        return y
+
+    got, fused, plan = _on_off(B, rocm, fn, ins)
+    assert fused == {True: 1, False: 0}, (fused, plan)
+    a, w, b = (x.astype(np.float64) for _, _, x in ins[:3])
+    want = a @ w + b
+    if tail.startswith("gelu"):
+        want = R.unary("gelu", want)
+    elif tail == "headsplit":
+        want = want.reshape(Bt, S, NH, D).transpose(0, 2, 1, 3)
+    want = want.reshape(got[True].shape)
+    for on in (True, False):
+        assert np.allclose(got[on], want, rtol=4e-3, atol=6e-3), (on, np.abs(got[on] - want).max())
+
+
+@pytest.mark.parametrize("kt", ["transpose", "merged"])
+@pytest.mark.parametrize("hipgraph", [False, True])
+def test_front_end_attention_block_in_exporter_order(B, rocm, kt, hipgraph):
+    """A whole self-attention block as a torch export orders it: q = MatMul + Add; k = MatMul, Add, Reshape, Transpose; v
+    likewise; THEN q's Reshape + Transpose; Transpose(K) (or the merged Transpose(0, 2, 3, 1) onnxsim leaves); MatMul, Div,
+    Add(mask), Softmax, MatMul, Transpose, Reshape; the output projection MatMul + Add; Add(residual) -> LayerNorm. The plan
+    is a handful of launches (q / k / v grouped when the layout allows), every operator inside one."""
+    rng = np.random.default_rng(43)
+    Bt, S, NH, D = 2, 128, 2, 64
+    H = NH * D
+    mask = np.where(rng.random((Bt, 1, 1, S)) < 0.85, 0.0, -10000.0).astype(np.float16)
+    W = lambda: (rng.standard_normal((H, H)) / 11).astype(np.float16)
+    bv = lambda: rng.standard_normal((H,)).astype(np.float16)
+    ins = [((Bt, S, H), F16, rng.standard_normal((Bt, S, H)).astype(np.float16))]
+    for _ in range(4):
+        ins += [((H, H), F16, W()), ((H,), F16, bv())]
+    ins += [((1,), F16, np.array([np.sqrt(D)], np.float16)), ((Bt, 1, 1, S), F16, mask),
+            ((H,), F16, (1 + 0.1 * rng.standard_normal(H)).astype(np.float16)), ((H,), F16, (0.1 * rng.standard_normal(H)).astype(np.float16))]
+
+    def fn(h, t):
+        _weights(t)
+        lin = B.ActType.Linear
+        x0 = h.relu(t[0], None)  # an intermediate, like a previous layer's output
+        linear = lambda a, i: h.add(t[2 + 2 * i], h.matmul(a, t[1 + 2 * i], None, False, False, None, lin, "default"), None)
+        hd = lambda y: h.transpose(h.reshape(y, None, [Bt, S, NH, D]), None, [0, 2, 1, 3])
+        ql = linear(x0, 0)
+        kl = linear(x0, 1)
+        if kt == "merged":
+            kx = h.transpose(h.reshape(kl, None, [Bt, S, NH, D]), None, [0, 2, 3, 1])
+        else:
+            k = hd(kl)
+        v = hd(linear(x0, 2))
+        q = hd(ql)
+        if kt == "transpose":
+            kx = h.transpose(k, None, [0, 1, 3, 2])
+        s = h.add(h.div(h.matmul(q, kx, None, False, False, None, lin, "default"), t[9], None), t[10], None)
+        ctx = h.matmul(h.softmax(s, None, 3), v, None, False, False, None, lin, "default")
+        ctx = h.reshape(h.transpose(ctx, None, [0, 2, 1, 3]), None, [Bt, S, H])
+        return h.layerNormalization(h.add(linear(ctx, 3), x0, None), t[11], None, t[12], 1e-5, 2, 1)
+
+    got, fused, plan = _on_off(B, rocm, fn, ins, hipgraph)
+    alone = [p for p in plan if " op [" in p]
+    # alone: the leading Relu; and the output projection's MatMul when the planner put its bias Add's output on the (dead)
+    # attention result — the bias then joins the residual Add + LayerNorm launch instead of the GEMM epilogue
+    assert fused[False] == 0 and 3 <= fused[True] <= 7 and len(alone) <= 2, (fused, plan)
+    assert any("attention" in p for p in plan) and any("headsplit" in p for p in plan), plan
+    f = lambda i: ins[i][2].astype(np.float64)
+    x0 = np.maximum(f(0), 0)
+    hd = lambda y: y.reshape(Bt, S, NH, D).transpose(0, 2, 1, 3)
+    q, k, v = (hd(x0 @ f(1 + 2 * i) + f(2 + 2 * i)) for i in range(3))
+    ctx = R.attention(q, k, v, 1.0 / float(np.float16(np.sqrt(D))), mask.astype(np.float64)).transpose(0, 2, 1, 3).reshape(Bt, S, H)
+    want = R.layer_norm(ctx @ f(7) + f(8) + x0, f(11), f(12), 1e-5, 2)
+    for on in (True, False):
+        assert np.allclose(got[on].reshape(want.shape), want, rtol=1e-2, atol=2e-2), (on, np.abs(got[on].reshape(want.shape) - want).max())
+
+
+@pytest.mark.parametrize("code,npdt,tol", [(F32, np.float32, 1e-4), (F16, np.float16, 6e-3)])
+@pytest.mark.parametrize("form", ["ln", "add+ln", "bias+add+ln", "pre-ln"])
+def test_decomposed_layer_norm_is_one_launch(B, rocm, code, npdt, tol, form):
+    """An opset < 17 export has no LayerNormalization: ReduceMean, Sub, Pow, ReduceMean, Add(eps), Sqrt, Div, Mul(gamma),
+    Add(beta) (onnx.py:837,510,528,504,604,522,516). Nine operators planned as one layer_norm launch — alone, behind the
+    residual Add (add_norm), behind MatMul-bias Add + residual Add (bias_add_norm), and in pre-LN position where the
+    normalised tensor has other readers (it then stays materialised). fp32 math inside; the per-operator run rounds each
+    step to the storage type."""
+    rng = np.random.default_rng(44)
+    Bt, S, H = 2, 96, 256
+    ins = [((Bt, S, H), code, (rng.standard_normal((Bt, S, H)) * 2 + 0.5).astype(npdt)),
+           ((H,), code, (1 + 0.1 * rng.standard_normal(H)).astype(npdt)), ((H,), code, (0.1 * rng.standard_normal(H)).astype(npdt)),
+           ((1,), code, np.array([2.0], npdt)), ((1,), code, np.array([1e-5], npdt)),
+           ((Bt, S, H), code, rng.standard_normal((Bt, S, H)).astype(npdt)), ((H,), code, rng.standard_normal((H,)).astype(npdt))]
+
+    def fn(h, t):
+        for i in (1, 2, 3, 4, 6):
+            t[i].set_weight()
+        x = h.relu(t[0], None)
+        if form == "add+ln":
+            x = h.add(x, t[5], None)
+        elif form == "bias+add+ln":
+            x = h.add(h.add(t[6], x, None), t[5], None)
+        d = h.sub(x, h.reduceMean(x, None, [2], True), None)
+        var = h.reduceMean(h.pow(d, t[3], None), None, [2], True)
+        y = h.add(h.mul(h.div(d, h.sqrt(h.add(var, t[4], None), None), None), t[1], None), t[2], None)
+        return h.add(y, x, None) if form == "pre-ln" else y
+
+    got, fused, plan = _on_off(B, rocm, fn, ins)
+    assert fused[False] == 0 and fused[True] == 1 and sum("layer" in p for p in plan) == 1, (fused, plan)
+    f = lambda i: ins[i][2].astype(np.float64)
+    x = np.maximum(f(0), 0)
+    if form == "add+ln":
+        x = x + f(5)
+    elif form == "bias+add+ln":
+        x = x + f(6) + f(5)
+    want = R.layer_norm(x, f(1), f(2), float(ins[4][2][0]), 2)
+    if form == "pre-ln":
+        want = want + x
+    for on in (True, False):
+        assert np.allclose(got[on].reshape(want.shape), want, rtol=tol, atol=tol * 4), (on, np.abs(got[on].reshape(want.shape) - want).max())
+
+
+def test_plan_follows_a_constant_the_host_overwrites(B, rocm):
+    """The planner reads one-element constants back to recognise Pow(d, 2) / sqrt 2 / 0.5. Writing a different value over
+    such a constant must re-plan — also under run_with_hipgraph, whose captured launches embed the old decision."""
+    rng = np.random.default_rng(45)
+    Bt, S, H = 2, 64, 128
+    x = (rng.standard_normal((Bt, S, H)) + 0.3).astype(np.float32)
+    h = B.GraphHandler(rocm)
+    tx = h.tensor([Bt, S, H], F32)
+    tx.set_input()
+    tg, tb, two, eps = (h.tensor(list(s), F32) for s in ((H,), (H,), (1,), (1,)))
+    for t in (tg, tb, two, eps):
+        t.set_weight()
+    d = h.sub(tx, h.reduceMean(tx, None, [2], True), None)
+    var = h.reduceMean(h.pow(d, two, None), None, [2], True)
+    out = h.add(h.mul(h.div(d, h.sqrt(h.add(var, eps, None), None), None), tg, None), tb, None)
+    h.data_malloc()
+    g, b = (1 + 0.1 * rng.standard_normal(H)).astype(np.float32), (0.1 * rng.standard_normal(H)).astype(np.float32)
+    for t, a in ((tx, x), (tg, g), (tb, b), (two, np.array([2.0], np.float32)), (eps, np.array([1e-5], np.float32))):
+        put(t, a)
+
+    def want(p):
+        X = x.astype(np.float64)
+        dd = X - X.mean(-1, keepdims=True)
+        return dd / np.sqrt((np.abs(dd) ** p).mean(-1, keepdims=True) + 1e-5) * g + b
+
+    for run in (h.run, h.run_with_hipgraph):
+        put(two, np.array([2.0], np.float32))
+        run()
+        assert any("layer_norm(decomposed)" in p for p in h.rocm_fusion_plan())
+        assert np.allclose(get(out, (Bt, S, H)), want(2), rtol=1e-4, atol=1e-4)
+        put(two, np.array([4.0], np.float32))  # no longer a variance: the nine operators must run as written
+        run()
+        assert not any("layer_norm" in p for p in h.rocm_fusion_plan())
+        assert np.allclose(get(out, (Bt, S, H)), want(4), rtol=1e-3, atol=1e-3)
+
+
+def test_sunk_chain_is_cut_when_its_input_is_recycled(B, rocm):
+    """q = MatMul + Add is issued first, reshaped LAST; in between, operators recycle the storage of the MatMul's (dead)
+    input. The planned launch would read that input at the Reshape's position — the planner must notice and cut the chain
+    there. Whatever it decides, the result equals the per-operator run."""
+    rng = np.random.default_rng(46)
+    Bt, S, NH, D = 2, 128, 2, 64
+    H = NH * D
+    ins = [((Bt, S, H), F16, rng.standard_normal((Bt, S, H)).astype(np.float16)),
+           ((H, H), F16, (rng.standard_normal((H, H)) / 11).astype(np.float16)), ((H,), F16, rng.standard_normal((H,)).astype(np.float16))]
+
+    def fn(h, t):
+        _weights(t)
+        a = h.relu(t[0], None)           # dies after the MatMul
+        other = h.tanh(t[0], None)
+        ql = h.add(t[2], h.matmul(a, t[1], None, False, False, None, B.ActType.Linear, "default"), None)
+        for _ in range(3):               # same-size temporaries: the allocator hands them a's block
+            other = h.sigmoid(h.neg(other, None), None)
+        q = h.transpose(h.reshape(ql, None, [Bt, S, NH, D]), None, [0, 2, 1, 3])
+        return h.add(q, h.transpose(h.reshape(other, None, [Bt, S, NH, D]), None, [0, 2, 1, 3]), None)
+
+    got, fused, plan = _on_off(B, rocm, fn, ins)
+    assert np.isfinite(got[True]).all()
+    assert np.allclose(got[True], got[False], rtol=4e-3, atol=6e-3), (np.abs(got[True] - got[False]).max(), plan)

@@ -179,6 +179,26 @@ def test_add_norm_matches_the_chain(rt, shape, rms, dt):
     assert (f != c).float().mean().item() < 1e-3
 
 
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("shape", [(64, 768), (3, 7, 1024), (5, 33), (2, 4096), (4, 520)])
+@pytest.mark.parametrize("rms", [False, True])
+def test_bias_add_norm_matches_the_chain(rt, shape, rms, dt):
+    """infini_rocm_bias_add_norm vs Norm(Add(Add(a, row bias), b)) — the chain the ONNX front-end emits behind a linear layer
+    (MatMul -> Add(bias) -> Add(residual) -> LayerNormalization): both sums rounded like their own Add kernels."""
+    rng = np.random.default_rng(23)
+    a, b = (dev(rng.standard_normal(shape).astype(np.float32), TD[dt]) for _ in range(2))
+    pre = dev(rng.standard_normal(shape[-1:]).astype(np.float32), TD[dt])
+    g = dev(rng.standard_normal(shape[-1:]).astype(np.float32), TD[dt])
+    be = None if rms else dev(rng.standard_normal(shape[-1:]).astype(np.float32), TD[dt])
+    fused = ops.add_layer_norm(rt, a, b, g, be, 1e-5, rms, pre=pre)
+    s = ops.binary(rt, "add", ops.binary(rt, "add", a, pre), b)
+    chain = ops.rms_norm(rt, s, g, 1e-5) if rms else ops.layer_norm(rt, s, g, be, 1e-5, -1)
+    ulp = {"f32": 2.0 ** -22, "f16": 2.0 ** -10, "bf16": 2.0 ** -7}[dt]
+    f, c = fused.float(), chain.float()
+    assert torch.allclose(f, c, rtol=ulp, atol=ulp * 1e-2)
+    assert (f != c).float().mean().item() < 1e-3
+
+
 @pytest.mark.parametrize("dt", ["f16", "f32"])
 def test_softmax_bert_full_size_properties(rt, dt):
     """BASELINE config 4's softmax at its full size ([32, 12, 512, 512] = 196 608 rows of 512) through size-independent

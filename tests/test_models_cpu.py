@@ -26,7 +26,11 @@ def test_resnet50_graph_shape(B):
     out = build_resnet50(bl, 2, 64)
     assert out.shape() == [2, 1000]
     ops = bl.h.operators()
-    assert len(ops) == 175  # 53 conv + 53 bias adds + 49 relu + 16 residual adds + 2 pools + flatten + fc
+    # 53 conv + 53 bias Reshapes (onnx.py:159-190) + 53 bias adds + 49 relu + 16 residual adds + 2 pools + flatten + Gemm
+    assert len(ops) == 228
+    bl2 = Builder(B, B.cpu_runtime(), "f32", seed=0)
+    build_resnet50(bl2, 2, 64, frontend=False)
+    assert len(bl2.h.operators()) == 175  # the idealised lowering of rounds 1-2 (pre-shaped bias): kept for A/B
     macs = bl.flops / 2 / 2  # per image
     assert abs(macs - 4.09e9 * (64 / 224) ** 2) / (4.09e9 * (64 / 224) ** 2) < 0.08  # ~4.1 GMAC per 224^2 image
 
@@ -37,8 +41,16 @@ def test_bert_graph_shape(B):
     bl = Builder(B, B.cpu_runtime(), "f32", seed=0)
     out = build_bert(bl, 2, 16, 2, hidden=64, heads=2, ffn=128, vocab=100)
     assert out.shape() == [2, 16, 64]
-    # per layer: 4 linear + 2 attention matmuls, 4 reshapes, 4 transposes, div, 3 adds, softmax, gelu, 2 layer norms
-    assert len(bl.h.operators()) == 3 + 2 * 24
+    # front-end form, per layer: 4 linear (MatMul + Add each) + 2 attention matmuls, 4 reshapes, 4 head transposes + Transpose(K),
+    # div, mask add, 2 residual adds, softmax, gelu, 2 layer norms
+    assert len(bl.h.operators()) == 3 + 2 * 31
+    bl2 = Builder(B, B.cpu_runtime(), "f32", seed=0)
+    build_bert(bl2, 2, 16, 2, hidden=64, heads=2, ffn=128, vocab=100, frontend=False)
+    assert len(bl2.h.operators()) == 3 + 2 * 24  # idealised: bias inside the MatMul, transB for K^T
+    bl3 = Builder(B, B.cpu_runtime(), "f32", seed=0)
+    build_bert(bl3, 2, 16, 2, hidden=64, heads=2, ffn=128, vocab=100, decomposed=True)
+    # + 8 operators per LayerNorm (5 of them), + 4 per Gelu (2)
+    assert len(bl3.h.operators()) == 3 + 2 * 31 + 5 * 8 + 2 * 4
 
 
 @pytest.mark.parametrize("world", [1, 2, 4])

@@ -62,9 +62,9 @@ def test_perf_engine_json_round_trip(plugin_backend, tmp_path):
     ROCM = 7  # enum class Device { CPU = 1, ..., ROCM } (build_plugin.py patch of include/core/runtime.h:35)
     doc = {"data": [
         [[[ROCM, 101], {"hashType": 1234567890123456789, "opType": 101, "attrs": [101, 1, 4096, 4096, 4096, 0, 0, 0]}],
-         {"type": 3, "data": [7, 0.104]}],
+         {"type": 3, "data": [4, 0.104, "persist256"]}],
         [[[ROCM, 30], {"hashType": 42, "opType": 30, "attrs": [30, 128, 64, 56, 56, 64, 3, 3, 1, 1, 1, 1, 1, 1, 0]}],
-         {"type": 4, "data": [2, 0.096]}],
+         {"type": 4, "data": [2, 0.096, "conv_s1"]}],
         [[[1, 5], {"hashType": 7, "opType": 5, "attrs": [5, 2, 3]}], {"type": 0, "data": 3}],
     ]}
     src = tmp_path / "perf_in.json"
@@ -76,6 +76,21 @@ def test_perf_engine_json_round_trip(plugin_backend, tmp_path):
     back = json.loads(dst.read_text())
     key = lambda e: (e[0][0][0], e[0][0][1], e[0][1]["hashType"])
     assert sorted(back["data"], key=key) == sorted(doc["data"], key=key)
+
+    # Variant numbers are an implementation detail that has been renumbered between rounds: records are resolved by the
+    # variant's NAME. A stale file — no name (round-2 schema: variant 7 no longer exists, variant 6 means something else
+    # now), or a name this build does not know, or a number that disagrees with the name — never throws at launch: it
+    # loads as "heuristic" (-1), or as the variant the name denotes.
+    stale = {"data": [
+        [[[ROCM, 101], {"hashType": 1, "opType": 101, "attrs": [101, 1, 64, 64, 64, 0, 0, 0]}], {"type": 3, "data": [7, 0.2]}],
+        [[[ROCM, 101], {"hashType": 2, "opType": 101, "attrs": [101, 1, 64, 64, 64, 0, 0, 1]}], {"type": 3, "data": [6, 0.2, "stagger_st16"]}],
+        [[[ROCM, 101], {"hashType": 3, "opType": 101, "attrs": [101, 1, 64, 64, 64, 0, 1, 0]}], {"type": 3, "data": [6, 0.2, "tile256_splitk"]}],
+    ]}
+    src.write_text(json.dumps(stale))
+    R.load_perf(str(src))
+    R.save_perf(str(dst))
+    got = {e[0][1]["hashType"]: e[1]["data"] for e in json.loads(dst.read_text())["data"]}
+    assert got == {1: [-1, 0.2, "heuristic"], 2: [-1, 0.2, "heuristic"], 3: [3, 0.2, "tile256_splitk"]}, got
 
     # records made by the reference's tune() itself
     R.clear_perf()

@@ -38,7 +38,10 @@ def build(seed, h, feeds):
 
     def conv_bias(x, ci, co, k, stride, relu):
         w = weight((co, ci, k, k), np.sqrt(2.0 / (ci * k * k)))
-        b = weight((1, co, 1, 1), 0.1)
+        if rng.random() < 0.7:  # the ONNX front-end's form: conv -> reshape(bias, [1, F, 1, 1]) -> add (onnx.py:159-190)
+            b = h.reshape(weight((co,), 0.1), None, [1, co, 1, 1])
+        else:
+            b = weight((1, co, 1, 1), 0.1)
         y = h.add(h.conv(x, w, None, k // 2, k // 2, stride, stride, 1, 1), b, None)
         return h.relu(y, None) if relu else y
 

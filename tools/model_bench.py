@@ -1,7 +1,10 @@
 """Graph-level benchmarks through the REFERENCE graph executor + the Device::ROCM plugin
-(BASELINE configs 3 and 4): the graphs are built op by op with backend.GraphHandler exactly as
-OnnxStub would emit them (onnx/onnxsim are not installed here): BN folded -> Conv + Add(bias) + Relu,
-MatMul + Add(bias), decomposed attention (MatMul, Div, Add(mask), Softmax, MatMul).
+(BASELINE configs 3, 4, 5): the graphs are built op by op with backend.GraphHandler in the very form and operator order
+pyinfinitensor/onnx.py emits for a torch export (onnx / onnxsim are not installed here, so OnnxStub itself cannot run):
+BN folded -> Conv + Reshape(bias) + Add + Relu (onnx.py:159-190), nn.Linear -> MatMul + Add(bias) (onnx.py:280-290),
+Q.K^T -> Transpose(K) + MatMul, attention as MatMul, Div, Add(mask), Softmax, MatMul; `--decomposed` additionally lowers
+LayerNorm / Gelu to the primitive operators of an opset < 17 export; `--idealised` is the friendlier round-1/2 lowering
+(bias inside the MatMul, transB) kept for A/B.
 
   python tools/model_bench.py resnet50 [--batch 128] [--dtype f16]
   python tools/model_bench.py bert     [--batch 32] [--seq 512] [--layers 12]
@@ -71,15 +74,24 @@ class Builder:
             t.copyin_numpy(np.ascontiguousarray(a))
 
 
-def build_resnet50(bl: Builder, batch: int, image: int = 224, fc_bias_as_add: bool = False):
-    """fc_bias_as_add: emit the classifier as MatMul + Add (the reference's native-CPU MatMul has no bias input), so the
-    same graph also runs on `backend.cpu_runtime()` for end-to-end parity (tests/test_gpu_models.py)."""
+def build_resnet50(bl: Builder, batch: int, image: int = 224, fc_bias_as_add: bool = False, frontend: bool = True):
+    """ResNet-50 (torchvision topology, BN folded) operator by operator AS pyinfinitensor/onnx.py EMITS IT:
+      * a Conv node with a bias input becomes  conv -> reshape(bias, [1, F, 1, 1]) -> add   (onnx.py:159-190), so the
+        operator order is [Conv, Reshape, Add, Relu];
+      * nodes appear in the exporter's order: conv1, conv2, conv3, (downsample conv), Add, Relu per bottleneck;
+      * the classifier is  Flatten -> Gemm(transB = 1, bias)  (onnx.py:291-311: only Gemm carries bias / transposes).
+    frontend=False builds the round-1/2 idealised lowering (bias pre-shaped [1, F, 1, 1], no Reshape operator) for A/B.
+    fc_bias_as_add: emit the classifier as MatMul + Add (the reference's native-CPU MatMul has no bias input and asserts
+    no transpose), so the same graph also runs on `backend.cpu_runtime()` for end-to-end parity (tests/test_gpu_models.py)."""
     h = bl.h
 
     def conv_bn_act(x, cin, cout, k, stride, pad, relu=True, hw=None):
         w = bl.weight((cout, cin, k, k), np.sqrt(2.0 / (cin * k * k)))
-        b = bl.weight((1, cout, 1, 1), 0.01)
         y = h.conv(x, w, None, pad, pad, stride, stride, 1, 1)
+        if frontend:
+            b = h.reshape(bl.weight((cout,), 0.01), None, [1, cout, 1, 1])
+        else:
+            b = bl.weight((1, cout, 1, 1), 0.01)
         oh = (hw + 2 * pad - k) // stride + 1
         bl.flops += 2.0 * batch * cout * oh * oh * cin * k * k
         y = h.add(y, b, None)
@@ -103,18 +115,32 @@ def build_resnet50(bl: Builder, batch: int, image: int = 224, fc_bias_as_add: bo
             cin, hw = width * 4, hw3
     y = h.avgPool(y, None, hw, hw, 1, 1, 0, 0, 1, 1, 0)
     y = h.flatten(y, None, 1)
-    wfc = bl.weight((2048, 1000), np.sqrt(1.0 / 2048))
     bfc = bl.weight((1000,), 0.01)
     if fc_bias_as_add:
+        wfc = bl.weight((2048, 1000), np.sqrt(1.0 / 2048))
         y = h.add(h.matmul(y, wfc, None, False, False, None, bl.B.ActType.Linear, "default"), bfc, None)
+    elif frontend:
+        wfc = bl.weight((1000, 2048), np.sqrt(1.0 / 2048))
+        y = h.matmul(y, wfc, None, False, True, bfc, bl.B.ActType.Linear, "default")
     else:
+        wfc = bl.weight((2048, 1000), np.sqrt(1.0 / 2048))
         y = h.matmul(y, wfc, None, False, False, bfc, bl.B.ActType.Linear, "default")
     bl.flops += 2.0 * batch * 2048 * 1000
     return y
 
 
 def build_bert(bl: Builder, batch: int, seq: int, layers: int, hidden: int = 768, heads: int = 12, ffn: int = 3072,
-               vocab: int = 30522):
+               vocab: int = 30522, frontend: bool = True, decomposed: bool = False, merged_kt: bool = False):
+    """A BERT encoder AS pyinfinitensor/onnx.py EMITS a torch export of it (frontend=True):
+      * every nn.Linear on a 3-D activation is  MatMul(x, W) -> Add(bias, .)  — onnx.py:280-290 imports MatMul with no
+        bias and no transposes; the exporter puts the bias FIRST in the Add;
+      * operator order is the exporter's (HF BertSelfAttention.forward): q = MatMul + Add; k = MatMul, Add, Reshape,
+        Transpose; v likewise; THEN q's Reshape, Transpose; then Transpose(K) (perm 0,1,3,2), MatMul(Q, K^T), Div, Add(mask),
+        Softmax, MatMul, Transpose, Reshape;
+      * merged_kt: the two transposes of K merged into one Transpose(0, 2, 3, 1) (what onnxsim leaves);
+      * decomposed (opset < 17 / < 20): LayerNorm as ReduceMean, Sub, Pow, ReduceMean, Add, Sqrt, Div, Mul, Add and Gelu as
+        Div, Erf, Add, Mul, Mul (onnx.py:522,528,604,837,1050).
+    frontend=False: the round-1/2 idealised lowering (bias inside the MatMul, transB for K^T) for A/B."""
     h, B = bl.h, bl.B
     lin = B.ActType.Linear
     D = hidden // heads
@@ -124,40 +150,74 @@ def build_bert(bl: Builder, batch: int, seq: int, layers: int, hidden: int = 768
     mask = bl.const(np.zeros((batch, 1, 1, seq), bl.np))
     scale = bl.const(np.array([np.sqrt(D)], bl.np))
     x = h.add(h.gather(emb, ids, None, 0), pos, None)
+    if decomposed:
+        two, one, half = (bl.const(np.array([v], bl.np)) for v in (2.0, 1.0, 0.5))
+        sqrt2 = bl.const(np.array([np.sqrt(2.0)], bl.np))
+        eps = bl.const(np.array([1e-5 if bl.np == np.float16 else 1e-12], bl.np))  # 1e-12 is not an f16 number
+    rank = 3
 
     def ln(t):
-        return h.layerNormalization(t, bl.const(np.ones(hidden, bl.np)), None, bl.const(np.zeros(hidden, bl.np)), 1e-12, 2, 1)
+        g, b = bl.const(np.ones(hidden, bl.np)), bl.const(np.zeros(hidden, bl.np))
+        if not decomposed:
+            return h.layerNormalization(t, g, None, b, 1e-12, 2, 1)
+        d = h.sub(t, h.reduceMean(t, None, [rank - 1], True), None)
+        var = h.reduceMean(h.pow(d, two, None), None, [rank - 1], True)
+        y = h.div(d, h.sqrt(h.add(var, eps, None), None), None)
+        return h.add(h.mul(y, g, None), b, None)
+
+    def gelu(t):
+        if not decomposed:
+            return h.gelu(t, None)
+        e = h.add(h.erf(h.div(t, sqrt2, None), None), one, None)
+        return h.mul(h.mul(t, e, None), half, None)
 
     def linear(t, cin, cout):
         w = bl.weight((cin, cout), 0.02)
         b = bl.weight((cout,), 0.02)
         bl.flops += 2.0 * batch * seq * cin * cout
-        return h.matmul(t, w, None, False, False, b, lin, "default")
+        if not frontend:
+            return h.matmul(t, w, None, False, False, b, lin, "default")
+        return h.add(b, h.matmul(t, w, None, False, False, None, lin, "default"), None)
+
+    def heads_of(t):
+        return h.transpose(h.reshape(t, None, [batch, seq, heads, D]), None, [0, 2, 1, 3])
 
     x = ln(x)
     for _ in range(layers):
-        def heads_of(t):
-            return h.transpose(h.reshape(t, None, [batch, seq, heads, D]), None, [0, 2, 1, 3])
-        q, k, v = heads_of(linear(x, hidden, hidden)), heads_of(linear(x, hidden, hidden)), heads_of(linear(x, hidden, hidden))
-        s = h.matmul(q, k, None, False, True, None, lin, "default")
+        if frontend:
+            ql = linear(x, hidden, hidden)
+            kl = linear(x, hidden, hidden)
+            if merged_kt:
+                kt = h.transpose(h.reshape(kl, None, [batch, seq, heads, D]), None, [0, 2, 3, 1])
+            else:
+                k = heads_of(kl)
+            v = heads_of(linear(x, hidden, hidden))
+            q = heads_of(ql)
+            if not merged_kt:
+                kt = h.transpose(k, None, [0, 1, 3, 2])
+            s = h.matmul(q, kt, None, False, False, None, lin, "default")
+        else:
+            q, k, v = heads_of(linear(x, hidden, hidden)), heads_of(linear(x, hidden, hidden)), heads_of(linear(x, hidden, hidden))
+            s = h.matmul(q, k, None, False, True, None, lin, "default")
         bl.flops += 2.0 * batch * heads * seq * seq * D * 2
         s = h.add(h.div(s, scale, None), mask, None)
         p = h.softmax(s, None, 3)
         ctx = h.matmul(p, v, None, False, False, None, lin, "default")
         ctx = h.reshape(h.transpose(ctx, None, [0, 2, 1, 3]), None, [batch, seq, hidden])
-        x = ln(h.add(x, linear(ctx, hidden, hidden), None))
-        f = linear(h.gelu(linear(x, hidden, ffn), None), ffn, hidden)
-        x = ln(h.add(x, f, None))
+        x = ln(h.add(linear(ctx, hidden, hidden), x, None))
+        f = linear(gelu(linear(x, hidden, ffn)), ffn, hidden)
+        x = ln(h.add(f, x, None))
     return x
 
 
 def build_llama_block(bl: Builder, batch: int, seq: int, heads: int = 32, head_dim: int = 128, ffn: int = 11008,
-                      world: int = 1, rank: int = 0, all_reduce: bool = True):
+                      world: int = 1, rank: int = 0, all_reduce: bool = True, frontend: bool = True):
     """BASELINE config 5: one Llama-7B-style decoder block, tensor-parallel over `world` ranks the way
     examples/distributed/parallel_opt.py rewrites it — q/k/v/gate/up column-parallel (weight sharded on the last dim,
     heads split), o_proj/down row-parallel (weight sharded on dim 0) followed by ONE AllReduceSum each
     (parallel_opt.py:46-59,81-119,195-210). Every rank draws the same full weights (seeded) and keeps its shard
-    (infinitensor_amd/tp.py). Attention is the decomposed chain with an additive causal mask [1, 1, S, S].
+    (infinitensor_amd/tp.py). Attention is the decomposed chain with an additive causal mask [1, 1, S, S]; Q.K^T is
+    Transpose(K) -> MatMul as onnx.py imports it (frontend=False: the MatMul's transB, which only Gemm can carry).
     all_reduce=False leaves the two partial sums un-reduced (their sum over ranks must equal the unsharded block:
     tests/test_gpu_models.py)."""
     from infinitensor_amd import tp
@@ -181,7 +241,11 @@ def build_llama_block(bl: Builder, batch: int, seq: int, heads: int = 32, head_d
     hn = h.RMSNorm(x, bl.const(n1), None)
     q, k = hd(h.RoPE(pos, mm(hn, col("q")), None)), hd(h.RoPE(pos, mm(hn, col("k")), None))
     v = hd(mm(hn, col("v")))
-    s = h.add(h.div(h.matmul(q, k, None, False, True, None, lin, "default"), scale, None), mask, None)
+    if frontend:
+        qk = h.matmul(q, h.transpose(k, None, [0, 1, 3, 2]), None, False, False, None, lin, "default")
+    else:
+        qk = h.matmul(q, k, None, False, True, None, lin, "default")
+    s = h.add(h.div(qk, scale, None), mask, None)
     ctx = h.matmul(h.softmax(s, None, 3), v, None, False, False, None, lin, "default")
     ctx = h.reshape(h.transpose(ctx, None, [0, 2, 1, 3]), None, [batch, seq, nh * head_dim])
     o = mm(ctx, row("o"))
@@ -219,7 +283,8 @@ def timed(fn, iters, warm_ms=40.0):
 
 
 def run_model(model: str, device: int = 0, batch: int | None = None, seq: int = 512, layers: int = 12,
-              dtype: str = "f16", iters: int = 10, tune: bool = False) -> dict:
+              dtype: str = "f16", iters: int = 10, tune: bool = False, frontend: bool = True, decomposed: bool = False,
+              merged_kt: bool = False) -> dict:
     """tune=True additionally runs the reference's h.tune() (MatMul / Conv pick their kernel variant by measurement,
     plugin/src/rocm_kernels.cc RocmTunableKernel) and times the graph again with the records in the PerfEngine."""
     B = load_backend()
@@ -227,12 +292,12 @@ def run_model(model: str, device: int = 0, batch: int | None = None, seq: int = 
     bl = Builder(B, rt, dtype)
     if model == "resnet50":
         batch = batch or 128
-        out = build_resnet50(bl, batch)
+        out = build_resnet50(bl, batch, frontend=frontend)
         name = f"ResNet-50 bs{batch} {dtype}"
     elif model == "llama":
         batch = batch or 4
         rt.init_comm("model_bench_llama", 1, 0)
-        out = build_llama_block(bl, batch, seq)
+        out = build_llama_block(bl, batch, seq, frontend=frontend)
         name = f"Llama-7B block bs{batch} seq{seq} {dtype} TP=1"
     elif model in ("matmul", "matmul_nt"):
         batch = 1
@@ -240,8 +305,8 @@ def run_model(model: str, device: int = 0, batch: int | None = None, seq: int = 
         name = f"MatMul 4096^3 {dtype} " + ("NT" if model == "matmul_nt" else "NN")
     else:
         batch = batch or 32
-        out = build_bert(bl, batch, seq, layers)
-        name = f"BERT-base L{layers} bs{batch} seq{seq} {dtype}"
+        out = build_bert(bl, batch, seq, layers, frontend=frontend, decomposed=decomposed, merged_kt=merged_kt)
+        name = f"BERT-base L{layers} bs{batch} seq{seq} {dtype}" + (" decomposed LN/Gelu" if decomposed else "") + (" merged-K^T" if merged_kt else "")
     nops = len(bl.h.operators())
     bl.finish()
     f0 = rt.fused_launch_count()
@@ -271,7 +336,8 @@ def run_model(model: str, device: int = 0, batch: int | None = None, seq: int = 
         y = out.copyout_numpy()
         tuned = {"tuned_eager_ms": round(te, 3), "tuned_hipgraph_ms": round(tg, 3), "tune_seconds": round(tune_s, 2),
                  "tuned_picks": picks}
-    return {**tuned, "model": name, "ops": nops, "fusion": bool(rt.get_fusion()), "fused_launches_per_run": int(fused), "gemm_conv_TFLOP": round(bl.flops / 1e12, 3),
+    lowering = "onnx.py" if frontend else "idealised"
+    return {**tuned, "model": name, "lowering": lowering, "ops": nops, "fusion": bool(rt.get_fusion()), "fused_launches_per_run": int(fused), "gemm_conv_TFLOP": round(bl.flops / 1e12, 3),
             "eager_ms": round(eager, 3), "hipgraph_ms": round(graph, 3),
             "hipgraph_TFLOPs": round(bl.flops / graph / 1e9, 1), "batch": batch,
             "per_unit": f"{batch / graph * 1e3:.0f} samples/s", "finite": bool(np.isfinite(y.astype(np.float32)).all())}
@@ -286,8 +352,12 @@ def main():
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--tune", action="store_true", help="also time the graph after h.tune() (autotuned MatMul / Conv variants)")
+    ap.add_argument("--idealised", action="store_true", help="the round-1/2 lowering (bias inside MatMul / pre-shaped conv bias, transB)")
+    ap.add_argument("--decomposed", action="store_true", help="bert: LayerNorm / Gelu as the primitive operators of an opset < 17 export")
+    ap.add_argument("--merged-kt", action="store_true", help="bert: K's two transposes merged into Transpose(0, 2, 3, 1) (onnxsim)")
     args = ap.parse_args()
-    print(json.dumps(run_model(args.model, 0, args.batch, args.seq, args.layers, args.dtype, args.iters, args.tune)))
+    print(json.dumps(run_model(args.model, 0, args.batch, args.seq, args.layers, args.dtype, args.iters, args.tune,
+                               not args.idealised, args.decomposed, args.merged_kt)))
 
 
 if __name__ == "__main__":
