@@ -516,6 +516,19 @@ int infini_rocm_comm_info(infiniRocmRuntime_t rt, int *world_size, int *rank);
 int infini_rocm_all_reduce(infiniRocmRuntime_t rt, int op, int dtype, const void *x, void *y,
                            int64_t count);
 /* y receives world_size * count elements, rank r's block at offset r * count. */
+/* Overlapped collectives. infini_rocm_all_reduce_async is ordered after everything enqueued on the runtime stream so far
+ * but runs on a second, runtime-owned stream: later work on the runtime stream does NOT wait for it until
+ * infini_rocm_comm_join. A row-parallel GEMM cut into row chunks can so hide each chunk's all-reduce under the next chunk's
+ * GEMM (the reference issues ONE whole-tensor ncclAllReduce behind the whole GEMM: all_reduce.cc:10-33). Capturable (the
+ * fork / join become edges of the hipGraph); every rank must issue its collectives in the same order. */
+int infini_rocm_all_reduce_async(infiniRocmRuntime_t rt, int op, int dtype, const void *x, void *y, int64_t count);
+int infini_rocm_comm_join(infiniRocmRuntime_t rt);
+/* y[count] = sum over ranks r of x_r[rank * count ..]: the reduce-scatter half of an all-reduce (x: world_size * count
+ * elements). direct != 0: one-hop exchange over the fully connected xGMI mesh (grouped send / recv of every slice to its
+ * owner, then a local fp32 sum) instead of RCCL's own algorithm choice; scratch from the runtime workspace. With
+ * infini_rocm_all_gather this is the sequence-parallel form of a TP block: reduce-scatter -> residual add + norm on the
+ * shard -> all-gather. No reference counterpart (the reference has AllReduce / AllGather only). */
+int infini_rocm_reduce_scatter(infiniRocmRuntime_t rt, int dtype, const void *x, void *y, int64_t count, int direct);
 int infini_rocm_all_gather(infiniRocmRuntime_t rt, int dtype, const void *x, void *y, int64_t count);
 int infini_rocm_broadcast(infiniRocmRuntime_t rt, int dtype, const void *x, void *y, int64_t count,
                           int root);

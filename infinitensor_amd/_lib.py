@@ -134,6 +134,9 @@ def lib() -> C.CDLL:
     sig("infini_rocm_comm_destroy", [vp])
     sig("infini_rocm_comm_info", [vp, C.POINTER(i32), C.POINTER(i32)])
     sig("infini_rocm_all_reduce", [vp, i32, i32, vp, vp, i64])
+    sig("infini_rocm_all_reduce_async", [vp, i32, i32, vp, vp, i64])
+    sig("infini_rocm_comm_join", [vp])
+    sig("infini_rocm_reduce_scatter", [vp, i32, vp, vp, i64, i32])
     sig("infini_rocm_all_gather", [vp, i32, vp, vp, i64])
     sig("infini_rocm_broadcast", [vp, i32, vp, vp, i64, i32])
     sig("infini_rocm_send", [vp, i32, vp, i64, i32])

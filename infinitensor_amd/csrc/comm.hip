@@ -62,6 +62,40 @@ static int comm_init_with_id(infiniRocmRuntime_t rt, const ncclUniqueId &id, int
     return INFINI_ROCM_OK;
 }
 
+// fork: `to` waits for everything enqueued on `from` so far. Works under stream capture too (the event record / wait
+// become an edge of the captured graph and pull `to` into the capture; comm_join brings it back before end_capture).
+static int stream_fork(infiniRocmRuntime_t rt, hipStream_t from, hipStream_t to) {
+    if (rt->comm_events.size() < 16) {
+        hipEvent_t e = nullptr;
+        IROCM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        rt->comm_events.push_back(e);
+        rt->comm_event_next = rt->comm_events.size() - 1;
+    }
+    hipEvent_t ev = rt->comm_events[rt->comm_event_next];
+    rt->comm_event_next = (rt->comm_event_next + 1) % rt->comm_events.size();
+    IROCM_HIP(hipEventRecord(ev, from));
+    IROCM_HIP(hipStreamWaitEvent(to, ev, 0));
+    return INFINI_ROCM_OK;
+}
+
+static int ensure_comm_stream(infiniRocmRuntime_t rt) {
+    if (!rt->comm_stream) {
+        IROCM_HIP(hipSetDevice(rt->device));
+        IROCM_HIP(hipStreamCreateWithFlags(&rt->comm_stream, hipStreamNonBlocking));
+    }
+    return INFINI_ROCM_OK;
+}
+
+// y[i] = sum over the `parts` slabs of x (x: [parts][count], y: [count]); fp32 accumulation for 16-bit types
+template <typename T> __global__ __launch_bounds__(256) void sum_slabs_kernel(const T *x, T *y, long count, int parts) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) {
+        float acc = 0.f;
+        for (int p = 0; p < parts; ++p)
+            acc += (float)x[(long)p * count + i];
+        y[i] = (T)acc;
+    }
+}
+
 } // namespace irocm
 
 using namespace irocm;
@@ -155,6 +189,88 @@ int infini_rocm_all_reduce(infiniRocmRuntime_t rt, int op, int dtype, const void
         return INFINI_ROCM_OK;
     IROCM_CHECK_ARG(x && y && count > 0, "all_reduce: bad buffer");
     IROCM_NCCL(ncclAllReduce(x, y, (size_t)count, t, ops[op], (ncclComm_t)rt->comm, rt->stream));
+    return INFINI_ROCM_OK;
+}
+
+// The all-reduce ordered after everything enqueued on the runtime stream so far, running on the runtime's COMM stream: work
+// enqueued on the runtime stream afterwards does not wait for it until infini_rocm_comm_join. This is what lets a
+// row-parallel GEMM be cut into row chunks whose all-reduces overlap the following chunks' GEMMs (bench.py tp_block, the
+// plugin's MatMul -> AllReduceSum item) instead of one whole-tensor all-reduce behind the whole GEMM
+// (reference: all_reduce.cc:10-33). Collectives of one communicator execute in issue order on every rank.
+int infini_rocm_all_reduce_async(infiniRocmRuntime_t rt, int op, int dtype, const void *x, void *y, int64_t count) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(rt->comm, "all_reduce: communicator not initialised (call init_comm)");
+    static const ncclRedOp_t ops[] = {ncclSum, ncclProd, ncclMin, ncclMax, ncclAvg};
+    IROCM_CHECK_ARG(op >= 0 && op <= 4, "all_reduce: bad op %d", op);
+    ncclDataType_t t;
+    IROCM_CHECK_ARG(nccl_type(dtype, &t), "all_reduce: unsupported dtype %s", dtype_name(dtype));
+    if (count == 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(x && y && count > 0, "all_reduce: bad buffer");
+    int st = ensure_comm_stream(rt);
+    if (st != INFINI_ROCM_OK)
+        return st;
+    st = stream_fork(rt, rt->stream, rt->comm_stream);
+    if (st != INFINI_ROCM_OK)
+        return st;
+    IROCM_NCCL(ncclAllReduce(x, y, (size_t)count, t, ops[op], (ncclComm_t)rt->comm, rt->comm_stream));
+    ++rt->comm_pending;
+    return INFINI_ROCM_OK;
+}
+
+// The runtime stream waits for every *_async collective issued since the last join (no-op when there is none).
+int infini_rocm_comm_join(infiniRocmRuntime_t rt) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    if (rt->comm_pending == 0 || !rt->comm_stream)
+        return INFINI_ROCM_OK;
+    rt->comm_pending = 0;
+    return stream_fork(rt, rt->comm_stream, rt->stream);
+}
+
+// y[count] = sum over ranks r of x_r[rank * count .. (rank + 1) * count): x holds world_size * count elements.
+// direct = 0: ncclReduceScatter (RCCL picks the algorithm). direct = 1: the one-hop exchange the fully connected xGMI mesh
+// of an MI355X node allows — every rank SENDS slice j straight to rank j and receives the other ranks' slices for itself
+// (grouped ncclSend / ncclRecv: all 7 links busy at once, world - 1 messages of count elements per rank instead of world - 1
+// ring steps), then sums the world_size slices locally in fp32. Scratch ((world - 1) * count elements) comes from the
+// runtime workspace. Sum only.
+int infini_rocm_reduce_scatter(infiniRocmRuntime_t rt, int dtype, const void *x, void *y, int64_t count, int direct) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(rt->comm, "reduce_scatter: communicator not initialised (call init_comm)");
+    ncclDataType_t t;
+    IROCM_CHECK_ARG(nccl_type(dtype, &t), "reduce_scatter: unsupported dtype %s", dtype_name(dtype));
+    if (count == 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(x && y && count > 0, "reduce_scatter: bad buffer");
+    const int world = rt->comm_world, rank = rt->comm_rank;
+    if (!direct || world == 1 || !(dtype == INFINI_DT_F32 || dtype == INFINI_DT_F16 || dtype == INFINI_DT_BF16)) {
+        IROCM_NCCL(ncclReduceScatter(x, y, (size_t)count, t, ncclSum, (ncclComm_t)rt->comm, rt->stream));
+        return INFINI_ROCM_OK;
+    }
+    const size_t es = dtype_size(dtype);
+    char *tmp = nullptr; // [world][count]: slot r = rank r's slice for me (slot `rank` is filled by a local copy)
+    int st = infini_rocm_workspace(rt, (size_t)world * count * es, (void **)&tmp);
+    if (st != INFINI_ROCM_OK)
+        return st;
+    IROCM_NCCL(ncclGroupStart());
+    for (int r = 0; r < world; ++r) {
+        if (r == rank)
+            continue;
+        IROCM_NCCL(ncclSend((const char *)x + (size_t)r * count * es, (size_t)count, t, r, (ncclComm_t)rt->comm, rt->stream));
+        IROCM_NCCL(ncclRecv(tmp + (size_t)r * count * es, (size_t)count, t, r, (ncclComm_t)rt->comm, rt->stream));
+    }
+    IROCM_NCCL(ncclGroupEnd());
+    IROCM_HIP(hipMemcpyAsync(tmp + (size_t)rank * count * es, (const char *)x + (size_t)rank * count * es, (size_t)count * es,
+                             hipMemcpyDeviceToDevice, rt->stream));
+    long g = ceil_div(count, 256);
+    if (g > (long)rt->num_cu * 8) g = (long)rt->num_cu * 8;
+    if (dtype == INFINI_DT_F32)
+        hipLaunchKernelGGL(sum_slabs_kernel<float>, dim3((unsigned)g), dim3(256), 0, rt->stream, (const float *)tmp, (float *)y, (long)count, world);
+    else if (dtype == INFINI_DT_F16)
+        hipLaunchKernelGGL(sum_slabs_kernel<__half>, dim3((unsigned)g), dim3(256), 0, rt->stream, (const __half *)tmp, (__half *)y, (long)count, world);
+    else
+        hipLaunchKernelGGL(sum_slabs_kernel<__hip_bfloat16>, dim3((unsigned)g), dim3(256), 0, rt->stream, (const __hip_bfloat16 *)tmp,
+                           (__hip_bfloat16 *)y, (long)count, world);
+    IROCM_LAUNCH_CHECK("sum_slabs");
     return INFINI_ROCM_OK;
 }
 

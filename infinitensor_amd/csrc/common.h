@@ -132,6 +132,11 @@ struct infiniRocmRuntime {
     int num_cu = 256;
     void *comm = nullptr; // rcclComm_t, owned by comm.cc
     int comm_world = 1, comm_rank = 0;
+    // overlapped collectives (comm.hip: *_async / comm_join): a second stream and a small ring of fork / join events
+    hipStream_t comm_stream = nullptr;
+    std::vector<hipEvent_t> comm_events;
+    size_t comm_event_next = 0;
+    int comm_pending = 0; // async collectives issued since the last join
     std::mutex mu;
 };
 

@@ -416,6 +416,9 @@ int launch_gemm256p_nt2(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bo
 int launch_gemm256p_trace(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, int nt, unsigned long long *trace);
 } // namespace g256p
 int launch_gemm256_splitk(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool a_kmajor, bool b_kmajor, int splits);
+// implemented in gemm32.hip: the fp32 128^2 LDS-DMA tile kernel (v_mfma_f32_32x32x2_f32)
+bool fast32_supported(const GemmArgs &p, bool a_kmajor, bool b_kmajor);
+int launch_fast32(infiniRocmRuntime_t rt, GemmArgs p, bool b_kmajor, int small_tiles);
 
 template <typename Tr> static int launch_fast128(infiniRocmRuntime_t rt, GemmArgs p, bool akm, bool bkm) {
     p.tiles_m = (int)ceil_div(p.m, f128::BM);
@@ -454,8 +457,8 @@ static bool fast128_supported(const GemmArgs &p, bool akm, bool bkm) {
 }
 
 static const char *kVariantNames[] = {"generic64", "fast128_glds", "tile256", "tile256_splitk", "persist256", "persist192",
-                                      "persist128"};
-constexpr int kNumVariants = 7;
+                                      "persist128", "fast32"};
+constexpr int kNumVariants = 8; // 1-6 serve f16 / bf16, 7 serves f32, 0 everything
 
 // Cost model behind the heuristic (microseconds; fitted to tools/gemm_shapes.py on MI355X, bf16 / f16, N(0,1) data).
 // A workgroup of the persistent kernel walks its tiles: a K-tile of a 256 x 64 NT tile costs kKt[NT]; every tile pays its
@@ -576,8 +579,15 @@ int infini_rocm_matmul_grouped(infiniRocmRuntime_t rt, int dtype, const void *a,
     const bool akm = !trans_a, bkm = trans_b != 0;
 
     int variant = rt->matmul_variant;
-    if (dtype == INFINI_DT_F32)
-        variant = 0;
+    if (dtype == INFINI_DT_F32) {
+        // fp32: the LDS-DMA tile kernel (gemm32.hip; 128^2 or 64^2 tiles) when it can serve the operands and the problem has
+        // at least 16 tiles of 64^2 (or it is forced); the generic register-staged 64^2 kernel otherwise
+        const long tiles64 = ceil_div(m, 64) * ceil_div(n, 64) * batch;
+        const bool want = variant == 7 || (variant < 0 && tiles64 >= 16 && k >= 64);
+        variant = (want && fast32_supported(p, akm, bkm)) ? 7 : 0;
+    } else if (variant == 7) {
+        variant = -1;
+    }
     // split-K factor for the 256^2 kernel: fill the CUs when the tiles alone cannot and K is long enough that every
     // slice still runs >= 8 K-tiles (the fp32 partial planes cost 8 bytes per output element and slice)
     const long tiles256 = ceil_div(m, 256) * ceil_div(n, 256) * batch;
@@ -609,6 +619,8 @@ int infini_rocm_matmul_grouped(infiniRocmRuntime_t rt, int dtype, const void *a,
         }
         if (variant < 0)
             variant = fast128_supported(p, akm, bkm) ? 1 : 0;
+    } else if (dtype == INFINI_DT_F32) {
+        // 0 or 7, decided above: the 16-bit kernels below never see fp32 operands
     } else if (variant >= 2 && !gemm256_supported(p, akm, bkm)) {
         variant = fast128_supported(p, akm, bkm) ? 1 : 0;
     } else if (variant == 1 && !fast128_supported(p, akm, bkm)) {
@@ -616,9 +628,11 @@ int infini_rocm_matmul_grouped(infiniRocmRuntime_t rt, int dtype, const void *a,
     }
 
     // sigmoid / tanh / erff-Gelu epilogues and biases other than one row vector live in the one-shot kernel (gemm256p_kernel.h)
-    if (variant >= 4 && (!(act == 0 || act == 1 || act == 5) || (p.bias && !(p.bias_m == 0 && p.bias_n == 1))))
+    if (variant >= 4 && variant <= 6 && (!(act == 0 || act == 1 || act == 5) || (p.bias && !(p.bias_m == 0 && p.bias_n == 1))))
         variant = 2;
     rt->last_matmul_variant = variant;
+    if (variant == 7) // 128^2 tiles when they give at least ~half a tile per CU, 64^2 tiles otherwise (512^3: 64 tiles)
+        return launch_fast32(rt, p, bkm, ceil_div(m, 128) * ceil_div(n, 128) * batch * 2 < rt->num_cu ? 1 : 0);
     if (variant == 4)
         return g256p::launch_gemm256p_nt4(rt, dtype, p, akm, bkm);
     if (variant == 5)

@@ -140,7 +140,13 @@ int infini_rocm_runtime_destroy(infiniRocmRuntime_t rt) {
     if (rt->own_stream) {
         (void)hipStreamSynchronize(rt->own_stream);
     }
+    if (rt->comm_stream)
+        (void)hipStreamSynchronize(rt->comm_stream);
     (void)infini_rocm_comm_destroy(rt);
+    for (hipEvent_t e : rt->comm_events)
+        (void)hipEventDestroy(e);
+    if (rt->comm_stream)
+        (void)hipStreamDestroy(rt->comm_stream);
     if (rt->workspace)
         (void)hipFree(rt->workspace);
     for (void *p : rt->retired)
@@ -197,6 +203,8 @@ int infini_rocm_runtime_use_own_stream(infiniRocmRuntime_t rt) {
 int infini_rocm_runtime_sync(infiniRocmRuntime_t rt) {
     IROCM_CHECK_ARG(rt, "NULL runtime");
     IROCM_HIP(hipStreamSynchronize(rt->stream));
+    if (rt->comm_stream && rt->comm_pending) // async collectives nobody joined yet (comm.hip)
+        IROCM_HIP(hipStreamSynchronize(rt->comm_stream));
     return INFINI_ROCM_OK;
 }
 

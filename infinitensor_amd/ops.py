@@ -752,6 +752,31 @@ def all_reduce(rt: RocmRuntime, kind: str, x: torch.Tensor, out: torch.Tensor | 
     return out
 
 
+def all_reduce_async(rt: RocmRuntime, kind: str, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """The all-reduce on the runtime's comm stream, ordered after the work enqueued so far; later work on the runtime stream
+    does not wait for it until comm_join (infini_rocm_all_reduce_async)."""
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().infini_rocm_all_reduce_async(rt.handle, _RED[kind], dtype_of(x), _ptr(x), _ptr(out), x.numel()))
+    return out
+
+
+def comm_join(rt: RocmRuntime) -> None:
+    check(lib().infini_rocm_comm_join(rt.handle))
+
+
+def reduce_scatter(rt: RocmRuntime, x: torch.Tensor, direct: bool = False, out: torch.Tensor | None = None) -> torch.Tensor:
+    """out = sum over ranks of x[rank] for x of shape [world, ...] (infini_rocm_reduce_scatter); direct: the one-hop xGMI
+    exchange (grouped send / recv + local sum) instead of RCCL's algorithm choice."""
+    world, _ = rt.comm_info()
+    if x.shape[0] != world:
+        raise ValueError("reduce_scatter: leading dim must be the world size")
+    if out is None:
+        out = torch.empty(x.shape[1:], dtype=x.dtype, device=x.device)
+    check(lib().infini_rocm_reduce_scatter(rt.handle, dtype_of(x), _ptr(x), _ptr(out), out.numel(), 1 if direct else 0))
+    return out
+
+
 def all_gather(rt: RocmRuntime, x: torch.Tensor) -> list[torch.Tensor]:
     world, _ = rt.comm_info()
     buf = torch.empty((world,) + tuple(x.shape), dtype=x.dtype, device=x.device)

@@ -421,7 +421,7 @@ class FusionPlanner {
     bool tryRules(size_t i) {
         const auto type = ops[i]->getOpType();
         if (type == OpType::MatMul)
-            return planAttentionAt(i) || planMatmul(i) || planGroupedAhead(i);
+            return planAttentionAt(i) || planMatmul(i) || planRowParallelAllReduce(i) || planGroupedAhead(i);
         if (type == OpType::Transpose)
             return planAttentionFromTranspose(i) || planIntoCopy(i);
         if (type == OpType::Conv)
@@ -830,7 +830,8 @@ class FusionPlanner {
         for (size_t m : members)
             claimed[m] = 1;
         Operator nx = feedOn ? onlyUser(a.dstT) : nullptr;
-        if (nx && nx->getOpType() == OpType::MatMul && pos(nx) == a.last + 1) {
+        if (nx && nx->getOpType() == OpType::MatMul && pos(nx) == a.last + 1 &&
+            !(R && R->comm && R->comm->getWorldSize() > 1 && userOfType(nx->getOutput(), OpType::AllReduceSum, pos(nx)))) {
             auto mmn = as<MatmulObj>(nx);
             const auto [nb, nm, nn, nk] = mmn->getBMNK();
             bool onlyA = mmn->getInputs(0) == a.dstT;
@@ -1449,6 +1450,53 @@ class FusionPlanner {
              park ? std::vector<size_t>{i} : mem);
         if (parkAt)
             parked[parkAt + 1] = ParkedFeed{ops[parkAt]->getOutput().get(), (size_t)cBytes};
+        return true;
+    }
+
+    // Row-parallel MatMul -> AllReduceSum (the o_proj / down projections of a tensor-parallel block, parallel_opt.py:195-210):
+    // the reference issues ONE whole-tensor ncclAllReduce behind the whole GEMM (all_reduce.cc:10-33), so the xGMI links idle
+    // during the GEMM and the matrix cores during the exchange. Here the GEMM is cut into row chunks (tokens); each chunk's
+    // all-reduce goes to the runtime's comm stream as soon as its GEMM is enqueued and runs under the next chunk's GEMM; the
+    // runtime stream joins once at the end (infini_rocm_all_reduce_async / comm_join; capturable). Same operands per output
+    // element; a chunk's GEMM may pick another tile form than the whole GEMM (fp16 rounding of the summation order). Only
+    // with more than one rank (INFINI_ROCM_TP_OVERLAP=0 off, =force also at world 1: tests).
+    bool planRowParallelAllReduce(size_t i) {
+        static const char *env = std::getenv("INFINI_ROCM_TP_OVERLAP");
+        static const int mode = !env ? 1 : (std::string(env) == "force" ? 2 : std::atoi(env));
+        if (mode == 0 || !R || !R->comm || (mode != 2 && R->comm->getWorldSize() < 2))
+            return false;
+        auto mm = as<MatmulObj>(ops[i]);
+        const Tensor A = mm->getInputs(0), W = mm->getInputs(1), C = mm->getOutput();
+        Operator ar = userOfType(C, OpType::AllReduceSum, i);
+        if (!ar || mm->numInputs() != 2 || mm->getTransA() || W->getRank() != 2 || tunedVariant(ops[i]) >= 0)
+            return false;
+        const auto [b, m, nn, kk] = mm->getBMNK();
+        const int64_t rows = (int64_t)b * m;
+        constexpr int kChunks = 4;
+        if (rows % kChunks != 0 || rows / kChunks < 256)
+            return false;
+        const Tensor Y = ar->getOutput();
+        if (Y->getBytes() != C->getBytes() || overlaps(Y, A) || overlaps(Y, W) || overlaps(C, A) || overlaps(C, W))
+            return false;
+        std::vector<size_t> members{i, pos(ar)};
+        std::vector<Read> reads{{A, i}, {W, i}};
+        if (!readsSurvive(reads, pos(ar), members))
+            return false;
+        noteLateReads(reads, pos(ar));
+        const RocmRuntimeObj *r = R;
+        const int dt = A->getDTypeIndex(), tb = mm->getTransB() ? 1 : 0;
+        const int64_t n64 = nn, k64 = kk, es = (int64_t)A->getDType().getSize();
+        emit(pos(ar), members, "matmul>allreduce (4 row chunks, overlapped)", true, [r, A, W, C, Y, rows, n64, k64, es, dt, tb] {
+            const int64_t rc = rows / kChunks;
+            for (int c = 0; c < kChunks; ++c) {
+                const char *a = (const char *)A->getRawDataPtr<void *>() + (size_t)c * rc * k64 * es;
+                char *cc = (char *)C->getRawDataPtr<void *>() + (size_t)c * rc * n64 * es;
+                char *y = (char *)Y->getRawDataPtr<void *>() + (size_t)c * rc * n64 * es;
+                ROCM_CALL(infini_rocm_matmul(r->handle(), dt, a, W->getRawDataPtr<void *>(), nullptr, cc, 1, rc, n64, k64, 0, tb, 0, 0, 0, 0, 0, 0));
+                ROCM_CALL(infini_rocm_all_reduce_async(r->handle(), 0, dt, cc, y, rc * n64));
+            }
+            ROCM_CALL(infini_rocm_comm_join(r->handle()));
+        });
         return true;
     }
 

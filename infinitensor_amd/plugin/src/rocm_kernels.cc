@@ -158,8 +158,10 @@ class RocmTunableKernel : public Kernel {
 // ---- MatMul (reference: matmulCublas, src/kernels/cuda/matmul.cc:66-209) --------------------------
 class MatmulRocm : public RocmTunableKernel {
     int setVariant(infiniRocmRuntime_t rt, int v) const override { return infini_rocm_matmul_set_variant(rt, v); }
-    // fast128 (LDS-DMA 128^2), tile256 one-shot, tile256 split-K, persistent 256 / 192 / 128 (gemm.hip kVariantNames)
-    std::vector<int> candidates() const override { return {1, 2, 3, 4, 5, 6}; }
+    // fast128 (LDS-DMA 128^2), tile256 one-shot, tile256 split-K, persistent 256 / 192 / 128, and for fp32 the generic 64^2
+    // kernel against the 128^2 fp32 tile kernel (gemm.hip kVariantNames); a variant that cannot serve the operator's dtype
+    // or shape falls back below the ABI
+    std::vector<int> candidates() const override { return {0, 1, 2, 3, 4, 5, 6, 7}; }
     int recordType() const override { return kRocmMatmulRecord; }
     void launch(const Operator &_op, const RuntimeObj *ctx) const override {
         auto op = as<MatmulObj>(_op);
@@ -187,7 +189,8 @@ class MatmulRocm : public RocmTunableKernel {
                 bsb = (int64_t)bt->getDims()[bt->getRank() - 2] * bt->getDims()[bt->getRank() - 1];
             }
         }
-        // `act` of the operator is ignored like in the reference CUDA kernel (matmul.cc never reads getAct()). What the
+        // `act` and `getComputeType()` ("tf32" / "fp16" / "bf16": reduced-precision products for fp32 operands in the
+        // reference, matmul.cc:51-64) are not applied: fp32 operands are always multiplied exactly (gemm32.hip). What the
         // launch plan folded into THIS MatMul arrives through the overrides (rocm_fusion.cc): the row bias of a following
         // Add (onnx.py:280-290 imports MatMul without bias), a Gelu, a head-split store.
         const auto &ov = RocmRuntimeObj::overrides;

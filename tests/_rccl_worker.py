@@ -91,6 +91,49 @@ def main():
     assert np.allclose(out.cpu().numpy(), want["sum"])
     done.append("abi_all_reduce_hipgraph")
 
+    # Overlapped collectives (infini_rocm_all_reduce_async / comm_join): a "row-parallel GEMM" cut into 4 row chunks, each chunk's
+    # all-reduce on the comm stream under the next chunk's GEMM — equal to one GEMM + one whole-tensor all-reduce (a chunk's GEMM
+    # may pick another tile / split-K form than the whole GEMM: fp16 rounding of a different summation order, nothing more)
+    g2 = torch.Generator(device=f"cuda:{rank}").manual_seed(100 + rank)
+    a_ = (torch.randn(1024, 512, device=f"cuda:{rank}", generator=g2) * 0.1).to(torch.float16)
+    w_ = (torch.randn(512, 768, device=f"cuda:{rank}", generator=g2) * 0.1).to(torch.float16)
+    ref = ops.matmul(rt, a_, w_)
+    ops.all_reduce(rt, "sum", ref, out=ref)
+    got = torch.empty_like(ref)
+    for c in range(4):
+        sl = slice(c * 256, (c + 1) * 256)
+        ops.matmul(rt, a_[sl], w_, out=got[sl])
+        ops.all_reduce_async(rt, "sum", got[sl], out=got[sl])
+    ops.comm_join(rt)
+    rt.sync()
+    assert torch.allclose(got.float(), ref.float(), rtol=2e-3, atol=2e-3 * world)
+    # ... and the same sequence captured into a hipGraph (fork / join edges) and replayed
+    got2 = torch.zeros_like(ref)
+    rt.begin_capture()
+    for c in range(4):
+        sl = slice(c * 256, (c + 1) * 256)
+        ops.matmul(rt, a_[sl], w_, out=got2[sl])
+        ops.all_reduce_async(rt, "sum", got2[sl], out=got2[sl])
+    ops.comm_join(rt)
+    g = rt.end_capture()
+    for _ in range(2):
+        rt.launch_graph(g)
+    rt.sync()
+    assert torch.equal(got2, got)  # the replayed capture IS the eager sequence
+    done.append("abi_all_reduce_overlapped")
+    # reduce-scatter, RCCL's algorithm and the direct one-hop exchange (grouped send / recv + local fp32 sum), then all-gather
+    # == all-reduce
+    xs = torch.stack([torch.full((2, 64), float((rank + 1) * (r + 2)), device=f"cuda:{rank}") for r in range(world)]).to(torch.float16)
+    want_shard = float(sum((q + 1) * (rank + 2) for q in range(world)))
+    for direct in (False, True):
+        sh = ops.reduce_scatter(rt, xs, direct)
+        rt.sync()
+        assert torch.all(sh == want_shard).item(), (direct, sh[0, 0].item(), want_shard)
+        parts = ops.all_gather(rt, sh)
+        rt.sync()
+        assert all(torch.all(pp == float(sum((q + 1) * (r + 2) for q in range(world)))).item() for r, pp in enumerate(parts))
+    done.append("abi_reduce_scatter")
+
     # ---- reference executor + plugin -----------------------------------------------------------------
     from conftest import load_backend_module
 
@@ -138,6 +181,31 @@ def main():
         assert np.allclose(o.copyout_numpy().ravel(), want["sum"] + rep * world), rep
     assert prt.hip_graph_capture_count() == 1
     done.append("plugin_all_reduce_hipgraph")
+    # Row-parallel MatMul -> AllReduceSum planned as 4 overlapped row chunks (rocm_fusion.cc; with more than one rank, or
+    # forced by INFINI_ROCM_TP_OVERLAP=force): same bits as the reference-shaped launch (planning off)
+    F16 = 10
+    rng = np.random.default_rng(5 + rank)
+    av, wv = (rng.standard_normal((1024, 256)) * 0.1).astype(np.float16), (rng.standard_normal((256, 512)) * 0.1).astype(np.float16)
+    res = {}
+    for on in (True, False):
+        prt.set_fusion(on)
+        h = B.GraphHandler(prt)
+        ta, tw = h.tensor([1024, 256], F16), h.tensor([256, 512], F16)
+        ta.set_input()
+        tw.set_weight()
+        o = h.allReduceSum(h.matmul(ta, tw, None, False, False, None, B.ActType.Linear, "default"), None)
+        h.data_malloc()
+        ta.copyin_numpy(av)
+        tw.copyin_numpy(wv)
+        if on:
+            plan = h.rocm_fusion_plan()
+            overlapped = any("overlapped" in ln for ln in plan)
+            assert overlapped == (world > 1 or os.environ.get("INFINI_ROCM_TP_OVERLAP") == "force"), plan
+        h.run_with_hipgraph() if on else h.run()
+        res[on] = o.copyout_numpy()
+    prt.set_fusion(True)
+    assert np.allclose(res[True].astype(np.float32), res[False].astype(np.float32), rtol=2e-3, atol=2e-3 * world)
+    done.append("plugin_row_parallel_overlap")
     prt.sync()
     print("RESULT " + json.dumps({"rank": rank, "world": world, "done": done}), flush=True)
 

@@ -164,6 +164,51 @@ def test_matmul_fp32(rt, shape, ta, tb):
     assert (np.abs(got - want)[~big] <= 2e-5).all(), np.abs((got - want)[~big]).max()
 
 
+@pytest.mark.parametrize("shape", [(1, 128, 128, 32), (1, 1024, 1024, 1024), (3, 130, 132, 100), (1, 257, 516, 36), (2, 64, 8, 4),
+                                   (1, 2048, 1536, 260), (1, 512, 512, 512), (5, 2048, 2048, 64)])
+@pytest.mark.parametrize("tb", [False, True])
+@pytest.mark.parametrize("bias_form", [None, "row", "full"])
+def test_matmul_fp32_tile_kernel(rt, shape, tb, bias_form):
+    """The fp32 128^2 LDS-DMA tile kernel (gemm32.hip, v_mfma_f32_32x32x2_f32; variant "fast32", what the heuristic picks
+    for fp32 problems of at least half a tile per CU) forced over full, ragged, K-tail and batched shapes, NN (ONNX MatMul) and
+    NT (ONNX Gemm), with the bias forms of matmul.cc:86-118: the same 1e-4 RELATIVE gate as the generic kernel, and equal to
+    it within fp32 summation-order noise."""
+    b, m, n, k = shape
+    rng = np.random.default_rng(17)
+    a = rng.uniform(-1, 1, (b, m, k)).astype(np.float32)
+    bm = rng.uniform(-1, 1, (b, n, k) if tb else (b, k, n)).astype(np.float32)
+    bias = None if bias_form is None else rng.uniform(-1, 1, (n,) if bias_form == "row" else (b, m, n)).astype(np.float32)
+    v7 = ops.matmul_variants().index("fast32")
+    ops.set_matmul_variant(rt, v7)
+    try:
+        c = ops.matmul(rt, dev(a), dev(bm), None if bias is None else dev(bias), False, tb)
+        assert ops.matmul_last_variant(rt) == "fast32"
+        ops.set_matmul_variant(rt, 0)
+        c0 = ops.matmul(rt, dev(a), dev(bm), None if bias is None else dev(bias), False, tb)
+        assert ops.matmul_last_variant(rt) == "generic64"
+    finally:
+        ops.set_matmul_variant(rt, -1)
+    want = R.matmul(a, bm, bias, False, tb)
+    got = host(c)
+    big = np.abs(want) >= 1.0
+    assert (np.abs(got - want)[big] <= 1e-4 * np.abs(want)[big]).all(), np.abs((got - want)[big] / want[big]).max()
+    assert (np.abs(got - want)[~big] <= 2e-5 * max(1.0, k / 256)).all(), np.abs((got - want)[~big]).max()
+    assert np.allclose(got, host(c0), rtol=1e-5, atol=1e-5 * max(1.0, k / 64))
+
+
+def test_matmul_fp32_heuristic_picks_the_tile_kernel_for_large_problems(rt):
+    a = torch.randn(2048, 512, device="cuda")
+    b = torch.randn(512, 2048, device="cuda")
+    ops.matmul(rt, a, b)
+    assert ops.matmul_last_variant(rt) == "fast32"
+    ops.matmul(rt, a[:64].contiguous(), b)  # 32 tiles of 64^2: still the tile kernel, in its 64^2 form
+    assert ops.matmul_last_variant(rt) == "fast32"
+    ops.matmul(rt, a[:32, :32].contiguous(), b[:32, :64].contiguous())  # one tile, K = 32: the generic kernel
+    assert ops.matmul_last_variant(rt) == "generic64"
+    ops.matmul(rt, torch.randn(512, 2048, device="cuda"), torch.randn(512, 2048, device="cuda"), None, True, False)  # transA: not served
+    assert ops.matmul_last_variant(rt) == "generic64"
+
+
 def test_matmul_bias_broadcast_forms(rt):
     """bias broadcast into C like the reference (matmul.cc:86-118): [n], [m,n], [1], [b,m,n]."""
     rng = np.random.default_rng(11)
@@ -187,7 +232,7 @@ def test_matmul_headline_shape_sampled_rows(rt):
     b64 = b.float().cpu().numpy().astype(np.float64)
     want = a64 @ b64
     for v, name in enumerate(ops.matmul_variants()):
-        if v == 0:
+        if v == 0 or name == "fast32":  # (fast32 serves fp32 only)
             continue
         ops.set_matmul_variant(rt, v)
         try:

@@ -27,11 +27,11 @@ def need(n):
     return pytest.mark.skipif(NGPU < n, reason=f"needs {n} GPUs on one node (have {NGPU})")
 
 
-def launch(world: int, script: Path, cwd: Path, extra_args=(), timeout=600):
+def launch(world: int, script: Path, cwd: Path, extra_args=(), timeout=600, extra_env=None):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, str(script), *extra_args], env=env, cwd=cwd, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = []
@@ -55,7 +55,16 @@ def test_rccl_collectives_match_the_reference_tests(world, tmp_path):
         res = json.loads([ln for ln in so.splitlines() if ln.startswith("RESULT ")][-1][7:])
         assert res["rank"] == r and res["world"] == world
         assert set(res["done"]) >= {"abi_all_reduce", "abi_all_gather", "abi_broadcast", "abi_send_recv",
-                                    "abi_all_reduce_hipgraph", "plugin_collectives", "plugin_all_reduce_hipgraph"}
+                                    "abi_all_reduce_hipgraph", "plugin_collectives", "plugin_all_reduce_hipgraph",
+                                    "abi_all_reduce_overlapped", "abi_reduce_scatter", "plugin_row_parallel_overlap"}
+
+
+def test_row_parallel_overlap_forced_on_one_rank(tmp_path):
+    """The chunked, overlapped MatMul -> AllReduceSum launch only plans itself with more than one rank; forced here at
+    world 1 so that the code path (comm stream, fork / join events, capture) runs on the builder's one-GPU boxes too."""
+    outs = launch(1, REPO / "tests" / "_rccl_worker.py", tmp_path, extra_env={"INFINI_ROCM_TP_OVERLAP": "force"})
+    res = json.loads([ln for ln in outs[0].splitlines() if ln.startswith("RESULT ")][-1][7:])
+    assert "plugin_row_parallel_overlap" in res["done"]
 
 
 @need(2)
