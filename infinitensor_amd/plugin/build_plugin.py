@@ -77,6 +77,7 @@ PATCHES = [
      "        .def(\"fused_launch_count\", &RocmRuntimeObj::getFusedLaunchCount)\n"
      "        .def(\"bridged_input_count\", &RocmRuntimeObj::getBridgedInputCount)\n"
      "        .def(\"parked_member_count\", &RocmRuntimeObj::getParkedMemberCount)\n"
+     "        .def(\"forwarded_output_count\", &RocmRuntimeObj::getForwardedCount)\n"
      "        .def_static(\"save_perf\", &RocmRuntimeObj::savePerfData)\n"
      "        .def_static(\"load_perf\", &RocmRuntimeObj::loadPerfData)\n"
      "        .def_static(\"clear_perf\", &RocmRuntimeObj::clearPerfData)\n"

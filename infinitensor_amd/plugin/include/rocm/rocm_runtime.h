@@ -100,7 +100,17 @@ class RocmRuntimeObj : public RuntimeObj {
         std::function<void()> run;  // empty: nothing to launch (the operators were absorbed by another item)
         bool fused = false;
     };
-    using LaunchPlan = std::vector<PlanItem>;
+    // Buffer forwarding: a tensor whose value a planned launch left in ANOTHER buffer than the tensor's own (the fused conv
+    // chain whose planned output buffer overlaps the conv's input writes into the Conv operator's own, otherwise unused,
+    // output buffer instead); every reader of the tensor — planned items and plain kernels (P() in rocm_kernels.cc) —
+    // resolves it through this map while the plan is made and while it runs.
+    using ForwardMap = std::unordered_map<const TensorObj *, void *>;
+    static thread_local const ForwardMap *forwards;
+    struct LaunchPlan {
+        std::vector<PlanItem> items;
+        std::shared_ptr<ForwardMap> forwarded;
+    };
+    size_t getForwardedCount() const { return forwardedCount; } // fused chains that wrote into a forwarded buffer (tests)
     // What launchAll would do for `graph` (any runtime: on a non-ROCM runtime nothing can be launched, the plan is only
     // described) — one line per item: "<slot> <what> [members]". Tests and tools/plan_dump.py read it.
     static std::vector<std::string> describeFusionPlan(const Graph &graph);
@@ -158,6 +168,7 @@ class RocmRuntimeObj : public RuntimeObj {
     mutable size_t fusedCount = 0;
     mutable size_t bridgedCount = 0;
     mutable size_t parkedCount = 0;
+    mutable size_t forwardedCount = 0;
     // values of one-element constant tensors (weights no operator writes) the planner looked at — Pow's exponent, the
     // sqrt(2) / 0.5 / 1 of a decomposed Gelu, LayerNorm's epsilon — keyed by device address; dropped by host writes
     mutable std::map<const void *, std::pair<size_t, double>> scalarCache;

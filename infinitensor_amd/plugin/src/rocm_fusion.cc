@@ -71,6 +71,7 @@
 namespace infini {
 
 thread_local RocmRuntimeObj::LaunchOverrides RocmRuntimeObj::overrides;
+thread_local const RocmRuntimeObj::ForwardMap *RocmRuntimeObj::forwards = nullptr;
 
 namespace {
 using PlanItem = RocmRuntimeObj::PlanItem;
@@ -92,7 +93,17 @@ bool envOn(const char *name) { // default on; NAME=0 is the A/B hook
     const char *e = std::getenv(name);
     return !(e && std::atoi(e) == 0);
 }
-uintptr_t addrOf(const Tensor &t) { return reinterpret_cast<uintptr_t>(t->getRawDataPtr<void *>()); }
+// where a tensor's value lives: its own buffer, unless the plan forwarded it (RocmRuntimeObj::ForwardMap) — valid while a
+// plan is being made (the planner installs its map) and while it runs (executePlan does)
+void *dataPtr(const Tensor &t) {
+    if (RocmRuntimeObj::forwards) {
+        auto it = RocmRuntimeObj::forwards->find(t.get());
+        if (it != RocmRuntimeObj::forwards->end())
+            return it->second;
+    }
+    return t->getRawDataPtr<void *>();
+}
+uintptr_t addrOf(const Tensor &t) { return reinterpret_cast<uintptr_t>(dataPtr(t)); }
 bool overlaps(const Tensor &a, const Tensor &b) {
     const auto pa = addrOf(a), pb = addrOf(b);
     return pa < pb + b->getBytes() && pb < pa + a->getBytes();
@@ -168,11 +179,14 @@ class FusionPlanner {
   public:
     FusionPlanner(const RocmRuntimeObj *R, const OpVec &ops, bool fusion)
         : R(R), rt(R ? R->handle() : nullptr), ops(ops), n(ops.size()), fusion(fusion), claimed(ops.size(), 0),
-          writeAt(ops.size(), -1), log(std::getenv("INFINI_ROCM_FUSION_LOG") != nullptr) {
+          writeAt(ops.size(), -1), log(std::getenv("INFINI_ROCM_FUSION_LOG") != nullptr),
+          fwd(std::make_shared<RocmRuntimeObj::ForwardMap>()) {
         posOf.reserve(n * 2);
         for (size_t i = 0; i < n; ++i)
             posOf[ops[i].get()] = i;
+        RocmRuntimeObj::forwards = fwd.get(); // addrOf / dataPtr see the forwarded buffers while the plan is made
     }
+    ~FusionPlanner() { RocmRuntimeObj::forwards = nullptr; }
 
     LaunchPlan run() {
         for (size_t i = 0; i < n; ++i) {
@@ -202,7 +216,10 @@ class FusionPlanner {
             }
         }
         std::stable_sort(items.begin(), items.end(), [](const PlanItem &a, const PlanItem &b) { return a.slot < b.slot; });
-        return std::move(items);
+        LaunchPlan plan;
+        plan.items = std::move(items);
+        plan.forwarded = fwd;
+        return plan;
     }
 
   private:
@@ -216,8 +233,9 @@ class FusionPlanner {
     // not materialised, a grouped result parked in the workspace)
     std::vector<long> writeAt;
     std::unordered_map<const OperatorObj *, size_t> posOf;
-    LaunchPlan items;
+    std::vector<PlanItem> items;
     const bool log;
+    std::shared_ptr<RocmRuntimeObj::ForwardMap> fwd;
     struct LateRead { // a sunk item reads `t` at `to` instead of `from`
         size_t from, to;
         Tensor t;
@@ -350,7 +368,7 @@ class FusionPlanner {
     bool scalarOf(const Tensor &t, double &v) const {
         if (t->size() != 1 || !persistent(t) || !t->hasData())
             return false;
-        const void *p = t->getRawDataPtr<void *>();
+        const void *p = dataPtr(t);
         if (R) {
             auto it = R->scalarCache.find(p);
             if (it != R->scalarCache.end() && it->second.first == t->getBytes()) {
@@ -566,8 +584,8 @@ class FusionPlanner {
         const int64_t nn = x->getDims().back(), outer = (int64_t)x->size() / nn;
         const float eps = (float)m.eps;
         emit(m.last, m.members, "layer_norm(decomposed)", true, [r, xx, g, b, out, nn, outer, eps] {
-            ROCM_CALL(infini_rocm_layer_norm(r->handle(), xx->getDTypeIndex(), xx->getRawDataPtr<void *>(), g->getRawDataPtr<void *>(),
-                                             b ? b->getRawDataPtr<void *>() : nullptr, out->getRawDataPtr<void *>(), outer, nn,
+            ROCM_CALL(infini_rocm_layer_norm(r->handle(), xx->getDTypeIndex(), dataPtr(xx), dataPtr(g),
+                                             b ? dataPtr(b) : nullptr, dataPtr(out), outer, nn,
                                              (int64_t)g->size(), b ? (int64_t)b->size() : 0, eps));
         });
         return true;
@@ -653,8 +671,8 @@ class FusionPlanner {
             const RocmRuntimeObj *r = R;
             const Tensor xx = x, out = m.out;
             emit(m.last, m.members, "gelu(decomposed)", true, [r, xx, out] {
-                ROCM_CALL(infini_rocm_unary(r->handle(), INFINI_UN_GELU, xx->getDTypeIndex(), xx->getRawDataPtr<void *>(),
-                                            out->getRawDataPtr<void *>(), out->size(), NAN, NAN));
+                ROCM_CALL(infini_rocm_unary(r->handle(), INFINI_UN_GELU, xx->getDTypeIndex(), dataPtr(xx),
+                                            dataPtr(out), out->size(), NAN, NAN));
             });
             return true;
         }
@@ -809,14 +827,14 @@ class FusionPlanner {
         const RocmRuntimeObj *r = R;
         const AttnPlan ap = a;
         auto attn = [r, ap, group](void *dst) {
-            ROCM_CALL(infini_rocm_attention_ex(r->handle(), ap.dt, ap.q->getRawDataPtr<void *>(), ap.kbuf->getRawDataPtr<void *>(),
-                                               ap.v->getRawDataPtr<void *>(), ap.mask ? ap.mask->getRawDataPtr<void *>() : nullptr, dst,
+            ROCM_CALL(infini_rocm_attention_ex(r->handle(), ap.dt, dataPtr(ap.q), dataPtr(ap.kbuf),
+                                               dataPtr(ap.v), ap.mask ? dataPtr(ap.mask) : nullptr, dst,
                                                (int64_t)ap.b * ap.h, ap.sq, ap.sk, ap.d, group,
-                                               ap.scale ? ap.scale->getRawDataPtr<void *>() : nullptr, ap.isDiv ? 1 : 0, 1.0f, 0, ap.heads,
+                                               ap.scale ? dataPtr(ap.scale) : nullptr, ap.isDiv ? 1 : 0, 1.0f, 0, ap.heads,
                                                ap.mask2d ? 1 : 0));
         };
         if (!hazard) {
-            emit(a.last, a.members, "attention", true, [attn, ap] { attn(ap.dstT->getRawDataPtr<void *>()); });
+            emit(a.last, a.members, "attention", true, [attn, ap] { attn(dataPtr(ap.dstT)); });
             return;
         }
         // The bridged result usually feeds exactly one operator, the output projection, right behind the chain: let that
@@ -840,6 +858,10 @@ class FusionPlanner {
             if (!mayUseWorkspace(nb, nm, nn) && onlyA && tunedVariant(nx) != 3) {
                 MMChain ch = buildMatmulChain(pos(nx), /*contiguousOnly*/ true, a.dstT);
                 if (ch.ok && !ch.attn) {
+                    if (ch.fwdTo) {
+                        (*fwd)[ch.out.get()] = ch.fwdTo;
+                        lateReads.push_back({ch.slot, ch.fwdLastUse, ch.mm->getOutput()});
+                    }
                     std::vector<size_t> all = members;
                     all.insert(all.end(), ch.members.begin(), ch.members.end());
                     noteLateReads(ch.reads, ch.slot);
@@ -855,7 +877,7 @@ class FusionPlanner {
         emit(a.last, members, "attention(bridged)+copy", true, [r, attn, ap, bytes] {
             void *ws = r->getWorkspace(bytes);
             attn(ws);
-            ROCM_CALL(infini_rocm_copy_inside(r->handle(), ap.dstT->getRawDataPtr<void *>(), ws, bytes));
+            ROCM_CALL(infini_rocm_copy_inside(r->handle(), dataPtr(ap.dstT), ws, bytes));
         });
     }
 
@@ -894,7 +916,7 @@ class FusionPlanner {
                 const auto &d = in->getDims();
                 const int64_t shape[4] = {d[0], d[1], d[2], d[3]};
                 const int p[4] = {0, 2, 1, 3};
-                ROCM_CALL(infini_rocm_transpose(r->handle(), in->getDTypeIndex(), in->getRawDataPtr<void *>(), kx->getRawDataPtr<void *>(), 4,
+                ROCM_CALL(infini_rocm_transpose(r->handle(), in->getDTypeIndex(), dataPtr(in), dataPtr(kx), 4,
                                                 shape, p));
             });
             commitAttention(a);
@@ -922,6 +944,8 @@ class FusionPlanner {
         int n = 0, k = 0;
         std::optional<AttnPlan> attn; // committed together with the chain (kHeadMajor)
         std::string what;
+        void *fwdTo = nullptr;        // the result goes to the MatMul's own output buffer and `out` is forwarded there
+        size_t fwdLastUse = 0;
     };
 
     // The longest fusable chain headed by the MatMul at `i` (ok = false: nothing to fold — not even a redirect).
@@ -952,7 +976,10 @@ class FusionPlanner {
         c.what = "matmul";
         // a candidate is valid when the reads of its earlier members survive until its slot and its output buffer does
         // not overlap what the GEMM reads
-        auto valid = [&](const MMChain &x) {
+        auto valid = [&](MMChain &x) {
+            x.fwdTo = nullptr;
+            if (const auto sfx = x.what.find(" (output forwarded)"); sfx != std::string::npos)
+                x.what.erase(sfx, 19);
             if (contiguousOnly) {
                 for (size_t q = 1; q < x.members.size(); ++q)
                     if (x.members[q] != x.members[q - 1] + 1)
@@ -960,11 +987,34 @@ class FusionPlanner {
             }
             if (!readsSurvive(x.reads, x.slot, x.members))
                 return false;
+            bool clash = x.biasSrc && overlaps(x.out, x.biasSrc);
             for (const auto &rd : x.reads)
-                if (overlaps(x.out, rd.t))
-                    return false;
-            if (x.biasSrc && overlaps(x.out, x.biasSrc))
+                clash = clash || overlaps(x.out, rd.t);
+            if (!clash)
+                return true;
+            // The planner put the chain's output on something the GEMM still reads (typically: the bias Add's output on the
+            // MatMul's dead A operand). The MatMul's OWN output buffer was allocated while every operand was live: write
+            // there and forward the chain's final tensor to it, if that block stays untouched until the tensor's last reader
+            // (plain store forms only: a head-split / K-for-attention store has a consumer that addresses the buffer itself).
+            static const bool fwdOn = envOn("INFINI_ROCM_FORWARD");
+            if (!fwdOn || x.out == C || x.store == 1 || x.out->isOutput() || x.out->getBytes() != C->getBytes() ||
+                x.out->getTargets().empty() || (x.biasSrc && overlaps(C, x.biasSrc)))
                 return false;
+            for (const auto &rd : x.reads)
+                if (overlaps(C, rd.t))
+                    return false;
+            size_t lastUse = x.slot;
+            for (const auto &u : x.out->getTargets()) {
+                auto it = posOf.find(u.get());
+                if (it == posOf.end() || it->second <= x.slot || claimed[it->second]) // (see planConv: an already-planned reader)
+                    return false;
+                lastUse = std::max(lastUse, it->second);
+            }
+            if (!survives(C, x.slot, lastUse + 1, x.members))
+                return false;
+            x.fwdTo = C->getRawDataPtr<void *>();
+            x.fwdLastUse = lastUse;
+            x.what += " (output forwarded)";
             return true;
         };
         auto add = [&](MMChain &x, size_t p) {
@@ -1114,14 +1164,16 @@ class FusionPlanner {
             auto &o = RocmRuntimeObj::overrides;
             o.matmul = op.get();
             if (cc.biasSrc)
-                o.biasPtr = cc.biasSrc->getRawDataPtr<void *>();
+                o.biasPtr = dataPtr(cc.biasSrc);
             o.act = cc.act;
             if (cc.store == 1) {
                 o.seq = (int)cc.S;
                 o.headDim = (int)cc.D;
             }
-            if (cc.out != cc.mm->getOutput())
-                s.redirect(cc.mm->getOutput().get(), cc.out->getRawDataPtr<void *>());
+            if (cc.fwdTo)
+                ++r->forwardedCount;
+            if (cc.out != cc.mm->getOutput()) // (a forwarded `out` resolves to the MatMul's own buffer: a no-op redirect)
+                s.redirect(cc.mm->getOutput().get(), dataPtr(cc.out));
             if (feedT)
                 s.redirect(feedT, r->getWorkspace(feedBytes));
             r->launchOne(op);
@@ -1130,6 +1182,10 @@ class FusionPlanner {
 
     void commitChain(const MMChain &c) {
         noteLateReads(c.reads, c.slot);
+        if (c.fwdTo) {
+            (*fwd)[c.out.get()] = c.fwdTo;
+            lateReads.push_back({c.slot, c.fwdLastUse, c.mm->getOutput()});
+        }
         emit(c.slot, c.members, c.what, true, chainLaunch(c, nullptr, 0));
         if (c.attn)
             commitAttention(*c.attn);
@@ -1171,7 +1227,7 @@ class FusionPlanner {
                 if (j < i)
                     continue;
                 MMChain hn = buildMatmulChain(j, false);
-                if (!hn.ok || hn.store != 1 || hn.act != 0)
+                if (!hn.ok || hn.store != 1 || hn.act != 0 || hn.fwdTo)
                     continue;
                 const auto &mn = hn.mm;
                 const Tensor wn = mn->getInputs(1), bn = biasOf(hn);
@@ -1272,8 +1328,8 @@ class FusionPlanner {
             writers.push_back(c.members.back());
         emit(slot, members, pick[0].what + " x" + std::to_string(cnt) + " (grouped)", true,
              [r, A, w0, bias0, out0, cnt, rows, nn, kk, strideB, strideBias, S, D, dt] {
-                 ROCM_CALL(infini_rocm_matmul_headsplit(r->handle(), dt, A->getRawDataPtr<void *>(), w0->getRawDataPtr<void *>(),
-                                                        bias0 ? bias0->getRawDataPtr<void *>() : nullptr, out0->getRawDataPtr<void *>(), cnt,
+                 ROCM_CALL(infini_rocm_matmul_headsplit(r->handle(), dt, dataPtr(A), dataPtr(w0),
+                                                        bias0 ? dataPtr(bias0) : nullptr, dataPtr(out0), cnt,
                                                         rows, nn, kk, 0, 0, /*strideA*/ 0, strideB, strideBias, 0, bias0 ? 1 : 0, 0, S, D));
              },
              writers);
@@ -1439,12 +1495,12 @@ class FusionPlanner {
                  intptr_t dcv = dc;
                  if (park) {
                      void *p = r->getWorkspace((size_t)cBytes);
-                     dcv = (intptr_t)p - (intptr_t)O->getRawDataPtr<void *>();
+                     dcv = (intptr_t)p - (intptr_t)dataPtr(O);
                      IT_ASSERT(dcv % 16 == 0 && !(dcv < cBytes && dcv > -cBytes), "parked GEMM output collides with the group's own");
                      ++r->parkedCount;
                  }
-                 ROCM_CALL(infini_rocm_matmul_grouped(r->handle(), dt, A->getRawDataPtr<void *>(), W->getRawDataPtr<void *>(),
-                                                      Bs ? Bs->getRawDataPtr<void *>() : nullptr, O->getRawDataPtr<void *>(), (int64_t)cnt,
+                 ROCM_CALL(infini_rocm_matmul_grouped(r->handle(), dt, dataPtr(A), dataPtr(W),
+                                                      Bs ? dataPtr(Bs) : nullptr, dataPtr(O), (int64_t)cnt,
                                                       rows, n64, k64, 0, tb, /*strideA*/ 0, dw / es, dcv / es, db / es, 0, Bs ? 1 : 0, 0, 0, 0));
              },
              park ? std::vector<size_t>{i} : mem);
@@ -1489,10 +1545,10 @@ class FusionPlanner {
         emit(pos(ar), members, "matmul>allreduce (4 row chunks, overlapped)", true, [r, A, W, C, Y, rows, n64, k64, es, dt, tb] {
             const int64_t rc = rows / kChunks;
             for (int c = 0; c < kChunks; ++c) {
-                const char *a = (const char *)A->getRawDataPtr<void *>() + (size_t)c * rc * k64 * es;
-                char *cc = (char *)C->getRawDataPtr<void *>() + (size_t)c * rc * n64 * es;
-                char *y = (char *)Y->getRawDataPtr<void *>() + (size_t)c * rc * n64 * es;
-                ROCM_CALL(infini_rocm_matmul(r->handle(), dt, a, W->getRawDataPtr<void *>(), nullptr, cc, 1, rc, n64, k64, 0, tb, 0, 0, 0, 0, 0, 0));
+                const char *a = (const char *)dataPtr(A) + (size_t)c * rc * k64 * es;
+                char *cc = (char *)dataPtr(C) + (size_t)c * rc * n64 * es;
+                char *y = (char *)dataPtr(Y) + (size_t)c * rc * n64 * es;
+                ROCM_CALL(infini_rocm_matmul(r->handle(), dt, a, dataPtr(W), nullptr, cc, 1, rc, n64, k64, 0, tb, 0, 0, 0, 0, 0, 0));
                 ROCM_CALL(infini_rocm_all_reduce_async(r->handle(), 0, dt, cc, y, rc * n64));
             }
             ROCM_CALL(infini_rocm_comm_join(r->handle()));
@@ -1596,23 +1652,61 @@ class FusionPlanner {
             static const bool bridgeOn = envOn("INFINI_ROCM_BRIDGE_X");
             const bool bridgeX = bridgeOn && onX && sh == 1 && sw == 1 && conv->getNumGroups() == 1 && ch < 1024 && ch % 32 == 0 &&
                                  (size_t)x->getBytes() * 3 <= (size_t)c.last->getBytes();
-            if (!(c.last->getDType() == x->getDType()) || (onX && !bridgeX) || overlaps(c.last, w) ||
-                (c.biasSrc && overlaps(c.last, c.biasSrc)) || resHazard)
+            if (!(c.last->getDType() == x->getDType()))
                 continue;
+            const bool otherHazard = overlaps(c.last, w) || (c.biasSrc && overlaps(c.last, c.biasSrc)) || resHazard;
+            const bool hazard = onX || otherHazard; // (forwarding costs nothing: it is tried before the bridging copy)
+            // Buffer forwarding. The chain's planned output buffer is unusable (it sits on something the conv still reads —
+            // the memory planner recycles the conv's dead input for the tail's output), but the Conv operator's OWN output
+            // buffer was allocated while every operand was live and nobody else needs it once the tail is folded: the fused
+            // kernel writes there, and every reader of the chain's final tensor is pointed there (ForwardMap) — provided
+            // nothing the planner placed on that (in its eyes free) block is written before the tensor's last reader ran.
+            void *fwdTo = nullptr;
+            size_t lastUse = c.slot;
+            if (hazard) {
+                static const bool fwdOn = envOn("INFINI_ROCM_FORWARD");
+                const Tensor y = conv->getOutput(), tfin = c.last;
+                bool ok = fwdOn && c.members.size() > 1 && !tfin->isOutput() && y->getBytes() == tfin->getBytes() && !overlaps(y, x) &&
+                          !overlaps(y, w) && !(c.biasSrc && overlaps(y, c.biasSrc)) && !(c.res && overlaps(y, c.res)) &&
+                          !tfin->getTargets().empty();
+                for (const auto &u : tfin->getTargets()) {
+                    auto it = posOf.find(u.get());
+                    // a reader some EARLIER-planned item already owns was checked against the tensor's own buffer (its
+                    // in-kernel hazards, the survival of what it reads until its slot): it cannot be re-pointed now
+                    ok = ok && it != posOf.end() && it->second > c.slot && !claimed[it->second];
+                    if (ok)
+                        lastUse = std::max(lastUse, it->second);
+                }
+                // nothing may land on y's block up to and including the last reader (a reader's own output too: a plain
+                // kernel does not know its input moved)
+                ok = ok && survives(y, c.slot, lastUse + 1, c.members);
+                if (ok)
+                    fwdTo = y->getRawDataPtr<void *>();
+                else if (otherHazard || !bridgeX)
+                    continue;
+            }
             noteLateReads(c.reads, c.slot);
+            if (fwdTo) {
+                (*fwd)[c.last.get()] = fwdTo;
+                lateReads.push_back({c.slot, lastUse, conv->getOutput()}); // y's block stays in use until then
+            }
             const RocmRuntimeObj *r = R;
             const Operator op = ops[i];
             const Tensor X = x, Wt = w, Bs = c.biasSrc, Rs = c.res, Out = c.last;
+            const bool forwarded = fwdTo != nullptr;
             const int act = c.act, groups = conv->getNumGroups();
             const int variant = tunedVariant(op);
             const int n_ = nb, c_ = ch, h_ = hh, w_ = wd, f_ = ff, r_ = rr, s_ = ss, ph_ = ph, pw_ = pw, sh_ = sh, sw_ = sw, dh_ = dh, dw_ = dw;
             const bool lg = log;
             const size_t idx = i;
+            const bool bridge = bridgeX && !forwarded;
             std::string what = std::string("conv") + (c.biasSrc ? "+bias" : "") + (c.res ? "+res" : "") + (c.act ? "+relu" : "") +
-                               (bridgeX ? " (x bridged)" : "");
+                               (bridge ? " (x bridged)" : "") + (forwarded ? " (output forwarded)" : "");
             emit(c.slot, c.members, what, true, [=] {
-                const void *xptr = X->getRawDataPtr<void *>();
-                if (bridgeX) {
+                const void *xptr = dataPtr(X);
+                if (forwarded)
+                    ++r->forwardedCount;
+                if (bridge) {
                     const size_t kpad = ((size_t)c_ * r_ * s_ + 31) & ~(size_t)31;
                     const size_t wArea = ((std::max((size_t)f_ * c_ * r_ * s_, (size_t)f_ * kpad) * 2 + 4096) + 255) & ~(size_t)255;
                     char *ws = (char *)r->getWorkspace(wArea + X->getBytes());
@@ -1636,9 +1730,9 @@ class FusionPlanner {
                     }
                 } scope(r->handle(), variant);
                 ConstWeightsScope constWeights(r->handle(), Wt); // graph weights: pack once, cache (rocm_runtime.h)
-                ROCM_CALL(infini_rocm_conv2d_res(r->handle(), X->getDTypeIndex(), xptr, Wt->getRawDataPtr<void *>(),
-                                                 Bs ? Bs->getRawDataPtr<void *>() : nullptr, Rs ? Rs->getRawDataPtr<void *>() : nullptr,
-                                                 Out->getRawDataPtr<void *>(), n_, c_, h_, w_, f_, r_, s_, ph_, pw_, sh_, sw_, dh_, dw_, groups,
+                ROCM_CALL(infini_rocm_conv2d_res(r->handle(), X->getDTypeIndex(), xptr, dataPtr(Wt),
+                                                 Bs ? dataPtr(Bs) : nullptr, Rs ? dataPtr(Rs) : nullptr,
+                                                 dataPtr(Out), n_, c_, h_, w_, f_, r_, s_, ph_, pw_, sh_, sw_, dh_, dw_, groups,
                                                  act));
             });
             return true;
@@ -1683,8 +1777,8 @@ class FusionPlanner {
         if (bParked)
             parked.erase(pf);
         emit(m, members, bParked ? "silu_mul(parked b)" : "silu_mul", true, [r, a, b, out, dt, bParked, pbytes] {
-            const void *bp = bParked ? r->getWorkspace(pbytes) : b->getRawDataPtr<void *>();
-            ROCM_CALL(infini_rocm_silu_mul(r->handle(), dt, a->getRawDataPtr<void *>(), bp, out->getRawDataPtr<void *>(), (int64_t)out->size()));
+            const void *bp = bParked ? r->getWorkspace(pbytes) : dataPtr(b);
+            ROCM_CALL(infini_rocm_silu_mul(r->handle(), dt, dataPtr(a), bp, dataPtr(out), (int64_t)out->size()));
         });
         return true;
     }
@@ -1707,7 +1801,7 @@ class FusionPlanner {
         const RocmRuntimeObj *r = R;
         const int n_ = nb, c_ = c, h_ = h, w_ = w, kh_ = kh, kw_ = kw, ph_ = ph, pw_ = pw, sh_ = sh, sw_ = sw, dh_ = dh, dw_ = dw;
         emit(pos(pl), members, "relu+maxpool", true, [=] {
-            ROCM_CALL(infini_rocm_pool2d_relu(r->handle(), 0, x->getDTypeIndex(), x->getRawDataPtr<void *>(), out->getRawDataPtr<void *>(), n_,
+            ROCM_CALL(infini_rocm_pool2d_relu(r->handle(), 0, x->getDTypeIndex(), dataPtr(x), dataPtr(out), n_,
                                               c_, h_, w_, kh_, kw_, dh_, dw_, ph_, pw_, sh_, sw_, ceil, 1));
         });
         return true;
@@ -1803,10 +1897,10 @@ class FusionPlanner {
         const RocmRuntimeObj *r = R;
         const int dt = t->getDTypeIndex();
         emit(slot, members, what, true, [r, a, b, pre, scale, bias, out, outer, nn, eps, rms, dt] {
-            ROCM_CALL(infini_rocm_bias_add_norm(r->handle(), dt, rms ? 1 : 0, a->getRawDataPtr<void *>(),
-                                                pre ? pre->getRawDataPtr<void *>() : nullptr, b->getRawDataPtr<void *>(),
-                                                scale->getRawDataPtr<void *>(), bias ? bias->getRawDataPtr<void *>() : nullptr,
-                                                out->getRawDataPtr<void *>(), outer, nn, (int64_t)scale->size(),
+            ROCM_CALL(infini_rocm_bias_add_norm(r->handle(), dt, rms ? 1 : 0, dataPtr(a),
+                                                pre ? dataPtr(pre) : nullptr, dataPtr(b),
+                                                dataPtr(scale), bias ? dataPtr(bias) : nullptr,
+                                                dataPtr(out), outer, nn, (int64_t)scale->size(),
                                                 bias ? (int64_t)bias->size() : 0, eps));
         });
         return true;
@@ -1862,8 +1956,8 @@ class FusionPlanner {
         const int dt = t->getDTypeIndex();
         const int64_t d0 = td[0], d1 = td[1];
         emit(slot, members, relu ? "bias+res+relu" : "bias+res", true, [r, xin, biasSrc, res, out, d0, d1, inner, relu, dt] {
-            ROCM_CALL(infini_rocm_bias_residual(r->handle(), dt, xin->getRawDataPtr<void *>(), biasSrc->getRawDataPtr<void *>(),
-                                                res->getRawDataPtr<void *>(), out->getRawDataPtr<void *>(), d0, d1, inner, relu));
+            ROCM_CALL(infini_rocm_bias_residual(r->handle(), dt, dataPtr(xin), dataPtr(biasSrc),
+                                                dataPtr(res), dataPtr(out), d0, d1, inner, relu));
         });
         return true;
     }
@@ -1889,8 +1983,8 @@ class FusionPlanner {
         emit(pos(rl), members, "add+relu", true, [r, a, b, out, od] {
             const auto shape = std::vector<int64_t>(od.begin(), od.end());
             const auto sa = strides64(a->getDims(), od), sb = strides64(b->getDims(), od);
-            ROCM_CALL(infini_rocm_binary(r->handle(), INFINI_BIN_ADD_RELU, a->getDTypeIndex(), a->getRawDataPtr<void *>(),
-                                         b->getRawDataPtr<void *>(), out->getRawDataPtr<void *>(), (int)shape.size(), shape.data(), sa.data(),
+            ROCM_CALL(infini_rocm_binary(r->handle(), INFINI_BIN_ADD_RELU, a->getDTypeIndex(), dataPtr(a),
+                                         dataPtr(b), dataPtr(out), (int)shape.size(), shape.data(), sa.data(),
                                          sb.data()));
         });
         return true;
@@ -1937,9 +2031,9 @@ class FusionPlanner {
         if (pf)
             parked.erase(i);
         emit(slot, members, isParked ? "rope+headsplit(parked x)" : "rope+headsplit", true, [r, x, posT, out, rows, width, seq, isParked, pbytes] {
-            const void *xp = isParked ? r->getWorkspace(pbytes) : x->getRawDataPtr<void *>();
-            ROCM_CALL(infini_rocm_rope_headsplit(r->handle(), x->getDTypeIndex(), posT->getDTypeIndex(), posT->getRawDataPtr<void *>(), xp,
-                                                 out->getRawDataPtr<void *>(), rows, width, 128, 10000.0f, seq));
+            const void *xp = isParked ? r->getWorkspace(pbytes) : dataPtr(x);
+            ROCM_CALL(infini_rocm_rope_headsplit(r->handle(), x->getDTypeIndex(), posT->getDTypeIndex(), dataPtr(posT), xp,
+                                                 dataPtr(out), rows, width, 128, 10000.0f, seq));
         });
         return true;
     }
@@ -1980,7 +2074,7 @@ class FusionPlanner {
         const RocmRuntimeObj *r = R;
         emit(pos(next), members, ">reshape", true, [r, op, mid, out] {
             OverrideScope s;
-            s.redirect(mid.get(), out->getRawDataPtr<void *>());
+            s.redirect(mid.get(), dataPtr(out));
             r->launchOne(op);
         });
         return true;
@@ -1999,7 +2093,8 @@ std::vector<std::string> RocmRuntimeObj::describeFusionPlan(const Graph &graph) 
     static const bool envFusion = !(std::getenv("INFINI_ROCM_FUSION") && std::string(std::getenv("INFINI_ROCM_FUSION")) == "0");
     FusionPlanner planner(self.get(), graph->getOperators(), self ? self->fusion : envFusion);
     std::vector<std::string> out;
-    for (const auto &it : planner.run()) {
+    const auto plan = planner.run();
+    for (const auto &it : plan.items) {
         std::string s = std::to_string(it.slot) + " " + (it.fused ? it.what : std::string("op")) + " [";
         for (size_t q = 0; q < it.members.size(); ++q)
             s += (q ? "," : "") + std::to_string(it.members[q]);

@@ -69,6 +69,11 @@ template <typename T = void> static T *P(const Tensor &t) {
         return (T *)ov.ptr[0];
     if (ov.tensor[1] && t.get() == ov.tensor[1])
         return (T *)ov.ptr[1];
+    if (RocmRuntimeObj::forwards) { // the plan left this tensor's value in another buffer (rocm_runtime.h: ForwardMap)
+        auto it = RocmRuntimeObj::forwards->find(t.get());
+        if (it != RocmRuntimeObj::forwards->end())
+            return (T *)it->second;
+    }
     return t->getRawDataPtr<T *>();
 }
 

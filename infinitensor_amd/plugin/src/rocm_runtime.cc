@@ -135,7 +135,11 @@ void RocmRuntimeObj::launchAll(const Graph &graph, bool validate) const {
 }
 
 void RocmRuntimeObj::executePlan(const LaunchPlan &plan, const OpVec &ops) const {
-    for (const auto &item : plan) {
+    struct ForwardScope { // the plan's forwarded tensors resolve for the duration of its launches only
+        ForwardScope(const ForwardMap *m) { RocmRuntimeObj::forwards = m; }
+        ~ForwardScope() { RocmRuntimeObj::forwards = nullptr; }
+    } scope(plan.forwarded && !plan.forwarded->empty() ? plan.forwarded.get() : nullptr);
+    for (const auto &item : plan.items) {
         if (!item.run)
             continue;
         try {

@@ -1441,3 +1441,44 @@ def test_sunk_chain_is_cut_when_its_input_is_recycled(B, rocm):
     got, fused, plan = _on_off(B, rocm, fn, ins)
     assert np.isfinite(got[True]).all()
     assert np.allclose(got[True], got[False], rtol=4e-3, atol=6e-3), (np.abs(got[True] - got[False]).max(), plan)
+
+
+@pytest.mark.parametrize("form", ["matmul", "conv"])
+def test_output_forwarding_when_the_planned_buffer_sits_on_an_operand(B, rocm, form):
+    """The memory planner recycles a producer's dead input for the output of the bias Add behind it — exactly the buffer a
+    fused GEMM / conv must not write while it still reads that input. The plan then writes the fused result into the
+    producer's OWN output buffer and forwards every reader of the final tensor there (ForwardMap): still one launch, no
+    copy; equal to the per-operator run."""
+    rng = np.random.default_rng(47)
+    if form == "matmul":
+        m, k = 512, 256
+        ins = [((m, k), F16, rng.standard_normal((m, k)).astype(np.float16)),
+               ((k, k), F16, (rng.standard_normal((k, k)) / 16).astype(np.float16)), ((k,), F16, rng.standard_normal((k,)).astype(np.float16))]
+
+        def fn(h, t):
+            _weights(t)
+            a = h.relu(t[0], None)  # an intermediate that dies at the MatMul: the bias Add's output (same size) lands on it
+            y = h.add(t[2], h.matmul(a, t[1], None, False, False, None, B.ActType.Linear, "default"), None)
+            return h.abs(h.sigmoid(y, None), None)
+    else:
+        c = 64
+        ins = [((4, c, 16, 16), F16, rng.standard_normal((4, c, 16, 16)).astype(np.float16)),
+               ((c, c, 1, 1), F16, (rng.standard_normal((c, c, 1, 1)) / 8).astype(np.float16)), ((c,), F16, rng.standard_normal((c,)).astype(np.float16))]
+
+        def fn(h, t):
+            _weights(t)
+            a = h.relu(t[0], None)
+            y = h.relu(h.add(h.conv(a, t[1], None, 0, 0, 1, 1, 1, 1), h.reshape(t[2], None, [1, c, 1, 1]), None), None)
+            return h.abs(h.sigmoid(y, None), None)
+
+    f0 = 0 if PLAN_ONLY else rocm.forwarded_output_count()
+    got, fused, plan = _on_off(B, rocm, fn, ins)
+    assert np.allclose(got[True], got[False], rtol=4e-3, atol=6e-3), (np.abs(got[True] - got[False]).max(), plan)
+    fwd = [p for p in plan if "forwarded" in p]
+    if fwd:  # (the layout decides; when it happened, it must have been counted)
+        assert rocm.forwarded_output_count() > f0
+    x, w, b = (a.astype(np.float64) for _, _, a in ins)
+    r = np.maximum(x, 0)
+    want = np.abs(1 / (1 + np.exp(-(r @ w + b)))) if form == "matmul" else None
+    if want is not None:
+        assert np.allclose(got[True].reshape(want.shape), want, rtol=4e-3, atol=4e-3)

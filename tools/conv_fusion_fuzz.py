@@ -21,7 +21,7 @@ F16 = 10
 n_graphs = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 seed0 = int(os.environ.get("FUZZ_SEED", "9"))
 bad = 0
-TOTAL = [0, 0]
+TOTAL = [0, 0, 0]
 
 
 def build(seed, h, feeds):
@@ -81,22 +81,24 @@ for g in range(n_graphs):
             h.data_malloc()
             for t, a in feeds:
                 t.copyin_numpy(np.ascontiguousarray(a))
-            c0 = (rocm.fused_launch_count(), rocm.bridged_input_count())
+            c0 = (rocm.fused_launch_count(), rocm.bridged_input_count(), rocm.forwarded_output_count())
             if g % 2:
                 h.run_with_hipgraph()
             else:
                 h.run()
-            counts[on] = (rocm.fused_launch_count() - c0[0], rocm.bridged_input_count() - c0[1])
+            counts[on] = (rocm.fused_launch_count() - c0[0], rocm.bridged_input_count() - c0[1], rocm.forwarded_output_count() - c0[2])
             got[on] = [o.copyout_numpy().astype(np.float64) for o in outs]
     finally:
         rocm.set_fusion(True)
     TOTAL[0] += counts[True][0]
     TOTAL[1] += counts[True][1]
+    TOTAL[2] += counts[True][2]
     a, b = got[True][0], got[False][0]
     scale = max(1e-6, float(np.abs(b).max()))
     err = float(np.abs(a - b).max()) / scale
     if not (np.isfinite(a).all() and err <= 1.5e-2):
         bad += 1
         print(f"FAIL graph seed {seed}: max diff {err:.3g} of the output scale {scale:.3g}; fused launches {counts[True][0]}, bridged {counts[True][1]}", flush=True)
-print(f"{n_graphs - bad}/{n_graphs} graphs agree with fusion on / off ({TOTAL[0]} fused launches, {TOTAL[1]} bridged conv inputs)")
+print(f"{n_graphs - bad}/{n_graphs} graphs agree with fusion on / off ({TOTAL[0]} fused launches, {TOTAL[1]} bridged conv inputs, "
+      f"{TOTAL[2]} forwarded outputs)")
 sys.exit(1 if bad else 0)

@@ -310,8 +310,11 @@ def run_model(model: str, device: int = 0, batch: int | None = None, seq: int = 
     nops = len(bl.h.operators())
     bl.finish()
     f0 = rt.fused_launch_count()
+    w0 = rt.forwarded_output_count() if hasattr(rt, "forwarded_output_count") else 0
     bl.h.run()
     fused = rt.fused_launch_count() - f0
+    forwarded = (rt.forwarded_output_count() - w0) if hasattr(rt, "forwarded_output_count") else 0
+    plan_alone = sum(1 for ln in bl.h.rocm_fusion_plan() if " op [" in ln) if hasattr(bl.h, "rocm_fusion_plan") else None
     eager = timed(bl.h.run, iters)
     graph = timed(bl.h.run_with_hipgraph, iters)
     y = out.copyout_numpy()
@@ -337,7 +340,8 @@ def run_model(model: str, device: int = 0, batch: int | None = None, seq: int = 
         tuned = {"tuned_eager_ms": round(te, 3), "tuned_hipgraph_ms": round(tg, 3), "tune_seconds": round(tune_s, 2),
                  "tuned_picks": picks}
     lowering = "onnx.py" if frontend else "idealised"
-    return {**tuned, "model": name, "lowering": lowering, "ops": nops, "fusion": bool(rt.get_fusion()), "fused_launches_per_run": int(fused), "gemm_conv_TFLOP": round(bl.flops / 1e12, 3),
+    return {**tuned, "model": name, "lowering": lowering, "ops": nops, "fusion": bool(rt.get_fusion()), "fused_launches_per_run": int(fused), "forwarded_outputs_per_run": int(forwarded),
+            "operators_launched_alone": plan_alone, "gemm_conv_TFLOP": round(bl.flops / 1e12, 3),
             "eager_ms": round(eager, 3), "hipgraph_ms": round(graph, 3),
             "hipgraph_TFLOPs": round(bl.flops / graph / 1e9, 1), "batch": batch,
             "per_unit": f"{batch / graph * 1e3:.0f} samples/s", "finite": bool(np.isfinite(y.astype(np.float32)).all())}
