@@ -70,6 +70,7 @@ class RocmRuntimeObj : public RuntimeObj {
     static void loadPerfData(const string &path);
     static void clearPerfData();
     static size_t perfDataSize();
+    static size_t perfEpoch; // bumped whenever the autotune records change (tune(), load_perf, clear_perf): plans embed the picks
 
     void initComm(const string &name, int worldSize, int rank) final;
     CommunicatorObj &getCommunicator() const final;
@@ -149,6 +150,11 @@ class RocmRuntimeObj : public RuntimeObj {
     void launchAll(const Graph &graph, bool validate) const;
     // the launch plan of a graph: which operators run fused, where (src/rocm_fusion.cc); fusion off = one item per operator
     LaunchPlan buildPlan(const Graph &graph) const;
+    // the plan of `graph`, re-made only when something it was decided on changed: the graph's capture generation (topology,
+    // shapes, storage — the same notion the hipGraph fast path uses), the fusion switch, the autotune records, a constant the
+    // planner read, the communicator
+    std::shared_ptr<const LaunchPlan> planOf(const Graph &graph) const;
+    void dropPlans() const;
     void executePlan(const LaunchPlan &plan, const OpVec &ops) const;
     void launchOne(const Operator &op) const; // one operator through KernelRegistry (+ its perf record, if tuned)
     // a host write went over [ptr, ptr + bytes): scalar constants the planner read from there are stale (returns whether
@@ -172,6 +178,14 @@ class RocmRuntimeObj : public RuntimeObj {
     // values of one-element constant tensors (weights no operator writes) the planner looked at — Pow's exponent, the
     // sqrt(2) / 0.5 / 1 of a decomposed Gelu, LayerNorm's epsilon — keyed by device address; dropped by host writes
     mutable std::map<const void *, std::pair<size_t, double>> scalarCache;
+    struct PlanEntry {
+        WRef<GraphObj> owner;
+        uint64_t graphId = 0;
+        size_t generation = 0, perfEpoch = 0;
+        bool fusion = true;
+        std::shared_ptr<const LaunchPlan> plan;
+    };
+    mutable std::map<const GraphObj *, PlanEntry> plans;
     Cache cache; // most recently used first
     mutable std::recursive_mutex executionMutex;
     mutable std::recursive_mutex cacheMutex;

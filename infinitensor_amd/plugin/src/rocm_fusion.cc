@@ -177,8 +177,12 @@ double halfToDouble(uint16_t h) {
 
 class FusionPlanner {
   public:
-    FusionPlanner(const RocmRuntimeObj *R, const OpVec &ops, bool fusion)
-        : R(R), rt(R ? R->handle() : nullptr), ops(ops), n(ops.size()), fusion(fusion), claimed(ops.size(), 0),
+    // silent: operators a previous planning pass found to write nothing of their own (members of fused items whose outputs
+    // are not materialised). `survives` then does not count their planned output buffers as written — which is what lets a
+    // forwarded buffer outlive the operators BEHIND the chain that will themselves be folded away. A speculation: the caller
+    // verifies it against this pass's own result (silentHolds) and falls back to the first pass's plan otherwise.
+    FusionPlanner(const RocmRuntimeObj *R, const OpVec &ops, bool fusion, const std::vector<char> *silent = nullptr)
+        : R(R), rt(R ? R->handle() : nullptr), ops(ops), n(ops.size()), fusion(fusion), silent(silent), claimed(ops.size(), 0),
           writeAt(ops.size(), -1), log(std::getenv("INFINI_ROCM_FUSION_LOG") != nullptr),
           fwd(std::make_shared<RocmRuntimeObj::ForwardMap>()) {
         posOf.reserve(n * 2);
@@ -222,12 +226,33 @@ class FusionPlanner {
         return plan;
     }
 
+    // operators that wrote nothing of their own in this pass
+    std::vector<char> silentOps() const {
+        std::vector<char> v(n, 0);
+        for (size_t p = 0; p < n; ++p)
+            v[p] = claimed[p] && writeAt[p] < 0;
+        return v;
+    }
+    bool silentHolds() const {
+        if (!silent)
+            return true;
+        for (size_t p = 0; p < n; ++p)
+            if ((*silent)[p] && !(claimed[p] && writeAt[p] < 0)) {
+                if (log)
+                    fprintf(stderr, "[fusion] two-pass: operator %zu was assumed silent but %s\n", p, claimed[p] ? "writes" : "is not planned");
+                return false;
+            }
+        return true;
+    }
+    size_t forwardedTensors() const { return fwd->size(); }
+
   private:
     const RocmRuntimeObj *R; // nullptr: dry run (describeFusionPlan on a non-ROCM runtime)
     infiniRocmRuntime_t rt;
     const OpVec &ops;
     const size_t n;
     const bool fusion;
+    const std::vector<char> *silent;
     std::vector<char> claimed;
     // for a claimed operator: the slot at which ITS output tensor is really written (-1: never — an intermediate that is
     // not materialised, a grouped result parked in the workspace)
@@ -305,14 +330,17 @@ class FusionPlanner {
         return cur;
     }
     // memory `t` occupies is not written by any operator at a position in (from, to) other than `members`
-    bool survives(const Tensor &t, size_t from, size_t to, const std::vector<size_t> &members) const {
+    // speculative: also trust the previous pass's `silent` set (forwarding checks only — the chains themselves are built
+    // on facts, so that the second pass reproduces the first one's shapes wherever forwarding changes nothing)
+    bool survives(const Tensor &t, size_t from, size_t to, const std::vector<size_t> &members, bool speculative = false) const {
         if (persistent(t) || from >= to)
             return true; // weights / graph inputs: no operator writes them, the planner never recycles them
         for (size_t p = from + 1; p < to; ++p) {
             if (std::find(members.begin(), members.end(), p) != members.end())
                 continue;
             // an operator some item already owns writes when (and if) that item says so; an unclaimed one at its own place
-            if (claimed[p] && !(writeAt[p] > (long)from && writeAt[p] < (long)to))
+            // (unless the previous pass found that it will be folded away: see `silent`)
+            if (claimed[p] ? !(writeAt[p] > (long)from && writeAt[p] < (long)to) : (speculative && silent && (*silent)[p]))
                 continue;
             for (const auto &o : ops[p]->getOutputs())
                 if (o && overlaps(o, t))
@@ -869,7 +897,7 @@ class FusionPlanner {
                     emit(ch.slot, all, "attention(bridged)>" + ch.what, true, [r, attn, chainRun, bytes] {
                         attn(r->getWorkspace(bytes));
                         chainRun();
-                    });
+                    }, ch.fwdTo ? std::vector<size_t>{ch.head} : std::vector<size_t>{});
                     return;
                 }
             }
@@ -1010,7 +1038,7 @@ class FusionPlanner {
                     return false;
                 lastUse = std::max(lastUse, it->second);
             }
-            if (!survives(C, x.slot, lastUse + 1, x.members))
+            if (!survives(C, x.slot, lastUse + 1, x.members, true))
                 return false;
             x.fwdTo = C->getRawDataPtr<void *>();
             x.fwdLastUse = lastUse;
@@ -1186,7 +1214,8 @@ class FusionPlanner {
             (*fwd)[c.out.get()] = c.fwdTo;
             lateReads.push_back({c.slot, c.fwdLastUse, c.mm->getOutput()});
         }
-        emit(c.slot, c.members, c.what, true, chainLaunch(c, nullptr, 0));
+        // (a forwarded chain writes the MatMul operator's own buffer, not its last member's)
+        emit(c.slot, c.members, c.what, true, chainLaunch(c, nullptr, 0), c.fwdTo ? std::vector<size_t>{c.head} : std::vector<size_t>{});
         if (c.attn)
             commitAttention(*c.attn);
     }
@@ -1679,7 +1708,7 @@ class FusionPlanner {
                 }
                 // nothing may land on y's block up to and including the last reader (a reader's own output too: a plain
                 // kernel does not know its input moved)
-                ok = ok && survives(y, c.slot, lastUse + 1, c.members);
+                ok = ok && survives(y, c.slot, lastUse + 1, c.members, true);
                 if (ok)
                     fwdTo = y->getRawDataPtr<void *>();
                 else if (otherHazard || !bridgeX)
@@ -1734,7 +1763,8 @@ class FusionPlanner {
                                                  Bs ? dataPtr(Bs) : nullptr, Rs ? dataPtr(Rs) : nullptr,
                                                  dataPtr(Out), n_, c_, h_, w_, f_, r_, s_, ph_, pw_, sh_, sw_, dh_, dw_, groups,
                                                  act));
-            });
+            },
+                 forwarded ? std::vector<size_t>{i} : std::vector<size_t>{}); // forwarded: the Conv operator's own buffer is the one written
             return true;
         }
         return false;
@@ -2081,9 +2111,40 @@ class FusionPlanner {
     }
 };
 
+namespace {
+// Two passes when forwarding is in play: the first finds which operators get folded away, the second may let forwarded
+// buffers outlive those (FusionPlanner's `silent`); its result is used only if its own folding confirms the assumption.
+RocmRuntimeObj::LaunchPlan planTwice(const RocmRuntimeObj *R, const OpVec &ops, bool fusion) {
+    static const bool twoPass = envOn("INFINI_ROCM_PLAN_TWO_PASS");
+    std::vector<char> silent;
+    RocmRuntimeObj::LaunchPlan first;
+    {
+        FusionPlanner p1(R, ops, fusion);
+        first = p1.run();
+        if (!fusion || !twoPass)
+            return first;
+        silent = p1.silentOps();
+    }
+    // iterate towards a self-consistent plan: each pass assumes the previous pass's silent set and is accepted as soon as
+    // its own result confirms the assumption (a forwarding that succeeds changes who writes what: the head operator's own
+    // buffer instead of the tail's)
+    for (int pass = 2; pass <= 4; ++pass) {
+        FusionPlanner pk(R, ops, fusion, &silent);
+        RocmRuntimeObj::LaunchPlan next = pk.run();
+        const bool holds = pk.silentHolds();
+        if (std::getenv("INFINI_ROCM_FUSION_LOG"))
+            fprintf(stderr, "[fusion] pass %d: %zu items (first pass %zu), %zu forwarded tensors, assumption %s\n", pass, next.items.size(),
+                    first.items.size(), pk.forwardedTensors(), holds ? "holds" : "violated");
+        if (holds)
+            return next.items.size() <= first.items.size() ? next : first;
+        silent = pk.silentOps();
+    }
+    return first;
+}
+} // namespace
+
 RocmRuntimeObj::LaunchPlan RocmRuntimeObj::buildPlan(const Graph &graph) const {
-    FusionPlanner planner(this, graph->getOperators(), fusion);
-    return planner.run();
+    return planTwice(this, graph->getOperators(), fusion);
 }
 
 std::vector<std::string> RocmRuntimeObj::describeFusionPlan(const Graph &graph) {
@@ -2091,9 +2152,8 @@ std::vector<std::string> RocmRuntimeObj::describeFusionPlan(const Graph &graph) 
     graph->validateMemory();
     auto self = std::dynamic_pointer_cast<RocmRuntimeObj>(graph->getRuntime());
     static const bool envFusion = !(std::getenv("INFINI_ROCM_FUSION") && std::string(std::getenv("INFINI_ROCM_FUSION")) == "0");
-    FusionPlanner planner(self.get(), graph->getOperators(), self ? self->fusion : envFusion);
+    const auto plan = planTwice(self.get(), graph->getOperators(), self ? self->fusion : envFusion);
     std::vector<std::string> out;
-    const auto plan = planner.run();
     for (const auto &it : plan.items) {
         std::string s = std::to_string(it.slot) + " " + (it.fused ? it.what : std::string("op")) + " [";
         for (size_t q = 0; q < it.members.size(); ++q)

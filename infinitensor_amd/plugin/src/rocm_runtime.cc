@@ -34,6 +34,7 @@ void RocmRuntimeObj::setFusion(bool on) {
 
 RocmRuntimeObj::~RocmRuntimeObj() {
     cache.clear();
+    plans.clear();
     if (rt)
         infini_rocm_runtime_destroy(rt);
 }
@@ -85,6 +86,7 @@ void RocmRuntimeObj::copyBlobFromCPU(void *dst, const void *src, size_t bytes) c
     if (forgetScalars(dst, bytes)) { // a constant a launch plan was decided on (Pow's exponent, a Gelu's sqrt 2): re-plan
         std::lock_guard<std::recursive_mutex> cacheLock(cacheMutex);
         const_cast<RocmRuntimeObj *>(this)->cache.clear();
+        dropPlans();
     }
 }
 void RocmRuntimeObj::copyBlobToCPU(void *dst, const void *src, size_t bytes) const {
@@ -97,6 +99,7 @@ void RocmRuntimeObj::copyBlobInsideRuntime(void *dst, const void *src, size_t by
     if (forgetScalars(dst, bytes)) {
         std::lock_guard<std::recursive_mutex> cacheLock(cacheMutex);
         const_cast<RocmRuntimeObj *>(this)->cache.clear();
+        dropPlans();
     }
     ROCM_CALL(infini_rocm_runtime_sync(rt)); // reference semantics: cudaMemcpy D2D is synchronous
 }
@@ -114,11 +117,19 @@ void RocmRuntimeObj::initComm(const string &name, int worldSize, int rank) {
     IT_ASSERT(!comm, "communicator is already initialized.");
     ROCM_CALL(infini_rocm_comm_init(rt, name.c_str(), worldSize, rank));
     comm = std::make_unique<RcclCommunicatorObj>(worldSize, rank);
+    dropPlans(); // the row-parallel overlap rule depends on the world size
 }
 
 void RocmRuntimeObj::savePerfData(const string &path) { PerfEngine::getInstance().savePerfEngineData(path); }
-void RocmRuntimeObj::loadPerfData(const string &path) { PerfEngine::getInstance().loadPerfEngineData(path); }
-void RocmRuntimeObj::clearPerfData() { PerfEngine::getInstance().set_data({}); }
+size_t RocmRuntimeObj::perfEpoch = 0;
+void RocmRuntimeObj::loadPerfData(const string &path) {
+    PerfEngine::getInstance().loadPerfEngineData(path);
+    ++perfEpoch;
+}
+void RocmRuntimeObj::clearPerfData() {
+    PerfEngine::getInstance().set_data({});
+    ++perfEpoch;
+}
 size_t RocmRuntimeObj::perfDataSize() { return PerfEngine::getInstance().get_data().size(); }
 
 CommunicatorObj &RocmRuntimeObj::getCommunicator() const {
@@ -131,8 +142,28 @@ void RocmRuntimeObj::launchAll(const Graph &graph, bool validate) const {
     IT_ASSERT(graph != nullptr, "Cannot run a null graph");
     if (validate)
         graph->validateMemory();
-    executePlan(buildPlan(graph), graph->getOperators());
+    executePlan(*planOf(graph), graph->getOperators());
 }
+
+std::shared_ptr<const RocmRuntimeObj::LaunchPlan> RocmRuntimeObj::planOf(const Graph &graph) const {
+    const size_t generation = graph->getCaptureGeneration(), perfNow = perfEpoch;
+    for (auto it = plans.begin(); it != plans.end();) // graphs that are gone
+        it = it->second.owner.expired() ? plans.erase(it) : std::next(it);
+    auto &e = plans[graph.get()];
+    auto owner = e.owner.lock();
+    if (!(e.plan && owner && owner.get() == graph.get() && e.generation == generation && e.perfEpoch == perfNow && e.fusion == fusion)) {
+        e.plan.reset(); // (its closures hold the graph's tensors)
+        e.owner = WRef<GraphObj>(graph);
+        e.graphId = graph->getCaptureStateId();
+        e.generation = generation;
+        e.perfEpoch = perfNow;
+        e.fusion = fusion;
+        e.plan = std::make_shared<const LaunchPlan>(buildPlan(graph));
+    }
+    return e.plan;
+}
+
+void RocmRuntimeObj::dropPlans() const { plans.clear(); }
 
 void RocmRuntimeObj::executePlan(const LaunchPlan &plan, const OpVec &ops) const {
     struct ForwardScope { // the plan's forwarded tensors resolve for the duration of its launches only
@@ -205,6 +236,7 @@ void RocmRuntimeObj::tuneImpl(const Graph &graph, bool profiling) const {
     }
     if (profiling)
         printProfilingData(total, opTime, opCnt);
+    ++perfEpoch;
 }
 
 void RocmRuntimeObj::run(const Graph &graph, bool tune, bool profiling) const {
@@ -294,7 +326,8 @@ void RocmRuntimeObj::runWithHipGraph(const Graph &graph) {
     // never execute.
     // The plan is made BEFORE the stream records: the planner may read one-element constants back from the device
     // (a decomposed Gelu's sqrt 2, LayerNorm's epsilon), which a recording stream cannot serve.
-    const LaunchPlan plan = buildPlan(graph);
+    const std::shared_ptr<const LaunchPlan> planRef = planOf(graph);
+    const LaunchPlan &plan = *planRef;
     for (int attempt = 0;; ++attempt) {
         uint64_t epochBefore = 0, epochAfter = 0;
         ROCM_CALL(infini_rocm_workspace_info(rt, nullptr, nullptr, &epochBefore));
@@ -323,6 +356,8 @@ void RocmRuntimeObj::invalidateGraphCaptureCache(uint64_t graphId) noexcept {
     std::lock_guard<std::recursive_mutex> executionLock(executionMutex);
     std::lock_guard<std::recursive_mutex> cacheLock(cacheMutex);
     cache.remove_if([graphId](const std::unique_ptr<CacheEntry> &e) { return e->state.graphId == graphId; });
+    for (auto it = plans.begin(); it != plans.end();) // the graph changed (or died): its plan holds its tensors
+        it = it->second.graphId == graphId ? plans.erase(it) : std::next(it);
 }
 
 void RocmRuntimeObj::clearHipGraphCache() {
