@@ -1,25 +1,35 @@
 #!/bin/bash
-# One GPU visit: parity suite, smoke(), bench.py, BERT through the executor (with h.tune()), kernel-trace profiles.
-# Everything lands under gpurun_out/round/ (copied to profiles/ by hand afterwards).
+# One GPU visit of round 3: parity suite, smoke(), bench.py (default flags and the driver's), the model graphs in every lowering,
+# kernel-trace profiles, PMC passes of the bf16 and fp32 headline GEMMs, the per-layer conv sweep.
+# Everything lands under gpurun_out/round/ (copied to profiles/r03_* by hand afterwards).
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd $REPO
 O=gpurun_out/round
-mkdir -p $O
+rm -rf $O; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 t0=$(date +%s)
-timeout ${PYTEST_LIMIT:-900} python -m pytest tests -m gpu -x -q --durations=12 > $O/pytest.log 2>&1
+timeout ${PYTEST_LIMIT:-900} python -m pytest tests -m gpu -q --durations=12 > $O/pytest.log 2>&1
 echo "pytest exit $? after $(( $(date +%s) - t0 )) s" | tee -a $O/pytest.log
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
 echo "smoke exit $?" | tee -a $O/smoke.log
-timeout 420 python bench.py > $O/bench.json 2> $O/bench.err
+timeout 500 python bench.py > $O/bench.json 2> $O/bench.err
 echo "bench exit $? after $(( $(date +%s) - t0 )) s"
-timeout 240 python tools/model_bench.py bert --tune > $O/bert.json 2> $O/bert.err
-timeout 240 python tools/model_bench.py llama > $O/llama.json 2> $O/llama.err
+timeout 500 python bench.py --warmup 5 --steps 20 --no-graph --no-tp --no-cpu-baseline --no-extras > $O/bench_driverflags.json 2>> $O/bench.err
+for m in "resnet50 --tune" "resnet50 --idealised" "bert --tune" "bert --idealised" "bert --decomposed" "bert --merged-kt" "llama" "llama --idealised"; do
+  timeout 240 python tools/model_bench.py $m >> $O/models.json 2>> $O/models.err
+done
 (cd $O && timeout 300 python $REPO/tools/rocm_launch.py --nproc_per_node 1 > rocm_launch.log 2>&1; echo "rocm_launch exit $?" >> rocm_launch.log)
+INFINI_ROCM_FUSION_LOG=1 timeout 200 python tools/model_bench.py resnet50 --iters 1 2> $O/resnet50_fusion_log.txt > /dev/null
+timeout 300 python tools/conv_bench.py --variants=-1 > $O/conv_layers.txt 2>&1
+timeout 200 python tools/probes/conv_as_gemm.py > $O/conv_as_gemm.txt 2>&1
+timeout 200 python tools/gemm_shapes.py --dtype bf16 > $O/gemm_shapes_bf16.txt 2>&1
 if [ -z "$NO_PROFILE" ]; then
   bash tools/profile_models.sh > $O/prof.log 2>&1
   mkdir -p $O/prof
   for f in $(find gpurun_out/prof_models -name "*kernel_stats.csv"); do cp $f $O/prof/; done
+  cp gpurun_out/prof_models/bench_trace_summary.json $O/prof/ 2>/dev/null
+  bash tools/profile_gemm.sh 4 > $O/prof_gemm.log 2>&1; cp gpurun_out/prof_gemm/summary.json $O/prof/gemm256p_pmc.json
+  bash tools/profile_cmd.sh gemm_fast32 gemm32 -- python tools/run_gemm32.py 4096 5 > $O/prof_gemm32.log 2>&1; cp gpurun_out/prof_gemm32/summary.json $O/prof/gemm_fast32_pmc.json
 fi
 echo "total $(( $(date +%s) - t0 )) s"
-tail -3 $O/pytest.log; tail -2 $O/smoke.log; cat $O/bench.json | cut -c1-1500; grep model $O/bert.json; grep model $O/llama.json; grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" $O/rocm_launch.log | tail -6
+tail -3 $O/pytest.log; tail -2 $O/smoke.log; cut -c1-600 $O/bench.json; cut -c1-400 $O/bench_driverflags.json; cat $O/models.json | cut -c1-420

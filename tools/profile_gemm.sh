@@ -22,8 +22,17 @@ for f in sorted(glob.glob("$OUT/**/*counter_collection.csv", recursive=True)):
     for k, v in acc.items():
         tot[k]=sum(v)/len(v); print(f"{k:36s} n={len(v):3d} mean={sum(v)/len(v):.5g}")
 import json
+sys_path = "$REPO"
+import sys
+sys.path.insert(0, sys_path)
+try:
+    from infinitensor_amd import ops
+    vname = ops.matmul_variants()[int("$V")]
+except Exception:
+    vname = None
+kern = sorted({r["Kernel_Name"] for f in glob.glob("$OUT/**/*counter_collection.csv", recursive=True) for r in csv.DictReader(open(f)) if "gemm" in r.get("Kernel_Name", "")})
 out = {"command": "rocprofv3 --kernel-trace --pmc <one set per pass> -- python tools/run_gemm.py 4096 $V 0 5 (bf16 NN 4096^3)",
-       "variant": int("$V"), "pmc_per_dispatch_mean": tot}
+       "variant": int("$V"), "variant_name": vname, "kernel": kern[0] if kern else None, "pmc_per_dispatch_mean": tot}
 if "GRBM_GUI_ACTIVE" in tot and "SQ_VALU_MFMA_BUSY_CYCLES" in tot:
     # SQ counters are summed over 1024 SIMDs (256 CU x 4), GRBM_GUI_ACTIVE over 8 XCDs
     out["mfma_busy_frac"] = tot["SQ_VALU_MFMA_BUSY_CYCLES"]/1024/(tot["GRBM_GUI_ACTIVE"]/8)

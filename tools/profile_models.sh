@@ -4,8 +4,8 @@ cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_models
 mkdir -p $OUT
-for m in "resnet50 --batch 128 --iters 3" "bert --batch 32 --seq 512 --iters 3"; do
-  name=$(echo $m | cut -d' ' -f1)
+for m in "resnet50 --batch 128 --iters 3" "bert --batch 32 --seq 512 --iters 3" "bert --batch 32 --seq 512 --iters 3 --decomposed" "llama --iters 3"; do
+  name=$(echo $m | cut -d' ' -f1)$(echo $m | grep -q decomposed && echo _decomposed)
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -o $name -- python $REPO/tools/model_bench.py $m > $OUT/$name.log 2>&1
 done
 # the SAME headline command bench.py runs by default (300 warm-up + 200 timed launches); the secondary sections are switched off
@@ -18,7 +18,8 @@ for f in glob.glob("$OUT/bench/**/*kernel_trace.csv", recursive=True):
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
 # launch order: 300 warm-up, 200 timed, then whatever later sections add (none with the flags above)
-timed = d[300:500] if len(d) >= 500 else d
+# launch order: 2 + 20 cold launches, the time-based pre-warm (a multiple of 16), 300 warm-up, 200 timed, then the per-launch pass
+timed = d[-400:-200] if len(d) >= 700 else d
 out = {"command": "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-extras --no-graph --no-tp",
        "kernel": rows[0]["Kernel_Name"] if rows else None, "launches": len(d),
        "us_mean_all": sum(d) / max(1, len(d)), "us_mean_timed_200": sum(timed) / max(1, len(timed)),
