@@ -7,13 +7,23 @@ A "step" is one launch of that MatMul through the C ABI (infini_rocm_matmul) on 
 stream. value = whole-job TFLOP/s = n_gpus * steps * 2*M*N*K / time, weak scaling (each rank owns an
 independent 4096^3 problem: the op has no exchange step when sharded by columns — SURVEY 8e).
 
+Before the W warm-up steps the kernel is launched back to back for >= --prewarm-ms (default 40 ms; reported as prewarm_ms /
+prewarm_launches): the chip needs ~15 ms to clock up from idle, and a caller that asks for five warm-up steps would otherwise
+time the ramp. `roofline.cold20` is the same kernel on an idle chip.
+
 The JSON line also carries
   roofline      dominant kernel (the GEMM) vs the dense bf16 MFMA peak, timed with HIP events on
-                the launch stream inside the timed region;
+                the launch stream inside the timed region; `traffic` from the committed PMC passes, only if they were taken
+                from the kernel variant this run launched (config.kernel_variant_launched);
   cpu_baseline  the reference's own native-CPU MatMul (oracle/_ref, built from /root/reference)
                 timed on a bounded row-slice of the same problem on this box's host cores
                 (rank 0, N=1 only), plus a torch/MKL sgemm figure as the intelcpu-family stand-in;
-  extras        stand-alone Softmax / LayerNorm HBM-roofline figures (SURVEY 8d C4 shapes).
+  tp_block      BASELINE config 5 (one Llama-7B block, Megatron TP over the ranks) incl. `overlap` (reference-shaped
+                all-reduce vs row chunks overlapped on a second stream) and, at N > 1, the one-hop reduce-scatter A/B;
+  graph_resnet50  BASELINE configs 3 / 4 / 5 through the reference executor + plugin, every graph built in the form and
+                operator order pyinfinitensor/onnx.py emits (tools/model_bench.py);
+  extras        stand-alone Softmax / LayerNorm HBM-roofline figures (SURVEY 8d C4 shapes), the fp32 MatMul rows against
+                the fp32 MFMA peak, the headline GEMM in its other layouts / dtypes.
 """
 from __future__ import annotations
 
