@@ -394,9 +394,15 @@ int infini_rocm_conv_transpose2d(infiniRocmRuntime_t rt, int dtype, const void *
 /* Kernel choice for the next f16 / bf16 conv2d calls: -1 heuristic, 1 generic implicit GEMM only,
  * 2 the conv_s1.hip kernels (LDS-resident input patch for unit-stride "same" R x S, tap-shifted implicit GEMM
  * otherwise) for every shape they serve, 3 batched-GEMM route for every eligible pointwise shape, 4 = 2 with the
- * patch kernel off (the tap-shifted kernel everywhere: A/B). All variants compute the same sums (fp32 accumulate).
+ * patch kernel off (the tap-shifted kernel everywhere: A/B), 5 = pointwise layers (1 x 1, any stride, channels % 64 == 0) as ONE
+ * GEMM over pixel slots on the persistent 256-row kernels for every shape that qualifies (the heuristic sends them there when
+ * they have >= 128 filters and enough tiles to fill half the chip). All variants compute the same sums (fp32 accumulate).
  * Used by tune() and tests. */
 int infini_rocm_conv2d_set_variant(infiniRocmRuntime_t rt, int variant);
+/* Which implementation the most recent conv2d call on this runtime launched: "direct32" (fp32), "pixel_gemm" (pointwise layer as
+ * one GEMM over pixel slots on the persistent kernels), "tap_shifted" (conv_s1.hip), "batched_gemm", "generic", "none". A forced
+ * variant falls back when a shape does not qualify; tests and measurement tools read the route instead of assuming it. */
+int infini_rocm_conv2d_last_route(infiniRocmRuntime_t rt, const char **route);
 /* Packed-weight cache. The f16 / bf16 conv kernels read their weights re-packed (FCRS -> [RS][F][C]); while `on` is set
  * the next conv2d calls treat `w` as CONSTANT data: the packed image is built once, kept in a runtime-owned buffer keyed
  * by (w, F, C, RS, layout) and reused by every later call — eager or captured (built on a side stream when the runtime

@@ -115,6 +115,7 @@ struct infiniRocmRuntime {
     bool capturing = false;
     int matmul_variant = -1;
     int last_matmul_variant = -1; // the variant the most recent matmul call actually launched
+    const char *last_conv_route = "none"; // which implementation the most recent conv2d call launched
     int conv_variant = -1;
     // conv weights declared constant by the caller: their re-packed images are cached (WCacheEntry) instead of rebuilt
     int conv_const_weights = 0;

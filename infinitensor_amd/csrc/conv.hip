@@ -397,6 +397,12 @@ __global__ __launch_bounds__(256) void conv_transpose_direct(const T *__restrict
 
 using namespace irocm;
 
+namespace irocm {
+// gemm256p_conv.hip: a unit-stride pointwise convolution as one GEMM over pixel slots; -1 when the operands do not qualify
+int launch_conv_pw_gemm(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, const void *bias, const void *res, void *y,
+                        int64_t n, int64_t c, int64_t hw, int64_t f, int act);
+} // namespace irocm
+
 extern "C" {
 
 int infini_rocm_conv_transpose2d(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, const void *bias,
@@ -480,10 +486,25 @@ int infini_rocm_conv2d_res(infiniRocmRuntime_t rt, int dtype, const void *x, con
         if (g > (long)rt->num_cu * 32) g = (long)rt->num_cu * 32;
         hipLaunchKernelGGL(conv_direct32, dim3((unsigned)g), dim3(256), 0, rt->stream, p);
         IROCM_LAUNCH_CHECK("conv_direct32");
+        rt->last_conv_route = "direct32";
         return INFINI_ROCM_OK;
     }
     const int variant = rt->conv_variant;
     const bool same_s1 = sh == 1 && sw == 1 && dh == 1 && dw == 1 && groups == 1 && p.oh == p.h && p.ow == p.wd;
+    // Round 3: a unit-stride pointwise layer with >= 256 filters is ONE GEMM  Y[f][slot] = W[f][c] X[c][slot]  over pixel slots
+    // (image, pixel) on the persistent 256-row kernels in conv mode (gemm256p_kernel.h, CONV): LDS-DMA staging of both operands,
+    // tiles that span images (14 x 14 and 7 x 7 planes do not waste tiles), per-filter bias, residual and activation in the epilogue,
+    // NCHW stores. As plain GEMMs these layers run 1.2-1.8 x faster on that machinery than on the register-staged tap-shifted
+    // kernel (tools/probes/conv_as_gemm.py, profiles/r03_conv_as_gemm.txt); with fewer filters the 256-row tile is mostly empty
+    // and the old kernels win. Variant 5 forces it for every eligible shape.
+    if ((variant < 0 || variant == 5) && r == 1 && s == 1 && ph == 0 && pw == 0 && same_s1 && c % 64 == 0 && (act == 0 || act == 1) &&
+        // (>= 128 filters: C256->F128 @56x56 78 vs 100 us, C512->F128 @28x28 33 vs 40; with 64 the 256-row tile is 3/4 empty:
+        // 69 vs 60 us. And the grid must fill at least half the chip: C2048->F512 @7x7 is 56 tiles of 256^2.)
+        ((f >= 128 && ceil_div(f, 256) * ceil_div(n * ((p.npix + 7) / 8 * 8), 256) * 2 >= rt->num_cu) || variant == 5)) {
+        const int st = launch_conv_pw_gemm(rt, dtype, x, w, bias, residual, y, n, c, p.npix, f, act);
+        if (st >= 0)
+            return st;
+    }
     const bool pointwise_gemm = r == 1 && s == 1 && ph == 0 && pw == 0 && same_s1 && (p.npix % 8 == 0) && c % 64 == 0;
     // big-plane pointwise layers with >= 256 filters and channels are plain batched GEMMs (LDS-DMA kernels); everything else whose
     // output extent is ceil(input / stride) goes to the tap-shifted implicit GEMM of conv_s1.hip (measured per
@@ -505,6 +526,7 @@ int infini_rocm_conv2d_res(infiniRocmRuntime_t rt, int dtype, const void *x, con
         // batched-GEMM route by default only for long-K pointwise layers on big planes: with K <= 512 its 256^2 tiles run 8
         // K-tiles each and the per-tile prologue + epilogue dominates (C512->F256 @28x28: 88 us vs 66 us on conv_s1)
         (variant == 2 || variant == 4 || residual || !(pointwise_gemm && f >= 256 && c >= 1024 && p.npix >= 2048))) {
+        rt->last_conv_route = "tap_shifted";
         const int st = launch_conv_s1(rt, dtype, x, w, bias, residual, y, (int)n, (int)c, (int)h, (int)wd, (int)f, (int)r, (int)s,
                                       ph, pw, sh, sw, dh, dw, p.oh, p.ow, act);
         if (st >= 0)
@@ -513,6 +535,7 @@ int infini_rocm_conv2d_res(infiniRocmRuntime_t rt, int dtype, const void *x, con
     // pointwise convolution == batched GEMM  Y[n] = W[F x C] . X[n][C x HW]  (A broadcast over batch)
     if (variant != 1 && !residual && r == 1 && s == 1 && ph == 0 && pw == 0 && sh == 1 && sw == 1 && groups == 1 && (p.npix % 8 == 0) &&
         c % 64 == 0) {
+        rt->last_conv_route = "batched_gemm";
         return infini_rocm_matmul(rt, dtype, w, x, bias, y, n, f, p.npix, c, 0, 0, 0, (int64_t)c * p.npix,
                                   0, bias ? 1 : 0, 0, act);
     }
@@ -526,12 +549,19 @@ generic:
     else
         hipLaunchKernelGGL(conv_igemm16<F16Traits>, dim3((unsigned)blocks), dim3(256), 0, rt->stream, p);
     IROCM_LAUNCH_CHECK("conv_igemm16");
+    rt->last_conv_route = "generic";
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_conv2d_last_route(infiniRocmRuntime_t rt, const char **route) {
+    IROCM_CHECK_ARG(rt && route, "NULL argument");
+    *route = rt->last_conv_route;
     return INFINI_ROCM_OK;
 }
 
 int infini_rocm_conv2d_set_variant(infiniRocmRuntime_t rt, int variant) {
     IROCM_CHECK_ARG(rt, "NULL runtime");
-    IROCM_CHECK_ARG(variant >= -1 && variant <= 4, "conv2d: bad variant %d", variant);
+    IROCM_CHECK_ARG(variant >= -1 && variant <= 5, "conv2d: bad variant %d", variant);
     rt->conv_variant = variant;
     return INFINI_ROCM_OK;
 }

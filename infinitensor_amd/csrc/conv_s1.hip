@@ -33,6 +33,12 @@
 #include <cstdlib>
 
 namespace irocm {
+// gemm256p_conv.hip
+int launch_conv_pw_gemm(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, const void *bias, const void *res, void *y,
+                        int64_t n, int64_t c, int64_t hw, int64_t f, int act);
+} // namespace irocm
+
+namespace irocm {
 
 template <int N> __device__ __forceinline__ void g256p_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -1299,7 +1305,8 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
         }
     }
     const size_t ws_w = cached ? 0 : w_bytes;
-    const size_t ws_bytes = ws_w + (split ? (size_t)x_bytes : 0);
+    // (+256: the pixel-slot GEMM a strided pointwise layer continues with reads up to 14 bytes past a ragged last plane)
+    const size_t ws_bytes = ws_w + (split ? (size_t)x_bytes + 256 : 0);
     char *ws = nullptr;
     if (ws_bytes) {
         int st = infini_rocm_workspace(rt, ws_bytes, (void **)&ws);
@@ -1371,6 +1378,16 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
         }
         IROCM_LAUNCH_CHECK("conv_phase_split");
         p.x = ps.o;
+        // a strided 1 x 1 layer (ResNet's down-sampling branches) reads ONE phase: the plane set just written is a dense
+        // [n][c][oh][ow] activation, i.e. a unit-stride pointwise layer — one GEMM over pixel slots on the persistent kernels
+        // when it has the filters to fill their 256-row tiles (conv.hip has the rule and the numbers)
+        if (r == 1 && s == 1 && ps.nslots == 1 && c % 64 == 0 && (act == 0 || act == 1) &&
+            (rt->conv_variant == 5 ||
+             (rt->conv_variant < 0 && f >= 128 && ceil_div(f, 256) * ceil_div((long)n * ((oh * ow + 7) / 8 * 8), 256) * 2 >= rt->num_cu))) {
+            const int st = launch_conv_pw_gemm(rt, dtype, ps.o, w, bias, res, y, n, c, (long)oh * ow, f, act);
+            if (st >= 0)
+                return st;
+        }
     }
     const bool bf = dtype == INFINI_DT_BF16;
     static const int pw_on = getenv("IROCM_CONV_PW") ? atoi(getenv("IROCM_CONV_PW")) : 1; // tuning hook: 0 = off

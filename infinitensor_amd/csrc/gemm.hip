@@ -480,6 +480,21 @@ static double splitk_cost(long m, long n, long k, long batch, int splits) {
     return 3.0 + (double)(k / 64) / splits * kKt[4] + 12.0 + (double)batch * m * n * (4.0 * splits + 2.0) / 5.0e6;
 }
 
+// tile width (NT = 4 / 3 / 2 -> 256 / 192 / 128 columns) the cost model prefers for an m x n x k problem on the persistent
+// kernels; max_nt caps it (the conv mode's residual copy exists up to NT = 3)
+int persist_pick_nt(long m, long n, long k, int cus, int max_nt) {
+    int best_nt = max_nt < 4 ? max_nt : 4;
+    double best = 1e30;
+    for (int nt = best_nt; nt >= 2; --nt) {
+        const double c = persist_cost(m, n, k, 1, nt, cus);
+        if (c < best * 0.97) {
+            best = c;
+            best_nt = nt;
+        }
+    }
+    return best_nt;
+}
+
 } // namespace irocm
 
 using namespace irocm;

@@ -1,0 +1,71 @@
+// gemm256p in conv mode (gemm256p_kernel.h, CONV): pointwise convolutions with >= 256 filters as ONE GEMM over pixel slots.
+// One translation unit for the three tile widths (A K-major, B gathered from NCHW: one layout each).
+#include "gemm256p_kernel.h"
+
+namespace irocm {
+namespace g256p {
+
+// p: m = F, n = images * hwp, k = C, a = W [F][C], b = X (NCHW), c = Y (NCHW), bias = [F] or nullptr, cv_* set by the caller.
+// The residual copy exists for tile widths 192 / 128 only (registers, gemm256p_kernel.h): nt = 4 with a residual runs as nt = 2.
+int launch_gemm256p_conv(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, int nt) {
+    const bool res = p.cv_res != nullptr;
+    if (res && nt == 4)
+        nt = 2;
+    if (dtype == INFINI_DT_BF16) {
+        if (res)
+            return nt == 3 ? launch_p_conv<Bf16Traits, 3, true>(rt, p) : launch_p_conv<Bf16Traits, 2, true>(rt, p);
+        if (nt == 4) return launch_p_conv<Bf16Traits, 4, false>(rt, p);
+        if (nt == 3) return launch_p_conv<Bf16Traits, 3, false>(rt, p);
+        return launch_p_conv<Bf16Traits, 2, false>(rt, p);
+    }
+    if (res)
+        return nt == 3 ? launch_p_conv<F16Traits, 3, true>(rt, p) : launch_p_conv<F16Traits, 2, true>(rt, p);
+    if (nt == 4) return launch_p_conv<F16Traits, 4, false>(rt, p);
+    if (nt == 3) return launch_p_conv<F16Traits, 3, false>(rt, p);
+    return launch_p_conv<F16Traits, 2, false>(rt, p);
+}
+
+} // namespace g256p
+
+int persist_pick_nt(long m, long n, long k, int cus, int max_nt);
+
+// Pointwise convolution as one GEMM over pixel slots (see infini_rocm_conv2d_res). Returns -1 when the operands do not qualify
+// (the caller falls through to the other kernels), a status otherwise.
+int launch_conv_pw_gemm(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, const void *bias, const void *res,
+                               void *y, int64_t n, int64_t c, int64_t hw, int64_t f, int act) {
+    const int64_t hwp = (hw + 7) & ~(int64_t)7;
+    if (hw < 8 || (((uintptr_t)w) & 15) != 0 || (((uintptr_t)x) & 1) != 0 || (((uintptr_t)y) & 1) != 0)
+        return -1;
+    // 32-bit byte offsets into X for the LDS-DMA, 32-bit element offsets into Y / the residual
+    if (n * c * hw * 2 >= (1ll << 32) - 64 || n * f * hw >= (1ll << 31) - 64 || n * hwp >= (1ll << 31) - 512)
+        return -1;
+    if (hw % 8 != 0) {
+        // the last 16-byte run of a plane reaches up to 14 bytes past it: at the very end of X that must be readable memory.
+        // True when the allocation X lives in goes on (an arena of infini_rocm_alloc always does: 256 bytes of slack; a caller's own
+        // tensor that ends exactly at the end of its hipMalloc block does not, and takes the other kernels).
+        const char *x_end = (const char *)x + n * c * hw * 2;
+        hipDeviceptr_t base = nullptr;
+        size_t size = 0;
+        if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)(x_end - 2)) != hipSuccess) {
+            (void)hipGetLastError();
+            return -1;
+        }
+        if (x_end + 16 > (const char *)base + size)
+            return -1;
+    }
+    GemmArgs p;
+    memset(&p, 0, sizeof(p));
+    p.a = w; p.b = x; p.bias = bias; p.c = y;
+    p.m = (int)f; p.n = (int)(n * hwp); p.k = (int)c; p.batch = 1;
+    p.a_rs = c; p.a_cs = 1;
+    p.act = act;
+    p.splitk = 1;
+    p.zeros = rt->zeros;
+    p.epi16 = 1;
+    p.cv_hw = (int)hw; p.cv_hwp = (int)hwp; p.cv_res = res;
+    const int nt = persist_pick_nt(f, n * hwp, c, rt->num_cu, res ? 3 : 4);
+    rt->last_conv_route = "pixel_gemm";
+    return g256p::launch_gemm256p_conv(rt, dtype, p, nt);
+}
+
+} // namespace irocm

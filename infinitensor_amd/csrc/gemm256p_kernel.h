@@ -69,7 +69,12 @@ constexpr int kTraceSlots = 128;
 
 // TRACE: every wave stamps s_memtime at phase boundaries into a private LDS strip behind the K-tile buffers (no VMEM
 // traffic, so the vmcnt bookkeeping is untouched) and dumps the strip at the end — tools/gemm_timeline.py.
-template <typename Tr, bool A_KMAJOR, bool B_KMAJOR, int NT, bool TRACE = false>
+// CONV (round 3): the pointwise-convolution mode described at GemmArgs::cv_hw — the B tile is gathered from an NCHW activation
+// by pixel slots (offs_mn_conv), the epilogue adds a per-FILTER bias and an optional residual and stores NCHW (16-byte runs inside
+// a plane, the ragged last run of a plane element-wise). A K-major (the FCRS weights of a 1 x 1 layer ARE [F][C]), B N-major.
+// CONV = 1: without, CONV = 2: with the residual (its own instantiation: the residual copy of the epilogue needs 16 NT more
+// registers, which the 256-column build does not have — it exists for NT <= 3 only).
+template <typename Tr, bool A_KMAJOR, bool B_KMAJOR, int NT, bool TRACE = false, int CONV = 0>
 __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     const GemmArgs &p = pa.g;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     };
 
     const long lda = A_KMAJOR ? p.a_rs : p.a_cs;
-    const long ldb = B_KMAJOR ? p.b_cs : p.b_rs;
+    const long ldb = CONV ? (long)p.cv_hw : (B_KMAJOR ? p.b_cs : p.b_rs);
     const long a_step = A_KMAJOR ? (long)BK * 2 : (long)BK * lda * 2; // bytes per K-tile (wave-uniform)
     const long b_step = B_KMAJOR ? (long)BK * 2 : (long)BK * ldb * 2;
 
@@ -131,7 +136,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         int ib, m0, n0;
         decode(s, ib, m0, n0);
         b_base = (const char *)((const unsigned short *)p.b + (long)ib * p.b_bs);
-        if constexpr (B_KMAJOR) offs_k_n<NT>(b_off, ldb, n0, p.n, w, lane);
+        if constexpr (CONV) offs_mn_conv(b_off, p.cv_hw, p.cv_hwp, (long)p.k * p.cv_hw, n0, p.n, w, lane);
+        else if constexpr (B_KMAJOR) offs_k_n<NT>(b_off, ldb, n0, p.n, w, lane);
         else offs_mn(b_off, ldb, n0, p.n, w, lane);
     };
     auto stage_a_next = [&](int buf) {
@@ -374,6 +380,154 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         }
     };
 
+    // ---- conv-mode epilogue: rows are filters, columns pixel slots; Y is NCHW ---------------------------------------
+    auto epilogue_conv = [&](auto actc, auto resc, int m0, int n0) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(actc)::value;
+        constexpr bool has_res = decltype(resc)::value; // compile-time: the residual registers exist in the residual copies only
+        auto act1 = [&](float v) {
+            if constexpr (ACT == 1) return v > 0.f ? v : 0.f;
+            else return v;
+        };
+        unsigned short *Y = (unsigned short *)p.c;
+        const unsigned short *bias = (const unsigned short *)p.bias;
+        const int HW = p.cv_hw, HWP = p.cv_hwp, F = p.m;
+        const bool odd = g4 & 1;
+        // this lane's column pieces: NT / 2 runs of 8 slots (after the lane-group exchange) and, for odd NT, one run of 4
+        int pbase[NT / 2 > 0 ? NT / 2 : 1]; // element offset of (img, filter 0, pix) (the launcher admits < 2^31 elements)
+        int plive[NT / 2 > 0 ? NT / 2 : 1];  // live pixels of the run: 8 inside a plane, fewer at its ragged end, 0 past the tensor
+        sfor<NT / 2>([&](auto jpc) {
+            constexpr int jp = decltype(jpc)::value;
+            const int col = n0 + wc * (16 * NT) + (jp * 2 + (odd ? 1 : 0)) * 16 + (g4 & ~1) * 4;
+            const int img = col / HWP, pix = col - img * HWP;
+            pbase[jp] = (img * F) * HW + pix;
+            plive[jp] = col < p.n ? min(8, HW - pix) : 0;
+        });
+        int obase = 0, olive = 0;
+        if constexpr (NT % 2 == 1) {
+            const int col = n0 + wc * (16 * NT) + (NT - 1) * 16 + g4 * 4;
+            const int img = col / HWP, pix = col - img * HWP;
+            obase = (img * F) * HW + pix;
+            olive = col < p.n ? max(0, min(4, HW - pix)) : 0;
+        }
+        float bvr[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = m0 + wr * 128 + i * 16 + l15;
+            bvr[i] = (bias != nullptr && row < F) ? Tr::to_f32(bias[row]) : 0.f;
+        }
+        // Residual: every piece of the tile is fetched BEFORE the first store (the operand-fragment registers are dead here),
+        // 4 slots (8 bytes) per accumulator tile — the lane's OWN columns, so that the sum, the activation and the rounding
+        // happen before the packed halves are exchanged between lane groups exactly as in the GEMM epilogue — through a
+        // range-checked buffer descriptor (a run in a dead slot or past the tensor reads zeros); one wait for all of them:
+        // a load inside the store sequence would have to drain the stores in front of it (loads and stores share vmcnt).
+        u32x2_t rr[has_res ? 8 : 1][has_res ? NT : 1];
+        if constexpr (has_res) {
+            const long total_bytes = (long)(p.n / HWP) * F * HW * 2;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.cv_res), 0, (int)total_bytes, 0x00020000);
+            int cb[NT]; // byte offset of the lane's 4 slots of tile j at filter 0; `total_bytes` (-> zeros) for dead slots
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int col = n0 + wc * (16 * NT) + j * 16 + g4 * 4;
+                const int img = col / HWP, pix = col - img * HWP;
+                cb[j] = (col < p.n && pix < HW) ? ((img * F) * HW + pix) * 2 : -1;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = m0 + wr * 128 + i * 16 + l15;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int voff = (cb[j] >= 0 && row < F) ? cb[j] + row * HW * 2 : (int)total_bytes; // else: zeros
+                    if (voff + 8 <= (int)total_bytes || voff >= (int)total_bytes) {
+                        rr[i][j] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0));
+                    } else {
+                        // the ragged run at the very end of the tensor: the descriptor's range check works per (misaligned)
+                        // dword and would zero the last live element together with the bytes behind it — fetch by element
+                        unsigned e[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            e[q] = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, voff + 2 * q, 0, 0);
+                        u32x2_t v;
+                        v[0] = e[0] | (e[1] << 16);
+                        v[1] = e[2] | (e[3] << 16);
+                        rr[i][j] = v;
+                    }
+                }
+            }
+        }
+        auto pack4 = [&](int i, auto jc, unsigned (&pk)[2]) { // bias + residual + activation + rounding of the lane's 4 slots of tile j
+            constexpr int j = decltype(jc)::value;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                v[r] = acc[i][j][r] + bvr[i];
+            if constexpr (has_res) {
+                v[0] += Tr::to_f32((unsigned short)(rr[i][j][0] & 0xffff));
+                v[1] += Tr::to_f32((unsigned short)(rr[i][j][0] >> 16));
+                v[2] += Tr::to_f32((unsigned short)(rr[i][j][1] & 0xffff));
+                v[3] += Tr::to_f32((unsigned short)(rr[i][j][1] >> 16));
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                v[r] = act1(v[r]);
+            pk[0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
+            pk[1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
+        };
+        auto store_run = [&](unsigned short *dst, const u32x4_t &o, int live) { // `live` of the 8 values in o
+            if (live == 8) {
+                *(u32x4_t *)dst = o; // (8-byte aligned when the plane is not a multiple of 8 pixels: dwordx4 only needs dwords)
+                return;
+            }
+            int e = 0;
+            if (live & 4) {
+                u32x2_t v;
+                v[0] = o[0]; v[1] = o[1];
+                *(u32x2_t *)dst = v;
+                e = 4;
+            }
+            if (live & 2) {
+                *(unsigned *)(dst + e) = e ? o[2] : o[0];
+                e += 2;
+            }
+            if (live & 1)
+                dst[e] = (unsigned short)((e == 0 ? o[0] : e == 2 ? o[1] : e == 4 ? o[2] : o[3]) & 0xffff);
+        };
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = m0 + wr * 128 + i * 16 + l15;
+            sfor<NT / 2>([&](auto jpc) {
+                constexpr int jp = decltype(jpc)::value;
+                unsigned pk[2][2];
+                pack4(i, std::integral_constant<int, jp * 2>{}, pk[0]);
+                pack4(i, std::integral_constant<int, jp * 2 + 1>{}, pk[1]);
+                // lane groups g4 / g4 ^ 1 trade halves (v_permlane16_swap, as in the GEMM epilogue): an even group ends with 8
+                // consecutive slots of tile 2 jp, an odd one with 8 of tile 2 jp + 1
+                const u32x2_t t0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                const u32x2_t t1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+                u32x4_t o;
+                o[0] = t0[0]; o[1] = t1[0]; o[2] = t0[1]; o[3] = t1[1];
+                if (row < F && plive[jp] > 0)
+                    store_run(Y + pbase[jp] + row * HW, o, plive[jp]);
+            });
+            if constexpr (NT % 2 == 1) {
+                unsigned pk[2];
+                pack4(i, std::integral_constant<int, NT - 1>{}, pk);
+                if (row < F && olive > 0) {
+                    unsigned short *dst = Y + obase + row * HW;
+                    if (olive == 4) {
+                        u32x2_t v;
+                        v[0] = pk[0]; v[1] = pk[1];
+                        *(u32x2_t *)dst = v;
+                    } else {
+                        if (olive & 2)
+                            *(unsigned *)dst = pk[0];
+                        if (olive & 1)
+                            dst[olive & 2] = (unsigned short)((olive & 2 ? pk[1] : pk[0]) & 0xffff);
+                    }
+                }
+            }
+        }
+    };
+
     // ---- the flat K-tile pipeline ------------------------------------------------------------------
     FA aq[4][2];
     FB bq0[2][2], bq1[2][2];
@@ -445,9 +599,15 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         if (wr == 0)
             barrier();
         // this wave's part of tile c_s is complete; G = first K-tile of the next tile
-        if (p.act == 0) epilogue(std::integral_constant<int, 0>{}, c_ib, c_m0, c_n0);
-        else if (p.act == 1) epilogue(std::integral_constant<int, 1>{}, c_ib, c_m0, c_n0);
-        else epilogue(std::integral_constant<int, 5>{}, c_ib, c_m0, c_n0); // launch_p admits act 0, 1, 5 only
+        if constexpr (CONV != 0) { // the conv launcher admits act 0 / 1 only
+            using R = std::integral_constant<bool, CONV == 2>;
+            if (p.act == 0) epilogue_conv(std::integral_constant<int, 0>{}, R{}, c_m0, c_n0);
+            else epilogue_conv(std::integral_constant<int, 1>{}, R{}, c_m0, c_n0);
+        } else {
+            if (p.act == 0) epilogue(std::integral_constant<int, 0>{}, c_ib, c_m0, c_n0);
+            else if (p.act == 1) epilogue(std::integral_constant<int, 1>{}, c_ib, c_m0, c_n0);
+            else epilogue(std::integral_constant<int, 5>{}, c_ib, c_m0, c_n0); // launch_p admits act 0, 1, 5 only
+        }
         if (c_s + 1 < my_tiles)
             zero_acc();
         if (wr == 1)
@@ -508,6 +668,28 @@ static int launch_p(infiniRocmRuntime_t rt, GemmArgs g, bool akm, bool bkm, unsi
     }
 #undef IROCM_G256P
     IROCM_LAUNCH_CHECK("gemm256p");
+    return INFINI_ROCM_OK;
+}
+
+// conv mode: one instantiation per tile width and residual flag (A K-major, B gathered by pixel slots)
+template <typename Tr, int NT, bool RES> static int launch_p_conv(infiniRocmRuntime_t rt, GemmArgs g) {
+    PArgs pa;
+    pa.trace = nullptr;
+    g.tiles_m = (int)ceil_div(g.m, BM);
+    g.tiles_n = (int)ceil_div(g.n, 64 * NT);
+    const long total = (long)g.tiles_m * g.tiles_n;
+    if (total >= (1l << 31))
+        IROCM_FAIL(INFINI_ROCM_INVALID_ARGUMENT, "conv: too many tiles");
+    pa.g = g;
+    pa.total_tiles = (int)total;
+    unsigned grid = (unsigned)total;
+    const unsigned cus = (unsigned)(rt->num_cu >= 8 ? (rt->num_cu / 8) * 8 : rt->num_cu);
+    if (grid > cus)
+        grid = cus;
+    auto kern = gemm256p_kernel<Tr, true, false, NT, false, RES ? 2 : 1>;
+    IROCM_LDS_ATTR(kern, LDS_BYTES, rt);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, rt->stream, pa);
+    IROCM_LAUNCH_CHECK("gemm256p(conv)");
     return INFINI_ROCM_OK;
 }
 

@@ -37,6 +37,12 @@ struct GemmArgs {
     // i.e. the MatMul -> Reshape([B, S, H, D]) -> Transpose(0, 2, 1, 3) chain of a transformer's q / k / v projections
     // written by the GEMM itself. hs_d % 8 == 0 so a 16-byte store never straddles two heads.
     int hs_s, hs_d;
+    // conv mode of the persistent kernels (gemm256p_kernel.h, CONV): a pointwise convolution Y[img][f][pix] = W[f][c] X[img][c][pix]
+    // as ONE GEMM whose columns are pixel SLOTS img * cv_hwp + pix (cv_hwp = the plane rounded up to 8, so a 16-byte run never
+    // straddles two images): m = F, k = C, n = images * cv_hwp; b = X, c = Y (NCHW), bias = one value per ROW (filter),
+    // cv_res = the residual added before the activation (NCHW like Y, or nullptr). 0 = off.
+    int cv_hw = 0, cv_hwp = 0;
+    const void *cv_res = nullptr;
 };
 
 // element offset of C(row, col) inside one batch's [m x n] block

@@ -214,7 +214,9 @@ int infini_rocm_alloc(infiniRocmRuntime_t rt, size_t bytes, void **ptr) {
     *ptr = nullptr;
     if (bytes == 0)
         return INFINI_ROCM_OK;
-    IROCM_HIP(hipMalloc(ptr, bytes));
+    // 256 bytes of slack behind every block: kernels that fetch whole 16-byte runs (the conv mode of the persistent GEMM on
+    // planes that are not a multiple of 8 pixels) may read a few bytes past the last tensor of an arena
+    IROCM_HIP(hipMalloc(ptr, bytes + 256));
     return INFINI_ROCM_OK;
 }
 

@@ -163,6 +163,15 @@ def set_matmul_variant(rt: RocmRuntime, variant: int) -> None:
     check(lib().infini_rocm_matmul_set_variant(rt.handle, int(variant)))
 
 
+def conv_last_route(rt: RocmRuntime) -> str:
+    """Which conv2d implementation the most recent call on this runtime launched (include/infini_rocm.h)."""
+    import ctypes as C
+
+    v = C.c_char_p()
+    check(lib().infini_rocm_conv2d_last_route(rt.handle, C.byref(v)))
+    return v.value.decode()
+
+
 def matmul_last_variant(rt: RocmRuntime) -> str:
     """Name of the GEMM kernel variant the most recent matmul on this runtime launched ("none" before the first)."""
     import ctypes as C

@@ -17,6 +17,14 @@ def dev(a, dtype=None):
     return (t.to(dtype) if dtype is not None else t).cuda()
 
 
+def dev_slack(a, dtype):
+    """`a` on the device with 64 spare elements behind it (what every tensor of the plugin's arena has): the pixel-slot GEMM reads
+    up to 14 bytes past a ragged last plane and refuses inputs for which it cannot prove those bytes readable."""
+    a = np.ascontiguousarray(a)
+    buf = torch.zeros((a.size + 64,), device="cuda", dtype=dtype)
+    return buf[: a.size].view(a.shape).copy_(torch.from_numpy(a))
+
+
 def host(t):
     return t.float().cpu().numpy().astype(np.float64)
 
@@ -393,3 +401,103 @@ def test_conv_residual_lds_epilogue_act_and_bf16(rt, dt, act):
         tol = {"f16": 3e-3, "bf16": 2.4e-2}[dt]
         assert np.allclose(host(y), want, rtol=tol, atol=tol), (dt, act, c, np.abs(host(y) - want).max())
         assert torch.equal(dres, keep)
+
+
+PW_GEMM = [  # (n, c, h, w, f): pointwise layers for the conv mode of the persistent GEMM (variant 5)
+    (3, 64, 8, 8, 256),      # plane of 64 pixels: a 256-slot tile spans four images
+    (5, 128, 14, 14, 512),   # 196 pixels: 4-pixel ragged run at every plane end, tiles span images
+    (9, 192, 7, 7, 320),     # 49 pixels: 1-pixel ragged run, filters not a multiple of 256 (ragged M), K = 3 tiles
+    (2, 256, 28, 28, 256),   # 784 pixels: whole tiles inside a plane
+    (1, 64, 3, 3, 64),       # 9 pixels (below the kernel's minimum of 8 usable... 9 >= 8: one run + one pixel), tiny
+    (2, 64, 5, 4, 300),      # 20 pixels: 4-pixel tail
+    (4, 64, 6, 5, 260),      # 30 pixels: 6-pixel tail (4 + 2)
+    (2, 64, 5, 3, 256),      # 15 pixels: 7-pixel tail (4 + 2 + 1)
+]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("mode", ["plain", "bias_relu", "bias_res_relu", "res"])
+@pytest.mark.parametrize("cfg", PW_GEMM)
+def test_conv_pointwise_gemm_mode(rt, cfg, dt, mode):
+    """Unit-stride 1 x 1 convolutions as ONE GEMM over pixel slots on the persistent 256-row kernels (gemm256p_kernel.h, CONV;
+    conv variant 5, the default for >= 256 filters): planes that are and are not multiples of 8 pixels (ragged last run of every
+    plane: 4 + 2 + 1 stores), tiles spanning images, ragged filter counts, with per-filter bias / residual / ReLU in the
+    epilogue — against the oracle and against the tap-shifted kernel (variant 2)."""
+    n, c, h, w, f = cfg
+    rng = np.random.default_rng(abs(hash(cfg)) % 2 ** 32)
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((f, c, 1, 1)) / np.sqrt(c)).astype(np.float32)
+    b = rng.standard_normal((f,)).astype(np.float32) if "bias" in mode else None
+    res = rng.standard_normal((n, f, h, w)).astype(np.float32) if "res" in mode else None
+    act = 1 if "relu" in mode else 0
+    xd, wd = dev_slack(x, TD[dt]), dev(wt, TD[dt])
+    bd = dev(b, TD[dt]) if b is not None else None
+    rd = dev(res, TD[dt]) if res is not None else None
+    keep = rd.clone() if rd is not None else None
+    guard = torch.full((n, f, h, w), 7.0, device="cuda", dtype=TD[dt])  # the output buffer, pre-filled: every element must be written
+    try:
+        ops.set_conv_variant(rt, 5)
+        y = ops.conv2d(rt, xd, wd, 0, 0, 1, 1, bias=bd, act=act, residual=rd, out=guard)
+        assert ops.conv_last_route(rt) == "pixel_gemm"  # not a silent fall-back to the kernel it is compared with
+        ops.set_conv_variant(rt, 2)
+        y2 = ops.conv2d(rt, xd, wd, 0, 0, 1, 1, bias=bd, act=act, residual=rd)
+    finally:
+        ops.set_conv_variant(rt, -1)
+    want = R.conv2d(R.round_to(x, dt), R.round_to(wt, dt), 0, 0, 1, 1, 1, 1)
+    if b is not None:
+        want = want + R.round_to(b, dt).reshape(1, f, 1, 1)
+    if res is not None:
+        want = want + R.round_to(res, dt)
+        assert torch.equal(rd, keep)
+    if act:
+        want = np.maximum(want, 0)
+    tol = {"f16": 3e-3, "bf16": 2.4e-2}[dt]
+    assert np.allclose(host(y), want, rtol=tol, atol=tol), np.abs(host(y) - want).max()
+    assert np.allclose(host(y), host(y2), rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("cfg", [(4, 256, 28, 28, 512, 2), (8, 128, 15, 13, 256, 2), (2, 64, 30, 30, 256, 3)])
+def test_conv_strided_pointwise_goes_through_the_phase_split_into_the_gemm_mode(rt, cfg, dt):
+    """ResNet's down-sampling 1 x 1 / 2 layers: the phase split leaves ONE dense [n][c][oh][ow] plane set, which then is a
+    unit-stride pointwise layer for the conv mode of the persistent GEMM (conv_s1.hip, launch_conv_s1). Odd input sizes (the
+    sampled grid ends before the input does) and stride 3 included; against the oracle and the tap-shifted kernel."""
+    n, c, h, w, f, st = cfg
+    rng = np.random.default_rng(abs(hash(cfg)) % 2 ** 32)
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((f, c, 1, 1)) / np.sqrt(c)).astype(np.float32)
+    b = rng.standard_normal((f,)).astype(np.float32)
+    xd, wd, bd = dev(x, TD[dt]), dev(wt, TD[dt]), dev(b, TD[dt])  # (the GEMM reads the phase planes in the workspace, not x)
+    try:
+        ops.set_conv_variant(rt, 5)
+        y = ops.conv2d(rt, xd, wd, 0, 0, st, st, bias=bd, act=0)
+        assert ops.conv_last_route(rt) == "pixel_gemm"
+        ops.set_conv_variant(rt, 2)
+        y2 = ops.conv2d(rt, xd, wd, 0, 0, st, st, bias=bd, act=0)
+        assert ops.conv_last_route(rt) == "tap_shifted"
+    finally:
+        ops.set_conv_variant(rt, -1)
+    want = R.conv2d(R.round_to(x, dt), R.round_to(wt, dt), 0, 0, st, st, 1, 1) + R.round_to(b, dt).reshape(1, f, 1, 1)
+    tol = {"f16": 3e-3, "bf16": 2.4e-2}[dt]
+    assert np.allclose(host(y), want, rtol=tol, atol=tol), np.abs(host(y) - want).max()
+    assert np.allclose(host(y), host(y2), rtol=tol, atol=tol)
+
+
+def test_conv_pointwise_gemm_mode_does_not_write_outside_its_output(rt):
+    """The NCHW store of the conv mode ends every plane with a ragged run: the bytes right behind the output tensor (and the
+    residual's) must stay untouched."""
+    n, c, h, f = 3, 64, 7, 256
+    buf = torch.full((n * f * h * h + 64,), 3.0, device="cuda", dtype=torch.float16)
+    out = buf[: n * f * h * h].view(n, f, h, h)
+    x = dev_slack(np.random.default_rng(3).standard_normal((n, c, h, h)).astype(np.float32), torch.float16)
+    w = (torch.randn(f, c, 1, 1, device="cuda") / 8).half()
+    try:
+        ops.set_conv_variant(rt, 5)
+        ops.conv2d(rt, x, w, 0, 0, 1, 1, out=out)
+        assert ops.conv_last_route(rt) == "pixel_gemm"
+    finally:
+        ops.set_conv_variant(rt, -1)
+    rt.sync()
+    assert torch.all(buf[n * f * h * h:] == 3.0).item()
+    ref = torch.einsum("fc,nchw->nfhw", w.view(f, c).float(), x.float())
+    assert torch.allclose(out.float(), ref, rtol=3e-3, atol=3e-3)
