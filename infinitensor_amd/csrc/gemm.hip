@@ -462,10 +462,11 @@ constexpr int kNumVariants = 8; // 1-6 serve f16 / bf16, 7 serves f32, 0 everyth
 
 // Cost model behind the heuristic (microseconds; fitted to tools/gemm_shapes.py on MI355X, bf16 / f16, N(0,1) data).
 // A workgroup of the persistent kernel walks its tiles: a K-tile of a 256 x 64 NT tile costs kKt[NT]; every tile pays its
-// tile boundary (both wave rows' epilogues side by side, ~10.5 k cycles, + the pipeline restart; gemm256p_kernel.h); launch +
-// first prologue ~3 us once. Re-fitted after the epilogues were de-serialised (profiles/r02_gemm_shapes_bf16.txt).
+// tile boundary (both wave rows' epilogues side by side + the pipeline restart; gemm256p_kernel.h); launch + first prologue
+// ~3 us once. Re-fitted after the epilogues were de-serialised (round 2: ~12.4 k cycles per boundary) and again after their
+// stores went quad-contiguous (round 3: ~7.9 k cycles; profiles/r03_gemm_shapes_bf16.txt).
 static const double kKt[5] = {0, 0, 0.91, 1.10, 1.40};
-static const double kStoreTail[5] = {0, 0, 5.4, 7.0, 7.5};
+static const double kStoreTail[5] = {0, 0, 4.2, 5.2, 5.5};
 static double persist_cost(long m, long n, long k, long batch, int nt, int cus) {
     const long tiles = ceil_div(m, 256) * ceil_div(n, 64 * nt) * batch;
     const long full = tiles / cus;

@@ -44,6 +44,18 @@ template <> struct Frag<false> {
     }
 };
 
+// ds_bpermute_b32 (dst lane L <- src lane addr[L] / 4) as opaque asm: hipcc then inserts no lgkmcnt(0) of its own before the first
+// use and the caller waits with a COUNT (wait_lgkm<N>: results of LDS instructions return in order), i.e. can keep the next
+// exchange in flight under the stores of this one. The result must not be read before that wait.
+__device__ __forceinline__ unsigned lds_bpermute(int addr, unsigned v) {
+    unsigned r;
+    asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(r) : "v"(addr), "v"(v));
+    return r;
+}
+template <int N> __device__ __forceinline__ void wait_lgkm() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
 __device__ __forceinline__ void wait_lgkm0() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);

@@ -312,13 +312,124 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 v[r] = act1(v[r] + bv[j][r]);
-            pk[0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
-            pk[1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
+            pk[0] = Tr::pack2(v[0], v[1]);
+            pk[1] = Tr::pack2(v[2], v[3]);
         };
         if (interior && p.epi16 && (p.n % 8 == 0) && ((((uintptr_t)p.c) & 15) == 0)) {
             // 16-byte stores: lane groups g4 / g4^1 swap halves of a PAIR of column tiles (gemm256.hip); an odd last
-            // column tile (NT = 3) goes out as 8-byte stores
+            // column tile (NT = 3) goes out as 8-byte stores.
+            // The epilogue is VALU-issue-bound, not store-bound (tools/probes/store_burst.hip: a CU retires this tile's 128 KiB in
+            // 2-4 k cycles from 128 back-to-back dwordx4 stores; the epilogue took 4.6 k cycles of VALU issue per SIMD): per store
+            // it now spends 8 bias adds, 4 packed conversions (v_cvt_pk_*: one per PAIR), 2 lane-group swaps and NO address
+            // arithmetic — the row part of the address is wave-uniform (scalar base, bumped by scalar adds), the lane part a
+            // 32-bit offset computed once per tile. (Before: one conversion per value + shift + or, and a 64-bit multiply-add
+            // chain with a branch on the head-split layout per store: 36 VALU slots per store.)
             const bool odd = g4 & 1;
+            // Head-split layout (the fused q / k / v projections: C[row][col] -> [row / S][col / D][row % S][col % D]) separates
+            // the same way when S % 16 == 0: a wave's 16 rows of one store never straddle a sequence, so (row / S, row % S) of
+            // the wave's first row is wave-uniform and advances by scalar adds; the lane adds l15 * D and its column part.
+            const bool hs = p.hs_d != 0;
+            if (!hs || (p.hs_s % 16 == 0 && (long)p.n * p.hs_s < (1l << 30))) {
+                const unsigned ldc2 = (unsigned)p.n * 2u; // bytes per row of a plain C
+                // Lane -> address map of a store. The texture addresser merges only CONSECUTIVE lanes into one request: with the
+                // accumulator layout's natural map (lane = g4 * 16 + l15: sixteen consecutive lanes walk down sixteen rows) every
+                // 16-byte lane is its own request and a CU retires 13-15 B/clk — the "store-issue-bound" 9-10 k-cycle epilogue of
+                // round 2. With four consecutive lanes on one row (64 contiguous bytes per quad) the same stores retire at
+                // 45-60 B/clk (tools/probes/store_burst2.hip: 128 KiB per CU in 2.3-2.6 k cycles instead of 7.4-8.2 k). The data
+                // moves to that map by one ds_bpermute_b32 per dword (the LDS crossbar, no LDS memory): destination lane
+                // L = 4 * row + chunk takes the registers of source lane 16 * g4 + row, g4 = 2 * (chunk & 1) + (chunk >> 1).
+                const int qrow = lane >> 2, qchunk = lane & 3;
+                const int bperm_src = (16 * (2 * (qchunk & 1) + (qchunk >> 1)) + qrow) * 4;
+                const int bperm_src_odd = (16 * qchunk + qrow) * 4; // odd last tile: 8 bytes per lane, chunk = g4
+                const unsigned lane_row = (unsigned)qrow * (hs ? (unsigned)p.hs_d * 2u : ldc2);
+                auto col_part = [&](int col) -> unsigned { // byte offset contributed by the column
+                    if (!hs)
+                        return (unsigned)col * 2u;
+                    const unsigned h = (unsigned)col / (unsigned)p.hs_d, d = (unsigned)col - h * (unsigned)p.hs_d;
+                    return (h * (unsigned)p.hs_s * (unsigned)p.hs_d + d) * 2u;
+                };
+                unsigned voff[NT / 2 > 0 ? NT / 2 : 1];
+                sfor<NT / 2>([&](auto jpc) {
+                    constexpr int jp = decltype(jpc)::value;
+                    voff[jp] = lane_row + col_part(n0 + wc * (16 * NT) + jp * 32 + qchunk * 8);
+                });
+                unsigned voff_odd = 0;
+                if constexpr (NT % 2 == 1)
+                    voff_odd = lane_row + col_part(n0 + wc * (16 * NT) + (NT - 1) * 16 + qchunk * 4);
+                // wave-uniform part: the wave's first row R0 = m0 + wr * 128 (+ 16 per step)
+                const int R0 = m0 + wr * 128;
+                int s0 = 0;              // R0 % S (head-split only)
+                long step = 16l * ldc2;  // bytes between steps
+                long wrap = 0;           // added when s0 wraps into the next sequence
+                char *sbase;
+                if (hs) {
+                    const int bq = R0 / p.hs_s;
+                    s0 = R0 - bq * p.hs_s;
+                    sbase = (char *)C + ((long)bq * p.n * p.hs_s + (long)s0 * p.hs_d) * 2;
+                    step = 32l * p.hs_d;
+                    wrap = ((long)p.n - p.hs_d) * p.hs_s * 2;
+                } else {
+                    sbase = (char *)C + (long)R0 * (long)ldc2;
+                }
+                // One step = the wave's 16 rows x 64 NT columns: NT / 2 16-byte stores (+ one 8-byte store for an odd NT). The
+                // lane exchange of step i + 1 is issued BEFORE the stores of step i, so that a store never waits out the
+                // ds_bpermute latency of its own data (LDS results return in order: the wait is a counted lgkmcnt).
+                u32x4_t ov[2][NT / 2 > 0 ? NT / 2 : 1];
+                u32x2_t ov_odd[2];
+                auto make = [&](int i, int slot) __attribute__((always_inline)) {
+                    sfor<NT / 2>([&](auto jpc) {
+                        constexpr int jp = decltype(jpc)::value;
+                        unsigned pk[2][2];
+                        pack2(i, std::integral_constant<int, jp * 2>{}, 0, pk[0]);
+                        pack2(i, std::integral_constant<int, jp * 2 + 1>{}, 0, pk[1]);
+                        // v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of the second: even lanes end
+                        // with {own, right neighbour's} 4 + 4 columns of tile 2jp, odd lanes with {left neighbour's, own} of
+                        // tile 2jp + 1 — one VALU op per dword, no LDS round trip, no selects
+                        const u32x2_t t0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                        const u32x2_t t1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+                        ov[slot][jp][0] = lds_bpermute(bperm_src, t0[0]);
+                        ov[slot][jp][1] = lds_bpermute(bperm_src, t1[0]);
+                        ov[slot][jp][2] = lds_bpermute(bperm_src, t0[1]);
+                        ov[slot][jp][3] = lds_bpermute(bperm_src, t1[1]);
+                    });
+                    if constexpr (NT % 2 == 1) {
+                        unsigned pk[2];
+                        pack2(i, std::integral_constant<int, NT - 1>{}, 0, pk);
+                        ov_odd[slot][0] = lds_bpermute(bperm_src_odd, pk[0]);
+                        ov_odd[slot][1] = lds_bpermute(bperm_src_odd, pk[1]);
+                    }
+                };
+                constexpr int kPerStep = (NT / 2) * 4 + (NT % 2) * 2; // exchanges in flight per step
+                make(0, 0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    fence_sched();
+                    if (i + 1 < 8) {
+                        make(i + 1, (i + 1) & 1);
+                        wait_lgkm<kPerStep>(); // step i's exchange has landed; step i + 1's stays in flight under the stores
+                    } else {
+                        wait_lgkm<0>();
+                    }
+                    sfor<NT / 2>([&](auto jpc) {
+                        constexpr int jp = decltype(jpc)::value;
+                        *(u32x4_t *)(sbase + voff[jp]) = ov[i & 1][jp];
+                    });
+                    if constexpr (NT % 2 == 1)
+                        *(u32x2_t *)(sbase + voff_odd) = ov_odd[i & 1];
+                    fence_sched();
+                    stamp(); // (TRACE build: progress of the store sequence)
+                    sbase += step;
+                    if (hs) {
+                        s0 += 16;
+                        if (s0 >= p.hs_s) {
+                            s0 -= p.hs_s;
+                            sbase += wrap;
+                        }
+                    }
+                }
+                return;
+            }
+            // head-split layout with a sequence length that is not a multiple of 16: per-store c_off (divisions)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int row = m0 + wr * 128 + i * 16 + l15;
@@ -393,22 +504,35 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         const int HW = p.cv_hw, HWP = p.cv_hwp, F = p.m;
         const bool odd = g4 & 1;
         // this lane's column pieces: NT / 2 runs of 8 slots (after the lane-group exchange) and, for odd NT, one run of 4
-        int pbase[NT / 2 > 0 ? NT / 2 : 1]; // element offset of (img, filter 0, pix) (the launcher admits < 2^31 elements)
-        int plive[NT / 2 > 0 ? NT / 2 : 1];  // live pixels of the run: 8 inside a plane, fewer at its ragged end, 0 past the tensor
+        // Addresses as in the GEMM epilogue: the filter row of a store is (wave-uniform first row) + l15, so the row part of the
+        // address is a scalar base bumped by scalar adds and the lane keeps ONE 32-bit byte offset per column run
+        // (the launcher admits < 2^31 elements): no vector address arithmetic per store.
+        // Stores use the quad-contiguous lane map of the GEMM epilogue (four consecutive lanes = 32 consecutive pixel slots of one
+        // filter row; data moved by ds_bpermute_b32): lane L owns filter row qrow = L / 4 and the 8-slot run qchunk = L % 4.
+        const int qrow = lane >> 2, qchunk = lane & 3;
+        const int bperm_src = (16 * (2 * (qchunk & 1) + (qchunk >> 1)) + qrow) * 4;
+        const int bperm_src_odd = (16 * qchunk + qrow) * 4;
+        unsigned pbase[NT / 2 > 0 ? NT / 2 : 1]; // byte offset of (img, filter qrow, pix)
+        int plive[NT / 2 > 0 ? NT / 2 : 1];       // live pixels of the run: 8 inside a plane, fewer at its ragged end, 0 past the tensor
         sfor<NT / 2>([&](auto jpc) {
             constexpr int jp = decltype(jpc)::value;
-            const int col = n0 + wc * (16 * NT) + (jp * 2 + (odd ? 1 : 0)) * 16 + (g4 & ~1) * 4;
+            const int col = n0 + wc * (16 * NT) + jp * 32 + qchunk * 8;
             const int img = col / HWP, pix = col - img * HWP;
-            pbase[jp] = (img * F) * HW + pix;
+            pbase[jp] = (unsigned)((img * F + qrow) * HW + pix) * 2u;
             plive[jp] = col < p.n ? min(8, HW - pix) : 0;
         });
-        int obase = 0, olive = 0;
+        unsigned obase = 0;
+        int olive = 0;
         if constexpr (NT % 2 == 1) {
-            const int col = n0 + wc * (16 * NT) + (NT - 1) * 16 + g4 * 4;
+            const int col = n0 + wc * (16 * NT) + (NT - 1) * 16 + qchunk * 4;
             const int img = col / HWP, pix = col - img * HWP;
-            obase = (img * F) * HW + pix;
+            obase = (unsigned)((img * F + qrow) * HW + pix) * 2u;
             olive = col < p.n ? max(0, min(4, HW - pix)) : 0;
         }
+        const int R0 = m0 + wr * 128;                      // wave-uniform first filter row
+        char *sbase = (char *)Y + (long)R0 * HW * 2;
+        const long sstep = 32l * HW;                        // 16 filter rows
+        const bool rows_inside = m0 + BM <= F;              // no filter-row check needed (uniform)
         float bvr[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -469,14 +593,15 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 v[r] = act1(v[r]);
-            pk[0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
-            pk[1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
+            pk[0] = Tr::pack2(v[0], v[1]);
+            pk[1] = Tr::pack2(v[2], v[3]);
         };
-        auto store_run = [&](unsigned short *dst, const u32x4_t &o, int live) { // `live` of the 8 values in o
+        auto store_run = [&](char *dstc, const u32x4_t &o, int live) { // `live` of the 8 values in o
             if (live == 8) {
-                *(u32x4_t *)dst = o; // (8-byte aligned when the plane is not a multiple of 8 pixels: dwordx4 only needs dwords)
+                *(u32x4_t *)dstc = o; // (8-byte aligned when the plane is not a multiple of 8 pixels: dwordx4 only needs dwords)
                 return;
             }
+            unsigned short *dst = (unsigned short *)dstc;
             int e = 0;
             if (live & 4) {
                 u32x2_t v;
@@ -491,9 +616,10 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
             if (live & 1)
                 dst[e] = (unsigned short)((e == 0 ? o[0] : e == 2 ? o[1] : e == 4 ? o[2] : o[3]) & 0xffff);
         };
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = m0 + wr * 128 + i * 16 + l15;
+        // (as in the GEMM epilogue: the exchange of step i + 1 is in flight under the stores of step i)
+        u32x4_t ov[2][NT / 2 > 0 ? NT / 2 : 1];
+        unsigned ov_odd[2][2];
+        auto make = [&](int i, int slot) __attribute__((always_inline)) {
             sfor<NT / 2>([&](auto jpc) {
                 constexpr int jp = decltype(jpc)::value;
                 unsigned pk[2][2];
@@ -503,28 +629,53 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
                 // consecutive slots of tile 2 jp, an odd one with 8 of tile 2 jp + 1
                 const u32x2_t t0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
                 const u32x2_t t1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
-                u32x4_t o;
-                o[0] = t0[0]; o[1] = t1[0]; o[2] = t0[1]; o[3] = t1[1];
-                if (row < F && plive[jp] > 0)
-                    store_run(Y + pbase[jp] + row * HW, o, plive[jp]);
+                ov[slot][jp][0] = lds_bpermute(bperm_src, t0[0]);
+                ov[slot][jp][1] = lds_bpermute(bperm_src, t1[0]);
+                ov[slot][jp][2] = lds_bpermute(bperm_src, t0[1]);
+                ov[slot][jp][3] = lds_bpermute(bperm_src, t1[1]);
             });
             if constexpr (NT % 2 == 1) {
                 unsigned pk[2];
                 pack4(i, std::integral_constant<int, NT - 1>{}, pk);
-                if (row < F && olive > 0) {
-                    unsigned short *dst = Y + obase + row * HW;
+                ov_odd[slot][0] = lds_bpermute(bperm_src_odd, pk[0]);
+                ov_odd[slot][1] = lds_bpermute(bperm_src_odd, pk[1]);
+            }
+        };
+        constexpr int kPerStep = (NT / 2) * 4 + (NT % 2) * 2;
+        make(0, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int srow = m0 + wr * 128 + i * 16 + qrow; // the filter row this lane STORES (after the lane exchange)
+            fence_sched();
+            if (i + 1 < 8) {
+                make(i + 1, (i + 1) & 1);
+                wait_lgkm<kPerStep>();
+            } else {
+                wait_lgkm<0>();
+            }
+            sfor<NT / 2>([&](auto jpc) {
+                constexpr int jp = decltype(jpc)::value;
+                if ((rows_inside || srow < F) && plive[jp] > 0)
+                    store_run(sbase + pbase[jp], ov[i & 1][jp], plive[jp]);
+            });
+            if constexpr (NT % 2 == 1) {
+                const unsigned pk0 = ov_odd[i & 1][0], pk1 = ov_odd[i & 1][1];
+                if ((rows_inside || srow < F) && olive > 0) {
+                    unsigned short *dst = (unsigned short *)(sbase + obase);
                     if (olive == 4) {
                         u32x2_t v;
-                        v[0] = pk[0]; v[1] = pk[1];
+                        v[0] = pk0; v[1] = pk1;
                         *(u32x2_t *)dst = v;
                     } else {
                         if (olive & 2)
-                            *(unsigned *)dst = pk[0];
+                            *(unsigned *)dst = pk0;
                         if (olive & 1)
-                            dst[olive & 2] = (unsigned short)((olive & 2 ? pk[1] : pk[0]) & 0xffff);
+                            dst[olive & 2] = (unsigned short)((olive & 2 ? pk1 : pk0) & 0xffff);
                     }
                 }
             }
+            fence_sched();
+            sbase += sstep;
         }
     };
 

@@ -67,6 +67,12 @@ struct Bf16Traits {
     __device__ static inline float to_f32(unsigned short h) {
         return __builtin_bit_cast(float, ((unsigned int)h) << 16);
     }
+    // two values -> one dword {lo, hi}: ONE v_cvt_pk_bf16_f32 (from_f32 twice + shift + or is four VALU slots)
+    __device__ static inline unsigned pack2(float lo, float hi) {
+        typedef float f32x2_ __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){lo, hi}, bf16x2_));
+    }
 };
 
 struct F16Traits {
@@ -81,6 +87,12 @@ struct F16Traits {
     }
     __device__ static inline float to_f32(unsigned short h) {
         return (float)__builtin_bit_cast(_Float16, h);
+    }
+    // two values -> one dword {lo, hi}: one v_cvt_pk_f16_f32 (RNE; gfx950)
+    __device__ static inline unsigned pack2(float lo, float hi) {
+        typedef float f32x2_ __attribute__((ext_vector_type(2)));
+        typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){lo, hi}, f16x2_));
     }
 };
 
