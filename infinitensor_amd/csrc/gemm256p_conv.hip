@@ -6,20 +6,19 @@ namespace irocm {
 namespace g256p {
 
 // p: m = F, n = images * hwp, k = C, a = W [F][C], b = X (NCHW), c = Y (NCHW), bias = [F] or nullptr, cv_* set by the caller.
-// The residual copy exists for tile widths 192 / 128 only (registers, gemm256p_kernel.h): nt = 4 with a residual runs as nt = 2.
 int launch_gemm256p_conv(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, int nt) {
     const bool res = p.cv_res != nullptr;
-    if (res && nt == 4)
-        nt = 2;
     if (dtype == INFINI_DT_BF16) {
         if (res)
-            return nt == 3 ? launch_p_conv<Bf16Traits, 3, true>(rt, p) : launch_p_conv<Bf16Traits, 2, true>(rt, p);
+            return nt == 4 ? launch_p_conv<Bf16Traits, 4, true>(rt, p)
+                           : (nt == 3 ? launch_p_conv<Bf16Traits, 3, true>(rt, p) : launch_p_conv<Bf16Traits, 2, true>(rt, p));
         if (nt == 4) return launch_p_conv<Bf16Traits, 4, false>(rt, p);
         if (nt == 3) return launch_p_conv<Bf16Traits, 3, false>(rt, p);
         return launch_p_conv<Bf16Traits, 2, false>(rt, p);
     }
     if (res)
-        return nt == 3 ? launch_p_conv<F16Traits, 3, true>(rt, p) : launch_p_conv<F16Traits, 2, true>(rt, p);
+        return nt == 4 ? launch_p_conv<F16Traits, 4, true>(rt, p)
+                       : (nt == 3 ? launch_p_conv<F16Traits, 3, true>(rt, p) : launch_p_conv<F16Traits, 2, true>(rt, p));
     if (nt == 4) return launch_p_conv<F16Traits, 4, false>(rt, p);
     if (nt == 3) return launch_p_conv<F16Traits, 3, false>(rt, p);
     return launch_p_conv<F16Traits, 2, false>(rt, p);
@@ -63,7 +62,10 @@ int launch_conv_pw_gemm(infiniRocmRuntime_t rt, int dtype, const void *x, const 
     p.zeros = rt->zeros;
     p.epi16 = 1;
     p.cv_hw = (int)hw; p.cv_hwp = (int)hwp; p.cv_res = res;
-    const int nt = persist_pick_nt(f, n * hwp, c, rt->num_cu, res ? 3 : 4);
+    // the 256-column residual copy spills 36-48 bytes per lane (epilogue only) and still wins where the cost model picks it:
+    // C256 -> F1024 @14x14 with a residual 40.4 vs 46.9 us on 192-column tiles, C512 -> F2048 @7x7 30.7 vs 36.6 (IROCM_CONV_RES_NT4=0: A/B)
+    static const int res_nt4 = getenv("IROCM_CONV_RES_NT4") ? atoi(getenv("IROCM_CONV_RES_NT4")) : 1;
+    const int nt = persist_pick_nt(f, n * hwp, c, rt->num_cu, (res && !res_nt4) ? 3 : 4);
     rt->last_conv_route = "pixel_gemm";
     return g256p::launch_gemm256p_conv(rt, dtype, p, nt);
 }

@@ -539,60 +539,68 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
             const int row = m0 + wr * 128 + i * 16 + l15;
             bvr[i] = (bias != nullptr && row < F) ? Tr::to_f32(bias[row]) : 0.f;
         }
-        // Residual: every piece of the tile is fetched BEFORE the first store (the operand-fragment registers are dead here),
-        // 4 slots (8 bytes) per accumulator tile — the lane's OWN columns, so that the sum, the activation and the rounding
-        // happen before the packed halves are exchanged between lane groups exactly as in the GEMM epilogue — through a
-        // range-checked buffer descriptor (a run in a dead slot or past the tensor reads zeros); one wait for all of them:
-        // a load inside the store sequence would have to drain the stores in front of it (loads and stores share vmcnt).
-        u32x2_t rr[has_res ? 8 : 1][has_res ? NT : 1];
+        // Residual: fetched in the STORE layout (the lane's 8-slot run of filter row qrow — four consecutive lanes read 64
+        // contiguous bytes, the map the texture addresser merges; in the accumulator layout's own map these loads crawled like
+        // the stores did: the residual cost a C64 -> F256 56 x 56 layer 71 us on top of its 51) and added after the lane exchange
+        // on the packed values: y = act(round(conv + bias) + residual) — the arithmetic of the reference's separate Conv and Add
+        // kernels (and of conv_s1.hip's row-wise epilogue). Every run of the tile is fetched BEFORE the first store (the
+        // operand-fragment registers are dead here) through a range-checked buffer descriptor (dead runs read zeros): a load
+        // inside the store sequence would have to drain the stores in front of it (loads and stores share vmcnt).
+        u32x4_t rq[has_res ? 8 : 1][has_res ? (NT / 2 > 0 ? NT / 2 : 1) : 1];
+        u32x2_t rq_odd[has_res ? 8 : 1];
         if constexpr (has_res) {
             const long total_bytes = (long)(p.n / HWP) * F * HW * 2;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.cv_res), 0, (int)total_bytes, 0x00020000);
-            int cb[NT]; // byte offset of the lane's 4 slots of tile j at filter 0; `total_bytes` (-> zeros) for dead slots
+            const unsigned rowb = (unsigned)R0 * (unsigned)HW * 2u; // wave-uniform byte offset of the wave's first filter row
+            auto fetch = [&](unsigned off, int live, auto nc) { // `live` leading 16-bit values of an N-value run at byte offset off
+                constexpr int N = decltype(nc)::value;
+                u32x4_t v = {0u, 0u, 0u, 0u};
+                if (live <= 0)
+                    return v;
+                if (off + 2u * N <= (unsigned)total_bytes) {
+                    if constexpr (N == 8) v = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+                    else {
+                        const u32x2_t h = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0));
+                        v[0] = h[0]; v[1] = h[1];
+                    }
+                } else {
+                    // the ragged run at the very end of the tensor: the descriptor's range check works per (misaligned) dword
+                    // and would zero the last live element together with the bytes behind it — fetch by element
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int col = n0 + wc * (16 * NT) + j * 16 + g4 * 4;
-                const int img = col / HWP, pix = col - img * HWP;
-                cb[j] = (col < p.n && pix < HW) ? ((img * F) * HW + pix) * 2 : -1;
-            }
+                    for (int q = 0; q < N; ++q) {
+                        const unsigned e = q < live ? (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)off + 2 * q, 0, 0) : 0u;
+                        v[q >> 1] |= e << ((q & 1) * 16);
+                    }
+                }
+                return v;
+            };
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int row = m0 + wr * 128 + i * 16 + l15;
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const int voff = (cb[j] >= 0 && row < F) ? cb[j] + row * HW * 2 : (int)total_bytes; // else: zeros
-                    if (voff + 8 <= (int)total_bytes || voff >= (int)total_bytes) {
-                        rr[i][j] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0));
-                    } else {
-                        // the ragged run at the very end of the tensor: the descriptor's range check works per (misaligned)
-                        // dword and would zero the last live element together with the bytes behind it — fetch by element
-                        unsigned e[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            e[q] = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, voff + 2 * q, 0, 0);
-                        u32x2_t v;
-                        v[0] = e[0] | (e[1] << 16);
-                        v[1] = e[2] | (e[3] << 16);
-                        rr[i][j] = v;
-                    }
+                const bool rowok = rows_inside || (R0 + i * 16 + qrow < F);
+                sfor<NT / 2>([&](auto jpc) {
+                    constexpr int jp = decltype(jpc)::value;
+                    rq[i][jp] = fetch(rowb + (unsigned)i * (unsigned)sstep + pbase[jp], rowok ? plive[jp] : 0, std::integral_constant<int, 8>{});
+                });
+                if constexpr (NT % 2 == 1) {
+                    const u32x4_t v = fetch(rowb + (unsigned)i * (unsigned)sstep + obase, rowok ? olive : 0, std::integral_constant<int, 4>{});
+                    rq_odd[i][0] = v[0]; rq_odd[i][1] = v[1];
                 }
             }
         }
-        auto pack4 = [&](int i, auto jc, unsigned (&pk)[2]) { // bias + residual + activation + rounding of the lane's 4 slots of tile j
+        auto add_res = [&](unsigned o, unsigned r) -> unsigned { // two packed values + two residual values, activation, rounding
+            float lo = Tr::to_f32((unsigned short)(o & 0xffffu)) + Tr::to_f32((unsigned short)(r & 0xffffu));
+            float hi = Tr::to_f32((unsigned short)(o >> 16)) + Tr::to_f32((unsigned short)(r >> 16));
+            return Tr::pack2(act1(lo), act1(hi));
+        };
+        auto pack4 = [&](int i, auto jc, unsigned (&pk)[2]) { // bias (+ activation when there is no residual) + rounding of the lane's 4 slots of tile j
             constexpr int j = decltype(jc)::value;
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 4; ++r) {
                 v[r] = acc[i][j][r] + bvr[i];
-            if constexpr (has_res) {
-                v[0] += Tr::to_f32((unsigned short)(rr[i][j][0] & 0xffff));
-                v[1] += Tr::to_f32((unsigned short)(rr[i][j][0] >> 16));
-                v[2] += Tr::to_f32((unsigned short)(rr[i][j][1] & 0xffff));
-                v[3] += Tr::to_f32((unsigned short)(rr[i][j][1] >> 16));
+                if constexpr (!has_res)
+                    v[r] = act1(v[r]);
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                v[r] = act1(v[r]);
             pk[0] = Tr::pack2(v[0], v[1]);
             pk[1] = Tr::pack2(v[2], v[3]);
         };
@@ -655,11 +663,21 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
             }
             sfor<NT / 2>([&](auto jpc) {
                 constexpr int jp = decltype(jpc)::value;
+                u32x4_t o = ov[i & 1][jp];
+                if constexpr (has_res) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        o[d] = add_res(o[d], rq[i][jp][d]);
+                }
                 if ((rows_inside || srow < F) && plive[jp] > 0)
-                    store_run(sbase + pbase[jp], ov[i & 1][jp], plive[jp]);
+                    store_run(sbase + pbase[jp], o, plive[jp]);
             });
             if constexpr (NT % 2 == 1) {
-                const unsigned pk0 = ov_odd[i & 1][0], pk1 = ov_odd[i & 1][1];
+                unsigned pk0 = ov_odd[i & 1][0], pk1 = ov_odd[i & 1][1];
+                if constexpr (has_res) {
+                    pk0 = add_res(pk0, rq_odd[i][0]);
+                    pk1 = add_res(pk1, rq_odd[i][1]);
+                }
                 if ((rows_inside || srow < F) && olive > 0) {
                     unsigned short *dst = (unsigned short *)(sbase + obase);
                     if (olive == 4) {

@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--variants", default="-1,1,2,3")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--res", action="store_true", help="add a residual operand to the expanding pointwise layers (f > c, 1 x 1 / 1): the join of a bottleneck")
     ap.add_argument("--layers", default="", help="comma-separated indices into the layer table (default: all)")
     args = ap.parse_args()
     dt = {"f16": torch.float16, "bf16": torch.bfloat16}[args.dtype]
@@ -57,11 +58,12 @@ def main():
         b = torch.randn((f,), device="cuda").to(dt)
         oh = (h + 2 * pad - r) // st + 1
         y = torch.empty((args.batch, f, oh, oh), device="cuda", dtype=dt)
+        res = torch.randn((args.batch, f, oh, oh), device="cuda").to(dt) if (args.res and r == 1 and st == 1 and f > c) else None
         flop = 2.0 * args.batch * f * oh * oh * c * r * r
         tot_flop += flop * cnt
         # roofline floor of the layer: algorithmic bytes (input + weights + output, each once) at the 6.3 TB/s the guide
         # measures as achievable, vs the FLOPs at the 2.15 PF the chip sustains at its ~2.05 GHz load clock
-        nbytes = 2.0 * (args.batch * c * h * h + f * c * r * r + args.batch * f * oh * oh)
+        nbytes = 2.0 * (args.batch * c * h * h + f * c * r * r + args.batch * f * oh * oh * (2 if res is not None else 1))
         floor_us = max(nbytes / 6.3e12, flop / 2.15e15) * 1e6
         tot_floor += floor_us * cnt
         line = f"x{cnt} C{c:<4d} {h:>3d}x{h:<3d} F{f:<4d} {r}x{r}/s{st} {flop / 1e9:8.2f} GF {nbytes / 1e6:7.1f} MB floor {floor_us:6.1f} us ({'hbm' if nbytes / 6.3e12 > flop / 2.15e15 else 'mfma'}) |"
@@ -72,11 +74,11 @@ def main():
         for v in variants:
             ops.set_conv_variant(rt, v)
             for _ in range(2):
-                ops.conv2d(rt, x, w, pad, pad, st, st, bias=b, act=1, out=y)
+                ops.conv2d(rt, x, w, pad, pad, st, st, bias=b, act=1, out=y, residual=res)
             e0, e1 = Event(), Event()
             rt.record(e0)
             for _ in range(args.iters):
-                ops.conv2d(rt, x, w, pad, pad, st, st, bias=b, act=1, out=y)
+                ops.conv2d(rt, x, w, pad, pad, st, st, bias=b, act=1, out=y, residual=res)
             rt.record(e1)
             rt.sync()
             ms = rt.elapsed_ms(e0, e1) / args.iters
