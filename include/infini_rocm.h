@@ -396,7 +396,8 @@ int infini_rocm_conv_transpose2d(infiniRocmRuntime_t rt, int dtype, const void *
  * otherwise) for every shape they serve, 3 batched-GEMM route for every eligible pointwise shape, 4 = 2 with the
  * patch kernel off (the tap-shifted kernel everywhere: A/B), 5 = pointwise layers (1 x 1, any stride, channels % 64 == 0) as ONE
  * GEMM over pixel slots on the persistent 256-row kernels for every shape that qualifies (the heuristic sends them there when
- * they have >= 128 filters and enough tiles to fill half the chip). All variants compute the same sums (fp32 accumulate).
+ * they have >= 128 filters and enough tiles to fill half the chip), 6 = 2 with the 8-wave 128 x 256 form of the patch kernel for every
+ * shape it serves (the heuristic picks it when its workgroups still fill most of the chip). All variants compute the same sums (fp32 accumulate).
  * Used by tune() and tests. */
 int infini_rocm_conv2d_set_variant(infiniRocmRuntime_t rt, int variant);
 /* Which implementation the most recent conv2d call on this runtime launched: "direct32" (fp32), "pixel_gemm" (pointwise layer as

@@ -55,11 +55,24 @@ struct ConvS1Args {
     int kdim, kpad;      // ROWTAP: C*R*S and its round-up to 32 (w is [F][kpad])
     int wide_epilogue;   // LDS-staged 16-byte-run epilogue: 0 off, 1 even planes only, 2 also odd planes (IROCM_CONV_WIDE)
     int epi_probe;       // ablation hook, 0 in production
+    unsigned hwp_m, wd_m; // floor(2^32 / hwp), floor(2^32 / wd): divisions by multiply-high + one correction (fast_divmod)
     unsigned x_bytes;    // bytes of everything behind x
     unsigned y_bytes;    // bytes of y (= bytes of the residual); 0 when they do not fit 32-bit buffer offsets
     long plane_elems;    // elements of one phase plane set [n][c][h][wd]
     signed char slot[16]; // phase py*sw + px -> index of its plane set behind x
 };
+
+// n / d and n % d for 0 <= n < 2^32 with m = min(floor(2^32 / d), 2^32 - 1): the multiply-high quotient is short by at most one.
+// (An integer division by a run-time value is ~45 VALU instructions; the conv prologues did 8-16 of them per lane.)
+__device__ __forceinline__ void fast_divmod(int n, int d, unsigned m, int &q, int &r) {
+    q = (int)__umulhi((unsigned)n, m);
+    r = n - q * d;
+    if (r >= d) {
+        ++q;
+        r -= d;
+    }
+}
+static inline unsigned divmod_magic(long d) { return d <= 1 ? 0xffffffffu : (unsigned)(((1ull << 32)) / (unsigned long long)d); }
 
 struct PhaseSplitArgs {
     const unsigned short *x;
@@ -325,7 +338,8 @@ __device__ __forceinline__ void conv_tile_epilogue_lds(const ConvS1Args &p, f32x
     // row-wise phase geometry: lane = (row sub-index, 16-byte chunk); one integer division per lane per tile
     const int ch = lane & 7, rsub = lane >> 3;
     const int col = n0 + wn * 64 + ch * 8;
-    const int im = col / p.hwp, pix = col - im * p.hwp;
+    int im, pix;
+    fast_divmod(col, p.hwp, p.hwp_m, im, pix);
     const bool live = col < p.ncols && pix < p.hw;
     const bool full = pix + 8 <= p.hw;
     const long ybase_off = (long)im * p.f * p.hw + pix;
@@ -459,22 +473,23 @@ __global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void conv_s1_kernel(ConvS1
     // ---- B staging assignment: one column run per thread, k-rows t / CPR + i * KSTEP ------------------
     const int cchunk = t % CPR, krow0 = t / CPR;
     const int col8 = n0 + cchunk * 8;
-    const int img = col8 / p.hwp, pp = col8 - img * p.hwp;
-    // validity bit sets: rowm bit (8*r + j) = pixel j of the run has input row oh + r - ph inside the image
+    int img, pp;
+    fast_divmod(col8, p.hwp, p.hwp_m, img, pp);
+    // validity bit sets: rowm bit (8*r + j) = pixel j of the run has input row oh + r - ph inside the image.
+    // (Selects, not branches, and multiply-high divisions: this block was a few thousand cycles of every workgroup's prologue.)
     unsigned long rowm = 0, colm = 0;
-    if (col8 < p.ncols) {
+    {
+        const bool run_live = col8 < p.ncols;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int pix = pp + j;
-            if (pix < p.hw) {
-                const int oh = pix / p.wd, ow = pix - oh * p.wd;
-                for (int r = 0; r < p.r; ++r)
-                    if ((unsigned)(oh * p.sh + r * p.dh - p.ph) < (unsigned)p.in_h)
-                        rowm |= 1ul << (8 * r + j);
-                for (int s = 0; s < p.s; ++s)
-                    if ((unsigned)(ow * p.sw + s * p.dw - p.pw) < (unsigned)p.in_w)
-                        colm |= 1ul << (8 * s + j);
-            }
+            const bool live = run_live && pix < p.hw;
+            int oh, ow;
+            fast_divmod(pix < p.hw ? pix : 0, p.wd, p.wd_m, oh, ow);
+            for (int r = 0; r < p.r; ++r) // (wave-uniform trip counts)
+                rowm |= (unsigned long)((live && (unsigned)(oh * p.sh + r * p.dh - p.ph) < (unsigned)p.in_h) ? 1 : 0) << (8 * r + j);
+            for (int s = 0; s < p.s; ++s)
+                colm |= (unsigned long)((live && (unsigned)(ow * p.sw + s * p.dw - p.pw) < (unsigned)p.in_w) ? 1 : 0) << (8 * s + j);
         }
     }
     const int b_base = (int)((((long)img * p.c + (ROWTAP ? 0 : krow0)) * p.hw + pp) * 2); // bytes; x_bytes < 2^31
@@ -905,16 +920,22 @@ __global__ __launch_bounds__(256, (NKB <= 2 ? 2 : 1)) void conv_pw_kernel(ConvS1
 // layout and epilogues (LDS-staged row-wise stores, bias / residual / activation) as conv_s1_kernel<2, 2, *>.
 // ------------------------------------------------------------------------------------------------
 template <typename Tr, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv_patch_kernel(ConvS1Args p, int halo8, int pslots) {
-    constexpr int BM = WM * 64, BN = WN * 64, BK = 32; // 4 waves of 64 x 64: <2, 2> = 128 f x 128 slots, <1, 4> = 64 f x 256 slots
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 ? 1 : 2)) void conv_patch_kernel(ConvS1Args p, int halo8, int pslots) {
+    // waves of 64 x 64: <2, 2> = 4 waves, 128 f x 128 slots, two workgroups per CU; <2, 4> = 8 waves, 128 f x 256 slots, one per CU —
+    // the same waves per CU, but every weight tile streamed from L2 serves twice the slots (the weight stream paces this kernel)
+    constexpr int BM = WM * 64, BN = WN * 64, BK = 32;
+    constexpr int NW = WM * WN, NTHR = NW * 64;
     constexpr int A_BYTES = BM * BK * 2;                     // weight tile: [BM f][32 c], 64-byte rows
     constexpr int TPS = 3;                                   // taps per step (= per barrier): a filter row of a 3x3
-    constexpr int STAGE_BYTES = TPS * A_BYTES, NSTAGE = 2;   // two stages, each the tiles of TPS consecutive taps
+    constexpr int STAGE_BYTES = TPS * A_BYTES;               // a stage = the tiles of TPS consecutive taps
+    // stages in flight: two with 4 waves (fetched one step ahead); three with 8 waves — one workgroup per CU has the LDS for it,
+    // and a weight step then has TWO steps (>= 2 x 48 MFMAs per wave) to make its L2 round trip
+    constexpr int NSTAGE = (WM * WN == 8) ? 3 : 2, AHEAD = NSTAGE - 1;
     constexpr int RAW_CH = WN == 4 ? 64 : 32;                // 16-byte chunks per RAW row (>= patch slots / 8)
     constexpr int RAW_ROWB = RAW_CH * 16, RAW_BYTES = BK * RAW_ROWB; // [32 k][slots], fixed pitch
-    constexpr int NR = WN == 4 ? 6 : 4;                      // patch runs per thread per channel block
-    constexpr int NPA = BM / 64;                             // weight DMA pieces (16 rows x 64 B) per wave and tile
-    static_assert(WM * WN == 4, "4 waves");
+    constexpr int NR = (BK * (BN + 128) / 8 + NTHR - 1) / NTHR; // patch runs per thread per channel block (patch <= BN + 128 slots)
+    constexpr int NPA = BM / 16 / NW;                        // weight DMA pieces (16 rows x 64 B) per wave and tile
+    static_assert((NW == 4 || NW == 8) && NPA >= 1, "4 or 8 waves");
     extern __shared__ __attribute__((aligned(16))) char smem[]; // [A stages | RAW | PM]
     char *const raw = smem + NSTAGE * STAGE_BYTES;
     char *const pm = raw + RAW_BYTES;
@@ -967,20 +988,21 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(ConvS1Args p, int ha
     };
     // ---- patch runs: id = t + i*256 -> channel row id / rpr, slot run id % rpr ---------------------------
     const int rpr = pslots / 8, nruns = BK * rpr;
+    const unsigned rpr_m = (unsigned)((1ull << 32) / (unsigned)rpr); // (wave-uniform, once; rpr >= 16)
     const int pstart = n0 - halo8; // first slot of the patch (a multiple of 8, may be negative)
     int p_voff[NR], p_lds[NR];
     unsigned p_valid = 0;
     bool risky_lane = false;
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-        const int id = t + i * 256;
-        const int kr = id / rpr, rc = id - kr * rpr;
+        const int id = t + i * NTHR;
+        int kr, rc;
+        fast_divmod(id, rpr, rpr_m, kr, rc);
         const int slot0 = pstart + rc * 8;
         int img = 0, pix = 0;
         bool ok = id < nruns && slot0 >= 0 && slot0 < p.ncols;
         if (ok) {
-            img = slot0 / p.hwp;
-            pix = slot0 - img * p.hwp;
+            fast_divmod(slot0, p.hwp, p.hwp_m, img, pix);
             ok = pix < p.hw;
         }
         p_voff[i] = (int)((((long)img * p.c + kr) * p.hw + pix) * 2);
@@ -993,24 +1015,30 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(ConvS1Args p, int ha
     }
     const bool wg_risky = __syncthreads_or(risky_lane) != 0;
     // ---- per-lane validity of (slot, tap) and PM row of the lane's slot for the four 16-slot blocks ------
+    // Computed AFTER the first loads are issued (sweep): the timeline (s_memtime stamps, round 3) showed 12.5 k cycles between kernel
+    // entry and the first load — 15 % of a workgroup's life — most of them in this block when it was a tap-by-tap loop under
+    // divergent conditions. Now: one column mask and one select per filter row, no divergence.
     int vm[4];
     const int brow64 = (halo8 + wn * 64 + l15) * 64; // PM byte offset of the lane's slot in block j = 0 (j adds 1024)
+    auto compute_vm = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int slot = n0 + wn * 64 + j * 16 + l15;
-        unsigned m = 0;
-        if (slot < p.ncols) {
-            const int img = slot / p.hwp, pix = slot - img * p.hwp;
-            if (pix < p.hw) {
-                const int oh = pix / p.wd, ow = pix - oh * p.wd;
-                for (int r_ = 0; r_ < p.r; ++r_)
-                    for (int s_ = 0; s_ < p.s; ++s_)
-                        if ((unsigned)(oh + r_ - p.ph) < (unsigned)p.in_h && (unsigned)(ow + s_ - p.pw) < (unsigned)p.in_w)
-                            m |= 1u << (r_ * p.s + s_);
-            }
+        for (int j = 0; j < 4; ++j) {
+            const int slot = n0 + wn * 64 + j * 16 + l15;
+            const int sl = slot < p.ncols ? slot : 0;
+            int img, pix, oh, ow;
+            fast_divmod(sl, p.hwp, p.hwp_m, img, pix);
+            const int px = pix < p.hw ? pix : 0;
+            fast_divmod(px, p.wd, p.wd_m, oh, ow);
+            const bool live = slot < p.ncols && pix < p.hw;
+            unsigned colmask = 0;
+            for (int s_ = 0; s_ < p.s; ++s_) // (wave-uniform trip count)
+                colmask |= ((unsigned)(ow + s_ - p.pw) < (unsigned)p.in_w ? 1u : 0u) << s_;
+            unsigned m = 0;
+            for (int r_ = 0; r_ < p.r; ++r_)
+                m |= ((unsigned)(oh + r_ - p.ph) < (unsigned)p.in_h ? colmask : 0u) << (r_ * p.s);
+            vm[j] = live ? (int)m : 0;
         }
-        vm[j] = (int)m;
-    }
+    };
     // ---- LDS fragment offsets ----------------------------------------------------------------------------
     // weight fragment of filter row wm*64 + i*16 + l15: chunk g4 of a 64-byte row, swizzled like the DMA source
     const unsigned a_frag = lds0 + (unsigned)((wm * 64 + l15) * 64 + ((g4 ^ (((l15 >> 2) & 1) << 1)) * 16)); // + i * 1024
@@ -1061,7 +1089,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(ConvS1Args p, int ha
     };
     // RAW [k][slots] -> PM [slot][k]: wave w transposes the 16-slot blocks w, w + 4, ...
     auto transpose = [&]() __attribute__((always_inline)) {
-        for (int sb = w; sb * 16 < pslots; sb += 4) {
+        for (int sb = w; sb * 16 < pslots; sb += NW) {
             s16x4_t h[2];
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
@@ -1119,7 +1147,10 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(ConvS1Args p, int ha
 
     auto sweep = [&](auto safec) __attribute__((always_inline)) {
         load_patch(safec, 0);
-        dma_step(0);
+#pragma unroll
+        for (int a = 0; a < AHEAD; ++a)
+            dma_step(a);
+        compute_vm(); // (under the loads' round trip)
         store_patch(); // (the compiler waits for the runs here — and with them for the weight tiles)
         __syncthreads();
         transpose();
@@ -1135,7 +1166,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(ConvS1Args p, int ha
             for (int st = 0; st < nst; ++st) {
                 // the tiles of the NEXT step, into the stage the previous step read (every wave is past that barrier);
                 // one step (TPS taps, >= 1 k cycles) covers their L2 round trip
-                dma_step(stage ^ 1);
+                dma_step(stage + AHEAD < NSTAGE ? stage + AHEAD : stage + AHEAD - NSTAGE);
                 if (st == 0) {
                     // the next channel block's runs: in flight during the remaining taps (the last block re-reads itself)
                     load_patch(safec, cb + 1 < ncb ? cb + 1 : cb);
@@ -1151,10 +1182,13 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(ConvS1Args p, int ha
                 // my pieces of the next step's tiles have landed: every VMEM op — except the NR runs when they were issued
                 // after the tiles in this step. (SAFE issues a data-dependent number of loads for the runs: there the
                 // plain vmcnt(0) is the only count that is right for every wave.)
-                if (!decltype(safec)::value && st == 0) g256p_wait_vm<NR>();
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // (loads return in order: "at most N outstanding" with N = what was issued AFTER the next step's tiles — the tiles of
+                // the steps beyond it and, in a block's first step, the NR runs)
+                if (decltype(safec)::value) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (st == 0) g256p_wait_vm<(AHEAD - 1) * NPA * TPS + NR>();
+                else g256p_wait_vm<(AHEAD - 1) * NPA * TPS>();
                 g256::barrier();
-                stage ^= 1;
+                stage = stage + 1 < NSTAGE ? stage + 1 : 0;
             }
             if (cb + 1 < ncb) {
                 store_patch();
@@ -1185,11 +1219,11 @@ template <typename Tr, int WM, int WN> static int launch_patch(infiniRocmRuntime
     p.tiles_n = (int)ceil_div(p.ncols, BN);
     const long blocks = (long)p.tiles_m * p.tiles_n;
     IROCM_CHECK_ARG(blocks < (1l << 31), "conv2d: too many tiles");
-    constexpr int fixed = 2 * 3 * (BM * 32 * 2) + 32 * (WN == 4 ? 1024 : 512); // weight stages + RAW
+    constexpr int fixed = (WM * WN == 8 ? 3 : 2) * 3 * (BM * 32 * 2) + 32 * (WN == 4 ? 1024 : 512); // weight stages + RAW
     const int lds = fixed + pslots * 64;                                         // + PM (<= 80 KiB: two per CU)
     auto kern = conv_patch_kernel<Tr, WM, WN>;
     IROCM_LDS_ATTR(kern, fixed + (BN + 128) * 64, rt);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, rt->stream, p, halo8, pslots);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WM * WN * 64), lds, rt->stream, p, halo8, pslots);
     IROCM_LAUNCH_CHECK("conv_patch");
     return INFINI_ROCM_OK;
 }
@@ -1247,6 +1281,8 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
     p.in_h = h; p.in_w = wd; p.h = oh; p.wd = ow;
     p.hw = oh * ow;
     p.hwp = (p.hw + 7) & ~7;
+    p.hwp_m = divmod_magic(p.hwp);
+    p.wd_m = divmod_magic(ow);
     if ((long)n * p.hwp >= (1l << 31))
         return -1;
     p.ncols = n * p.hwp;
@@ -1403,6 +1439,14 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
         // 128 f x 128 slots. (The 64 f x 256 slots form of the same kernel, <1, 4>, was measured on ResNet's C64 -> F64
         // 56x56 layers — two channel blocks, 18 taps per workgroup: 119 us against 96 us for the tap-shifted kernel, whose
         // 64 x 256 x 32 tile has no patch / transpose prologue to amortise — and is not instantiated.)
+        // 128 f x 256 slots on 8 waves (one workgroup per CU, three weight stages) when that still fills most of the chip: every
+        // weight tile streamed from L2 then serves twice the slots. C128 28x28 60.6 -> 58.3 us, C256 14x14 55.1 -> 51.6; C512 7x7
+        // (100 workgroups) 73.8 -> 83.2: stays on the 4-wave form. IROCM_CONV_PATCH_WIDE = 0 / 1 forces either (A/B); conv variant 6 forces the wide form (tests, tune()).
+        static const int patch_wide = getenv("IROCM_CONV_PATCH_WIDE") ? atoi(getenv("IROCM_CONV_PATCH_WIDE")) : -1;
+        const bool wide_fills = ceil_div(f, 128) * ceil_div(p.ncols, 256) * 10 >= (long)rt->num_cu * 7;
+        if (f > 64 && 2 * halo8 <= 128 && (patch_wide == 1 || rt->conv_variant == 6 || (patch_wide < 0 && wide_fills)))
+            return bf ? launch_patch<Bf16Traits, 2, 4>(rt, p, halo8, 256 + 2 * halo8)
+                      : launch_patch<F16Traits, 2, 4>(rt, p, halo8, 256 + 2 * halo8);
         if (f > 64 && 2 * halo8 <= 128)
             return bf ? launch_patch<Bf16Traits, 2, 2>(rt, p, halo8, 128 + 2 * halo8)
                       : launch_patch<F16Traits, 2, 2>(rt, p, halo8, 128 + 2 * halo8);

@@ -209,7 +209,8 @@ def weight_cache_info(rt: RocmRuntime) -> dict:
 
 
 def set_conv_variant(rt: RocmRuntime, variant: int) -> None:
-    """-1 heuristic, 1 generic implicit GEMM, 2 conv_s1 wherever eligible, 3 batched-GEMM route for pointwise."""
+    """-1 heuristic, 1 generic implicit GEMM, 2 conv_s1 wherever eligible, 3 batched-GEMM route for pointwise, 4 = 2 without the patch
+    kernel, 5 pointwise layers as one pixel-slot GEMM, 6 = 2 with the 8-wave patch kernel (include/infini_rocm.h)."""
     check(lib().infini_rocm_conv2d_set_variant(rt.handle, int(variant)))
 
 

@@ -17,14 +17,14 @@ namespace infini {
 // the variant's NAME and is resolved by name on load. A record without a name (an older file), with an unknown name or —
 // for Conv, whose variants have no names — outside the current range falls back to the heuristic (-1) instead of making
 // every such operator throw at launch.
-static const char *kConvVariantNames[] = {"heuristic0", "generic", "conv_s1", "batched_gemm", "conv_s1_nopatch", "pixel_gemm"};
+static const char *kConvVariantNames[] = {"heuristic0", "generic", "conv_s1", "batched_gemm", "conv_s1_nopatch", "pixel_gemm", "conv_patch_wide"};
 
 static std::string variantName(int recordType, int v) {
     if (v < 0)
         return "heuristic";
     if (recordType == kRocmMatmulRecord)
         return infini_rocm_matmul_variant_name(v);
-    return (v <= 5) ? kConvVariantNames[v] : "invalid";
+    return (v <= 6) ? kConvVariantNames[v] : "invalid";
 }
 
 void RocmVariantPerfRecordObj::to_json(json &j) {

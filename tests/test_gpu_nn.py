@@ -403,6 +403,31 @@ def test_conv_residual_lds_epilogue_act_and_bf16(rt, dt, act):
         assert torch.equal(dres, keep)
 
 
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("cfg", [(3, 64, 14, 14, 256, 3), (5, 96, 7, 7, 130, 3), (2, 32, 28, 28, 128, 3), (9, 64, 9, 5, 200, 3), (2, 64, 12, 12, 128, 5)])
+def test_conv_patch_wide_form(rt, cfg, dt):
+    """The 8-wave 128 f x 256 slots form of the LDS-resident-patch kernel (conv variant 6; three weight stages, one workgroup per
+    CU): unit-stride "same" R x S layers with ragged planes, filter counts that are not multiples of 128, a slot count that is not
+    a multiple of 256 — against the oracle and against the 4-wave form (variant 2), with bias + ReLU."""
+    n, c, h, w, f, k = cfg
+    rng = np.random.default_rng(abs(hash(cfg)) % 2 ** 32)
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((f, c, k, k)) / np.sqrt(c * k * k)).astype(np.float32)
+    b = rng.standard_normal((f,)).astype(np.float32)
+    xd, wd, bd = dev(x, TD[dt]), dev(wt, TD[dt]), dev(b, TD[dt])
+    try:
+        ops.set_conv_variant(rt, 6)
+        y = ops.conv2d(rt, xd, wd, k // 2, k // 2, 1, 1, bias=bd, act=1)
+        ops.set_conv_variant(rt, 2)
+        y2 = ops.conv2d(rt, xd, wd, k // 2, k // 2, 1, 1, bias=bd, act=1)
+    finally:
+        ops.set_conv_variant(rt, -1)
+    want = np.maximum(R.conv2d(R.round_to(x, dt), R.round_to(wt, dt), k // 2, k // 2, 1, 1, 1, 1) + R.round_to(b, dt).reshape(1, f, 1, 1), 0)
+    tol = {"f16": 3e-3, "bf16": 2.4e-2}[dt]
+    assert np.allclose(host(y), want, rtol=tol, atol=tol), np.abs(host(y) - want).max()
+    assert np.allclose(host(y), host(y2), rtol=tol, atol=tol)
+
+
 PW_GEMM = [  # (n, c, h, w, f): pointwise layers for the conv mode of the persistent GEMM (variant 5)
     (3, 64, 8, 8, 256),      # plane of 64 pixels: a 256-slot tile spans four images
     (5, 128, 14, 14, 512),   # 196 pixels: 4-pixel ragged run at every plane end, tiles span images
