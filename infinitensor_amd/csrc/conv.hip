@@ -499,8 +499,9 @@ int infini_rocm_conv2d_res(infiniRocmRuntime_t rt, int dtype, const void *x, con
     // and the old kernels win. Variant 5 forces it for every eligible shape.
     if ((variant < 0 || variant == 5) && r == 1 && s == 1 && ph == 0 && pw == 0 && same_s1 && c % 64 == 0 && (act == 0 || act == 1) &&
         // (>= 128 filters: C256->F128 @56x56 78 vs 100 us, C512->F128 @28x28 33 vs 40; with 64 the 256-row tile is 3/4 empty:
-        // 69 vs 60 us. And the grid must fill at least half the chip: C2048->F512 @7x7 is 56 tiles of 256^2.)
-        ((f >= 128 && ceil_div(f, 256) * ceil_div(n * ((p.npix + 7) / 8 * 8), 256) * 2 >= rt->num_cu) || variant == 5)) {
+        // 69 vs 60 us. The grid may be thin — C1024->F256 @14x14 is 100 tiles of 256^2 and still 22.6 vs 31.1 us, C2048->F512 @7x7
+        // 50 tiles and 38.8 vs 45.1 — but below ~3/16 of the CUs the 128 x 128 tiles of the tap-shifted kernel spread better.)
+        ((f >= 128 && ceil_div(f, 256) * ceil_div(n * ((p.npix + 7) / 8 * 8), 256) * 16 >= rt->num_cu * 3) || variant == 5)) {
         const int st = launch_conv_pw_gemm(rt, dtype, x, w, bias, residual, y, n, c, p.npix, f, act);
         if (st >= 0)
             return st;

@@ -1419,7 +1419,7 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
         // when it has the filters to fill their 256-row tiles (conv.hip has the rule and the numbers)
         if (r == 1 && s == 1 && ps.nslots == 1 && c % 64 == 0 && (act == 0 || act == 1) &&
             (rt->conv_variant == 5 ||
-             (rt->conv_variant < 0 && f >= 128 && ceil_div(f, 256) * ceil_div((long)n * ((oh * ow + 7) / 8 * 8), 256) * 2 >= rt->num_cu))) {
+             (rt->conv_variant < 0 && f >= 128 && ceil_div(f, 256) * ceil_div((long)n * ((oh * ow + 7) / 8 * 8), 256) * 16 >= rt->num_cu * 3))) {
             const int st = launch_conv_pw_gemm(rt, dtype, ps.o, w, bias, res, y, n, c, (long)oh * ow, f, act);
             if (st >= 0)
                 return st;
