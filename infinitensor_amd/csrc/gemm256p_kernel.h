@@ -159,6 +159,16 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         }
     };
 
+    // The first K-tiles go out NOW: the fragment address arithmetic, the accumulator clear (128 v_mov per lane) and everything
+    // else up to the first barrier then run under their memory round trip instead of in front of it.
+    stamp();
+    set_a_tile(0);
+    set_b_tile(0);
+    stage_b_next(0);
+    stage_a_next(0);
+    if (total_kt > 1)
+        stage_b_next(1);
+
     // ---- per-lane LDS read addresses (gemm256.hip) ------------------------------------------------
     const unsigned lds0 = (unsigned)(unsigned long)IROCM_LDS_PTR(smem);
     const unsigned kmaj_lane = (unsigned)(l15 * 128 + (((g4 ^ (l15 >> 1)) & 3) | (((l15 >> 1) >> 2) << 2)) * 16);
@@ -736,17 +746,11 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         barrier();
     };
 
-    stamp();
-    set_a_tile(0);
-    set_b_tile(0);
-    stage_b_next(0);
-    stage_a_next(0);
-    if (total_kt > 1) {
-        stage_b_next(1);
+    // (the first K-tiles were requested at the top of the kernel, before the address arithmetic and the accumulator clear)
+    if (total_kt > 1)
         wait_vm<NB>();
-    } else {
+    else
         wait_vm<0>();
-    }
     barrier();
     if (wr == 1)
         barrier(); // stagger: wave row 1 runs one barrier interval behind wave row 0
