@@ -401,7 +401,8 @@ int infini_rocm_conv_transpose2d(infiniRocmRuntime_t rt, int dtype, const void *
  * Used by tune() and tests. */
 int infini_rocm_conv2d_set_variant(infiniRocmRuntime_t rt, int variant);
 /* Which implementation the most recent conv2d call on this runtime launched: "direct32" (fp32), "pixel_gemm" (pointwise layer as
- * one GEMM over pixel slots on the persistent kernels), "tap_shifted" (conv_s1.hip), "batched_gemm", "generic", "none". A forced
+ * one GEMM over pixel slots on the persistent kernels), "resident" (F <= 64, C <= 64: weights resident in LDS, persistent
+ * workgroups), "tap_shifted" (the other kernels of conv_s1.hip), "batched_gemm", "generic", "none". A forced
  * variant falls back when a shape does not qualify; tests and measurement tools read the route instead of assuming it. */
 int infini_rocm_conv2d_last_route(infiniRocmRuntime_t rt, const char **route);
 /* Packed-weight cache. The f16 / bf16 conv kernels read their weights re-packed (FCRS -> [RS][F][C]); while `on` is set

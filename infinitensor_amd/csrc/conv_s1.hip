@@ -245,8 +245,8 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvS1Args &p, f32x4 (&
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         v[r] = apply_act(v[r], p.act);
-                    pk[t2][0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
-                    pk[t2][1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
+                    pk[t2][0] = Tr::pack2(v[0], v[1]);
+                    pk[t2][1] = Tr::pack2(v[2], v[3]);
                 }
                 const unsigned s0 = odd ? pk[0][0] : pk[1][0], s1 = odd ? pk[0][1] : pk[1][1];
                 const unsigned r0 = (unsigned)__shfl_xor((int)s0, 16), r1 = (unsigned)__shfl_xor((int)s1, 16);
@@ -298,8 +298,8 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvS1Args &p, f32x4 (&
             unsigned short *dst = Y + yoff;
             if (vec_ok && pix + 3 < p.hw) {
                 u32x2_t pk;
-                pk[0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
-                pk[1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
+                pk[0] = Tr::pack2(v[0], v[1]);
+                pk[1] = Tr::pack2(v[2], v[3]);
                 *(u32x2_t *)dst = pk;
             } else {
 #pragma unroll
@@ -377,8 +377,8 @@ __device__ __forceinline__ void conv_tile_epilogue_lds(const ConvS1Args &p, f32x
                         v[r] = apply_act(v[r], p.act);
                 }
                 u32x2_t pk;
-                pk[0] = (unsigned)Tr::from_f32(v[0]) | ((unsigned)Tr::from_f32(v[1]) << 16);
-                pk[1] = (unsigned)Tr::from_f32(v[2]) | ((unsigned)Tr::from_f32(v[3]) << 16);
+                pk[0] = Tr::pack2(v[0], v[1]);
+                pk[1] = Tr::pack2(v[2], v[3]);
                 *(u32x2_t *)(wbuf + (i * 16 + l15) * ROWP + (j * 16 + g4 * 4) * 2) = pk;
             }
         }
@@ -408,7 +408,7 @@ __device__ __forceinline__ void conv_tile_epilogue_lds(const ConvS1Args &p, f32x
                     lo = apply_act(lo, p.act);
                     hi = apply_act(hi, p.act);
                 }
-                v[d] = (unsigned)Tr::from_f32(lo) | ((unsigned)Tr::from_f32(hi) << 16);
+                v[d] = Tr::pack2(lo, hi);
             }
         }
         if (p.epi_probe == 2) { // ablation hooks (IROCM_CONV_EPI_PROBE): 2 = no global stores
@@ -1213,6 +1213,279 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 ? 1 : 2)) void conv_pat
     conv_tile_epilogue<Tr>(p, acc, m0, n0, wm, wn, l15, g4);
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv_resident: unit-stride "same" R x S layers with F <= 64 filters and C <= 64 channels (ResNet's C64 -> F64 3x3 @56x56: three
+// layers, 0.3 ms of the 3.4 ms graph, 6 x their floor on the tap-shifted kernel, which re-fetches its B tile from L2 for every
+// tap through registers one step ahead and idles out the round trip: 7 % MFMA busy). The whole re-packed weight tensor
+// ([R S][64 f][C] = 72 KiB for 3x3 x 64) stays RESIDENT in LDS; a persistent workgroup (one per CU, 4 waves of 64 f x 64 slots)
+// walks 256-slot tiles: per tile the input patch of both 32-channel blocks is brought in ONCE (global -> registers, one tile
+// ahead, -> RAW -> transposed PM images, exactly as conv_patch), and the R S x C / 32 tap steps then run with NO global memory
+// traffic and NO barrier — fragment reads one step ahead of the MFMAs (counted lgkmcnt; with one wave per SIMD nothing else
+// would cover the LDS latency). The prologue (weights, address setup, cold instruction fetch) is paid once per CU, not per tile.
+// Planes must be a multiple of 8 pixels (no run ever ends past the tensor; other layers keep the tap-shifted kernel).
+// ------------------------------------------------------------------------------------------------
+template <typename Tr>
+__global__ __launch_bounds__(256, 1) void conv_resident_kernel(ConvS1Args p, int halo8, int pslots, int ntiles) {
+    constexpr int BN = 256, BK = 32, NCBMAX = 2;
+    constexpr int WT_TILE = 64 * BK * 2;                 // one (tap, channel block) weight tile: [64 f][32 c], 64-byte rows
+    constexpr int RAW_ROWB = 64 * 16, RAW_BYTES = BK * RAW_ROWB; // [32 k][<= 512 slots]
+    constexpr int NR = (BK * (BN + 128) / 8 + 255) / 256; // patch runs per thread per channel block
+    extern __shared__ __attribute__((aligned(16))) char smem[]; // [weights | RAW | PM of block 0 | PM of block 1]
+    const int ncb = p.c / BK, ntaps = p.r * p.s, nsteps = ntaps * ncb;
+    char *const raw = smem + nsteps * WT_TILE;
+    char *const pm = raw + RAW_BYTES;
+    const int pm_bytes = pslots * 64;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6); // = wn: wave w owns slots [64 w, 64 w + 64) of the tile
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const unsigned lds0 = (unsigned)(unsigned long)IROCM_LDS_PTR(smem);
+    const __amdgpu_buffer_rsrc_t xrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.x), 0, (int)p.x_bytes, 0x00020000);
+
+    // ---- weights: nsteps tiles of 4 pieces (16 rows x 64 B) each, by LDS-DMA, once. Tile index = cb * ntaps + tap. The image is
+    // lane-linear (row = piece * 16 + lane / 4, chunk lane % 4); the chunk swizzle ((row >> 2) & 1) << 1 that makes the fragment
+    // reads conflict-free is applied to the global SOURCE chunk (as in conv_patch). -------------------------------------------
+    {
+        const unsigned short *Wp = (const unsigned short *)p.w;
+        const long tap_stride = (long)p.f * p.c;
+        for (int pc = w; pc < nsteps * 4; pc += 4) { // (wave w takes piece w of every tile)
+            const int tile = pc >> 2, q = pc & 3;
+            const int cb = tile >= ntaps ? 1 : 0, tap = tile - cb * ntaps; // at most two channel blocks
+            const int row = q * 16 + (lane >> 2);
+            const int c_src = (lane & 3) ^ (((row >> 2) & 1) << 1);
+            const int gm = row < p.f ? row : p.f - 1; // rows past F re-read the last filter; never stored
+            const char *src = (const char *)(Wp + tap * tap_stride + (long)gm * p.c + cb * BK + c_src * 8);
+            __builtin_amdgcn_global_load_lds(IROCM_GLB_PTR(src), IROCM_LDS_PTR(smem + tile * WT_TILE + q * 1024), 16, 0, 0);
+        }
+    }
+    // ---- per-lane constants ------------------------------------------------------------------------------
+    const int rpr = pslots / 8, nruns = BK * rpr;
+    const unsigned rpr_m = (unsigned)((1ull << 32) / (unsigned)rpr);
+    int run_kr[NR], run_rc[NR], p_lds[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int id = t + i * 256;
+        fast_divmod(id, rpr, rpr_m, run_kr[i], run_rc[i]);
+        p_lds[i] = id < nruns ? run_kr[i] * RAW_ROWB + ((run_rc[i] ^ (f128::mn_f(run_kr[i]) << 1)) * 16) : -1;
+    }
+    const unsigned a_frag = lds0 + (unsigned)(l15 * 64 + ((g4 ^ (((l15 >> 2) & 1) << 1)) * 16)); // + tile * WT_TILE + i * 1024
+    const unsigned pm0 = lds0 + (unsigned)(nsteps * WT_TILE + RAW_BYTES);
+    const int g4_16 = g4 * 16;
+    const int brow64 = (halo8 + w * 64 + l15) * 64;
+    int t_frag[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+        t_frag[hh] = (g4 * 8 + hh * 4 + (l15 >> 2)) * RAW_ROWB + (l15 & 1) * 8;
+    const int mnf_lane[2] = {f128::mn_f(g4 * 8 + (l15 >> 2)), f128::mn_f(g4 * 8 + 4 + (l15 >> 2))};
+    float bias_v[4];
+    conv_load_bias<Tr>(p, 0, 0, l15, bias_v);
+
+    u32x4_t p_reg[NCBMAX][NR];
+    // the patch of tile `tile`: slots [n0 - halo8, n0 + 256 + halo8), both channel blocks; runs that do not exist read zeros.
+    // Two phases: the run offsets (patch_addr), then one buffer load per (run, block) (patch_issue) — the tile loop spreads the
+    // issues over the tap steps of the previous tile (with one wave per SIMD a burst of twelve loads is twelve issue slots the MFMA
+    // pipe idles through).
+    int run_voff[NR];
+    auto patch_addr = [&](int tile) __attribute__((always_inline)) {
+        const int pstart = tile * BN - halo8;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int slot0 = pstart + run_rc[i] * 8;
+            const bool ok = p_lds[i] >= 0 && slot0 >= 0 && slot0 < p.ncols;
+            int img, pix;
+            fast_divmod(ok ? slot0 : 0, p.hwp, p.hwp_m, img, pix); // hwp == hw here (planes are multiples of 8)
+            run_voff[i] = ok ? ((img * p.c + run_kr[i]) * p.hw + pix) * 2 : (int)0xfffffff0u; // (x_bytes < 2^31: 32-bit is enough)
+        }
+    };
+    auto patch_issue = [&](auto ic, auto cbc) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value, cb = decltype(cbc)::value;
+        if (cb < ncb) {
+            const int voff = run_voff[i];
+            p_reg[cb][i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff == (int)0xfffffff0u ? voff : voff + cb * BK * p.hw * 2, 0, 0);
+        }
+    };
+    auto load_patch = [&](int tile) __attribute__((always_inline)) { // everything at once (the first tile)
+        patch_addr(tile);
+        g256::sfor<NR>([&](auto ic) {
+            patch_issue(ic, std::integral_constant<int, 0>{});
+            patch_issue(ic, std::integral_constant<int, 1>{});
+        });
+    };
+    auto store_patch = [&](int cb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+            if (p_lds[i] >= 0)
+                *(u32x4_t *)(raw + p_lds[i]) = p_reg[cb][i];
+    };
+    auto transpose = [&](char *pmc) __attribute__((always_inline)) { // RAW [k][slots] -> PM [slot][k], 16-slot blocks w, w + 4, ...
+        for (int sb = w; sb * 16 < pslots; sb += 4) {
+            s16x4_t h[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int c16 = (sb * 2 + ((l15 >> 1) & 1)) ^ (mnf_lane[hh] << 1);
+                const char *addr = raw + t_frag[hh] + c16 * 16;
+                h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t *)(addr));
+            }
+            const int row = sb * 16 + l15;
+            *(s16x8_t *)(pmc + row * 64 + ((g4 ^ (((row >> 2) & 1) << 1)) * 16)) =
+                s16x8_t{h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
+        }
+    };
+    int vm[4];
+    auto compute_vm = [&](int n0) __attribute__((always_inline)) { // 3 x 3, pad 1 (the launcher admits nothing else): nine bits per slot
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int slot = n0 + w * 64 + j * 16 + l15;
+            int img, pix, oh, ow;
+            fast_divmod(slot < p.ncols ? slot : 0, p.hwp, p.hwp_m, img, pix);
+            fast_divmod(pix, p.wd, p.wd_m, oh, ow);
+            const unsigned colmask = (ow > 0 ? 1u : 0u) | 2u | (ow + 1 < p.in_w ? 4u : 0u);
+            const unsigned m = (oh > 0 ? colmask : 0u) | (colmask << 3) | (oh + 1 < p.in_h ? colmask << 6 : 0u);
+            vm[j] = slot < p.ncols ? (int)m : 0;
+        }
+    };
+    struct TapFrags {
+        s16x8_t af[4];
+        u32x4_t bv[4];
+    };
+    // One step = 16 MFMAs on the fragments of (tap, block) `step`, with the eight fragment reads of step + 1 issued BETWEEN them
+    // (one wave per SIMD: an LDS or VALU instruction issued in front of the MFMA block delays it by its issue slots; placed between two
+    // MFMAs it rides in the 16 cycles the matrix pipe needs anyway). Reads are opaque asm, the order is pinned with scheduling
+    // fences, and the wait at the top of a step is a plain lgkmcnt(0): only that step's own reads are outstanding then.
+    auto frag_addrs = [&](int step, int shift64, unsigned &abase, unsigned &baddr) __attribute__((always_inline)) {
+        abase = a_frag + (unsigned)(step * WT_TILE);
+        const int r64 = brow64 + shift64;
+        baddr = pm0 + (unsigned)((step >= ntaps ? pm_bytes : 0) + r64 + (((r64 >> 3) & 32) ^ g4_16));
+    };
+    auto read_all = [&](unsigned abase, unsigned baddr, TapFrags &f) __attribute__((always_inline)) {
+        f.af[0] = g256::lds_read_b128<0>(abase);
+        f.af[1] = g256::lds_read_b128<1024>(abase);
+        f.af[2] = g256::lds_read_b128<2048>(abase);
+        f.af[3] = g256::lds_read_b128<3072>(abase);
+        f.bv[0] = __builtin_bit_cast(u32x4_t, g256::lds_read_b128<0>(baddr));
+        f.bv[1] = __builtin_bit_cast(u32x4_t, g256::lds_read_b128<1024>(baddr));
+        f.bv[2] = __builtin_bit_cast(u32x4_t, g256::lds_read_b128<2048>(baddr));
+        f.bv[3] = __builtin_bit_cast(u32x4_t, g256::lds_read_b128<3072>(baddr));
+    };
+    f32x4 acc[4][4];
+    // MFMAs of `cur` (masked with tap `tap0`), reads into `nxt` interleaved when HAVE_NEXT
+    auto step_fn = [&](auto have_next, const TapFrags &cur, int tap0, TapFrags &nxt, unsigned abase, unsigned baddr) __attribute__((always_inline)) {
+        constexpr bool HN = decltype(have_next)::value;
+        s16x8_t bf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned m = (unsigned)__builtin_amdgcn_sbfe(vm[j], tap0, 1); // 0 or 0xffffffff
+            u32x4_t v = cur.bv[j];
+            v[0] &= m; v[1] &= m; v[2] &= m; v[3] &= m;
+            bf[j] = __builtin_bit_cast(s16x8_t, v);
+        }
+        g256::fence_sched();
+        g256::sfor<16>([&](auto kc) {
+            constexpr int k = decltype(kc)::value, i = k >> 2, j = k & 3;
+            acc[i][j] = Tr::mfma(bf[j], cur.af[i], acc[i][j]);
+            if constexpr (HN && k < 8) {
+                g256::fence_sched();
+                if constexpr (k == 0) nxt.af[0] = g256::lds_read_b128<0>(abase);
+                if constexpr (k == 1) nxt.af[1] = g256::lds_read_b128<1024>(abase);
+                if constexpr (k == 2) nxt.af[2] = g256::lds_read_b128<2048>(abase);
+                if constexpr (k == 3) nxt.af[3] = g256::lds_read_b128<3072>(abase);
+                if constexpr (k == 4) nxt.bv[0] = __builtin_bit_cast(u32x4_t, g256::lds_read_b128<0>(baddr));
+                if constexpr (k == 5) nxt.bv[1] = __builtin_bit_cast(u32x4_t, g256::lds_read_b128<1024>(baddr));
+                if constexpr (k == 6) nxt.bv[2] = __builtin_bit_cast(u32x4_t, g256::lds_read_b128<2048>(baddr));
+                if constexpr (k == 7) nxt.bv[3] = __builtin_bit_cast(u32x4_t, g256::lds_read_b128<3072>(baddr));
+                g256::fence_sched();
+            }
+        });
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles)
+        load_patch(tile);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // weights (and the first patch) have landed
+    __syncthreads();
+    const int row64 = p.wd * 64;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int n0 = tile * BN;
+        // ---- patch -> PM images (the registers were filled one tile ago) ----------------------------------
+        for (int cb = 0; cb < ncb; ++cb) {
+            if (cb == 0) store_patch(0);
+            else store_patch(1);
+            __syncthreads();
+            transpose(pm + cb * pm_bytes);
+            __syncthreads();
+        }
+        const bool more = tile + (int)gridDim.x < ntiles;
+        if (more)
+            patch_addr(tile + gridDim.x);
+        compute_vm(n0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // ---- the tap steps: no global memory, no barrier ---------------------------------------------------
+        int sh64 = (-p.ph * p.wd - p.pw) * 64, ss = 0, tap = 0;
+        auto next_tap = [&]() {
+            sh64 += 64;
+            if (++ss == p.s) { ss = 0; sh64 += row64 - p.s * 64; }
+            if (++tap == ntaps) { tap = 0; ss = 0; sh64 = (-p.ph * p.wd - p.pw) * 64; }
+        };
+        // Fully unrolled, branch-free step sequence per supported step count (3 x 3 taps x one or two channel blocks): with a
+        // conditional second half in a rolled loop hipcc kept the accumulators in AGPRs on one path and VGPRs on the other and
+        // moved all 64 of them across EVERY step (64 v_accvgpr_write + 64 v_accvgpr_read per 16 MFMAs: 970 cycles per step).
+        TapFrags fr[2];
+        auto run_steps = [&](auto nc) __attribute__((always_inline)) {
+            constexpr int N = decltype(nc)::value;
+            {
+                unsigned ab, bb;
+                frag_addrs(0, sh64, ab, bb);
+                read_all(ab, bb, fr[0]);
+            }
+            g256::sfor<N>([&](auto sc) {
+                constexpr int step = decltype(sc)::value;
+                const int tap0 = tap;
+                next_tap();
+                unsigned ab = 0, bb = 0;
+                if constexpr (step + 1 < N)
+                    frag_addrs(step + 1, sh64, ab, bb);
+                g256::wait_lgkm0(); // this step's fragments (issued during the previous step's MFMAs)
+                step_fn(std::integral_constant<bool, (step + 1 < N)>{}, fr[step & 1], tap0, fr[(step + 1) & 1], ab, bb);
+                // the next tile's patch: one (run, block) load behind each of the first 2 NR steps (N >= NR for one block)
+                if constexpr (step < 2 * NR) {
+                    if (more) {
+                        if constexpr (N >= 2 * NR) patch_issue(std::integral_constant<int, step / 2>{}, std::integral_constant<int, step % 2>{});
+                        else if constexpr (step < NR) patch_issue(std::integral_constant<int, step>{}, std::integral_constant<int, 0>{});
+                    }
+                }
+                g256::fence_sched();
+            });
+        };
+        if (nsteps == 18) run_steps(std::integral_constant<int, 18>{});
+        else run_steps(std::integral_constant<int, 9>{}); // (the launcher admits 9 and 18 only)
+        // ---- epilogue: staged through RAW + PM (dead now; 36 KiB for the four waves) ---------------------------
+        __syncthreads();
+        conv_tile_epilogue_lds<Tr>(p, acc, bias_v, 0, n0, 0, w, lane, raw + w * kEpiWaveBytes);
+        __syncthreads();
+    }
+}
+
+template <typename Tr> static int launch_resident(infiniRocmRuntime_t rt, ConvS1Args &p, int halo8) {
+    const int pslots = 256 + 2 * halo8;
+    const int ncb = p.c / 32, nsteps = p.r * p.s * ncb;
+    const int lds = nsteps * 4096 + 32 * 1024 + ncb * pslots * 64;
+    const int ntiles = (int)ceil_div(p.ncols, 256);
+    p.tiles_m = 1;
+    p.tiles_n = ntiles;
+    auto kern = conv_resident_kernel<Tr>;
+    IROCM_LDS_ATTR(kern, 160 * 1024, rt);
+    const int grid = ntiles < rt->num_cu ? ntiles : rt->num_cu;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, rt->stream, p, halo8, pslots, ntiles);
+    IROCM_LAUNCH_CHECK("conv_resident");
+    rt->last_conv_route = "resident";
+    return INFINI_ROCM_OK;
+}
+
 template <typename Tr, int WM, int WN> static int launch_patch(infiniRocmRuntime_t rt, ConvS1Args &p, int halo8, int pslots) {
     constexpr int BM = WM * 64, BN = WN * 64;
     p.tiles_m = (int)ceil_div(p.f, BM);
@@ -1450,6 +1723,11 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
         if (f > 64 && 2 * halo8 <= 128)
             return bf ? launch_patch<Bf16Traits, 2, 2>(rt, p, halo8, 128 + 2 * halo8)
                       : launch_patch<F16Traits, 2, 2>(rt, p, halo8, 128 + 2 * halo8);
+        // F <= 64, C <= 64: the whole weight tensor resident in LDS, persistent workgroups over 256-slot tiles (conv_resident)
+        static const int resident_on = getenv("IROCM_CONV_RESIDENT") ? atoi(getenv("IROCM_CONV_RESIDENT")) : 1; // A/B hook
+        if (resident_on && f <= 64 && c <= 64 && p.hw % 8 == 0 && 2 * halo8 <= 128 && (((uintptr_t)x) & 15) == 0 && !res &&
+            r == 3 && s == 3 && ph == 1 && pw == 1 && (c == 32 || c == 64) && p.wide_epilogue == 2 && rt->conv_variant != 4)
+            return bf ? launch_resident<Bf16Traits>(rt, p, halo8) : launch_resident<F16Traits>(rt, p, halo8);
     }
     if (f <= 64)
         return bf ? launch_s1<Bf16Traits, 1, 4, 32>(rt, p) : launch_s1<F16Traits, 1, 4, 32>(rt, p);

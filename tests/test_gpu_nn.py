@@ -428,6 +428,34 @@ def test_conv_patch_wide_form(rt, cfg, dt):
     assert np.allclose(host(y), host(y2), rtol=tol, atol=tol)
 
 
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("cfg", [(2, 64, 8, 8, 64, 3), (3, 32, 16, 16, 48, 3), (5, 64, 12, 12, 64, 3), (70, 64, 8, 8, 64, 3), (1, 64, 56, 56, 64, 3),
+                                 (3, 64, 4, 6, 17, 3)])
+def test_conv_resident_weights_kernel(rt, cfg, dt):
+    """F <= 64, C <= 64 unit-stride "same" layers on planes that are multiples of 8 pixels: the whole weight tensor resident in LDS,
+    persistent workgroups over 256-slot tiles (conv_resident_kernel). One tile, several tiles per workgroup (70 x 64 slots = 18
+    tiles... on 256 CUs one each; 1 x 3136 = 13 tiles), a ragged last tile, C = 32 (one channel block, odd step count), ragged
+    filter counts; bias + ReLU; against the oracle and the tap-shifted kernel (variant 4)."""
+    n, c, h, w, f, k = cfg
+    rng = np.random.default_rng(abs(hash(cfg)) % 2 ** 32)
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((f, c, k, k)) / np.sqrt(c * k * k)).astype(np.float32)
+    b = rng.standard_normal((f,)).astype(np.float32)
+    xd, wd, bd = dev(x, TD[dt]), dev(wt, TD[dt]), dev(b, TD[dt])
+    try:
+        y = ops.conv2d(rt, xd, wd, k // 2, k // 2, 1, 1, bias=bd, act=1)
+        assert ops.conv_last_route(rt) == "resident"
+        ops.set_conv_variant(rt, 4)
+        y2 = ops.conv2d(rt, xd, wd, k // 2, k // 2, 1, 1, bias=bd, act=1)
+        assert ops.conv_last_route(rt) == "tap_shifted"
+    finally:
+        ops.set_conv_variant(rt, -1)
+    want = np.maximum(R.conv2d(R.round_to(x, dt), R.round_to(wt, dt), k // 2, k // 2, 1, 1, 1, 1) + R.round_to(b, dt).reshape(1, f, 1, 1), 0)
+    tol = {"f16": 3e-3, "bf16": 2.4e-2}[dt]
+    assert np.allclose(host(y), want, rtol=tol, atol=tol), np.abs(host(y) - want).max()
+    assert np.allclose(host(y), host(y2), rtol=tol, atol=tol)
+
+
 PW_GEMM = [  # (n, c, h, w, f): pointwise layers for the conv mode of the persistent GEMM (variant 5)
     (3, 64, 8, 8, 256),      # plane of 64 pixels: a 256-slot tile spans four images
     (5, 128, 14, 14, 512),   # 196 pixels: 4-pixel ragged run at every plane end, tiles span images
