@@ -62,6 +62,7 @@ int launch_conv_pw_gemm(infiniRocmRuntime_t rt, int dtype, const void *x, const 
     p.zeros = rt->zeros;
     p.epi16 = 1;
     p.cv_hw = (int)hw; p.cv_hwp = (int)hwp; p.cv_res = res;
+    p.cv_res_bytes = (unsigned)(n * f * hw * 2); // (< 2^32: checked above)
     // the 256-column residual copy spills 36-48 bytes per lane (epilogue only) and still wins where the cost model picks it:
     // C256 -> F1024 @14x14 with a residual 40.4 vs 46.9 us on 192-column tiles, C512 -> F2048 @7x7 30.7 vs 36.6 (IROCM_CONV_RES_NT4=0: A/B)
     static const int res_nt4 = getenv("IROCM_CONV_RES_NT4") ? atoi(getenv("IROCM_CONV_RES_NT4")) : 1;

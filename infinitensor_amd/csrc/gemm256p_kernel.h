@@ -559,8 +559,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         u32x4_t rq[has_res ? 8 : 1][has_res ? (NT / 2 > 0 ? NT / 2 : 1) : 1];
         u32x2_t rq_odd[has_res ? 8 : 1];
         if constexpr (has_res) {
-            const long total_bytes = (long)(p.n / HWP) * F * HW * 2;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.cv_res), 0, (int)total_bytes, 0x00020000);
+            const long total_bytes = (long)p.cv_res_bytes;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.cv_res), 0, (int)p.cv_res_bytes, 0x00020000);
             const unsigned rowb = (unsigned)R0 * (unsigned)HW * 2u; // wave-uniform byte offset of the wave's first filter row
             auto fetch = [&](unsigned off, int live, auto nc) { // `live` leading 16-bit values of an N-value run at byte offset off
                 constexpr int N = decltype(nc)::value;
@@ -584,16 +584,38 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
                 }
                 return v;
             };
+            // Only a tile that holds the LAST run of the tensor on a plane of hw % 8 != 0 pixels needs the element-wise form
+            // (wave-uniform test). Everywhere else the fetch is straight-line code: a dead run gets an out-of-range offset and reads
+            // zeros. (With the per-run branches of `fetch` hipcc put an s_waitcnt vmcnt(0) behind EVERY load — 16-24 serialised
+            // memory round trips per tile: the residual cost a C64 -> F256 56 x 56 layer 67 us for 205 MB.)
+            const bool tail_tile = (HW % 8 != 0) && (n0 + BN_ + HWP > p.n) && (m0 + BM >= F);
+            if (tail_tile) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const bool rowok = rows_inside || (R0 + i * 16 + qrow < F);
-                sfor<NT / 2>([&](auto jpc) {
-                    constexpr int jp = decltype(jpc)::value;
-                    rq[i][jp] = fetch(rowb + (unsigned)i * (unsigned)sstep + pbase[jp], rowok ? plive[jp] : 0, std::integral_constant<int, 8>{});
-                });
-                if constexpr (NT % 2 == 1) {
-                    const u32x4_t v = fetch(rowb + (unsigned)i * (unsigned)sstep + obase, rowok ? olive : 0, std::integral_constant<int, 4>{});
-                    rq_odd[i][0] = v[0]; rq_odd[i][1] = v[1];
+                for (int i = 0; i < 8; ++i) {
+                    const bool rowok = rows_inside || (R0 + i * 16 + qrow < F);
+                    sfor<NT / 2>([&](auto jpc) {
+                        constexpr int jp = decltype(jpc)::value;
+                        rq[i][jp] = fetch(rowb + (unsigned)i * (unsigned)sstep + pbase[jp], rowok ? plive[jp] : 0, std::integral_constant<int, 8>{});
+                    });
+                    if constexpr (NT % 2 == 1) {
+                        const u32x4_t v = fetch(rowb + (unsigned)i * (unsigned)sstep + obase, rowok ? olive : 0, std::integral_constant<int, 4>{});
+                        rq_odd[i][0] = v[0]; rq_odd[i][1] = v[1];
+                    }
+                }
+            } else {
+                const unsigned dead = (unsigned)total_bytes; // past the descriptor's range: zeros, no memory access
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const bool rowok = rows_inside || (R0 + i * 16 + qrow < F);
+                    sfor<NT / 2>([&](auto jpc) {
+                        constexpr int jp = decltype(jpc)::value;
+                        const unsigned off = (rowok && plive[jp] > 0) ? rowb + (unsigned)i * (unsigned)sstep + pbase[jp] : dead;
+                        rq[i][jp] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+                    });
+                    if constexpr (NT % 2 == 1) {
+                        const unsigned off = (rowok && olive > 0) ? rowb + (unsigned)i * (unsigned)sstep + obase : dead;
+                        rq_odd[i] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0));
+                    }
                 }
             }
         }

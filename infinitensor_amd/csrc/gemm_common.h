@@ -43,6 +43,9 @@ struct GemmArgs {
     // cv_res = the residual added before the activation (NCHW like Y, or nullptr). 0 = off.
     int cv_hw = 0, cv_hwp = 0;
     const void *cv_res = nullptr;
+    unsigned cv_res_bytes = 0; // bytes of the residual tensor (images * F * hw * 2): the range of its buffer descriptor, computed on the host
+                          // (computed in the kernel — a division — hipcc kept it in vector registers and wrapped every buffer load of
+                          // the residual in a readfirstlane waterfall loop)
 };
 
 // element offset of C(row, col) inside one batch's [m x n] block
