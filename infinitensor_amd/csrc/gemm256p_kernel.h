@@ -296,16 +296,24 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         if (rowbias) {
             const unsigned short *bb = bias + (long)ib * p.bias_b;
             const bool al8 = ((((uintptr_t)bb) & 7) == 0);
+            if (al8 && n0 + BN_ <= p.n) {
+                // the common case as straight-line code: NT loads, ONE wait (a per-load condition puts every load in its own branch
+                // with an s_waitcnt vmcnt(0) behind it: NT serialised round trips at the head of every tile's epilogue)
+                u32x2_t q[NT];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int col = n0 + wc * (16 * NT) + j * 16 + g4 * 4;
-                if (al8 && col + 3 < p.n) {
-                    const u32x2_t q = *(const u32x2_t *)(bb + col);
-                    bv[j][0] = Tr::to_f32((unsigned short)(q[0] & 0xffff));
-                    bv[j][1] = Tr::to_f32((unsigned short)(q[0] >> 16));
-                    bv[j][2] = Tr::to_f32((unsigned short)(q[1] & 0xffff));
-                    bv[j][3] = Tr::to_f32((unsigned short)(q[1] >> 16));
-                } else {
+                for (int j = 0; j < NT; ++j)
+                    q[j] = *(const u32x2_t *)(bb + (n0 + wc * (16 * NT) + j * 16 + g4 * 4));
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    bv[j][0] = Tr::to_f32((unsigned short)(q[j][0] & 0xffff));
+                    bv[j][1] = Tr::to_f32((unsigned short)(q[j][0] >> 16));
+                    bv[j][2] = Tr::to_f32((unsigned short)(q[j][1] & 0xffff));
+                    bv[j][3] = Tr::to_f32((unsigned short)(q[j][1] >> 16));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int col = n0 + wc * (16 * NT) + j * 16 + g4 * 4;
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         bv[j][r] = col + r < p.n ? Tr::to_f32(bb[col + r]) : 0.f;
@@ -543,11 +551,24 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         char *sbase = (char *)Y + (long)R0 * HW * 2;
         const long sstep = 32l * HW;                        // 16 filter rows
         const bool rows_inside = m0 + BM <= F;              // no filter-row check needed (uniform)
+        // per-filter bias of the lane's eight accumulator rows: eight UNCONDITIONAL loads (row clamped; a missing bias is a uniform
+        // branch around all of them) and one wait. (As `cond ? bias[row] : 0` each load sat in its own branch with an
+        // s_waitcnt vmcnt(0) behind it: eight serialised memory round trips at the head of every tile's epilogue.)
         float bvr[8];
+        if (bias != nullptr) {
+            unsigned short braw[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = m0 + wr * 128 + i * 16 + l15;
-            bvr[i] = (bias != nullptr && row < F) ? Tr::to_f32(bias[row]) : 0.f;
+            for (int i = 0; i < 8; ++i) {
+                const int row = m0 + wr * 128 + i * 16 + l15;
+                braw[i] = bias[row < F ? row : F - 1];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                bvr[i] = Tr::to_f32(braw[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                bvr[i] = 0.f;
         }
         // Residual: fetched in the STORE layout (the lane's 8-slot run of filter row qrow — four consecutive lanes read 64
         // contiguous bytes, the map the texture addresser merges; in the accumulator layout's own map these loads crawled like
