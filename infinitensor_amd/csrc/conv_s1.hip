@@ -323,10 +323,22 @@ constexpr int kEpiWaveBytes = 64 * 144;
 template <typename Tr>
 __device__ __forceinline__ void conv_load_bias(const ConvS1Args &p, int m0, int wm, int l15, float (&bv)[4]) {
     const unsigned short *bias = (const unsigned short *)p.bias;
+    // unconditional loads (filter index clamped) under ONE uniform branch: as `cond ? bias[fm] : 0` every load sat in its own
+    // branch with an s_waitcnt vmcnt(0) behind it — four serialised round trips in the kernel prologue
+    if (bias) {
+        unsigned short raw[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int fm = m0 + wm * 64 + i * 16 + l15;
-        bv[i] = (bias && fm < p.f) ? Tr::to_f32(bias[fm]) : 0.f;
+        for (int i = 0; i < 4; ++i) {
+            const int fm = m0 + wm * 64 + i * 16 + l15;
+            raw[i] = bias[fm < p.f ? fm : p.f - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            bv[i] = Tr::to_f32(raw[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            bv[i] = 0.f;
     }
 }
 
