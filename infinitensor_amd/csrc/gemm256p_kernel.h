@@ -703,50 +703,68 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
             }
         };
         constexpr int kPerStep = (NT / 2) * 4 + (NT % 2) * 2;
-        make(0, 0);
+        // Two copies of the store sequence, chosen by ONE uniform branch: planes of hw % 8 == 0 pixels (56 x 56, 28 x 28) have
+        // no ragged runs — a run is whole or dead — so their copy stores 16 (8) bytes under one lane predicate; the general copy
+        // keeps the 4 + 2 + 1 element stores of a plane's last run (ten exec-mask branches per 16-row step when inlined for all).
+        auto store_all = [&](auto fullc) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(fullc)::value;
+            make(0, 0);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int srow = m0 + wr * 128 + i * 16 + qrow; // the filter row this lane STORES (after the lane exchange)
-            fence_sched();
-            if (i + 1 < 8) {
-                make(i + 1, (i + 1) & 1);
-                wait_lgkm<kPerStep>();
-            } else {
-                wait_lgkm<0>();
-            }
-            sfor<NT / 2>([&](auto jpc) {
-                constexpr int jp = decltype(jpc)::value;
-                u32x4_t o = ov[i & 1][jp];
-                if constexpr (has_res) {
+            for (int i = 0; i < 8; ++i) {
+                const int srow = m0 + wr * 128 + i * 16 + qrow; // the filter row this lane STORES (after the lane exchange)
+                fence_sched();
+                if (i + 1 < 8) {
+                    make(i + 1, (i + 1) & 1);
+                    wait_lgkm<kPerStep>();
+                } else {
+                    wait_lgkm<0>();
+                }
+                const bool rowok = rows_inside || srow < F;
+                sfor<NT / 2>([&](auto jpc) {
+                    constexpr int jp = decltype(jpc)::value;
+                    u32x4_t o = ov[i & 1][jp];
+                    if constexpr (has_res) {
 #pragma unroll
-                    for (int d = 0; d < 4; ++d)
-                        o[d] = add_res(o[d], rq[i][jp][d]);
-                }
-                if ((rows_inside || srow < F) && plive[jp] > 0)
-                    store_run(sbase + pbase[jp], o, plive[jp]);
-            });
-            if constexpr (NT % 2 == 1) {
-                unsigned pk0 = ov_odd[i & 1][0], pk1 = ov_odd[i & 1][1];
-                if constexpr (has_res) {
-                    pk0 = add_res(pk0, rq_odd[i][0]);
-                    pk1 = add_res(pk1, rq_odd[i][1]);
-                }
-                if ((rows_inside || srow < F) && olive > 0) {
-                    unsigned short *dst = (unsigned short *)(sbase + obase);
-                    if (olive == 4) {
-                        u32x2_t v;
-                        v[0] = pk0; v[1] = pk1;
-                        *(u32x2_t *)dst = v;
+                        for (int d = 0; d < 4; ++d)
+                            o[d] = add_res(o[d], rq[i][jp][d]);
+                    }
+                    if constexpr (FULL) {
+                        if (rowok && plive[jp] > 0)
+                            *(u32x4_t *)(sbase + pbase[jp]) = o;
                     } else {
-                        if (olive & 2)
-                            *(unsigned *)dst = pk0;
-                        if (olive & 1)
-                            dst[olive & 2] = (unsigned short)((olive & 2 ? pk1 : pk0) & 0xffff);
+                        if (rowok && plive[jp] > 0)
+                            store_run(sbase + pbase[jp], o, plive[jp]);
+                    }
+                });
+                if constexpr (NT % 2 == 1) {
+                    unsigned pk0 = ov_odd[i & 1][0], pk1 = ov_odd[i & 1][1];
+                    if constexpr (has_res) {
+                        pk0 = add_res(pk0, rq_odd[i][0]);
+                        pk1 = add_res(pk1, rq_odd[i][1]);
+                    }
+                    if (rowok && olive > 0) {
+                        unsigned short *dst = (unsigned short *)(sbase + obase);
+                        if (FULL || olive == 4) {
+                            u32x2_t v;
+                            v[0] = pk0; v[1] = pk1;
+                            *(u32x2_t *)dst = v;
+                        } else {
+                            if (olive & 2)
+                                *(unsigned *)dst = pk0;
+                            if (olive & 1)
+                                dst[olive & 2] = (unsigned short)((olive & 2 ? pk1 : pk0) & 0xffff);
+                        }
                     }
                 }
+                fence_sched();
+                sbase += sstep;
             }
-            fence_sched();
-            sbase += sstep;
+        };
+        if constexpr (has_res && NT == 4) {
+            store_all(std::false_type{}); // (the 256-column residual copy is out of registers: one copy of the sequence only)
+        } else {
+            if (HW % 8 == 0) store_all(std::true_type{});
+            else store_all(std::false_type{});
         }
     };
 
