@@ -96,7 +96,8 @@ __device__ __forceinline__ void offs_mn(unsigned (&off)[4], long ld, int col0, i
 // conv mode: the B tile's columns are pixel slots (image, pixel) of an NCHW activation; k-row kr of the tile is channel k0 + kr.
 // Byte offset of the lane's 16-byte run from X: ((img * C + kr) * HW + pix) * 2. A run that starts inside a plane may reach past
 // its end when HW % 8 != 0: the surplus lands in dead slots (never stored); the caller guarantees the bytes are readable.
-__device__ __forceinline__ void offs_mn_conv(unsigned (&off)[4], int hw, int hwp, long chw, int col0, int cols, int w, int lane) {
+__device__ __forceinline__ void offs_mn_conv(unsigned (&off)[4], int hw, int hwp, unsigned hwp_m, long chw, int col0, int cols, int w,
+                                             int lane) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int piece = w * 4 + i;
@@ -104,7 +105,8 @@ __device__ __forceinline__ void offs_mn_conv(unsigned (&off)[4], int hw, int hwp
         const int c_log = (lane & 31) ^ (mn_f(kr) << 1);
         int gc = col0 + c_log * 8;
         gc = gc <= cols - 8 ? gc : cols - 8;
-        const int img = gc / hwp, pix = gc - img * hwp;
+        unsigned img, pix;
+        udivmod_m((unsigned)gc, (unsigned)hwp, hwp_m, img, pix);
         off[i] = (unsigned)(((long)img * chw + (long)kr * hw + pix) * 2);
     }
 }

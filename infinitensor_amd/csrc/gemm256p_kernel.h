@@ -62,6 +62,7 @@ __device__ __forceinline__ void stage_n(const char *ubase, const unsigned (&off)
 struct PArgs {
     GemmArgs g;
     int total_tiles; // tiles_m * tiles_n * batch
+    unsigned per_batch_m, per_group_m; // floor(2^32 / (tiles_m * tiles_n)), floor(2^32 / (8 * tiles_n)): decode() divides by multiply-high
     unsigned long long *trace; // TRACE instantiation only: [gridDim.x][8 waves][kTraceSlots] s_memtime stamps
 };
 
@@ -103,16 +104,25 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     // step s of this workgroup -> (batch, m0, n0). Linear tile ids keep the XCD of the workgroup (gridDim.x % 8 == 0
     // whenever a workgroup has more than one tile), then the grouped raster of gemm256.hip.
     auto decode = [&](int s, int &ib, int &m0, int &n0) {
+        // (every division by multiply-high + one correction: with plain `/` and `%` on run-time values this was 3 emulated
+        // divisions of ~45 instructions, three times per tile — A cursor, B cursor, tile loop)
         unsigned wg = xcd_remap((unsigned)s * gridDim.x + blockIdx.x, (unsigned)pa.total_tiles);
-        ib = wg / per_batch;
-        wg -= ib * per_batch;
+        unsigned ibu, rest;
+        udivmod_m(wg, per_batch, pa.per_batch_m, ibu, rest);
+        ib = (int)ibu;
         constexpr int GROUP_M = 8;
         const unsigned per_group = GROUP_M * p.tiles_n;
-        const unsigned group = wg / per_group;
+        unsigned group, in_group;
+        udivmod_m(rest, per_group, pa.per_group_m, group, in_group);
         const int first_m = group * GROUP_M;
         const int gsz = min(p.tiles_m - first_m, GROUP_M);
-        m0 = (first_m + (wg % per_group) % gsz) * BM;
-        n0 = ((wg % per_group) / gsz) * BN_;
+        // floor(2^32 / gsz) for gsz = 1 .. 8
+        const unsigned gm = gsz == 8 ? 0x20000000u : gsz == 7 ? 0x24924924u : gsz == 6 ? 0x2aaaaaaau : gsz == 5 ? 0x33333333u
+                          : gsz == 4 ? 0x40000000u : gsz == 3 ? 0x55555555u : gsz == 2 ? 0x80000000u : 0xffffffffu;
+        unsigned qn, rm;
+        udivmod_m(in_group, (unsigned)gsz, gm, qn, rm);
+        m0 = (first_m + (int)rm) * BM;
+        n0 = (int)qn * BN_;
     };
 
     const long lda = A_KMAJOR ? p.a_rs : p.a_cs;
@@ -136,7 +146,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         int ib, m0, n0;
         decode(s, ib, m0, n0);
         b_base = (const char *)((const unsigned short *)p.b + (long)ib * p.b_bs);
-        if constexpr (CONV) offs_mn_conv(b_off, p.cv_hw, p.cv_hwp, (long)p.k * p.cv_hw, n0, p.n, w, lane);
+        if constexpr (CONV) offs_mn_conv(b_off, p.cv_hw, p.cv_hwp, p.cv_hwp_m, (long)p.k * p.cv_hw, n0, p.n, w, lane);
         else if constexpr (B_KMAJOR) offs_k_n<NT>(b_off, ldb, n0, p.n, w, lane);
         else offs_mn(b_off, ldb, n0, p.n, w, lane);
     };
@@ -535,7 +545,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         sfor<NT / 2>([&](auto jpc) {
             constexpr int jp = decltype(jpc)::value;
             const int col = n0 + wc * (16 * NT) + jp * 32 + qchunk * 8;
-            const int img = col / HWP, pix = col - img * HWP;
+            unsigned imgu, pixu;
+            udivmod_m((unsigned)col, (unsigned)HWP, p.cv_hwp_m, imgu, pixu);
+            const int img = (int)imgu, pix = (int)pixu;
             pbase[jp] = (unsigned)((img * F + qrow) * HW + pix) * 2u;
             plive[jp] = col < p.n ? min(8, HW - pix) : 0;
         });
@@ -543,7 +555,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         int olive = 0;
         if constexpr (NT % 2 == 1) {
             const int col = n0 + wc * (16 * NT) + (NT - 1) * 16 + qchunk * 4;
-            const int img = col / HWP, pix = col - img * HWP;
+            unsigned imgu, pixu;
+            udivmod_m((unsigned)col, (unsigned)HWP, p.cv_hwp_m, imgu, pixu);
+            const int img = (int)imgu, pix = (int)pixu;
             obase = (unsigned)((img * F + qrow) * HW + pix) * 2u;
             olive = col < p.n ? max(0, min(4, HW - pix)) : 0;
         }
@@ -879,6 +893,8 @@ static int launch_p(infiniRocmRuntime_t rt, GemmArgs g, bool akm, bool bkm, unsi
         IROCM_FAIL(INFINI_ROCM_INVALID_ARGUMENT, "matmul: too many tiles");
     pa.g = g;
     pa.total_tiles = (int)total;
+    pa.per_batch_m = udiv_magic((unsigned long long)g.tiles_m * g.tiles_n);
+    pa.per_group_m = udiv_magic(8ull * g.tiles_n);
     // one workgroup per CU walking its tiles; gridDim.x % 8 == 0 keeps every workgroup's tiles on its XCD's id range
     unsigned grid = (unsigned)total;
     const unsigned cus = (unsigned)(rt->num_cu >= 8 ? (rt->num_cu / 8) * 8 : rt->num_cu);
@@ -915,7 +931,10 @@ template <typename Tr, int NT, bool RES> static int launch_p_conv(infiniRocmRunt
     if (total >= (1l << 31))
         IROCM_FAIL(INFINI_ROCM_INVALID_ARGUMENT, "conv: too many tiles");
     pa.g = g;
+    pa.g.cv_hwp_m = udiv_magic((unsigned long long)g.cv_hwp);
     pa.total_tiles = (int)total;
+    pa.per_batch_m = udiv_magic((unsigned long long)g.tiles_m * g.tiles_n);
+    pa.per_group_m = udiv_magic(8ull * g.tiles_n);
     unsigned grid = (unsigned)total;
     const unsigned cus = (unsigned)(rt->num_cu >= 8 ? (rt->num_cu / 8) * 8 : rt->num_cu);
     if (grid > cus)

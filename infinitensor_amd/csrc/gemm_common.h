@@ -43,6 +43,7 @@ struct GemmArgs {
     // cv_res = the residual added before the activation (NCHW like Y, or nullptr). 0 = off.
     int cv_hw = 0, cv_hwp = 0;
     const void *cv_res = nullptr;
+    unsigned cv_hwp_m = 0;     // floor(2^32 / cv_hwp): slot -> (image, pixel) by multiply-high (udivmod_m below)
     unsigned cv_res_bytes = 0; // bytes of the residual tensor (images * F * hw * 2): the range of its buffer descriptor, computed on the host
                           // (computed in the kernel — a division — hipcc kept it in vector registers and wrapped every buffer load of
                           // the residual in a readfirstlane waterfall loop)
@@ -132,6 +133,18 @@ __device__ static inline float apply_act(float v, int act) {
 
 // Bijective XCD-aware remap of a linear workgroup id: consecutive ids returned to one XCD
 // (dispatch is round-robin over the 8 XCDs: block b runs on XCD b % 8 — speed only).
+// n / d and n % d for n < 2^32 with m = min(floor(2^32 / d), 2^32 - 1): the multiply-high quotient is short by at most one.
+// (A division by a run-time value is ~45 instructions; the persistent kernels did 9-17 of them per tile.)
+__device__ __forceinline__ void udivmod_m(unsigned n, unsigned d, unsigned m, unsigned &q, unsigned &r) {
+    q = __umulhi(n, m);
+    r = n - q * d;
+    if (r >= d) {
+        ++q;
+        r -= d;
+    }
+}
+static inline unsigned udiv_magic(unsigned long long d) { return d <= 1 ? 0xffffffffu : (unsigned)((1ull << 32) / d); }
+
 __device__ static inline unsigned xcd_remap(unsigned bid, unsigned nwg) {
     const unsigned q = nwg / kNumXcd, r = nwg % kNumXcd;
     const unsigned xcd = bid % kNumXcd, idx = bid / kNumXcd;
