@@ -519,6 +519,36 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         }
     };
 
+    // conv mode: the per-filter bias of the lane's eight accumulator rows lives in registers ACROSS tiles and is (re)loaded only
+    // when the tile's filter block m0 changes (layers with F <= 256 have one block: loaded once per kernel), before the tile's K
+    // loop so that nothing waits for it at the head of the epilogue. (Not in the 256-column residual copy: it has no registers.)
+    constexpr bool kBiasEarly = (CONV == 1) || (CONV == 2 && NT < 4);
+    float cbias[kBiasEarly ? 8 : 1];
+    int cbias_m0 = -1;
+    auto load_cbias = [&](int m0) __attribute__((always_inline)) {
+        if constexpr (kBiasEarly) {
+            if (m0 != cbias_m0) { // (wave-uniform)
+                cbias_m0 = m0;
+                const unsigned short *bias = (const unsigned short *)p.bias;
+                if (bias != nullptr) {
+                    unsigned short braw[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int row = m0 + wr * 128 + i * 16 + l15;
+                        braw[i] = bias[row < p.m ? row : p.m - 1];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        cbias[i] = Tr::to_f32(braw[i]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        cbias[i] = 0.f;
+                }
+            }
+        }
+    };
+
     // ---- conv-mode epilogue: rows are filters, columns pixel slots; Y is NCHW ---------------------------------------
     auto epilogue_conv = [&](auto actc, auto resc, int m0, int n0) __attribute__((always_inline)) {
         constexpr int ACT = decltype(actc)::value;
@@ -569,7 +599,11 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         // branch around all of them) and one wait. (As `cond ? bias[row] : 0` each load sat in its own branch with an
         // s_waitcnt vmcnt(0) behind it: eight serialised memory round trips at the head of every tile's epilogue.)
         float bvr[8];
-        if (bias != nullptr) {
+        if constexpr (kBiasEarly) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                bvr[i] = cbias[i];
+        } else if (bias != nullptr) {
             unsigned short braw[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -836,6 +870,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     for (int c_s = 0; c_s < my_tiles; ++c_s) {
         int c_ib, c_m0, c_n0; // the tile being accumulated
         decode(c_s, c_ib, c_m0, c_n0);
+        if constexpr (CONV != 0)
+            load_cbias(c_m0);
         for (int kt = 0; kt < nk; ++kt, ++G)
             ktile(G & 1);
         stamp();
