@@ -66,7 +66,12 @@ int launch_conv_pw_gemm(infiniRocmRuntime_t rt, int dtype, const void *x, const 
     // the 256-column residual copy spills 36-48 bytes per lane (epilogue only) and still wins where the cost model picks it:
     // C256 -> F1024 @14x14 with a residual 40.4 vs 46.9 us on 192-column tiles, C512 -> F2048 @7x7 30.7 vs 36.6 (IROCM_CONV_RES_NT4=0: A/B)
     static const int res_nt4 = getenv("IROCM_CONV_RES_NT4") ? atoi(getenv("IROCM_CONV_RES_NT4")) : 1;
-    const int nt = persist_pick_nt(f, n * hwp, c, rt->num_cu, (res && !res_nt4) ? 3 : 4);
+    int nt = persist_pick_nt(f, n * hwp, c, rt->num_cu, (res && !res_nt4) ? 3 : 4);
+    if (const char *force = getenv("IROCM_CONV_PW_NT")) { // test hook (read per call): force the tile width 2 / 3 / 4
+        const int v = atoi(force);
+        if (v >= 2 && v <= 4)
+            nt = v;
+    }
     rt->last_conv_route = "pixel_gemm";
     return g256p::launch_gemm256p_conv(rt, dtype, p, nt);
 }

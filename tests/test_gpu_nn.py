@@ -536,6 +536,35 @@ def test_conv_strided_pointwise_goes_through_the_phase_split_into_the_gemm_mode(
     assert np.allclose(host(y), host(y2), rtol=tol, atol=tol)
 
 
+@pytest.mark.parametrize("nt", [2, 3, 4])
+@pytest.mark.parametrize("mode", ["bias_relu", "bias_res_relu"])
+@pytest.mark.parametrize("cfg", [(5, 128, 14, 14, 512), (3, 64, 8, 8, 256), (9, 192, 7, 7, 320)])
+def test_conv_pointwise_gemm_mode_every_tile_width(rt, cfg, mode, nt, monkeypatch):
+    """Every instantiation of the conv mode (128 / 192 / 256-column tiles, with and without a residual; whole-run planes — 8 x 8 —
+    and ragged ones — 14 x 14, 7 x 7) on the same layers: the cost model alone would pick one width per shape (IROCM_CONV_PW_NT is
+    the test hook that forces it)."""
+    n, c, h, w, f = cfg
+    monkeypatch.setenv("IROCM_CONV_PW_NT", str(nt))
+    rng = np.random.default_rng(abs(hash((cfg, nt))) % 2 ** 32)
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((f, c, 1, 1)) / np.sqrt(c)).astype(np.float32)
+    b = rng.standard_normal((f,)).astype(np.float32)
+    res = rng.standard_normal((n, f, h, w)).astype(np.float32) if "res" in mode else None
+    xd, wd, bd = dev_slack(x, torch.float16), dev(wt, torch.float16), dev(b, torch.float16)
+    rd = dev(res, torch.float16) if res is not None else None
+    try:
+        ops.set_conv_variant(rt, 5)
+        y = ops.conv2d(rt, xd, wd, 0, 0, 1, 1, bias=bd, act=1, residual=rd)
+        assert ops.conv_last_route(rt) == "pixel_gemm"
+    finally:
+        ops.set_conv_variant(rt, -1)
+    want = R.conv2d(R.round_to(x, "f16"), R.round_to(wt, "f16"), 0, 0, 1, 1, 1, 1) + R.round_to(b, "f16").reshape(1, f, 1, 1)
+    if res is not None:
+        want = want + R.round_to(res, "f16")
+    want = np.maximum(want, 0)
+    assert np.allclose(host(y), want, rtol=3e-3, atol=3e-3), np.abs(host(y) - want).max()
+
+
 def test_conv_pointwise_gemm_mode_does_not_write_outside_its_output(rt):
     """The NCHW store of the conv mode ends every plane with a ragged run: the bytes right behind the output tensor (and the
     residual's) must stay untouched."""
