@@ -98,6 +98,39 @@ __global__ __launch_bounds__(256) void conv_phase_split(PhaseSplitArgs a) {
     }
 }
 
+// 1 x 1 / 2 layers read ONE phase: o[plane][oy][ox] = x[plane][2 oy][2 ox]. One thread takes VEC consecutive input columns of an
+// even input row (one VEC * 2-byte load) and stores the VEC / 2 even ones; only the rows and columns that are read are touched
+// (the generic kernel spent three emulated divisions and a 2-byte load per OUTPUT element: 30 us for 6-13 MB of output).
+struct Subsample2Args {
+    const unsigned short *x;
+    unsigned short *o;
+    int planes, in_h, in_w, oh, ow;
+    unsigned groups_m, oh_m; // multiply-high reciprocals of the column groups per row and of oh
+};
+template <int VEC> __global__ __launch_bounds__(256) void conv_subsample2_kernel(Subsample2Args a) {
+    const int groups = a.in_w / VEC; // in_w % VEC == 0 (launcher)
+    const int total = a.planes * a.oh * groups;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        int q, g, pl, oy;
+        fast_divmod(i, groups, a.groups_m, q, g);
+        fast_divmod(q, a.oh, a.oh_m, pl, oy);
+        const unsigned short *src = a.x + ((long)pl * a.in_h + 2 * oy) * a.in_w + VEC * g;
+        unsigned short *dst = a.o + ((long)pl * a.oh + oy) * a.ow + (VEC / 2) * g;
+        if constexpr (VEC == 8) {
+            const u32x4_t v = *(const u32x4_t *)src;
+            u32x2_t ev;
+            ev[0] = (v[0] & 0xffffu) | (v[1] << 16);
+            ev[1] = (v[2] & 0xffffu) | (v[3] << 16);
+            *(u32x2_t *)dst = ev;
+        } else if constexpr (VEC == 4) {
+            const u32x2_t v = *(const u32x2_t *)src;
+            *(unsigned *)dst = (v[0] & 0xffffu) | (v[1] << 16);
+        } else {
+            *dst = (unsigned short)(*(const unsigned *)src & 0xffffu);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void conv_repack_w(const unsigned short *__restrict__ w,
                                                      unsigned short *__restrict__ o, int f, int c, int rs) {
     // o[t][f][c] = w[f][c][t]
@@ -1678,7 +1711,20 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
         // vector kernels: 8 columns per thread when the row length allows (any phase set), else the quad kernel when all
         // four phases are wanted (3x3/2, 7x7/2); a 1x1/2 on odd-sized rows reads one phase and is faster element-wise
         const bool v8ok = wd % 8 == 0 && (((uintptr_t)x) & 15) == 0 && (w_off % 8 == 0) && (p.plane_elems % 4 == 0);
-        if (sh == 2 && sw == 2 && (ps.nslots == 4 || v8ok) && work2 + (long)rt->num_cu * 32 * 256 < (1l << 31)) {
+        // one phase, (0, 0), of an even-width input (the 1 x 1 / 2 layers): the subsampling kernel
+        const int vec = wd % 8 == 0 ? 8 : (wd % 4 == 0 ? 4 : (wd % 2 == 0 ? 2 : 0));
+        if (sh == 2 && sw == 2 && ps.nslots == 1 && ps.py[0] == 0 && ps.px[0] == 0 && vec && (((uintptr_t)x) & 3) == 0 && (w_off % 4 == 0) &&
+            (long)n * c * oh * (wd / vec) < (1l << 31)) {
+            Subsample2Args sa;
+            sa.x = ps.x; sa.o = ps.o; sa.planes = n * c; sa.in_h = h; sa.in_w = wd; sa.oh = oh; sa.ow = ow;
+            sa.groups_m = divmod_magic(wd / vec);
+            sa.oh_m = divmod_magic(oh);
+            long g = ceil_div((long)n * c * oh * (wd / vec), 256);
+            if (g > (long)rt->num_cu * 32) g = (long)rt->num_cu * 32;
+            if (vec == 8) hipLaunchKernelGGL(conv_subsample2_kernel<8>, dim3((unsigned)g), dim3(256), 0, rt->stream, sa);
+            else if (vec == 4) hipLaunchKernelGGL(conv_subsample2_kernel<4>, dim3((unsigned)g), dim3(256), 0, rt->stream, sa);
+            else hipLaunchKernelGGL(conv_subsample2_kernel<2>, dim3((unsigned)g), dim3(256), 0, rt->stream, sa);
+        } else if (sh == 2 && sw == 2 && (ps.nslots == 4 || v8ok) && work2 + (long)rt->num_cu * 32 * 256 < (1l << 31)) {
             PhaseSplit2Args a2;
             a2.x = ps.x; a2.o = ps.o; a2.planes = n * c; a2.in_h = h; a2.in_w = wd; a2.oh = oh; a2.ow = ow;
             a2.plane_elems = p.plane_elems;

@@ -510,7 +510,8 @@ def test_conv_pointwise_gemm_mode(rt, cfg, dt, mode):
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
-@pytest.mark.parametrize("cfg", [(4, 256, 28, 28, 512, 2), (8, 128, 15, 13, 256, 2), (2, 64, 30, 30, 256, 3)])
+@pytest.mark.parametrize("cfg", [(4, 256, 28, 28, 512, 2), (8, 128, 15, 13, 256, 2), (2, 64, 30, 30, 256, 3), (2, 64, 56, 56, 128, 2),
+                                 (6, 64, 15, 14, 256, 2), (3, 128, 14, 14, 256, 2)])
 def test_conv_strided_pointwise_goes_through_the_phase_split_into_the_gemm_mode(rt, cfg, dt):
     """ResNet's down-sampling 1 x 1 / 2 layers: the phase split leaves ONE dense [n][c][oh][ow] plane set, which then is a
     unit-stride pointwise layer for the conv mode of the persistent GEMM (conv_s1.hip, launch_conv_s1). Odd input sizes (the
