@@ -217,6 +217,47 @@ __global__ __launch_bounds__(256) void conv_phase_split_2x2_v8(PhaseSplit2Args a
     }
 }
 
+// The 2 x 2 split for rows of in_w % 4 == 0 (VEC = 4: one 8-byte load, one 4-byte store per column phase) or in_w % 2 == 0
+// (VEC = 2: one 4-byte load, one 2-byte store per phase) columns — ResNet's 28- and 14-pixel rows, which the 8-column kernel
+// cannot take — with multiply-high index math. Rows past the input (odd heights) are written as zeros.
+struct PhaseSplit2vArgs {
+    PhaseSplit2Args a;
+    unsigned groups_m, rows_m;
+};
+template <int VEC> __global__ __launch_bounds__(256) void conv_phase_split_2x2_vn(PhaseSplit2vArgs v) {
+    const PhaseSplit2Args &a = v.a;
+    const int groups = a.in_w / VEC;
+    const int rows = 2 * a.oh;
+    const int total = a.planes * rows * groups;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        int q, g, pl, iy;
+        fast_divmod(i, groups, v.groups_m, q, g);
+        fast_divmod(q, rows, v.rows_m, pl, iy);
+        const int py = iy & 1, oy = iy >> 1;
+        if (a.slot[py * 2] < 0 && a.slot[py * 2 + 1] < 0)
+            continue;
+        const unsigned short *src = a.x + ((long)pl * a.in_h + iy) * a.in_w + VEC * g;
+        const long off = ((long)pl * a.oh + oy) * a.ow + (VEC / 2) * g;
+        if constexpr (VEC == 4) {
+            u32x2_t w = {0u, 0u};
+            if (iy < a.in_h)
+                w = *(const u32x2_t *)src;
+            if (a.slot[py * 2] >= 0)
+                *(unsigned *)(a.o + a.slot[py * 2] * a.plane_elems + off) = (w[0] & 0xffffu) | (w[1] << 16);
+            if (a.slot[py * 2 + 1] >= 0)
+                *(unsigned *)(a.o + a.slot[py * 2 + 1] * a.plane_elems + off) = (w[0] >> 16) | (w[1] & 0xffff0000u);
+        } else {
+            unsigned w = 0u;
+            if (iy < a.in_h)
+                w = *(const unsigned *)src;
+            if (a.slot[py * 2] >= 0)
+                a.o[a.slot[py * 2] * a.plane_elems + off] = (unsigned short)(w & 0xffffu);
+            if (a.slot[py * 2 + 1] >= 0)
+                a.o[a.slot[py * 2 + 1] * a.plane_elems + off] = (unsigned short)(w >> 16);
+        }
+    }
+}
+
 // o[f][t*c + cc] = w[f][cc][t], zero for k in [c*rs, kpad)
 __global__ __launch_bounds__(256) void conv_repack_w_flat(const unsigned short *__restrict__ w,
                                                           unsigned short *__restrict__ o, int f, int c, int rs, int kpad) {
@@ -1734,10 +1775,21 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
                             (p.plane_elems % 4 == 0);
             long g = ceil_div(v8 ? work2 / 2 : work2, 256);
             if (g > (long)rt->num_cu * 32) g = (long)rt->num_cu * 32;
-            if (v8)
+            const int vn = v8 ? 0 : (wd % 4 == 0 && p.plane_elems % 2 == 0 ? 4 : (wd % 2 == 0 ? 2 : 0));
+            if (v8) {
                 hipLaunchKernelGGL(conv_phase_split_2x2_v8, dim3((unsigned)g), dim3(256), 0, rt->stream, a2);
-            else
+            } else if (vn && (((uintptr_t)a2.x) & 3) == 0 && (((uintptr_t)a2.o) & 3) == 0 && (long)n * c * 2 * oh * (wd / vn) < (1l << 31)) {
+                PhaseSplit2vArgs av;
+                av.a = a2;
+                av.groups_m = divmod_magic(wd / vn);
+                av.rows_m = divmod_magic(2 * oh);
+                long gv = ceil_div((long)n * c * 2 * oh * (wd / vn), 256);
+                if (gv > (long)rt->num_cu * 32) gv = (long)rt->num_cu * 32;
+                if (vn == 4) hipLaunchKernelGGL(conv_phase_split_2x2_vn<4>, dim3((unsigned)gv), dim3(256), 0, rt->stream, av);
+                else hipLaunchKernelGGL(conv_phase_split_2x2_vn<2>, dim3((unsigned)gv), dim3(256), 0, rt->stream, av);
+            } else {
                 hipLaunchKernelGGL(conv_phase_split_2x2, dim3((unsigned)g), dim3(256), 0, rt->stream, a2);
+            }
         } else {
             long g = ceil_div(p.plane_elems * ps.nslots, 256);
             if (g > (long)rt->num_cu * 32) g = (long)rt->num_cu * 32;
