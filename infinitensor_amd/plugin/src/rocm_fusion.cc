@@ -1636,8 +1636,17 @@ class FusionPlanner {
         // direct epilogue (32-byte segments per filter row) the fused form was slower than conv + one ADD_RELU pass, which
         // is still what odd planes (7x7) and fp32 get. INFINI_ROCM_FUSE_RES=0 / =1 forces it off / on for every shape.
         static const int fuseResEnv = std::getenv("INFINI_ROCM_FUSE_RES") ? std::atoi(std::getenv("INFINI_ROCM_FUSE_RES")) : -1;
+        // Round 3: pointwise layers that the library runs as a pixel-slot GEMM (csrc/conv.hip: 1 x 1, no padding, C % 64 == 0,
+        // >= 128 filters) take the residual on ANY plane, odd ones included (ResNet's 7 x 7 stage: 29 us fused against 24.5 + a
+        // 12.7 us ADD_RELU pass).
+        bool pixelGemm = false;
+        if (od.size() == 4) {
+            const auto [nb_, ch_, hh_, wd_, ff_, rr_, ss_] = conv->getNCHWFRS();
+            const auto [ph_, pw_, sh_, sw_, dh_, dw_] = conv->getPadStrideDilation();
+            pixelGemm = rr_ == 1 && ss_ == 1 && ph_ == 0 && pw_ == 0 && dh_ == 1 && dw_ == 1 && ch_ % 64 == 0 && ff_ >= 128;
+        }
         const bool fuseRes = fuseResEnv >= 0 ? fuseResEnv == 1
-                                             : (od.size() == 4 && ((long)od[2] * od[3]) % 2 == 0 && conv->getNumGroups() == 1 &&
+                                             : (od.size() == 4 && (((long)od[2] * od[3]) % 2 == 0 || pixelGemm) && conv->getNumGroups() == 1 &&
                                                 !(x->getDType() == DataType::Float32) && !(x->getDType() == DataType::Double));
         if (fuseRes && cur.biasSrc) { // residual join: the tail of a ResNet bottleneck
             if (Operator u = userOfType(cur.last, OpType::Add, cur.slot)) {
