@@ -195,3 +195,31 @@ def test_fusion_off_plans_one_item_per_operator(B, monkeypatch):
                        env=dict(os.environ, INFINI_ROCM_FUSION="0"))
     assert r.returncode == 0, r.stderr[-2000:]
     assert "0 op [0]" in r.stdout and "1 op [1]" in r.stdout
+
+
+@pytest.mark.parametrize("kernel,channels,expect_res", [(1, 64, True), (3, 64, False), (1, 32, False)])
+def test_residual_join_on_odd_planes_rides_only_in_a_pixel_slot_gemm(B, kernel, channels, expect_res):
+    """conv -> reshape(bias) -> add -> add(residual) -> relu on a 7 x 7 plane (ResNet's last stage). The library takes a residual in
+    the conv epilogue on odd planes only where the layer runs as a pixel-slot GEMM (1 x 1, C % 64 == 0, >= 128 filters:
+    csrc/conv.hip, rocm_fusion.cc planConv); a 3 x 3 layer or a 32-channel one keeps conv+bias and a separate add+relu."""
+    h = B.GraphHandler(B.cpu_runtime())
+    rng = np.random.default_rng(11)
+    x = h.tensor([2, channels, 7, 7], F16)
+    x.set_input()
+    res = h.tensor([2, 128, 7, 7], F16)
+    res.set_input()
+    w, wa = weight(h, rng.standard_normal((128, channels, kernel, kernel)))
+    b, ba = weight(h, rng.standard_normal((128,)))
+    y = h.conv(x, w, None, kernel // 2, kernel // 2, 1, 1, 1, 1)
+    r = h.reshape(b, None, [1, 128, 1, 1])
+    out = h.relu(h.add(h.add(y, r, None), res, None), None)
+    finish(h, [(x, rng.standard_normal((2, channels, 7, 7)).astype(np.float16)), (res, rng.standard_normal((2, 128, 7, 7)).astype(np.float16)),
+               (w, wa), (b, ba)])
+    plan = plan_of(h)
+    whats = [p[1] for p in plan]
+    if expect_res:
+        assert len(plan) == 1 and "res" in whats[0] and "relu" in whats[0], plan
+    else:
+        assert not any("res" in wt for wt in whats), plan
+        conv_item = [pl for pl in plan if pl[1].startswith("conv+bias")]
+        assert len(conv_item) == 1 and conv_item[0][2] == [0, 1, 2], plan  # the join (operators 3, 4) stays outside the conv launch
