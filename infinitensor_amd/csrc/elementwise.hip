@@ -249,21 +249,29 @@ static int binary_op_dispatch(infiniRocmRuntime_t rt, int op, const void *a, con
 // out[o, c, i] = act(round(a[o, c, i] + bias[c]) + res[o, c, i]) — the element-wise tail of a ResNet bottleneck,
 // Add(per-channel bias) -> Add(identity) [-> Relu], in one pass (used by the runtime's fusion when the bias cannot go
 // into the conv epilogue). The intermediate is rounded to T exactly like the unfused chain: bit-identical results.
-template <typename T, int VEC>
-__global__ __launch_bounds__(256) void bias_residual_kernel(const T *__restrict__ a, const T *__restrict__ bias,
-                                                            const T *__restrict__ res, T *__restrict__ out, long outer,
-                                                            int channels, long inner_v, int relu) {
+template <typename T, int VEC, bool ROW>
+__global__ __launch_bounds__(256) void bias_residual_kernel(const T *a, const T *__restrict__ bias, const T *res, T *out,
+                                                            long outer, int channels, long inner_v, int relu) {
+    // a / res / out carry no __restrict__: the caller may pass out == a or out == res (exactly in place; every thread
+    // reads its own vector before it writes it). ROW: inner == 1, the vector runs along the channels (a row bias).
     using A = typename Cvt<T>::acc_t;
-    const long total = outer * channels * inner_v;
+    const long total = ROW ? outer * (channels / VEC) : outer * channels * inner_v;
+    const int cv = channels / VEC;
     for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long)gridDim.x * 256) {
-        const int c = (int)((v / inner_v) % channels);
-        const A bv = Cvt<T>::load(bias + c);
+        VecT<T, VEC> bvec;
+        A bv = (A)0;
+        if constexpr (ROW)
+            bvec = *reinterpret_cast<const VecT<T, VEC> *>(bias + (long)(v % cv) * VEC);
+        else
+            bv = Cvt<T>::load(bias + (int)((v / inner_v) % channels));
         const VecT<T, VEC> av = *reinterpret_cast<const VecT<T, VEC> *>(a + v * VEC);
         const VecT<T, VEC> rv = *reinterpret_cast<const VecT<T, VEC> *>(res + v * VEC);
         VecT<T, VEC> o;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             T mid;
+            if constexpr (ROW)
+                bv = Cvt<T>::load(&bvec.v[j]);
             Cvt<T>::store(&mid, Cvt<T>::load(&av.v[j]) + bv);
             A x = Cvt<T>::load(&mid) + Cvt<T>::load(&rv.v[j]);
             if (relu)
@@ -279,17 +287,28 @@ static int bias_residual_launch(infiniRocmRuntime_t rt, const void *a, const voi
                                 int64_t outer, int64_t channels, int64_t inner, int relu) {
     constexpr int VMAX = 16 / (int)sizeof(T);
     int vec = VMAX;
+    const bool row = inner == 1 && channels > 1;
     auto ok = [&](int v) {
         const uintptr_t m = (uintptr_t)(v * sizeof(T)) - 1;
+        if (row)
+            return channels % v == 0 && !(((uintptr_t)a | (uintptr_t)res | (uintptr_t)out | (uintptr_t)bias) & m);
         return inner % v == 0 && !(((uintptr_t)a | (uintptr_t)res | (uintptr_t)out) & m);
     };
     while (vec > 1 && !ok(vec))
         vec >>= 1;
-    const long total = outer * channels * (inner / vec);
+    const long total = row ? outer * (channels / vec) : outer * channels * (inner / vec);
     const unsigned grid = capped_grid(total, rt->num_cu);
-#define BR(V)                                                                                             \
-    hipLaunchKernelGGL((bias_residual_kernel<T, V>), dim3(grid), dim3(256), 0, rt->stream, (const T *)a,  \
-                       (const T *)bias, (const T *)res, (T *)out, (long)outer, (int)channels, (long)(inner / V), relu)
+#define BR(V)                                                                                                     \
+    do {                                                                                                          \
+        if (row)                                                                                                  \
+            hipLaunchKernelGGL((bias_residual_kernel<T, V, true>), dim3(grid), dim3(256), 0, rt->stream,          \
+                               (const T *)a, (const T *)bias, (const T *)res, (T *)out, (long)outer, (int)channels, \
+                               (long)1, relu);                                                                    \
+        else                                                                                                      \
+            hipLaunchKernelGGL((bias_residual_kernel<T, V, false>), dim3(grid), dim3(256), 0, rt->stream,         \
+                               (const T *)a, (const T *)bias, (const T *)res, (T *)out, (long)outer, (int)channels, \
+                               (long)(inner / V), relu);                                                          \
+    } while (0)
     switch (vec) {
     case 8: if constexpr (VMAX >= 8) { BR(8); } break;
     case 4: if constexpr (VMAX >= 4) { BR(4); } break;

@@ -47,10 +47,25 @@ template <> struct Frag<false> {
 // ds_bpermute_b32 (dst lane L <- src lane addr[L] / 4) as opaque asm: hipcc then inserts no lgkmcnt(0) of its own before the first
 // use and the caller waits with a COUNT (wait_lgkm<N>: results of LDS instructions return in order), i.e. can keep the next
 // exchange in flight under the stores of this one. The result must not be read before that wait.
+// The counted form rests on two things the compiler does not know about: it must not touch the result registers (copy, coalesce,
+// spill) between the exchange and the wait, and it must issue no LDS / SMEM operation of its own in between. Verified (ISA
+// read + the bit-exact epilogue tests of tests/test_gpu_matmul.py / test_gpu_nn.py) for the ROCm 7.2 compiler only: any other
+// compiler — or -DIROCM_SAFE_BPERMUTE=1 — gets the builtin, whose waits the compiler manages itself (slower, always right).
+#if !defined(IROCM_SAFE_BPERMUTE)
+#if defined(__clang_major__) && __clang_major__ == 22 && defined(HIP_VERSION_MAJOR) && HIP_VERSION_MAJOR == 7 && HIP_VERSION_MINOR == 2
+#define IROCM_SAFE_BPERMUTE 0
+#else
+#define IROCM_SAFE_BPERMUTE 1
+#endif
+#endif
 __device__ __forceinline__ unsigned lds_bpermute(int addr, unsigned v) {
+#if IROCM_SAFE_BPERMUTE
+    return (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)v);
+#else
     unsigned r;
     asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(r) : "v"(addr), "v"(v));
     return r;
+#endif
 }
 template <int N> __device__ __forceinline__ void wait_lgkm() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");

@@ -1037,15 +1037,16 @@ int infini_rocm_bias_add_norm(infiniRocmRuntime_t rt, int dtype, int rms, const 
 #undef GO
     if (st != INFINI_ROCM_UNSUPPORTED)
         return st;
-    // outside the fused kernel's reach (long or unaligned rows): the operator chain, in place over y
-    const int64_t shape[2] = {outer, norm_size}, str[2] = {norm_size, 1}, rowstr[2] = {0, 1};
+    // outside the fused kernel's reach (long or unaligned rows): the operator chain, in place over y. y may BE a or b (the
+    // planner allows the row-wise in-place forms): with a row bias the two Adds run as ONE element-wise pass
+    // (round(round(a + pre) + b), every element read before it is written), never as y = a + pre followed by y + b, which
+    // would read an overwritten b when y aliases it.
     if (pre) {
-        st = infini_rocm_binary(rt, INFINI_BIN_ADD, dtype, a, pre, y, 2, shape, str, rowstr);
-        if (st != INFINI_ROCM_OK)
-            return st;
-        a = y;
+        st = infini_rocm_bias_residual(rt, dtype, a, pre, b, y, outer, norm_size, 1, 0);
+    } else {
+        const int64_t shape[2] = {outer, norm_size}, str[2] = {norm_size, 1};
+        st = infini_rocm_binary(rt, INFINI_BIN_ADD, dtype, a, b, y, 2, shape, str, str);
     }
-    st = infini_rocm_binary(rt, INFINI_BIN_ADD, dtype, a, b, y, 2, shape, str, str);
     if (st != INFINI_ROCM_OK)
         return st;
     return rms ? infini_rocm_rms_norm(rt, dtype, y, scale, y, outer, norm_size, eps)

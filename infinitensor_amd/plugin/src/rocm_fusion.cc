@@ -393,8 +393,11 @@ class FusionPlanner {
         return may != 0;
     }
     // value of a one-element constant (a tensor no operator writes)
+    // Weights only (the front-end's initializers): their values change through copyin / copy_inside alone, which drop the
+    // scalar cache, the plans and the captured graphs. A graph INPUT may be rewritten behind the runtime's back (an externally
+    // owned device pointer, a dlpack / torch write, another kernel): its value is never baked into a plan.
     bool scalarOf(const Tensor &t, double &v) const {
-        if (t->size() != 1 || !persistent(t) || !t->hasData())
+        if (t->size() != 1 || !persistent(t) || !t->isWeight() || !t->hasData())
             return false;
         const void *p = dataPtr(t);
         if (R) {
@@ -888,7 +891,7 @@ class FusionPlanner {
                 if (ch.ok && !ch.attn) {
                     if (ch.fwdTo) {
                         (*fwd)[ch.out.get()] = ch.fwdTo;
-                        lateReads.push_back({ch.slot, ch.fwdLastUse, ch.mm->getOutput()});
+                        lateReads.push_back({ch.head, ch.fwdLastUse, ch.mm->getOutput()});
                     }
                     std::vector<size_t> all = members;
                     all.insert(all.end(), ch.members.begin(), ch.members.end());
@@ -1038,7 +1041,10 @@ class FusionPlanner {
                     return false;
                 lastUse = std::max(lastUse, it->second);
             }
-            if (!survives(C, x.slot, lastUse + 1, x.members, true))
+            // from the MatMul's OWN position: the planner considers C free once its reader (the bias Add) ran, so a non-member
+            // operator between the head and the slot may have been given C's block — the fused kernel's write at the slot
+            // would clobber that operator's result (round-3 advisor finding)
+            if (!survives(C, i, lastUse + 1, x.members, true))
                 return false;
             x.fwdTo = C->getRawDataPtr<void *>();
             x.fwdLastUse = lastUse;
@@ -1212,7 +1218,7 @@ class FusionPlanner {
         noteLateReads(c.reads, c.slot);
         if (c.fwdTo) {
             (*fwd)[c.out.get()] = c.fwdTo;
-            lateReads.push_back({c.slot, c.fwdLastUse, c.mm->getOutput()});
+            lateReads.push_back({c.head, c.fwdLastUse, c.mm->getOutput()});
         }
         // (a forwarded chain writes the MatMul operator's own buffer, not its last member's)
         emit(c.slot, c.members, c.what, true, chainLaunch(c, nullptr, 0), c.fwdTo ? std::vector<size_t>{c.head} : std::vector<size_t>{});
@@ -1553,7 +1559,10 @@ class FusionPlanner {
         auto mm = as<MatmulObj>(ops[i]);
         const Tensor A = mm->getInputs(0), W = mm->getInputs(1), C = mm->getOutput();
         Operator ar = userOfType(C, OpType::AllReduceSum, i);
-        if (!ar || mm->numInputs() != 2 || mm->getTransA() || W->getRank() != 2 || tunedVariant(ops[i]) >= 0)
+        // Rank symmetry: whether this rule fires decides how many collectives (4 chunked / 1 whole-tensor) a rank issues on the
+        // shared communicator, so it may depend on the graph and on INFINI_ROCM_TP_OVERLAP only (which must be set alike on
+        // every rank) — never on per-process state such as PerfEngine records of a tune() only some ranks ran.
+        if (!ar || mm->numInputs() != 2 || mm->getTransA() || W->getRank() != 2)
             return false;
         const auto [b, m, nn, kk] = mm->getBMNK();
         const int64_t rows = (int64_t)b * m;
@@ -1717,7 +1726,11 @@ class FusionPlanner {
                 }
                 // nothing may land on y's block up to and including the last reader (a reader's own output too: a plain
                 // kernel does not know its input moved)
-                ok = ok && survives(y, c.slot, lastUse + 1, c.members, true);
+                // a reader's own output too: a plain kernel does not know its input moved), counted from the CONV's position: the
+                // planner treats y as free once the bias Add read it, so a non-member operator between the conv and the slot
+                // (another branch of an Inception- / SE-style graph) may own y's block, and the fused kernel — which writes y
+                // at the slot — would clobber its result (round-3 advisor finding)
+                ok = ok && survives(y, i, lastUse + 1, c.members, true);
                 if (ok)
                     fwdTo = y->getRawDataPtr<void *>();
                 else if (otherHazard || !bridgeX)
@@ -1726,7 +1739,7 @@ class FusionPlanner {
             noteLateReads(c.reads, c.slot);
             if (fwdTo) {
                 (*fwd)[c.last.get()] = fwdTo;
-                lateReads.push_back({c.slot, lastUse, conv->getOutput()}); // y's block stays in use until then
+                lateReads.push_back({i, lastUse, conv->getOutput()}); // y's block stays in use until then
             }
             const RocmRuntimeObj *r = R;
             const Operator op = ops[i];

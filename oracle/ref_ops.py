@@ -267,6 +267,35 @@ def conv2d(x: np.ndarray, w: np.ndarray, ph: int, pw: int, sh: int, sw: int, dh:
     return Y
 
 
+def conv2d_at(x: np.ndarray, w: np.ndarray, coords: np.ndarray, ph: int, pw: int, sh: int, sw: int, dh: int, dw: int) -> np.ndarray:
+    """conv2d above at sampled output positions only: coords [k, 4] = (n, f, oh, ow) -> [k] values, one C/g * R * S dot
+    product each in fp64 — the checker for full-size layers (batch 128) whose whole output the dense form cannot produce in
+    seconds. Index math as the reference's naive kernel (src/kernels/cpu/conv.cc:25-50: posH = h * sh - ph + r * dh,
+    out-of-range taps contribute zero; filter f reads channel group f / (F / g))."""
+    X = np.asarray(x)
+    W = np.asarray(w, dtype=np.float64)
+    n, c, h, wd = X.shape
+    f, cpg, r, s = W.shape
+    g = c // cpg
+    fpg = f // g
+    co = np.asarray(coords, dtype=np.int64)
+    ni, fi, oy, ox = co[:, 0], co[:, 1], co[:, 2], co[:, 3]
+    k = co.shape[0]
+    acc = np.zeros(k, dtype=np.float64)
+    cidx = (fi // fpg)[:, None] * cpg + np.arange(cpg)[None, :]  # [k, cpg]
+    for ir in range(r):
+        iy = oy * sh - ph + ir * dh
+        for is_ in range(s):
+            ix = ox * sw - pw + is_ * dw
+            ok = (iy >= 0) & (iy < h) & (ix >= 0) & (ix < wd)
+            if not ok.any():
+                continue
+            iyc, ixc = np.clip(iy, 0, h - 1), np.clip(ix, 0, wd - 1)
+            xv = X[ni[:, None], cidx, iyc[:, None], ixc[:, None]].astype(np.float64)  # [k, cpg]
+            acc += np.where(ok, np.einsum("kc,kc->k", xv, W[fi, :, ir, is_]), 0.0)
+    return acc
+
+
 # ------------------------------------------------------------------------------------------------
 # Pooling (reference: src/operators/pooling.cc:17-35 output size with ceil_mode; kernels
 # src/kernels/cuda/pooling.cc:6-95: MaxPool pads with -inf, AveragePool = COUNT_INCLUDE_PADDING

@@ -223,3 +223,27 @@ def test_residual_join_on_odd_planes_rides_only_in_a_pixel_slot_gemm(B, kernel, 
         assert not any("res" in wt for wt in whats), plan
         conv_item = [pl for pl in plan if pl[1].startswith("conv+bias")]
         assert len(conv_item) == 1 and conv_item[0][2] == [0, 1, 2], plan  # the join (operators 3, 4) stays outside the conv launch
+
+
+def test_forwarding_declines_when_another_branch_owns_the_convs_block(B):
+    """Round-3 advisor finding: buffer forwarding writes the Conv operator's OWN buffer at the chain's slot, but the memory
+    planner considers that buffer free once the bias Add has read it — another branch's operator between the Add and the
+    chain's last member may have been given the block (tests/_fwd_graph.py builds exactly that; the placement is verified
+    here through the CPU runtime's shared arena). The planner must not forward: the shorter chain conv + bias is planned."""
+    import _fwd_graph as G
+
+    h, t, feeds = G.build(B, B.cpu_runtime())
+
+    def lands_on(a, b):  # does writing tensor a change tensor b (same arena block)?
+        shape = t[a].shape()
+        t[a].copyin_numpy(np.zeros(shape, np.float16))
+        before = t[b].copyout_numpy().copy()
+        t[a].copyin_numpy(np.full(shape, 7.0, np.float16))
+        return float((before != t[b].copyout_numpy()).mean())
+
+    assert lands_on("y", "v") > 0.9, "scenario: Tanh's output was planned onto the conv's own output block"
+    assert lands_on("out", "x") > 0.4, "scenario: the chain's final output was planned onto the conv's input"
+    assert lands_on("t", "x") == 0 and lands_on("v", "x") == 0
+    plan = plan_of(h)
+    assert not any("forwarded" in what for _, what, _ in plan), plan
+    assert (7, "conv+bias", [6, 7]) in plan and (8, "op", [8]) in plan and (9, "op", [9]) in plan, plan

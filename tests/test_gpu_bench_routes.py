@@ -1,0 +1,220 @@
+"""The routes the BENCH graphs take, at the bench's own sizes, against the fp64 oracle (round-3 verdict, "do this" #1).
+
+The per-kernel parity tests force a variant at N <= 9; at batch 128 / 16384 rows the heuristics pick other tile widths and a
+workgroup walks 6-25 tiles. Here every distinct ResNet-50 layer runs at N = 128 through `ops.conv2d` with the HEURISTIC route
+(asserted against the route `profiles/r03_conv_layers*.txt` lists), with the epilogues the graph really uses (bias, ReLU,
+residual), and ~2000 sampled outputs per layer are compared with `R.conv2d_at` — one C * R * S dot product each in fp64
+(index math of src/kernels/cpu/conv.cc:25-50; comparator semantics of include/core/tensor.h:197-234 with the f16 tolerance of
+the per-kernel tests). The samples always contain image 0, image 127, the last pixel slot tile, the ragged plane ends and the
+first / last filter. BERT-base's launches (grouped q / k / v at 16384 rows, FFN1 + Gelu, bias_add_norm) and the Llama block's
+grouped gate / up launch are checked the same way on sampled rows against `R.matmul`."""
+import numpy as np
+import pytest
+import torch
+
+from infinitensor_amd import ops
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+
+# (C, H, F, R, stride, pad, route of the heuristic in profiles/r03_conv_layers.txt, epilogues the graph uses on this layer type)
+#   "br" bias + ReLU, "b" bias only (the down-sampling branch), "brr" bias + residual + ReLU (the bottleneck's join)
+LAYERS = [
+    (3, 224, 64, 7, 2, 3, "tap_shifted", ("br",)),
+    (64, 56, 64, 1, 1, 0, "tap_shifted", ("br",)),
+    (64, 56, 64, 3, 1, 1, "resident", ("br",)),
+    (64, 56, 256, 1, 1, 0, "pixel_gemm", ("b", "brr")),
+    (256, 56, 64, 1, 1, 0, "tap_shifted", ("br",)),
+    (256, 56, 128, 1, 1, 0, "pixel_gemm", ("br",)),
+    (128, 56, 128, 3, 2, 1, "tap_shifted", ("br",)),
+    (128, 28, 512, 1, 1, 0, "pixel_gemm", ("brr",)),
+    (256, 56, 512, 1, 2, 0, "pixel_gemm", ("b",)),
+    (512, 28, 128, 1, 1, 0, "pixel_gemm", ("br",)),
+    (128, 28, 128, 3, 1, 1, "tap_shifted", ("br",)),
+    (512, 28, 256, 1, 1, 0, "pixel_gemm", ("br",)),
+    (256, 28, 256, 3, 2, 1, "tap_shifted", ("br",)),
+    (256, 14, 1024, 1, 1, 0, "pixel_gemm", ("brr",)),
+    (512, 28, 1024, 1, 2, 0, "pixel_gemm", ("b",)),
+    (1024, 14, 256, 1, 1, 0, "pixel_gemm", ("br",)),
+    (256, 14, 256, 3, 1, 1, "tap_shifted", ("br",)),
+    (1024, 14, 512, 1, 1, 0, "pixel_gemm", ("br",)),
+    (512, 14, 512, 3, 2, 1, "tap_shifted", ("br",)),
+    (512, 7, 2048, 1, 1, 0, "pixel_gemm", ("brr",)),
+    (1024, 14, 2048, 1, 2, 0, "pixel_gemm", ("b",)),
+    (2048, 7, 512, 1, 1, 0, "pixel_gemm", ("br",)),
+    (512, 7, 512, 3, 1, 1, "tap_shifted", ("br",)),
+]
+BATCH = 128
+
+
+def sample_coords(rng, n, f, oh, ow, count=2000):
+    """Random output positions plus the corners a wrong last tile / last image / ragged plane end would hit."""
+    co = np.stack([rng.integers(0, n, count), rng.integers(0, f, count), rng.integers(0, oh, count), rng.integers(0, ow, count)], 1)
+    edge = []
+    for img in (0, n - 1, n // 2):
+        for fi in (0, f - 1, f // 2, min(f - 1, 127), min(f - 1, 128)):
+            for oy, ox in ((0, 0), (oh - 1, ow - 1), (oh - 1, 0), (0, ow - 1), (oh // 2, ow - 1), (oh - 1, ow - 2 if ow > 1 else 0)):
+                edge.append((img, fi, oy, ox))
+    # the last pixel-slot tile (slots = img * HWp + pix: the highest slots are the last image's last rows), every filter block
+    for fi in range(0, f, max(1, f // 16)):
+        for px in range(max(0, oh * ow - 24), oh * ow):
+            edge.append((n - 1, fi, px // ow, px % ow))
+    return np.concatenate([co, np.array(edge, dtype=np.int64)], 0)
+
+
+@pytest.mark.parametrize("layer", LAYERS, ids=lambda l: f"C{l[0]}_{l[1]}x{l[1]}_F{l[2]}_{l[3]}x{l[3]}s{l[4]}")
+def test_resnet50_layer_at_batch_128_sampled_vs_oracle(rt, layer):
+    c, h, f, r, st, pad, route, epilogues = layer
+    g = torch.Generator(device="cuda").manual_seed(c * 131 + h * 7 + f + r)
+    # (64 spare elements behind the input, as in the plugin's arena: the pixel-slot GEMM reads up to 14 bytes past a ragged plane)
+    xbuf = torch.empty((BATCH * c * h * h + 64,), device="cuda", dtype=torch.float16)
+    x = xbuf[: BATCH * c * h * h].view(BATCH, c, h, h)
+    x.copy_(torch.randn((BATCH, c, h, h), device="cuda", generator=g))
+    w = (torch.randn((f, c, r, r), device="cuda", generator=g) / (c * r * r) ** 0.5).to(torch.float16)
+    b = torch.randn((f,), device="cuda", generator=g).to(torch.float16)
+    oh = (h + 2 * pad - r) // st + 1
+    xh, wh, bh = x.cpu().numpy(), w.cpu().numpy(), b.cpu().numpy().astype(np.float64)
+    rng = np.random.default_rng(c + h + f)
+    coords = sample_coords(rng, BATCH, f, oh, oh)
+    base = R.conv2d_at(xh, wh, coords, pad, pad, st, st, 1, 1)
+    ni, fi, oy, ox = (torch.from_numpy(coords[:, i]).cuda() for i in range(4))
+    for ep in epilogues:
+        res = torch.randn((BATCH, f, oh, oh), device="cuda", generator=g).to(torch.float16) if ep == "brr" else None
+        keep = res.clone() if res is not None else None
+        y = ops.conv2d(rt, x, w, pad, pad, st, st, bias=b, act=0 if ep == "b" else 1, residual=res)
+        assert ops.conv_last_route(rt) == route, (ep, ops.conv_last_route(rt))
+        rt.sync()
+        got = y[ni, fi, oy, ox].float().cpu().numpy().astype(np.float64)
+        want = base + bh[coords[:, 1]]
+        if res is not None:  # y = act(round(conv + bias) + res): the arithmetic of the reference's separate Conv / Add kernels
+            want = want.astype(np.float16).astype(np.float64) + res[ni, fi, oy, ox].float().cpu().numpy().astype(np.float64)
+            assert torch.equal(res, keep)
+        if ep != "b":
+            want = np.maximum(want, 0)
+        assert np.isfinite(got).all()
+        bad = ~np.isclose(got, want, rtol=3e-3, atol=3e-3)
+        assert not bad.any(), (ep, int(bad.sum()), coords[bad][:5].tolist(), got[bad][:5], want[bad][:5])
+        # and nothing outside the samples is garbage: the whole tensor is finite and of plausible scale
+        assert bool(torch.isfinite(y).all()) and float(y.float().abs().max()) < 64
+
+
+def _rows(rng, m, count=96):
+    """Sampled rows of a [m, n] result: random ones plus the first / last rows and the rows around every 256-row tile edge of the
+    last tiles a persistent workgroup walks."""
+    fixed = [0, 1, 255, 256, m - 257, m - 256, m - 255, m - 2, m - 1, m // 2, m // 2 + 1]
+    return np.unique(np.concatenate([rng.integers(0, m, count), np.array([v for v in fixed if 0 <= v < m])]))
+
+
+def test_bert_grouped_qkv_launch_at_16384_rows_vs_oracle(rt):
+    """BERT-base bs32 seq512: the three head-split projections of one activation as ONE grouped launch (m = 16384, n = k = 768,
+    row biases), checked on sampled rows of all three members against R.matmul."""
+    m, n, k = 32 * 512, 768, 768
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a = torch.randn((m, k), device="cuda", generator=g).to(torch.float16)
+    wall = (torch.randn((3, k, n), device="cuda", generator=g) * 0.03).to(torch.float16)
+    ball = torch.randn((3, n), device="cuda", generator=g).to(torch.float16)
+    oall = torch.empty((3, m, n), device="cuda", dtype=torch.float16)
+    ops.matmul_grouped(rt, a, [wall[j] for j in range(3)], [oall[j] for j in range(3)], [ball[j] for j in range(3)])
+    rt.sync()
+    rows = _rows(np.random.default_rng(0), m)
+    ah = a[torch.from_numpy(rows).cuda()].float().cpu().numpy().astype(np.float64)
+    for j in range(3):
+        want = R.matmul(ah, wall[j].float().cpu().numpy().astype(np.float64), ball[j].float().cpu().numpy().astype(np.float64))
+        got = oall[j][torch.from_numpy(rows).cuda()].float().cpu().numpy().astype(np.float64)
+        assert np.allclose(got, want, rtol=3e-3, atol=3e-3), (j, np.abs(got - want).max())
+    assert bool(torch.isfinite(oall).all())
+
+
+def test_bert_ffn1_gelu_and_ffn2_at_16384_rows_vs_oracle(rt):
+    """FFN1 (16384 x 3072 x 768, bias, Gelu in the GEMM epilogue: three 256-column tiles per workgroup) and FFN2 (16384 x 768 x
+    3072, bias, 192-column tiles) at the bench's size, sampled rows against the oracle's matmul + Gelu (0.5 x (1 + erf(x / sqrt 2)),
+    src/kernels/cpu/unary.cc)."""
+    m, hid, ffn = 32 * 512, 768, 3072
+    g = torch.Generator(device="cuda").manual_seed(4)
+    a = torch.randn((m, hid), device="cuda", generator=g).to(torch.float16)
+    w1 = (torch.randn((hid, ffn), device="cuda", generator=g) * 0.05).to(torch.float16)
+    b1 = torch.randn((ffn,), device="cuda", generator=g).to(torch.float16)
+    w2 = (torch.randn((ffn, hid), device="cuda", generator=g) * 0.03).to(torch.float16)
+    b2 = torch.randn((hid,), device="cuda", generator=g).to(torch.float16)
+    h1 = ops.matmul(rt, a, w1, b1, act=5)
+    y = ops.matmul(rt, h1, w2, b2)
+    rt.sync()
+    rows = _rows(np.random.default_rng(1), m)
+    ridx = torch.from_numpy(rows).cuda()
+    f64 = lambda t: t.float().cpu().numpy().astype(np.float64)
+    want1 = R.unary("gelu", R.matmul(f64(a[ridx]), f64(w1), f64(b1)))
+    got1 = f64(h1[ridx])
+    assert np.allclose(got1, want1, rtol=3e-3, atol=3e-3), np.abs(got1 - want1).max()
+    want2 = R.matmul(got1, f64(w2), f64(b2))  # FFN2 on the f16 values FFN1 really stored
+    got2 = f64(y[ridx])
+    assert np.allclose(got2, want2, rtol=3e-3, atol=6e-3), np.abs(got2 - want2).max()
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.float32])
+def test_bert_bias_add_norm_at_16384_rows_vs_oracle(rt, dt):
+    """bias_add_norm on [16384, 768] (MatMul -> Add(bias) -> Add(residual) -> LayerNorm of the front-end's form), every row
+    against the oracle's LayerNorm of the rounded sums (ONNX LayerNormalization-17, eps 1e-12 like HF BERT)."""
+    m, n = 32 * 512, 768
+    g = torch.Generator(device="cuda").manual_seed(6)
+    a = torch.randn((m, n), device="cuda", generator=g).to(dt)
+    b = torch.randn((m, n), device="cuda", generator=g).to(dt)
+    pre = torch.randn((n,), device="cuda", generator=g).to(dt)
+    gam = torch.randn((n,), device="cuda", generator=g).to(dt)
+    bet = torch.randn((n,), device="cuda", generator=g).to(dt)
+    y = ops.add_layer_norm(rt, a, b, gam, bet, 1e-12, False, pre=pre)
+    rt.sync()
+    f64 = lambda t: t.float().cpu().numpy().astype(np.float64)
+    name = "f16" if dt == torch.float16 else "f32"
+    s = R.round_to(R.round_to(f64(a) + f64(pre), name) + f64(b), name)
+    want = R.layer_norm(s, f64(gam), f64(bet), 1e-12, -1)
+    tol = 3e-3 if dt == torch.float16 else 1e-4
+    got = f64(y)
+    assert np.allclose(got, want, rtol=tol, atol=tol), np.abs(got - want).max()
+
+
+def test_llama_grouped_gate_up_launch_vs_oracle(rt):
+    """The Llama-7B block's gate / up projections (2048 x 11008 x 4096 each) as one grouped launch, then silu_mul and the down
+    projection (2048 x 4096 x 11008: split-K or 128-column tiles by the cost model) — sampled rows against R.matmul."""
+    m, hid, ffn = 2048, 4096, 11008
+    g = torch.Generator(device="cuda").manual_seed(8)
+    a = torch.randn((m, hid), device="cuda", generator=g).to(torch.float16)
+    wall = (torch.randn((2, hid, ffn), device="cuda", generator=g) * 0.02).to(torch.float16)
+    oall = torch.empty((2, m, ffn), device="cuda", dtype=torch.float16)
+    wd = (torch.randn((ffn, hid), device="cuda", generator=g) * 0.02).to(torch.float16)
+    ops.matmul_grouped(rt, a, [wall[0], wall[1]], [oall[0], oall[1]])
+    act = ops.silu_mul(rt, oall[0], oall[1])
+    y = ops.matmul(rt, act, wd)
+    rt.sync()
+    rows = _rows(np.random.default_rng(2), m, 48)
+    ridx = torch.from_numpy(rows).cuda()
+    f64 = lambda t: t.float().cpu().numpy().astype(np.float64)
+    ah = f64(a[ridx])
+    for j in range(2):
+        want = R.matmul(ah, f64(wall[j]))
+        got = f64(oall[j][ridx])
+        assert np.allclose(got, want, rtol=3e-3, atol=3e-3), (j, np.abs(got - want).max())
+    gate, up = f64(oall[0][ridx]), f64(oall[1][ridx])
+    want_act = R.round_to(R.round_to(gate / (1 + np.exp(-gate)), "f16") * up, "f16")
+    got_act = f64(act[ridx])
+    assert np.allclose(got_act, want_act, rtol=2e-3, atol=2e-3), np.abs(got_act - want_act).max()
+    want_y = R.matmul(got_act, f64(wd))
+    got_y = f64(y[ridx])
+    assert np.allclose(got_y, want_y, rtol=3e-3, atol=3e-3), np.abs(got_y - want_y).max()
+
+
+def test_headline_gemm_rows_vs_oracle(rt):
+    """BASELINE configs[1] itself: bf16 4096^3 NN through infini_rocm_matmul (the persistent 256 x 256 kernel, one tile per CU),
+    sampled rows incl. the first / last of every 256-row tile band against the fp64 product of the rounded inputs."""
+    n = 4096
+    g = torch.Generator(device="cuda").manual_seed(0)
+    a = torch.randn((n, n), device="cuda", generator=g).to(torch.bfloat16)
+    b = torch.randn((n, n), device="cuda", generator=g).to(torch.bfloat16)
+    c = ops.matmul(rt, a, b)
+    rt.sync()
+    rows = np.unique(np.concatenate([np.arange(0, n, 256), np.arange(255, n, 256), np.random.default_rng(3).integers(0, n, 24)]))
+    ridx = torch.from_numpy(rows).cuda()
+    f64 = lambda t: t.float().cpu().numpy().astype(np.float64)
+    want = f64(a[ridx]) @ f64(b)
+    got = f64(c[ridx])
+    # bf16 output: one storage ulp (2^-8 relative) on top of fp32 accumulation over k = 4096 products of N(0,1) values
+    assert np.allclose(got, want, rtol=2.0 ** -7, atol=0.35), np.abs(got - want).max()

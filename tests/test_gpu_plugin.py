@@ -1482,3 +1482,26 @@ def test_output_forwarding_when_the_planned_buffer_sits_on_an_operand(B, rocm, f
     want = np.abs(1 / (1 + np.exp(-(r @ w + b)))) if form == "matmul" else None
     if want is not None:
         assert np.allclose(got[True].reshape(want.shape), want, rtol=4e-3, atol=4e-3)
+
+
+def test_forwarding_declined_when_another_branch_owns_the_convs_block(B, rocm):
+    """tests/_fwd_graph.py on the device: another branch's Tanh was planned onto the Conv operator's own output block and is
+    read after the chain's slot (round-3 advisor finding). With forwarding from the chain's slot only, the fused kernel
+    clobbered it; the result must equal the oracle and the per-operator run."""
+    import _fwd_graph as G
+
+    want = G.oracle(G.build(B, B.cpu_runtime())[2])
+    res = {}
+    for on in (True, False):
+        rocm.set_fusion(on)
+        try:
+            h, t, feeds = G.build(B, rocm)
+            for k, a in feeds.items():
+                put(t[k], a)
+            assert not any("forwarded" in p for p in h.rocm_fusion_plan()) or not on
+            h.run()
+            res[on] = get(t["f2"]).astype(np.float64)
+        finally:
+            rocm.set_fusion(True)
+    assert np.allclose(res[True], want, rtol=4e-3, atol=4e-3), np.abs(res[True] - want).max()
+    assert np.allclose(res[True], res[False], rtol=2e-3, atol=2e-3)

@@ -199,6 +199,31 @@ def test_bias_add_norm_matches_the_chain(rt, shape, rms, dt):
     assert (f != c).float().mean().item() < 1e-3
 
 
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("shape", [(6, 4096), (5, 33), (3, 8200), (64, 768)])
+@pytest.mark.parametrize("alias", ["b", "a"])
+@pytest.mark.parametrize("with_pre", [True, False])
+def test_bias_add_norm_in_place_over_an_operand(rt, shape, dt, alias, with_pre):
+    """The planner lets the norm's output sit on the residual b (or on a): `ops.add_layer_norm(..., out=b, pre=...)` must
+    give the out-of-place result bit for bit — on the fused kernel AND on the fallback for rows beyond 4 KiB / unaligned rows
+    (round-3 advisor finding: the fallback stored y = a + pre over b and then added the overwritten b)."""
+    rng = np.random.default_rng(29)
+    a, b = (dev(rng.standard_normal(shape).astype(np.float32), TD[dt]) for _ in range(2))
+    pre = dev(rng.standard_normal(shape[-1:]).astype(np.float32), TD[dt]) if with_pre else None
+    g = dev(rng.standard_normal(shape[-1:]).astype(np.float32), TD[dt])
+    be = dev(rng.standard_normal(shape[-1:]).astype(np.float32), TD[dt])
+    want = ops.add_layer_norm(rt, a, b, g, be, 1e-5, False, pre=pre)
+    s = ops.binary(rt, "add", ops.binary(rt, "add", a, pre), b) if with_pre else ops.binary(rt, "add", a, b)
+    chain = ops.layer_norm(rt, s, g, be, 1e-5, -1)
+    ulp = {"f32": 2.0 ** -22, "f16": 2.0 ** -10, "bf16": 2.0 ** -7}[dt]
+    assert torch.allclose(want.float(), chain.float(), rtol=ulp, atol=ulp * 1e-2)
+    tgt = (b if alias == "b" else a).clone()
+    args = (a, tgt) if alias == "b" else (tgt, b)
+    got = ops.add_layer_norm(rt, *args, g, be, 1e-5, False, out=tgt, pre=pre)
+    rt.sync()
+    assert got.data_ptr() == tgt.data_ptr() and torch.equal(got, want)
+
+
 @pytest.mark.parametrize("dt", ["f16", "f32"])
 def test_softmax_bert_full_size_properties(rt, dt):
     """BASELINE config 4's softmax at its full size ([32, 12, 512, 512] = 196 608 rows of 512) through size-independent

@@ -43,6 +43,23 @@ def test_conv_vs_reference_native_cpu(ref_backend):
         assert np.allclose(got, want, rtol=1e-4, atol=1e-4)
 
 
+def test_sampled_conv_oracle_equals_the_dense_one():
+    """R.conv2d_at (the checker of the full-size, batch-128 layers) against R.conv2d at EVERY output position of small
+    cases incl. groups, strides, dilation, asymmetric padding — and the reference's golden vector test_cuda_conv.cc:53."""
+    rng = np.random.default_rng(1)
+    for (n, c, h, w, f, cpg, r, s, ph, pw, sh, sw, dh, dw) in [
+        (2, 4, 9, 8, 6, 4, 3, 3, 1, 1, 1, 1, 1, 1), (1, 6, 10, 10, 4, 3, 3, 2, 2, 0, 2, 1, 1, 2),
+        (2, 3, 12, 12, 8, 3, 7, 7, 3, 3, 2, 2, 1, 1), (1, 8, 5, 5, 8, 8, 1, 1, 0, 0, 1, 1, 1, 1), (3, 8, 7, 7, 4, 2, 3, 3, 1, 1, 2, 2, 1, 1)]:
+        x = rng.standard_normal((n, c, h, w))
+        wt = rng.standard_normal((f, cpg, r, s))
+        dense = R.conv2d(x, wt, ph, pw, sh, sw, dh, dw)
+        coords = np.stack(np.meshgrid(*[np.arange(d) for d in dense.shape], indexing="ij"), -1).reshape(-1, 4)
+        assert np.allclose(R.conv2d_at(x, wt, coords, ph, pw, sh, sw, dh, dw), dense.ravel(), rtol=1e-12, atol=1e-12)
+    x, wt = R.incremental((1, 3, 4, 4)), R.incremental((2, 3, 3, 3))
+    coords = np.stack(np.meshgrid(*[np.arange(d) for d in (1, 2, 2, 2)], indexing="ij"), -1).reshape(-1, 4)
+    assert eq(R.conv2d_at(x, wt, coords, 1, 1, 2, 1, 1, 2), kat(CU + "test_cuda_conv.cc", 53, "float"))
+
+
 # Reduce: test_cuda_reduce.cc:42-75
 RF = CU + "test_cuda_reduce.cc"
 
