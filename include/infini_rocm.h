@@ -161,8 +161,9 @@ int infini_rocm_graph_destroy(infiniRocmGraph_t graph);
 /*   dtype F32: exact-f32 MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate.                       */
 /*   dtype F16 / BF16: v_mfma_f32_16x16x32_{f16,bf16}, fp32 accumulate, one rounding on store.  */
 /*   act: 0 none, 1 relu, 2 sigmoid, 3 tanh (reference ActType, include/core/common.h), 4 gelu  */
-/*   (erf form, erff), 5 gelu with erf by Abramowitz-Stegun 7.1.26 (abs error 1.5e-7; what the  */
-/*   runtime's MatMul -> Gelu fusion uses for f16 / bf16 outputs); the                          */
+/*   (erf form, erff), 5 gelu for 16-bit outputs: erf by a clamped odd polynomial, no            */
+/*   transcendentals, abs error < 2^-12 (what the runtime's MatMul -> Gelu fusion uses for f16  */
+/*   / bf16 outputs; an fp32 caller wants 4); the                                               */
 /*   reference CUDA kernel ignores it — the plugin passes 0 to stay op-for-op identical).       */
 /* ------------------------------------------------------------------------------------------ */
 int infini_rocm_matmul(infiniRocmRuntime_t rt, int dtype, const void *a, const void *b,
@@ -518,6 +519,20 @@ int infini_rocm_comm_init(infiniRocmRuntime_t rt, const char *name, int world_si
 int infini_rocm_comm_unique_id(void *buf, size_t *nbytes);
 int infini_rocm_comm_init_id(infiniRocmRuntime_t rt, const void *unique_id, size_t nbytes,
                              int world_size, int rank);
+/* The hand-written one-hop transport (csrc/comm_direct.hip): collectives as HIP kernels pushing into IPC-mapped, uncached
+ * peer buffers with flag signalling — the fully connected xGMI mesh of one MI355X node needs no ring and no RCCL
+ * (reference counterpart: the same NcclCommunicatorObj / *NCCL kernels as above). Ranks may share a device, which RCCL
+ * refuses: the reference's multi-rank tests then run on a one-GPU box. File rendezvous ./<name>_xgmi_<rank>.bin in the cwd;
+ * every process needs HSA_ENABLE_IPC_MODE_LEGACY=0. world_size <= 8. infini_rocm_comm_init does the same when the
+ * environment holds INFINI_ROCM_COMM=direct (how the plugin's init_comm selects it). Settings (equal on all ranks):
+ * INFINI_ROCM_DIRECT_CAP_MB (8: bytes per box slot; a message of more than world x cap goes in pieces),
+ * INFINI_ROCM_DIRECT_TIMEOUT_S (20: a kernel gives up waiting for a peer, sets the error word and terminates — it never
+ * hangs the GPU; infini_rocm_comm_check reports it). */
+int infini_rocm_comm_init_direct(infiniRocmRuntime_t rt, const char *name, int world_size, int rank);
+/* Which transport the collectives use when both are initialised: 0 RCCL (default), 1 the direct transport. */
+int infini_rocm_comm_set_algo(infiniRocmRuntime_t rt, int algo);
+/* Blocking (one 4-byte device read): INFINI_ROCM_RCCL_ERROR when a direct-transport kernel ran into its time limit. */
+int infini_rocm_comm_check(infiniRocmRuntime_t rt);
 int infini_rocm_comm_destroy(infiniRocmRuntime_t rt);
 int infini_rocm_comm_info(infiniRocmRuntime_t rt, int *world_size, int *rank);
 /* op: 0 sum, 1 prod, 2 min, 3 max, 4 avg; count in elements; in-place allowed (x == y). */

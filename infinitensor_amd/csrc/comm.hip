@@ -20,6 +20,7 @@
 #include "common.h"
 
 #include <chrono>
+#include <cstdlib>
 #include <fstream>
 #include <rccl/rccl.h>
 #include <sys/stat.h>
@@ -96,6 +97,13 @@ template <typename T> __global__ __launch_bounds__(256) void sum_slabs_kernel(co
     }
 }
 
+// the hand-written transport serves the call when it is the only one initialised or was selected (comm_set_algo)
+static bool use_direct(const infiniRocmRuntime *rt) { return rt->dcomm && (rt->comm_algo == 1 || !rt->comm); }
+static bool direct_wanted_by_env() {
+    const char *e = std::getenv("INFINI_ROCM_COMM");
+    return e && std::string(e) == "direct";
+}
+
 } // namespace irocm
 
 using namespace irocm;
@@ -128,6 +136,8 @@ int infini_rocm_comm_init_id(infiniRocmRuntime_t rt, const void *unique_id, size
 int infini_rocm_comm_init(infiniRocmRuntime_t rt, const char *name, int world_size, int rank) {
     IROCM_CHECK_ARG(rt && name, "NULL argument");
     IROCM_CHECK_ARG(world_size >= 1 && rank >= 0 && rank < world_size, "bad world/rank %d/%d", world_size, rank);
+    if (direct_wanted_by_env()) // INFINI_ROCM_COMM=direct: the hand-written IPC / xGMI transport instead of RCCL
+        return direct_init(rt, name, world_size, rank);
     const std::string path = std::string("./") + name + "_nccl_id.bin";
     ncclUniqueId id;
     if (rank == 0) {
@@ -156,8 +166,39 @@ int infini_rocm_comm_init(infiniRocmRuntime_t rt, const char *name, int world_si
     return st;
 }
 
+// The hand-written transport next to (or instead of) RCCL: same rendezvous scheme, files ./<name>_xgmi_<rank>.bin.
+int infini_rocm_comm_init_direct(infiniRocmRuntime_t rt, const char *name, int world_size, int rank) {
+    IROCM_CHECK_ARG(rt && name, "NULL argument");
+    IROCM_CHECK_ARG(world_size >= 1 && rank >= 0 && rank < world_size, "bad world/rank %d/%d", world_size, rank);
+    IROCM_CHECK_ARG(!rt->comm || (rt->comm_world == world_size && rt->comm_rank == rank),
+                    "direct transport: world/rank %d/%d differ from the RCCL communicator's %d/%d", world_size, rank, rt->comm_world,
+                    rt->comm_rank);
+    return direct_init(rt, name, world_size, rank);
+}
+
+int infini_rocm_comm_set_algo(infiniRocmRuntime_t rt, int algo) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(algo == 0 || algo == 1, "comm_set_algo: 0 (RCCL when initialised) or 1 (direct)");
+    IROCM_CHECK_ARG(algo == 0 || rt->dcomm, "comm_set_algo: the direct transport is not initialised (infini_rocm_comm_init_direct)");
+    rt->comm_algo = algo;
+    return INFINI_ROCM_OK;
+}
+
+int infini_rocm_comm_check(infiniRocmRuntime_t rt) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    return direct_check(rt);
+}
+
 int infini_rocm_comm_destroy(infiniRocmRuntime_t rt) {
     IROCM_CHECK_ARG(rt, "NULL runtime");
+    if (rt->dcomm) {
+        (void)direct_destroy(rt);
+        rt->comm_algo = 0;
+        if (!rt->comm) {
+            rt->comm_world = 1;
+            rt->comm_rank = 0;
+        }
+    }
     if (rt->comm) {
         ncclComm_t c = (ncclComm_t)rt->comm;
         (void)hipStreamSynchronize(rt->stream);
@@ -171,7 +212,7 @@ int infini_rocm_comm_destroy(infiniRocmRuntime_t rt) {
 
 int infini_rocm_comm_info(infiniRocmRuntime_t rt, int *world_size, int *rank) {
     IROCM_CHECK_ARG(rt && world_size && rank, "NULL argument");
-    IROCM_CHECK_ARG(rt->comm, "communicator not initialised");
+    IROCM_CHECK_ARG(rt->comm || rt->dcomm, "communicator not initialised");
     *world_size = rt->comm_world;
     *rank = rt->comm_rank;
     return INFINI_ROCM_OK;
@@ -180,9 +221,15 @@ int infini_rocm_comm_info(infiniRocmRuntime_t rt, int *world_size, int *rank) {
 // op: 0 sum, 1 prod, 2 min, 3 max, 4 avg (reference: AllReduce{Sum,Prod,Min,Max,Avg})
 int infini_rocm_all_reduce(infiniRocmRuntime_t rt, int op, int dtype, const void *x, void *y, int64_t count) {
     IROCM_CHECK_ARG(rt, "NULL runtime");
-    IROCM_CHECK_ARG(rt->comm, "all_reduce: communicator not initialised (call init_comm)");
+    IROCM_CHECK_ARG(rt->comm || rt->dcomm, "all_reduce: communicator not initialised (call init_comm)");
     static const ncclRedOp_t ops[] = {ncclSum, ncclProd, ncclMin, ncclMax, ncclAvg};
     IROCM_CHECK_ARG(op >= 0 && op <= 4, "all_reduce: bad op %d", op);
+    if (use_direct(rt)) {
+        if (count == 0)
+            return INFINI_ROCM_OK;
+        IROCM_CHECK_ARG(x && y && count > 0, "all_reduce: bad buffer");
+        return direct_all_reduce(rt, op, dtype, x, y, count, rt->stream);
+    }
     ncclDataType_t t;
     IROCM_CHECK_ARG(nccl_type(dtype, &t), "all_reduce: unsupported dtype %s", dtype_name(dtype));
     if (count == 0)
@@ -199,7 +246,7 @@ int infini_rocm_all_reduce(infiniRocmRuntime_t rt, int op, int dtype, const void
 // (reference: all_reduce.cc:10-33). Collectives of one communicator execute in issue order on every rank.
 int infini_rocm_all_reduce_async(infiniRocmRuntime_t rt, int op, int dtype, const void *x, void *y, int64_t count) {
     IROCM_CHECK_ARG(rt, "NULL runtime");
-    IROCM_CHECK_ARG(rt->comm, "all_reduce: communicator not initialised (call init_comm)");
+    IROCM_CHECK_ARG(rt->comm || rt->dcomm, "all_reduce: communicator not initialised (call init_comm)");
     static const ncclRedOp_t ops[] = {ncclSum, ncclProd, ncclMin, ncclMax, ncclAvg};
     IROCM_CHECK_ARG(op >= 0 && op <= 4, "all_reduce: bad op %d", op);
     ncclDataType_t t;
@@ -213,7 +260,13 @@ int infini_rocm_all_reduce_async(infiniRocmRuntime_t rt, int op, int dtype, cons
     st = stream_fork(rt, rt->stream, rt->comm_stream);
     if (st != INFINI_ROCM_OK)
         return st;
-    IROCM_NCCL(ncclAllReduce(x, y, (size_t)count, t, ops[op], (ncclComm_t)rt->comm, rt->comm_stream));
+    if (use_direct(rt)) {
+        st = direct_all_reduce(rt, op, dtype, x, y, count, rt->comm_stream);
+        if (st != INFINI_ROCM_OK)
+            return st;
+    } else {
+        IROCM_NCCL(ncclAllReduce(x, y, (size_t)count, t, ops[op], (ncclComm_t)rt->comm, rt->comm_stream));
+    }
     ++rt->comm_pending;
     return INFINI_ROCM_OK;
 }
@@ -235,12 +288,14 @@ int infini_rocm_comm_join(infiniRocmRuntime_t rt) {
 // runtime workspace. Sum only.
 int infini_rocm_reduce_scatter(infiniRocmRuntime_t rt, int dtype, const void *x, void *y, int64_t count, int direct) {
     IROCM_CHECK_ARG(rt, "NULL runtime");
-    IROCM_CHECK_ARG(rt->comm, "reduce_scatter: communicator not initialised (call init_comm)");
+    IROCM_CHECK_ARG(rt->comm || rt->dcomm, "reduce_scatter: communicator not initialised (call init_comm)");
     ncclDataType_t t;
     IROCM_CHECK_ARG(nccl_type(dtype, &t), "reduce_scatter: unsupported dtype %s", dtype_name(dtype));
     if (count == 0)
         return INFINI_ROCM_OK;
     IROCM_CHECK_ARG(x && y && count > 0, "reduce_scatter: bad buffer");
+    if (use_direct(rt)) // the hand-written transport IS a one-hop exchange; `direct` has nothing left to choose
+        return direct_reduce_scatter(rt, dtype, x, y, count, rt->stream);
     const int world = rt->comm_world, rank = rt->comm_rank;
     if (!direct || world == 1 || !(dtype == INFINI_DT_F32 || dtype == INFINI_DT_F16 || dtype == INFINI_DT_BF16)) {
         IROCM_NCCL(ncclReduceScatter(x, y, (size_t)count, t, ncclSum, (ncclComm_t)rt->comm, rt->stream));
@@ -277,51 +332,59 @@ int infini_rocm_reduce_scatter(infiniRocmRuntime_t rt, int dtype, const void *x,
 // y holds world_size * count elements, rank r's contribution at y + r * count.
 int infini_rocm_all_gather(infiniRocmRuntime_t rt, int dtype, const void *x, void *y, int64_t count) {
     IROCM_CHECK_ARG(rt, "NULL runtime");
-    IROCM_CHECK_ARG(rt->comm, "all_gather: communicator not initialised (call init_comm)");
+    IROCM_CHECK_ARG(rt->comm || rt->dcomm, "all_gather: communicator not initialised (call init_comm)");
     ncclDataType_t t;
     IROCM_CHECK_ARG(nccl_type(dtype, &t), "all_gather: unsupported dtype %s", dtype_name(dtype));
     if (count == 0)
         return INFINI_ROCM_OK;
     IROCM_CHECK_ARG(x && y && count > 0, "all_gather: bad buffer");
+    if (use_direct(rt))
+        return direct_all_gather(rt, x, y, (size_t)count * dtype_size(dtype), rt->stream);
     IROCM_NCCL(ncclAllGather(x, y, (size_t)count, t, (ncclComm_t)rt->comm, rt->stream));
     return INFINI_ROCM_OK;
 }
 
 int infini_rocm_broadcast(infiniRocmRuntime_t rt, int dtype, const void *x, void *y, int64_t count, int root) {
     IROCM_CHECK_ARG(rt, "NULL runtime");
-    IROCM_CHECK_ARG(rt->comm, "broadcast: communicator not initialised (call init_comm)");
+    IROCM_CHECK_ARG(rt->comm || rt->dcomm, "broadcast: communicator not initialised (call init_comm)");
     ncclDataType_t t;
     IROCM_CHECK_ARG(nccl_type(dtype, &t), "broadcast: unsupported dtype %s", dtype_name(dtype));
     IROCM_CHECK_ARG(root >= 0 && root < rt->comm_world, "broadcast: bad root %d", root);
     if (count == 0)
         return INFINI_ROCM_OK;
     IROCM_CHECK_ARG(x && y && count > 0, "broadcast: bad buffer");
+    if (use_direct(rt))
+        return direct_broadcast(rt, x, y, (size_t)count * dtype_size(dtype), root, rt->stream);
     IROCM_NCCL(ncclBroadcast(x, y, (size_t)count, t, root, (ncclComm_t)rt->comm, rt->stream));
     return INFINI_ROCM_OK;
 }
 
 int infini_rocm_send(infiniRocmRuntime_t rt, int dtype, const void *x, int64_t count, int peer) {
     IROCM_CHECK_ARG(rt, "NULL runtime");
-    IROCM_CHECK_ARG(rt->comm, "send: communicator not initialised (call init_comm)");
+    IROCM_CHECK_ARG(rt->comm || rt->dcomm, "send: communicator not initialised (call init_comm)");
     ncclDataType_t t;
     IROCM_CHECK_ARG(nccl_type(dtype, &t), "send: unsupported dtype %s", dtype_name(dtype));
     IROCM_CHECK_ARG(peer >= 0 && peer < rt->comm_world && peer != rt->comm_rank, "send: bad peer %d", peer);
     if (count == 0)
         return INFINI_ROCM_OK;
     IROCM_CHECK_ARG(x && count > 0, "send: bad buffer");
+    if (use_direct(rt))
+        return direct_send(rt, x, (size_t)count * dtype_size(dtype), peer, rt->stream);
     IROCM_NCCL(ncclSend(x, (size_t)count, t, peer, (ncclComm_t)rt->comm, rt->stream));
     return INFINI_ROCM_OK;
 }
 
 int infini_rocm_recv(infiniRocmRuntime_t rt, int dtype, void *y, int64_t count, int peer) {
     IROCM_CHECK_ARG(rt, "NULL runtime");
-    IROCM_CHECK_ARG(rt->comm, "recv: communicator not initialised (call init_comm)");
+    IROCM_CHECK_ARG(rt->comm || rt->dcomm, "recv: communicator not initialised (call init_comm)");
     ncclDataType_t t;
     IROCM_CHECK_ARG(nccl_type(dtype, &t), "recv: unsupported dtype %s", dtype_name(dtype));
     IROCM_CHECK_ARG(peer >= 0 && peer < rt->comm_world && peer != rt->comm_rank, "recv: bad peer %d", peer);
     if (count == 0)
         return INFINI_ROCM_OK;
     IROCM_CHECK_ARG(y && count > 0, "recv: bad buffer");
+    if (use_direct(rt))
+        return direct_recv(rt, y, (size_t)count * dtype_size(dtype), peer, rt->stream);
     IROCM_NCCL(ncclRecv(y, (size_t)count, t, peer, (ncclComm_t)rt->comm, rt->stream));
     return INFINI_ROCM_OK;
 }

@@ -131,7 +131,9 @@ struct infiniRocmRuntime {
     hipStream_t side_stream = nullptr; // non-captured helper stream (packs weights while the main stream records)
     void *zeros = nullptr; // 256 zero bytes (K-tail source for the LDS-DMA GEMM staging)
     int num_cu = 256;
-    void *comm = nullptr; // rcclComm_t, owned by comm.cc
+    void *comm = nullptr; // rcclComm_t, owned by comm.hip
+    void *dcomm = nullptr; // irocm::DirectComm (the hand-written IPC / xGMI transport), owned by comm_direct.hip
+    int comm_algo = 0;     // 0: RCCL when it is initialised, else the direct transport; 1: the direct transport
     int comm_world = 1, comm_rank = 0;
     // overlapped collectives (comm.hip: *_async / comm_join): a second stream and a small ring of fork / join events
     hipStream_t comm_stream = nullptr;
@@ -153,6 +155,19 @@ int wcache_commit(infiniRocmRuntime *rt, hipStream_t stream);
 void wcache_forget(infiniRocmRuntime *rt, const void *packed);
 // drops every entry whose SOURCE overlaps [ptr, ptr + bytes); the packed buffers are retired, not freed
 void wcache_invalidate(infiniRocmRuntime *rt, const void *ptr, size_t bytes);
+} // namespace irocm
+
+namespace irocm {
+// the hand-written one-hop transport (comm_direct.hip); all on the given stream
+int direct_init(infiniRocmRuntime *rt, const char *name, int world, int rank);
+int direct_destroy(infiniRocmRuntime *rt);
+int direct_check(infiniRocmRuntime *rt);
+int direct_all_reduce(infiniRocmRuntime *rt, int op, int dtype, const void *x, void *y, int64_t count, hipStream_t st);
+int direct_reduce_scatter(infiniRocmRuntime *rt, int dtype, const void *x, void *y, int64_t count, hipStream_t st);
+int direct_all_gather(infiniRocmRuntime *rt, const void *x, void *y, size_t bytes, hipStream_t st);
+int direct_broadcast(infiniRocmRuntime *rt, const void *x, void *y, size_t bytes, int root, hipStream_t st);
+int direct_send(infiniRocmRuntime *rt, const void *x, size_t bytes, int peer, hipStream_t st);
+int direct_recv(infiniRocmRuntime *rt, void *y, size_t bytes, int peer, hipStream_t st);
 } // namespace irocm
 
 struct infiniRocmGraph {

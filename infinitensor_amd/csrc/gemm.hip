@@ -92,7 +92,7 @@ template <typename Tr> __global__ __launch_bounds__(256) void gemm_generic16(Gem
         constexpr int ACT = decltype(actc)::value;
         auto act1 = [&](float v) {
             if constexpr (ACT == 1) return v > 0.f ? v : 0.f;
-            else if constexpr (ACT == 5) return gelu_erf_as(v);
+            else if constexpr (ACT == 5) return gelu_poly(v);
             else if constexpr (ACT < 0) return apply_act(v, p.act);
             else return v;
         };
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void gemm_fast128(GemmArgs p) {
         constexpr int ACT = decltype(actc)::value;
         auto act1 = [&](float v) {
             if constexpr (ACT == 1) return v > 0.f ? v : 0.f;
-            else if constexpr (ACT == 5) return gelu_erf_as(v);
+            else if constexpr (ACT == 5) return gelu_poly(v);
             else if constexpr (ACT < 0) return apply_act(v, p.act);
             else return v;
         };

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         constexpr int ACT = decltype(actc)::value;
         auto act1 = [&](float v) {
             if constexpr (ACT == 1) return v > 0.f ? v : 0.f;
-            else if constexpr (ACT == 5) return gelu_erf_as(v);
+            else if constexpr (ACT == 5) return gelu_poly(v);
             else return v;
         };
         unsigned short *C = (unsigned short *)p.c + (long)ib * p.c_bs;

@@ -173,6 +173,30 @@ __global__ __launch_bounds__(256) void gather_kernel(const void *__restrict__ da
     }
 }
 
+// Rows of >= 16 vectors (an embedding lookup: 768 f16 = 96 x 16 B): one wave per gathered row, the index read once per row
+// (wave-uniform), no per-element division (gather_kernel above does three 64-bit ones per 16 bytes).
+template <typename I>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const void *__restrict__ data, const I *__restrict__ idx,
+                                                          void *__restrict__ out, long outer, long axis_dim, long n_idx,
+                                                          int inner /* 16-byte vectors per row */) {
+    using R = typename Raw<16>::t;
+    const R *src = (const R *)data;
+    R *dst = (R *)out;
+    const int lane = threadIdx.x & 63;
+    const long rows = outer * n_idx;
+    for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * 4) {
+        const long o = outer == 1 ? 0 : r / n_idx;
+        const long j = r - o * n_idx;
+        long k = (long)idx[j];
+        if (k < 0)
+            k += axis_dim; // ONNX negative index
+        const R *s = src + (o * axis_dim + k) * inner;
+        R *d = dst + r * inner;
+        for (int v = lane; v < inner; v += 64)
+            d[v] = s[v];
+    }
+}
+
 // ---- where -------------------------------------------------------------------------------------
 struct WhereArgs {
     int ndim;
@@ -431,6 +455,18 @@ int infini_rocm_gather(infiniRocmRuntime_t rt, int dtype, int index_dtype, const
             inner_w = inner / f;
             break;
         }
+    }
+    if (bytes == 16 && inner_w >= 16 && inner_w < (1l << 30)) {
+        long gr = ceil_div(outer * n_indices, 4);
+        if (gr > (long)rt->num_cu * 16) gr = (long)rt->num_cu * 16;
+        if (index_dtype == INFINI_DT_I64)
+            hipLaunchKernelGGL((gather_rows_kernel<int64_t>), dim3((unsigned)gr), dim3(256), 0, rt->stream, data, (const int64_t *)indices, y,
+                               (long)outer, (long)axis_dim, (long)n_indices, (int)inner_w);
+        else
+            hipLaunchKernelGGL((gather_rows_kernel<int32_t>), dim3((unsigned)gr), dim3(256), 0, rt->stream, data, (const int32_t *)indices, y,
+                               (long)outer, (long)axis_dim, (long)n_indices, (int)inner_w);
+        IROCM_LAUNCH_CHECK("gather_rows");
+        return INFINI_ROCM_OK;
     }
     const unsigned g = grid_for(outer * n_indices * inner_w, rt->num_cu);
 #define GO(B)                                                                                      \

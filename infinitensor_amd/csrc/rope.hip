@@ -8,8 +8,13 @@
 // 10000: rope.cc:25); the partner element is never read outside its head (the reference test relies on an
 // out-of-bounds read returning 0: test_cuda_rope.cc:17-31 uses dim_model 32 < dim_head 128 — a trailing partial
 // head is accepted here and its missing partner columns count as 0, which reproduces that test without the read).
-// One thread per (token, head, pair): one angle, one sincos, two outputs. fp32 math. HBM-bound:
-// 2 * numel * sizeof(T) bytes.
+// Two kernels. rope_rows_kernel (whole heads, 16-byte-aligned rows — every decoder shape): a workgroup takes TOK tokens at
+// a time; the angle of column pair c depends on (token, c) only, so its sine / cosine is computed ONCE per (token, c) —
+// TOK * half values per step, one per thread — parked in LDS and shared by all heads of the token (round 3 computed a
+// sincosf per (token, head, pair): 32 x the transcendental work at 32 heads, behind 2-byte loads and two 64-bit divisions per
+// element: 1.5 TB/s); the row then moves in 16-byte vectors, the low and the high half of a head by the same thread.
+// rope_kernel: the general form (a trailing partial head, odd alignments), one thread per (token, head, pair).
+// fp32 math. HBM-bound: 2 * numel * sizeof(T) bytes.
 #include "common.h"
 
 namespace irocm {
@@ -58,6 +63,61 @@ __global__ __launch_bounds__(256) void rope_kernel(const P *__restrict__ pos, co
     }
 }
 
+template <typename T, int N> struct alignas(sizeof(T) * N) RVec { T v[N]; };
+
+// TOK tokens per workgroup step; dim_model % dim_head == 0, half % VEC == 0, rows 16-byte aligned.
+template <typename T, typename P, int TOK>
+__global__ __launch_bounds__(256) void rope_rows_kernel(const P *__restrict__ pos, const T *__restrict__ x, T *__restrict__ y,
+                                                        int tokens, int dim_model, int dim_head, float neg2_log2theta_over_dh,
+                                                        int hs_seq) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    using V = RVec<T, VEC>;
+    extern __shared__ float sc[]; // [TOK][half] cos, then [TOK][half] sin
+    const int half = dim_head / 2, heads = dim_model / dim_head;
+    const int nv = half / VEC;            // vectors per half head
+    const int pairs = heads * nv;         // (lo, hi) vector pairs per token
+    float *cs_s = sc, *sn_s = sc + TOK * half;
+    for (int t0 = blockIdx.x * TOK; t0 < tokens; t0 += gridDim.x * TOK) {
+        for (int i = threadIdx.x; i < TOK * half; i += 256) {
+            const int tl = i / half, c = i - tl * half;
+            const int tok = t0 + tl;
+            float sn = 0.f, cs = 1.f;
+            if (tok < tokens) {
+                const float ang = (float)pos[tok] * exp2f((float)c * neg2_log2theta_over_dh);
+                sincosf(ang, &sn, &cs);
+            }
+            cs_s[i] = cs;
+            sn_s[i] = sn;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < TOK * pairs; i += 256) {
+            const int tl = i / pairs, pr = i - tl * pairs;
+            const int tok = t0 + tl;
+            if (tok >= tokens)
+                break;
+            const int head = pr / nv, v = pr - head * nv;
+            const long j = (long)tok * dim_model + head * dim_head + v * VEC;
+            const V lo = *reinterpret_cast<const V *>(x + j), hi = *reinterpret_cast<const V *>(x + j + half);
+            V olo, ohi;
+            const float *cp = cs_s + tl * half + v * VEC, *sp = sn_s + tl * half + v * VEC;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                const float a = RLd<T>::ld(&lo.v[q]), b = RLd<T>::ld(&hi.v[q]), cs = cp[q], sn = sp[q];
+                RLd<T>::st(&olo.v[q], a * cs - b * sn);
+                RLd<T>::st(&ohi.v[q], b * cs + a * sn);
+            }
+            long jo = j;
+            if (hs_seq) { // token (b, s), head h -> y[b][h][s][:]
+                const int bb = tok / hs_seq, ss = tok - bb * hs_seq;
+                jo = (((long)bb * heads + head) * hs_seq + ss) * dim_head + v * VEC;
+            }
+            *reinterpret_cast<V *>(y + jo) = olo;
+            *reinterpret_cast<V *>(y + jo + half) = ohi;
+        }
+        __syncthreads();
+    }
+}
+
 } // namespace irocm
 
 using namespace irocm;
@@ -81,6 +141,38 @@ extern "C" int infini_rocm_rope_headsplit(infiniRocmRuntime_t rt, int dtype, int
         return INFINI_ROCM_OK;
     IROCM_CHECK_ARG(pos && x && y, "rope: NULL tensor");
     const float k = -2.0f * log2f(theta) / (float)dim_head;
+    {
+        const size_t es = dtype_size(dtype);
+        const int vec = es ? (int)(16 / es) : 1;
+        const bool rows = es && dim_model % dim_head == 0 && (dim_head / 2) % vec == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 &&
+                          tokens < (1ll << 31) && dim_model < (1ll << 24) && dim_head <= 1024 &&
+                          (dtype == INFINI_DT_F32 || dtype == INFINI_DT_F16 || dtype == INFINI_DT_BF16) &&
+                          (pos_dtype == INFINI_DT_I32 || pos_dtype == INFINI_DT_U32 || pos_dtype == INFINI_DT_I64);
+        if (rows) {
+            constexpr int TOK = 4;
+            const size_t lds = (size_t)2 * TOK * (dim_head / 2) * sizeof(float);
+            long g = ceil_div(tokens, TOK);
+            if (g > (long)rt->num_cu * 8) g = (long)rt->num_cu * 8;
+#define GOR(T, P)                                                                                                    \
+    hipLaunchKernelGGL((rope_rows_kernel<T, P, TOK>), dim3((unsigned)g), dim3(256), lds, rt->stream, (const P *)pos, \
+                       (const T *)x, (T *)y, (int)tokens, (int)dim_model, (int)dim_head, k, (int)seq)
+#define GORP(T)                                                                                                      \
+    switch (pos_dtype) {                                                                                             \
+    case INFINI_DT_I32: GOR(T, int32_t); break;                                                                      \
+    case INFINI_DT_U32: GOR(T, uint32_t); break;                                                                     \
+    default: GOR(T, int64_t); break;                                                                                 \
+    }
+            switch (dtype) {
+            case INFINI_DT_F32: GORP(float); break;
+            case INFINI_DT_F16: GORP(__half); break;
+            default: GORP(__hip_bfloat16); break;
+            }
+#undef GORP
+#undef GOR
+            IROCM_LAUNCH_CHECK("rope_rows");
+            return INFINI_ROCM_OK;
+        }
+    }
     const long total = tokens * (ceil_div(dim_model, dim_head) * (dim_head / 2));
     long g = ceil_div(total, 256);
     if (g > (long)rt->num_cu * 16) g = (long)rt->num_cu * 16;

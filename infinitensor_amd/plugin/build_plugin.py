@@ -156,7 +156,10 @@ def build(verbose: bool = True) -> Path | None:
         srcs.extend(plugin_srcs)
         # every TU sees the patched runtime.h, so nothing can be shared with oracle/_ref's objects
         objdir = OUT / "obj"
-        objs = compile_all(srcs, objdir, flags, stamp=newest_in)
+        # a changed HEADER (or patch set) recompiles everything; a changed plugin source only itself (compile_all compares every
+        # object with its own source's mtime)
+        header_stamp = max(p.stat().st_mtime for p in [HERE / "include/rocm/rocm_runtime.h", Path(__file__), REPO / "include/infini_rocm.h"])
+        objs = compile_all(srcs, objdir, flags, stamp=header_stamp)
         ldflags = subprocess.check_output(["python3-config", "--ldflags", "--embed"], text=True).split()
         link_shared(objs, out, ["-fopenmp", f"-L{lib.parent}", "-linfini_rocm", "-Wl,-rpath,$ORIGIN/../../lib", *ldflags])
     finally:

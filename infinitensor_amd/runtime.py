@@ -190,6 +190,19 @@ class RocmRuntime:
     def init_comm(self, name: str, world_size: int, rank: int) -> None:
         check(lib().infini_rocm_comm_init(self._h, name.encode(), int(world_size), int(rank)))
 
+    def init_comm_direct(self, name: str, world_size: int, rank: int) -> None:
+        """The hand-written one-hop transport over IPC-mapped peer buffers (csrc/comm_direct.hip) — next to an RCCL
+        communicator (pick with comm_set_algo) or alone; ranks may share a device."""
+        check(lib().infini_rocm_comm_init_direct(self._h, name.encode(), int(world_size), int(rank)))
+
+    def comm_set_algo(self, algo: int) -> None:
+        """0: RCCL when initialised (default), 1: the direct transport."""
+        check(lib().infini_rocm_comm_set_algo(self._h, int(algo)))
+
+    def comm_check(self) -> None:
+        """Raises when a direct-transport kernel gave up waiting for a peer (call after sync())."""
+        check(lib().infini_rocm_comm_check(self._h))
+
     def init_comm_with_id(self, unique_id: bytes, world_size: int, rank: int) -> None:
         check(lib().infini_rocm_comm_init_id(self._h, unique_id, len(unique_id), int(world_size), int(rank)))
 

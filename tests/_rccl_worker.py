@@ -1,4 +1,6 @@
-"""Worker of tests/test_gpu_multi.py: one rank (= one process = one GPU) of an RCCL job on one node.
+"""Worker of tests/test_gpu_multi.py: one rank (= one process = one GPU) of an RCCL job on one node — or, with
+INFINI_ROCM_COMM=direct and IROCM_WORKER_SHARED_DEVICE=1 in the environment, one rank of a job on the hand-written IPC / xGMI
+transport (csrc/comm_direct.hip) whose ranks all open device 0: the same cases at world 2 / 4 / 8 on a one-GPU box.
 
 Runs the reference's collective tests on Device::ROCM, twice: through the C ABI (ctypes) and through the reference's
 graph executor + plugin (`backend.RocmRuntime(rank).init_comm(name, world, rank)`, file rendezvous in the cwd exactly
@@ -17,21 +19,145 @@ sys.path.insert(0, str(REPO))
 sys.path.insert(0, str(REPO / "tests"))
 
 
+def direct_transport_cases(rt, ops, torch, world, rank, devid):
+    """What the hand-written transport has to get right beyond the reference's small cases: bit-exact integer sums against the
+    oracle (oracle/ref_ops.py::all_reduce), messages of several protocol pieces (more than world x cap bytes), element counts
+    that are not multiples of the 16-byte vector or of the world size, unaligned buffers, back-to-back calls (the parity
+    double-buffering of the boxes), broadcasts from every root in a row and a send / recv ring (the credit protocol)."""
+    from oracle import ref_ops as R
+
+    dev = f"cuda:{devid}"
+    torch.cuda.synchronize()
+    rt.use_torch_stream()  # inputs are made by torch: one stream orders their initialisation, the collectives and the checks
+
+    def data(shape, dtype, it):  # every rank can rebuild every rank's data
+        vals = []
+        for r in range(world):
+            g = np.random.default_rng(7919 * it + 31 * r + 5)
+            if np.issubdtype(dtype, np.integer):
+                vals.append(g.integers(-50, 50, shape).astype(dtype))
+            else:
+                vals.append(g.standard_normal(shape).astype(dtype))
+        return vals
+
+    # integers: bit-identical to the oracle for sum / min / max, odd sizes, three widths
+    it = 0
+    for dtype in (np.int32, np.int64, np.int8):
+        for count in (1, 7, 1000, 4099, 65537):
+            for kind in ("sum", "min", "max"):
+                it += 1
+                xs = data((count,), dtype, it)
+                if dtype == np.int8:
+                    xs = [(x // 8).astype(np.int8) for x in xs]  # keep the sum of 8 ranks inside int8
+                y = ops.all_reduce(rt, kind, torch.from_numpy(xs[rank]).to(dev))
+                rt.sync()
+                want = R.all_reduce(kind, xs).astype(dtype)
+                assert np.array_equal(y.cpu().numpy(), want), (dtype, count, kind)
+    # floats: fp32 close to the fp64 result (rank-ordered fp32 accumulation), f16 within one storage ulp; avg and prod too
+    for dtype, tol in ((np.float32, 1e-5), (np.float16, 2e-3)):
+        for count in (3, 1024, 100003):
+            for kind in ("sum", "avg", "max", "prod"):
+                it += 1
+                xs = data((count,), dtype, it)
+                if kind == "prod":
+                    xs = [(1 + 0.1 * x).astype(dtype) for x in xs]
+                y = ops.all_reduce(rt, kind, torch.from_numpy(xs[rank]).to(dev))
+                rt.sync()
+                want = R.all_reduce(kind, [x.astype(np.float64) for x in xs])
+                assert np.allclose(y.float().cpu().numpy(), want, rtol=tol, atol=tol * 4), (dtype, count, kind)
+    # every rank holds the same bits afterwards (rank j computes slice j and pushes it to everybody): digest all-gather
+    xs = data((50000,), np.float16, 999)
+    y = ops.all_reduce(rt, "sum", torch.from_numpy(xs[rank]).to(dev))
+    digest = torch.tensor([int(y.view(torch.int16).to(torch.int64).sum().item())], dtype=torch.int64, device=dev)
+    parts = ops.all_gather(rt, digest)
+    rt.sync()
+    assert len({int(p.item()) for p in parts}) == 1
+    # a misaligned view (2-byte offset): the element-wise instantiation
+    base = torch.zeros(4099 + 8, dtype=torch.float16, device=dev)
+    xs = data((4099,), np.float16, 1234)
+    v = base[1:4100]
+    v.copy_(torch.from_numpy(xs[rank]).to(dev))
+    ops.all_reduce(rt, "sum", v, out=v)
+    rt.sync()
+    assert np.allclose(v.float().cpu().numpy(), R.all_reduce("sum", [x.astype(np.float64) for x in xs]), rtol=2e-3, atol=8e-3)
+    # more than world x cap bytes: several protocol pieces (cap 8 MiB: 2^25 int32 = 128 MiB is 8 pieces at world 2, 2 at world 8)
+    n = 1 << 25
+    big = (torch.arange(n, dtype=torch.int32, device=dev) % 1000) * (rank + 1)
+    ops.all_reduce(rt, "sum", big, out=big)
+    rt.sync()
+    assert torch.equal(big, (torch.arange(n, dtype=torch.int32, device=dev) % 1000) * (world * (world + 1) // 2))
+    del big
+    # back-to-back calls without a host sync in between: 40 all-reduces + all-gathers chained on the stream, checked at the end
+    outs = []
+    for k in range(40):
+        x = torch.full((3001 + k,), float(rank + k), dtype=torch.float32, device=dev)
+        outs.append((k, ops.all_reduce(rt, "sum", x)))
+        if k % 5 == 0:
+            outs.append((-k - 1, ops.all_gather(rt, torch.full((17,), float(rank * 100 + k), device=dev))))
+    rt.sync()
+    for k, o in outs:
+        if k >= 0:
+            assert torch.all(o == float(sum(r + k for r in range(world)))).item(), k
+        else:
+            kk = -k - 1
+            assert all(torch.all(p == float(r * 100 + kk)).item() for r, p in enumerate(o)), kk
+    # reduce-scatter in pieces (count x 2 bytes > cap) and with a count that is not a multiple of 8
+    for count in ((5 << 20) + 3, 777):
+        xs_t = torch.stack([torch.full((count,), float((rank + 1) * (r + 1)), device=dev) for r in range(world)]).to(torch.float16)
+        sh = ops.reduce_scatter(rt, xs_t, True)
+        rt.sync()
+        assert torch.all(sh == float((rank + 1) * world * (world + 1) / 2)).item(), count
+    # broadcast from every root, three rounds back to back (credits), then a payload of several pieces
+    for rnd in range(3):
+        for root in range(world):
+            x = torch.full((100003,), float(root * 10 + rnd), device=dev) if rank == root else torch.zeros(100003, device=dev)
+            y = ops.broadcast(rt, x, root)
+            rt.sync()
+            assert torch.all(y == float(root * 10 + rnd)).item(), (rnd, root)
+    pay = (torch.arange(5 << 20, dtype=torch.int32, device=dev) * 3) if rank == world - 1 else torch.zeros(5 << 20, dtype=torch.int32, device=dev)
+    y = ops.broadcast(rt, pay, world - 1)
+    rt.sync()
+    assert torch.equal(y, torch.arange(5 << 20, dtype=torch.int32, device=dev) * 3)
+    # send / recv ring: everybody sends to rank + 1 BEFORE receiving from rank - 1 (one message of credit per pair), 4 rounds;
+    # then one 24 MiB message (three pieces against one slot of credit: rank 0 receives first, as any NCCL program must)
+    nxt, prv = (rank + 1) % world, (rank - 1) % world
+    for rnd in range(4):
+        cnt = 1000 + rnd
+        ops.send(rt, torch.full((cnt,), float(rank * 7 + rnd), device=dev), nxt)
+        got = ops.recv(rt, (cnt,), torch.float32, prv)
+        rt.sync()
+        assert torch.all(got == float(prv * 7 + rnd)).item(), rnd
+    cnt = 6 << 20
+    msg = torch.full((cnt,), float(rank * 7 + 4), device=dev)
+    if rank == 0:
+        got = ops.recv(rt, (cnt,), torch.float32, prv)
+        ops.send(rt, msg, nxt)
+    else:
+        ops.send(rt, msg, nxt)
+        got = ops.recv(rt, (cnt,), torch.float32, prv)
+    rt.sync()
+    assert torch.all(got == float(prv * 7 + 4)).item()
+    rt.comm_check()
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     import torch
 
     from infinitensor_amd import RocmRuntime, ops
 
-    torch.cuda.set_device(rank)
+    shared = os.environ.get("IROCM_WORKER_SHARED_DEVICE") == "1"
+    direct = os.environ.get("INFINI_ROCM_COMM") == "direct"
+    devid = 0 if shared else rank
+    torch.cuda.set_device(devid)
     done = []
 
     # ---- C ABI -------------------------------------------------------------------------------------
-    rt = RocmRuntime(rank)
+    rt = RocmRuntime(devid)
     rt.use_torch_stream()  # order with torch's tensor initialisation
     rt.init_comm("abi_comm", world, rank)  # file rendezvous ./abi_comm_nccl_id.bin (nccl_communicator.h:27-51)
     assert rt.comm_info() == (world, rank)
-    dev = lambda a, dt=torch.float32: torch.tensor(a, dtype=dt, device=f"cuda:{rank}")
+    dev = lambda a, dt=torch.float32: torch.tensor(a, dtype=dt, device=f"cuda:{devid}")
     # test_nccl_comm.cc:37-52: {1, 4} -> {5, 5}
     y = ops.all_reduce(rt, "sum", dev([1.0 if rank == 0 else 4.0] if world == 2 else [float(rank + 1)]))
     rt.sync()
@@ -48,7 +174,7 @@ def main():
     done.append("abi_all_reduce")
     # a payload at the size of the TP block's messages: 16 MiB fp16, sum of rank-coloured data
     n = 8 * 1024 * 1024
-    big = torch.full((n,), float(rank + 1), dtype=torch.float16, device=f"cuda:{rank}")
+    big = torch.full((n,), float(rank + 1), dtype=torch.float16, device=f"cuda:{devid}")
     ops.all_reduce(rt, "sum", big, out=big)
     rt.sync()
     assert torch.all(big == world * (world + 1) / 2).item()
@@ -58,7 +184,7 @@ def main():
     assert len(parts) == world and all(np.array_equal(p.cpu().numpy(), rows[r]) for r, p in enumerate(parts))
     done.append("abi_all_gather")
     # test_cuda_broadcast.cc:41-55: only the root holds the data
-    x = dev([2.0, 3.0, 5.0, 6.0]) if rank == 0 else torch.zeros(4, device=f"cuda:{rank}")
+    x = dev([2.0, 3.0, 5.0, 6.0]) if rank == 0 else torch.zeros(4, device=f"cuda:{devid}")
     y = ops.broadcast(rt, x, 0)
     rt.sync()
     assert np.array_equal(y.cpu().numpy(), [2.0, 3.0, 5.0, 6.0])
@@ -94,12 +220,14 @@ def main():
     # Overlapped collectives (infini_rocm_all_reduce_async / comm_join): a "row-parallel GEMM" cut into 4 row chunks, each chunk's
     # all-reduce on the comm stream under the next chunk's GEMM — equal to one GEMM + one whole-tensor all-reduce (a chunk's GEMM
     # may pick another tile / split-K form than the whole GEMM: fp16 rounding of a different summation order, nothing more)
-    g2 = torch.Generator(device=f"cuda:{rank}").manual_seed(100 + rank)
-    a_ = (torch.randn(1024, 512, device=f"cuda:{rank}", generator=g2) * 0.1).to(torch.float16)
-    w_ = (torch.randn(512, 768, device=f"cuda:{rank}", generator=g2) * 0.1).to(torch.float16)
+    g2 = torch.Generator(device=f"cuda:{devid}").manual_seed(100 + rank)
+    a_ = (torch.randn(1024, 512, device=f"cuda:{devid}", generator=g2) * 0.1).to(torch.float16)
+    w_ = (torch.randn(512, 768, device=f"cuda:{devid}", generator=g2) * 0.1).to(torch.float16)
+    torch.cuda.synchronize()  # (the runtime is on its own, non-blocking stream since the capture above)
     ref = ops.matmul(rt, a_, w_)
     ops.all_reduce(rt, "sum", ref, out=ref)
     got = torch.empty_like(ref)
+    torch.cuda.synchronize()
     for c in range(4):
         sl = slice(c * 256, (c + 1) * 256)
         ops.matmul(rt, a_[sl], w_, out=got[sl])
@@ -109,6 +237,7 @@ def main():
     assert torch.allclose(got.float(), ref.float(), rtol=2e-3, atol=2e-3 * world)
     # ... and the same sequence captured into a hipGraph (fork / join edges) and replayed
     got2 = torch.zeros_like(ref)
+    torch.cuda.synchronize()
     rt.begin_capture()
     for c in range(4):
         sl = slice(c * 256, (c + 1) * 256)
@@ -123,8 +252,9 @@ def main():
     done.append("abi_all_reduce_overlapped")
     # reduce-scatter, RCCL's algorithm and the direct one-hop exchange (grouped send / recv + local fp32 sum), then all-gather
     # == all-reduce
-    xs = torch.stack([torch.full((2, 64), float((rank + 1) * (r + 2)), device=f"cuda:{rank}") for r in range(world)]).to(torch.float16)
+    xs = torch.stack([torch.full((2, 64), float((rank + 1) * (r + 2)), device=f"cuda:{devid}") for r in range(world)]).to(torch.float16)
     want_shard = float(sum((q + 1) * (rank + 2) for q in range(world)))
+    torch.cuda.synchronize()
     for direct in (False, True):
         sh = ops.reduce_scatter(rt, xs, direct)
         rt.sync()
@@ -133,13 +263,16 @@ def main():
         rt.sync()
         assert all(torch.all(pp == float(sum((q + 1) * (r + 2) for q in range(world)))).item() for r, pp in enumerate(parts))
     done.append("abi_reduce_scatter")
+    if direct:
+        direct_transport_cases(rt, ops, torch, world, rank, devid)
+        done.append("direct_stress")
 
     # ---- reference executor + plugin -----------------------------------------------------------------
     from conftest import load_backend_module
 
     B = load_backend_module()
     assert B is not None and hasattr(B, "RocmRuntime"), "plugin build missing"
-    prt = B.RocmRuntime(rank)
+    prt = B.RocmRuntime(devid)
     prt.init_comm("plugin_comm", world, rank)
     F32 = 1
 
@@ -207,6 +340,8 @@ def main():
     assert np.allclose(res[True].astype(np.float32), res[False].astype(np.float32), rtol=2e-3, atol=2e-3 * world)
     done.append("plugin_row_parallel_overlap")
     prt.sync()
+    if direct:
+        rt.comm_check()  # no kernel of the hand-written transport ran into its time limit
     print("RESULT " + json.dumps({"rank": rank, "world": world, "done": done}), flush=True)
 
 

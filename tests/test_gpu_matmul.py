@@ -301,9 +301,10 @@ def test_matmul_head_split_rejects_bad_tilings(rt):
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
 @pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3, 4, 5, 6])
 def test_matmul_fast_gelu_epilogue(rt, dtype, tol, variant):
-    """act = 5: Gelu (erf form) in the GEMM epilogue with erf by Abramowitz-Stegun 7.1.26 (abs error 1.5e-7) vs the oracle's
-    exact Gelu of the fp64 product, over the whole input range incl. the negative tail (no cancellation in 1 + erf), and
-    against act = 4 (erff) to one output ulp."""
+    """act = 5: Gelu (erf form) in the GEMM epilogue with erf by a clamped odd polynomial (no transcendentals; abs error
+    < 2^-12, gemm_common.h::gelu_poly) vs the oracle's exact Gelu of the fp64 product, over the whole input range incl. the
+    negative tail (exactly 0 below -4, where |gelu| < 1.3e-4) and the positive one (exactly x above 4), and against act = 4
+    (erff) to one output ulp."""
     rng = np.random.default_rng(9)
     a = (rng.standard_normal((512, 256)) * 1.5).astype(np.float32)
     w = (rng.standard_normal((256, 768)) / 8).astype(np.float32)

@@ -59,6 +59,24 @@ def test_rccl_collectives_match_the_reference_tests(world, tmp_path):
                                     "abi_all_reduce_overlapped", "abi_reduce_scatter", "plugin_row_parallel_overlap"}
 
 
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_direct_transport_collectives_on_one_device(world, tmp_path):
+    """The hand-written IPC / xGMI transport (csrc/comm_direct.hip; INFINI_ROCM_COMM=direct) with `world` ranks that all open
+    device 0 — RCCL refuses two ranks per device, push kernels over IPC-mapped buffers do not — running the reference's
+    collective tests (test_cuda_all_reduce.cc:38-106, test_cuda_all_gather.cc:38-50, test_cuda_broadcast.cc:41-55,
+    test_cuda_sendrecv.cc:50-87, test_nccl_comm.cc:37-52) through the C ABI and through the reference executor + plugin, plus
+    the transport's own stress cases (bit-exact integer sums vs the oracle, multi-piece messages, odd counts, back-to-back
+    calls, broadcast roots in a row, a send / recv ring): the first non-identity reduction evidence on a one-GPU box."""
+    outs = launch(world, REPO / "tests" / "_rccl_worker.py", tmp_path, timeout=900,
+                  extra_env={"INFINI_ROCM_COMM": "direct", "IROCM_WORKER_SHARED_DEVICE": "1", "INFINI_ROCM_DIRECT_TIMEOUT_S": "60"})
+    for r, so in enumerate(outs):
+        res = json.loads([ln for ln in so.splitlines() if ln.startswith("RESULT ")][-1][7:])
+        assert res["rank"] == r and res["world"] == world
+        assert set(res["done"]) >= {"abi_all_reduce", "abi_all_gather", "abi_broadcast", "abi_send_recv", "abi_all_reduce_hipgraph",
+                                    "plugin_collectives", "plugin_all_reduce_hipgraph", "abi_all_reduce_overlapped", "abi_reduce_scatter",
+                                    "plugin_row_parallel_overlap", "direct_stress"}
+
+
 def test_row_parallel_overlap_forced_on_one_rank(tmp_path):
     """The chunked, overlapped MatMul -> AllReduceSum launch only plans itself with more than one rank; forced here at
     world 1 so that the code path (comm stream, fork / join events, capture) runs on the builder's one-GPU boxes too."""
