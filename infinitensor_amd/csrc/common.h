@@ -97,6 +97,27 @@ struct DeviceOnce {
         }                                                                                          \
     } while (0)
 
+// Gelu for a GEMM epilogue WITHOUT transcendentals (round 4): erf(x / sqrt 2) ~ xc * P(xc^2) on |x| <= 4 with P an odd-minimax
+// fit of degree 13 (7 coefficients, weighted by the 0.5 |x| the error is multiplied with; P(16) * 4 = 1 + 2e-5 so that the
+// clamp to [-1, 1] returns EXACTLY +-1 from |x| = 4 on: x for large positive inputs, 0 for large negative ones, +-inf / NaN
+// carried by the final fma). Max |error| against 0.5 x (1 + erf(x / sqrt 2)): 1.96e-4 < 2^-12 inside the fit range (fp32
+// Horner, tools/gelu_fit.py), 1.3e-4 from the truncation at x < -4 — below half an f16 ulp of every value the epilogue can
+// store there. 12 plain fp32 VALU operations (10 of them mul / fma that hipcc pairs into v_pk_* forms) against 14 + v_rcp +
+// v_exp (quarter-rate each) of gelu_erf_as: the FFN1 epilogue of BERT was VALU-bound on exactly those.
+__device__ inline float gelu_poly(float v) {
+    const float xc = __builtin_amdgcn_fmed3f(v, -4.0f, 4.0f);
+    const float u = xc * xc;
+    float p = fmaf(4.563833937e-08f, u, -3.201370338e-06f);
+    p = fmaf(p, u, 9.599663829e-05f);
+    p = fmaf(p, u, -1.628826435e-03f);
+    p = fmaf(p, u, 1.754786860e-02f);
+    p = fmaf(p, u, -1.291485240e-01f);
+    p = fmaf(p, u, 7.957602372e-01f);
+    const float e = __builtin_amdgcn_fmed3f(xc * p, -1.0f, 1.0f);
+    const float hx = 0.5f * v;
+    return fmaf(hx, e, hx);
+}
+
 constexpr int kNumXcd = 8; // MI355X: 8 XCDs, block b is dispatched to XCD b % 8 (speed only)
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -321,8 +321,15 @@ static int bias_residual_launch(infiniRocmRuntime_t rt, const void *a, const voi
 }
 
 // ---- unary ops -------------------------------------------------------------------------------
-template <int OP> __device__ inline float un_op(float x, float p0, float p1) {
+// H16: the result is stored in a 16-bit type. Sigmoid / Silu / Gelu then take forms without libm calls or divisions — v_exp_f32 +
+// v_rcp_f32 (1 ulp of fp32 each) and the clamped polynomial of common.h::gelu_poly (abs error < 2^-12) — all far inside half
+// an output ulp; at the HBM-sized shapes of tools/membound_sweep.py the libm forms made Gelu VALU-bound (erff: ~40
+// instructions per element; 4.8 TB/s) and Silu x Mul 4.6 TB/s. fp32 outputs keep the exact forms (the 1e-4 relative gate).
+template <int OP, bool H16> __device__ inline float un_op(float x, float p0, float p1) {
     if constexpr (OP == INFINI_UN_RELU) return fmaxf(x, 0.f);
+    else if constexpr (OP == INFINI_UN_SIGMOID && H16) return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+    else if constexpr (OP == INFINI_UN_GELU && H16) return gelu_poly(x);
+    else if constexpr (OP == INFINI_UN_SILU && H16) return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
     else if constexpr (OP == INFINI_UN_SIGMOID) return 1.f / (1.f + expf(-x));
     else if constexpr (OP == INFINI_UN_TANH) return tanhf(x);
     else if constexpr (OP == INFINI_UN_ABS) return fabsf(x);
@@ -359,20 +366,20 @@ __global__ __launch_bounds__(256) void unary_kernel(const T *__restrict__ x, T *
         VecT<T, VEC> t = reinterpret_cast<const VecT<T, VEC> *>(x)[v], o;
 #pragma unroll
         for (int j = 0; j < VEC; ++j)
-            Cvt<T>::store(&o.v[j], un_op<OP>((float)Cvt<T>::load(&t.v[j]), p0, p1));
+            Cvt<T>::store(&o.v[j], un_op<OP, sizeof(T) == 2>((float)Cvt<T>::load(&t.v[j]), p0, p1));
         reinterpret_cast<VecT<T, VEC> *>(y)[v] = o;
     }
     // tail (n not a multiple of the vector width): first block's first threads
     const long tail0 = nvec * VEC;
     if (blockIdx.x == 0 && tail0 + threadIdx.x < n)
-        Cvt<T>::store(y + tail0 + threadIdx.x, un_op<OP>((float)Cvt<T>::load(x + tail0 + threadIdx.x), p0, p1));
+        Cvt<T>::store(y + tail0 + threadIdx.x, un_op<OP, sizeof(T) == 2>((float)Cvt<T>::load(x + tail0 + threadIdx.x), p0, p1));
 }
 
 template <typename T, int OP>
 __global__ __launch_bounds__(256) void unary_kernel_unaligned(const T *__restrict__ x, T *__restrict__ y,
                                                               long n, float p0, float p1) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
-        Cvt<T>::store(y + i, un_op<OP>((float)Cvt<T>::load(x + i), p0, p1));
+        Cvt<T>::store(y + i, un_op<OP, sizeof(T) == 2>((float)Cvt<T>::load(x + i), p0, p1));
 }
 
 // y = silu(a) * b (a gated MLP's Silu -> Mul pair as one pass): the Silu value is rounded to T before the product, exactly as
@@ -387,7 +394,7 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const T *__restrict__ a, 
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             T s_;
-            Cvt<T>::store(&s_, un_op<INFINI_UN_SILU>((float)Cvt<T>::load(&ta.v[j]), 0.f, 0.f));
+            Cvt<T>::store(&s_, un_op<INFINI_UN_SILU, sizeof(T) == 2>((float)Cvt<T>::load(&ta.v[j]), 0.f, 0.f));
             Cvt<T>::store(&o.v[j], (float)Cvt<T>::load(&s_) * (float)Cvt<T>::load(&tb.v[j]));
         }
         reinterpret_cast<VecT<T, VEC> *>(y)[v] = o;
@@ -395,7 +402,7 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const T *__restrict__ a, 
     const long tail0 = nvec * VEC;
     if (blockIdx.x == 0 && tail0 + threadIdx.x < n) {
         T s_;
-        Cvt<T>::store(&s_, un_op<INFINI_UN_SILU>((float)Cvt<T>::load(a + tail0 + threadIdx.x), 0.f, 0.f));
+        Cvt<T>::store(&s_, un_op<INFINI_UN_SILU, sizeof(T) == 2>((float)Cvt<T>::load(a + tail0 + threadIdx.x), 0.f, 0.f));
         Cvt<T>::store(y + tail0 + threadIdx.x, (float)Cvt<T>::load(&s_) * (float)Cvt<T>::load(b + tail0 + threadIdx.x));
     }
 }

@@ -88,6 +88,56 @@ __global__ __launch_bounds__(256) void transpose2d_kernel(const void *__restrict
     }
 }
 
+// The same transpose for 2- / 4-byte elements when both extents are multiples of the 16-byte vector: 16-byte global loads AND
+// stores (the kernel above moves one element per lane: 2.9 TB/s on K^T of a BERT head, [512, 64] f16). A 64 x 64 tile goes
+// through LDS with an 8-byte row pad; a lane gathers the V elements of its output vector from V tile rows (2-way bank
+// conflicts at most) and the 8 lanes of an output row segment store 128 contiguous bytes.
+template <int BYTES>
+__global__ __launch_bounds__(256) void transpose2d_vec_kernel(const void *__restrict__ in, void *__restrict__ out, long rows,
+                                                              long cols, long tiles_r, long tiles_c) {
+    using R = typename Raw<BYTES>::t;
+    constexpr int V = 16 / BYTES;      // elements per vector
+    constexpr int NV = 64 / V;         // vectors per tile row
+    constexpr int PITCH = 64 + 8 / BYTES; // elements
+    struct alignas(16) RV { R v[V]; };
+    struct alignas(8) RH { R v[V / 2]; };
+    __shared__ __attribute__((aligned(16))) R tile[64 * PITCH];
+    const long b = blockIdx.x / (tiles_r * tiles_c);
+    const long t = blockIdx.x % (tiles_r * tiles_c);
+    const long r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+    const R *src = (const R *)in + b * rows * cols;
+    R *dst = (R *)out + b * rows * cols;
+#pragma unroll
+    for (int i = 0; i < 64 * NV / 256; ++i) {
+        const int q = threadIdx.x + i * 256;
+        const int r = q / NV, cv = q % NV;
+        if (r0 + r < rows && c0 + cv * V < cols) {
+            const RV v = *reinterpret_cast<const RV *>(src + (r0 + r) * cols + c0 + cv * V);
+            RH lo, hi;
+#pragma unroll
+            for (int j = 0; j < V / 2; ++j) {
+                lo.v[j] = v.v[j];
+                hi.v[j] = v.v[V / 2 + j];
+            }
+            *reinterpret_cast<RH *>(&tile[r * PITCH + cv * V]) = lo;
+            *reinterpret_cast<RH *>(&tile[r * PITCH + cv * V + V / 2]) = hi;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 64 * NV / 256; ++i) {
+        const int q = threadIdx.x + i * 256;
+        const int c = q / NV, rv = q % NV; // output row c0 + c, output columns r0 + rv * V ..
+        if (c0 + c < cols && r0 + rv * V < rows) {
+            RV o;
+#pragma unroll
+            for (int j = 0; j < V; ++j)
+                o.v[j] = tile[(rv * V + j) * PITCH + c];
+            *reinterpret_cast<RV *>(dst + (c0 + c) * rows + r0 + rv * V) = o;
+        }
+    }
+}
+
 static int launch_strided(infiniRocmRuntime_t rt, int elem, const void *in, void *out, IdxArgs p) {
     // widen the element when the innermost dim is contiguous (stride 1) and everything is aligned
     int bytes = elem;
@@ -234,6 +284,39 @@ __global__ __launch_bounds__(256) void where_kernel(const void *__restrict__ x, 
     }
 }
 
+// Flat form: after collapsing, ONE dimension in which every operand is dense (stride 1) or a scalar (stride 0) — masks and
+// selects of same-shape tensors. V elements per thread, 16-byte loads / stores, no index arithmetic.
+template <int BYTES, int CB>
+__global__ __launch_bounds__(256) void where_flat_kernel(const void *__restrict__ xv, const void *__restrict__ yv,
+                                                         const void *__restrict__ cv, void *__restrict__ out, long total, int sx,
+                                                         int sy, int sc, unsigned long long keep) {
+    using R = typename Raw<BYTES>::t;
+    using C = typename CondRaw<CB>::t;
+    constexpr int V = 16 / BYTES;
+    struct alignas(16) RV { R v[V]; };
+    struct alignas((V * CB) < 16 ? (V * CB) : 16) CV { C v[V]; };
+    const R *x = (const R *)xv, *y = (const R *)yv;
+    const C *c = (const C *)cv;
+    const long nvec = total / V;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
+        RV a, b, o;
+        CV m;
+        if (sx) a = reinterpret_cast<const RV *>(x)[v];
+        if (sy) b = reinterpret_cast<const RV *>(y)[v];
+        if (sc) m = reinterpret_cast<const CV *>(c)[v];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const R av = sx ? a.v[j] : x[0], bv = sy ? b.v[j] : y[0];
+            const C mv = sc ? m.v[j] : c[0];
+            o.v[j] = ((unsigned long long)mv & keep) ? av : bv;
+        }
+        reinterpret_cast<RV *>(out)[v] = o;
+    }
+    if (blockIdx.x == 0)
+        for (long i = nvec * V + threadIdx.x; i < total; i += 256)
+            ((R *)out)[i] = ((unsigned long long)c[sc ? i : 0] & keep) ? x[sx ? i : 0] : y[sy ? i : 0];
+}
+
 // ---- pad / slice -------------------------------------------------------------------------------
 struct PadSliceArgs {
     int ndim;
@@ -271,10 +354,12 @@ template <int BYTES>
 __global__ __launch_bounds__(256) void copy2d_kernel(const char *__restrict__ src, char *__restrict__ dst,
                                                      long rows, long row_items, long src_pitch, long dst_pitch) {
     using R = typename Raw<BYTES>::t;
-    const long total = rows * row_items;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long r = i / row_items, c = i - r * row_items;
-        *(R *)(dst + r * dst_pitch + c * BYTES) = *(const R *)(src + r * src_pitch + c * BYTES);
+    // grid (column chunks, row groups): no per-element division
+    for (long r = blockIdx.y; r < rows; r += gridDim.y) {
+        const char *s = src + r * src_pitch;
+        char *d = dst + r * dst_pitch;
+        for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < row_items; c += (long)gridDim.x * 256)
+            *(R *)(d + c * BYTES) = *(const R *)(s + c * BYTES);
     }
 }
 
@@ -338,6 +423,15 @@ int infini_rocm_transpose(infiniRocmRuntime_t rt, int dtype, const void *x, void
         const long in_rows = cols, in_cols = rows, batch = nd == 3 ? p.shape[0] : 1;
         const long tr = ceil_div(in_rows, 64), tc = ceil_div(in_cols, 64);
         const long blocks = batch * tr * tc;
+        if (blocks < (1l << 31) && (elem == 2 || elem == 4) && in_rows % (16 / elem) == 0 && in_cols % (16 / elem) == 0 &&
+            ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0) {
+            if (elem == 2)
+                hipLaunchKernelGGL(transpose2d_vec_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, rt->stream, x, y, in_rows, in_cols, tr, tc);
+            else
+                hipLaunchKernelGGL(transpose2d_vec_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, rt->stream, x, y, in_rows, in_cols, tr, tc);
+            IROCM_LAUNCH_CHECK("transpose2d_vec");
+            return INFINI_ROCM_OK;
+        }
         if (blocks < (1l << 31)) {
             switch (elem) {
             case 1: hipLaunchKernelGGL(transpose2d_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, rt->stream, x, y, in_rows, in_cols, tr, tc); break;
@@ -533,6 +627,31 @@ int infini_rocm_where_ex(infiniRocmRuntime_t rt, int dtype, int cond_dtype, cons
         p.ndim = 1; p.shape[0] = 1; p.sx[0] = p.sy[0] = p.sc[0] = 0;
     }
     p.total = total;
+    const bool flat = p.ndim == 1 && (p.sx[0] == 0 || p.sx[0] == 1) && (p.sy[0] == 0 || p.sy[0] == 1) && (p.sc[0] == 0 || p.sc[0] == 1) &&
+                      ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)cond) | ((uintptr_t)out)) & 15) == 0 && total >= 16 / elem;
+    if (flat) {
+        const unsigned gf = grid_for(total / (16 / elem), rt->num_cu);
+#define IROCM_WHEREF(EB, CB_)                                                                                      \
+    hipLaunchKernelGGL((where_flat_kernel<EB, CB_>), dim3(gf), dim3(256), 0, rt->stream, x, y, cond, out, total, (int)p.sx[0], \
+                       (int)p.sy[0], (int)p.sc[0], keep)
+#define IROCM_WHEREF_C(EB)                                                                                         \
+    switch (cb) {                                                                                                  \
+    case 1: IROCM_WHEREF(EB, 1); break;                                                                            \
+    case 2: IROCM_WHEREF(EB, 2); break;                                                                            \
+    case 4: IROCM_WHEREF(EB, 4); break;                                                                            \
+    default: IROCM_WHEREF(EB, 8); break;                                                                           \
+    }
+        switch (elem) {
+        case 1: IROCM_WHEREF_C(1); break;
+        case 2: IROCM_WHEREF_C(2); break;
+        case 4: IROCM_WHEREF_C(4); break;
+        default: IROCM_WHEREF_C(8); break;
+        }
+#undef IROCM_WHEREF_C
+#undef IROCM_WHEREF
+        IROCM_LAUNCH_CHECK("where_flat");
+        return INFINI_ROCM_OK;
+    }
     const unsigned g = grid_for(total, rt->num_cu);
 #define IROCM_WHERE(EB, CB_)                                                                      \
     hipLaunchKernelGGL((where_kernel<EB, CB_>), dim3(g), dim3(256), 0, rt->stream, x, y, cond, out, p, keep)
@@ -615,15 +734,21 @@ int infini_rocm_strided_copy(infiniRocmRuntime_t rt, const void *src, void *dst,
                      ((uintptr_t)dst % w)))
         w >>= 1;
     const long items = row_bytes / w;
-    const unsigned g = grid_for(rows * items, rt->num_cu);
+    // grid: x = 256-item column chunks of a row, y = row groups (grid-stride in both): ~16 blocks per CU in all
+    long gx = ceil_div(items, 256), gy = rows;
+    const long cap = (long)rt->num_cu * 16;
+    if (gx > cap) gx = cap;
+    if (gy > 65535) gy = 65535;
+    if (gx * gy > cap) gy = std::max<long>(1, cap / gx);
+    const dim3 g((unsigned)gx, (unsigned)gy);
     const char *s = (const char *)src;
     char *d = (char *)dst;
     switch (w) {
-    case 16: hipLaunchKernelGGL(copy2d_kernel<16>, dim3(g), dim3(256), 0, rt->stream, s, d, (long)rows, items, (long)src_pitch, (long)dst_pitch); break;
-    case 8: hipLaunchKernelGGL(copy2d_kernel<8>, dim3(g), dim3(256), 0, rt->stream, s, d, (long)rows, items, (long)src_pitch, (long)dst_pitch); break;
-    case 4: hipLaunchKernelGGL(copy2d_kernel<4>, dim3(g), dim3(256), 0, rt->stream, s, d, (long)rows, items, (long)src_pitch, (long)dst_pitch); break;
-    case 2: hipLaunchKernelGGL(copy2d_kernel<2>, dim3(g), dim3(256), 0, rt->stream, s, d, (long)rows, items, (long)src_pitch, (long)dst_pitch); break;
-    default: hipLaunchKernelGGL(copy2d_kernel<1>, dim3(g), dim3(256), 0, rt->stream, s, d, (long)rows, items, (long)src_pitch, (long)dst_pitch); break;
+    case 16: hipLaunchKernelGGL(copy2d_kernel<16>, g, dim3(256), 0, rt->stream, s, d, (long)rows, items, (long)src_pitch, (long)dst_pitch); break;
+    case 8: hipLaunchKernelGGL(copy2d_kernel<8>, g, dim3(256), 0, rt->stream, s, d, (long)rows, items, (long)src_pitch, (long)dst_pitch); break;
+    case 4: hipLaunchKernelGGL(copy2d_kernel<4>, g, dim3(256), 0, rt->stream, s, d, (long)rows, items, (long)src_pitch, (long)dst_pitch); break;
+    case 2: hipLaunchKernelGGL(copy2d_kernel<2>, g, dim3(256), 0, rt->stream, s, d, (long)rows, items, (long)src_pitch, (long)dst_pitch); break;
+    default: hipLaunchKernelGGL(copy2d_kernel<1>, g, dim3(256), 0, rt->stream, s, d, (long)rows, items, (long)src_pitch, (long)dst_pitch); break;
     }
     IROCM_LAUNCH_CHECK("strided_copy");
     return INFINI_ROCM_OK;

@@ -672,10 +672,13 @@ __device__ inline float block_max(float v, float *red, int lane, int w) {
     return r;
 }
 
-template <typename T, int CH, bool RMS>
-__global__ __launch_bounds__(256) void norm_blockreg_kernel(const T *__restrict__ x, const T *__restrict__ scale,
-                                                            const T *__restrict__ bias, T *__restrict__ y, long rows,
-                                                            int n, int scale_size, int bias_size, float eps) {
+// ADD = 1: the row is a + b (x2 = b); ADD = 2: (a + pre) + b — each sum rounded to T like its own Add kernel would have
+// stored it (the same contract as norm_rows_kernel; round 4: rows beyond 4 KiB, e.g. the 4096-wide rows of a Llama block,
+// used to take a separate Add pass — 0.34 of the HBM peak for the pair).
+template <typename T, int CH, bool RMS, int ADD>
+__global__ __launch_bounds__(256) void norm_blockreg_kernel(const T *__restrict__ x, const T *x2, const T *__restrict__ pre,
+                                                            const T *__restrict__ scale, const T *__restrict__ bias, T *y,
+                                                            long rows, int n, int scale_size, int bias_size, float eps) {
     constexpr int VEC = Elem<T>::VEC;
     using P = Pack<T, VEC>;
     __shared__ float red[4];
@@ -689,6 +692,29 @@ __global__ __launch_bounds__(256) void norm_blockreg_kernel(const T *__restrict_
             const int base = (i * 256 + t) * VEC;
             if (base < n)
                 c[i] = *reinterpret_cast<const P *>(xr + base);
+        }
+        if constexpr (ADD != 0) {
+            const T *br = x2 + row * (long)n; // (may be y itself: every element is read before the row is written)
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int base = (i * 256 + t) * VEC;
+                if (base < n) {
+                    const P b2 = *reinterpret_cast<const P *>(br + base);
+                    P pv;
+                    if constexpr (ADD == 2)
+                        pv = *reinterpret_cast<const P *>(pre + base);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        float a = Elem<T>::ld(&c[i].v[j]);
+                        if constexpr (ADD == 2) {
+                            T mid;
+                            Elem<T>::st(&mid, a + Elem<T>::ld(&pv.v[j]));
+                            a = Elem<T>::ld(&mid);
+                        }
+                        Elem<T>::st(&c[i].v[j], a + Elem<T>::ld(&b2.v[j]));
+                    }
+                }
+            }
         }
         float mu = 0.f;
         if (!RMS) {
@@ -919,8 +945,8 @@ static int norm_dispatch(infiniRocmRuntime_t rt, const T *x, const T *scale, con
         const unsigned g = (unsigned)(outer < 8192 ? outer : 8192);
         const int bch = (int)ceil_div(n, (int64_t)256 * VEC); // 16-byte chunks per thread of a block-resident row
 #define NORM_BR(C)                                                                                 \
-    hipLaunchKernelGGL((norm_blockreg_kernel<T, C, RMS>), dim3(g), dim3(256), 0, rt->stream, x, scale, bias, y, \
-                       (long)outer, (int)n, (int)scale_size, (int)bias_size, eps)
+    hipLaunchKernelGGL((norm_blockreg_kernel<T, C, RMS, 0>), dim3(g), dim3(256), 0, rt->stream, x, (const T *)nullptr,   \
+                       (const T *)nullptr, scale, bias, y, (long)outer, (int)n, (int)scale_size, (int)bias_size, eps)
         if (al && bch <= 2) NORM_BR(2);
         else if (al && bch <= 4) NORM_BR(4);
         else if (al && bch <= 8) NORM_BR(8);
@@ -940,8 +966,26 @@ static int add_norm_dispatch(infiniRocmRuntime_t rt, const T *a, const T *b, con
                              int64_t outer, int64_t n, int64_t scale_size, int64_t bias_size, float eps) {
     const bool ok = pre ? launch_norm_rows<T, RMS, 2>(rt, a, b, pre, scale, bias, y, outer, n, scale_size, bias_size, eps)
                         : launch_norm_rows<T, RMS, 1>(rt, a, b, pre, scale, bias, y, outer, n, scale_size, bias_size, eps);
-    if (!ok)
-        return INFINI_ROCM_UNSUPPORTED; // the caller falls back to Add + Norm
+    if (!ok) {
+        // rows beyond the wave-resident kernel's 4 KiB: block-resident rows (up to 256 threads x 8 chunks x 16 B = 32 KiB)
+        constexpr int VEC = Elem<T>::VEC;
+        const bool al = is_aligned16(a) && is_aligned16(b) && (!pre || is_aligned16(pre)) && is_aligned16(y) && is_aligned16(scale) &&
+                        (bias == nullptr || is_aligned16(bias)) && (n % VEC == 0);
+        const int bch = (int)ceil_div(n, (int64_t)256 * VEC);
+        if (!al || bch > 8 || outer == 0)
+            return INFINI_ROCM_UNSUPPORTED; // the caller falls back to Add + Norm
+        const unsigned g = (unsigned)(outer < 8192 ? outer : 8192);
+#define ADD_BR(C, A)                                                                                                  \
+    hipLaunchKernelGGL((norm_blockreg_kernel<T, C, RMS, A>), dim3(g), dim3(256), 0, rt->stream, a, b, pre, scale, bias, y, \
+                       (long)outer, (int)n, (int)scale_size, (int)bias_size, eps)
+#define ADD_BRC(A)                                                                                                    \
+    do {                                                                                                              \
+        if (bch <= 2) ADD_BR(2, A); else if (bch <= 4) ADD_BR(4, A); else ADD_BR(8, A);                               \
+    } while (0)
+        if (pre) ADD_BRC(2); else ADD_BRC(1);
+#undef ADD_BRC
+#undef ADD_BR
+    }
     IROCM_LAUNCH_CHECK("add_norm");
     return INFINI_ROCM_OK;
 }

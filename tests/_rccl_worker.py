@@ -147,7 +147,7 @@ def main():
     from infinitensor_amd import RocmRuntime, ops
 
     shared = os.environ.get("IROCM_WORKER_SHARED_DEVICE") == "1"
-    direct = os.environ.get("INFINI_ROCM_COMM") == "direct"
+    on_direct_transport = os.environ.get("INFINI_ROCM_COMM") == "direct"
     devid = 0 if shared else rank
     torch.cuda.set_device(devid)
     done = []
@@ -170,7 +170,9 @@ def main():
         for dt, tol in ((torch.float32, 1e-6), (torch.float16, 2e-3)):
             y = ops.all_reduce(rt, kind, dev(rows[rank], dt))
             rt.sync()
-            assert np.allclose(y.float().cpu().numpy(), w, rtol=tol), (kind, dt, y, w)
+            # (the product of 8 ranks' rows exceeds the f16 range: the expected value is then +inf, like the stored one)
+            wd = w.astype(np.float16).astype(np.float64) if dt == torch.float16 and np.abs(w).max() > 65504 else w
+            assert np.allclose(y.float().cpu().numpy(), wd, rtol=tol), (kind, dt, y, w)
     done.append("abi_all_reduce")
     # a payload at the size of the TP block's messages: 16 MiB fp16, sum of rank-coloured data
     n = 8 * 1024 * 1024
@@ -263,7 +265,7 @@ def main():
         rt.sync()
         assert all(torch.all(pp == float(sum((q + 1) * (r + 2) for q in range(world)))).item() for r, pp in enumerate(parts))
     done.append("abi_reduce_scatter")
-    if direct:
+    if on_direct_transport:
         direct_transport_cases(rt, ops, torch, world, rank, devid)
         done.append("direct_stress")
 
@@ -340,7 +342,7 @@ def main():
     assert np.allclose(res[True].astype(np.float32), res[False].astype(np.float32), rtol=2e-3, atol=2e-3 * world)
     done.append("plugin_row_parallel_overlap")
     prt.sync()
-    if direct:
+    if on_direct_transport:
         rt.comm_check()  # no kernel of the hand-written transport ran into its time limit
     print("RESULT " + json.dumps({"rank": rank, "world": world, "done": done}), flush=True)
 

@@ -50,10 +50,12 @@ def test_resnet50_logits_match_the_reference_cpu_backend(plugin_backend):
         rocm.set_fusion(True)
 
 
-LOWERINGS = {"onnx": {}, "onnx-merged-kt": {"merged_kt": True}, "onnx-decomposed": {"decomposed": True}, "idealised": {"frontend": False}}
+LOWERINGS = {"onnx": {}, "onnx-merged-kt": {"merged_kt": True}, "onnx-decomposed": {"decomposed": True}, "idealised": {"frontend": False},
+             # the operator order / forms of a REAL transformers-5.x export (tests/golden/onnx/bert_layer_tiny_opset*.onnx)
+             "onnx-hf5": {"exporter": "hf5"}, "onnx-hf5-decomposed": {"exporter": "hf5", "decomposed": True}}
 
 
-def _bert_oracle(feeds, batch, seq, layers, hidden, heads, decomposed=False):
+def _bert_oracle(feeds, batch, seq, layers, hidden, heads, decomposed=False, hf5=False):
     """fp64 restatement of tools/model_bench.py::build_bert over the very arrays fed to the graph (in creation
     order), written with the pinned oracle ops (oracle/ref_ops.py). Every lowering of the builder computes this function."""
     from oracle import ref_ops as R
@@ -62,6 +64,9 @@ def _bert_oracle(feeds, batch, seq, layers, hidden, heads, decomposed=False):
     nxt = lambda: next(it).astype(np.float64)
     ids = next(it)
     emb, pos, mask, scale = nxt(), nxt(), nxt(), nxt()
+    if hf5:  # the exporter's Mul(scores, 1 / sqrt(D)) constant
+        inv = nxt()
+        assert abs(float(inv) * float(scale[0]) - 1) < 2e-3
     eps = 1e-12
     if decomposed:  # the constants of the primitive-operator forms: 2, 1, 0.5, sqrt 2, epsilon (as stored)
         two, one, half, sqrt2, epsa = nxt(), nxt(), nxt(), nxt(), nxt()
@@ -135,7 +140,7 @@ def test_bert_encoder_end_to_end_vs_oracle(plugin_backend, dtype, tol, lowering)
                     assert alone <= (5 + layers * 2 if dtype == "f16" else 5 + layers * 10), (alone, plan)
             results[mode] = out.copyout_numpy().astype(np.float64).reshape(batch, seq, hidden)
             if want is None:
-                want = _bert_oracle(bl.feeds, batch, seq, layers, hidden, heads, decomposed="decomposed" in lowering)
+                want = _bert_oracle(bl.feeds, batch, seq, layers, hidden, heads, decomposed="decomposed" in lowering, hf5="hf5" in lowering)
     finally:
         rocm.set_fusion(True)
     scale = np.abs(want).max()
@@ -311,7 +316,7 @@ def test_bert_base_one_full_width_layer_vs_oracle(plugin_backend):
             bl.finish()
             bl.h.run()
             got = out.copyout_numpy().astype(np.float64).reshape(batch, seq, hidden)
-            want = _bert_oracle(bl.feeds, batch, seq, layers, hidden, heads, decomposed="decomposed" in lowering)
+            want = _bert_oracle(bl.feeds, batch, seq, layers, hidden, heads, decomposed="decomposed" in lowering, hf5="hf5" in lowering)
             scale = np.abs(want).max()
             assert np.isfinite(got).all()
             assert np.abs(got - want).max() <= tol * scale, (lowering, dtype, np.abs(got - want).max(), scale)

@@ -35,10 +35,32 @@ def test_transpose_reference_kat(rt):
 @pytest.mark.parametrize("dtype", NPDT)
 @pytest.mark.parametrize("shape,perm", [((4, 512, 12, 64), (0, 2, 1, 3)), ((3, 130, 70), (0, 2, 1)), ((65, 33), (1, 0)),
                                         ((2, 3, 4, 5), (3, 2, 1, 0)), ((2, 3, 4, 5, 6), (4, 0, 3, 1, 2)), ((7,), (0,)),
-                                        ((2, 1, 3, 1, 4), (3, 4, 1, 0, 2)), ((5, 6, 7), (0, 1, 2)), ((2, 3, 2, 3, 2, 3, 2, 3), (7, 6, 5, 4, 3, 2, 1, 0))])
+                                        ((2, 1, 3, 1, 4), (3, 4, 1, 0, 2)), ((5, 6, 7), (0, 1, 2)), ((2, 3, 2, 3, 2, 3, 2, 3), (7, 6, 5, 4, 3, 2, 1, 0)),
+                                        # batched 2-D transposes whose extents are multiples of the 16-byte vector: the vectorised tile kernel
+                                        # (whole tiles, ragged tiles in both directions, K^T of a BERT head, one tile)
+                                        ((3, 64, 72), (0, 2, 1)), ((2, 40, 24), (0, 2, 1)), ((24, 512, 64), (0, 2, 1)), ((2, 12, 128, 64), (0, 1, 3, 2)),
+                                        ((200, 8), (1, 0)), ((8, 136), (1, 0))])
 def test_transpose_bit_exact(rt, shape, perm, dtype):
     x = rnd(shape, dtype)
     assert np.array_equal(host(ops.transpose(rt, dev(x), perm)), R.transpose(x, perm))
+
+
+@pytest.mark.parametrize("dtype", [np.float16, np.float32, np.int8, np.int64])
+@pytest.mark.parametrize("form", ["dense", "y_scalar", "x_scalar", "cond_scalar", "ragged_tail"])
+def test_where_flat_forms_bit_exact(rt, dtype, form):
+    """Same-shape operands / scalar operands (every operand dense or a one-element broadcast): the vectorised flat kernel,
+    incl. a length that is not a multiple of the 16-byte vector — bit-exact against the oracle (where.cu:4-19 semantics)."""
+    n = (37, 1000) if form != "ragged_tail" else (3, 1237)
+    x, y_ = rnd(n, dtype, 3), rnd(n, dtype, 4)
+    cond = np.random.default_rng(5).random(n) > 0.4
+    if form == "y_scalar":
+        y_ = rnd((1,), dtype, 6)
+    elif form == "x_scalar":
+        x = rnd((1,), dtype, 7)
+    elif form == "cond_scalar":
+        cond = np.array([True])
+    got = ops.where(rt, dev(x), dev(y_), dev(cond))
+    assert np.array_equal(host(got), R.where(x, y_, cond))
 
 
 def test_gather_reference_kats(rt):

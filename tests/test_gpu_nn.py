@@ -266,7 +266,10 @@ def test_reduce_reference_kats(rt):
 
 @pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
 @pytest.mark.parametrize("shape,axes", [((4, 512, 768), [2]), ((3, 5, 7, 9), [1, 3]), ((6, 40), [0]), ((2, 3, 4, 5), None),
-                                        ((8, 2048, 7, 7), [2, 3]), ((5, 1, 6), [0, 1]), ((3, 1000), [-1])])
+                                        ((8, 2048, 7, 7), [2, 3]), ((5, 1, 6), [0, 1]), ((3, 1000), [-1]),
+                                        # short trailing rows (< 64 elements): the LDS-staged kernel — ragged last block, even row length,
+                                        # rows that do not start on 16-byte boundaries
+                                        ((3, 431, 4, 4), [2, 3]), ((300, 63), [1]), ((1293, 2), [1])])
 def test_reduce_vs_oracle(rt, shape, axes, dt):
     rng = np.random.default_rng(21)
     x = rng.standard_normal(shape).astype(np.float32)

@@ -204,17 +204,58 @@ def sweep(rt, ops, Event, only=None, budget_s: float | None = None) -> dict:
     return out
 
 
+def source_stamp() -> str:
+    """sha1 over the kernel sources: a counter file is only valid for the kernels it was taken from (bench.py refuses others)."""
+    import hashlib
+
+    h = hashlib.sha1()
+    csrc = Path(__file__).resolve().parent.parent / "infinitensor_amd" / "csrc"
+    for f in sorted(csrc.glob("*.hip")) + sorted(csrc.glob("*.h")):
+        if f.name in ("rowops.hip", "elementwise.hip", "movement.hip", "nnops.hip", "rope.hip", "common.h"):
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def pmc_run(rt, ops, only=None):
+    """For tools/profile_membound.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each): every case launched 5 times,
+    cases separated by a sentinel launch (a 1-element f32 -> int8 Cast, a kernel no case uses) so that the summariser can cut the
+    dispatch list per case without marker tracing. Prints the case list (order, algorithmic bytes) as JSON."""
+    listing = []
+    s_in = torch.zeros(1, device="cuda")
+    s_out = torch.zeros(1, device="cuda", dtype=torch.int8)
+    for big in (False, True):
+        for name, make in cases(ops, rt, big).items():
+            if only and name not in only:
+                continue
+            fn, nbytes, shape = make()
+            rt.sync()
+            ops.cast(rt, s_in, torch.int8, out=s_out)
+            for _ in range(5):
+                fn()
+            rt.sync()
+            listing.append({"case": f"{name}{'_hbm' if big else ''}", "shape": shape, "algorithmic_bytes": nbytes, "launches": 5})
+            del fn
+            torch.cuda.empty_cache()
+    ops.cast(rt, s_in, torch.int8, out=s_out)
+    rt.sync()
+    print("PMC_CASES " + json.dumps({"stamp": source_stamp(), "cases": listing}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     ap.add_argument("--json", default="")
     ap.add_argument("--once", default="", help="launch this case a few times and exit (for rocprofv3): name or name_hbm")
+    ap.add_argument("--pmc-run", action="store_true", help="launch every case 5 times behind a sentinel (tools/profile_membound.sh)")
     args = ap.parse_args()
     from infinitensor_amd import RocmRuntime, ops
     from infinitensor_amd.runtime import Event
 
     rt = RocmRuntime(0)
     rt.use_torch_stream()
+    if args.pmc_run:
+        pmc_run(rt, ops, set(args.only.split(",")) if args.only else None)
+        return
     if args.once:
         big = args.once.endswith("_hbm")
         fn, nbytes, shape = cases(ops, rt, big)[args.once[:-4] if big else args.once]()

@@ -74,7 +74,8 @@ class Builder:
             t.copyin_numpy(np.ascontiguousarray(a))
 
 
-def build_resnet50(bl: Builder, batch: int, image: int = 224, fc_bias_as_add: bool = False, frontend: bool = True):
+def build_resnet50(bl: Builder, batch: int, image: int = 224, fc_bias_as_add: bool = False, frontend: bool = True,
+                   stem: int = 64, stages=((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)), classes: int = 1000):
     """ResNet-50 (torchvision topology, BN folded) operator by operator AS pyinfinitensor/onnx.py EMITS IT:
       * a Conv node with a bias input becomes  conv -> reshape(bias, [1, F, 1, 1]) -> add   (onnx.py:159-190), so the
         operator order is [Conv, Reshape, Add, Relu];
@@ -98,39 +99,41 @@ def build_resnet50(bl: Builder, batch: int, image: int = 224, fc_bias_as_add: bo
         return (h.relu(y, None) if relu else y), oh
 
     x = bl.input(bl.rng.uniform(0, 1, (batch, 3, image, image)).astype(bl.np))
-    y, hw = conv_bn_act(x, 3, 64, 7, 2, 3, hw=image)
+    y, hw = conv_bn_act(x, 3, stem, 7, 2, 3, hw=image)
     y = h.maxPool(y, None, 3, 3, 1, 1, 1, 1, 2, 2, 0)
     hw = (hw + 2 - 3) // 2 + 1
-    cin = 64
-    for width, blocks, stride in ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)):
+    cin = stem
+    # (stem / stages / classes: the tiny topology of tests/golden/onnx/resnet_tiny_opset13.onnx is built by this same code, so
+    # that tests/test_frontend_form_cpu.py can hold its operator sequence against a REAL export's)
+    for width, blocks, stride in stages:
         for bi in range(blocks):
             s = stride if bi == 0 else 1
             idt = y
             o, hw1 = conv_bn_act(y, cin, width, 1, 1, 0, hw=hw)
             o, hw2 = conv_bn_act(o, width, width, 3, s, 1, hw=hw1)
             o, hw3 = conv_bn_act(o, width, width * 4, 1, 1, 0, relu=False, hw=hw2)
-            if bi == 0:
+            if bi == 0 and (s != 1 or cin != width * 4):
                 idt, _ = conv_bn_act(y, cin, width * 4, 1, s, 0, relu=False, hw=hw)
             y = h.relu(h.add(o, idt, None), None)
             cin, hw = width * 4, hw3
     y = h.avgPool(y, None, hw, hw, 1, 1, 0, 0, 1, 1, 0)
     y = h.flatten(y, None, 1)
-    bfc = bl.weight((1000,), 0.01)
+    bfc = bl.weight((classes,), 0.01)
     if fc_bias_as_add:
-        wfc = bl.weight((2048, 1000), np.sqrt(1.0 / 2048))
+        wfc = bl.weight((cin, classes), np.sqrt(1.0 / cin))
         y = h.add(h.matmul(y, wfc, None, False, False, None, bl.B.ActType.Linear, "default"), bfc, None)
     elif frontend:
-        wfc = bl.weight((1000, 2048), np.sqrt(1.0 / 2048))
+        wfc = bl.weight((classes, cin), np.sqrt(1.0 / cin))
         y = h.matmul(y, wfc, None, False, True, bfc, bl.B.ActType.Linear, "default")
     else:
-        wfc = bl.weight((2048, 1000), np.sqrt(1.0 / 2048))
+        wfc = bl.weight((cin, classes), np.sqrt(1.0 / cin))
         y = h.matmul(y, wfc, None, False, False, bfc, bl.B.ActType.Linear, "default")
-    bl.flops += 2.0 * batch * 2048 * 1000
+    bl.flops += 2.0 * batch * cin * classes
     return y
 
 
 def build_bert(bl: Builder, batch: int, seq: int, layers: int, hidden: int = 768, heads: int = 12, ffn: int = 3072,
-               vocab: int = 30522, frontend: bool = True, decomposed: bool = False, merged_kt: bool = False):
+               vocab: int = 30522, frontend: bool = True, decomposed=False, merged_kt: bool = False, exporter: str = "hf4"):
     """A BERT encoder AS pyinfinitensor/onnx.py EMITS a torch export of it (frontend=True):
       * every nn.Linear on a 3-D activation is  MatMul(x, W) -> Add(bias, .)  — onnx.py:280-290 imports MatMul with no
         bias and no transposes; the exporter puts the bias FIRST in the Add;
@@ -140,6 +143,10 @@ def build_bert(bl: Builder, batch: int, seq: int, layers: int, hidden: int = 768
       * merged_kt: the two transposes of K merged into one Transpose(0, 2, 3, 1) (what onnxsim leaves);
       * decomposed (opset < 17 / < 20): LayerNorm as ReduceMean, Sub, Pow, ReduceMean, Add, Sqrt, Div, Mul, Add and Gelu as
         Div, Erf, Add, Mul, Mul (onnx.py:522,528,604,837,1050).
+      * decomposed="gelu": only the Gelu decomposed (an opset-17 export: LayerNormalization exists, Gelu arrives with opset 20);
+      * exporter="hf5": the operator order and forms transformers 5.x really exports (pinned by the fixture
+        tests/golden/onnx/bert_layer_tiny_opset13.onnx and tests/test_frontend_form_cpu.py): q's Reshape / Transpose right
+        behind its Add, K reshaped only, V, then K's single Transpose(0, 2, 3, 1), the scale as Mul(scores, 1 / sqrt(D)).
     frontend=False: the round-1/2 idealised lowering (bias inside the MatMul, transB for K^T) for A/B."""
     h, B = bl.h, bl.B
     lin = B.ActType.Linear
@@ -149,7 +156,9 @@ def build_bert(bl: Builder, batch: int, seq: int, layers: int, hidden: int = 768
     pos = bl.weight((1, seq, hidden), 0.02)
     mask = bl.const(np.zeros((batch, 1, 1, seq), bl.np))
     scale = bl.const(np.array([np.sqrt(D)], bl.np))
+    inv_scale = bl.const(np.array(1.0 / np.sqrt(D), bl.np)) if exporter == "hf5" else None  # (a rank-0 Constant in the export)
     x = h.add(h.gather(emb, ids, None, 0), pos, None)
+    dec_ln, dec_gelu = decomposed is True, bool(decomposed)
     if decomposed:
         two, one, half = (bl.const(np.array([v], bl.np)) for v in (2.0, 1.0, 0.5))
         sqrt2 = bl.const(np.array([np.sqrt(2.0)], bl.np))
@@ -158,7 +167,7 @@ def build_bert(bl: Builder, batch: int, seq: int, layers: int, hidden: int = 768
 
     def ln(t):
         g, b = bl.const(np.ones(hidden, bl.np)), bl.const(np.zeros(hidden, bl.np))
-        if not decomposed:
+        if not dec_ln:
             return h.layerNormalization(t, g, None, b, 1e-12, 2, 1)
         d = h.sub(t, h.reduceMean(t, None, [rank - 1], True), None)
         var = h.reduceMean(h.pow(d, two, None), None, [rank - 1], True)
@@ -166,7 +175,7 @@ def build_bert(bl: Builder, batch: int, seq: int, layers: int, hidden: int = 768
         return h.add(h.mul(y, g, None), b, None)
 
     def gelu(t):
-        if not decomposed:
+        if not dec_gelu:
             return h.gelu(t, None)
         e = h.add(h.erf(h.div(t, sqrt2, None), None), one, None)
         return h.mul(h.mul(t, e, None), half, None)
@@ -184,7 +193,13 @@ def build_bert(bl: Builder, batch: int, seq: int, layers: int, hidden: int = 768
 
     x = ln(x)
     for _ in range(layers):
-        if frontend:
+        if frontend and exporter == "hf5":
+            q = heads_of(linear(x, hidden, hidden))
+            kr = h.reshape(linear(x, hidden, hidden), None, [batch, seq, heads, D])
+            v = heads_of(linear(x, hidden, hidden))
+            kt = h.transpose(kr, None, [0, 2, 3, 1])
+            s = h.matmul(q, kt, None, False, False, None, lin, "default")
+        elif frontend:
             ql = linear(x, hidden, hidden)
             kl = linear(x, hidden, hidden)
             if merged_kt:
@@ -200,7 +215,7 @@ def build_bert(bl: Builder, batch: int, seq: int, layers: int, hidden: int = 768
             q, k, v = heads_of(linear(x, hidden, hidden)), heads_of(linear(x, hidden, hidden)), heads_of(linear(x, hidden, hidden))
             s = h.matmul(q, k, None, False, True, None, lin, "default")
         bl.flops += 2.0 * batch * heads * seq * seq * D * 2
-        s = h.add(h.div(s, scale, None), mask, None)
+        s = h.add(h.mul(s, inv_scale, None) if (frontend and exporter == "hf5") else h.div(s, scale, None), mask, None)
         p = h.softmax(s, None, 3)
         ctx = h.matmul(p, v, None, False, False, None, lin, "default")
         ctx = h.reshape(h.transpose(ctx, None, [0, 2, 1, 3]), None, [batch, seq, hidden])
@@ -284,7 +299,7 @@ def timed(fn, iters, warm_ms=40.0):
 
 def run_model(model: str, device: int = 0, batch: int | None = None, seq: int = 512, layers: int = 12,
               dtype: str = "f16", iters: int = 10, tune: bool = False, frontend: bool = True, decomposed: bool = False,
-              merged_kt: bool = False) -> dict:
+              merged_kt: bool = False, exporter: str = "hf5") -> dict:
     """tune=True additionally runs the reference's h.tune() (MatMul / Conv pick their kernel variant by measurement,
     plugin/src/rocm_kernels.cc RocmTunableKernel) and times the graph again with the records in the PerfEngine."""
     B = load_backend()
@@ -305,8 +320,9 @@ def run_model(model: str, device: int = 0, batch: int | None = None, seq: int = 
         name = f"MatMul 4096^3 {dtype} " + ("NT" if model == "matmul_nt" else "NN")
     else:
         batch = batch or 32
-        out = build_bert(bl, batch, seq, layers, frontend=frontend, decomposed=decomposed, merged_kt=merged_kt)
-        name = f"BERT-base L{layers} bs{batch} seq{seq} {dtype}" + (" decomposed LN/Gelu" if decomposed else "") + (" merged-K^T" if merged_kt else "")
+        out = build_bert(bl, batch, seq, layers, frontend=frontend, decomposed=decomposed, merged_kt=merged_kt, exporter=exporter)
+        name = (f"BERT-base L{layers} bs{batch} seq{seq} {dtype}" + (" decomposed LN/Gelu" if decomposed else "") + (" merged-K^T" if merged_kt else "") +
+                (f" [{exporter} export order]" if frontend else ""))
     nops = len(bl.h.operators())
     bl.finish()
     f0 = rt.fused_launch_count()
@@ -359,9 +375,11 @@ def main():
     ap.add_argument("--idealised", action="store_true", help="the round-1/2 lowering (bias inside MatMul / pre-shaped conv bias, transB)")
     ap.add_argument("--decomposed", action="store_true", help="bert: LayerNorm / Gelu as the primitive operators of an opset < 17 export")
     ap.add_argument("--merged-kt", action="store_true", help="bert: K's two transposes merged into Transpose(0, 2, 3, 1) (onnxsim)")
+    ap.add_argument("--exporter", default="hf5", choices=["hf4", "hf5"],
+                    help="bert: operator order of the export — hf5 = what transformers 5.x emits (pinned by tests/golden/onnx), hf4 = the older order")
     args = ap.parse_args()
     print(json.dumps(run_model(args.model, 0, args.batch, args.seq, args.layers, args.dtype, args.iters, args.tune,
-                               not args.idealised, args.decomposed, args.merged_kt)))
+                               not args.idealised, args.decomposed, args.merged_kt, args.exporter)))
 
 
 if __name__ == "__main__":
