@@ -406,6 +406,18 @@ int infini_rocm_conv2d_set_variant(infiniRocmRuntime_t rt, int variant);
  * workgroups), "tap_shifted" (the other kernels of conv_s1.hip), "batched_gemm", "generic", "none". A forced
  * variant falls back when a shape does not qualify; tests and measurement tools read the route instead of assuming it. */
 int infini_rocm_conv2d_last_route(infiniRocmRuntime_t rt, const char **route);
+/* The stem of a CNN as one launch (csrc/conv_stem.hip): y = MaxPool(pool_k x pool_k, stride pool_s, pad pool_p)(act(conv2d(x, w) +
+ * bias)) — the chain Conv -> Reshape(bias) -> Add -> Relu -> MaxPool the front-end emits for ResNet's first layers (reference:
+ * conv.cc:57-168, element_wise.cu, unary.cc:70-122, pooling.cc:6-95 as four kernels). The conv tile is pooled out of LDS: the conv
+ * output never exists in HBM. Served: 7 x 7 / stride 2 / pad 3, C = 3, F = 64, groups 1, act = 1 (ReLU), MaxPool 3 x 3 / 2 / 1,
+ * f16 / bf16, W % 8 == 0, 16-byte aligned x / y; infini_rocm_conv2d_pool_supported says so without a runtime (the plugin's planner
+ * asks it); anything else returns INFINI_ROCM_UNSUPPORTED — the caller runs the separate kernels. y: [n, f, ph, pw] with
+ * oh = (h + 2 ph - r) / sh + 1 and ph = (oh + 2 pool_p - pool_k) / pool_s + 1 (floor mode). */
+int infini_rocm_conv2d_pool_supported(int dtype, int64_t c, int64_t h, int64_t w, int64_t f, int64_t r, int64_t s, int ph, int pw, int sh,
+                                      int sw, int dh, int dw, int groups, int act, int pool_k, int pool_s, int pool_p);
+int infini_rocm_conv2d_pool(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, const void *bias, void *y, int64_t n, int64_t c,
+                            int64_t h, int64_t wd, int64_t f, int64_t r, int64_t s, int ph, int pw, int sh, int sw, int dh, int dw, int groups,
+                            int act, int pool_k, int pool_s, int pool_p);
 /* Packed-weight cache. The f16 / bf16 conv kernels read their weights re-packed (FCRS -> [RS][F][C]); while `on` is set
  * the next conv2d calls treat `w` as CONSTANT data: the packed image is built once, kept in a runtime-owned buffer keyed
  * by (w, F, C, RS, layout) and reused by every later call — eager or captured (built on a side stream when the runtime

@@ -97,6 +97,8 @@ def lib() -> C.CDLL:
     sig("infini_rocm_rms_norm", [vp, i32, vp, vp, vp, i64, i64, f32])
     sig("infini_rocm_conv2d_set_variant", [vp, i32])
     sig("infini_rocm_conv2d_last_route", [vp, C.POINTER(C.c_char_p)])
+    sig("infini_rocm_conv2d_pool_supported", [i32, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32])
+    sig("infini_rocm_conv2d_pool", [vp, i32, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32])
     sig("infini_rocm_conv2d_set_const_weights", [vp, i32])
     sig("infini_rocm_weight_cache_info", [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(C.c_uint64)])
     sig("infini_rocm_weight_cache_clear", [vp])

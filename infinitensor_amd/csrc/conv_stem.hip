@@ -1,0 +1,293 @@
+// The stem of a CNN as ONE kernel: Conv2d(7 x 7, stride 2, pad 3, C = 3 -> F = 64) + per-filter bias + ReLU + MaxPool(3 x 3,
+// stride 2, pad 1), f16 / bf16, NCHW — ResNet-50's first four operators after the front-end's lowering
+// (Conv -> Reshape(bias) -> Add -> Relu -> MaxPool; reference kernels: conv.cc:57-168 (cuDNN), element_wise.cu, unary.cc,
+// pooling.cc:6-95). Round 3 ran them as a tap-shifted implicit GEMM with a per-k offset table (171 us at batch 128, 4.4 x its
+// floor, behind a phase-split pre-pass) plus a pooling pass (52 us) that re-read the 205 MB the conv had just written.
+//
+// Here the conv tile never leaves the CU: a workgroup owns 2 x 28 POOLED outputs of one image (all 64 filters), computes the
+// 5 x 57 conv pixels they need on the matrix cores, parks them (bias added, rounded, ReLU'd — the values the unfused chain
+// would have stored) in LDS and pools from there; HBM sees the input once (+ halo rows from L2) and the pooled output once.
+//   * GEMM view: M = 64 filters, N = conv pixels, K = (c, r, s8) with the 7 taps of a filter row padded to 8, so that a lane's B
+//     fragment of v_mfma_f32_16x16x32 — 8 consecutive k of one pixel — is 8 CONSECUTIVE input pixels of one (channel, input
+//     row): one 16-byte read of the input tile in LDS at a 4-byte-aligned address (the tile's origin is the odd input column
+//     2 x0 - 3, so a run starts on an even element). 21 (c, r) pairs -> 6 k-steps of 4 pairs (3 zero-weight pairs).
+//   * A = the weights, re-packed ONCE (packed-weight cache) into fragment order [k-step][filter tile][lane][8]: a lane keeps all
+//     24 fragments (96 VGPRs) for the whole workgroup.
+//   * input tile: 3 channels x 15 rows x 120 columns, pitch 160 elements (row stride = 16 banks: the four (c, r) pairs a wave
+//     reads at once hit disjoint banks); conv tile for the pool: even / odd / even-shifted column planes so that the three taps
+//     of 8 adjacent pooled columns are three aligned 16-byte reads and v_pk_max_u16 does the rest (ReLU made everything >= 0:
+//     unsigned 16-bit order = float order for f16 and bf16, and padding with 0 equals MaxPool's -inf padding).
+// Served: C = 3, F = 64, 7 x 7 / 2 / pad 3 / dilation 1, groups 1, activation ReLU, pool 3 x 3 / 2 / pad 1 / dilation 1 /
+// floor mode, W % 8 == 0, 16-byte aligned tensors. Everything else keeps the separate kernels (the query below says which).
+// A zero weight multiplies the 8th element of every run: an Inf / NaN pixel therefore poisons the conv pixel to its LEFT as
+// well (its true window ends one column earlier) — finite images, i.e. every real one, are unaffected.
+#include "gemm_common.h"
+
+namespace irocm {
+
+constexpr int kStemF = 64;          // filters
+constexpr int kStemQ = 24;          // (c, r) pairs incl. 3 padding pairs
+constexpr int kStemKS = 6;          // k-steps of 32
+constexpr int kStemPR = 2, kStemPC = 28; // pooled rows / columns per workgroup
+constexpr int kStemCR = 2 * kStemPR + 1, kStemCC = 2 * kStemPC + 1; // conv rows / columns per workgroup: 5 x 57
+constexpr int kStemIR = 2 * kStemCR + 5; // input rows: 15
+constexpr int kStemPitch = 160;     // input tile row pitch (elements)
+constexpr int kStemInElems = 3 * kStemIR * kStemPitch; // 7200
+constexpr int kStemPlane = 32;      // columns of one conv-tile plane row (29 / 28 used)
+constexpr int kStemFStride = kStemCR * kStemPlane + 8; // 168 elements: 4 filters apart = 16 banks apart
+constexpr int kStemPlaneElems = kStemF * kStemFStride; // 10752
+constexpr int kStemLds = (kStemInElems + 3 * kStemPlaneElems) * 2; // 78,912 B: two workgroups per CU
+
+struct StemArgs {
+    const unsigned short *x;   // [n][3][h][w]
+    const unsigned short *wp;  // packed weights: [6 k-steps][4 filter tiles][64 lanes][8]
+    const unsigned short *bias; // [64] or nullptr
+    unsigned short *y;         // [n][64][ph][pw]
+    int n, h, w, oh, ow, ph, pw;
+    int tiles_r, tiles_c;      // pooled row / column tiles per image
+};
+
+// FCRS [64][3][7][7] -> fragment order. Element e of lane (g4, l15) of fragment (ks, mt): filter mt * 16 + l15,
+// pair q = 4 ks + g4 -> (c, r) = (q / 7, q % 7) for q < 21, tap s = e (< 7); zero otherwise.
+__global__ __launch_bounds__(256) void stem_pack_w_kernel(const unsigned short *__restrict__ w, unsigned short *__restrict__ wp) {
+    const int i = blockIdx.x * 256 + threadIdx.x; // one element
+    if (i >= kStemKS * 4 * 64 * 8)
+        return;
+    const int e = i & 7, lane = (i >> 3) & 63, mt = (i >> 9) & 3, ks = i >> 11;
+    const int f = mt * 16 + (lane & 15), q = 4 * ks + (lane >> 4);
+    unsigned short v = 0;
+    if (q < 21 && e < 7)
+        v = w[((f * 3 + q / 7) * 7 + q % 7) * 7 + e];
+    wp[i] = v;
+}
+
+template <typename Tr>
+__global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(StemArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+    unsigned short *tin = lds;                       // [3][15][160]
+    unsigned short *pev = lds + kStemInElems;        // even conv columns   [64][5][32] (+ pad)
+    unsigned short *pod = pev + kStemPlaneElems;     // odd conv columns
+    unsigned short *pes = pod + kStemPlaneElems;     // even columns shifted by one: pes[k] = pev[k + 1]
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l15 = lane & 15, g4 = lane >> 4;
+    int b = blockIdx.x;
+    const int tc = b % p.tiles_c;
+    b /= p.tiles_c;
+    const int tr = b % p.tiles_r, img = b / p.tiles_r;
+    const int p0 = tr * kStemPR, c0 = tc * kStemPC;  // first pooled row / column
+    const int y0 = 2 * p0 - 1, x0 = 2 * c0 - 1;      // first conv row / column of the tile
+    const int iy0 = 2 * y0 - 3, ix0 = 2 * x0 - 3;    // first input row / column of the tile (ix0 is odd)
+
+    // ---- weights: 24 fragments per lane, resident -------------------------------------------------------------------
+    s16x8_t af[kStemKS][4];
+#pragma unroll
+    for (int ks = 0; ks < kStemKS; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            af[ks][mt] = *(const s16x8_t *)(p.wp + ((ks * 4 + mt) * 64 + lane) * 8);
+    float bv[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            bv[mt][r] = p.bias ? Tr::to_f32(p.bias[mt * 16 + 4 * g4 + r]) : 0.f;
+
+    // ---- input tile -----------------------------------------------------------------------------------------------
+    for (int i = t; i < kStemInElems / 8; i += 256)
+        *(s16x8_t *)(tin + i * 8) = s16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+    __syncthreads();
+    {
+        // 16-byte chunks of the image rows: chunk m holds input columns 8 m .. 8 m + 7; the tile needs columns ix0 .. ix0 + 119
+        const int m_first = ix0 >= 0 ? ix0 / 8 : -1; // floor(ix0 / 8): ix0 = -5 for the first column tile, positive afterwards
+        const unsigned short *X = p.x + (long)img * 3 * p.h * p.w;
+        for (int i = t; i < 3 * kStemIR * 16; i += 256) {
+            const int m = m_first + (i & 15), rowc = i >> 4; // rowc = c * 15 + j
+            const int c = rowc / kStemIR, j = rowc - c * kStemIR;
+            const int iy = iy0 + j, ix = 8 * m;
+            if (iy < 0 || iy >= p.h || ix < 0 || ix >= p.w)
+                continue; // stays zero (padding)
+            const s16x8_t v = *(const s16x8_t *)(X + ((long)c * p.h + iy) * p.w + ix);
+            unsigned short *dst = tin + rowc * kStemPitch + (ix - ix0); // odd element offset: element stores
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (ix - ix0 + e >= 0 && ix - ix0 + e < kStemPitch)
+                    dst[e] = (unsigned short)v[e];
+        }
+    }
+    __syncthreads();
+
+    // ---- conv tile: wave wv takes the 16-column block wv of each of the 5 conv rows -------------------------------------
+    int qoff[kStemKS]; // element offset of pair q = 4 ks + g4 inside the tile (padding pairs read pair 0: finite data x weight 0)
+#pragma unroll
+    for (int ks = 0; ks < kStemKS; ++ks) {
+        const int q = 4 * ks + g4;
+        qoff[ks] = q < 21 ? ((q / 7) * kStemIR + q % 7) * kStemPitch : 0;
+    }
+    const int xl = wv * 16 + l15; // conv column inside the tile (0 .. 63; 57 used)
+#pragma unroll 1
+    for (int yi = 0; yi < kStemCR; ++yi) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned short *base = tin + 2 * yi * kStemPitch + 2 * xl;
+#pragma unroll
+        for (int ks = 0; ks < kStemKS; ++ks) {
+            const unsigned *src = (const unsigned *)(base + qoff[ks]); // 4-byte aligned
+            const unsigned d0 = src[0], d1 = src[1], d2 = src[2], d3 = src[3];
+            const s16x8_t bf = __builtin_bit_cast(s16x8_t, u32x4_t{d0, d1, d2, d3});
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                acc[mt] = Tr::mfma(af[ks][mt], bf, acc[mt]);
+        }
+        // bias, round, ReLU -> the three column planes. Pixels outside the conv output (or past the tile's 57 columns) are 0.
+        const int gy = y0 + yi, gx = x0 + xl;
+        const bool live = xl < kStemCC && gy >= 0 && gy < p.oh && gx >= 0 && gx < p.ow;
+        const int k = xl >> 1;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // round(relu(v)) == relu(round(v)): the bits the unfused Conv + Add -> Relu chain stores
+                float v = acc[mt][r] + bv[mt][r];
+                v = v > 0.f ? v : 0.f;
+                const unsigned short hv = live ? Tr::from_f32(v) : (unsigned short)0;
+                const int o = (mt * 16 + 4 * g4 + r) * kStemFStride + yi * kStemPlane;
+                if (xl < 64) {
+                    if (xl & 1) {
+                        pod[o + k] = hv;
+                    } else {
+                        pev[o + k] = hv;
+                        if (k > 0)
+                            pes[o + k - 1] = hv;
+                    }
+                }
+            }
+    }
+    __syncthreads();
+
+    // ---- pool: (filter, pooled row, group of 8 pooled columns) -> 16 bytes --------------------------------------------------
+    typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
+    for (int i = t; i < kStemF * kStemPR * 4; i += 256) {
+        const int g = i & 3, pr = (i >> 2) % kStemPR, f = i / (4 * kStemPR);
+        const int prow = p0 + pr;
+        if (prow >= p.ph)
+            continue;
+        u16x8_t m = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int o = f * kStemFStride + (2 * pr + dy) * kStemPlane + 8 * g;
+            const u16x8_t a = *(const u16x8_t *)(pev + o), bb = *(const u16x8_t *)(pod + o), c = *(const u16x8_t *)(pes + o);
+            m = __builtin_elementwise_max(m, __builtin_elementwise_max(__builtin_elementwise_max(a, bb), c));
+        }
+        const int pc = c0 + 8 * g;
+        unsigned short *dst = p.y + (((long)img * kStemF + f) * p.ph + prow) * p.pw + pc;
+        const int ncol = min(min(8, kStemPC - 8 * g), p.pw - pc); // 8, or 4 in the last group, or what is left of the row
+        const u32x4_t mm = __builtin_bit_cast(u32x4_t, m);
+        if (ncol == 8 && ((((uintptr_t)dst) & 7) == 0)) {
+            *(u32x2_t *)dst = u32x2_t{mm[0], mm[1]};
+            *(u32x2_t *)(dst + 4) = u32x2_t{mm[2], mm[3]};
+        } else if (ncol == 4 && ((((uintptr_t)dst) & 7) == 0)) {
+            *(u32x2_t *)dst = u32x2_t{mm[0], mm[1]};
+        } else {
+            for (int e = 0; e < ncol; ++e)
+                dst[e] = m[e];
+        }
+    }
+}
+
+static bool stem_pool_shape_ok(int dtype, int c, int h, int w, int f, int r, int s, int ph, int pw, int sh, int sw, int dh, int dw,
+                               int groups, int act, int pk, int ps, int pp) {
+    return (dtype == INFINI_DT_F16 || dtype == INFINI_DT_BF16) && c == 3 && f == kStemF && r == 7 && s == 7 && ph == 3 && pw == 3 && sh == 2 &&
+           sw == 2 && dh == 1 && dw == 1 && groups == 1 && act == 1 && pk == 3 && ps == 2 && pp == 1 && w % 8 == 0 && h >= 7 && w >= 8;
+}
+
+} // namespace irocm
+
+using namespace irocm;
+
+extern "C" int infini_rocm_conv2d_pool_supported(int dtype, int64_t c, int64_t h, int64_t w, int64_t f, int64_t r, int64_t s, int ph,
+                                                 int pw, int sh, int sw, int dh, int dw, int groups, int act, int pool_k, int pool_s,
+                                                 int pool_p) {
+    return h < (1 << 20) && w < (1 << 20) &&
+                   stem_pool_shape_ok(dtype, (int)c, (int)h, (int)w, (int)f, (int)r, (int)s, ph, pw, sh, sw, dh, dw, groups, act, pool_k, pool_s, pool_p)
+               ? 1
+               : 0;
+}
+
+extern "C" int infini_rocm_conv2d_pool(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, const void *bias, void *y,
+                                       int64_t n, int64_t c, int64_t h, int64_t wd, int64_t f, int64_t r, int64_t s, int ph, int pw, int sh,
+                                       int sw, int dh, int dw, int groups, int act, int pool_k, int pool_s, int pool_p) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(n >= 0, "conv2d_pool: negative batch");
+    if (!infini_rocm_conv2d_pool_supported(dtype, c, h, wd, f, r, s, ph, pw, sh, sw, dh, dw, groups, act, pool_k, pool_s, pool_p) ||
+        ((((uintptr_t)x) | ((uintptr_t)y)) & 15) != 0)
+        IROCM_FAIL(INFINI_ROCM_UNSUPPORTED, "conv2d_pool: only the 7 x 7 / 2 stem (C = 3, F = 64, bias + ReLU) followed by MaxPool 3 x 3 / 2 / 1 on "
+                                            "16-byte aligned f16 / bf16 tensors with W %% 8 == 0 is fused (ask infini_rocm_conv2d_pool_supported)");
+    if (n == 0)
+        return INFINI_ROCM_OK;
+    IROCM_CHECK_ARG(x && w && y, "conv2d_pool: NULL tensor");
+    StemArgs p;
+    p.n = (int)n; p.h = (int)h; p.w = (int)wd;
+    p.oh = (int)((h + 6 - 7) / 2 + 1);
+    p.ow = (int)((wd + 6 - 7) / 2 + 1);
+    p.ph = (p.oh + 2 - 3) / 2 + 1;
+    p.pw = (p.ow + 2 - 3) / 2 + 1;
+    p.tiles_r = (p.ph + kStemPR - 1) / kStemPR;
+    p.tiles_c = (p.pw + kStemPC - 1) / kStemPC;
+    IROCM_CHECK_ARG((long)n * p.tiles_r * p.tiles_c < (1l << 31), "conv2d_pool: too many tiles");
+    // packed weights: cached for graph weights (ConstWeightsScope), else built per call in the workspace
+    const size_t w_bytes = (size_t)kStemKS * 4 * 64 * 8 * 2;
+    const bool cached = rt->conv_const_weights != 0;
+    const void *packed = nullptr;
+    hipStream_t pack_stream = rt->stream;
+    bool need_pack = true;
+    if (cached) {
+        packed = wcache_lookup(rt, w, (int)f, (int)c, (int)(r * s), 2);
+        if (!packed) {
+            void *buf = nullptr;
+            int st = wcache_insert(rt, w, (size_t)f * c * r * s * 2, (int)f, (int)c, (int)(r * s), 2, w_bytes, &buf, &pack_stream);
+            if (st != INFINI_ROCM_OK)
+                return st;
+            packed = buf;
+        } else {
+            need_pack = false;
+        }
+    } else {
+        void *ws = nullptr;
+        int st = infini_rocm_workspace(rt, w_bytes, &ws);
+        if (st != INFINI_ROCM_OK)
+            return st;
+        packed = ws;
+    }
+    if (need_pack) {
+        hipLaunchKernelGGL(stem_pack_w_kernel, dim3((unsigned)(w_bytes / 2 / 256)), dim3(256), 0, pack_stream, (const unsigned short *)w,
+                           (unsigned short *)const_cast<void *>(packed));
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) {
+            if (cached)
+                wcache_forget(rt, packed);
+            IROCM_FAIL(INFINI_ROCM_HIP_ERROR, "launch of stem_pack_w failed: %s", hipGetErrorString(e));
+        }
+        if (cached) {
+            int st = wcache_commit(rt, pack_stream);
+            if (st != INFINI_ROCM_OK) {
+                wcache_forget(rt, packed);
+                return st;
+            }
+        }
+    }
+    p.x = (const unsigned short *)x;
+    p.wp = (const unsigned short *)packed;
+    p.bias = (const unsigned short *)bias;
+    p.y = (unsigned short *)y;
+    const unsigned grid = (unsigned)(n * p.tiles_r * p.tiles_c);
+    if (dtype == INFINI_DT_F16) {
+        IROCM_LDS_ATTR(conv_stem_pool_kernel<F16Traits>, kStemLds, rt);
+        hipLaunchKernelGGL(conv_stem_pool_kernel<F16Traits>, dim3(grid), dim3(256), kStemLds, rt->stream, p);
+    } else {
+        IROCM_LDS_ATTR(conv_stem_pool_kernel<Bf16Traits>, kStemLds, rt);
+        hipLaunchKernelGGL(conv_stem_pool_kernel<Bf16Traits>, dim3(grid), dim3(256), kStemLds, rt->stream, p);
+    }
+    IROCM_LAUNCH_CHECK("conv_stem_pool");
+    rt->last_conv_route = "stem_pool";
+    return INFINI_ROCM_OK;
+}

@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const T *__restrict__ 
 template <typename T, int RB>
 __global__ __launch_bounds__(256) void reduce_short_rows_kernel(const T *__restrict__ x, T *__restrict__ y, long rows, int n,
                                                                 float scale) {
-    extern __shared__ float rbuf[]; // RB * n
+    extern __shared__ __attribute__((aligned(16))) unsigned char rbuf_raw[]; // RB * n elements of T (kept in the storage type:
+    T *rbuf = reinterpret_cast<T *>(rbuf_raw);                               //  25 KB per block at n = 49 f16 -> 6 blocks per CU)
     constexpr int VEC = 16 / (int)sizeof(T);
     const long nblk = (rows + RB - 1) / RB;
     for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
@@ -81,20 +82,16 @@ __global__ __launch_bounds__(256) void reduce_short_rows_kernel(const T *__restr
         const T *src = x + row0 * n;
         const bool al = (((uintptr_t)src) & 15) == 0;
         const int nv = al ? cnt / VEC : 0;
-        for (int v = threadIdx.x; v < nv; v += 256) {
-            const PackN<T, VEC> pk = reinterpret_cast<const PackN<T, VEC> *>(src)[v];
-#pragma unroll
-            for (int j = 0; j < VEC; ++j)
-                rbuf[v * VEC + j] = LdSt<T>::ld(&pk.v[j]);
-        }
+        for (int v = threadIdx.x; v < nv; v += 256)
+            reinterpret_cast<PackN<T, VEC> *>(rbuf)[v] = reinterpret_cast<const PackN<T, VEC> *>(src)[v];
         for (int i = nv * VEC + threadIdx.x; i < cnt; i += 256)
-            rbuf[i] = LdSt<T>::ld(src + i);
+            rbuf[i] = src[i];
         __syncthreads();
         if ((int)threadIdx.x < nrows) {
             float s = 0.f;
-            const float *r = rbuf + threadIdx.x * n;
+            const T *r = rbuf + threadIdx.x * n;
             for (int k = 0; k < n; ++k)
-                s += r[k];
+                s += LdSt<T>::ld(r + k);
             LdSt<T>::st(y + row0 + threadIdx.x, s * scale);
         }
         __syncthreads();
@@ -183,7 +180,7 @@ static int reduce_dispatch(infiniRocmRuntime_t rt, const void *x, void *y, int n
         constexpr int RB = 256;
         long g = ceil_div(p.nout, RB);
         if (g > (long)rt->num_cu * 8) g = (long)rt->num_cu * 8;
-        hipLaunchKernelGGL((reduce_short_rows_kernel<T, RB>), dim3((unsigned)g), dim3(256), (size_t)RB * p.nred * sizeof(float), rt->stream,
+        hipLaunchKernelGGL((reduce_short_rows_kernel<T, RB>), dim3((unsigned)g), dim3(256), (size_t)RB * p.nred * sizeof(T), rt->stream,
                            (const T *)x, (T *)y, p.nout, (int)p.nred, p.scale);
     } else if (trailing && p.nred >= 64) {
         hipLaunchKernelGGL((reduce_rows_kernel<T>), dim3((unsigned)ceil_div(p.nout, 4)), dim3(256), 0,

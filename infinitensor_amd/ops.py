@@ -482,6 +482,21 @@ def conv2d(rt: RocmRuntime, x: torch.Tensor, w: torch.Tensor, ph: int = 0, pw: i
     return out
 
 
+def conv2d_pool(rt: RocmRuntime, x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, ph: int, pw: int, sh: int, sw: int,
+                pool_k: int, pool_s: int, pool_p: int, act: int = 1, out: torch.Tensor | None = None) -> torch.Tensor:
+    """MaxPool(act(conv2d(x, w) + bias)) as one launch (infini_rocm_conv2d_pool: the 7 x 7 / 2 stem of a CNN); raises where the
+    library does not serve the shape."""
+    n, c, h, wd = x.shape
+    f, cpg, r, s = w.shape
+    oh, ow = (h + 2 * ph - r) // sh + 1, (wd + 2 * pw - s) // sw + 1
+    p_h, p_w = (oh + 2 * pool_p - pool_k) // pool_s + 1, (ow + 2 * pool_p - pool_k) // pool_s + 1
+    if out is None:
+        out = torch.empty((n, f, p_h, p_w), dtype=x.dtype, device=x.device)
+    check(lib().infini_rocm_conv2d_pool(rt.handle, dtype_of(x), _ptr(x), _ptr(w), _ptr(bias), _ptr(out), n, c, h, wd, f, r, s, ph, pw, sh, sw,
+                                        1, 1, c // cpg, int(act), int(pool_k), int(pool_s), int(pool_p)))
+    return out
+
+
 def conv_transpose2d(rt: RocmRuntime, x: torch.Tensor, w: torch.Tensor, ph: int = 0, pw: int = 0, sh: int = 1, sw: int = 1,
                      dh: int = 1, dw: int = 1, oph: int = 0, opw: int = 0, groups: int = 1,
                      bias: torch.Tensor | None = None, act: int = 0) -> torch.Tensor:

@@ -474,7 +474,7 @@ class FusionPlanner {
         if (type == OpType::Transpose)
             return planAttentionFromTranspose(i) || planIntoCopy(i);
         if (type == OpType::Conv)
-            return planConv(i);
+            return planConvStemPool(i) || planConv(i);
         if (type == OpType::Silu && planSiluMul(i))
             return true;
         if (type == OpType::Relu && planReluPool(i))
@@ -1604,6 +1604,70 @@ class FusionPlanner {
     // ============================================================================================================
     // Conv chains
     // ============================================================================================================
+    // Conv(7 x 7 / 2, C = 3 -> F = 64) -> Reshape(bias) -> Add -> Relu -> MaxPool(3 x 3 / 2 / 1): the stem of a CNN as ONE launch
+    // (csrc/conv_stem.hip): the conv tile is pooled out of LDS, the 205 MB (batch 128) the conv used to write and the pool to
+    // re-read never exist. Only the exact chain the library serves (infini_rocm_conv2d_pool_supported); every intermediate has
+    // one reader; the pooled output must not sit on anything the conv reads.
+    bool planConvStemPool(size_t i) {
+        static const bool on = envOn("INFINI_ROCM_FUSE_STEM_POOL");
+        if (!on)
+            return false;
+        auto conv = as<ConvObj>(ops[i]);
+        const Tensor x = conv->getInputs(0), w = conv->getInputs(1), y = conv->getOutput();
+        if (y->getDims().size() != 4)
+            return false;
+        const auto [nb, ch, hh, wd, ff, rr, ss] = conv->getNCHWFRS();
+        const auto [ph, pw, sh, sw, dh, dw] = conv->getPadStrideDilation();
+        Operator add = userOfType(y, OpType::Add, i);
+        if (!add)
+            return false;
+        const Tensor other = otherOf(add, y);
+        if (other == y || !isChannelBias(other->getDims(), ff) || !(other->getDType() == y->getDType()) ||
+            add->getOutput()->getDims() != y->getDims())
+            return false;
+        Operator relu = userOfType(add->getOutput(), OpType::Relu, pos(add));
+        if (!relu)
+            return false;
+        Operator pl = userOfType(relu->getOutput(), OpType::MaxPool, pos(relu));
+        if (!pl)
+            return false;
+        auto pool = as<PoolingObj>(pl);
+        const auto [pn, pc, phh, pww, kh, kw] = pool->getNCHWRS();
+        const auto [pph, ppw, psh, psw, pdh, pdw] = pool->getPadStrideDilation();
+        if (kh != kw || pph != ppw || psh != psw || pdh != 1 || pdw != 1 || pool->getCeilMode() != 0 || ph != pw || sh != sw)
+            return false;
+        if (!infini_rocm_conv2d_pool_supported(x->getDTypeIndex(), ch, hh, wd, ff, rr, ss, ph, pw, sh, sw, dh, dw, conv->getNumGroups(), 1, kh,
+                                               psh, pph))
+            return false;
+        std::vector<size_t> members{i}, dead;
+        std::vector<Read> reads{{x, i}, {w, i}};
+        const Tensor root = aliasRoot(other, dead); // the front-end's Reshape(bias, [1, F, 1, 1])
+        const Tensor bias = root ? root : other;
+        for (size_t dp : dead)
+            members.push_back(dp);
+        if (!root)
+            reads.push_back({other, pos(add)});
+        members.push_back(pos(add));
+        members.push_back(pos(relu));
+        members.push_back(pos(pl));
+        std::sort(members.begin(), members.end());
+        const size_t slot = pos(pl);
+        const Tensor out = pool->getOutput();
+        if (overlaps(out, x) || overlaps(out, w) || overlaps(out, bias) || !(out->getDType() == x->getDType()) ||
+            !al16((uintptr_t)x->getRawDataPtr<void *>()) || !al16((uintptr_t)out->getRawDataPtr<void *>()) || !readsSurvive(reads, slot, members))
+            return false;
+        noteLateReads(reads, slot);
+        const RocmRuntimeObj *r = R;
+        const int n_ = nb, c_ = ch, h_ = hh, w_ = wd, f_ = ff, r_ = rr, s_ = ss, ph_ = ph, pw_ = pw, sh_ = sh, sw_ = sw, dh_ = dh, dw_ = dw;
+        const int groups = conv->getNumGroups(), pk = kh, ps = psh, pp = pph;
+        emit(slot, members, "conv+bias+relu+maxpool (stem)", true, [=] {
+            ConstWeightsScope constWeights(r->handle(), w);
+            ROCM_CALL(infini_rocm_conv2d_pool(r->handle(), x->getDTypeIndex(), dataPtr(x), dataPtr(w), dataPtr(bias), dataPtr(out), n_, c_, h_, w_,
+                                              f_, r_, s_, ph_, pw_, sh_, sw_, dh_, dw_, groups, 1, pk, ps, pp));
+        });
+        return true;
+    }
+
     bool planConv(size_t i) {
         auto conv = as<ConvObj>(ops[i]);
         const Tensor x = conv->getInputs(0), w = conv->getInputs(1);

@@ -218,3 +218,36 @@ def test_headline_gemm_rows_vs_oracle(rt):
     got = f64(c[ridx])
     # bf16 output: one storage ulp (2^-8 relative) on top of fp32 accumulation over k = 4096 products of N(0,1) values
     assert np.allclose(got, want, rtol=2.0 ** -7, atol=0.35), np.abs(got - want).max()
+
+
+def test_resnet50_stem_and_pool_at_batch_128_sampled_vs_oracle(rt):
+    """The stem as the bench graph runs it since round 4: Conv(7 x 7 / 2) + bias + ReLU + MaxPool(3 x 3 / 2) as ONE launch
+    (csrc/conv_stem.hip) at N = 128, 224 x 224: ~2000 sampled POOLED outputs against the oracle (each the maximum of 9 conv
+    pixels, each a 147-term dot product: R.conv2d_at on the 9 positions), incl. image 0 / 127, the plane corners and the seam
+    between the two column tiles of a row (pooled columns 27 / 28)."""
+    g = torch.Generator(device="cuda").manual_seed(224)
+    x = (torch.rand((BATCH, 3, 224, 224), device="cuda", generator=g) * 2 - 0.5).to(torch.float16)
+    w = (torch.randn((64, 3, 7, 7), device="cuda", generator=g) * (2 / 147) ** 0.5).to(torch.float16)
+    b = (torch.randn((64,), device="cuda", generator=g) * 0.2).to(torch.float16)
+    y = ops.conv2d_pool(rt, x, w, b, 3, 3, 2, 2, 3, 2, 1)
+    assert ops.conv_last_route(rt) == "stem_pool" and tuple(y.shape) == (BATCH, 64, 56, 56)
+    rt.sync()
+    rng = np.random.default_rng(7)
+    co = sample_coords(rng, BATCH, 64, 56, 56, 1500)
+    seam = np.array([(n_, f_, py, px) for n_ in (0, 64, 127) for f_ in (0, 31, 63) for py in (0, 1, 2, 27, 55) for px in (26, 27, 28, 29)])
+    co = np.concatenate([co, seam], 0)
+    xh, wh, bh = x.cpu().numpy(), w.cpu().numpy(), b.cpu().numpy().astype(np.float64)
+    best = np.full(len(co), -np.inf)
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            cy, cx = 2 * co[:, 2] + dy, 2 * co[:, 3] + dx
+            ok = (cy >= 0) & (cy < 112) & (cx >= 0) & (cx < 112)
+            cc = np.stack([co[:, 0], co[:, 1], np.clip(cy, 0, 111), np.clip(cx, 0, 111)], 1)
+            v = R.conv2d_at(xh, wh, cc, 3, 3, 2, 2, 1, 1) + bh[co[:, 1]]
+            v = np.maximum(v.astype(np.float16).astype(np.float64), 0)
+            best = np.where(ok, np.maximum(best, v), best)
+    ni, fi, py, px = (torch.from_numpy(co[:, i]).cuda() for i in range(4))
+    got = y[ni, fi, py, px].float().cpu().numpy().astype(np.float64)
+    bad = ~np.isclose(got, best, rtol=3e-3, atol=3e-3)
+    assert not bad.any(), (int(bad.sum()), co[bad][:5].tolist(), got[bad][:5], best[bad][:5])
+    assert bool(torch.isfinite(y).all()) and float(y.float().min()) >= 0

@@ -587,3 +587,41 @@ def test_conv_pointwise_gemm_mode_does_not_write_outside_its_output(rt):
     assert torch.all(buf[n * f * h * h:] == 3.0).item()
     ref = torch.einsum("fc,nchw->nfhw", w.view(f, c).float(), x.float())
     assert torch.allclose(out.float(), ref, rtol=3e-3, atol=3e-3)
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("cfg", [(2, 32, 32), (3, 64, 40), (1, 224, 224), (2, 70, 120), (1, 23, 16), (2, 9, 8)])
+def test_conv_stem_pool_fused_vs_oracle(rt, cfg, dt):
+    """infini_rocm_conv2d_pool: Conv(7 x 7 / 2 / 3, C = 3 -> F = 64) + bias + ReLU + MaxPool(3 x 3 / 2 / 1) as one launch
+    (csrc/conv_stem.hip) against the oracle's conv2d -> + bias -> round -> relu -> pool2d, and against the library's own
+    unfused chain (conv2d with the bias / ReLU epilogue, then max_pool): whole planes, ragged tiles in both directions (the
+    workgroup tile is 2 x 28 pooled outputs), odd conv / pool extents, an image smaller than one tile."""
+    n, h, w = cfg
+    rng = np.random.default_rng(abs(hash(cfg)) % 2 ** 32)
+    x = rng.random((n, 3, h, w)).astype(np.float32) * 2 - 0.5
+    wt = (rng.standard_normal((64, 3, 7, 7)) * np.sqrt(2 / 147)).astype(np.float32)
+    b = (rng.standard_normal(64) * 0.2).astype(np.float32)
+    xd, wd, bd = dev(x, TD[dt]), dev(wt, TD[dt]), dev(b, TD[dt])
+    y = ops.conv2d_pool(rt, xd, wd, bd, 3, 3, 2, 2, 3, 2, 1)
+    assert ops.conv_last_route(rt) == "stem_pool"
+    conv = R.conv2d(R.round_to(x, dt), R.round_to(wt, dt), 3, 3, 2, 2, 1, 1) + R.round_to(b, dt).reshape(1, 64, 1, 1)
+    want = R.pool2d(np.maximum(R.round_to(conv, dt), 0), "max", 3, 3, 1, 1, 1, 1, 2, 2, 0)
+    assert tuple(y.shape) == want.shape
+    tol = {"f16": 3e-3, "bf16": 2.4e-2}[dt]
+    assert np.allclose(host(y), want, rtol=tol, atol=tol), np.abs(host(y) - want).max()
+    chain = ops.max_pool(rt, ops.conv2d(rt, xd, wd, 3, 3, 2, 2, bias=bd, act=1), 3, 3, 1, 1, 1, 1, 2, 2, 0)
+    assert np.allclose(host(y), host(chain), rtol=tol, atol=tol)
+
+
+def test_conv_stem_pool_declines_what_it_does_not_serve(rt):
+    import torch
+
+    x = torch.zeros((1, 3, 32, 32), dtype=torch.float16, device="cuda")
+    w5 = torch.zeros((64, 3, 5, 5), dtype=torch.float16, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.conv2d_pool(rt, x, w5, None, 2, 2, 2, 2, 3, 2, 1)
+    w7 = torch.zeros((64, 3, 7, 7), dtype=torch.float16, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.conv2d_pool(rt, x, w7, None, 3, 3, 2, 2, 2, 2, 0)  # another pooling window
+    with pytest.raises(RuntimeError):
+        ops.conv2d_pool(rt, x.float(), w7.float(), None, 3, 3, 2, 2, 3, 2, 1)  # fp32 keeps the separate kernels

@@ -1505,3 +1505,38 @@ def test_forwarding_declined_when_another_branch_owns_the_convs_block(B, rocm):
             rocm.set_fusion(True)
     assert np.allclose(res[True], want, rtol=4e-3, atol=4e-3), np.abs(res[True] - want).max()
     assert np.allclose(res[True], res[False], rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("code,npdt", [(F16, np.float16)])
+def test_stem_chain_is_one_launch(B, rocm, code, npdt):
+    """Conv(7 x 7 / 2) -> Reshape(bias) -> Add -> Relu -> MaxPool(3 x 3 / 2 / 1) — ResNet's stem in the front-end's form — planned
+    as ONE launch (conv_stem.hip: the conv tile is pooled out of LDS) and equal to the per-operator run and the oracle."""
+    rng = np.random.default_rng(61)
+    x = (rng.random((2, 3, 64, 64)) * 2 - 0.5).astype(npdt)
+    w = (rng.standard_normal((64, 3, 7, 7)) * np.sqrt(2 / 147)).astype(npdt)
+    b = (rng.standard_normal(64) * 0.2).astype(npdt)
+    res = {}
+    for on in (True, False):
+        rocm.set_fusion(on)
+        try:
+            h = B.GraphHandler(rocm)
+            tx, tw, tb = h.tensor([2, 3, 64, 64], code), h.tensor([64, 3, 7, 7], code), h.tensor([64], code)
+            tx.set_input()
+            tw.set_weight()
+            tb.set_weight()
+            y = h.relu(h.add(h.conv(tx, tw, None, 3, 3, 2, 2, 1, 1), h.reshape(tb, None, [1, 64, 1, 1]), None), None)
+            out = h.relu(h.maxPool(y, None, 3, 3, 1, 1, 1, 1, 2, 2, 0), None)  # (a consumer behind the pool)
+            h.data_malloc()
+            for t_, a_ in ((tx, x), (tw, w), (tb, b)):
+                put(t_, a_)
+            if on:
+                plan = h.rocm_fusion_plan()
+                assert any("conv+bias+relu+maxpool (stem)" in p for p in plan), plan
+            h.run()
+            res[on] = get(out).astype(np.float64)
+        finally:
+            rocm.set_fusion(True)
+    conv = R.conv2d(x.astype(np.float64), w.astype(np.float64), 3, 3, 2, 2, 1, 1) + b.astype(np.float64).reshape(1, 64, 1, 1)
+    want = R.pool2d(np.maximum(conv.astype(npdt).astype(np.float64), 0), "max", 3, 3, 1, 1, 1, 1, 2, 2, 0)
+    assert np.allclose(res[True].reshape(want.shape), want, rtol=3e-3, atol=3e-3), np.abs(res[True].reshape(want.shape) - want).max()
+    assert np.allclose(res[True], res[False], rtol=3e-3, atol=3e-3)

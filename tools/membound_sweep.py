@@ -174,7 +174,26 @@ def cases(ops, rt, big: bool):
         y = torch.empty_like(a)
         return (lambda: ops.add_layer_norm(rt, a, b, g, be, 1e-12, False, out=y)), 3 * a.numel() * 2, f"[{n},768] f16 (a + b, then LayerNorm)"
 
-    return {"rope": rope, "rope_headsplit": rope_headsplit, "rmsnorm": rmsnorm, "add_rmsnorm": add_rmsnorm, "gather": gather,
+    def softmax_of(dt, name):
+        def make():
+            rows = 1048576 if big else 196608
+            x = torch.randn(rows, 512, device=dev).to(dt)
+            y = torch.empty_like(x)
+            return (lambda: ops.softmax(rt, x, 1, out=y)), 2 * x.numel() * x.element_size(), f"{rows}x512 {name}"
+        return make
+
+    def layernorm_of(dt, name):
+        def make():
+            rows = 524288 if big else 16384
+            x = torch.randn(rows, 768, device=dev).to(dt)
+            g_, b_ = torch.randn(768, device=dev).to(dt), torch.randn(768, device=dev).to(dt)
+            y = torch.empty_like(x)
+            return (lambda: ops.layer_norm(rt, x, g_, b_, 1e-5, -1, out=y)), 2 * x.numel() * x.element_size(), f"{rows}x768 {name}"
+        return make
+
+    return {"softmax": softmax_of(f16, "f16"), "softmax_f32": softmax_of(torch.float32, "f32"),
+            "layernorm": layernorm_of(f16, "f16"), "layernorm_f32": layernorm_of(torch.float32, "f32"),
+            "rope": rope, "rope_headsplit": rope_headsplit, "rmsnorm": rmsnorm, "add_rmsnorm": add_rmsnorm, "gather": gather,
             "transpose_0213": transpose, "transpose_0132": transpose_last, "add_bias_nchw": add_bias_nchw, "add": add, "relu": relu,
             "gelu": gelu, "maxpool": maxpool, "reduce_mean": reduce_mean, "where": where, "concat": concat, "split": split, "cast": cast,
             "silu_mul": silu_mul, "add_layernorm": add_layernorm}
