@@ -171,6 +171,12 @@ int infini_rocm_matmul(infiniRocmRuntime_t rt, int dtype, const void *a, const v
                        int trans_a, int trans_b, int64_t stride_a, int64_t stride_b,
                        int64_t bias_stride_b, int64_t bias_stride_m, int64_t bias_stride_n,
                        int act);
+/* MatmulObj::getComputeType() (reference: matmul.cc:51-64): how an fp32 MatMul forms its PRODUCTS. 0 = "default" and "tf32":
+ * exact fp32 (gfx950 has no xf32 matrix instruction; more accurate than asked). 1 = "bf16", 2 = "fp16": A and B are converted
+ * once (workspace) and multiplied on the 16-bit MFMA path with fp32 accumulation and fp32 output (~10x the exact kernel's
+ * rate) wherever that kernel serves the shape (K % 64 == 0, 16-byte aligned rows), else exactly. Sticky per runtime until
+ * reset to 0; 16-bit MatMuls ignore it. */
+int infini_rocm_matmul_set_compute_type(infiniRocmRuntime_t rt, int compute_type);
 /* MatMul whose result is stored head-split: the [m x n] block of every batch entry is written as
  * [m / seq][n / head_dim][seq][head_dim], i.e. MatMul -> Reshape([B, S, H, D]) -> Transpose(0, 2, 1, 3) — the q / k / v
  * projection of a transformer layer as ONNX exporters emit it (reference: matmul.cc + CopyCuda reshape.cc:4-13 +

@@ -134,6 +134,7 @@ def lib() -> C.CDLL:
     sig("infini_rocm_comm_init", [vp, C.c_char_p, i32, i32])
     sig("infini_rocm_comm_unique_id", [vp, C.POINTER(sz)])
     sig("infini_rocm_comm_init_id", [vp, vp, sz, i32, i32])
+    sig("infini_rocm_matmul_set_compute_type", [vp, i32])
     sig("infini_rocm_comm_init_direct", [vp, C.c_char_p, i32, i32])
     sig("infini_rocm_comm_set_algo", [vp, i32])
     sig("infini_rocm_comm_check", [vp])

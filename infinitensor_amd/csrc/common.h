@@ -135,6 +135,7 @@ struct infiniRocmRuntime {
     uint64_t workspace_epoch = 0; // bumped whenever `workspace` changes
     bool capturing = false;
     int matmul_variant = -1;
+    int matmul_compute_type = 0; // 0 exact fp32 products, 1 bf16, 2 fp16 (fp32 MatMul only; MatmulObj::getComputeType())
     int last_matmul_variant = -1; // the variant the most recent matmul call actually launched
     const char *last_conv_route = "none"; // which implementation the most recent conv2d call launched
     int conv_variant = -1;

@@ -13,10 +13,13 @@
 //     2 x0 - 3, so a run starts on an even element). 21 (c, r) pairs -> 6 k-steps of 4 pairs (3 zero-weight pairs).
 //   * A = the weights, re-packed ONCE (packed-weight cache) into fragment order [k-step][filter tile][lane][8]: a lane keeps all
 //     24 fragments (96 VGPRs) for the whole workgroup.
+//   * persistent workgroups (two per CU) walk the tiles: weights and bias are fetched once per workgroup, not once per tile
+//     (the first version re-read its 96 KB of fragments per tile and took 163 us).
 //   * input tile: 3 channels x 15 rows x 120 columns, pitch 160 elements (row stride = 16 banks: the four (c, r) pairs a wave
-//     reads at once hit disjoint banks); conv tile for the pool: even / odd / even-shifted column planes so that the three taps
-//     of 8 adjacent pooled columns are three aligned 16-byte reads and v_pk_max_u16 does the rest (ReLU made everything >= 0:
-//     unsigned 16-bit order = float order for f16 and bf16, and padding with 0 equals MaxPool's -inf padding).
+//     reads at once hit disjoint banks); conv tile for the pool: [row][column][filter] with a pixel pitch of 72 elements — a
+//     lane's four consecutive filters of a pixel are ONE conflict-free 8-byte LDS store, and a pooled output's 3 x 3 window
+//     of 8 filters is nine aligned 16-byte reads reduced by v_pk_max_u16 (ReLU made everything >= 0: unsigned 16-bit order =
+//     float order for f16 and bf16, and padding with 0 equals MaxPool's -inf padding).
 // Served: C = 3, F = 64, 7 x 7 / 2 / pad 3 / dilation 1, groups 1, activation ReLU, pool 3 x 3 / 2 / pad 1 / dilation 1 /
 // floor mode, W % 8 == 0, 16-byte aligned tensors. Everything else keeps the separate kernels (the query below says which).
 // A zero weight multiplies the 8th element of every run: an Inf / NaN pixel therefore poisons the conv pixel to its LEFT as
@@ -33,10 +36,9 @@ constexpr int kStemCR = 2 * kStemPR + 1, kStemCC = 2 * kStemPC + 1; // conv rows
 constexpr int kStemIR = 2 * kStemCR + 5; // input rows: 15
 constexpr int kStemPitch = 160;     // input tile row pitch (elements)
 constexpr int kStemInElems = 3 * kStemIR * kStemPitch; // 7200
-constexpr int kStemPlane = 32;      // columns of one conv-tile plane row (29 / 28 used)
-constexpr int kStemFStride = kStemCR * kStemPlane + 8; // 168 elements: 4 filters apart = 16 banks apart
-constexpr int kStemPlaneElems = kStemF * kStemFStride; // 10752
-constexpr int kStemLds = (kStemInElems + 3 * kStemPlaneElems) * 2; // 78,912 B: two workgroups per CU
+constexpr int kStemPix = 72;        // conv tile: elements per pixel (64 filters + 8 pad: 36 dwords -> conflict-free b64 stores)
+constexpr int kStemConvElems = kStemCR * kStemCC * kStemPix; // 20,520
+constexpr int kStemLds = (kStemInElems + kStemConvElems) * 2; // 55,440 B: two workgroups per CU
 
 struct StemArgs {
     const unsigned short *x;   // [n][3][h][w]
@@ -64,20 +66,11 @@ __global__ __launch_bounds__(256) void stem_pack_w_kernel(const unsigned short *
 template <typename Tr>
 __global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(StemArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
-    unsigned short *tin = lds;                       // [3][15][160]
-    unsigned short *pev = lds + kStemInElems;        // even conv columns   [64][5][32] (+ pad)
-    unsigned short *pod = pev + kStemPlaneElems;     // odd conv columns
-    unsigned short *pes = pod + kStemPlaneElems;     // even columns shifted by one: pes[k] = pev[k + 1]
+    unsigned short *tin = lds;                  // [3][15][160]
+    unsigned short *tcv = lds + kStemInElems;   // [5][57][72]: conv + bias, rounded, ReLU'd
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l15 = lane & 15, g4 = lane >> 4;
-    int b = blockIdx.x;
-    const int tc = b % p.tiles_c;
-    b /= p.tiles_c;
-    const int tr = b % p.tiles_r, img = b / p.tiles_r;
-    const int p0 = tr * kStemPR, c0 = tc * kStemPC;  // first pooled row / column
-    const int y0 = 2 * p0 - 1, x0 = 2 * c0 - 1;      // first conv row / column of the tile
-    const int iy0 = 2 * y0 - 3, ix0 = 2 * x0 - 3;    // first input row / column of the tile (ix0 is odd)
 
-    // ---- weights: 24 fragments per lane, resident -------------------------------------------------------------------
+    // ---- weights: 24 fragments per lane, resident for every tile this workgroup walks ----------------------------------
     s16x8_t af[kStemKS][4];
 #pragma unroll
     for (int ks = 0; ks < kStemKS; ++ks)
@@ -90,32 +83,6 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(StemArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             bv[mt][r] = p.bias ? Tr::to_f32(p.bias[mt * 16 + 4 * g4 + r]) : 0.f;
-
-    // ---- input tile -----------------------------------------------------------------------------------------------
-    for (int i = t; i < kStemInElems / 8; i += 256)
-        *(s16x8_t *)(tin + i * 8) = s16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
-    __syncthreads();
-    {
-        // 16-byte chunks of the image rows: chunk m holds input columns 8 m .. 8 m + 7; the tile needs columns ix0 .. ix0 + 119
-        const int m_first = ix0 >= 0 ? ix0 / 8 : -1; // floor(ix0 / 8): ix0 = -5 for the first column tile, positive afterwards
-        const unsigned short *X = p.x + (long)img * 3 * p.h * p.w;
-        for (int i = t; i < 3 * kStemIR * 16; i += 256) {
-            const int m = m_first + (i & 15), rowc = i >> 4; // rowc = c * 15 + j
-            const int c = rowc / kStemIR, j = rowc - c * kStemIR;
-            const int iy = iy0 + j, ix = 8 * m;
-            if (iy < 0 || iy >= p.h || ix < 0 || ix >= p.w)
-                continue; // stays zero (padding)
-            const s16x8_t v = *(const s16x8_t *)(X + ((long)c * p.h + iy) * p.w + ix);
-            unsigned short *dst = tin + rowc * kStemPitch + (ix - ix0); // odd element offset: element stores
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (ix - ix0 + e >= 0 && ix - ix0 + e < kStemPitch)
-                    dst[e] = (unsigned short)v[e];
-        }
-    }
-    __syncthreads();
-
-    // ---- conv tile: wave wv takes the 16-column block wv of each of the 5 conv rows -------------------------------------
     int qoff[kStemKS]; // element offset of pair q = 4 ks + g4 inside the tile (padding pairs read pair 0: finite data x weight 0)
 #pragma unroll
     for (int ks = 0; ks < kStemKS; ++ks) {
@@ -123,75 +90,103 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(StemArgs p) {
         qoff[ks] = q < 21 ? ((q / 7) * kStemIR + q % 7) * kStemPitch : 0;
     }
     const int xl = wv * 16 + l15; // conv column inside the tile (0 .. 63; 57 used)
+    const int ntiles = p.n * p.tiles_r * p.tiles_c;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int b = tile;
+        const int tc = b % p.tiles_c;
+        b /= p.tiles_c;
+        const int tr = b % p.tiles_r, img = b / p.tiles_r;
+        const int p0 = tr * kStemPR, c0 = tc * kStemPC;  // first pooled row / column
+        const int y0 = 2 * p0 - 1, x0 = 2 * c0 - 1;      // first conv row / column of the tile
+        const int iy0 = 2 * y0 - 3, ix0 = 2 * x0 - 3;    // first input row / column of the tile (ix0 is odd)
+
+        // ---- input tile ---------------------------------------------------------------------------------------------
+        for (int i = t; i < kStemInElems / 8; i += 256)
+            *(s16x8_t *)(tin + i * 8) = s16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        __syncthreads(); // (also: every reader of the previous tile's LDS images is done)
+        {
+            // 16-byte chunks of the image rows: chunk m holds input columns 8 m .. 8 m + 7; the tile needs columns ix0 .. ix0 + 119
+            const int m_first = ix0 >= 0 ? ix0 / 8 : -1; // floor(ix0 / 8): ix0 = -5 for the first column tile, positive afterwards
+            const unsigned short *X = p.x + (long)img * 3 * p.h * p.w;
+            for (int i = t; i < 3 * kStemIR * 16; i += 256) {
+                const int m = m_first + (i & 15), rowc = i >> 4; // rowc = c * 15 + j
+                const int c = rowc / kStemIR, j = rowc - c * kStemIR;
+                const int iy = iy0 + j, ix = 8 * m;
+                if (iy < 0 || iy >= p.h || ix < 0 || ix >= p.w)
+                    continue; // stays zero (padding)
+                const s16x8_t v = *(const s16x8_t *)(X + ((long)c * p.h + iy) * p.w + ix);
+                unsigned short *dst = tin + rowc * kStemPitch + (ix - ix0); // odd element offset: element stores
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (ix - ix0 + e >= 0 && ix - ix0 + e < kStemPitch)
+                        dst[e] = (unsigned short)v[e];
+            }
+        }
+        __syncthreads();
+
+        // ---- conv tile: wave wv takes the 16-column block wv of each of the 5 conv rows ---------------------------------
 #pragma unroll 1
-    for (int yi = 0; yi < kStemCR; ++yi) {
-        f32x4 acc[4];
+        for (int yi = 0; yi < kStemCR; ++yi) {
+            const unsigned short *base = tin + 2 * yi * kStemPitch + 2 * xl;
+            u32x4_t bq[kStemKS];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-            acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const unsigned short *base = tin + 2 * yi * kStemPitch + 2 * xl;
-#pragma unroll
-        for (int ks = 0; ks < kStemKS; ++ks) {
-            const unsigned *src = (const unsigned *)(base + qoff[ks]); // 4-byte aligned
-            const unsigned d0 = src[0], d1 = src[1], d2 = src[2], d3 = src[3];
-            const s16x8_t bf = __builtin_bit_cast(s16x8_t, u32x4_t{d0, d1, d2, d3});
+            for (int ks = 0; ks < kStemKS; ++ks) { // all six fragments first: the LDS latency is paid once per pixel tile
+                const unsigned *src = (const unsigned *)(base + qoff[ks]); // 4-byte aligned
+                bq[ks] = u32x4_t{src[0], src[1], src[2], src[3]};
+            }
+            f32x4 acc[4];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
-                acc[mt] = Tr::mfma(af[ks][mt], bf, acc[mt]);
-        }
-        // bias, round, ReLU -> the three column planes. Pixels outside the conv output (or past the tile's 57 columns) are 0.
-        const int gy = y0 + yi, gx = x0 + xl;
-        const bool live = xl < kStemCC && gy >= 0 && gy < p.oh && gx >= 0 && gx < p.ow;
-        const int k = xl >> 1;
+                acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+            for (int ks = 0; ks < kStemKS; ++ks) {
+                const s16x8_t bf = __builtin_bit_cast(s16x8_t, bq[ks]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                // round(relu(v)) == relu(round(v)): the bits the unfused Conv + Add -> Relu chain stores
-                float v = acc[mt][r] + bv[mt][r];
-                v = v > 0.f ? v : 0.f;
-                const unsigned short hv = live ? Tr::from_f32(v) : (unsigned short)0;
-                const int o = (mt * 16 + 4 * g4 + r) * kStemFStride + yi * kStemPlane;
-                if (xl < 64) {
-                    if (xl & 1) {
-                        pod[o + k] = hv;
-                    } else {
-                        pev[o + k] = hv;
-                        if (k > 0)
-                            pes[o + k - 1] = hv;
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[mt] = Tr::mfma(af[ks][mt], bf, acc[mt]);
+            }
+            // bias, ReLU, round -> [row][column][filter]: the lane's filters mt * 16 + 4 g4 .. + 3 of its pixel are 8 contiguous bytes.
+            // round(relu(v)) == relu(round(v)): the bits the unfused Conv + Add -> Relu chain stores. Pixels outside the conv
+            // output are 0 (= MaxPool's padding after a ReLU); columns 57 .. 63 of the block are never read.
+            const int gy = y0 + yi, gx = x0 + xl;
+            const bool live = gy >= 0 && gy < p.oh && gx >= 0 && gx < p.ow;
+            if (xl < kStemCC) {
+                unsigned short *dst = tcv + (yi * kStemCC + xl) * kStemPix + 4 * g4;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = acc[mt][r] + bv[mt][r];
+                        v[r] = (live && v[r] > 0.f) ? v[r] : 0.f;
                     }
+                    *(u32x2_t *)(dst + mt * 16) = u32x2_t{Tr::pack2(v[0], v[1]), Tr::pack2(v[2], v[3])};
                 }
             }
-    }
-    __syncthreads();
+        }
+        __syncthreads();
 
-    // ---- pool: (filter, pooled row, group of 8 pooled columns) -> 16 bytes --------------------------------------------------
-    typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
-    for (int i = t; i < kStemF * kStemPR * 4; i += 256) {
-        const int g = i & 3, pr = (i >> 2) % kStemPR, f = i / (4 * kStemPR);
-        const int prow = p0 + pr;
-        if (prow >= p.ph)
-            continue;
-        u16x8_t m = {0, 0, 0, 0, 0, 0, 0, 0};
+        // ---- pool: (pooled row, pooled column, 8 filters): nine 16-byte reads, packed unsigned max, 8 element stores ------------
+        typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
+        for (int i = t; i < kStemPR * kStemPC * 8; i += 256) {
+            const int pcl = i % kStemPC, rest = i / kStemPC, pr = rest % kStemPR, f8 = rest / kStemPR;
+            const int prow = p0 + pr, pc = c0 + pcl;
+            if (prow >= p.ph || pc >= p.pw)
+                continue;
+            u16x8_t m = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int o = f * kStemFStride + (2 * pr + dy) * kStemPlane + 8 * g;
-            const u16x8_t a = *(const u16x8_t *)(pev + o), bb = *(const u16x8_t *)(pod + o), c = *(const u16x8_t *)(pes + o);
-            m = __builtin_elementwise_max(m, __builtin_elementwise_max(__builtin_elementwise_max(a, bb), c));
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+                    m = __builtin_elementwise_max(m, *(const u16x8_t *)(tcv + ((2 * pr + dy) * kStemCC + 2 * pcl + dx) * kStemPix + f8 * 8));
+            unsigned short *dst = p.y + (((long)img * kStemF + f8 * 8) * p.ph + prow) * p.pw + pc;
+            const long fstride = (long)p.ph * p.pw;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                dst[e * fstride] = m[e];
         }
-        const int pc = c0 + 8 * g;
-        unsigned short *dst = p.y + (((long)img * kStemF + f) * p.ph + prow) * p.pw + pc;
-        const int ncol = min(min(8, kStemPC - 8 * g), p.pw - pc); // 8, or 4 in the last group, or what is left of the row
-        const u32x4_t mm = __builtin_bit_cast(u32x4_t, m);
-        if (ncol == 8 && ((((uintptr_t)dst) & 7) == 0)) {
-            *(u32x2_t *)dst = u32x2_t{mm[0], mm[1]};
-            *(u32x2_t *)(dst + 4) = u32x2_t{mm[2], mm[3]};
-        } else if (ncol == 4 && ((((uintptr_t)dst) & 7) == 0)) {
-            *(u32x2_t *)dst = u32x2_t{mm[0], mm[1]};
-        } else {
-            for (int e = 0; e < ncol; ++e)
-                dst[e] = m[e];
-        }
+        // (the next tile's zero fill touches `tin` only; its first barrier orders it against these reads of `tcv`)
     }
 }
 
@@ -279,7 +274,8 @@ extern "C" int infini_rocm_conv2d_pool(infiniRocmRuntime_t rt, int dtype, const 
     p.wp = (const unsigned short *)packed;
     p.bias = (const unsigned short *)bias;
     p.y = (unsigned short *)y;
-    const unsigned grid = (unsigned)(n * p.tiles_r * p.tiles_c);
+    const long tiles = (long)n * p.tiles_r * p.tiles_c;
+    const unsigned grid = (unsigned)std::min<long>(tiles, (long)rt->num_cu * 2); // persistent: two workgroups per CU
     if (dtype == INFINI_DT_F16) {
         IROCM_LDS_ATTR(conv_stem_pool_kernel<F16Traits>, kStemLds, rt);
         hipLaunchKernelGGL(conv_stem_pool_kernel<F16Traits>, dim3(grid), dim3(256), kStemLds, rt->stream, p);

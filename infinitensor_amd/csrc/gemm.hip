@@ -416,6 +416,7 @@ int launch_gemm256p_nt2(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bo
 int launch_gemm256p_trace(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, int nt, unsigned long long *trace);
 } // namespace g256p
 int launch_gemm256_splitk(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool a_kmajor, bool b_kmajor, int splits);
+int launch_gemm256_f32out(infiniRocmRuntime_t rt, int dtype16, const GemmArgs &p, bool a_kmajor, bool b_kmajor, int splits, float *planes);
 // implemented in gemm32.hip: the fp32 128^2 LDS-DMA tile kernel (v_mfma_f32_32x32x2_f32)
 bool fast32_supported(const GemmArgs &p, bool a_kmajor, bool b_kmajor);
 int launch_fast32(infiniRocmRuntime_t rt, GemmArgs p, bool b_kmajor, int small_tiles);
@@ -514,6 +515,18 @@ int infini_rocm_matmul_last_variant(infiniRocmRuntime_t rt, int *variant) {
     return INFINI_ROCM_OK;
 }
 
+// MatmulObj::getComputeType() (reference: matmul.cc:51-64 — "tf32" / "fp16" / "bf16" select cuBLAS compute types whose PRODUCTS
+// take reduced-precision inputs while sums and outputs stay fp32). 0 "default" / "tf32": exact fp32 products (gfx950 has no
+// xf32 MFMA; more accurate than asked). 1 "bf16", 2 "fp16": an fp32 MatMul converts A and B once into the workspace and runs the
+// 16-bit MFMA kernel with fp32 accumulation and fp32 output — the reference's opt-in ~10x over exact fp32. Sticky per runtime
+// (the plugin sets it around the one launch); ignored for 16-bit operands.
+int infini_rocm_matmul_set_compute_type(infiniRocmRuntime_t rt, int compute_type) {
+    IROCM_CHECK_ARG(rt, "NULL runtime");
+    IROCM_CHECK_ARG(compute_type >= 0 && compute_type <= 2, "compute type %d: 0 default / tf32, 1 bf16, 2 fp16", compute_type);
+    rt->matmul_compute_type = compute_type;
+    return INFINI_ROCM_OK;
+}
+
 int infini_rocm_matmul_set_variant(infiniRocmRuntime_t rt, int variant) {
     IROCM_CHECK_ARG(rt, "NULL runtime");
     IROCM_CHECK_ARG(variant >= -1 && variant < kNumVariants, "variant %d out of range", variant);
@@ -594,6 +607,34 @@ int infini_rocm_matmul_grouped(infiniRocmRuntime_t rt, int dtype, const void *a,
     p.hs_d = (int)head_dim;
     const bool akm = !trans_a, bkm = trans_b != 0;
 
+    if (dtype == INFINI_DT_F32 && rt->matmul_compute_type != 0 && head_dim == 0 && stride_c == 0) {
+        // reduced-precision products on request: 16-bit copies of A and B in the workspace, the 256^2 split-K kernel (raw fp32
+        // slice sums), fp32 output. Shapes it cannot serve (K % 64, alignment) keep the exact kernels: never LESS accurate than asked.
+        const int dt16 = rt->matmul_compute_type == 1 ? INFINI_DT_BF16 : INFINI_DT_F16;
+        const int64_t na = (stride_a ? batch : 1) * m * k, nb = (stride_b ? batch : 1) * n * k;
+        GemmArgs q = p;
+        const size_t a_bytes = ((size_t)na * 2 + 255) & ~(size_t)255, b_bytes = ((size_t)nb * 2 + 255) & ~(size_t)255;
+        const long tiles = ceil_div(m, 256) * ceil_div(n, 256) * batch;
+        int splits = (int)std::max<long>(1, rt->num_cu / tiles);
+        splits = std::min(splits, std::max(1, (int)(k / 512)));
+        splits = std::min(splits, 16);
+        const size_t plane_bytes = (size_t)splits * batch * m * n * sizeof(float);
+        char *ws = nullptr;
+        int st = infini_rocm_workspace(rt, a_bytes + b_bytes + plane_bytes, (void **)&ws);
+        if (st != INFINI_ROCM_OK)
+            return st;
+        q.a = ws;
+        q.b = ws + a_bytes;
+        if (gemm256_supported(q, akm, bkm) && (((uintptr_t)c) & 15) == 0) {
+            st = infini_rocm_cast(rt, INFINI_DT_F32, dt16, a, ws, na);
+            if (st == INFINI_ROCM_OK)
+                st = infini_rocm_cast(rt, INFINI_DT_F32, dt16, b, ws + a_bytes, nb);
+            if (st != INFINI_ROCM_OK)
+                return st;
+            rt->last_matmul_variant = 3;
+            return launch_gemm256_f32out(rt, dt16, q, akm, bkm, splits, (float *)(ws + a_bytes + b_bytes));
+        }
+    }
     int variant = rt->matmul_variant;
     if (dtype == INFINI_DT_F32) {
         // fp32: the LDS-DMA tile kernel (gemm32.hip; 128^2 or 64^2 tiles) when it can serve the operands and the problem has

@@ -458,6 +458,77 @@ int launch_gemm256_splitk(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, 
                                    : launch256_splitk<F16Traits>(rt, p, akm, bkm, splits);
 }
 
+// fp32 output from the split-K planes (the reduced-precision compute types of an fp32 MatMul, gemm.hip): out = act(sum_s
+// partial[s] + bias) with an fp32 bias, written as fp32. One thread per 4 consecutive columns when n % 4 == 0.
+__global__ __launch_bounds__(256) void splitk_reduce_f32_kernel(GemmArgs p) {
+    const long mn = (long)p.m * p.n, total = (long)p.batch * mn;
+    const float *bias = (const float *)p.bias;
+    float *C = (float *)p.c;
+    const bool vec = (p.n % 4 == 0);
+    const long items = vec ? total / 4 : total;
+    for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const long e0 = vec ? it * 4 : it;
+        const int cnt = vec ? 4 : 1;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < p.splitk; ++s) {
+            if (vec) {
+                const f32x4 t = *(const f32x4 *)(p.partial + s * total + e0);
+                v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+            } else {
+                v[0] += p.partial[s * total + e0];
+            }
+        }
+        const long ib = e0 / mn, rem = e0 - ib * mn;
+        const long row = rem / p.n, col = rem - row * p.n;
+        for (int r = 0; r < cnt; ++r) {
+            float x = v[r];
+            if (bias)
+                x += bias[ib * p.bias_b + row * p.bias_m + (col + r) * p.bias_n];
+            C[ib * p.c_bs + row * p.n + col + r] = apply_act(x, p.act);
+        }
+    }
+}
+
+// 16-bit operands (p.a / p.b), fp32 accumulation, fp32 OUTPUT (p.c): the split-K form of the 256^2 kernel whose slices write
+// raw fp32 sums. One slice, no bias, no activation: the single plane IS the result (the kernel writes p.c directly); otherwise
+// the planes go to `planes` (splits * batch * m * n floats, from the caller's workspace carve) and the fp32 reduce follows.
+template <typename Tr> static int launch256_f32out(infiniRocmRuntime_t rt, GemmArgs p, bool akm, bool bkm, int splits, float *planes) {
+    p.tiles_m = (int)ceil_div(p.m, g256::BM);
+    p.tiles_n = (int)ceil_div(p.n, g256::BN);
+    const int nk = p.k / g256::BK;
+    const int per = (nk + splits - 1) / splits;
+    splits = (nk + per - 1) / per;
+    const bool direct = splits == 1 && !p.bias && p.act == 0 && p.c_bs == (long)p.m * p.n;
+    p.splitk = splits;
+    p.partial = direct ? (float *)p.c : planes;
+    const unsigned grid = (unsigned)p.tiles_m * p.tiles_n * p.batch * splits;
+#define IROCM_G256F(AK, BK_)                                                                       \
+    do {                                                                                           \
+        auto kern = g256::gemm256_kernel<Tr, AK, BK_, true>;                                       \
+        IROCM_LDS_ATTR(kern, g256::LDS_BYTES, rt);                                                 \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), g256::LDS_BYTES, rt->stream, p);           \
+    } while (0)
+    if (akm && bkm) IROCM_G256F(true, true);
+    else if (akm && !bkm) IROCM_G256F(true, false);
+    else if (!akm && bkm) IROCM_G256F(false, true);
+    else IROCM_G256F(false, false);
+#undef IROCM_G256F
+    IROCM_LAUNCH_CHECK("gemm256_f32out");
+    if (direct)
+        return INFINI_ROCM_OK;
+    const long items = (long)p.batch * p.m * p.n / ((p.n % 4 == 0) ? 4 : 1);
+    long g = ceil_div(items, 256);
+    if (g > (long)rt->num_cu * 16) g = (long)rt->num_cu * 16;
+    hipLaunchKernelGGL(splitk_reduce_f32_kernel, dim3((unsigned)g), dim3(256), 0, rt->stream, p);
+    IROCM_LAUNCH_CHECK("splitk_reduce_f32");
+    return INFINI_ROCM_OK;
+}
+
+int launch_gemm256_f32out(infiniRocmRuntime_t rt, int dtype16, const GemmArgs &p, bool akm, bool bkm, int splits, float *planes) {
+    return dtype16 == INFINI_DT_BF16 ? launch256_f32out<Bf16Traits>(rt, p, akm, bkm, splits, planes)
+                                     : launch256_f32out<F16Traits>(rt, p, akm, bkm, splits, planes);
+}
+
 template <typename Tr> static int launch256(infiniRocmRuntime_t rt, GemmArgs p, bool akm, bool bkm) {
     p.tiles_m = (int)ceil_div(p.m, g256::BM);
     p.tiles_n = (int)ceil_div(p.n, g256::BN);

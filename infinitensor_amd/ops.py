@@ -159,6 +159,12 @@ def matmul(rt: RocmRuntime, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor
     return out
 
 
+def set_matmul_compute_type(rt: RocmRuntime, compute_type: str) -> None:
+    """MatmulObj::getComputeType() for fp32 MatMuls: "default" / "tf32" exact fp32 products, "bf16" / "fp16" 16-bit products with
+    fp32 accumulation and output (infini_rocm_matmul_set_compute_type). Sticky until reset to "default"."""
+    check(lib().infini_rocm_matmul_set_compute_type(rt.handle, {"default": 0, "tf32": 0, "bf16": 1, "fp16": 2}[compute_type]))
+
+
 def set_matmul_variant(rt: RocmRuntime, variant: int) -> None:
     check(lib().infini_rocm_matmul_set_variant(rt.handle, int(variant)))
 

@@ -194,10 +194,23 @@ class MatmulRocm : public RocmTunableKernel {
                 bsb = (int64_t)bt->getDims()[bt->getRank() - 2] * bt->getDims()[bt->getRank() - 1];
             }
         }
-        // `act` and `getComputeType()` ("tf32" / "fp16" / "bf16": reduced-precision products for fp32 operands in the
-        // reference, matmul.cc:51-64) are not applied: fp32 operands are always multiplied exactly (gemm32.hip). What the
-        // launch plan folded into THIS MatMul arrives through the overrides (rocm_fusion.cc): the row bias of a following
-        // Add (onnx.py:280-290 imports MatMul without bias), a Gelu, a head-split store.
+        // getComputeType() (matmul.cc:51-64; onnx.py:41-47 passes `matmul_compute_type`): "bf16" / "fp16" ask for reduced-precision
+        // PRODUCTS of fp32 operands — honoured below (16-bit MFMA, fp32 sums and output); "default" and "tf32" multiply exactly
+        // (gemm32.hip). `act` is not applied (the reference ignores it). What the launch plan folded into THIS MatMul arrives
+        // through the overrides (rocm_fusion.cc): the row bias of a following Add (onnx.py:280-290 imports MatMul without
+        // bias), a Gelu, a head-split store.
+        struct ComputeTypeScope {
+            infiniRocmRuntime_t rt;
+            bool set;
+            ComputeTypeScope(infiniRocmRuntime_t rt, int ct) : rt(rt), set(ct != 0) {
+                if (set)
+                    ROCM_CALL(infini_rocm_matmul_set_compute_type(rt, ct));
+            }
+            ~ComputeTypeScope() {
+                if (set)
+                    (void)infini_rocm_matmul_set_compute_type(rt, 0);
+            }
+        } ctScope(H(ctx), A->getDType() == DataType::Float32 ? (op->getComputeType() == "bf16" ? 1 : (op->getComputeType() == "fp16" ? 2 : 0)) : 0);
         const auto &ov = RocmRuntimeObj::overrides;
         const bool mine = ov.matmul == _op.get();
         if (mine && ov.biasPtr) {

@@ -377,3 +377,35 @@ def test_matmul_grouped_members_at_a_stride(rt, dtype, tol, variant):
         assert torch.all(oslab[j, m * n:] == 7.0).item()  # the gap behind every member
     with pytest.raises(ValueError):
         ops.matmul_grouped(rt, a, [ws[0], ws[2], ws[1]], outs, bs)  # not a uniform progression
+
+
+@pytest.mark.parametrize("ct,dt16,tol", [("bf16", "bf16", 2.0 ** -7), ("fp16", "f16", 2.0 ** -10)])
+@pytest.mark.parametrize("shape", [(512, 768, 256, False, False), (300, 520, 1024, True, True), (2048, 512, 4096, True, False)])
+def test_fp32_matmul_honours_the_compute_type(rt, ct, dt16, tol, shape):
+    """MatmulObj::getComputeType() (matmul.cc:51-64; onnx.py:41-47 `matmul_compute_type`): "bf16" / "fp16" on an fp32 MatMul
+    multiply 16-bit roundings of A and B with fp32 accumulation and an fp32 result — checked against the oracle's product of the
+    ROUNDED operands (so the only error left is fp32 summation) and shown to differ from the exact product by the 16-bit input
+    rounding, i.e. the attribute really took effect; with "default" the result is the exact fp32 one again. Bias and ReLU ride
+    in the reduce pass; a K that is not a multiple of 64 keeps the exact kernel."""
+    m, n, k, use_bias, relu = shape
+    rng = np.random.default_rng(m + n + k)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    b = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
+    bias = rng.standard_normal((n,)).astype(np.float32) if use_bias else None
+    da, db, dbias = dev(a, torch.float32), dev(b, torch.float32), (dev(bias, torch.float32) if use_bias else None)
+    try:
+        ops.set_matmul_compute_type(rt, ct)
+        y = ops.matmul(rt, da, db, dbias, act=1 if relu else 0)
+        assert y.dtype == torch.float32
+        y_odd = ops.matmul(rt, da[:, : k - 8].contiguous(), db[: k - 8].contiguous())  # K % 64 != 0: exact kernel
+    finally:
+        ops.set_matmul_compute_type(rt, "default")
+    exact = ops.matmul(rt, da, db, dbias, act=1 if relu else 0)
+    fin = lambda v: np.maximum(v, 0) if relu else v
+    want16 = fin(R.matmul(R.round_to(a, dt16), R.round_to(b, dt16), bias))
+    want32 = fin(R.matmul(a, b, bias))
+    assert np.allclose(host(y), want16, rtol=2e-5, atol=2e-5 * np.sqrt(k)), np.abs(host(y) - want16).max()
+    assert np.allclose(host(exact), want32, rtol=1e-4, atol=2e-5)
+    err16 = np.abs(host(y) - want32).max()
+    assert 1e-5 < err16 < 64 * tol, err16  # the 16-bit rounding of the inputs is visible, and no larger than it should be
+    assert np.allclose(host(y_odd), R.matmul(a[:, : k - 8], b[: k - 8]), rtol=1e-4, atol=2e-5)

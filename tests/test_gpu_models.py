@@ -294,7 +294,11 @@ def test_resnet50_bs128_full_size_properties(plugin_backend):
     b1, _ = logits(2, pick)
     scale = np.abs(a1).max()
     assert np.abs(a1[pick] - b1).max() <= 2e-2 * scale, (np.abs(a1[pick] - b1).max(), scale)
-    assert (a1[pick].argmax(1) == b1.argmax(1)).all()
+    # the predicted class agrees — unless an image's two best logits are closer than the tolerance just applied (a random-weight
+    # network's logits are nearly tied: a different accumulation order in ONE layer may then swap them)
+    for row128, row2 in zip(a1[pick], b1):
+        ia, ib = int(row128.argmax()), int(row2.argmax())
+        assert ia == ib or abs(row128[ia] - row128[ib]) <= 2e-2 * scale, (ia, ib, row128[ia], row128[ib])
 
 
 def test_bert_base_one_full_width_layer_vs_oracle(plugin_backend):

@@ -1540,3 +1540,31 @@ def test_stem_chain_is_one_launch(B, rocm, code, npdt):
     want = R.pool2d(np.maximum(conv.astype(npdt).astype(np.float64), 0), "max", 3, 3, 1, 1, 1, 1, 2, 2, 0)
     assert np.allclose(res[True].reshape(want.shape), want, rtol=3e-3, atol=3e-3), np.abs(res[True].reshape(want.shape) - want).max()
     assert np.allclose(res[True], res[False], rtol=3e-3, atol=3e-3)
+
+
+@pytest.mark.parametrize("ct", ["bf16", "fp16", "tf32", "default"])
+def test_matmul_compute_type_through_the_reference_operator(B, rocm, ct):
+    """MatmulObj carries `computeType` (operators/matmul.h:67; the front-end passes `matmul_compute_type`, onnx.py:41-47): the
+    plugin honours "bf16" / "fp16" for fp32 graphs (16-bit products, fp32 sums and output) and multiplies exactly for
+    "default" / "tf32"."""
+    rng = np.random.default_rng(71)
+    a = rng.standard_normal((256, 512)).astype(np.float32)
+    w = (rng.standard_normal((512, 384)) / 22).astype(np.float32)
+    h = B.GraphHandler(rocm)
+    ta, tw = h.tensor([256, 512], F32), h.tensor([512, 384], F32)
+    ta.set_input()
+    tw.set_weight()
+    out = h.matmul(ta, tw, None, False, False, None, B.ActType.Linear, ct)
+    h.data_malloc()
+    put(ta, a)
+    put(tw, w)
+    h.run()
+    got = get(out).astype(np.float64)
+    exact = a.astype(np.float64) @ w.astype(np.float64)
+    if ct in ("bf16", "fp16"):
+        name = {"bf16": "bf16", "fp16": "f16"}[ct]
+        want = R.matmul(R.round_to(a, name), R.round_to(w, name))
+        assert np.allclose(got, want, rtol=2e-5, atol=1e-4), np.abs(got - want).max()
+        assert np.abs(got - exact).max() > 1e-5  # the attribute took effect
+    else:
+        assert np.allclose(got, exact, rtol=1e-4, atol=2e-5), np.abs(got - exact).max()

@@ -6,7 +6,7 @@ O=gpurun_out/r4e
 rm -rf $O; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 t0=$(date +%s)
-timeout 600 python -m pytest tests/test_gpu_nn.py tests/test_gpu_bench_routes.py tests/test_gpu_plugin.py -m gpu -q -x -k "stem or reduce" --durations=5 > $O/pytest_stem.log 2>&1
+timeout 600 python -m pytest tests/test_gpu_nn.py tests/test_gpu_bench_routes.py tests/test_gpu_plugin.py tests/test_gpu_matmul.py tests/test_gpu_models.py -m gpu -q -x -k "stem or reduce or compute_type or full_size or frontend" --durations=5 > $O/pytest_stem.log 2>&1
 echo "pytest_stem exit $? after $(( $(date +%s) - t0 )) s" | tee -a $O/pytest_stem.log
 timeout 120 python - > $O/stem_time.txt 2>&1 <<'PY'
 import sys, torch
