@@ -35,6 +35,7 @@ constexpr int kStemPR = 2, kStemPC = 28; // pooled rows / columns per workgroup
 constexpr int kStemCR = 2 * kStemPR + 1, kStemCC = 2 * kStemPC + 1; // conv rows / columns per workgroup: 5 x 57
 constexpr int kStemIR = 2 * kStemCR + 5; // input rows: 15
 constexpr int kStemPitch = 160;     // input tile row pitch (elements)
+constexpr int kStemMargin = 8;      // elements in front of a tile row (see the staging loop); 8 + 134 < 160
 constexpr int kStemInElems = 3 * kStemIR * kStemPitch; // 7200
 constexpr int kStemPix = 72;        // conv tile: elements per pixel (64 filters + 8 pad: 36 dwords -> conflict-free b64 stores)
 constexpr int kStemConvElems = kStemCR * kStemCC * kStemPix; // 20,520
@@ -92,43 +93,70 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(StemArgs p) {
     const int xl = wv * 16 + l15; // conv column inside the tile (0 .. 63; 57 used)
     const int ntiles = p.n * p.tiles_r * p.tiles_c;
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        int b = tile;
-        const int tc = b % p.tiles_c;
-        b /= p.tiles_c;
-        const int tr = b % p.tiles_r, img = b / p.tiles_r;
-        const int p0 = tr * kStemPR, c0 = tc * kStemPC;  // first pooled row / column
-        const int y0 = 2 * p0 - 1, x0 = 2 * c0 - 1;      // first conv row / column of the tile
-        const int iy0 = 2 * y0 - 3, ix0 = 2 * x0 - 3;    // first input row / column of the tile (ix0 is odd)
-
-        // ---- input tile ---------------------------------------------------------------------------------------------
-        for (int i = t; i < kStemInElems / 8; i += 256)
-            *(s16x8_t *)(tin + i * 8) = s16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
-        __syncthreads(); // (also: every reader of the previous tile's LDS images is done)
-        {
-            // 16-byte chunks of the image rows: chunk m holds input columns 8 m .. 8 m + 7; the tile needs columns ix0 .. ix0 + 119
-            const int m_first = ix0 >= 0 ? ix0 / 8 : -1; // floor(ix0 / 8): ix0 = -5 for the first column tile, positive afterwards
-            const unsigned short *X = p.x + (long)img * 3 * p.h * p.w;
-            for (int i = t; i < 3 * kStemIR * 16; i += 256) {
-                const int m = m_first + (i & 15), rowc = i >> 4; // rowc = c * 15 + j
-                const int c = rowc / kStemIR, j = rowc - c * kStemIR;
-                const int iy = iy0 + j, ix = 8 * m;
-                if (iy < 0 || iy >= p.h || ix < 0 || ix >= p.w)
-                    continue; // stays zero (padding)
-                const s16x8_t v = *(const s16x8_t *)(X + ((long)c * p.h + iy) * p.w + ix);
-                unsigned short *dst = tin + rowc * kStemPitch + (ix - ix0); // odd element offset: element stores
+    // The input tile of the NEXT tile is fetched into registers (3 x 16 bytes per thread) while this tile computes: the first
+    // version loaded it at the top of every tile and idled out the HBM round trip (6.5 us per tile).
+    // 16-byte chunks of the image rows: chunk m holds input columns 8 m .. 8 m + 7; a tile needs columns ix0 .. ix0 + 119,
+    // i.e. the 16 chunks from floor(ix0 / 8) on; chunks / rows outside the image are zeros (the convolution's padding).
+    constexpr int kItems = 3 * kStemIR * 16, kPer = (kItems + 255) / 256; // 720 items, 3 per thread
+    s16x8_t pre[kPer];
+    auto decode = [&](int tile, int &img, int &p0, int &c0) {
+        const int tc = tile % p.tiles_c;
+        const int rest = tile / p.tiles_c;
+        p0 = (rest % p.tiles_r) * kStemPR;
+        c0 = tc * kStemPC;
+        img = rest / p.tiles_r;
+    };
+    auto fetch = [&](int tile) {
+        int img, p0, c0;
+        decode(tile, img, p0, c0);
+        const int iy0 = 2 * (2 * p0 - 1) - 3, ix0 = 2 * (2 * c0 - 1) - 3;
+        const int m_first = ix0 >= 0 ? ix0 / 8 : -1; // floor(ix0 / 8): ix0 = -5 for the first column tile, positive afterwards
+        const unsigned short *X = p.x + (long)img * 3 * p.h * p.w;
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (ix - ix0 + e >= 0 && ix - ix0 + e < kStemPitch)
-                        dst[e] = (unsigned short)v[e];
+        for (int j = 0; j < kPer; ++j) {
+            const int i = t + j * 256;
+            const int m = m_first + (i & 15), rowc = i >> 4; // rowc = c * 15 + row
+            const int c = rowc / kStemIR, iy = iy0 + rowc - c * kStemIR, ix = 8 * m;
+            const bool ok = i < kItems && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+            pre[j] = s16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            if (ok)
+                pre[j] = *(const s16x8_t *)(X + ((long)c * p.h + iy) * p.w + ix);
+        }
+    };
+    if ((int)blockIdx.x < ntiles)
+        fetch(blockIdx.x);
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int img, p0, c0;
+        decode(tile, img, p0, c0);
+        const int y0 = 2 * p0 - 1, x0 = 2 * c0 - 1;      // first conv row / column of the tile
+        const int ix0 = 2 * x0 - 3;                      // first input column of the tile (odd)
+
+        // ---- input tile: registers -> LDS (every element a live pixel reads is written: no zero fill) -----------------------
+        {
+            const int m_first = ix0 >= 0 ? ix0 / 8 : -1;
+#pragma unroll
+            for (int j = 0; j < kPer; ++j) {
+                const int i = t + j * 256;
+                if (i < kItems) {
+                    // odd element offset (-7 .. 120): element stores; a row starts kStemMargin elements into its pitch, so the
+                    // first chunk's elements left of the tile land in the margin (never read) instead of needing a guard
+                    const int rowc = i >> 4, off = 8 * (m_first + (i & 15)) - ix0;
+                    unsigned short *dst = tin + rowc * kStemPitch + kStemMargin + off;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        dst[e] = (unsigned short)pre[j][e];
+                }
             }
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles)
+            fetch(tile + gridDim.x); // in flight during the conv and pool phases below
 
         // ---- conv tile: wave wv takes the 16-column block wv of each of the 5 conv rows ---------------------------------
 #pragma unroll 1
         for (int yi = 0; yi < kStemCR; ++yi) {
-            const unsigned short *base = tin + 2 * yi * kStemPitch + 2 * xl;
+            const unsigned short *base = tin + 2 * yi * kStemPitch + kStemMargin + 2 * xl;
             u32x4_t bq[kStemKS];
 #pragma unroll
             for (int ks = 0; ks < kStemKS; ++ks) { // all six fragments first: the LDS latency is paid once per pixel tile
@@ -167,7 +195,10 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(StemArgs p) {
         }
         __syncthreads();
 
-        // ---- pool: (pooled row, pooled column, 8 filters): nine 16-byte reads, packed unsigned max, 8 element stores ------------
+        // ---- pool: (pooled row, pooled column, 8 filters): nine 16-byte reads, packed unsigned max, 8 element stores (lanes run
+        // along the pooled columns: 56 contiguous bytes per store instruction). A form with 8-byte stores — a thread pooling four
+        // adjacent columns of four filters from 27 8-byte reads — was measured SLOWER (110 vs 86 us at batch 128): the pool phase
+        // is bound by its per-thread instruction count, not by the 2-byte stores.
         typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
         for (int i = t; i < kStemPR * kStemPC * 8; i += 256) {
             const int pcl = i % kStemPC, rest = i / kStemPC, pr = rest % kStemPR, f8 = rest / kStemPR;
@@ -186,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(StemArgs p) {
             for (int e = 0; e < 8; ++e)
                 dst[e * fstride] = m[e];
         }
-        // (the next tile's zero fill touches `tin` only; its first barrier orders it against these reads of `tcv`)
+        // (the next tile's staging touches `tin` only; its barrier orders the next conv phase against these reads of `tcv`)
     }
 }
 

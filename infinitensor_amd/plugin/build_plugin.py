@@ -17,6 +17,7 @@ gpurun) is used and this script is a no-op.
 """
 from __future__ import annotations
 
+import os
 import shutil
 import subprocess
 import sys
@@ -125,7 +126,13 @@ def build(verbose: bool = True) -> Path | None:
     lib = PKG / "lib" / "libinfini_rocm.so"
     assert lib.exists(), "build libinfini_rocm.so first (infinitensor_amd/build.py)"
     plugin_srcs = sorted((HERE / "src").glob("*.cc"))
-    newest_in = max(p.stat().st_mtime for p in [*plugin_srcs, HERE / "include/rocm/rocm_runtime.h", Path(__file__),
+    # the planner's rule families live in src/rocm_fusion_rules_*.inc, included inside class FusionPlanner (rocm_fusion.cc): an
+    # edited .inc makes that one TU stale
+    incs = sorted((HERE / "src").glob("*.inc"))
+    fusion_cc = HERE / "src" / "rocm_fusion.cc"
+    if incs and max(p.stat().st_mtime for p in incs) > fusion_cc.stat().st_mtime:
+        os.utime(fusion_cc, None)
+    newest_in = max(p.stat().st_mtime for p in [*plugin_srcs, *incs, HERE / "include/rocm/rocm_runtime.h", Path(__file__),
                                                 REPO / "include/infini_rocm.h"])
     if out.exists() and out.stat().st_mtime >= newest_in:
         return out
