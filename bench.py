@@ -317,7 +317,20 @@ def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
     scale = torch.full((1,), float(D) ** 0.5, device="cuda", dtype=dt)
     torch.cuda.synchronize()
     # communicator: rank 0 creates the RCCL id, torch.distributed (already up) carries it
-    if world > 1:
+    direct_only = os.environ.get("INFINI_ROCM_COMM") == "direct"
+    if world > 1 and direct_only:
+        # the hand-written transport alone (file rendezvous in a directory every rank of this job derives from MASTER_PORT)
+        import tempfile
+
+        rdv = tempfile.gettempdir() + "/irocm_bench_tp_%s" % os.environ.get("MASTER_PORT", "0")
+        os.makedirs(rdv, exist_ok=True)
+        cwd = os.getcwd()
+        os.chdir(rdv)
+        try:
+            rt.init_comm("bench_tp", world, rank)
+        finally:
+            os.chdir(cwd)
+    elif world > 1:
         idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             uid = rt.comm_unique_id()
@@ -480,7 +493,10 @@ def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
     # against RCCL on the same 16 MiB all-reduce. Its kernels give up after a time limit instead of hanging (comm_check), and
     # any failure here is reported, never fatal: the RCCL figures above are already taken.
     direct_info = None
-    if world > 1:
+    if world > 1 and direct_only:
+        direct_info = {"note": "INFINI_ROCM_COMM=direct: every collective of this section already ran on the hand-written transport"}
+    elif world > 1:
+        d_ms, diff, err = 0.0, 0.0, None
         try:
             os.environ.setdefault("INFINI_ROCM_DIRECT_TIMEOUT_S", "10")
             import tempfile
@@ -494,7 +510,6 @@ def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
             finally:
                 os.chdir(cwd)
             rt.comm_set_algo(1)
-            ref = buf.clone()
             for _ in range(3):
                 ops.all_reduce(rt, "sum", buf, out=buf)
             rt.record(e0)
@@ -509,20 +524,24 @@ def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
             got_r = ops.all_reduce(rt, "sum", probe)
             rt.sync()
             rt.comm_check()
-            tm = torch.tensor([d_ms], device="cuda", dtype=torch.float64)
-            dist_mod.all_reduce(tm, op=dist_mod.ReduceOp.MAX)
-            d_ms = float(tm[0])
-            direct_info = {"allreduce_direct_ms": round(d_ms, 4),
-                           "allreduce_direct_busbw_GBs": round(2 * (world - 1) / world * nbytes / (d_ms * 1e-3) / 1e9, 1),
-                           "max_abs_diff_vs_rccl": float((got_d.float() - got_r.float()).abs().max().item()),
-                           "note": "reduce-scatter + all-gather as ONE push kernel per rank (32 workgroups), fp32 sums in rank order"}
-            del ref
+            diff = float((got_d.float() - got_r.float()).abs().max().item())
         except Exception as e:  # noqa: BLE001
-            direct_info = {"error": repr(e)[:300]}
+            err = repr(e)[:300]
             try:
                 rt.comm_set_algo(0)
             except Exception:  # noqa: BLE001
                 pass
+        # every rank reaches this collective whatever happened above (a rank that failed must not leave the others waiting)
+        tm = torch.tensor([0.0 if err else 1.0, -d_ms, -diff], device="cuda", dtype=torch.float64)
+        dist_mod.all_reduce(tm, op=dist_mod.ReduceOp.MIN)
+        if float(tm[0]) > 0.5:
+            d_ms = -float(tm[1])
+            direct_info = {"allreduce_direct_ms": round(d_ms, 4),
+                           "allreduce_direct_busbw_GBs": round(2 * (world - 1) / world * nbytes / (d_ms * 1e-3) / 1e9, 1),
+                           "max_abs_diff_vs_rccl": -float(tm[2]),
+                           "note": "reduce-scatter + all-gather as ONE push kernel per rank (32 workgroups), fp32 sums in rank order"}
+        else:
+            direct_info = {"error": err or "another rank failed"}
     gemm_shards = {
         "workload": "one bf16 4096^3 GEMM strong-scaled over %d GPUs" % world,
         "column_shard_ms": round(col_ms, 4), "column_shard_TFLOPs_aggregate": round(2.0 * G ** 3 / col_ms / 1e9, 1),
@@ -570,6 +589,12 @@ def pmc_traffic(launched: str) -> dict:
     return {"traffic": None, "traffic_source": "no counter file under profiles/"}
 
 
+# Test mode (tests/test_gpu_multi.py): IROCM_BENCH_ONE_DEVICE=1 with INFINI_ROCM_COMM=direct runs the N ranks on ONE device — the
+# hand-written transport allows what RCCL refuses — with torch.distributed on gloo. The figures are meaningless as scaling
+# numbers (the ranks share a GPU); what it checks is that the tensor-parallel block at world N equals the unsharded block.
+ONE_DEVICE = os.environ.get("IROCM_BENCH_ONE_DEVICE") == "1"
+
+
 def self_spawn(args) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU, RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* in the environment — exactly what `python -m torch.distributed.run` would set) and relay
@@ -581,7 +606,7 @@ def self_spawn(args) -> int:
     import torch
 
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not ONE_DEVICE:
         print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible", file=sys.stderr)
         return 2
     with socket.socket() as sk:
@@ -620,8 +645,13 @@ def main() -> int:
         import torch.distributed as td
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if ONE_DEVICE:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            td.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
         local_rank = 0
