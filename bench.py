@@ -512,6 +512,8 @@ def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
             rt.comm_set_algo(1)
             for _ in range(3):
                 ops.all_reduce(rt, "sum", buf, out=buf)
+            rt.sync()
+            rt.comm_check()  # a transport that does not work on this node is reported after ONE time limit, not timed
             rt.record(e0)
             for _ in range(iters):
                 ops.all_reduce(rt, "sum", buf, out=buf)

@@ -100,6 +100,10 @@ __device__ __forceinline__ char *pbox_of(const DirectArgs &a, int r, int src) {
 
 // lane 0 only. Returns after *f >= want (flags grow monotonically) or after the time limit (error word set).
 __device__ __forceinline__ void wait_flag(const DirectArgs &a, unsigned *f, unsigned want) {
+    // a communicator that already ran into its time limit does not wait again: every later wait of this rank returns at once,
+    // so a peer that never shows up costs ONE time limit per rank, not one per flag and call
+    if (__hip_atomic_load(&ctrl_of(a, a.rank)->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)
+        return;
     const long long t0 = wall_clock64();
     while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
         __builtin_amdgcn_s_sleep(4);
