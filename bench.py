@@ -572,7 +572,7 @@ def pmc_traffic(launched: str) -> dict:
     WRITE_SIZE of the same shape; FETCH_SIZE x2 per the gfx950 note). The counter file names the kernel variant it was
     taken from; a file from ANOTHER variant than the one this run launched is refused (traffic: null) instead of silently
     going stale when the kernel changes."""
-    for name in ("r03_gemm256p_pmc.json", "r02_gemm256p_pmc.json"):
+    for name in ("r04_gemm256p_pmc.json", "r03_gemm256p_pmc.json", "r02_gemm256p_pmc.json"):
         p = REPO / "profiles" / name
         try:
             d = json.loads(p.read_text())
