@@ -152,10 +152,28 @@ __global__ __launch_bounds__(256, (NT == 2 && D == 64) ? 3 : 2) void attention_k
         for (int nt = 0; nt < NT; ++nt)
             o[dt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run[NT], l_run[NT]; // running max (S' units, reduced over the 4 lanes of a column) and per-lane partial sum
+    // MMA_SUM (D = 64, round 4): the row sum l = sum_k P[k][q] is a 17th output row of the P V product — one more MFMA tile per
+    // (query tile, key half) against an all-ones A operand — instead of 16 v_add per query tile and key tile on the VALU pipe, which
+    // is the busy one (59 % against 21 % for the matrix pipe, profiles/r03_attention_bert_pmc.json). The sum is then taken over
+    // the ROUNDED weights (the values the P V product really uses) and needs no cross-lane reduction at the end. D = 128 has no
+    // registers to spare (240-256 VGPRs) and keeps the VALU sum.
+    constexpr bool MMA_SUM = D == 64 && !(CAUSAL && MASK == 2); // (that variant sits at the 168-register limit already: it would spill)
+    f32x4 osum[MMA_SUM ? NT : 1];
+    s16x8_t ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        ones[e] = (short)Tr::from_f32(1.0f);
+    if constexpr (MMA_SUM) { // opaque to the compiler: otherwise it re-materialises the constant with four v_mov in front of every MFMA
+        u32x4_t ow = __builtin_bit_cast(u32x4_t, ones);
+        asm volatile("" : "+v"(ow));
+        ones = __builtin_bit_cast(s16x8_t, ow);
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         m_run[nt] = -INFINITY;
         l_run[nt] = 0.f;
+        if constexpr (MMA_SUM)
+            osum[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
     // key tiles this workgroup needs (causal: nothing past its last query row)
@@ -256,14 +274,18 @@ __global__ __launch_bounds__(256, (NT == 2 && D == 64) ? 3 : 2) void attention_k
                 for (int r = 0; r < 4; ++r) {
                     const float e = fast_exp2(fmaf(s[mt][nt][r], c, nmc));
                     s[mt][nt][r] = e;
-                    ps += e;
+                    if constexpr (!MMA_SUM)
+                        ps += e;
                 }
-            l_run[nt] = l_run[nt] * alpha + ps;
+            if constexpr (!MMA_SUM)
+                l_run[nt] = l_run[nt] * alpha + ps;
             // the running maximum settles after the first tiles: skip the 16 multiplies when no lane's changed
             if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
                     o[dt][nt] *= alpha;
+                if constexpr (MMA_SUM)
+                    osum[nt] *= alpha;
             }
         }
         // ---- P fragments (B operand): k-slots 0..3 = keys 4*g4 + e of sub-tile 2*kk, 4..7 = of sub-tile 2*kk+1 ----
@@ -298,6 +320,13 @@ __global__ __launch_bounds__(256, (NT == 2 && D == 64) ? 3 : 2) void attention_k
                 for (int nt = 0; nt < NT; ++nt)
                     o[dt][nt] = Tr::mfma(vf, pf[nt][kk], o[dt][nt]);
             }
+        if constexpr (MMA_SUM) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    osum[nt] = Tr::mfma(ones, pf[nt][kk], osum[nt]);
+        }
         if (kt + 1 < nkt)
             store_tile(smem + ((kt + 1) & 1) * STAGE, mstrips + ((kt + 1) & 1) * KT, kbase + KT);
         __syncthreads();
@@ -310,9 +339,14 @@ __global__ __launch_bounds__(256, (NT == 2 && D == 64) ? 3 : 2) void attention_k
                         (p.o_heads ? ((long)(bh / p.o_heads) * p.sq * p.o_heads + (bh % p.o_heads)) * D : (long)bh * p.sq * D);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        float l = l_run[nt];
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
+        float l;
+        if constexpr (MMA_SUM) {
+            l = osum[nt][0]; // every row of the ones tile holds the column's sum over all 64 keys of every tile
+        } else {
+            l = l_run[nt];
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+        }
         const float inv = l > 0.f ? 1.0f / l : 0.f;
         const int qi = q0 + nt * 16 + l15;
         if (qi >= p.sq)
