@@ -17,3 +17,12 @@ ops.set_conv_const_weights(rt, True)
 for _ in range(6):
     ops.conv2d_pool(rt, x, w, b, 3, 3, 2, 2, 3, 2, 1, out=y)
 rt.sync()
+from infinitensor_amd.runtime import Event  # noqa: E402
+
+e0, e1 = Event(), Event()
+rt.record(e0)
+for _ in range(50):
+    ops.conv2d_pool(rt, x, w, b, 3, 3, 2, 2, 3, 2, 1, out=y)
+rt.record(e1)
+rt.sync()
+print(f"stem+pool fused bs128: {rt.elapsed_ms(e0, e1) / 50 * 1e3:.1f} us")
