@@ -62,11 +62,27 @@ __device__ __forceinline__ void stage_n(const char *ubase, const unsigned (&off)
 struct PArgs {
     GemmArgs g;
     int total_tiles; // tiles_m * tiles_n * batch
+    int tab_n;       // steps of a workgroup served by the LDS tile table (kTileTab, or 0: tile counts beyond 16 bits)
     unsigned per_batch_m, per_group_m; // floor(2^32 / (tiles_m * tiles_n)), floor(2^32 / (8 * tiles_n)): decode() divides by multiply-high
     unsigned long long *trace; // TRACE instantiation only: [gridDim.x][8 waves][kTraceSlots] s_memtime stamps
 };
 
 constexpr int kTraceSlots = 128;
+constexpr int kTraceBytes = 8 * kTraceSlots * 8;
+// Decoded tiles (batch, m0, n0) of this workgroup's first kTileTab steps, 16 bytes each, in LDS behind the K-tile buffers (and
+// the TRACE strip). Round 4: the scalar decode() — XCD remap, three multiply-high divisions, the group-size ladder: ~120 SALU
+// instructions with ~20 branches, ~1.0-1.3 k cycles — ran three times per tile (B cursor, A cursor, tile loop), the first two
+// inside a LOAD phase the partner wave row waits for at the barrier: the timeline (tools/gemm_timeline.py) showed +1.3 k cycles
+// on exactly the two K-tiles where the cursors cross into the next tile, ~4 k cycles per tile boundary with the third = 8 % of a
+// 12-K-tile tile (BERT). Now every thread decodes ONE tile in the prologue (under the first DMA round trip), a cursor that crosses
+// fetches its entry with one asm ds_read issued in front of the phase's lgkmcnt wait, and the per-lane offsets are rebuilt
+// AFTER the MFMA burst of the following COMPUTE phase, where this wave row has slack.
+// An entry is two dwords {batch << 16 | m0 / 256, batch << 16 | n0 / tile width}: the A cursor reads the first, the B cursor the second
+// (launch_p / launch_p_conv switch the table off — PArgs::tab_n = 0 — for problems whose batch or tile counts do not fit 16
+// bits): ONE VGPR per cursor across a barrier interval; the 256-column bf16 builds sit at 256 VGPRs and a three-dword entry per
+// cursor put 24-44 bytes per lane into scratch, a two-dword one 8.
+constexpr int kTileTab = 256;
+constexpr int kTabBytes = kTileTab * 8;
 
 // TRACE: every wave stamps s_memtime at phase boundaries into a private LDS strip behind the K-tile buffers (no VMEM
 // traffic, so the vmcnt bookkeeping is untouched) and dumps the strip at the end — tools/gemm_timeline.py.
@@ -125,6 +141,14 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         n0 = (int)qn * BN_;
     };
 
+    const unsigned tab0 = (unsigned)(unsigned long)IROCM_LDS_PTR(smem) + LDS_BYTES + (TRACE ? kTraceBytes : 0);
+    auto tab_read = [&](int s, int which) __attribute__((always_inline)) { // (asm: see gemm256_common.h on what hipcc does around LDS-DMA)
+        unsigned v;
+        asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(tab0 + (unsigned)s * 8u + (unsigned)which * 4u));
+        return v;
+    };
+    const int tab_n = pa.tab_n;
+
     const long lda = A_KMAJOR ? p.a_rs : p.a_cs;
     const long ldb = CONV ? (long)p.cv_hw : (B_KMAJOR ? p.b_cs : p.b_rs);
     const long a_step = A_KMAJOR ? (long)BK * 2 : (long)BK * lda * 2; // bytes per K-tile (wave-uniform)
@@ -135,37 +159,79 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     const char *a_base, *b_base;
     int a_s = 0, a_kt = 0, a_G = 0; // tile step, K-tile inside it, flat index
     int b_s = 0, b_kt = 0, b_G = 0;
-    auto set_a_tile = [&](int s) {
-        int ib, m0, n0;
-        decode(s, ib, m0, n0);
+    auto set_a_at = [&](int ib, int m0) __attribute__((always_inline)) {
         a_base = (const char *)((const unsigned short *)p.a + (long)ib * p.a_bs);
         if constexpr (A_KMAJOR) offs_k(a_off, lda, m0, p.m, w, lane);
         else offs_mn(a_off, lda, m0, p.m, w, lane);
     };
-    auto set_b_tile = [&](int s) {
-        int ib, m0, n0;
-        decode(s, ib, m0, n0);
+    auto set_b_at = [&](int ib, int n0) __attribute__((always_inline)) {
         b_base = (const char *)((const unsigned short *)p.b + (long)ib * p.b_bs);
         if constexpr (CONV) offs_mn_conv(b_off, p.cv_hw, p.cv_hwp, p.cv_hwp_m, (long)p.k * p.cv_hw, n0, p.n, w, lane);
         else if constexpr (B_KMAJOR) offs_k_n<NT>(b_off, ldb, n0, p.n, w, lane);
         else offs_mn(b_off, ldb, n0, p.n, w, lane);
     };
-    auto stage_a_next = [&](int buf) {
+    auto set_a_tile = [&](int s) {
+        int ib, m0, n0;
+        decode(s, ib, m0, n0);
+        set_a_at(ib, m0);
+    };
+    auto set_b_tile = [&](int s) {
+        int ib, m0, n0;
+        decode(s, ib, m0, n0);
+        set_b_at(ib, n0);
+    };
+    // A cursor that crosses into tile s < kTileTab only REQUESTS the table entry (one ds_read in front of the phase's lgkmcnt wait);
+    // finish_cursors, called behind the MFMA burst of the next C1 phase, turns it into base pointer and lane offsets —
+    // before the cursor's next DMA (A: the next K-tile's L1, B: its L2). DIRECT (the prologue, before the table exists) and
+    // steps beyond the table decode in place.
+    // Both are finished in C1 and nowhere else: of the four barrier intervals of a K-tile only the one where this wave row's C1
+    // faces the partner row's (long) L1 has slack behind the MFMA burst; a check behind C2 (which faces the short L2) cost the
+    // 64-K-tile headline 2 %. B crosses in an L2 and waits for the C1 of the next K-tile (its next DMA is that K-tile's L2).
+    int pend = 0; // bit 0: A, bit 1: B
+    unsigned a_ent = 0u, b_ent = 0u;
+    auto stage_a_next = [&](int buf, auto directc) __attribute__((always_inline)) {
         stage4(a_base + (long)a_kt * a_step, a_off, smem + buf * BUF_BYTES, w);
         ++a_G;
         if (++a_kt == nk) {
             a_kt = 0;
-            if (++a_s < my_tiles)
-                set_a_tile(a_s);
+            if (++a_s < my_tiles) {
+                if (decltype(directc)::value || a_s >= tab_n) {
+                    set_a_tile(a_s);
+                } else {
+                    a_ent = tab_read(a_s, 0);
+                    pend |= 1;
+                }
+            }
         }
     };
-    auto stage_b_next = [&](int buf) {
+    auto stage_b_next = [&](int buf, auto directc) __attribute__((always_inline)) {
         stage_n<NB>(b_base + (long)b_kt * b_step, b_off, smem + buf * BUF_BYTES + OPER_BYTES, w);
         ++b_G;
         if (++b_kt == nk) {
             b_kt = 0;
-            if (++b_s < my_tiles)
-                set_b_tile(b_s);
+            if (++b_s < my_tiles) {
+                if (decltype(directc)::value || b_s >= tab_n) {
+                    set_b_tile(b_s);
+                } else {
+                    b_ent = tab_read(b_s, 1);
+                    pend |= 2;
+                }
+            }
+        }
+    };
+    auto finish_cursors = [&]() __attribute__((always_inline)) {
+        if (pend) { // (wave-uniform; the entries are read only from here on, i.e. behind the lgkmcnt waits that followed their ds_reads)
+            if (pend & 1) {
+                asm volatile("" : "+v"(a_ent));
+                const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)a_ent);
+                set_a_at((int)(e >> 16), (int)(e & 0xffffu) * BM);
+            }
+            if (pend & 2) {
+                asm volatile("" : "+v"(b_ent));
+                const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)b_ent);
+                set_b_at((int)(e >> 16), (int)(e & 0xffffu) * BN_);
+            }
+            pend = 0;
         }
     };
 
@@ -174,10 +240,17 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     stamp();
     set_a_tile(0);
     set_b_tile(0);
-    stage_b_next(0);
-    stage_a_next(0);
+    stage_b_next(0, std::true_type{});
+    stage_a_next(0, std::true_type{});
     if (total_kt > 1)
-        stage_b_next(1);
+        stage_b_next(1, std::true_type{});
+    // the tile table: thread s decodes step s (under the round trip of the loads above; published by the barrier in front of the loop)
+    if (t < my_tiles && t < tab_n) {
+        int ib, m0, n0;
+        decode(t, ib, m0, n0);
+        const u32x2_t e = {((unsigned)ib << 16) | (unsigned)(m0 / BM), ((unsigned)ib << 16) | (unsigned)(n0 / BN_)};
+        asm volatile("ds_write_b64 %0, %1" ::"v"(tab0 + (unsigned)t * 8u), "v"(e) : "memory");
+    }
 
     // ---- per-lane LDS read addresses (gemm256.hip) ------------------------------------------------
     const unsigned lds0 = (unsigned)(unsigned long)IROCM_LDS_PTR(smem);
@@ -826,7 +899,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         if constexpr (NJ1 > 0) read_b(I1{}, IJ1{}, bq1);
         read_a(I0{}, aq);
         if (a_G < total_kt)
-            stage_a_next(buf ^ 1);
+            stage_a_next(buf ^ 1, std::false_type{});
         wait_lgkm0();
         barrier();
         // C1
@@ -834,13 +907,15 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         compute(I0{}, I0{}, I2{}, aq, bq0);
         if constexpr (NJ1 > 0) compute(I0{}, I1{}, IJ1{}, aq, bq1);
         __builtin_amdgcn_s_setprio(0);
+        fence_sched();
+        finish_cursors(); // (issues behind the MFMA burst, which is still executing)
         barrier();
         // L2
         stamp();
         read_a(I1{}, aq);
         flip_buf(buf ? -BUF_BYTES : BUF_BYTES); // every read of this K-tile is issued
         if (b_G < total_kt) {
-            stage_b_next(buf);
+            stage_b_next(buf, std::false_type{});
             wait_vm<NB>(); // everything older than these NB loads has landed (C stores of a previous tile included)
         } else {
             wait_vm<0>();
@@ -860,6 +935,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         wait_vm<NB>();
     else
         wait_vm<0>();
+    wait_lgkm0(); // (the tile table's ds_write)
     barrier();
     if (wr == 1)
         barrier(); // stagger: wave row 1 runs one barrier interval behind wave row 0
@@ -869,7 +945,18 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     int G = 0;
     for (int c_s = 0; c_s < my_tiles; ++c_s) {
         int c_ib, c_m0, c_n0; // the tile being accumulated
-        decode(c_s, c_ib, c_m0, c_n0);
+        if (c_s < tab_n) {
+            unsigned e0 = tab_read(c_s, 0), e1 = tab_read(c_s, 1);
+            wait_lgkm0();
+            asm volatile("" : "+v"(e0), "+v"(e1));
+            e0 = (unsigned)__builtin_amdgcn_readfirstlane((int)e0);
+            e1 = (unsigned)__builtin_amdgcn_readfirstlane((int)e1);
+            c_ib = (int)(e0 >> 16);
+            c_m0 = (int)(e0 & 0xffffu) * BM;
+            c_n0 = (int)(e1 & 0xffffu) * BN_;
+        } else {
+            decode(c_s, c_ib, c_m0, c_n0);
+        }
         if constexpr (CONV != 0)
             load_cbias(c_m0);
         for (int kt = 0; kt < nk; ++kt, ++G)
@@ -919,7 +1006,7 @@ template <typename Tr, int NT, bool TRACE = false>
 static int launch_p(infiniRocmRuntime_t rt, GemmArgs g, bool akm, bool bkm, unsigned long long *trace = nullptr) {
     PArgs pa;
     pa.trace = trace;
-    constexpr int kLds = LDS_BYTES + (TRACE ? 8 * kTraceSlots * 8 : 0);
+    constexpr int kLds = LDS_BYTES + (TRACE ? kTraceBytes : 0) + kTabBytes;
     if (!(g.act == 0 || g.act == 1 || g.act == 5) || (g.bias && !(g.bias_m == 0 && g.bias_n == 1)))
         IROCM_FAIL(INFINI_ROCM_UNSUPPORTED, "gemm256p: activation %d / this bias layout is not served by the persistent kernels", g.act);
     g.tiles_m = (int)ceil_div(g.m, BM);
@@ -929,6 +1016,7 @@ static int launch_p(infiniRocmRuntime_t rt, GemmArgs g, bool akm, bool bkm, unsi
         IROCM_FAIL(INFINI_ROCM_INVALID_ARGUMENT, "matmul: too many tiles");
     pa.g = g;
     pa.total_tiles = (int)total;
+    pa.tab_n = (g.tiles_m < 65536 && g.tiles_n < 65536 && g.batch < 65536) ? kTileTab : 0;
     pa.per_batch_m = udiv_magic((unsigned long long)g.tiles_m * g.tiles_n);
     pa.per_group_m = udiv_magic(8ull * g.tiles_n);
     // one workgroup per CU walking its tiles; gridDim.x % 8 == 0 keeps every workgroup's tiles on its XCD's id range
@@ -969,6 +1057,7 @@ template <typename Tr, int NT, bool RES> static int launch_p_conv(infiniRocmRunt
     pa.g = g;
     pa.g.cv_hwp_m = udiv_magic((unsigned long long)g.cv_hwp);
     pa.total_tiles = (int)total;
+    pa.tab_n = (g.tiles_m < 65536 && g.tiles_n < 65536) ? kTileTab : 0;
     pa.per_batch_m = udiv_magic((unsigned long long)g.tiles_m * g.tiles_n);
     pa.per_group_m = udiv_magic(8ull * g.tiles_n);
     unsigned grid = (unsigned)total;
@@ -976,8 +1065,8 @@ template <typename Tr, int NT, bool RES> static int launch_p_conv(infiniRocmRunt
     if (grid > cus)
         grid = cus;
     auto kern = gemm256p_kernel<Tr, true, false, NT, false, RES ? 2 : 1>;
-    IROCM_LDS_ATTR(kern, LDS_BYTES, rt);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, rt->stream, pa);
+    IROCM_LDS_ATTR(kern, LDS_BYTES + kTabBytes, rt);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES + kTabBytes, rt->stream, pa);
     IROCM_LAUNCH_CHECK("gemm256p(conv)");
     return INFINI_ROCM_OK;
 }
