@@ -83,6 +83,16 @@ constexpr int kTraceBytes = 8 * kTraceSlots * 8;
 // cursor put 24-44 bytes per lane into scratch, a two-dword one 8.
 constexpr int kTileTab = 256;
 constexpr int kTabBytes = kTileTab * 8;
+// Behind the table: two 512-byte slots for the row bias of the tile being accumulated (tile step & 1). The epilogue used to fetch
+// its bias with global loads whose wait is a vmcnt(0) — i.e. it also waited out the NEXT tile's first (cold) operand DMAs, already
+// in flight: ~1.4 k of the ~2.1 k cycles of the first store step in the timeline. Now wave 0 requests the 64 NT bias values by ONE
+// LDS-DMA at the top of the tile (older than every load the K loop's counted waits leave outstanding, so the first of those
+// waits covers it) and the epilogue reads them with ds_read_b64.
+// (Slots are 1 KiB apart: all 64 lanes of the DMA write 16 bytes each — the upper lanes re-read the tile's last 16 bytes into the
+// unused half — so the request needs no lane mask: a divergent branch at the top of the tile loop cost the 256-column builds two
+// VGPRs they do not have, 8 bytes of scratch per lane.)
+constexpr int kBiasSlotBytes = 1024;
+constexpr int kExtraLds = kTabBytes + 2 * kBiasSlotBytes;
 
 // TRACE: every wave stamps s_memtime at phase boundaries into a private LDS strip behind the K-tile buffers (no VMEM
 // traffic, so the vmcnt bookkeeping is untouched) and dumps the strip at the end — tools/gemm_timeline.py.
@@ -148,6 +158,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         return v;
     };
     const int tab_n = pa.tab_n;
+    const unsigned bias0 = tab0 + kTabBytes;
 
     const long lda = A_KMAJOR ? p.a_rs : p.a_cs;
     const long ldb = CONV ? (long)p.cv_hw : (B_KMAJOR ? p.b_cs : p.b_rs);
@@ -353,8 +364,14 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     // (erff, tanhf, expf bodies) between two stores — with the Gelu selected at run time BERT's FFN1 launch cost +85 us.
     // Sigmoid / tanh / erff-Gelu are served by the one-shot kernel (gemm.hip routes them; a run-time copy here beside the
     // three spills 528 bytes per lane).
-    auto epilogue = [&](auto actc, int ib, int m0, int n0) __attribute__((always_inline)) {
+    auto epilogue = [&](auto actc, int ib, int m0, int n0, int bslot) __attribute__((always_inline)) {
         constexpr int ACT = decltype(actc)::value;
+        // Lane-derived values of the epilogue are rebuilt from an OPAQUE copy of the lane id (shadowing the kernel's lane / l15 / g4):
+        // hipcc hoists loop-invariant lane arithmetic (store offsets, exchange sources, bias addresses) out of the tile loop, where it
+        // then occupies VGPRs across the K loop — registers the 256-column builds do not have (two of them = 8 bytes of scratch).
+        int lane_o = (int)(threadIdx.x & 63);
+        asm volatile("" : "+v"(lane_o));
+        const int lane = lane_o, l15 = lane_o & 15, g4 = lane_o >> 4;
         auto act1 = [&](float v) {
             if constexpr (ACT == 1) return v > 0.f ? v : 0.f;
             else if constexpr (ACT == 5) return gelu_poly(v);
@@ -369,6 +386,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         // general forms (column vectors, full matrices) live in the one-shot kernel: their strides cost this kernel four
         // scalar registers it does not have — at 106 SGPRs ONE more 64-bit argument (the output batch stride) tipped the
         // 256-column build into 408-468 bytes of scratch per lane and 76 -> 116 us on BERT's FFN1.
+        stamp(); // (TRACE: epilogue entry)
         const bool rowbias = bias != nullptr;
         float bv[NT][4];
 #pragma unroll
@@ -378,16 +396,16 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
                 bv[j][r] = 0.f;
         if (rowbias) {
             const unsigned short *bb = bias + (long)ib * p.bias_b;
-            const bool al8 = ((((uintptr_t)bb) & 7) == 0);
-            if (al8 && n0 + BN_ <= p.n) {
-                // the common case as straight-line code: NT loads, ONE wait (a per-load condition puts every load in its own branch
-                // with an s_waitcnt vmcnt(0) behind it: NT serialised round trips at the head of every tile's epilogue)
+            if (n0 + BN_ <= p.n && ((((uintptr_t)(bb + n0)) & 15) == 0)) { // (the test of the tile loop's DMA: the values are in LDS)
                 u32x2_t q[NT];
+                const unsigned src = bias0 + (unsigned)bslot * kBiasSlotBytes + (unsigned)(wc * (16 * NT) + g4 * 4) * 2u;
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    q[j] = *(const u32x2_t *)(bb + (n0 + wc * (16 * NT) + j * 16 + g4 * 4));
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(q[j]) : "v"(src), "i"(j * 32));
+                wait_lgkm0();
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
+                    asm volatile("" : "+v"(q[j]));
                     bv[j][0] = Tr::to_f32((unsigned short)(q[j][0] & 0xffff));
                     bv[j][1] = Tr::to_f32((unsigned short)(q[j][0] >> 16));
                     bv[j][2] = Tr::to_f32((unsigned short)(q[j][1] & 0xffff));
@@ -403,6 +421,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
                 }
             }
         }
+        stamp(); // (TRACE: bias)
         auto pack2 = [&](int i, auto jc, int row, unsigned (&pk)[2]) { // bias + activation + rounding of one 4-wide piece
             constexpr int j = decltype(jc)::value;
             const int col = n0 + wc * (16 * NT) + j * 16 + g4 * 4;
@@ -426,6 +445,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
             // 32-bit offset computed once per tile. (Before: one conversion per value + shift + or, and a 64-bit multiply-add
             // chain with a branch on the head-split layout per store: 36 VALU slots per store.)
             const bool odd = g4 & 1;
+            stamp(); // (TRACE: 16-byte store path entered)
             // Head-split layout (the fused q / k / v projections: C[row][col] -> [row / S][col / D][row % S][col % D]) separates
             // the same way when S % 16 == 0: a wave's 16 rows of one store never straddle a sequence, so (row / S, row % S) of
             // the wave's first row is wave-uniform and advances by scalar adds; the lane adds l15 * D and its column part.
@@ -446,8 +466,13 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
                 auto col_part = [&](int col) -> unsigned { // byte offset contributed by the column
                     if (!hs)
                         return (unsigned)col * 2u;
-                    const unsigned h = (unsigned)col / (unsigned)p.hs_d, d = (unsigned)col - h * (unsigned)p.hs_d;
-                    return (h * (unsigned)p.hs_s * (unsigned)p.hs_d + d) * 2u;
+                    // (the divisor is made opaque HERE: hipcc otherwise hoists the reciprocal of hs_d into the kernel prologue and
+                    // keeps it in a VGPR for the whole kernel — the one register the 256-column builds spilled, reloaded in this
+                    // epilogue behind a vmcnt(0) that also drains the next tile's operand DMAs)
+                    unsigned hsd = (unsigned)p.hs_d;
+                    asm volatile("" : "+s"(hsd));
+                    const unsigned h = (unsigned)col / hsd, d = (unsigned)col - h * hsd;
+                    return (h * (unsigned)p.hs_s * hsd + d) * 2u;
                 };
                 unsigned voff[NT / 2 > 0 ? NT / 2 : 1];
                 sfor<NT / 2>([&](auto jpc) {
@@ -501,7 +526,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
                     }
                 };
                 constexpr int kPerStep = (NT / 2) * 4 + (NT % 2) * 2; // exchanges in flight per step
+                stamp(); // (TRACE: bias + address set-up)
                 make(0, 0);
+                stamp(); // (TRACE: the first pack + exchange)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     fence_sched();
@@ -625,6 +652,10 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     // ---- conv-mode epilogue: rows are filters, columns pixel slots; Y is NCHW ---------------------------------------
     auto epilogue_conv = [&](auto actc, auto resc, int m0, int n0) __attribute__((always_inline)) {
         constexpr int ACT = decltype(actc)::value;
+        // (opaque lane id: see epilogue)
+        int lane_o = (int)(threadIdx.x & 63);
+        asm volatile("" : "+v"(lane_o));
+        const int lane = lane_o, l15 = lane_o & 15, g4 = lane_o >> 4;
         constexpr bool has_res = decltype(resc)::value; // compile-time: the residual registers exist in the residual copies only
         auto act1 = [&](float v) {
             if constexpr (ACT == 1) return v > 0.f ? v : 0.f;
@@ -959,6 +990,18 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         }
         if constexpr (CONV != 0)
             load_cbias(c_m0);
+        if constexpr (CONV == 0) {
+            if (p.bias != nullptr && c_n0 + BN_ <= p.n) { // (wave-uniform)
+                const char *bb = (const char *)((const unsigned short *)p.bias + (long)c_ib * p.bias_b + c_n0);
+                if (((((uintptr_t)bb) & 15) == 0) && w == 0) {
+                    int lo = lane; // (opaque: see the epilogue's bias read)
+                    asm volatile("" : "+v"(lo));
+                    __builtin_amdgcn_global_load_lds(IROCM_GLB_PTR(bb + (unsigned long)(unsigned)min(lo * 16, BN_ * 2 - 16)),
+                                                     IROCM_LDS_PTR(smem + LDS_BYTES + (TRACE ? kTraceBytes : 0) + kTabBytes + (c_s & 1) * kBiasSlotBytes),
+                                                     16, 0, 0);
+                }
+            }
+        }
         for (int kt = 0; kt < nk; ++kt, ++G)
             ktile(G & 1);
         stamp();
@@ -969,15 +1012,16 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         // falls back one interval.
         if (wr == 0)
             barrier();
+        stamp(); // (TRACE: row 0's wait for row 1)
         // this wave's part of tile c_s is complete; G = first K-tile of the next tile
         if constexpr (CONV != 0) { // the conv launcher admits act 0 / 1 only
             using R = std::integral_constant<bool, CONV == 2>;
             if (p.act == 0) epilogue_conv(std::integral_constant<int, 0>{}, R{}, c_m0, c_n0);
             else epilogue_conv(std::integral_constant<int, 1>{}, R{}, c_m0, c_n0);
         } else {
-            if (p.act == 0) epilogue(std::integral_constant<int, 0>{}, c_ib, c_m0, c_n0);
-            else if (p.act == 1) epilogue(std::integral_constant<int, 1>{}, c_ib, c_m0, c_n0);
-            else epilogue(std::integral_constant<int, 5>{}, c_ib, c_m0, c_n0); // launch_p admits act 0, 1, 5 only
+            if (p.act == 0) epilogue(std::integral_constant<int, 0>{}, c_ib, c_m0, c_n0, c_s & 1);
+            else if (p.act == 1) epilogue(std::integral_constant<int, 1>{}, c_ib, c_m0, c_n0, c_s & 1);
+            else epilogue(std::integral_constant<int, 5>{}, c_ib, c_m0, c_n0, c_s & 1); // launch_p admits act 0, 1, 5 only
         }
         if (c_s + 1 < my_tiles)
             zero_acc();
@@ -1006,7 +1050,7 @@ template <typename Tr, int NT, bool TRACE = false>
 static int launch_p(infiniRocmRuntime_t rt, GemmArgs g, bool akm, bool bkm, unsigned long long *trace = nullptr) {
     PArgs pa;
     pa.trace = trace;
-    constexpr int kLds = LDS_BYTES + (TRACE ? kTraceBytes : 0) + kTabBytes;
+    constexpr int kLds = LDS_BYTES + (TRACE ? kTraceBytes : 0) + kExtraLds;
     if (!(g.act == 0 || g.act == 1 || g.act == 5) || (g.bias && !(g.bias_m == 0 && g.bias_n == 1)))
         IROCM_FAIL(INFINI_ROCM_UNSUPPORTED, "gemm256p: activation %d / this bias layout is not served by the persistent kernels", g.act);
     g.tiles_m = (int)ceil_div(g.m, BM);
@@ -1065,8 +1109,8 @@ template <typename Tr, int NT, bool RES> static int launch_p_conv(infiniRocmRunt
     if (grid > cus)
         grid = cus;
     auto kern = gemm256p_kernel<Tr, true, false, NT, false, RES ? 2 : 1>;
-    IROCM_LDS_ATTR(kern, LDS_BYTES + kTabBytes, rt);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES + kTabBytes, rt->stream, pa);
+    IROCM_LDS_ATTR(kern, LDS_BYTES + kExtraLds, rt);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES + kExtraLds, rt->stream, pa);
     IROCM_LAUNCH_CHECK("gemm256p(conv)");
     return INFINI_ROCM_OK;
 }

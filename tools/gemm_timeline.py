@@ -50,13 +50,15 @@ for wg in (int(x) for x in a_.wg.split(",")):
         i = 1
         line = []
         for tile in range(my):
-            if i + 2 * nk + 10 > n:
+            if i + 2 * nk + 16 > n:
                 break
             kt = s[i:i + 2 * nk:2]
             l2 = s[i + 1:i + 2 * nk:2]
-            e0, e1 = s[i + 2 * nk], s[i + 2 * nk + 9]
-            steps = np.diff(s[i + 2 * nk:i + 2 * nk + 9])  # e0 -> after store step 0 -> ... -> after step 7
+            # stamps behind the K loop: e0 | row barrier | epilogue entry | bias | 16-byte path entered | address set-up | first pack + exchange | after store step 0 .. 7 | end
+            e0, e1 = s[i + 2 * nk], s[i + 2 * nk + 15]
+            pre = np.diff(s[i + 2 * nk:i + 2 * nk + 7])
+            steps = np.diff(s[i + 2 * nk + 6:i + 2 * nk + 15])
             d = np.diff(np.append(kt, e0))
-            print(f"   tile {tile}: first L1 at +{kt[0]}, K-tile ticks {d.tolist()}, epilogue {e1 - e0} (store steps {steps.tolist()})")
-            i += 2 * nk + 10
+            print(f"   tile {tile}: first L1 at +{kt[0]}, K-tile ticks {d.tolist()}, epilogue {e1 - e0} (row barrier / entry / bias / path / set-up / first exchange {pre.tolist()}, store steps {steps.tolist()})")
+            i += 2 * nk + 16
         print(f"   final drain (last epilogue end -> all stores done): {s[-1] - s[-2]}")

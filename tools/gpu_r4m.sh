@@ -3,7 +3,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd $REPO
 O=gpurun_out/r4m
 rm -rf $O; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_matmul.py tests/test_gpu_bench_routes.py tests/test_gpu_fuzz.py -m gpu -q -x > $O/pytest.log 2>&1
+timeout 900 python -m pytest tests/test_gpu_matmul.py tests/test_gpu_bench_routes.py tests/test_gpu_fuzz.py tests/test_gpu_nn.py tests/test_gpu_models.py tests/test_gpu_plugin.py -m gpu -q -x > $O/pytest.log 2>&1
 echo "pytest exit $?" | tee -a $O/pytest.log
 tail -5 $O/pytest.log
 timeout 200 python tools/gemm_timeline.py --m 16384 --n 3072 --k 768 --tile 256 --wg 0 2>&1 | grep -v amdgpu.ids | tee $O/timeline_ffn1.txt
