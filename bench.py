@@ -385,6 +385,7 @@ def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
 
     wqkv, wgu = torch.stack([wq, wk, wv]).contiguous(), torch.stack([wg, wu]).contiguous()
     del wq, wk, wv, wg, wu
+    torch.cuda.synchronize()  # torch built the stacks on ITS stream; the block runs on the runtime's own (non-blocking) stream
 
     def block(overlap=0):
         return run_block(wqkv, wo, wgu, wd, nh, True, overlap)
@@ -415,11 +416,22 @@ def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
     # parity of the sharded block against the unsharded one on the same GPU (reference launcher: cuda_launch.py:70-76)
     tp_diff = 0.0
     if full is not None:
-        y_full = run_block(torch.stack([full["q"], full["k"], full["v"]]), full["o"], torch.stack([full["g"], full["u"]]),
-                           full["d"], NH, False)
+        # (the stacked unsharded weights are torch kernels on torch's stream: finished before the runtime's stream reads them — round
+        # 4: without this wait the unsharded reference was intermittently NaN / off by whole units once N ranks shared one GPU)
+        f_qkv, f_gu = torch.stack([full["q"], full["k"], full["v"]]), torch.stack([full["g"], full["u"]])
+        torch.cuda.synchronize()
+        y_full = run_block(f_qkv, full["o"], f_gu, full["d"], NH, False)
         rt.sync()
         tp_diff = float((y.float() - y_full.float()).abs().max().item())
-        del y_full
+        if os.environ.get("IROCM_BENCH_TP_DEBUG"):  # which side moved? (both blocks once more; identical launches are bit-identical)
+            y_full2 = run_block(f_qkv, full["o"], f_gu, full["d"], NH, False)
+            rt.sync()
+            print("[tp debug] unsharded run 1 vs 2: %g; sharded vs unsharded 2: %g; nan in sharded %s / unsharded %s %s" % (
+                float((y_full.float() - y_full2.float()).abs().max().item()), float((y.float() - y_full2.float()).abs().max().item()),
+                bool(torch.isnan(y).any().item()), bool(torch.isnan(y_full).any().item()), bool(torch.isnan(y_full2).any().item())),
+                file=sys.stderr, flush=True)
+            del y_full2
+        del y_full, f_qkv, f_gu
         full = None
     # all-reduce alone: 16 MiB fp16 message
     buf = torch.zeros(T, H, device="cuda", dtype=dt)

@@ -18,16 +18,21 @@
 // Synchronisation. A launch is G workgroups (the same G on every rank and for every call); workgroup b of rank r exchanges
 // data with workgroup b of every peer ONLY (it pushes / reduces / copies sub-range b of each slice), so the whole protocol
 // is per-workgroup point-to-point flags — no grid barrier, no atomics on remote memory:
-//   writer: stores -> __syncthreads -> lane 0: release fence (system scope) -> s_waitcnt vmcnt(0) -> flag[me][b] = s in the
-//           peer's ctrl;      reader: lane 0 polls its OWN ctrl until flag[src][b] >= s (bounded: a time limit sets the
+//   writer: stores -> EVERY thread: release fence (system scope) + s_waitcnt vmcnt(0) (release_stores) -> __syncthreads ->
+//           lane 0: release fence -> s_waitcnt vmcnt(0) -> flag[me][b] = s in the peer's ctrl;      reader: lane 0 polls its OWN ctrl until flag[src][b] >= s (bounded: a time limit sets the
 //           communicator's error word instead of hanging the GPU) -> acquire fence -> __syncthreads -> loads.
 // s is a per-workgroup call counter kept in device memory (incremented by the kernel itself), so a launch carries no
 // sequence number and a hipGraph that captured it can be replayed.
 // Buffer reuse. all-reduce / all-gather / reduce-scatter make every rank wait for every other rank's push of the same call,
-// and a rank issues call s + 1's pushes only after it finished call s; with the boxes double-buffered by the parity of s a
-// rank can therefore never overwrite data a slower peer still reads (it cannot be two calls ahead). Broadcast and
-// send / recv are one-sided: they use their own boxes with CREDITS (the receiver acknowledges into the sender's ctrl; the
-// sender waits for the previous message's acknowledgement before it pushes the next one).
+// and a rank issues call s + 1's pushes only after it finished call s; the boxes are double-buffered by the parity of s. The
+// per-workgroup flags alone do NOT make that safe: workgroup b of rank A may be at call s + 1 while workgroup b' of rank B is
+// still reading call s - 1's boxes (same parity), and when the two calls differ in length their ranges differ, so A's range b can
+// overlap B's range b'. Every kernel of the family therefore starts by waiting until EVERY workgroup of every peer has published
+// call s - 1 (wait_all_workgroups on flagS / flagG in its own ctrl — a peer's workgroup publishes call s - 1 only after it left
+// call s - 2). Broadcast and send / recv are one-sided: they use their own boxes with CREDITS (the receiver's workgroups
+// acknowledge into the sender's ctrl; before it pushes the next message the sender waits for the acknowledgement of the
+// previous one from ALL of the receiver's workgroups, for the same reason). The range of workgroup b is cut in 16-byte units
+// whatever vector width a rank's kernel uses (elem_range), so writer and reader always agree on it.
 //
 // Ranks may share a device (every rank opens device `rt->device`): RCCL refuses that, this transport does not — which is
 // how the reference's multi-rank collective tests (test_cuda_all_reduce.cc:38-106, ...) run on a one-GPU box.
@@ -120,27 +125,70 @@ __device__ __forceinline__ void publish(unsigned *remote_flag, unsigned s) {
     __hip_atomic_store(remote_flag, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ __forceinline__ void acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); }
+// EVERY thread, in front of the __syncthreads() that precedes publish(): its own remote stores are performed at system scope.
+// The barrier does not do that — for a workgroup-scope barrier hipcc emits no vmcnt wait (outside tgsplit mode the waves of a
+// workgroup share their CU's L1, which is all workgroup scope asks for) — and the fence inside publish() covers the stores of lane
+// 0's wave only: without this the flag could overtake the other seven waves' data (round 4: the send / recv ring of the world-8
+// test and the TP block's all-reduces failed intermittently once eight processes time-sliced one GPU).
+__device__ __forceinline__ void release_stores() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 
-// sub-range b of `units` units
-__device__ __forceinline__ void sub_range(long units, int b, long &u0, long &u1) {
-    u0 = units * b / kDGrid;
-    u1 = units * (b + 1) / kDGrid;
+// Element range [e0, e1) of workgroup b in a `len`-element range. The partition is in 16-BYTE units whatever vector width a
+// rank's kernel uses (the width follows the alignment of that rank's own pointers; the flags are per workgroup, so writer and
+// reader of a call must cut it identically): boundaries are multiples of 16 / sizeof(T) elements, the last range ends at len.
+template <typename T> __device__ __forceinline__ void elem_range(long len, int b, long &e0, long &e1) {
+    constexpr long PU = 16 / (long)sizeof(T);
+    const long units = (len + PU - 1) / PU;
+    e0 = units * b / kDGrid * PU;
+    e1 = units * (b + 1) / kDGrid * PU;
+    e0 = e0 < len ? e0 : len;
+    e1 = e1 < len ? e1 : len;
 }
 
 template <typename T, int VEC> struct alignas(sizeof(T) * VEC) Pack { T v[VEC]; };
 
-// copy units [u0, u1) of a `len`-element range (unit = VEC elements; the last unit may be partial)
+// copy elements [e0, e1) (e0 a multiple of VEC; a last partial vector goes element by element)
 template <typename T, int VEC>
-__device__ __forceinline__ void copy_units(const T *src, T *dst, long len, long u0, long u1) {
-    for (long u = u0 + threadIdx.x; u < u1; u += kDThreads) {
-        const long e = u * VEC;
-        if (VEC > 1 && e + VEC <= len) {
+__device__ __forceinline__ void copy_range(const T *src, T *dst, long e0, long e1) {
+    for (long e = e0 + (long)threadIdx.x * VEC; e < e1; e += (long)kDThreads * VEC) {
+        if (VEC > 1 && e + VEC <= e1) {
             *reinterpret_cast<Pack<T, VEC> *>(dst + e) = *reinterpret_cast<const Pack<T, VEC> *>(src + e);
         } else {
-            for (long i = e; i < len && i < e + VEC; ++i)
+            for (long i = e; i < e1 && i < e + VEC; ++i)
                 dst[i] = src[i];
         }
     }
+}
+
+// Every thread; ends with a __syncthreads(). Thread t < (world - 1) * G waits for ONE word: flags fa (or, when given, fb) of peer
+// t / G, workgroup t % G in MY ctrl to reach `want`. Used where a workgroup is about to overwrite box space that workgroups OTHER
+// than its own partner may still be reading: the ranges of two calls differ when their lengths do, so the per-workgroup flag of
+// the partner proves nothing about the neighbours' ranges (round 4: the last, shorter piece of a multi-piece broadcast overwrote
+// what slower workgroups of a peer were still copying out; eight processes time-slicing one GPU made it visible).
+__device__ __forceinline__ void wait_all_workgroups(const DirectArgs &a, unsigned (*fa)[kDGrid], unsigned (*fb)[kDGrid], unsigned want,
+                                                    int only_peer) {
+    const int n = a.world, me = a.rank, t = threadIdx.x;
+    const int npeers = only_peer >= 0 ? 1 : n - 1;
+    if (want != 0 && t < npeers * kDGrid) {
+        const int p = only_peer >= 0 ? only_peer : (me + 1 + t / kDGrid) % n, wb = t % kDGrid;
+        if (__hip_atomic_load(&ctrl_of(a, me)->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+            const long long t0 = wall_clock64();
+            for (;;) {
+                if ((int)(__hip_atomic_load(&fa[p][wb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - want) >= 0)
+                    break;
+                if (fb && (int)(__hip_atomic_load(&fb[p][wb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - want) >= 0)
+                    break;
+                __builtin_amdgcn_s_sleep(4);
+                if (wall_clock64() - t0 > a.timeout_ticks) {
+                    __hip_atomic_store(&ctrl_of(a, me)->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+        }
+    }
+    __syncthreads();
 }
 
 template <typename T> struct Acc { using type = long long; };
@@ -183,42 +231,42 @@ __global__ __launch_bounds__(kDThreads) void direct_reduce_kernel(DirectArgs a, 
     __syncthreads();
     const unsigned s = s_sh;
     const int par = s & 1;
+    // boxes of parity par were last used by call s - 2: EVERY workgroup of every peer has left it once it published call s - 1
+    wait_all_workgroups(a, ctrl_of(a, me)->flagS, ctrl_of(a, me)->flagG, s - 1, -1);
     auto slice_len = [&](int j) {
         if (fixed_len >= 0)
             return fixed_len;
         const long rest = count - (long)j * slice;
         return rest < 0 ? 0 : (rest < slice ? rest : slice);
     };
-    // ---- phase 1: push slice j of my x into inbox[par][me] of rank j (all peers inside the unit loop: every link busy)
+    // ---- phase 1: push slice j of my x into inbox[par][me] of rank j (all peers inside the loop: every link busy)
     {
-        long maxu = 0;
+        long maxe = 0;
         for (int j = 0; j < n; ++j)
             if (j != me) {
-                const long units = (slice_len(j) + VEC - 1) / VEC;
-                long u0, u1;
-                sub_range(units, b, u0, u1);
-                maxu = u1 - u0 > maxu ? u1 - u0 : maxu;
+                long e0, e1;
+                elem_range<T>(slice_len(j), b, e0, e1);
+                maxe = e1 - e0 > maxe ? e1 - e0 : maxe;
             }
-        for (long i = threadIdx.x; i < maxu; i += kDThreads)
+        for (long i = (long)threadIdx.x * VEC; i < maxe; i += (long)kDThreads * VEC)
             for (int d = 1; d < n; ++d) {
                 const int j = (me + d) % n;
-                const long len = slice_len(j), units = (len + VEC - 1) / VEC;
-                long u0, u1;
-                sub_range(units, b, u0, u1);
-                const long u = u0 + i;
-                if (u >= u1)
+                long e0, e1;
+                elem_range<T>(slice_len(j), b, e0, e1);
+                const long e = e0 + i;
+                if (e >= e1)
                     continue;
                 const T *src = x + (long)j * slice;
                 T *dst = (T *)inbox_of(a, j, par, me);
-                const long e = u * VEC;
-                if (VEC > 1 && e + VEC <= len) {
+                if (VEC > 1 && e + VEC <= e1) {
                     *reinterpret_cast<Pack<T, VEC> *>(dst + e) = *reinterpret_cast<const Pack<T, VEC> *>(src + e);
                 } else {
-                    for (long q = e; q < len && q < e + VEC; ++q)
+                    for (long q = e; q < e1 && q < e + VEC; ++q)
                         dst[q] = src[q];
                 }
             }
     }
+    release_stores();
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int d = 1; d < n; ++d)
@@ -230,14 +278,12 @@ __global__ __launch_bounds__(kDThreads) void direct_reduce_kernel(DirectArgs a, 
     __syncthreads();
     // ---- phase 2: reduce my slice; mode 0: result to my y and into gbox[par][me] of every peer
     {
-        const long len = slice_len(me), units = (len + VEC - 1) / VEC;
-        long u0, u1;
-        sub_range(units, b, u0, u1);
+        long e0, e1;
+        elem_range<T>(slice_len(me), b, e0, e1);
         const T *mine = x + (long)me * slice;
         T *out = mode == 0 ? y + (long)me * slice : y;
-        for (long u = u0 + threadIdx.x; u < u1; u += kDThreads) {
-            const long e = u * VEC;
-            const int lim = (int)(len - e < VEC ? len - e : VEC);
+        for (long e = e0 + (long)threadIdx.x * VEC; e < e1; e += (long)kDThreads * VEC) {
+            const int lim = (int)(e1 - e < VEC ? e1 - e : VEC);
             A acc[VEC];
             for (int r = 0; r < n; ++r) {
                 const T *src = r == me ? mine : (const T *)inbox_of(a, me, par, r);
@@ -274,6 +320,7 @@ __global__ __launch_bounds__(kDThreads) void direct_reduce_kernel(DirectArgs a, 
         }
     }
     if (mode == 0) {
+        release_stores();
         __syncthreads();
         if (threadIdx.x == 0)
             for (int d = 1; d < n; ++d)
@@ -286,10 +333,9 @@ __global__ __launch_bounds__(kDThreads) void direct_reduce_kernel(DirectArgs a, 
                 acquire();
             }
             __syncthreads();
-            const long len = slice_len(src), units = (len + VEC - 1) / VEC;
-            long u0, u1;
-            sub_range(units, b, u0, u1);
-            copy_units<T, VEC>((const T *)gbox_of(a, me, par, src), y + (long)src * slice, len, u0, u1);
+            long e0, e1;
+            elem_range<T>(slice_len(src), b, e0, e1);
+            copy_range<T, VEC>((const T *)gbox_of(a, me, par, src), y + (long)src * slice, e0, e1);
         }
     }
     __syncthreads();
@@ -308,18 +354,17 @@ __global__ __launch_bounds__(kDThreads) void direct_gather_kernel(DirectArgs a, 
     __syncthreads();
     const unsigned s = s_sh;
     const int par = s & 1;
-    const long units = (len + VEC - 1) / VEC;
-    long u0, u1;
-    sub_range(units, b, u0, u1);
-    for (long u = u0 + threadIdx.x; u < u1; u += kDThreads) {
-        const long e = u * VEC;
-        if (VEC > 1 && e + VEC <= len) {
+    wait_all_workgroups(a, ctrl_of(a, me)->flagS, ctrl_of(a, me)->flagG, s - 1, -1); // (see direct_reduce_kernel)
+    long e0, e1;
+    elem_range<T>(len, b, e0, e1);
+    for (long e = e0 + (long)threadIdx.x * VEC; e < e1; e += (long)kDThreads * VEC) {
+        if (VEC > 1 && e + VEC <= e1) {
             const Pack<T, VEC> v = *reinterpret_cast<const Pack<T, VEC> *>(x + e);
             for (int d = 1; d < n; ++d)
                 *reinterpret_cast<Pack<T, VEC> *>(gbox_of(a, (me + d) % n, par, me) + e) = v;
             *reinterpret_cast<Pack<T, VEC> *>(y + (long)me * ystride + e) = v;
         } else {
-            for (long q = e; q < len && q < e + VEC; ++q) {
+            for (long q = e; q < e1 && q < e + VEC; ++q) {
                 const char v = x[q];
                 for (int d = 1; d < n; ++d)
                     gbox_of(a, (me + d) % n, par, me)[q] = v;
@@ -327,6 +372,7 @@ __global__ __launch_bounds__(kDThreads) void direct_gather_kernel(DirectArgs a, 
             }
         }
     }
+    release_stores();
     __syncthreads();
     if (threadIdx.x == 0)
         for (int d = 1; d < n; ++d)
@@ -338,7 +384,7 @@ __global__ __launch_bounds__(kDThreads) void direct_gather_kernel(DirectArgs a, 
             acquire();
         }
         __syncthreads();
-        copy_units<T, VEC>(gbox_of(a, me, par, src), y + (long)src * ystride, len, u0, u1);
+        copy_range<T, VEC>(gbox_of(a, me, par, src), y + (long)src * ystride, e0, e1);
     }
     __syncthreads();
     if (threadIdx.x == 0)
@@ -349,31 +395,28 @@ template <int VEC>
 __global__ __launch_bounds__(kDThreads) void direct_broadcast_kernel(DirectArgs a, const char *x, char *y, long len, int root) {
     using T = char;
     const int b = blockIdx.x, me = a.rank, n = a.world;
-    __shared__ unsigned s_sh;
-    if (threadIdx.x == 0)
+    __shared__ unsigned s_sh, last_sh;
+    if (threadIdx.x == 0) {
         s_sh = a.local->bseq[b] + 1;
+        last_sh = a.local->broot_last[b];
+    }
     __syncthreads();
     const unsigned s = s_sh;
-    const long units = (len + VEC - 1) / VEC;
-    long u0, u1;
-    sub_range(units, b, u0, u1);
+    long e0, e1;
+    elem_range<T>(len, b, e0, e1);
     if (me == root) {
-        if (threadIdx.x == 0) { // credit: my previous broadcast has been copied out of every peer's bbox[me]
-            const unsigned last = a.local->broot_last[b];
-            for (int d = 1; d < n; ++d)
-                wait_flag(a, &ctrl_of(a, me)->ackB[(me + d) % n][b], last);
-        }
-        __syncthreads();
-        for (long u = u0 + threadIdx.x; u < u1; u += kDThreads) {
-            const long e = u * VEC;
-            if (VEC > 1 && e + VEC <= len) {
+        // credit: my previous broadcast has been copied out of every peer's bbox[me] by ALL of the peer's workgroups (its length,
+        // and with it the ranges, may have been different)
+        wait_all_workgroups(a, ctrl_of(a, me)->ackB, nullptr, last_sh, -1);
+        for (long e = e0 + (long)threadIdx.x * VEC; e < e1; e += (long)kDThreads * VEC) {
+            if (VEC > 1 && e + VEC <= e1) {
                 const Pack<T, VEC> v = *reinterpret_cast<const Pack<T, VEC> *>(x + e);
                 for (int d = 1; d < n; ++d)
                     *reinterpret_cast<Pack<T, VEC> *>(bbox_of(a, (me + d) % n, root) + e) = v;
                 if (y != x)
                     *reinterpret_cast<Pack<T, VEC> *>(y + e) = v;
             } else {
-                for (long q = e; q < len && q < e + VEC; ++q) {
+                for (long q = e; q < e1 && q < e + VEC; ++q) {
                     const char v = x[q];
                     for (int d = 1; d < n; ++d)
                         bbox_of(a, (me + d) % n, root)[q] = v;
@@ -381,6 +424,7 @@ __global__ __launch_bounds__(kDThreads) void direct_broadcast_kernel(DirectArgs 
                 }
             }
         }
+        release_stores();
         __syncthreads();
         if (threadIdx.x == 0) {
             for (int d = 1; d < n; ++d)
@@ -393,8 +437,8 @@ __global__ __launch_bounds__(kDThreads) void direct_broadcast_kernel(DirectArgs 
             acquire();
         }
         __syncthreads();
-        copy_units<T, VEC>(bbox_of(a, me, root), y, len, u0, u1);
-        __syncthreads(); // (carries the wait for this workgroup's loads: the values are in registers / stored)
+        copy_range<T, VEC>(bbox_of(a, me, root), y, e0, e1);
+        __syncthreads(); // (a wave that arrives here has issued its stores to y, i.e. its loads from the box have returned)
         if (threadIdx.x == 0)
             publish(&ctrl_of(a, root)->ackB[me][b], s);
     }
@@ -407,16 +451,16 @@ __global__ __launch_bounds__(kDThreads) void direct_send_kernel(DirectArgs a, co
     using T = char;
     const int b = blockIdx.x, me = a.rank;
     __shared__ unsigned s_sh;
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0)
         s_sh = a.local->sseq[peer][b] + 1;
-        wait_flag(a, &ctrl_of(a, me)->ackP[peer][b], s_sh - 1); // credit: the previous message left the peer's pbox[me]
-    }
     __syncthreads();
     const unsigned s = s_sh;
-    const long units = (len + VEC - 1) / VEC;
-    long u0, u1;
-    sub_range(units, b, u0, u1);
-    copy_units<T, VEC>(x, pbox_of(a, peer, me), len, u0, u1);
+    // credit: the previous message has left the peer's pbox[me] — ALL of the peer's workgroups have copied their ranges out
+    wait_all_workgroups(a, ctrl_of(a, me)->ackP, nullptr, s - 1, peer);
+    long e0, e1;
+    elem_range<T>(len, b, e0, e1);
+    copy_range<T, VEC>(x, pbox_of(a, peer, me), e0, e1);
+    release_stores();
     __syncthreads();
     if (threadIdx.x == 0) {
         publish(&ctrl_of(a, peer)->flagP[me][b], s);
@@ -436,10 +480,9 @@ __global__ __launch_bounds__(kDThreads) void direct_recv_kernel(DirectArgs a, ch
     }
     __syncthreads();
     const unsigned s = s_sh;
-    const long units = (len + VEC - 1) / VEC;
-    long u0, u1;
-    sub_range(units, b, u0, u1);
-    copy_units<T, VEC>(pbox_of(a, me, peer), y, len, u0, u1);
+    long e0, e1;
+    elem_range<T>(len, b, e0, e1);
+    copy_range<T, VEC>(pbox_of(a, me, peer), y, e0, e1);
     __syncthreads();
     if (threadIdx.x == 0) {
         publish(&ctrl_of(a, peer)->ackP[me][b], s);

@@ -117,7 +117,11 @@ def direct_transport_cases(rt, ops, torch, world, rank, devid):
     pay = (torch.arange(5 << 20, dtype=torch.int32, device=dev) * 3) if rank == world - 1 else torch.zeros(5 << 20, dtype=torch.int32, device=dev)
     y = ops.broadcast(rt, pay, world - 1)
     rt.sync()
-    assert torch.equal(y, torch.arange(5 << 20, dtype=torch.int32, device=dev) * 3)
+    want = torch.arange(5 << 20, dtype=torch.int32, device=dev) * 3
+    if not torch.equal(y, want):
+        bad = torch.nonzero(y != want).flatten()
+        raise AssertionError(f"multi-piece broadcast: {bad.numel()} wrong, first at {int(bad[0])}..{int(bad[-1])}, got {y[bad[:4]].tolist()} "
+                             f"want {want[bad[:4]].tolist()}")
     # send / recv ring: everybody sends to rank + 1 BEFORE receiving from rank - 1 (one message of credit per pair), 4 rounds;
     # then one 24 MiB message (three pieces against one slot of credit: rank 0 receives first, as any NCCL program must)
     nxt, prv = (rank + 1) % world, (rank - 1) % world
@@ -126,7 +130,10 @@ def direct_transport_cases(rt, ops, torch, world, rank, devid):
         ops.send(rt, torch.full((cnt,), float(rank * 7 + rnd), device=dev), nxt)
         got = ops.recv(rt, (cnt,), torch.float32, prv)
         rt.sync()
-        assert torch.all(got == float(prv * 7 + rnd)).item(), rnd
+        if not torch.all(got == float(prv * 7 + rnd)).item():
+            bad = torch.nonzero(got != float(prv * 7 + rnd)).flatten()
+            raise AssertionError(f"ring round {rnd}: {bad.numel()} of {cnt} wrong, first at {int(bad[0])}..{int(bad[-1])}, got "
+                                 f"{got[bad[:4]].tolist()} want {prv * 7 + rnd}")
     cnt = 6 << 20
     msg = torch.full((cnt,), float(rank * 7 + 4), device=dev)
     if rank == 0:

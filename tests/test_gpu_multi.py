@@ -117,7 +117,8 @@ def test_bench_tp_block_on_one_device_over_the_direct_transport(world):
     the UNSHARDED block (the reference's own check, cuda_launch.py:70-76). The timings of such a run mean nothing (the ranks
     share a GPU); the parity does, and it is the first one measured at world > 1."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    env.update(IROCM_BENCH_ONE_DEVICE="1", INFINI_ROCM_COMM="direct", HSA_ENABLE_IPC_MODE_LEGACY="0", INFINI_ROCM_DIRECT_TIMEOUT_S="60")
+    env.update(IROCM_BENCH_ONE_DEVICE="1", INFINI_ROCM_COMM="direct", HSA_ENABLE_IPC_MODE_LEGACY="0", INFINI_ROCM_DIRECT_TIMEOUT_S="60",
+               IROCM_BENCH_TP_DEBUG="1")
     r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", str(world), "--steps", "5", "--warmup", "2", "--no-graph",
                         "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -125,7 +126,8 @@ def test_bench_tp_block_on_one_device_over_the_direct_transport(world):
     assert line["n_gpus"] == world and line["value"] > 0
     tp = line["tp_block"]
     assert f"TP={world}" in tp["workload"]
-    assert tp["finite"] and tp["max_abs_diff_vs_unsharded"] < 5e-2, tp
+    dbg = [ln for ln in r.stderr.splitlines() if "[tp debug]" in ln]
+    assert tp["finite"] and tp["max_abs_diff_vs_unsharded"] < 5e-2, (tp, dbg)
     assert tp["allreduce_16MiB_ms"] and tp["allreduce_16MiB_ms"] > 0
     assert tp["overlap"]["max_abs_diff_on_vs_off"] < 5e-2
     assert "error" not in (tp["reduce_scatter_all_gather"] or {}), tp["reduce_scatter_all_gather"]
