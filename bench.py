@@ -153,6 +153,7 @@ def extras(rt, ops, Event) -> dict:
         # warm-up launches leaves the chip at idle clocks (the round-1 driver run read 11.5 us for a LayerNorm that
         # takes 8.5-9.4 us warm, profiles/r02_layernorm_sweep.txt). Warm up for >= 30 ms of back-to-back launches, then
         # time >= 20 ms of them.
+        torch.cuda.synchronize()  # the inputs were made by torch on ITS stream; `rt` launches on a stream of its own
         fn()
         rt.sync()
         e0, e1 = Event(), Event()
@@ -435,6 +436,7 @@ def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
         full = None
     # all-reduce alone: 16 MiB fp16 message
     buf = torch.zeros(T, H, device="cuda", dtype=dt)
+    torch.cuda.synchronize()  # (torch's stream -> the runtime's stream)
     for _ in range(3):
         ops.all_reduce(rt, "sum", buf, out=buf)
     rt.record(e0)
@@ -484,6 +486,7 @@ def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
         try:
             xs = torch.zeros(world, T // world, H, device="cuda", dtype=dt)
             sh = torch.empty(T // world, H, device="cuda", dtype=dt)
+            torch.cuda.synchronize()
             res = {}
             for direct in (False, True):
                 for _ in range(3):
@@ -533,6 +536,7 @@ def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
             d_ms = rt.elapsed_ms(e0, e1) / iters
             # parity of the two transports on fresh data: same sum (fp32 accumulation in rank order vs RCCL's order: f16 rounding)
             probe = (torch.randn(1 << 20, device="cuda", generator=g) * 0.1).to(dt)
+            torch.cuda.synchronize()
             got_d = ops.all_reduce(rt, "sum", probe)
             rt.comm_set_algo(0)
             got_r = ops.all_reduce(rt, "sum", probe)
@@ -839,13 +843,18 @@ def main() -> int:
         line["roofline"]["attainable_peak"] = None
         line["roofline"]["attainable_peak_error"] = repr(e)[:200]
 
+    def note(what):  # progress on stderr: which secondary section a fault or a stall belongs to
+        print(f"[bench] rank {rank}: {what}", file=sys.stderr, flush=True)
+
     if not args.no_tp:
+        note("tp_block")
         try:  # never let the secondary measurement take the headline line down
             line["tp_block"] = tp_block(rt, ops, Event, world, rank, td if dist else None)
         except Exception as e:  # noqa: BLE001
             line["tp_block"] = {"error": repr(e)[:300]}
 
     if not args.no_graph:
+        note("graph_resnet50")
         try:
             line["graph_resnet50"] = graph_resnet50(local_rank, world, td if dist else None)
         except BaseException as e:  # noqa: BLE001  (SystemExit when the plugin build is absent)
@@ -853,6 +862,7 @@ def main() -> int:
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
+            note("cpu_baseline")
             try:
                 cb = cpu_baseline_reference()
             except Exception as e:  # keep the bench line even if the oracle module is missing
@@ -872,10 +882,12 @@ def main() -> int:
             else:
                 line["cpu_baseline"] = {"error": "oracle/_ref is not built", f"mkl_standin_{os.cpu_count()}core": mkl}
         if world == 1 and not args.no_extras:
+            note("extras")
             try:
                 line["extras"] = extras(rt, ops, Event)
             except Exception as e:
                 line["extras"] = {"error": repr(e)}
+    note("done")
     emit()
     if dist:  # the watchdog stays armed: a rank that never reaches this barrier must not hold the others
         td.barrier()

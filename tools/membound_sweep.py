@@ -213,6 +213,10 @@ def sweep(rt, ops, Event, only=None, budget_s: float | None = None) -> dict:
                 continue
             try:
                 fn, nbytes, shape = make()
+                # the inputs are torch kernels on torch's stream; `rt` may launch on a stream of its own (bench.py's does): a Gather
+                # that started before its index tensor was written read indices from uninitialised memory — an intermittent
+                # HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION that took the whole bench line down (round 4)
+                torch.cuda.synchronize()
                 t = timeit(rt, Event, fn)
                 gbs = nbytes / t / 1e9
                 out[f"{name}{'_hbm' if big else ''}"] = {"shape": shape, "us": round(t * 1e6, 2), "MB": round(nbytes / 1e6, 1),
@@ -247,6 +251,7 @@ def pmc_run(rt, ops, only=None):
             if only and name not in only:
                 continue
             fn, nbytes, shape = make()
+            torch.cuda.synchronize()
             rt.sync()
             ops.cast(rt, s_in, torch.int8, out=s_out)
             for _ in range(5):
