@@ -125,6 +125,25 @@ class RocmRuntime:
 
         self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def wait_torch(self) -> None:
+        """Order this runtime's stream behind torch's current stream (an event wait on the device, no host sync).
+
+        A runtime created with a stream of its own does NOT order with torch: a tensor torch is still filling on its stream
+        can be read too early by a kernel launched here (round 4: bench.py's Gather read an index tensor torch.randint had not
+        written yet and faulted). Call this between building inputs with torch and launching, or use `use_torch_stream()`."""
+        import torch
+
+        s = self.stream()
+        cur = torch.cuda.current_stream(self.device)
+        if s == cur.cuda_stream:
+            return
+        if not s:  # the legacy default stream cannot be wrapped: a full wait
+            cur.synchronize()
+            return
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        torch.cuda.ExternalStream(s, device=self.device).wait_event(ev)
+
     def sync(self) -> None:
         check(lib().infini_rocm_runtime_sync(self._h))
 

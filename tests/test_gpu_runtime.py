@@ -163,3 +163,26 @@ def test_collective_without_communicator_fails_loudly():
     r = RocmRuntime(0)
     with pytest.raises(InfiniRocmError, match="communicator not initialised"):
         ops.all_reduce(r, "sum", torch.ones(4, device="cuda"))
+
+
+@pytest.mark.gpu
+def test_wait_torch_orders_a_private_stream_behind_torch():
+    """A runtime with a stream of its own does not order with torch's stream by itself; `wait_torch()` makes it (an event wait, no
+    host sync). torch fills a large tensor (a long kernel on torch's stream); the runtime's own stream then copies it with a unary
+    identity-like op — with the wait the copy always sees the filled values."""
+    import torch
+
+    from infinitensor_amd import RocmRuntime, ops
+
+    rt = RocmRuntime(0)  # own non-blocking stream
+    assert rt.stream() != torch.cuda.current_stream().cuda_stream
+    for i in range(8):
+        x = torch.empty(64 << 20, device="cuda", dtype=torch.float16)
+        x.fill_(float(i + 1))
+        x.mul_(2.0)
+        rt.wait_torch()
+        y = ops.unary(rt, "relu", x)
+        rt.sync()
+        assert torch.all(y == float(2 * (i + 1))).item(), i
+    rt.use_torch_stream()
+    rt.wait_torch()  # same stream: nothing to do
