@@ -1061,6 +1061,11 @@ static int launch_p(infiniRocmRuntime_t rt, GemmArgs g, bool akm, bool bkm, unsi
     pa.g = g;
     pa.total_tiles = (int)total;
     pa.tab_n = (g.tiles_m < 65536 && g.tiles_n < 65536 && g.batch < 65536) ? kTileTab : 0;
+    if (const char *cap = getenv("IROCM_GEMM_TAB_N")) { // test hook (read per call): a shorter table exercises the in-place decode of
+        const int v = atoi(cap);                        // the steps beyond it, which production shapes reach only past 65 536 tiles
+        if (v >= 0 && v < pa.tab_n)
+            pa.tab_n = v;
+    }
     pa.per_batch_m = udiv_magic((unsigned long long)g.tiles_m * g.tiles_n);
     pa.per_group_m = udiv_magic(8ull * g.tiles_n);
     // one workgroup per CU walking its tiles; gridDim.x % 8 == 0 keeps every workgroup's tiles on its XCD's id range

@@ -129,6 +129,30 @@ def test_persistent_gemm_walks_several_tiles(rt, shape, ta, tb, variant):
     assert (err <= tol * np.abs(want) + tol * np.sqrt(k)).all(), float(err.max())
 
 
+@pytest.mark.parametrize("tab_n", [0, 1, 2])
+@pytest.mark.parametrize("variant,shape", [(4, (1, 16384, 3072, 128)), (5, (3, 4096, 2304, 64)), (6, (1, 8192, 2048, 192))])
+def test_persistent_gemm_tile_table_and_in_place_decode_agree(rt, monkeypatch, variant, shape, tab_n):
+    """Round 4: a workgroup of the persistent kernels reads its tiles' coordinates from an LDS table (first 256 steps) and decodes the
+    steps beyond it in place. Production shapes reach the second path only past 65 536 tiles; IROCM_GEMM_TAB_N (read per launch)
+    shortens the table, so both paths — and the hand-over between them, with the B cursor up to two tiles ahead at K = 64 — run on
+    shapes with 3-12 tiles per workgroup: bit-identical to the full table."""
+    b, m, n, k = shape
+    rng = np.random.default_rng(hash((shape, variant)) % 2 ** 32)
+    ad = dev(rng.standard_normal((b, m, k)).astype(np.float32), torch.bfloat16)
+    bd = dev(rng.standard_normal((k, n)).astype(np.float32), torch.bfloat16)
+    biasd = dev(rng.standard_normal((n,)).astype(np.float32), torch.bfloat16)
+    ops.set_matmul_variant(rt, variant)
+    try:
+        monkeypatch.delenv("IROCM_GEMM_TAB_N", raising=False)
+        want = ops.matmul(rt, ad, bd, biasd)
+        monkeypatch.setenv("IROCM_GEMM_TAB_N", str(tab_n))
+        got = ops.matmul(rt, ad, bd, biasd)
+        rt.sync()
+    finally:
+        ops.set_matmul_variant(rt, -1)
+    assert torch.equal(got, want)
+
+
 def test_matmul_splitk_heuristic_shapes(rt):
     """Shapes the heuristic routes to split-K (Llama projections at 2048 tokens; a TP-8 shard): vs the fp64 oracle on a
     row sample, and bit-identical across repeats (the reduce pass sums the slices in a fixed order)."""
