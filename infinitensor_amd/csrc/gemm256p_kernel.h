@@ -299,14 +299,6 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     };
 
     f32x4 acc[8][NT];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-                acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    };
-    zero_acc();
 
     using FA = Frag<A_KMAJOR>;
     using FB = Frag<B_KMAJOR>;
@@ -341,16 +333,19 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
             });
         });
     };
-    auto compute = [&](auto qac, auto qbc, auto cntc, FA(&aq)[4][2], FB(&bq)[2][2]) {
+    // ZERO: the first K-tile of a tile — the ks = 0 MFMA of every accumulator takes a literal zero as its C operand, so the
+    // accumulators are never cleared (128 v_mov per lane = ~530 cycles per tile boundary in the timeline, behind the store steps).
+    auto compute = [&](auto qac, auto qbc, auto cntc, auto zeroc, FA(&aq)[4][2], FB(&bq)[2][2]) {
         constexpr int qa = decltype(qac)::value, qb = decltype(qbc)::value, CNT = decltype(cntc)::value;
+        constexpr bool ZERO = decltype(zeroc)::value;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < CNT; ++j)
-                    acc[qa * 4 + i][qb * 2 + j] =
-                        Tr::mfma(bq[j][ks].get(), aq[i][ks].get(), acc[qa * 4 + i][qb * 2 + j]);
+                    acc[qa * 4 + i][qb * 2 + j] = Tr::mfma(bq[j][ks].get(), aq[i][ks].get(),
+                                                           (ZERO && ks == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[qa * 4 + i][qb * 2 + j]);
     };
 
     using I0 = std::integral_constant<int, 0>;
@@ -923,7 +918,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     // ---- the flat K-tile pipeline ------------------------------------------------------------------
     FA aq[4][2];
     FB bq0[2][2], bq1[2][2];
-    auto ktile = [&](int buf) {
+    auto ktile = [&](int buf, auto zeroc) {
         // L1
         stamp();
         read_b(I0{}, I2{}, bq0);
@@ -935,8 +930,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         barrier();
         // C1
         __builtin_amdgcn_s_setprio(1);
-        compute(I0{}, I0{}, I2{}, aq, bq0);
-        if constexpr (NJ1 > 0) compute(I0{}, I1{}, IJ1{}, aq, bq1);
+        compute(I0{}, I0{}, I2{}, zeroc, aq, bq0);
+        if constexpr (NJ1 > 0) compute(I0{}, I1{}, IJ1{}, zeroc, aq, bq1);
         __builtin_amdgcn_s_setprio(0);
         fence_sched();
         finish_cursors(); // (issues behind the MFMA burst, which is still executing)
@@ -955,8 +950,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         barrier();
         // C2
         __builtin_amdgcn_s_setprio(1);
-        if constexpr (NJ1 > 0) compute(I1{}, I1{}, IJ1{}, aq, bq1);
-        compute(I1{}, I0{}, I2{}, aq, bq0);
+        if constexpr (NJ1 > 0) compute(I1{}, I1{}, IJ1{}, zeroc, aq, bq1);
+        compute(I1{}, I0{}, I2{}, zeroc, aq, bq0);
         __builtin_amdgcn_s_setprio(0);
         barrier();
     };
@@ -1002,8 +997,10 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
                 }
             }
         }
-        for (int kt = 0; kt < nk; ++kt, ++G)
-            ktile(G & 1);
+        ktile(G & 1, std::true_type{}); // (the tile's first K-tile starts the accumulators from zero)
+        ++G;
+        for (int kt = 1; kt < nk; ++kt, ++G)
+            ktile(G & 1, std::false_type{});
         stamp();
         // Wave row 0 reaches here one barrier interval before row 1. Without the two barriers below the rows' epilogues
         // serialise: row 1's last (short) compute interval lasts as long as row 0's epilogue, and row 0's first compute of
@@ -1023,8 +1020,6 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
             else if (p.act == 1) epilogue(std::integral_constant<int, 1>{}, c_ib, c_m0, c_n0, c_s & 1);
             else epilogue(std::integral_constant<int, 5>{}, c_ib, c_m0, c_n0, c_s & 1); // launch_p admits act 0, 1, 5 only
         }
-        if (c_s + 1 < my_tiles)
-            zero_acc();
         if (wr == 1)
             barrier();
         stamp();
