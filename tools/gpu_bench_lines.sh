@@ -4,7 +4,7 @@ cd $REPO
 O=gpurun_out/round4
 mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-for rep in 1 2 3; do
+for rep in 1; do
   timeout 600 python bench.py > $O/bench_$rep.json 2> $O/bench_$rep.err; echo "bench rep $rep rc $?"
 done
 cp $O/bench_1.json $O/bench.json
