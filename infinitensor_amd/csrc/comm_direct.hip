@@ -18,8 +18,8 @@
 // Synchronisation. A launch is G workgroups (the same G on every rank and for every call); workgroup b of rank r exchanges
 // data with workgroup b of every peer ONLY (it pushes / reduces / copies sub-range b of each slice), so the whole protocol
 // is per-workgroup point-to-point flags — no grid barrier, no atomics on remote memory:
-//   writer: stores -> EVERY thread: release fence (system scope) + s_waitcnt vmcnt(0) (release_stores) -> __syncthreads ->
-//           lane 0: release fence -> s_waitcnt vmcnt(0) -> flag[me][b] = s in the peer's ctrl;      reader: lane 0 polls its OWN ctrl until flag[src][b] >= s (bounded: a time limit sets the
+//   writer: stores -> EVERY thread: s_waitcnt vmcnt(0) (release_stores: its stores have left the wave) -> __syncthreads ->
+//           lane 0: release fence (system scope) -> s_waitcnt vmcnt(0) -> flag[me][b] = s in the peer's ctrl;      reader: lane 0 polls its OWN ctrl until flag[src][b] >= s (bounded: a time limit sets the
 //           communicator's error word instead of hanging the GPU) -> acquire fence -> __syncthreads -> loads.
 // s is a per-workgroup call counter kept in device memory (incremented by the kernel itself), so a launch carries no
 // sequence number and a hipGraph that captured it can be replayed.
@@ -130,10 +130,11 @@ __device__ __forceinline__ void acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQU
 // workgroup share their CU's L1, which is all workgroup scope asks for) — and the fence inside publish() covers the stores of lane
 // 0's wave only: without this the flag could overtake the other seven waves' data (round 4: the send / recv ring of the world-8
 // test and the TP block's all-reduces failed intermittently once eight processes time-sliced one GPU).
-__device__ __forceinline__ void release_stores() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
+// (A wait, not a fence: once a wave's stores have left it — vmcnt(0): written through for the uncached destination, or sitting in
+// this XCD's L2 — the ONE system-scope release fence lane 0 executes behind the barrier (publish: buffer_wbl2 + wait) covers them,
+// because the L2 it writes back is the one every wave of this workgroup stores through: a fence per wave would repeat that
+// write-back eight times per workgroup and phase.)
+__device__ __forceinline__ void release_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // Element range [e0, e1) of workgroup b in a `len`-element range. The partition is in 16-BYTE units whatever vector width a
 // rank's kernel uses (the width follows the alignment of that rank's own pointers; the flags are per workgroup, so writer and
