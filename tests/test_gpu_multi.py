@@ -99,12 +99,14 @@ def test_rocm_launch_two_ranks_match_single_gpu(tmp_path):
 def test_bench_spawns_its_own_ranks():
     """`python bench.py --gpus 2` (no launcher): n_gpus 2, a real all-reduce bus bandwidth, TP parity."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--no-graph"],
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--no-graph", "--print-detail"],
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0
     tp = line["tp_block"]
+    # the flat scalars the driver's record keeps (config.*) carry the same figures as the nested detail
+    assert line["config"]["allreduce_16MiB_rccl_busbw_GBs"] == tp["allreduce_busbw_GBs"] and line["config"]["llama7b_block_tp2_ms"] == tp["ms_per_block"]
     assert tp["allreduce_busbw_GBs"] and tp["allreduce_busbw_GBs"] > 1.0
     assert tp["max_abs_diff_vs_unsharded"] < 5e-2 and tp["finite"]
 
@@ -120,11 +122,12 @@ def test_bench_tp_block_on_one_device_over_the_direct_transport(world):
     env.update(IROCM_BENCH_ONE_DEVICE="1", INFINI_ROCM_COMM="direct", HSA_ENABLE_IPC_MODE_LEGACY="0", INFINI_ROCM_DIRECT_TIMEOUT_S="60",
                IROCM_BENCH_TP_DEBUG="1")
     r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", str(world), "--steps", "5", "--warmup", "2", "--no-graph",
-                        "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=900, env=env)
+                        "--no-cpu-baseline", "--no-extras", "--print-detail"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == world and line["value"] > 0
     tp = line["tp_block"]
+    assert line["config"][f"llama7b_block_tp{world}_ms"] == tp["ms_per_block"]
     assert f"TP={world}" in tp["workload"]
     dbg = [ln for ln in r.stderr.splitlines() if "[tp debug]" in ln]
     assert tp["finite"] and tp["max_abs_diff_vs_unsharded"] < 5e-2, (tp, dbg)

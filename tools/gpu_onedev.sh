@@ -6,7 +6,7 @@ O=gpurun_out/onedev
 rm -rf $O; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0 IROCM_BENCH_ONE_DEVICE=1 INFINI_ROCM_COMM=direct
 for w in 2 4; do
-  timeout 300 python bench.py --gpus $w --steps 5 --warmup 2 --no-graph --no-cpu-baseline --no-extras > $O/b$w.json 2> $O/b$w.err
+  timeout 300 python bench.py --gpus $w --steps 5 --warmup 2 --no-graph --no-cpu-baseline --no-extras --print-detail > $O/b$w.json 2> $O/b$w.err
   python - <<PY
 import json
 d=json.loads(open("$O/b$w.json").read().strip().splitlines()[-1])["tp_block"]
