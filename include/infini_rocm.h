@@ -544,12 +544,15 @@ int infini_rocm_comm_init_id(infiniRocmRuntime_t rt, const void *unique_id, size
  * every process needs HSA_ENABLE_IPC_MODE_LEGACY=0. world_size <= 8. infini_rocm_comm_init does the same when the
  * environment holds INFINI_ROCM_COMM=direct (how the plugin's init_comm selects it). Settings (equal on all ranks):
  * INFINI_ROCM_DIRECT_CAP_MB (8: bytes per box slot; a message of more than world x cap goes in pieces),
- * INFINI_ROCM_DIRECT_TIMEOUT_S (20: a kernel gives up waiting for a peer, sets the error word and terminates — it never
- * hangs the GPU; infini_rocm_comm_check reports it). */
+ * INFINI_ROCM_DIRECT_TIMEOUT_S (600: a kernel gives up waiting for a peer, sets the error word and terminates — it never
+ * hangs the GPU; the next infini_rocm_runtime_sync (or infini_rocm_comm_check) returns INFINI_ROCM_RCCL_ERROR ONCE and clears the
+ * word: the tensors of the collectives since the previous sync are undefined, later collectives wait again).
+ * One process per rank (an IPC handle cannot be opened by its exporter). A synchronous collective issued while *_async ones are
+ * pending first joins the comm stream (the two families share the communicator's sequence numbers). */
 int infini_rocm_comm_init_direct(infiniRocmRuntime_t rt, const char *name, int world_size, int rank);
 /* Which transport the collectives use when both are initialised: 0 RCCL (default), 1 the direct transport. */
 int infini_rocm_comm_set_algo(infiniRocmRuntime_t rt, int algo);
-/* Blocking (one 4-byte device read): INFINI_ROCM_RCCL_ERROR when a direct-transport kernel ran into its time limit. */
+/* Blocking (one 4-byte device read): INFINI_ROCM_RCCL_ERROR when a direct-transport kernel ran into its time limit; clears the error. */
 int infini_rocm_comm_check(infiniRocmRuntime_t rt);
 int infini_rocm_comm_destroy(infiniRocmRuntime_t rt);
 int infini_rocm_comm_info(infiniRocmRuntime_t rt, int *world_size, int *rank);

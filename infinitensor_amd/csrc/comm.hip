@@ -99,6 +99,14 @@ template <typename T> __global__ __launch_bounds__(256) void sum_slabs_kernel(co
 
 // the hand-written transport serves the call when it is the only one initialised or was selected (comm_set_algo)
 static bool use_direct(const infiniRocmRuntime *rt) { return rt->dcomm && (rt->comm_algo == 1 || !rt->comm); }
+// Synchronous direct-transport collectives run on the runtime stream, the *_async ones on the comm stream, and both families share
+// the communicator's sequence number, flag words and parity boxes: a synchronous one issued before comm_join must not run
+// beside a pending async one (RCCL serialises this case itself). The runtime stream joins the comm stream first.
+static int direct_order(infiniRocmRuntime *rt) {
+    if (rt->comm_pending && rt->comm_stream)
+        return infini_rocm_comm_join(rt);
+    return INFINI_ROCM_OK;
+}
 static bool direct_wanted_by_env() {
     const char *e = std::getenv("INFINI_ROCM_COMM");
     return e && std::string(e) == "direct";
@@ -228,6 +236,11 @@ int infini_rocm_all_reduce(infiniRocmRuntime_t rt, int op, int dtype, const void
         if (count == 0)
             return INFINI_ROCM_OK;
         IROCM_CHECK_ARG(x && y && count > 0, "all_reduce: bad buffer");
+        {
+            const int ord = direct_order(rt);
+            if (ord != INFINI_ROCM_OK)
+                return ord;
+        }
         return direct_all_reduce(rt, op, dtype, x, y, count, rt->stream);
     }
     ncclDataType_t t;
@@ -294,8 +307,12 @@ int infini_rocm_reduce_scatter(infiniRocmRuntime_t rt, int dtype, const void *x,
     if (count == 0)
         return INFINI_ROCM_OK;
     IROCM_CHECK_ARG(x && y && count > 0, "reduce_scatter: bad buffer");
-    if (use_direct(rt)) // the hand-written transport IS a one-hop exchange; `direct` has nothing left to choose
+    if (use_direct(rt)) { // the hand-written transport IS a one-hop exchange; `direct` has nothing left to choose
+        const int ord = direct_order(rt);
+        if (ord != INFINI_ROCM_OK)
+            return ord;
         return direct_reduce_scatter(rt, dtype, x, y, count, rt->stream);
+    }
     const int world = rt->comm_world, rank = rt->comm_rank;
     if (!direct || world == 1 || !(dtype == INFINI_DT_F32 || dtype == INFINI_DT_F16 || dtype == INFINI_DT_BF16)) {
         IROCM_NCCL(ncclReduceScatter(x, y, (size_t)count, t, ncclSum, (ncclComm_t)rt->comm, rt->stream));
@@ -338,8 +355,12 @@ int infini_rocm_all_gather(infiniRocmRuntime_t rt, int dtype, const void *x, voi
     if (count == 0)
         return INFINI_ROCM_OK;
     IROCM_CHECK_ARG(x && y && count > 0, "all_gather: bad buffer");
-    if (use_direct(rt))
+    if (use_direct(rt)) {
+        const int ord = direct_order(rt);
+        if (ord != INFINI_ROCM_OK)
+            return ord;
         return direct_all_gather(rt, x, y, (size_t)count * dtype_size(dtype), rt->stream);
+    }
     IROCM_NCCL(ncclAllGather(x, y, (size_t)count, t, (ncclComm_t)rt->comm, rt->stream));
     return INFINI_ROCM_OK;
 }
@@ -353,8 +374,12 @@ int infini_rocm_broadcast(infiniRocmRuntime_t rt, int dtype, const void *x, void
     if (count == 0)
         return INFINI_ROCM_OK;
     IROCM_CHECK_ARG(x && y && count > 0, "broadcast: bad buffer");
-    if (use_direct(rt))
+    if (use_direct(rt)) {
+        const int ord = direct_order(rt);
+        if (ord != INFINI_ROCM_OK)
+            return ord;
         return direct_broadcast(rt, x, y, (size_t)count * dtype_size(dtype), root, rt->stream);
+    }
     IROCM_NCCL(ncclBroadcast(x, y, (size_t)count, t, root, (ncclComm_t)rt->comm, rt->stream));
     return INFINI_ROCM_OK;
 }
@@ -368,8 +393,12 @@ int infini_rocm_send(infiniRocmRuntime_t rt, int dtype, const void *x, int64_t c
     if (count == 0)
         return INFINI_ROCM_OK;
     IROCM_CHECK_ARG(x && count > 0, "send: bad buffer");
-    if (use_direct(rt))
+    if (use_direct(rt)) {
+        const int ord = direct_order(rt);
+        if (ord != INFINI_ROCM_OK)
+            return ord;
         return direct_send(rt, x, (size_t)count * dtype_size(dtype), peer, rt->stream);
+    }
     IROCM_NCCL(ncclSend(x, (size_t)count, t, peer, (ncclComm_t)rt->comm, rt->stream));
     return INFINI_ROCM_OK;
 }
@@ -383,8 +412,12 @@ int infini_rocm_recv(infiniRocmRuntime_t rt, int dtype, void *y, int64_t count, 
     if (count == 0)
         return INFINI_ROCM_OK;
     IROCM_CHECK_ARG(y && count > 0, "recv: bad buffer");
-    if (use_direct(rt))
+    if (use_direct(rt)) {
+        const int ord = direct_order(rt);
+        if (ord != INFINI_ROCM_OK)
+            return ord;
         return direct_recv(rt, y, (size_t)count * dtype_size(dtype), peer, rt->stream);
+    }
     IROCM_NCCL(ncclRecv(y, (size_t)count, t, peer, (ncclComm_t)rt->comm, rt->stream));
     return INFINI_ROCM_OK;
 }

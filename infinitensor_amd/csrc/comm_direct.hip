@@ -40,6 +40,8 @@
 
 #include <chrono>
 #include <fstream>
+#include <signal.h>
+#include <cerrno>
 #include <sys/stat.h>
 #include <thread>
 #include <unistd.h>
@@ -509,7 +511,10 @@ int direct_init(infiniRocmRuntime *rt, const char *name, int world, int rank) {
     const char *cap_env = std::getenv("INFINI_ROCM_DIRECT_CAP_MB");
     const char *to_env = std::getenv("INFINI_ROCM_DIRECT_TIMEOUT_S");
     size_t cap = (size_t)(cap_env ? std::max(1, std::atoi(cap_env)) : 8) << 20;
-    const double timeout_s = to_env ? std::atof(to_env) : 20.0;
+    // Default 600 s: a peer that is merely slow (weight loading, tune(), first-iteration skew) must be waited for like RCCL would;
+    // the limit exists so that a DEAD peer ends as an error (reported by the next runtime_sync) instead of a hung GPU. Tests and
+    // bench.py set a short one.
+    const double timeout_s = to_env ? std::atof(to_env) : 600.0;
     dc->block_bytes = kCtrlBytes + (size_t)6 * world * cap;
     // uncached / fine-grained: a peer's stores must not be shadowed by stale lines in my L2 (RCCL allocates its buffers the
     // same way); plain hipMalloc only as a last resort (enough when all ranks share one device).
@@ -557,6 +562,7 @@ int direct_init(infiniRocmRuntime *rt, const char *name, int world, int rank) {
                                                    " (is HSA_ENABLE_IPC_MODE_LEGACY=0 exported?)");
         auto path = [&](int r) { return std::string("./") + name + "_xgmi_" + std::to_string(r) + ".bin"; };
         dc->my_file = path(rank);
+        (void)unlink(dc->my_file.c_str()); // a file of the same name left by a crashed job must never be read as mine
         {
             const std::string tmp = dc->my_file + ".tmp";
             std::ofstream ofs(tmp, std::ios::binary | std::ios::trunc);
@@ -578,6 +584,16 @@ int direct_init(infiniRocmRuntime *rt, const char *name, int world, int rank) {
             DirectHello peer{};
             std::ifstream ifs(path(r), std::ios::binary);
             ifs.read((char *)&peer, sizeof(peer));
+            if (peer.pid == (int)getpid())
+                return fail(INFINI_ROCM_UNSUPPORTED, "direct transport: rank " + std::to_string(r) + " lives in THIS process; an IPC handle cannot be "
+                                                     "opened by its exporter (one process per rank; ranks may share a device)");
+            if (kill((pid_t)peer.pid, 0) != 0 && errno == ESRCH) { // a stale file of a crashed job: its writer is gone — wait for the real one
+                if (std::chrono::steady_clock::now() > begin + std::chrono::seconds(120))
+                    return fail(INFINI_ROCM_RCCL_ERROR, "direct transport: " + path(r) + " was written by a process that no longer exists");
+                std::this_thread::sleep_for(std::chrono::milliseconds(50));
+                --r;
+                continue;
+            }
             if (memcmp(peer.magic, "IROCMXG1", 8) || peer.world != world || peer.rank != r || peer.grid != kDGrid || peer.cap != cap)
                 return fail(INFINI_ROCM_RCCL_ERROR, "direct transport: " + path(r) + " does not match this job (stale file or different settings)");
             if ((e = hipIpcOpenMemHandle(&dc->opened[r], peer.handle, hipIpcMemLazyEnablePeerAccess)) != hipSuccess)
@@ -641,10 +657,16 @@ int direct_check(infiniRocmRuntime *rt) {
     if (!dc)
         return INFINI_ROCM_OK;
     unsigned err = 0;
+    rt->dcomm_dirty = 0;
     IROCM_HIP(hipMemcpy(&err, &((DirectCtrl *)dc->block)->error, sizeof(err), hipMemcpyDeviceToHost));
-    if (err)
-        IROCM_FAIL(INFINI_ROCM_RCCL_ERROR, "direct transport: a peer did not arrive within the time limit (results of the affected "
-                                           "collectives are undefined)");
+    if (err) {
+        // reported ONCE, then cleared: the kernels skip every wait while the word is set (one time limit per rank, not one per flag),
+        // so leaving it set would turn every later collective of this communicator into garbage without a wait (round-4 advisor)
+        const unsigned zero = 0;
+        IROCM_HIP(hipMemcpy(&((DirectCtrl *)dc->block)->error, &zero, sizeof(zero), hipMemcpyHostToDevice));
+        IROCM_FAIL(INFINI_ROCM_RCCL_ERROR, "direct transport: a peer did not arrive within the time limit (results of the collectives "
+                                           "since the last sync are undefined; the error is now cleared)");
+    }
     return INFINI_ROCM_OK;
 }
 
@@ -680,6 +702,7 @@ static int reduce_typed(DirectComm *dc, int dtype, const void *x, void *y, long 
 
 int direct_all_reduce(infiniRocmRuntime *rt, int op, int dtype, const void *x, void *y, int64_t count, hipStream_t st) {
     auto *dc = (DirectComm *)rt->dcomm;
+    rt->dcomm_dirty = 1; // (infini_rocm_runtime_sync reads the error word once after the stream has drained)
     const size_t es = dtype_size(dtype);
     IROCM_CHECK_ARG(es, "direct transport: unsupported dtype %s", dtype_name(dtype));
     const int n = dc->args.world;
@@ -700,6 +723,7 @@ int direct_all_reduce(infiniRocmRuntime *rt, int op, int dtype, const void *x, v
 // x: world slices of `count` elements, y: my reduced slice (sum)
 int direct_reduce_scatter(infiniRocmRuntime *rt, int dtype, const void *x, void *y, int64_t count, hipStream_t st) {
     auto *dc = (DirectComm *)rt->dcomm;
+    rt->dcomm_dirty = 1; // (infini_rocm_runtime_sync reads the error word once after the stream has drained)
     const size_t es = dtype_size(dtype);
     IROCM_CHECK_ARG(es, "direct transport: unsupported dtype %s", dtype_name(dtype));
     const long vec = 16 / (long)es, cap_elems = (long)(dc->args.cap / es) / vec * vec;
@@ -717,6 +741,7 @@ int direct_reduce_scatter(infiniRocmRuntime *rt, int dtype, const void *x, void 
 // bytes-level all-gather: y + r * bytes receives rank r's `bytes`
 int direct_all_gather(infiniRocmRuntime *rt, const void *x, void *y, size_t bytes, hipStream_t st) {
     auto *dc = (DirectComm *)rt->dcomm;
+    rt->dcomm_dirty = 1; // (infini_rocm_runtime_sync reads the error word once after the stream has drained)
     for (size_t off = 0; off < bytes;) {
         const size_t len = std::min(bytes - off, dc->args.cap);
         const char *xs = (const char *)x + off;
@@ -734,6 +759,7 @@ int direct_all_gather(infiniRocmRuntime *rt, const void *x, void *y, size_t byte
 
 int direct_broadcast(infiniRocmRuntime *rt, const void *x, void *y, size_t bytes, int root, hipStream_t st) {
     auto *dc = (DirectComm *)rt->dcomm;
+    rt->dcomm_dirty = 1; // (infini_rocm_runtime_sync reads the error word once after the stream has drained)
     for (size_t off = 0; off < bytes;) {
         const size_t len = std::min(bytes - off, dc->args.cap);
         const char *xs = (const char *)x + off;
@@ -750,6 +776,7 @@ int direct_broadcast(infiniRocmRuntime *rt, const void *x, void *y, size_t bytes
 
 int direct_send(infiniRocmRuntime *rt, const void *x, size_t bytes, int peer, hipStream_t st) {
     auto *dc = (DirectComm *)rt->dcomm;
+    rt->dcomm_dirty = 1; // (infini_rocm_runtime_sync reads the error word once after the stream has drained)
     for (size_t off = 0; off < bytes;) {
         const size_t len = std::min(bytes - off, dc->args.cap);
         const char *xs = (const char *)x + off;
@@ -765,6 +792,7 @@ int direct_send(infiniRocmRuntime *rt, const void *x, size_t bytes, int peer, hi
 
 int direct_recv(infiniRocmRuntime *rt, void *y, size_t bytes, int peer, hipStream_t st) {
     auto *dc = (DirectComm *)rt->dcomm;
+    rt->dcomm_dirty = 1; // (infini_rocm_runtime_sync reads the error word once after the stream has drained)
     for (size_t off = 0; off < bytes;) {
         const size_t len = std::min(bytes - off, dc->args.cap);
         char *ys = (char *)y + off;

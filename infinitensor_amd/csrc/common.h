@@ -155,6 +155,7 @@ struct infiniRocmRuntime {
     int num_cu = 256;
     void *comm = nullptr; // rcclComm_t, owned by comm.hip
     void *dcomm = nullptr; // irocm::DirectComm (the hand-written IPC / xGMI transport), owned by comm_direct.hip
+    int dcomm_dirty = 0;   // a direct-transport collective was enqueued since the error word was last read (runtime_sync reads it)
     int comm_algo = 0;     // 0: RCCL when it is initialised, else the direct transport; 1: the direct transport
     int comm_world = 1, comm_rank = 0;
     // overlapped collectives (comm.hip: *_async / comm_join): a second stream and a small ring of fork / join events

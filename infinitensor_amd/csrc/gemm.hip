@@ -607,25 +607,36 @@ int infini_rocm_matmul_grouped(infiniRocmRuntime_t rt, int dtype, const void *a,
     p.hs_d = (int)head_dim;
     const bool akm = !trans_a, bkm = trans_b != 0;
 
-    if (dtype == INFINI_DT_F32 && rt->matmul_compute_type != 0 && head_dim == 0 && stride_c == 0) {
+    // (batch strides: the casts below copy (stride ? batch : 1) CONTIGUOUS blocks of m * k (n * k) elements, so the path is taken only
+    // for operands that ARE such blocks — stride 0 (shared) or exactly one block; any other stride keeps the exact kernels.
+    // Round-4 advisor: with another stride the cast read the wrong rows and the kernel indexed the 16-bit copy past its end.)
+    const bool ct_strides = (stride_a == 0 || stride_a == m * k || batch == 1) && (stride_b == 0 || stride_b == n * k || batch == 1);
+    if (dtype == INFINI_DT_F32 && rt->matmul_compute_type != 0 && head_dim == 0 && stride_c == 0 && ct_strides) {
         // reduced-precision products on request: 16-bit copies of A and B in the workspace, the 256^2 split-K kernel (raw fp32
         // slice sums), fp32 output. Shapes it cannot serve (K % 64, alignment) keep the exact kernels: never LESS accurate than asked.
         const int dt16 = rt->matmul_compute_type == 1 ? INFINI_DT_BF16 : INFINI_DT_F16;
-        const int64_t na = (stride_a ? batch : 1) * m * k, nb = (stride_b ? batch : 1) * n * k;
+        const bool a_shared = stride_a == 0 || batch == 1, b_shared = stride_b == 0 || batch == 1;
+        const int64_t na = (a_shared ? 1 : batch) * m * k, nb = (b_shared ? 1 : batch) * n * k;
         GemmArgs q = p;
+        q.a_bs = a_shared ? 0 : m * k;
+        q.b_bs = b_shared ? 0 : n * k;
         const size_t a_bytes = ((size_t)na * 2 + 255) & ~(size_t)255, b_bytes = ((size_t)nb * 2 + 255) & ~(size_t)255;
-        const long tiles = ceil_div(m, 256) * ceil_div(n, 256) * batch;
-        int splits = (int)std::max<long>(1, rt->num_cu / tiles);
-        splits = std::min(splits, std::max(1, (int)(k / 512)));
-        splits = std::min(splits, 16);
-        const size_t plane_bytes = (size_t)splits * batch * m * n * sizeof(float);
-        char *ws = nullptr;
-        int st = infini_rocm_workspace(rt, a_bytes + b_bytes + plane_bytes, (void **)&ws);
-        if (st != INFINI_ROCM_OK)
-            return st;
-        q.a = ws;
-        q.b = ws + a_bytes;
+        // the support test reads alignment and shape only: a 256-byte-aligned stand-in for the workspace pointers decides it BEFORE
+        // the workspace is grown (an unsupported shape must not cost an allocation)
+        q.a = (const void *)(uintptr_t)256;
+        q.b = (const void *)(uintptr_t)(256 + a_bytes);
         if (gemm256_supported(q, akm, bkm) && (((uintptr_t)c) & 15) == 0) {
+            const long tiles = ceil_div(m, 256) * ceil_div(n, 256) * batch;
+            int splits = (int)std::max<long>(1, rt->num_cu / tiles);
+            splits = std::min(splits, std::max(1, (int)(k / 512)));
+            splits = std::min(splits, 16);
+            const size_t plane_bytes = (size_t)splits * batch * m * n * sizeof(float);
+            char *ws = nullptr;
+            int st = infini_rocm_workspace(rt, a_bytes + b_bytes + plane_bytes, (void **)&ws);
+            if (st != INFINI_ROCM_OK)
+                return st;
+            q.a = ws;
+            q.b = ws + a_bytes;
             st = infini_rocm_cast(rt, INFINI_DT_F32, dt16, a, ws, na);
             if (st == INFINI_ROCM_OK)
                 st = infini_rocm_cast(rt, INFINI_DT_F32, dt16, b, ws + a_bytes, nb);

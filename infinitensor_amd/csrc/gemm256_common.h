@@ -1,4 +1,4 @@
-// Shared pieces of the 256x256x64 GEMM kernels (gemm256.hip: 16x16x32 MFMA; gemm256m32.hip: 32x32x16 MFMA).
+// Shared pieces of the 256x256x64 GEMM kernels (gemm256.hip, gemm256p_kernel.h: 16x16x32 MFMA).
 #pragma once
 #include "gemm_common.h"
 #include <type_traits>

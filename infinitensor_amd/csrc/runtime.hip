@@ -205,6 +205,10 @@ int infini_rocm_runtime_sync(infiniRocmRuntime_t rt) {
     IROCM_HIP(hipStreamSynchronize(rt->stream));
     if (rt->comm_stream && rt->comm_pending) // async collectives nobody joined yet (comm.hip)
         IROCM_HIP(hipStreamSynchronize(rt->comm_stream));
+    // the hand-written transport's kernels give up after a time limit instead of hanging and leave an error word: the first sync
+    // behind such a collective reports it (RCCL error code) — nothing else would, and the tensors are garbage (round-4 advisor)
+    if (rt->dcomm && rt->dcomm_dirty)
+        return irocm::direct_check(rt);
     return INFINI_ROCM_OK;
 }
 

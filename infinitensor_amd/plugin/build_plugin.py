@@ -147,7 +147,7 @@ def build(verbose: bool = True) -> Path | None:
             f"-I{HERE}/include",
             f"-I{REPO}/include",
             f"-I{REF}/include",
-            f"-I{REPO}/oracle/shim",          # nlohmann/json.hpp shim (json 3.1.1)
+            f"-I{HERE}/third_party_shim",      # nlohmann/json.hpp shim (json 3.1.1) — the product build names nothing under oracle/
             f"-I{pybind11.get_include()}",
             f"-I{sysconfig.get_paths()['include']}",
         ]

@@ -433,3 +433,41 @@ def test_fp32_matmul_honours_the_compute_type(rt, ct, dt16, tol, shape):
     err16 = np.abs(host(y) - want32).max()
     assert 1e-5 < err16 < 64 * tol, err16  # the 16-bit rounding of the inputs is visible, and no larger than it should be
     assert np.allclose(host(y_odd), R.matmul(a[:, : k - 8], b[: k - 8]), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("ct,dt16", [("bf16", "bf16"), ("fp16", "f16")])
+def test_compute_type_with_batch_strides(rt, ct, dt16):
+    """Round-4 advisor (gemm.hip compute-type path): the 16-bit copies are contiguous blocks, so only batch strides of 0 or exactly one
+    block may take the path. (1) a batched MatMul with a shared B (stride 0) and a per-batch A takes it and matches the oracle's
+    product of the rounded operands; (2) a grouped launch whose weights sit at a LARGER distance than one block (gaps between the
+    members) must not: it keeps the exact kernel (checked against the exact product — the old code cast the wrong rows)."""
+    rng = np.random.default_rng(5)
+    bt, m, n, k = 3, 256, 512, 512
+    a = rng.standard_normal((bt, m, k)).astype(np.float32)
+    b = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
+    da, db = dev(a, torch.float32), dev(b, torch.float32)
+    gap = 192  # elements between the members' weights
+    slab = torch.zeros(3 * (k * n + gap), device="cuda", dtype=torch.float32)
+    wsn = [(rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32) for _ in range(3)]
+    ws = []
+    for j in range(3):
+        v = slab[j * (k * n + gap): j * (k * n + gap) + k * n].view(k, n)
+        v.copy_(dev(wsn[j], torch.float32))
+        ws.append(v)
+    outs = [torch.empty(m, n, device="cuda", dtype=torch.float32) for _ in range(3)]
+    oslab = torch.empty(3, m, n, device="cuda", dtype=torch.float32)
+    outs = [oslab[j] for j in range(3)]
+    try:
+        ops.set_matmul_compute_type(rt, ct)
+        y = ops.matmul(rt, da, db)
+        took = ops.matmul_last_variant(rt)
+        ops.matmul_grouped(rt, da[0].contiguous(), ws, outs)
+    finally:
+        ops.set_matmul_compute_type(rt, "default")
+    rt.sync()
+    want16 = R.matmul(R.round_to(a, dt16), R.round_to(b, dt16))
+    assert took == "tile256_splitk", took
+    assert np.allclose(host(y), want16, rtol=2e-5, atol=2e-5 * np.sqrt(k)), np.abs(host(y) - want16).max()
+    for j in range(3):
+        want = R.matmul(a[0], wsn[j])
+        assert np.allclose(host(outs[j]), want, rtol=1e-4, atol=2e-5), (j, np.abs(host(outs[j]) - want).max())
