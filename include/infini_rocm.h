@@ -404,11 +404,14 @@ int infini_rocm_conv_transpose2d(infiniRocmRuntime_t rt, int dtype, const void *
  * patch kernel off (the tap-shifted kernel everywhere: A/B), 5 = pointwise layers (1 x 1, any stride, channels % 64 == 0) as ONE
  * GEMM over pixel slots on the persistent 256-row kernels for every shape that qualifies (the heuristic sends them there when
  * they have >= 128 filters and enough tiles to fill half the chip), 6 = 2 with the 8-wave 128 x 256 form of the patch kernel for every
- * shape it serves (the heuristic picks it when its workgroups still fill most of the chip). All variants compute the same sums (fp32 accumulate).
+ * shape it serves (the heuristic picks it when its workgroups still fill most of the chip), 7 = 3 x 3 / pad 1 layers of stride 1 or 2
+ * (channels % 64 == 0, no residual) as ONE GEMM with K = 9 C over pixel slots on the persistent 256-row kernels ("tap mode": a tap
+ * moves the pointwise tile's 16-byte runs, the zero padding is a per-lane mask on the B fragments; the heuristic sends layers with
+ * >= 256 filters and enough slot tiles there). All variants compute the same sums (fp32 accumulate).
  * Used by tune() and tests. */
 int infini_rocm_conv2d_set_variant(infiniRocmRuntime_t rt, int variant);
 /* Which implementation the most recent conv2d call on this runtime launched: "direct32" (fp32), "pixel_gemm" (pointwise layer as
- * one GEMM over pixel slots on the persistent kernels), "resident" (F <= 64, C <= 64: weights resident in LDS, persistent
+ * one GEMM over pixel slots on the persistent kernels), "tap_gemm" (3 x 3 layer as one GEMM with K = 9 C on the same kernels), "resident" (F <= 64, C <= 64: weights resident in LDS, persistent
  * workgroups), "tap_shifted" (the other kernels of conv_s1.hip), "batched_gemm", "generic", "none". A forced
  * variant falls back when a shape does not qualify; tests and measurement tools read the route instead of assuming it. */
 int infini_rocm_conv2d_last_route(infiniRocmRuntime_t rt, const char **route);

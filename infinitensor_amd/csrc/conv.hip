@@ -526,7 +526,7 @@ int infini_rocm_conv2d_res(infiniRocmRuntime_t rt, int dtype, const void *x, con
     if (groups == 1 && variant != 1 && !(variant == 3 && pointwise_gemm) &&
         // batched-GEMM route by default only for long-K pointwise layers on big planes: with K <= 512 its 256^2 tiles run 8
         // K-tiles each and the per-tile prologue + epilogue dominates (C512->F256 @28x28: 88 us vs 66 us on conv_s1)
-        (variant == 2 || variant == 4 || variant == 6 || residual || !(pointwise_gemm && f >= 256 && c >= 1024 && p.npix >= 2048))) {
+        (variant == 2 || variant == 4 || variant == 6 || variant == 7 || residual || !(pointwise_gemm && f >= 256 && c >= 1024 && p.npix >= 2048))) {
         rt->last_conv_route = "tap_shifted";
         const int st = launch_conv_s1(rt, dtype, x, w, bias, residual, y, (int)n, (int)c, (int)h, (int)wd, (int)f, (int)r, (int)s,
                                       ph, pw, sh, sw, dh, dw, p.oh, p.ow, act);
@@ -562,7 +562,7 @@ int infini_rocm_conv2d_last_route(infiniRocmRuntime_t rt, const char **route) {
 
 int infini_rocm_conv2d_set_variant(infiniRocmRuntime_t rt, int variant) {
     IROCM_CHECK_ARG(rt, "NULL runtime");
-    IROCM_CHECK_ARG(variant >= -1 && variant <= 6, "conv2d: bad variant %d", variant);
+    IROCM_CHECK_ARG(variant >= -1 && variant <= 7, "conv2d: bad variant %d", variant);
     rt->conv_variant = variant;
     return INFINI_ROCM_OK;
 }

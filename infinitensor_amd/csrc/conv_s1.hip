@@ -40,6 +40,9 @@ int launch_conv_pw_gemm(infiniRocmRuntime_t rt, int dtype, const void *x, const 
 
 namespace irocm {
 
+int launch_conv_tap_gemm(infiniRocmRuntime_t rt, int dtype, const void *x, const void *wp, const void *bias, void *y, int64_t n,
+                         int64_t c, int oh, int ow, int in_h, int in_w, int stride, int64_t plane_elems, int64_t f, int act);
+
 template <int N> __device__ __forceinline__ void g256p_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 struct ConvS1Args {
@@ -1669,6 +1672,23 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
                 p.slot[py * sw + px] = (signed char)ps.nslots++;
             }
         }
+    // Round 5: 3 x 3 / pad 1 layers of stride 1 or 2 with >= 256 filters as ONE GEMM with K = 9 C on the persistent 256-row kernels
+    // (gemm256p_kernel.h, CONV = 3: TAP mode; gemm256p_conv3.hip). Conv variant 7 forces it for every eligible shape (tests, tune(),
+    // tools/conv_bench.py); by default it takes the layers whose filters fill the 256-row tile and whose slot tiles give the chip
+    // enough work (ResNet-50 at batch 128: C256 14 x 14, C512 7 x 7 and the strided C256 / C512 layers).
+    const bool tap_shape = r == 3 && s == 3 && ph == 1 && pw == 1 && dh == 1 && dw == 1 && ((sh == 1 && sw == 1) || (sh == 2 && sw == 2)) &&
+                           c % 64 == 0 && !res && (act == 0 || act == 1) && (long)oh * ow >= 8;
+    static const int tap_on = getenv("IROCM_CONV_TAP") ? atoi(getenv("IROCM_CONV_TAP")) : 1; // A/B hook: 0 = off
+    const bool tap_want = tap_shape && (rt->conv_variant == 7 || (rt->conv_variant < 0 && tap_on && f >= 256 &&
+                                                                  ceil_div(f, 256) * ceil_div((long)n * (((long)oh * ow + 7) / 8 * 8), 256) * 4 >= rt->num_cu));
+    if (tap_want && sh == 2) { // the tap mode addresses the phase planes in the fixed order py * 2 + px
+        ps.nslots = 4;
+        for (int i = 0; i < 4; ++i) {
+            p.slot[i] = (signed char)i;
+            ps.py[i] = (signed char)(i >> 1);
+            ps.px[i] = (signed char)(i & 1);
+        }
+    }
     const bool split = sh * sw > 1;
     const long x_bytes = p.plane_elems * 2 * (split ? ps.nslots : 1);
     if (x_bytes >= (1l << 31) - 64 || x_bytes < 64) // 32-bit buffer offsets; `x_bytes - 16` must not wrap
@@ -1807,6 +1827,31 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
             if (st >= 0)
                 return st;
         }
+    }
+    if (tap_want) {
+        bool safe = true;
+        if (!split) {
+            // a tap moves a 16-byte run by up to one row + one pixel: the bytes in front of and behind X it then reaches (masked away,
+            // but fetched) must be readable memory. True inside an arena of infini_rocm_alloc (256 bytes of slack on both sides) and
+            // for a tensor in the middle of a caller's block; a tensor at the very edge of its allocation takes the other kernels.
+            const long reach = ((long)ow + 1) * 2 + 16;
+            hipDeviceptr_t base = nullptr;
+            size_t size = 0;
+            if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)x) != hipSuccess) {
+                (void)hipGetLastError();
+                safe = false;
+            } else {
+                const char *lo = (const char *)x - reach, *hi = (const char *)x + p.plane_elems * 2 + reach;
+                safe = lo >= (const char *)base && hi <= (const char *)base + size;
+            }
+        }
+        if (safe) {
+            const int st = launch_conv_tap_gemm(rt, dtype, p.x, p.w, bias, y, n, c, oh, ow, h, wd, sh, p.plane_elems, f, act);
+            if (st >= 0)
+                return st;
+        }
+        if (split && rt->conv_variant == 7) // (the tap-shifted kernel below reads the planes through p.slot: any order serves it)
+            rt->last_conv_route = "tap_shifted";
     }
     const bool bf = dtype == INFINI_DT_BF16;
     static const int pw_on = getenv("IROCM_CONV_PW") ? atoi(getenv("IROCM_CONV_PW")) : 1; // tuning hook: 0 = off

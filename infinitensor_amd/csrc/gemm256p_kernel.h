@@ -101,6 +101,14 @@ constexpr int kExtraLds = kTabBytes + 2 * kBiasSlotBytes;
 // a plane, the ragged last run of a plane element-wise). A K-major (the FCRS weights of a 1 x 1 layer ARE [F][C]), B N-major.
 // CONV = 1: without, CONV = 2: with the residual (its own instantiation: the residual copy of the epilogue needs 16 NT more
 // registers, which the 256-column build does not have — it exists for NT <= 3 only).
+// CONV = 3 (round 5): TAP mode — a 3 x 3 convolution as the same GEMM with K = 9 C (GemmArgs::cv_taps): the K-tile sequence of a tile
+// is (channel block, tap) with the tap inner; the A cursor walks the re-packed weights [tap][F][C], the B cursor adds a per-tap
+// byte offset to the pointwise tile's addresses (a tap only MOVES a 16-byte run of pixel slots: unit stride on X itself, stride 2
+// on the de-interleaved phase planes), and what the move drags in from the neighbouring row / image / plane — the zero padding —
+// is removed by ONE per-lane AND mask per B fragment (a lane's B fragment of v_mfma_f32_16x16x32 is 8 channels of ONE slot):
+// 4 NT v_bfe + 8 NT v_and per K-tile beside 16 NT MFMAs. Why here and not in conv_s1.hip's patch kernels: those stream the weight
+// slab through 128 x 128 tiles (64 FLOP per L2 byte, 23 % MFMA busy); this loop runs 256 x 256 tiles
+// (128 FLOP per byte) through the pipeline that holds 0.58 of the MFMA peak on a plain GEMM.
 template <typename Tr, bool A_KMAJOR, bool B_KMAJOR, int NT, bool TRACE = false, int CONV = 0>
 __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     const GemmArgs &p = pa.g;
@@ -170,6 +178,14 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     const char *a_base, *b_base;
     int a_s = 0, a_kt = 0, a_G = 0; // tile step, K-tile inside it, flat index
     int b_s = 0, b_kt = 0, b_G = 0;
+    // tap mode: where inside (channel block, tap) each cursor stands. A: weights [tap][F][C] — tap a_t, channel block a_cb.
+    // B: (b_r, b_s3) and the byte offset b_koff of that tap's tile relative to the pointwise tile (cv_b0 at tap (0, 0) of block 0).
+    constexpr bool TAPS = CONV == 3;
+    // (ONE tap counter per cursor and value selects only: with separate row / column counters bumped in two branches hipcc merged the
+    // two increments into one store through a selected POINTER, which kept all three variables in scratch memory — and, loaded from
+    // there, in vector registers under exec masks)
+    int a_t = 0, a_cb = 0;
+    int b_t = 0, b_koff = TAPS ? p.cv_b0 : 0;
     auto set_a_at = [&](int ib, int m0) __attribute__((always_inline)) {
         a_base = (const char *)((const unsigned short *)p.a + (long)ib * p.a_bs);
         if constexpr (A_KMAJOR) offs_k(a_off, lda, m0, p.m, w, lane);
@@ -177,7 +193,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     };
     auto set_b_at = [&](int ib, int n0) __attribute__((always_inline)) {
         b_base = (const char *)((const unsigned short *)p.b + (long)ib * p.b_bs);
-        if constexpr (CONV) offs_mn_conv(b_off, p.cv_hw, p.cv_hwp, p.cv_hwp_m, (long)p.k * p.cv_hw, n0, p.n, w, lane);
+        if constexpr (CONV) offs_mn_conv(b_off, p.cv_hw, p.cv_hwp, p.cv_hwp_m, (long)(CONV == 3 ? p.k / 9 : p.k) * p.cv_hw, n0, p.n, w, lane);
         else if constexpr (B_KMAJOR) offs_k_n<NT>(b_off, ldb, n0, p.n, w, lane);
         else offs_mn(b_off, ldb, n0, p.n, w, lane);
     };
@@ -201,10 +217,18 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     int pend = 0; // bit 0: A, bit 1: B
     unsigned a_ent = 0u, b_ent = 0u;
     auto stage_a_next = [&](int buf, auto directc) __attribute__((always_inline)) {
-        stage4(a_base + (long)a_kt * a_step, a_off, smem + buf * BUF_BYTES, w);
+        if constexpr (TAPS) {
+            stage4(a_base + ((long)a_t * p.cv_atap + (long)a_cb * (BK * 2)), a_off, smem + buf * BUF_BYTES, w);
+            a_cb += a_t == 8 ? 1 : 0;
+            a_t = a_t == 8 ? 0 : a_t + 1;
+        } else {
+            stage4(a_base + (long)a_kt * a_step, a_off, smem + buf * BUF_BYTES, w);
+        }
         ++a_G;
         if (++a_kt == nk) {
             a_kt = 0;
+            if constexpr (TAPS)
+                a_cb = 0; // (a_t is 0 again: nk = 9 * channel blocks)
             if (++a_s < my_tiles) {
                 if (decltype(directc)::value || a_s >= tab_n) {
                     set_a_tile(a_s);
@@ -216,10 +240,20 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         }
     };
     auto stage_b_next = [&](int buf, auto directc) __attribute__((always_inline)) {
-        stage_n<NB>(b_base + (long)b_kt * b_step, b_off, smem + buf * BUF_BYTES + OPER_BYTES, w);
+        if constexpr (TAPS) {
+            stage_n<NB>(b_base + (long)b_koff, b_off, smem + buf * BUF_BYTES + OPER_BYTES, w);
+            // the step from tap b_t to the next one (tap = 3 r + s): s 0 -> 1, s 1 -> 2, row ends, the block's last tap
+            const int d = b_t == 8 ? p.cv_dcb : (b_t == 2 ? p.cv_dr01 : (b_t == 5 ? p.cv_dr12 : ((b_t == 0 || b_t == 3 || b_t == 6) ? p.cv_ds01 : p.cv_ds12)));
+            b_koff += d;
+            b_t = b_t == 8 ? 0 : b_t + 1;
+        } else {
+            stage_n<NB>(b_base + (long)b_kt * b_step, b_off, smem + buf * BUF_BYTES + OPER_BYTES, w);
+        }
         ++b_G;
         if (++b_kt == nk) {
             b_kt = 0;
+            if constexpr (TAPS)
+                b_koff = p.cv_b0; // (b_t is 0 again)
             if (++b_s < my_tiles) {
                 if (decltype(directc)::value || b_s >= tab_n) {
                     set_b_tile(b_s);
@@ -617,7 +651,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     // conv mode: the per-filter bias of the lane's eight accumulator rows lives in registers ACROSS tiles and is (re)loaded only
     // when the tile's filter block m0 changes (layers with F <= 256 have one block: loaded once per kernel), before the tile's K
     // loop so that nothing waits for it at the head of the epilogue. (Not in the 256-column residual copy: it has no registers.)
-    constexpr bool kBiasEarly = (CONV == 1) || (CONV == 2 && NT < 4);
+    constexpr bool kBiasEarly = (CONV == 1) || (CONV == 3) || (CONV == 2 && NT < 4);
     float cbias[kBiasEarly ? 8 : 1];
     int cbias_m0 = -1;
     auto load_cbias = [&](int m0) __attribute__((always_inline)) {
@@ -918,6 +952,33 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     // ---- the flat K-tile pipeline ------------------------------------------------------------------
     FA aq[4][2];
     FB bq0[2][2], bq1[2][2];
+    // tap mode: tv[j] holds, for this lane's slot of column tile j of the tile being accumulated, one validity bit per tap
+    // (bit 3 r + s: the tap's input pixel lies inside the image); c_t = the tap of the K-tile being computed. A B fragment whose bit
+    // is clear is zeroed — that IS the convolution's zero padding (what the moved run fetched instead is a neighbour's pixel).
+    unsigned tv[TAPS ? NT : 1];
+    int c_t = 0;
+    auto mask_b = [&](auto qc, auto cntc, FB(&bq)[2][2]) __attribute__((always_inline)) {
+        if constexpr (TAPS && !B_KMAJOR) {
+            constexpr int q = decltype(qc)::value, CNT = decltype(cntc)::value;
+            sfor<CNT>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const int m = __builtin_amdgcn_sbfe((int)tv[q * 2 + j], (unsigned)c_t, 1u); // 0 or -1
+                sfor<2>([&](auto kc) {
+                    constexpr int ks = decltype(kc)::value;
+                    // (the empty asm statements keep the AND a 32-bit operation: left to itself hipcc re-types it as an AND of
+                    // four 16-bit elements and emits v_and_b32 + v_and_b32_sdwa per dword — twice the instructions)
+                    typedef int i32x2_ __attribute__((ext_vector_type(2)));
+                    i32x2_ lo = __builtin_bit_cast(i32x2_, bq[j][ks].lo), hi = __builtin_bit_cast(i32x2_, bq[j][ks].hi);
+                    asm("" : "+v"(lo), "+v"(hi));
+                    lo[0] &= m; lo[1] &= m;
+                    hi[0] &= m; hi[1] &= m;
+                    asm("" : "+v"(lo), "+v"(hi));
+                    bq[j][ks].lo = __builtin_bit_cast(s16x4_t, lo);
+                    bq[j][ks].hi = __builtin_bit_cast(s16x4_t, hi);
+                });
+            });
+        }
+    };
     auto ktile = [&](int buf, auto zeroc) {
         // L1
         stamp();
@@ -930,8 +991,23 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         barrier();
         // C1
         __builtin_amdgcn_s_setprio(1);
+        mask_b(I0{}, I2{}, bq0); // (tap mode; hipcc spreads the ANDs of the later fragments between the first MFMAs)
+        if constexpr (NJ1 > 0) mask_b(I1{}, IJ1{}, bq1);
         compute(I0{}, I0{}, I2{}, zeroc, aq, bq0);
         if constexpr (NJ1 > 0) compute(I0{}, I1{}, IJ1{}, zeroc, aq, bq1);
+        if constexpr (TAPS && !B_KMAJOR) {
+            // order of this interval: the two masks the first eight MFMAs need (1 v_bfe + 4 v_and per column tile), then two mask
+            // instructions in the shadow of each MFMA until all 4 NT + 1 per... are out (left alone hipcc issues every AND first:
+            // ~30 VALU = 150-250 cycles in front of the burst, every K-tile)
+            __builtin_amdgcn_sched_group_barrier(0x2, 10, 0);
+            constexpr int kRest = NT * 9 - 10; // VALU left: NT bfe + 8 NT and, minus the ten in front
+#pragma unroll
+            for (int g = 0; g < (kRest + 1) / 2; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x8, NT * 8 - (kRest + 1) / 2, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
         fence_sched();
         finish_cursors(); // (issues behind the MFMA burst, which is still executing)
@@ -953,6 +1029,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         if constexpr (NJ1 > 0) compute(I1{}, I1{}, IJ1{}, zeroc, aq, bq1);
         compute(I1{}, I0{}, I2{}, zeroc, aq, bq0);
         __builtin_amdgcn_s_setprio(0);
+        if constexpr (TAPS)
+            c_t = c_t == 8 ? 0 : c_t + 1;
         barrier();
     };
 
@@ -985,6 +1063,22 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         }
         if constexpr (CONV != 0)
             load_cbias(c_m0);
+        if constexpr (TAPS) {
+            // validity bits of this tile's slots (nine per column tile and lane; rebuilt from an opaque lane id: see epilogue)
+            int lane_o = (int)(threadIdx.x & 63);
+            asm volatile("" : "+v"(lane_o));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const unsigned slot = (unsigned)(c_n0 + wc * (16 * NT) + j * 16 + (lane_o & 15));
+                unsigned img, pix, oy, ox;
+                udivmod_m(slot, (unsigned)p.cv_hwp, p.cv_hwp_m, img, pix);
+                udivmod_m(pix, (unsigned)p.cv_ow, p.cv_ow_m, oy, ox);
+                const unsigned rowm = ((int)oy >= p.cv_ylo ? 1u : 0u) | 2u | ((int)oy < p.cv_yhi ? 4u : 0u);
+                const unsigned colm = ((int)ox >= p.cv_xlo ? 1u : 0u) | 2u | ((int)ox < p.cv_xhi ? 4u : 0u);
+                tv[j] = ((rowm & 1u) ? colm : 0u) | (colm << 3) | ((rowm & 4u) ? (colm << 6) : 0u);
+            }
+            c_t = 0;
+        }
         if constexpr (CONV == 0) {
             if (p.bias != nullptr && c_n0 + BN_ <= p.n) { // (wave-uniform)
                 const char *bb = (const char *)((const unsigned short *)p.bias + (long)c_ib * p.bias_b + c_n0);
@@ -1012,7 +1106,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         stamp(); // (TRACE: row 0's wait for row 1)
         // this wave's part of tile c_s is complete; G = first K-tile of the next tile
         if constexpr (CONV != 0) { // the conv launcher admits act 0 / 1 only
-            using R = std::integral_constant<bool, CONV == 2>;
+            using R = std::integral_constant<bool, CONV == 2>; // (tap mode: no residual copy)
             if (p.act == 0) epilogue_conv(std::integral_constant<int, 0>{}, R{}, c_m0, c_n0);
             else epilogue_conv(std::integral_constant<int, 1>{}, R{}, c_m0, c_n0);
         } else {
@@ -1090,7 +1184,8 @@ static int launch_p(infiniRocmRuntime_t rt, GemmArgs g, bool akm, bool bkm, unsi
 }
 
 // conv mode: one instantiation per tile width and residual flag (A K-major, B gathered by pixel slots)
-template <typename Tr, int NT, bool RES> static int launch_p_conv(infiniRocmRuntime_t rt, GemmArgs g) {
+template <typename Tr, int NT, bool RES, bool TAPS = false> static int launch_p_conv(infiniRocmRuntime_t rt, GemmArgs g) {
+    static_assert(!(RES && TAPS), "tap mode has no residual copy");
     PArgs pa;
     pa.trace = nullptr;
     g.tiles_m = (int)ceil_div(g.m, BM);
@@ -1108,7 +1203,7 @@ template <typename Tr, int NT, bool RES> static int launch_p_conv(infiniRocmRunt
     const unsigned cus = (unsigned)(rt->num_cu >= 8 ? (rt->num_cu / 8) * 8 : rt->num_cu);
     if (grid > cus)
         grid = cus;
-    auto kern = gemm256p_kernel<Tr, true, false, NT, false, RES ? 2 : 1>;
+    auto kern = gemm256p_kernel<Tr, true, false, NT, false, TAPS ? 3 : (RES ? 2 : 1)>;
     IROCM_LDS_ATTR(kern, LDS_BYTES + kExtraLds, rt);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES + kExtraLds, rt->stream, pa);
     IROCM_LAUNCH_CHECK("gemm256p(conv)");

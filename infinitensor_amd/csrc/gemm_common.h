@@ -44,6 +44,21 @@ struct GemmArgs {
     int cv_hw = 0, cv_hwp = 0;
     const void *cv_res = nullptr;
     unsigned cv_hwp_m = 0;     // floor(2^32 / cv_hwp): slot -> (image, pixel) by multiply-high (udivmod_m below)
+    // Tap mode of the conv mode (gemm256p_kernel.h, CONV = 3; round 5): an R x S = 3 x 3 convolution as ONE GEMM with K = 9 C — K-tile
+    // index -> (channel block of 64, tap), TAP INNER (the nine taps of a channel block re-read nearly the same activation bytes:
+    // L2 hits). a = weights re-packed [tap][F][C] (conv_repack_w), b = the activation (unit stride: X itself; stride 2: the four
+    // de-interleaved phase planes in slot order py * 2 + px). The B tile of tap (r, s) is the pointwise tile moved by a constant
+    // byte offset rowoff[r] + coloff[s]; zero padding is a per-lane AND on the B fragments (one validity bit per (slot, tap)).
+    int cv_taps = 0;                 // 0: pointwise; 9: 3 x 3
+    int cv_ow = 0;                   // output row length: slot -> (oy, ox)
+    unsigned cv_ow_m = 0;            // floor(2^32 / cv_ow)
+    int cv_ylo = 0, cv_yhi = 0;      // tap row r = 0 lies inside the image for oy >= cv_ylo, r = 2 for oy < cv_yhi (r = 1 always)
+    int cv_xlo = 0, cv_xhi = 0;      // columns alike
+    int cv_b0 = 0;                   // byte offset of tap (0, 0) relative to b (negative for a unit-stride layer: -(W + 1) * 2)
+    int cv_ds01 = 0, cv_ds12 = 0;    // byte-offset steps of B: s 0 -> 1, s 1 -> 2
+    int cv_dr01 = 0, cv_dr12 = 0;    //   r 0 -> 1, r 1 -> 2 (s back to 0 included)
+    int cv_dcb = 0;                  //   tap (2, 2) -> tap (0, 0) of the next channel block
+    int cv_atap = 0;                 // bytes between two taps' weight images: F * C * 2
     unsigned cv_res_bytes = 0; // bytes of the residual tensor (images * F * hw * 2): the range of its buffer descriptor, computed on the host
                           // (computed in the kernel — a division — hipcc kept it in vector registers and wrapped every buffer load of
                           // the residual in a readfirstlane waterfall loop)

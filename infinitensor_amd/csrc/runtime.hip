@@ -212,15 +212,21 @@ int infini_rocm_runtime_sync(infiniRocmRuntime_t rt) {
     return INFINI_ROCM_OK;
 }
 
+static constexpr size_t kAllocSlack = 256;
+
 int infini_rocm_alloc(infiniRocmRuntime_t rt, size_t bytes, void **ptr) {
     IROCM_CHECK_ARG(rt && ptr, "NULL argument");
     IROCM_HIP(hipSetDevice(rt->device));
     *ptr = nullptr;
     if (bytes == 0)
         return INFINI_ROCM_OK;
-    // 256 bytes of slack behind every block: kernels that fetch whole 16-byte runs (the conv mode of the persistent GEMM on
-    // planes that are not a multiple of 8 pixels) may read a few bytes past the last tensor of an arena
-    IROCM_HIP(hipMalloc(ptr, bytes + 256));
+    // 256 bytes of slack behind AND in front of every block: kernels that fetch whole 16-byte runs (the conv mode of the persistent GEMM
+    // on planes that are not a multiple of 8 pixels) may read a few bytes past the last tensor of an arena, and the tap mode (3 x 3
+    // layers: a tap moves a run by up to one image row + one pixel) the same distance in front of the first one. The slack is never
+    // written and what is read from it is masked away. infini_rocm_dealloc undoes the offset.
+    void *raw = nullptr;
+    IROCM_HIP(hipMalloc(&raw, bytes + 2 * kAllocSlack));
+    *ptr = (char *)raw + kAllocSlack;
     return INFINI_ROCM_OK;
 }
 
@@ -235,7 +241,7 @@ int infini_rocm_dealloc(infiniRocmRuntime_t rt, void *ptr) {
             else
                 (void)hipGetLastError();
         }
-        IROCM_HIP(hipFree(ptr));
+        IROCM_HIP(hipFree((char *)ptr - kAllocSlack));
     }
     return INFINI_ROCM_OK;
 }

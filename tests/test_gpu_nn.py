@@ -625,3 +625,119 @@ def test_conv_stem_pool_declines_what_it_does_not_serve(rt):
         ops.conv2d_pool(rt, x, w7, None, 3, 3, 2, 2, 2, 2, 0)  # another pooling window
     with pytest.raises(RuntimeError):
         ops.conv2d_pool(rt, x.float(), w7.float(), None, 3, 3, 2, 2, 3, 2, 1)  # fp32 keeps the separate kernels
+
+
+def dev_slack2(a, dtype, fill=float("nan"), spare=512):
+    """`a` on the device in the MIDDLE of a block whose `spare` elements on both sides hold `fill`: the tap mode (3 x 3 layers as one
+    GEMM) fetches up to one row + one pixel in front of and behind the tensor and must mask all of it away — NaNs would survive."""
+    a = np.ascontiguousarray(a)
+    buf = torch.full((a.size + 2 * spare,), fill, device="cuda", dtype=dtype)
+    return buf[spare: spare + a.size].view(a.shape).copy_(torch.from_numpy(a))
+
+
+TAP_CFGS = [
+    # n, c, h, w, f, stride
+    (3, 64, 14, 14, 256, 1),    # ragged plane (196 = 24.5 runs), tiles span images
+    (2, 128, 7, 7, 512, 1),     # 49-pixel planes, two filter tiles
+    (2, 64, 16, 24, 256, 1),    # whole-run plane, non-square
+    (1, 64, 56, 56, 256, 1),    # long rows (front slack 114 bytes)
+    (5, 192, 9, 11, 320, 1),    # three channel blocks, ragged filters, odd rows
+    (3, 64, 28, 28, 256, 2),    # stride 2: phase planes 14 x 14
+    (2, 128, 14, 14, 512, 2),   # stride 2: 7 x 7 output
+    (2, 64, 15, 13, 256, 2),    # stride 2 on odd input extents (the last input row / column is read by r = 1 only)
+    (2, 64, 30, 18, 300, 2),
+]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("mode", ["plain", "bias_relu"])
+@pytest.mark.parametrize("cfg", TAP_CFGS)
+def test_conv3x3_tap_gemm_mode(rt, cfg, mode, dt):
+    """Round 5: 3 x 3 / pad 1 layers of stride 1 and 2 as ONE GEMM with K = 9 C on the persistent 256-row kernels (conv variant 7,
+    route "tap_gemm"; csrc/gemm256p_kernel.h CONV = 3). A tap moves the pointwise tile's 16-byte runs, so the runs at a row's /
+    image's / plane's edge drag in neighbours (or the NaN-filled slack around the tensor): the per-lane masks must remove exactly
+    those. Against the oracle (reference semantics: src/kernels/cuda/conv.cc:57-168) and against the tap-shifted kernel."""
+    n, c, h, w, f, st = cfg
+    rng = np.random.default_rng(abs(hash(cfg)) % 2 ** 32)
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((f, c, 3, 3)) / np.sqrt(9 * c)).astype(np.float32)
+    b = rng.standard_normal((f,)).astype(np.float32) if "bias" in mode else None
+    act = 1 if "relu" in mode else 0
+    xd, wd = dev_slack2(x, TD[dt]), dev(wt, TD[dt])
+    bd = dev(b, TD[dt]) if b is not None else None
+    oh, ow = (h + st - 1) // st, (w + st - 1) // st
+    guard = torch.full((n, f, oh, ow), 7.0, device="cuda", dtype=TD[dt])  # every element must be written
+    try:
+        ops.set_conv_variant(rt, 7)
+        y = ops.conv2d(rt, xd, wd, 1, 1, st, st, bias=bd, act=act, out=guard)
+        assert ops.conv_last_route(rt) == "tap_gemm"  # not a silent fall-back to the kernel it is compared with
+        ops.set_conv_variant(rt, 4)
+        y2 = ops.conv2d(rt, xd, wd, 1, 1, st, st, bias=bd, act=act)
+        assert ops.conv_last_route(rt) == "tap_shifted"
+    finally:
+        ops.set_conv_variant(rt, -1)
+    want = R.conv2d(R.round_to(x, dt), R.round_to(wt, dt), 1, 1, st, st, 1, 1)
+    if b is not None:
+        want = want + R.round_to(b, dt).reshape(1, f, 1, 1)
+    if act:
+        want = np.maximum(want, 0)
+    tol = {"f16": 3e-3, "bf16": 2.4e-2}[dt]
+    got = host(y)
+    assert np.isfinite(got).all(), "a masked-away neighbour (NaN slack) leaked into the sum"
+    assert np.allclose(got, want, rtol=tol, atol=tol), np.abs(got - want).max()
+    assert np.allclose(got, host(y2), rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("nt", [2, 3, 4])
+@pytest.mark.parametrize("cfg", [(3, 64, 14, 14, 256, 1), (2, 128, 14, 14, 512, 2), (6, 64, 7, 7, 256, 1)])
+def test_conv3x3_tap_gemm_every_tile_width(rt, cfg, nt, monkeypatch):
+    """Every instantiation of the tap mode (128 / 192 / 256-column tiles; IROCM_CONV_TAP_NT forces the width the cost model would
+    otherwise pick), several tiles per workgroup included (the cursors cross tile boundaries with their tap state)."""
+    n, c, h, w, f, st = cfg
+    monkeypatch.setenv("IROCM_CONV_TAP_NT", str(nt))
+    rng = np.random.default_rng(abs(hash((cfg, nt))) % 2 ** 32)
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((f, c, 3, 3)) / np.sqrt(9 * c)).astype(np.float32)
+    b = rng.standard_normal((f,)).astype(np.float32)
+    xd, wd, bd = dev_slack2(x, torch.float16), dev(wt, torch.float16), dev(b, torch.float16)
+    try:
+        ops.set_conv_variant(rt, 7)
+        y = ops.conv2d(rt, xd, wd, 1, 1, st, st, bias=bd, act=1)
+        assert ops.conv_last_route(rt) == "tap_gemm"
+    finally:
+        ops.set_conv_variant(rt, -1)
+    want = np.maximum(R.conv2d(R.round_to(x, "f16"), R.round_to(wt, "f16"), 1, 1, st, st, 1, 1) + R.round_to(b, "f16").reshape(1, f, 1, 1), 0)
+    assert np.allclose(host(y), want, rtol=3e-3, atol=3e-3), np.abs(host(y) - want).max()
+
+
+def test_conv3x3_tap_gemm_many_tiles_per_workgroup_and_edges(rt):
+    """Several slot tiles per workgroup (the A / B cursors run ahead across tile boundaries and reset their tap state there) on a plane
+    whose rows are shorter than a 16-byte run (every run straddles rows), plus a tensor that may start its allocation: the launcher
+    proves the bytes in front of X readable or falls back — either way the result must be right. Checked on ~6 000 sampled outputs
+    (R.conv2d_at: one fp64 dot product each), always including every image's corners and the first / last image."""
+    n, c, h, w, f = 1024, 64, 12, 6, 256   # 1024 * 72 = 73 728 slots = 288 tiles of 256 on 256 CUs
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((f, c, 3, 3)) / np.sqrt(9 * c)).astype(np.float32)
+    xd, wd = dev_slack2(x, torch.float16), dev(wt, torch.float16)
+    co = np.stack([rng.integers(0, n, 6000), rng.integers(0, f, 6000), rng.integers(0, h, 6000), rng.integers(0, w, 6000)], axis=1)
+    fixed = [(i, fi, yy, xx) for i in (0, 1, n // 2, n - 1) for fi in (0, f - 1) for yy in (0, 1, h - 2, h - 1) for xx in (0, 1, w - 2, w - 1)]
+    co = np.concatenate([co, np.array(fixed)], axis=0)
+    want = R.conv2d_at(R.round_to(x, "f16"), R.round_to(wt, "f16"), co, 1, 1, 1, 1, 1, 1)
+    try:
+        ops.set_conv_variant(rt, 7)
+        y = ops.conv2d(rt, xd, wd, 1, 1, 1, 1)
+        assert ops.conv_last_route(rt) == "tap_gemm"
+        big = torch.empty(x.size + 64, dtype=torch.float16, device="cuda")  # (likely the start of a fresh caching-allocator segment)
+        xe = big[: x.size].view(x.shape).copy_(xd)
+        ye = ops.conv2d(rt, xe, wd, 1, 1, 1, 1)
+        route_edge = ops.conv_last_route(rt)
+    finally:
+        ops.set_conv_variant(rt, -1)
+    pick = lambda t: t[co[:, 0], co[:, 1], co[:, 2], co[:, 3]].float().cpu().numpy().astype(np.float64)
+    ci = torch.from_numpy(co).cuda()
+    pick = lambda t: t[ci[:, 0], ci[:, 1], ci[:, 2], ci[:, 3]].float().cpu().numpy().astype(np.float64)
+    assert torch.isfinite(y.float()).all().item() and torch.isfinite(ye.float()).all().item()
+    assert np.allclose(pick(y), want, rtol=3e-3, atol=3e-3), np.abs(pick(y) - want).max()
+    assert route_edge in ("tap_gemm", "tap_shifted")  # (whether `big` starts its segment is the allocator's business; both must be right)
+    assert np.allclose(pick(ye), want, rtol=3e-3, atol=3e-3), (route_edge, np.abs(pick(ye) - want).max())

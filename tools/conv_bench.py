@@ -41,19 +41,21 @@ def main():
     ap.add_argument("--variants", default="-1,1,2,3")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--res", action="store_true", help="add a residual operand to the expanding pointwise layers (f > c, 1 x 1 / 1): the join of a bottleneck")
+    ap.add_argument("--tap-nt", default="", help="for variant 7: comma-separated tile widths (2,3,4) to force, one column each")
     ap.add_argument("--layers", default="", help="comma-separated indices into the layer table (default: all)")
     args = ap.parse_args()
     dt = {"f16": torch.float16, "bf16": torch.bfloat16}[args.dtype]
     rt = RocmRuntime(0)
     variants = [int(v) for v in args.variants.split(",")]
-    totals = {v: 0.0 for v in variants}
+    totals = {}
     tot_flop = 0.0
     tot_floor = 0.0
     table = [RESNET50[int(i)] for i in args.layers.split(",")] if args.layers else RESNET50
     for cnt, c, h, f, r, st, pad in table:
         # (64 spare elements behind the input, as in the plugin's arena: the pixel-slot GEMM reads up to 14 bytes past a ragged plane)
-        xbuf = torch.empty((args.batch * c * h * h + 64,), device="cuda", dtype=dt)
-        x = xbuf[: args.batch * c * h * h].view(args.batch, c, h, h).copy_(torch.randn((args.batch, c, h, h), device="cuda"))
+        # and 256 in front: the tap mode (3 x 3 layers as one GEMM) reads up to one row + one pixel in front of the first plane)
+        xbuf = torch.empty((args.batch * c * h * h + 64 + 256,), device="cuda", dtype=dt)
+        x = xbuf[256: 256 + args.batch * c * h * h].view(args.batch, c, h, h).copy_(torch.randn((args.batch, c, h, h), device="cuda"))
         w = (torch.randn((f, c, r, r), device="cuda") / (c * r * r) ** 0.5).to(dt)
         b = torch.randn((f,), device="cuda").to(dt)
         oh = (h + 2 * pad - r) // st + 1
@@ -71,8 +73,18 @@ def main():
             print(f"x {x.data_ptr():#x}+{x.numel() * 2:#x} w {w.data_ptr():#x} b {b.data_ptr():#x} y {y.data_ptr():#x}+{y.numel() * 2:#x} "
                   f"ws {rt.workspace(1):#x}", flush=True)
         torch.cuda.synchronize()
+        runs = []
         for v in variants:
+            if v == 7 and args.tap_nt:
+                runs += [(v, nt) for nt in args.tap_nt.split(",")]
+            else:
+                runs.append((v, None))
+        for v, tnt in runs:
             ops.set_conv_variant(rt, v)
+            if tnt is not None:
+                os.environ["IROCM_CONV_TAP_NT"] = tnt
+            else:
+                os.environ.pop("IROCM_CONV_TAP_NT", None)
             for _ in range(2):
                 ops.conv2d(rt, x, w, pad, pad, st, st, bias=b, act=1, out=y, residual=res)
             e0, e1 = Event(), Event()
@@ -82,12 +94,13 @@ def main():
             rt.record(e1)
             rt.sync()
             ms = rt.elapsed_ms(e0, e1) / args.iters
-            totals[v] += ms * cnt
-            route = {"pixel_gemm": "P", "tap_shifted": "T", "resident": "R", "batched_gemm": "B", "generic": "G", "direct32": "D"}[ops.conv_last_route(rt)]
-            line += f" v{v}: {ms * 1e3:8.1f} us {flop / ms / 1e9:7.1f} TF x{ms * 1e3 / floor_us:4.1f} {route} |"
+            key = v if tnt is None else f"{v}/nt{tnt}"
+            totals[key] = totals.get(key, 0.0) + ms * cnt
+            route = {"tap_gemm": "X", "pixel_gemm": "P", "tap_shifted": "T", "resident": "R", "batched_gemm": "B", "generic": "G", "direct32": "D"}[ops.conv_last_route(rt)]
+            line += f" v{key}: {ms * 1e3:8.1f} us {flop / ms / 1e9:7.1f} TF x{ms * 1e3 / floor_us:4.1f} {route} |"
         print(line, flush=True)
     ops.set_conv_variant(rt, -1)
-    print("route letters: P pixel-slot GEMM on the persistent kernels, R resident-weights kernel, T tap-shifted / patch kernels (conv_s1.hip), B batched GEMM, G generic")
+    print("route letters: X 3 x 3 layer as one GEMM with K = 9 C (tap mode), P pixel-slot GEMM on the persistent kernels, R resident-weights kernel, T tap-shifted / patch kernels (conv_s1.hip), B batched GEMM, G generic")
     print(f"network roofline floor: {tot_floor / 1e3:.3f} ms")
     print("network conv total: " + "  ".join(f"v{v}: {t:.3f} ms ({tot_flop / t / 1e9:.1f} TF/s)" for v, t in totals.items()))
 
