@@ -152,6 +152,10 @@ struct infiniRocmRuntime {
     uint64_t wcache_epoch = 0;      // bumped whenever an entry is dropped (captured graphs may still address it)
     hipStream_t side_stream = nullptr; // non-captured helper stream (packs weights while the main stream records)
     void *zeros = nullptr; // 256 zero bytes (K-tail source for the LDS-DMA GEMM staging)
+    // hand-off flag words of kernels whose workgroups exchange data inside a launch (the split-K form of the conv tap GEMM):
+    // zeroed at creation, every kernel leaves them zero (each word's single consumer resets it)
+    unsigned *sync_flags = nullptr;
+    static constexpr size_t kSyncFlagWords = 32768;
     int num_cu = 256;
     void *comm = nullptr; // rcclComm_t, owned by comm.hip
     void *dcomm = nullptr; // irocm::DirectComm (the hand-written IPC / xGMI transport), owned by comm_direct.hip

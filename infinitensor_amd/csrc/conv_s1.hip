@@ -41,7 +41,9 @@ int launch_conv_pw_gemm(infiniRocmRuntime_t rt, int dtype, const void *x, const 
 namespace irocm {
 
 int launch_conv_tap_gemm(infiniRocmRuntime_t rt, int dtype, const void *x, const void *wp, const void *bias, void *y, int64_t n,
-                         int64_t c, int oh, int ow, int in_h, int in_w, int stride, int64_t plane_elems, int64_t f, int act);
+                         int64_t c, int oh, int ow, int in_h, int in_w, int stride, int64_t plane_elems, int64_t f, int act,
+                         int split, void *slab, size_t slab_bytes);
+int conv_tap_split(infiniRocmRuntime_t rt, int64_t n, int64_t hw, int64_t c, int64_t f, size_t *slab_bytes);
 
 template <int N> __device__ __forceinline__ void g256p_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -1674,13 +1676,22 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
         }
     // Round 5: 3 x 3 / pad 1 layers of stride 1 or 2 with >= 256 filters as ONE GEMM with K = 9 C on the persistent 256-row kernels
     // (gemm256p_kernel.h, CONV = 3: TAP mode; gemm256p_conv3.hip). Conv variant 7 forces it for every eligible shape (tests, tune(),
-    // tools/conv_bench.py); by default it takes the layers whose filters fill the 256-row tile and whose slot tiles give the chip
-    // enough work (ResNet-50 at batch 128: C256 14 x 14, C512 7 x 7 and the strided C256 / C512 layers).
+    // tools/conv_bench.py). Default routing by measurement (batch 128, f16, us; tools/conv_bench.py on three boxes):
+    //   strided layers (the tap-shifted kernel on phase planes was their only kernel): C256 28 x 28 / 2 -> 74-77 vs 87-92,
+    //     C512 14 x 14 / 2 -> 78-82 vs 115-120 (split-K x 4): taken whenever F >= 256;
+    //   unit-stride layers compete with the patch kernels: C512 7 x 7 (56 tiles, split-K x 4) 58-61 vs 69-73: taken; C256 14 x 14 (100
+    //     tiles, split-K x 2) 51-57 vs 49.5: not taken — i.e. only where the tiles are so few that the split is by four.
     const bool tap_shape = r == 3 && s == 3 && ph == 1 && pw == 1 && dh == 1 && dw == 1 && ((sh == 1 && sw == 1) || (sh == 2 && sw == 2)) &&
                            c % 64 == 0 && !res && (act == 0 || act == 1) && (long)oh * ow >= 8;
     static const int tap_on = getenv("IROCM_CONV_TAP") ? atoi(getenv("IROCM_CONV_TAP")) : 1; // A/B hook: 0 = off
-    const bool tap_want = tap_shape && (rt->conv_variant == 7 || (rt->conv_variant < 0 && tap_on && f >= 256 &&
-                                                                  ceil_div(f, 256) * ceil_div((long)n * (((long)oh * ow + 7) / 8 * 8), 256) * 4 >= rt->num_cu));
+    bool tap_want = tap_shape && rt->conv_variant == 7;
+    if (tap_shape && rt->conv_variant < 0 && tap_on && f >= 256) {
+        const long tiles256 = ceil_div(f, 256) * ceil_div((long)n * (((long)oh * ow + 7) / 8 * 8), 256);
+        if (sh == 2)
+            tap_want = tiles256 * 4 >= rt->num_cu / 2;                       // enough work for the persistent kernels at all
+        else
+            tap_want = conv_tap_split(rt, n, (long)oh * ow, c, f, nullptr) >= 4; // few tiles, long K
+    }
     if (tap_want && sh == 2) { // the tap mode addresses the phase planes in the fixed order py * 2 + px
         ps.nslots = 4;
         for (int i = 0; i < 4; ++i) {
@@ -1720,8 +1731,13 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
         }
     }
     const size_t ws_w = cached ? 0 : w_bytes;
+    // the tap GEMM's split-K exchange slab (fp32 partial row blocks) sits behind the weights / phase planes
+    size_t tap_slab_bytes = 0;
+    const int tap_split = tap_want ? conv_tap_split(rt, n, (long)oh * ow, c, f, &tap_slab_bytes) : 1;
     // (+256: the pixel-slot GEMM a strided pointwise layer continues with reads up to 14 bytes past a ragged last plane)
-    const size_t ws_bytes = ws_w + (split ? (size_t)x_bytes + 256 : 0);
+    const size_t ws_planes = ws_w + (split ? (size_t)x_bytes + 256 : 0);
+    const size_t ws_slab_off = (ws_planes + 255) & ~(size_t)255;
+    const size_t ws_bytes = tap_slab_bytes ? ws_slab_off + tap_slab_bytes : ws_planes;
     char *ws = nullptr;
     if (ws_bytes) {
         int st = infini_rocm_workspace(rt, ws_bytes, (void **)&ws);
@@ -1846,7 +1862,8 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
             }
         }
         if (safe) {
-            const int st = launch_conv_tap_gemm(rt, dtype, p.x, p.w, bias, y, n, c, oh, ow, h, wd, sh, p.plane_elems, f, act);
+            const int st = launch_conv_tap_gemm(rt, dtype, p.x, p.w, bias, y, n, c, oh, ow, h, wd, sh, p.plane_elems, f, act, tap_split,
+                                                tap_slab_bytes ? ws + ws_slab_off : nullptr, tap_slab_bytes);
             if (st >= 0)
                 return st;
         }

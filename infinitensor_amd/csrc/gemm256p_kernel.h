@@ -51,6 +51,20 @@ __device__ __forceinline__ void offs_k_n(unsigned (&off)[4], long ld, int row0, 
         off[i] = (unsigned)(((long)gr * ld + c_log * 8) * 2);
     }
 }
+// offs_k with the eight 16-row blocks of each 128-row half rotated: LDS row block b holds the tile's row block (b + rot) % 8
+// (split-K of the tap mode: see exchange() in the kernel)
+__device__ __forceinline__ void offs_k_rot(unsigned (&off)[4], long ld, int row0, int rows, int w, int lane, int rot) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = w * 4 + i;
+        const int r = piece * 8 + (lane >> 3);
+        const int c_log = (lane & 7) ^ ((r >> 1) & 7);
+        const int rr = (r & ~0x70) | ((((r >> 4) + rot) & 7) << 4);
+        int gr = row0 + rr;
+        gr = gr < rows ? gr : rows - 1;
+        off[i] = (unsigned)(((long)gr * ld + c_log * 8) * 2);
+    }
+}
 template <int CNT>
 __device__ __forceinline__ void stage_n(const char *ubase, const unsigned (&off)[4], char *lds_oper, int w) {
 #pragma unroll
@@ -65,6 +79,13 @@ struct PArgs {
     int tab_n;       // steps of a workgroup served by the LDS tile table (kTileTab, or 0: tile counts beyond 16 bits)
     unsigned per_batch_m, per_group_m; // floor(2^32 / (tiles_m * tiles_n)), floor(2^32 / (8 * tiles_n)): decode() divides by multiply-high
     unsigned long long *trace; // TRACE instantiation only: [gridDim.x][8 waves][kTraceSlots] s_memtime stamps
+    // tap mode, split-K (CONV = 3 only; 1 = off): `split` workgroups share ONE output tile, each sums a contiguous range of the
+    // tile's K-tiles, then the slices trade accumulator row blocks through `slab` (fp32, written through) and every slice
+    // finishes 8 / split of each wave's eight 16-row blocks: see exchange() in the kernel.
+    int split;
+    char *slab;       // [tile][source slice][wave][row block][column tile][lane] x 16 bytes
+    unsigned slab_bytes;
+    unsigned *flags;  // [tile][source slice][destination slice][wave]: zero between launches (the consumer resets its flag)
 };
 
 constexpr int kTraceSlots = 128;
@@ -130,8 +151,23 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     const int wr = w >> 2, wc = w & 3;
     const int l15 = lane & 15, g4 = lane >> 4;
 
-    const int nk = p.k / BK;
-    const int my_tiles = (pa.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    // split-K (tap mode): workgroup b = 8 idx + xcd works on slice idx % S of tile (idx / S) * 8 + xcd — the S slices of a tile run
+    // on ONE XCD (their slabs meet in its L2), every workgroup has exactly one unit and the grid is <= the CU count (launcher), so
+    // all units are resident at once and the slices' mutual waits cannot deadlock.
+    const int S = (CONV == 3) ? pa.split : 1;
+    int sp_slice = 0, sp_tile = 0;
+    if constexpr (CONV == 3) {
+        if (S > 1) {
+            const int idx = (int)(blockIdx.x >> 3);
+            sp_slice = idx % S;
+            sp_tile = (idx / S) * 8 + (int)(blockIdx.x & 7);
+            if (sp_tile >= pa.total_tiles)
+                return;
+        }
+    }
+    const int nk = (p.k / BK) / S;
+    const int kt0 = sp_slice * nk; // first K-tile of this workgroup's range
+    const int my_tiles = S > 1 ? 1 : (pa.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int total_kt = my_tiles * nk; // this workgroup's flat K-tile sequence
     const unsigned per_batch = (unsigned)p.tiles_m * p.tiles_n;
 
@@ -140,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     auto decode = [&](int s, int &ib, int &m0, int &n0) {
         // (every division by multiply-high + one correction: with plain `/` and `%` on run-time values this was 3 emulated
         // divisions of ~45 instructions, three times per tile — A cursor, B cursor, tile loop)
-        unsigned wg = xcd_remap((unsigned)s * gridDim.x + blockIdx.x, (unsigned)pa.total_tiles);
+        unsigned wg = S > 1 ? (unsigned)sp_tile : xcd_remap((unsigned)s * gridDim.x + blockIdx.x, (unsigned)pa.total_tiles);
         unsigned ibu, rest;
         udivmod_m(wg, per_batch, pa.per_batch_m, ibu, rest);
         ib = (int)ibu;
@@ -184,11 +220,21 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     // (ONE tap counter per cursor and value selects only: with separate row / column counters bumped in two branches hipcc merged the
     // two increments into one store through a selected POINTER, which kept all three variables in scratch memory — and, loaded from
     // there, in vector registers under exec masks)
-    int a_t = 0, a_cb = 0;
-    int b_t = 0, b_koff = TAPS ? p.cv_b0 : 0;
+    auto b_delta = [&](int t) { // the step of B's byte offset from tap t to the next one (tap = 3 r + s)
+        return t == 8 ? p.cv_dcb : (t == 2 ? p.cv_dr01 : (t == 5 ? p.cv_dr12 : ((t == 0 || t == 3 || t == 6) ? p.cv_ds01 : p.cv_ds12)));
+    };
+    int a_t = TAPS ? kt0 % 9 : 0, a_cb = TAPS ? kt0 / 9 : 0;
+    int b_t = a_t, b_koff = 0;
+    if constexpr (TAPS) {
+        // (one channel block's nine steps add up to 64 channels: BK * hw * 2 bytes)
+        b_koff = p.cv_b0 + a_cb * (BK * 2 * p.cv_hw);
+        for (int u = 0; u < b_t; ++u)
+            b_koff += b_delta(u);
+    }
     auto set_a_at = [&](int ib, int m0) __attribute__((always_inline)) {
         a_base = (const char *)((const unsigned short *)p.a + (long)ib * p.a_bs);
-        if constexpr (A_KMAJOR) offs_k(a_off, lda, m0, p.m, w, lane);
+        if constexpr (CONV == 3) offs_k_rot(a_off, lda, m0, p.m, w, lane, sp_slice * (8 / S));
+        else if constexpr (A_KMAJOR) offs_k(a_off, lda, m0, p.m, w, lane);
         else offs_mn(a_off, lda, m0, p.m, w, lane);
     };
     auto set_b_at = [&](int ib, int n0) __attribute__((always_inline)) {
@@ -243,8 +289,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         if constexpr (TAPS) {
             stage_n<NB>(b_base + (long)b_koff, b_off, smem + buf * BUF_BYTES + OPER_BYTES, w);
             // the step from tap b_t to the next one (tap = 3 r + s): s 0 -> 1, s 1 -> 2, row ends, the block's last tap
-            const int d = b_t == 8 ? p.cv_dcb : (b_t == 2 ? p.cv_dr01 : (b_t == 5 ? p.cv_dr12 : ((b_t == 0 || b_t == 3 || b_t == 6) ? p.cv_ds01 : p.cv_ds12)));
-            b_koff += d;
+            b_koff += b_delta(b_t);
             b_t = b_t == 8 ? 0 : b_t + 1;
         } else {
             stage_n<NB>(b_base + (long)b_kt * b_step, b_off, smem + buf * BUF_BYTES + OPER_BYTES, w);
@@ -679,7 +724,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     };
 
     // ---- conv-mode epilogue: rows are filters, columns pixel slots; Y is NCHW ---------------------------------------
-    auto epilogue_conv = [&](auto actc, auto resc, int m0, int n0) __attribute__((always_inline)) {
+    auto epilogue_conv = [&](auto actc, auto resc, int m0, int n0, unsigned rbmask) __attribute__((always_inline)) {
         constexpr int ACT = decltype(actc)::value;
         // (opaque lane id: see epilogue)
         int lane_o = (int)(threadIdx.x & 63);
@@ -900,7 +945,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
                 } else {
                     wait_lgkm<0>();
                 }
-                const bool rowok = rows_inside || srow < F;
+                const bool rowok = (rows_inside || srow < F) && ((rbmask >> i) & 1u); // (split-K: the row blocks this slice finishes)
                 sfor<NT / 2>([&](auto jpc) {
                     constexpr int jp = decltype(jpc)::value;
                     u32x4_t o = ov[i & 1][jp];
@@ -947,6 +992,90 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
             if (HW % 8 == 0) store_all(std::true_type{});
             else store_all(std::false_type{});
         }
+    };
+
+    // ---- split-K exchange (tap mode) ----------------------------------------------------------------------------------
+    // After its K range every wave holds PARTIAL sums of its 128 x 16 NT block. Slice d of the tile finishes row blocks
+    // [d * 8 / S, (d + 1) * 8 / S) of EVERY wave: a wave hands the other slices' row blocks to the wave of the same index in those
+    // slices (fragment layout, 1 KiB per (row block, column tile): fully coalesced 16-byte stores) and adds what they hand it.
+    // All eight waves of all S workgroups move data at once — S - 1 of S of a wave's accumulators out, as many in — and each
+    // workgroup then stores 1 / S of the tile. Hand-off as MI355X_MICROARCH.md / cdna_hip_programming.md Guideline 16, form R1, per
+    // WAVE PAIR (no workgroup barrier): payload written through (sc1) -> the storing wave drains vmcnt -> ONE flag word per (source,
+    // destination, wave) stored at agent scope -> the consumer polls that word relaxed (bounded) -> payload read with sc1 loads ->
+    // the consumer zeroes the flag (every flag has exactly one consumer: the words are zero again when the kernel ends; the launcher
+    // zeroes them once at allocation). Sums: own partial first, then the other slices' in ascending slice order — fixed per output
+    // element, so results are reproducible run to run.
+    // Which row blocks a slice keeps must not select REGISTERS at run time (that would put the accumulators into scratch), and one
+    // code copy per (factor, slice) made hipcc spill ~350 registers. Instead the A tile is staged with its 16-row blocks ROTATED by
+    // rot = slice * (8 / S) (set_a_at: LDS row block b of a wave row holds filter block (b + rot) % 8 — per-lane DMA offsets, free),
+    // so in EVERY slice the blocks it keeps are accumulators 0 .. 8 / S - 1 and the ones it hands out are the rest; the slab is indexed
+    // by the PHYSICAL block (b + rot) % 8, which is scalar arithmetic. All loads of one source are issued back to back into their own
+    // registers (<= 8 pieces = 32 registers at a time) and added behind counted waits (left to itself hipcc reused one temporary and
+    // waited vmcnt(0) behind every load: sixteen serialised round trips, 5 us).
+    auto exchange = [&]() __attribute__((always_inline)) -> unsigned {
+        int lane_o = (int)(threadIdx.x & 63);
+        asm volatile("" : "+v"(lane_o));
+        const int per = 8 / S, rot = sp_slice * per;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pa.slab, 0, (int)pa.slab_bytes, 0x00020000);
+        // byte offset of (source slice, physical row block 0, column tile 0) of this wave and lane; a (row block, column tile) piece is 1 KiB
+        auto slab_at = [&](int src) -> int {
+            return (int)(((((unsigned)(sp_tile * S + src) * 8u + (unsigned)w) * 8u) * (unsigned)NT * 64u + (unsigned)lane_o) * 16u);
+        };
+        auto flag_of = [&](int src, int dst) -> unsigned * { return pa.flags + (((sp_tile * S + src) * S + dst) * 8 + w); };
+        stamp(); // (TRACE: exchange entry)
+        const int mine = slab_at(sp_slice);
+#pragma unroll
+        for (int a = 2; a < 8; ++a) { // (accumulators 0 and 1 are kept under every factor)
+            if (a >= per) {           // (wave-uniform)
+                const int pb = (a + rot) & 7;
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[a][j]), rs, mine + (pb * NT + j) * 1024, 0, 16);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (this wave's payload is written through before its flags go out)
+        stamp(); // (TRACE: payload drained)
+        if (lane_o == 0) {
+            for (int d = 0; d < S; ++d)
+                if (d != sp_slice)
+                    __hip_atomic_store(flag_of(sp_slice, d), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        auto take = [&](auto perc, int src) __attribute__((always_inline)) {
+            constexpr int PER = decltype(perc)::value, PIECES = PER * NT, BATCH = PIECES < 8 ? PIECES : 8;
+            const int theirs = slab_at(src) + rot * NT * 1024; // my physical blocks rot .. rot + PER - 1 in the source's slab
+            sfor<PIECES / BATCH>([&](auto bc) {
+                constexpr int b0 = decltype(bc)::value * BATCH;
+                u32x4_t in[BATCH];
+                sfor<BATCH>([&](auto qc) {
+                    constexpr int q = b0 + decltype(qc)::value;
+                    in[q - b0] = __builtin_amdgcn_raw_buffer_load_b128(rs, theirs + q * 1024, 0, 16);
+                });
+                fence_sched();
+                sfor<BATCH>([&](auto qc) {
+                    constexpr int q = b0 + decltype(qc)::value;
+                    acc[q / NT][q % NT] += __builtin_bit_cast(f32x4, in[q - b0]);
+                });
+                fence_sched();
+            });
+        };
+        for (int src = 0; src < S; ++src) {
+            if (src == sp_slice)
+                continue;
+            unsigned *fp = flag_of(src, sp_slice);
+            const long long t0 = (long long)wall_clock64();
+            while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                __builtin_amdgcn_s_sleep(2);
+                if ((long long)wall_clock64() - t0 > 200000000ll) // 2 s at 100 MHz: a lost partner ends as wrong numbers, not as a hung GPU
+                    break;
+            }
+            stamp(); // (TRACE: this source's flag seen)
+            if (S == 2) take(std::integral_constant<int, 4>{}, src); // (the launcher admits 2 and 4)
+            else take(std::integral_constant<int, 2>{}, src);
+            if (lane_o == 0)
+                __hip_atomic_store(fp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            stamp(); // (TRACE: this source's row blocks added)
+        }
+        return (1u << per) - 1u; // the epilogue's steps 0 .. per - 1 (filter rows m0 + rot * 16 ...: see the tile loop)
     };
 
     // ---- the flat K-tile pipeline ------------------------------------------------------------------
@@ -1061,8 +1190,11 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         } else {
             decode(c_s, c_ib, c_m0, c_n0);
         }
+        // (split-K of the tap mode: the accumulators' row blocks are rotated by rot — block 0 is filter block rot — and the slice stores
+        // blocks 0 .. 8 / S - 1 only, so bias rows and store rows simply start rot * 16 rows further down)
+        const int c_rot16 = (CONV == 3 && S > 1) ? sp_slice * (8 / S) * 16 : 0;
         if constexpr (CONV != 0)
-            load_cbias(c_m0);
+            load_cbias(c_m0 + c_rot16);
         if constexpr (TAPS) {
             // validity bits of this tile's slots (nine per column tile and lane; rebuilt from an opaque lane id: see epilogue)
             int lane_o = (int)(threadIdx.x & 63);
@@ -1077,7 +1209,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
                 const unsigned colm = ((int)ox >= p.cv_xlo ? 1u : 0u) | 2u | ((int)ox < p.cv_xhi ? 4u : 0u);
                 tv[j] = ((rowm & 1u) ? colm : 0u) | (colm << 3) | ((rowm & 4u) ? (colm << 6) : 0u);
             }
-            c_t = 0;
+            c_t = kt0 % 9;
         }
         if constexpr (CONV == 0) {
             if (p.bias != nullptr && c_n0 + BN_ <= p.n) { // (wave-uniform)
@@ -1107,8 +1239,13 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         // this wave's part of tile c_s is complete; G = first K-tile of the next tile
         if constexpr (CONV != 0) { // the conv launcher admits act 0 / 1 only
             using R = std::integral_constant<bool, CONV == 2>; // (tap mode: no residual copy)
-            if (p.act == 0) epilogue_conv(std::integral_constant<int, 0>{}, R{}, c_m0, c_n0);
-            else epilogue_conv(std::integral_constant<int, 1>{}, R{}, c_m0, c_n0);
+            unsigned rbmask = 0xffu;
+            if constexpr (CONV == 3) {
+                if (S > 1)
+                    rbmask = exchange();
+            }
+            if (p.act == 0) epilogue_conv(std::integral_constant<int, 0>{}, R{}, c_m0 + c_rot16, c_n0, rbmask);
+            else epilogue_conv(std::integral_constant<int, 1>{}, R{}, c_m0 + c_rot16, c_n0, rbmask);
         } else {
             if (p.act == 0) epilogue(std::integral_constant<int, 0>{}, c_ib, c_m0, c_n0, c_s & 1);
             else if (p.act == 1) epilogue(std::integral_constant<int, 1>{}, c_ib, c_m0, c_n0, c_s & 1);
@@ -1139,6 +1276,7 @@ template <typename Tr, int NT, bool TRACE = false>
 static int launch_p(infiniRocmRuntime_t rt, GemmArgs g, bool akm, bool bkm, unsigned long long *trace = nullptr) {
     PArgs pa;
     pa.trace = trace;
+    pa.split = 1; pa.slab = nullptr; pa.slab_bytes = 0; pa.flags = nullptr;
     constexpr int kLds = LDS_BYTES + (TRACE ? kTraceBytes : 0) + kExtraLds;
     if (!(g.act == 0 || g.act == 1 || g.act == 5) || (g.bias && !(g.bias_m == 0 && g.bias_n == 1)))
         IROCM_FAIL(INFINI_ROCM_UNSUPPORTED, "gemm256p: activation %d / this bias layout is not served by the persistent kernels", g.act);
@@ -1184,10 +1322,14 @@ static int launch_p(infiniRocmRuntime_t rt, GemmArgs g, bool akm, bool bkm, unsi
 }
 
 // conv mode: one instantiation per tile width and residual flag (A K-major, B gathered by pixel slots)
-template <typename Tr, int NT, bool RES, bool TAPS = false> static int launch_p_conv(infiniRocmRuntime_t rt, GemmArgs g) {
+// split > 1 (tap mode only): `split` workgroups per tile trade partial sums through `slab` (>= conv_tap_slab_bytes) / `flags`.
+template <typename Tr, int NT, bool RES, bool TAPS = false, bool TRACE = false>
+static int launch_p_conv(infiniRocmRuntime_t rt, GemmArgs g, int split = 1, char *slab = nullptr, size_t slab_bytes = 0, unsigned *flags = nullptr,
+                         unsigned long long *trace = nullptr) {
     static_assert(!(RES && TAPS), "tap mode has no residual copy");
     PArgs pa;
-    pa.trace = nullptr;
+    pa.trace = trace;
+    pa.split = TAPS ? split : 1; pa.slab = slab; pa.slab_bytes = (unsigned)slab_bytes; pa.flags = flags;
     g.tiles_m = (int)ceil_div(g.m, BM);
     g.tiles_n = (int)ceil_div(g.n, 64 * NT);
     const long total = (long)g.tiles_m * g.tiles_n;
@@ -1203,9 +1345,16 @@ template <typename Tr, int NT, bool RES, bool TAPS = false> static int launch_p_
     const unsigned cus = (unsigned)(rt->num_cu >= 8 ? (rt->num_cu / 8) * 8 : rt->num_cu);
     if (grid > cus)
         grid = cus;
-    auto kern = gemm256p_kernel<Tr, true, false, NT, false, TAPS ? 3 : (RES ? 2 : 1)>;
-    IROCM_LDS_ATTR(kern, LDS_BYTES + kExtraLds, rt);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES + kExtraLds, rt->stream, pa);
+    if (pa.split > 1) {
+        // one unit per workgroup, the slices of a tile on one XCD: workgroup 8 idx + xcd = (tile (idx / S) * 8 + xcd, slice idx % S)
+        grid = (unsigned)(ceil_div(total, 8) * 8 * pa.split);
+        if (grid > cus || (g.k / BK) % pa.split != 0 || !(pa.split == 2 || pa.split == 4) || !slab || !flags)
+            IROCM_FAIL(INFINI_ROCM_INVALID_ARGUMENT, "conv tap GEMM: split %d of %ld tiles is not launchable on %u CUs", pa.split, total, cus);
+    }
+    auto kern = gemm256p_kernel<Tr, true, false, NT, TRACE, TAPS ? 3 : (RES ? 2 : 1)>;
+    constexpr int kLds = LDS_BYTES + (TRACE ? kTraceBytes : 0) + kExtraLds;
+    IROCM_LDS_ATTR(kern, kLds, rt);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), kLds, rt->stream, pa);
     IROCM_LAUNCH_CHECK("gemm256p(conv)");
     return INFINI_ROCM_OK;
 }

@@ -121,7 +121,9 @@ int infini_rocm_runtime_create(int device, infiniRocmRuntime_t *out) {
         IROCM_FAIL(INFINI_ROCM_HIP_ERROR, "hipStreamCreate failed: %s", hipGetErrorString(e));
     }
     rt->stream = rt->own_stream;
-    if (hipMalloc(&rt->zeros, 256) != hipSuccess || hipMemset(rt->zeros, 0, 256) != hipSuccess) {
+    if (hipMalloc(&rt->zeros, 256) != hipSuccess || hipMemset(rt->zeros, 0, 256) != hipSuccess ||
+        hipMalloc((void **)&rt->sync_flags, infiniRocmRuntime::kSyncFlagWords * 4) != hipSuccess ||
+        hipMemset(rt->sync_flags, 0, infiniRocmRuntime::kSyncFlagWords * 4) != hipSuccess) {
         (void)hipStreamDestroy(rt->own_stream);
         delete rt;
         IROCM_FAIL(INFINI_ROCM_HIP_ERROR, "cannot allocate the runtime's zero block");
@@ -157,6 +159,8 @@ int infini_rocm_runtime_destroy(infiniRocmRuntime_t rt) {
         (void)hipStreamDestroy(rt->side_stream);
     if (rt->zeros)
         (void)hipFree(rt->zeros);
+    if (rt->sync_flags)
+        (void)hipFree(rt->sync_flags);
     if (rt->own_stream)
         (void)hipStreamDestroy(rt->own_stream);
     delete rt;

@@ -32,17 +32,17 @@ LAYERS = [
     (512, 28, 128, 1, 1, 0, "pixel_gemm", ("br",)),
     (128, 28, 128, 3, 1, 1, "tap_shifted", ("br",)),
     (512, 28, 256, 1, 1, 0, "pixel_gemm", ("br",)),
-    (256, 28, 256, 3, 2, 1, "tap_shifted", ("br",)),
+    (256, 28, 256, 3, 2, 1, "tap_gemm_splitk", ("br",)),
     (256, 14, 1024, 1, 1, 0, "pixel_gemm", ("brr",)),
     (512, 28, 1024, 1, 2, 0, "pixel_gemm", ("b",)),
     (1024, 14, 256, 1, 1, 0, "pixel_gemm", ("br",)),
     (256, 14, 256, 3, 1, 1, "tap_shifted", ("br",)),
     (1024, 14, 512, 1, 1, 0, "pixel_gemm", ("br",)),
-    (512, 14, 512, 3, 2, 1, "tap_shifted", ("br",)),
+    (512, 14, 512, 3, 2, 1, "tap_gemm_splitk", ("br",)),   # round 5: the tap mode of the persistent GEMM, split-K x 4
     (512, 7, 2048, 1, 1, 0, "pixel_gemm", ("brr",)),
     (1024, 14, 2048, 1, 2, 0, "pixel_gemm", ("b",)),
     (2048, 7, 512, 1, 1, 0, "pixel_gemm", ("br",)),
-    (512, 7, 512, 3, 1, 1, "tap_shifted", ("br",)),
+    (512, 7, 512, 3, 1, 1, "tap_gemm_splitk", ("br",)),
 ]
 BATCH = 128
 
@@ -67,8 +67,9 @@ def test_resnet50_layer_at_batch_128_sampled_vs_oracle(rt, layer):
     c, h, f, r, st, pad, route, epilogues = layer
     g = torch.Generator(device="cuda").manual_seed(c * 131 + h * 7 + f + r)
     # (64 spare elements behind the input, as in the plugin's arena: the pixel-slot GEMM reads up to 14 bytes past a ragged plane)
-    xbuf = torch.empty((BATCH * c * h * h + 64,), device="cuda", dtype=torch.float16)
-    x = xbuf[: BATCH * c * h * h].view(BATCH, c, h, h)
+    # (and 256 in front: the tap mode reads up to one row + one pixel in front of the first plane and declines a tensor that starts its block)
+    xbuf = torch.empty((BATCH * c * h * h + 64 + 256,), device="cuda", dtype=torch.float16)
+    x = xbuf[256: 256 + BATCH * c * h * h].view(BATCH, c, h, h)
     x.copy_(torch.randn((BATCH, c, h, h), device="cuda", generator=g))
     w = (torch.randn((f, c, r, r), device="cuda", generator=g) / (c * r * r) ** 0.5).to(torch.float16)
     b = torch.randn((f,), device="cuda", generator=g).to(torch.float16)

@@ -670,7 +670,7 @@ def test_conv3x3_tap_gemm_mode(rt, cfg, mode, dt):
     try:
         ops.set_conv_variant(rt, 7)
         y = ops.conv2d(rt, xd, wd, 1, 1, st, st, bias=bd, act=act, out=guard)
-        assert ops.conv_last_route(rt) == "tap_gemm"  # not a silent fall-back to the kernel it is compared with
+        assert ops.conv_last_route(rt).startswith("tap_gemm")  # not a silent fall-back to the kernel it is compared with
         ops.set_conv_variant(rt, 4)
         y2 = ops.conv2d(rt, xd, wd, 1, 1, st, st, bias=bd, act=act)
         assert ops.conv_last_route(rt) == "tap_shifted"
@@ -703,7 +703,7 @@ def test_conv3x3_tap_gemm_every_tile_width(rt, cfg, nt, monkeypatch):
     try:
         ops.set_conv_variant(rt, 7)
         y = ops.conv2d(rt, xd, wd, 1, 1, st, st, bias=bd, act=1)
-        assert ops.conv_last_route(rt) == "tap_gemm"
+        assert ops.conv_last_route(rt) == "tap_gemm"  # (a forced width is the unsplit form)
     finally:
         ops.set_conv_variant(rt, -1)
     want = np.maximum(R.conv2d(R.round_to(x, "f16"), R.round_to(wt, "f16"), 1, 1, st, st, 1, 1) + R.round_to(b, "f16").reshape(1, f, 1, 1), 0)
@@ -741,3 +741,44 @@ def test_conv3x3_tap_gemm_many_tiles_per_workgroup_and_edges(rt):
     assert np.allclose(pick(y), want, rtol=3e-3, atol=3e-3), np.abs(pick(y) - want).max()
     assert route_edge in ("tap_gemm", "tap_shifted")  # (whether `big` starts its segment is the allocator's business; both must be right)
     assert np.allclose(pick(ye), want, rtol=3e-3, atol=3e-3), (route_edge, np.abs(pick(ye) - want).max())
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("cfg", [
+    # n, c, h, w, f, stride, split
+    (16, 128, 14, 14, 256, 1, 2),    # 13 tiles x 2 slices of 9 K-tiles
+    (16, 256, 14, 14, 256, 1, 4),    # 13 tiles x 4 slices of 9 K-tiles
+    (24, 512, 7, 7, 512, 1, 4),      # 12 tiles (two filter blocks) x 4 slices of 18
+    (10, 256, 28, 28, 256, 2, 2),    # stride 2: phase planes, 8 tiles x 2
+    (30, 128, 9, 11, 320, 1, 2),     # ragged filters (rows beyond F in the second filter block), odd rows
+])
+def test_conv3x3_tap_gemm_split_k(rt, cfg, dt, monkeypatch):
+    """The split-K form of the tap GEMM (route "tap_gemm_splitk"): S workgroups per 256 x 256 tile, each over a contiguous range of
+    the tile's K-tiles (the cursors start in the middle of a channel block's taps), the slices trading accumulator row blocks
+    through the fp32 slab (written through, one flag word per wave pair) and each finishing 8 / S row blocks of every wave.
+    IROCM_CONV_TAP_SPLIT forces the factor; run TWICE (the flag words must be zero again after the first launch) and checked
+    against the oracle with bias + ReLU."""
+    n, c, h, w, f, st, split = cfg
+    monkeypatch.setenv("IROCM_CONV_TAP_SPLIT", str(split))
+    rng = np.random.default_rng(abs(hash(cfg)) % 2 ** 32)
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((f, c, 3, 3)) / np.sqrt(9 * c)).astype(np.float32)
+    b = rng.standard_normal((f,)).astype(np.float32)
+    xd, wd, bd = dev_slack2(x, TD[dt]), dev(wt, TD[dt]), dev(b, TD[dt])
+    oh, ow = (h + st - 1) // st, (w + st - 1) // st
+    outs = []
+    try:
+        ops.set_conv_variant(rt, 7)
+        for rep in range(2):
+            guard = torch.full((n, f, oh, ow), 7.0, device="cuda", dtype=TD[dt])
+            outs.append(ops.conv2d(rt, xd, wd, 1, 1, st, st, bias=bd, act=1, out=guard))
+            assert ops.conv_last_route(rt) == "tap_gemm_splitk"
+    finally:
+        ops.set_conv_variant(rt, -1)
+    want = np.maximum(R.conv2d(R.round_to(x, dt), R.round_to(wt, dt), 1, 1, st, st, 1, 1) + R.round_to(b, dt).reshape(1, f, 1, 1), 0)
+    tol = {"f16": 3e-3, "bf16": 2.4e-2}[dt]
+    for y in outs:
+        got = host(y)
+        assert np.isfinite(got).all()
+        assert np.allclose(got, want, rtol=tol, atol=tol), np.abs(got - want).max()
+    assert torch.equal(outs[0], outs[1])  # fixed summation order: bit-identical run to run

@@ -96,11 +96,11 @@ def main():
             ms = rt.elapsed_ms(e0, e1) / args.iters
             key = v if tnt is None else f"{v}/nt{tnt}"
             totals[key] = totals.get(key, 0.0) + ms * cnt
-            route = {"tap_gemm": "X", "pixel_gemm": "P", "tap_shifted": "T", "resident": "R", "batched_gemm": "B", "generic": "G", "direct32": "D"}[ops.conv_last_route(rt)]
+            route = {"tap_gemm": "X", "tap_gemm_splitk": "K", "pixel_gemm": "P", "tap_shifted": "T", "resident": "R", "batched_gemm": "B", "generic": "G", "direct32": "D"}[ops.conv_last_route(rt)]
             line += f" v{key}: {ms * 1e3:8.1f} us {flop / ms / 1e9:7.1f} TF x{ms * 1e3 / floor_us:4.1f} {route} |"
         print(line, flush=True)
     ops.set_conv_variant(rt, -1)
-    print("route letters: X 3 x 3 layer as one GEMM with K = 9 C (tap mode), P pixel-slot GEMM on the persistent kernels, R resident-weights kernel, T tap-shifted / patch kernels (conv_s1.hip), B batched GEMM, G generic")
+    print("route letters: X 3 x 3 layer as one GEMM with K = 9 C (tap mode), K the same with split-K, P pixel-slot GEMM on the persistent kernels, R resident-weights kernel, T tap-shifted / patch kernels (conv_s1.hip), B batched GEMM, G generic")
     print(f"network roofline floor: {tot_floor / 1e3:.3f} ms")
     print("network conv total: " + "  ".join(f"v{v}: {t:.3f} ms ({tot_flop / t / 1e9:.1f} TF/s)" for v, t in totals.items()))
 
