@@ -278,7 +278,11 @@ int infini_rocm_attention_ex(infiniRocmRuntime_t rt, int dtype, const void *q, c
 /* AttentionKVCache: one decode step with in-place cache append (reference: attention_kvcache.cu:8-169).
  *   n = position_id[0] + 1; k_cache/v_cache[bh, n-1, :] = k/v[bh, :]; out[bh, :] = softmax(q . K[0:n]^T / sqrt(D)) V[0:n].
  * caches [batch_heads, max_seq, D]; q, k, v, out [batch_heads, D]; position_id: device I32 / U32 / I64 (element 0 is
- * used for all heads, as in the reference). f32 (the reference's only type) / f16 / bf16; D in {128, 256}. */
+ * used for all heads, as in the reference). f32 (the reference's only type) / f16 / bf16; D in {128, 256}.
+ * Round 5: the cache is cut into G chunks over workgroups (~one workgroup per CU; n is read on the device, the chunk length is
+ * computed in the kernel) and a second small kernel merges the G fp32 partials (m, l, o[D]) per head — the reference splits over
+ * gridDim.y = ceil(S / 16) and merges the same way (attention_kvcache.cu:18-25, 118-166); G x batch_heads x (D + 2) floats come from
+ * the runtime workspace. 16-byte aligned tensors; others keep the one-workgroup element-wise kernel. */
 int infini_rocm_attention_kvcache(infiniRocmRuntime_t rt, int dtype, void *k_cache, void *v_cache, const void *q,
                                   const void *k, const void *v, int pos_dtype, const void *position_id, void *out,
                                   int64_t batch_heads, int64_t max_seq, int64_t head_dim);

@@ -125,6 +125,40 @@ def test_attention_kvcache_vs_oracle(rt, dt, tol, pos, ms):
     assert np.array_equal(host(kc), kc_w) and np.array_equal(host(vc), vc_w)  # appended in place, nothing else touched
 
 
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-5), (torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+@pytest.mark.parametrize("split", [0, 1, 2, 5, 16])
+@pytest.mark.parametrize("pos,ms,d", [(0, 64, 128), (62, 64, 128), (63, 64, 128), (64, 80, 128), (700, 1024, 128), (1023, 1024, 256), (130, 4096, 128)])
+def test_attention_kvcache_split_over_workgroups(rt, dt, tol, split, pos, ms, d, monkeypatch):
+    """Round 5: the cache cut into G chunks over workgroups + a merge kernel (reference: attention_kvcache.cu:18-25, 118-166 splits over
+    gridDim.y and merges). IROCM_KVCACHE_SPLIT forces G (0 = the one-workgroup element-wise kernel): chunk ends that fall inside an
+    iteration's four keys, EMPTY chunks (n far below the capacity the split was sized for), the new key in the last / first chunk,
+    head dim 256 — same oracle, same in-place append."""
+    monkeypatch.setenv("IROCM_KVCACHE_SPLIT", str(split))
+    rng = np.random.default_rng(pos + 7 * split)
+    b, h = 2, 3
+    mk = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).to(dt).cuda()  # noqa: E731
+    kc, vc, q, k, v = mk(b, h, ms, d), mk(b, h, ms, d), mk(b, h, 1, d), mk(b, h, 1, d), mk(b, h, 1, d)
+    kc0, vc0 = host(kc), host(vc)
+    p = torch.tensor([[pos]], dtype=torch.int64).cuda()
+    y = ops.attention_kvcache(rt, kc, vc, q, k, v, p)
+    want, kc_w, vc_w = R.attention_kvcache(kc0, vc0, host(q), host(k), host(v), pos)
+    assert np.allclose(host(y), want, rtol=tol, atol=tol), np.abs(host(y) - want).max()
+    assert np.array_equal(host(kc), kc_w) and np.array_equal(host(vc), vc_w)  # appended in place, nothing else touched
+
+
+def test_attention_kvcache_llama_decode_shape(rt):
+    """B x H = 32, 4096 cached keys, D = 128, f16 (a batch-1 Llama-7B decode step): the heuristic split (no env) against the oracle."""
+    rng = np.random.default_rng(3)
+    b, h, ms, d, pos = 1, 32, 4096, 128, 4095
+    mk = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).to(torch.float16).cuda()  # noqa: E731
+    kc, vc, q, k, v = mk(b, h, ms, d), mk(b, h, ms, d), mk(b, h, 1, d), mk(b, h, 1, d), mk(b, h, 1, d)
+    kc0, vc0 = host(kc), host(vc)
+    y = ops.attention_kvcache(rt, kc, vc, q, k, v, torch.tensor([pos], dtype=torch.int32).cuda())
+    want, kc_w, vc_w = R.attention_kvcache(kc0, vc0, host(q), host(k), host(v), pos)
+    assert np.allclose(host(y), want, rtol=2e-3, atol=2e-3), np.abs(host(y) - want).max()
+    assert np.array_equal(host(kc), kc_w) and np.array_equal(host(vc), vc_w)
+
+
 def test_attention_kvcache_reference_kat(rt):
     """test_cuda_attention.cc:17-43: ones everywhere, position 0 -> ones."""
     from conftest import kat
