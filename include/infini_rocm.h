@@ -415,7 +415,7 @@ int infini_rocm_conv_transpose2d(infiniRocmRuntime_t rt, int dtype, const void *
  * Used by tune() and tests. */
 int infini_rocm_conv2d_set_variant(infiniRocmRuntime_t rt, int variant);
 /* Which implementation the most recent conv2d call on this runtime launched: "direct32" (fp32), "pixel_gemm" (pointwise layer as
- * one GEMM over pixel slots on the persistent kernels), "tap_gemm" (3 x 3 layer as one GEMM with K = 9 C on the same kernels), "resident" (F <= 64, C <= 64: weights resident in LDS, persistent
+ * one GEMM over pixel slots on the persistent kernels), "tap_gemm" (3 x 3 layer as one GEMM with K = 9 C on the same kernels), "depthwise" (groups == C, 3 x 3 / 5 x 5, stride 1 / 2: the HBM-bound kernel of conv_dw.hip), "resident" (F <= 64, C <= 64: weights resident in LDS, persistent
  * workgroups), "tap_shifted" (the other kernels of conv_s1.hip), "batched_gemm", "generic", "none". A forced
  * variant falls back when a shape does not qualify; tests and measurement tools read the route instead of assuming it. */
 int infini_rocm_conv2d_last_route(infiniRocmRuntime_t rt, const char **route);

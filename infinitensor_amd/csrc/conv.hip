@@ -50,6 +50,9 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
                    void *y, int n, int c, int h, int wd, int f, int r, int s, int ph, int pw, int sh, int sw, int dh, int dw,
                    int oh, int ow, int act); // conv_s1.hip
 
+int launch_conv_depthwise(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, const void *bias, void *y, int64_t n, int64_t c,
+                          int64_t h, int64_t wd, int64_t f, int r, int s, int ph, int pw, int sh, int sw, int oh, int ow, int act); // conv_dw.hip
+
 struct ConvArgs {
     const void *x, *w, *bias, *res; // res: optional residual of y's shape, added before the activation
     void *y;
@@ -490,6 +493,13 @@ int infini_rocm_conv2d_res(infiniRocmRuntime_t rt, int dtype, const void *x, con
         return INFINI_ROCM_OK;
     }
     const int variant = rt->conv_variant;
+    // Round 5: depthwise layers (groups == C: one input channel per filter) have their own HBM-bound kernel (conv_dw.hip); variant 1
+    // keeps the generic implicit GEMM (A/B, tests)
+    if (groups == c && groups > 1 && dh == 1 && dw == 1 && !residual && variant != 1) {
+        const int st = launch_conv_depthwise(rt, dtype, x, w, bias, y, n, c, h, wd, f, (int)r, (int)s, ph, pw, sh, sw, p.oh, p.ow, act);
+        if (st >= 0)
+            return st;
+    }
     const bool same_s1 = sh == 1 && sw == 1 && dh == 1 && dw == 1 && groups == 1 && p.oh == p.h && p.ow == p.wd;
     // Round 3: a unit-stride pointwise layer with >= 256 filters is ONE GEMM  Y[f][slot] = W[f][c] X[c][slot]  over pixel slots
     // (image, pixel) on the persistent 256-row kernels in conv mode (gemm256p_kernel.h, CONV): LDS-DMA staging of both operands,

@@ -782,3 +782,56 @@ def test_conv3x3_tap_gemm_split_k(rt, cfg, dt, monkeypatch):
         assert np.isfinite(got).all()
         assert np.allclose(got, want, rtol=tol, atol=tol), np.abs(got - want).max()
     assert torch.equal(outs[0], outs[1])  # fixed summation order: bit-identical run to run
+
+
+DW_CFGS = [
+    # n, c, h, w, mult, k, stride, pad
+    (2, 32, 30, 30, 1, 3, 1, 1),     # rows of 30: every row has a ragged last run; whole planes per workgroup
+    (3, 24, 19, 19, 1, 5, 2, 2),     # odd planes, stride 2 (output 10 x 10): element stores on odd row starts
+    (1, 16, 150, 150, 1, 3, 1, 1),   # EfficientNet-Lite4 stem-side plane: row strips, several strips per plane
+    (2, 48, 75, 75, 1, 5, 2, 2),     # 75 -> 38, 5 x 5 / 2
+    (2, 12, 17, 23, 2, 3, 1, 1),     # channel multiplier 2 (F = 2 C), non-square
+    (1, 8, 9, 40, 1, 5, 1, 2),       # wide and flat
+    (4, 20, 7, 7, 1, 3, 1, 1),       # tiny planes: many planes per workgroup
+    (2, 10, 16, 16, 1, 3, 2, 1),     # even input, stride 2, pad 1 (the last input row / column is never read by r = 2... it is: 15 = 2*7+1)
+    (1, 6, 12, 12, 1, 3, 1, 0),      # no padding (valid convolution)
+]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("mode", ["plain", "bias_relu"])
+@pytest.mark.parametrize("cfg", DW_CFGS)
+def test_conv_depthwise_kernel(rt, cfg, mode, dt):
+    """Round 5: depthwise layers (groups == C; reference: src/operators/conv.cc:47-114 with channel_per_group = 1, cuDNN group
+    convolution in src/kernels/cuda/conv.cc:57-168) on their own HBM-bound kernel (csrc/conv_dw.hip, route "depthwise") against the
+    oracle and against the generic implicit GEMM (variant 1) they used before. The output buffer is pre-filled (every element must
+    be written) and sits inside a larger block whose neighbours must stay untouched."""
+    n, c, h, w, mult, k, st, pad = cfg
+    f = c * mult
+    rng = np.random.default_rng(abs(hash(cfg)) % 2 ** 32)
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((f, 1, k, k)) / k).astype(np.float32)
+    b = rng.standard_normal((f,)).astype(np.float32) if "bias" in mode else None
+    act = 1 if "relu" in mode else 0
+    xd, wd = dev(x, TD[dt]), dev(wt, TD[dt])
+    bd = dev(b, TD[dt]) if b is not None else None
+    oh, ow = (h + 2 * pad - k) // st + 1, (w + 2 * pad - k) // st + 1
+    block = torch.full((n * f * oh * ow + 128,), 7.0, device="cuda", dtype=TD[dt])
+    out = block[64: 64 + n * f * oh * ow].view(n, f, oh, ow)
+    y = ops.conv2d(rt, xd, wd, pad, pad, st, st, bias=bd, act=act, out=out)
+    assert ops.conv_last_route(rt) == "depthwise"
+    try:
+        ops.set_conv_variant(rt, 1)
+        y2 = ops.conv2d(rt, xd, wd, pad, pad, st, st, bias=bd, act=act)
+        assert ops.conv_last_route(rt) == "generic"
+    finally:
+        ops.set_conv_variant(rt, -1)
+    want = R.conv2d(R.round_to(x, dt), R.round_to(wt, dt), pad, pad, st, st, 1, 1)
+    if b is not None:
+        want = want + R.round_to(b, dt).reshape(1, f, 1, 1)
+    if act:
+        want = np.maximum(want, 0)
+    tol = {"f16": 3e-3, "bf16": 2.4e-2}[dt]
+    assert np.allclose(host(y), want, rtol=tol, atol=tol), np.abs(host(y) - want).max()
+    assert np.allclose(host(y), host(y2), rtol=tol, atol=tol)
+    assert torch.all(block[:64] == 7.0).item() and torch.all(block[64 + n * f * oh * ow:] == 7.0).item()

@@ -36,11 +36,17 @@ for sp in (int(x) for x in a.splits.split(",")):
         os.environ["IROCM_KVCACHE_SPLIT"] = str(sp)
     for i in range(5):
         ops.attention_kvcache(rt, kc[i % sets], vc[i % sets], q, k, v, pos, out=out)
-    e0, e1 = Event(), Event()
+    # timed as a hipGraph of `iters` steps: a Python call costs 10-20 us, as much as the step itself
     iters = 40
-    rt.record(e0)
+    rt.sync()
+    rt.begin_capture()
     for i in range(iters):
         ops.attention_kvcache(rt, kc[i % sets], vc[i % sets], q, k, v, pos, out=out)
+    g = rt.end_capture()
+    rt.launch_graph(g)
+    e0, e1 = Event(), Event()
+    rt.record(e0)
+    rt.launch_graph(g)
     rt.record(e1)
     rt.sync()
     us = rt.elapsed_ms(e0, e1) / iters * 1e3
