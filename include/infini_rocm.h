@@ -414,7 +414,9 @@ int infini_rocm_conv_transpose2d(infiniRocmRuntime_t rt, int dtype, const void *
  * >= 256 filters and enough slot tiles there). All variants compute the same sums (fp32 accumulate).
  * Used by tune() and tests. */
 int infini_rocm_conv2d_set_variant(infiniRocmRuntime_t rt, int variant);
-/* Which implementation the most recent conv2d call on this runtime launched: "direct32" (fp32), "pixel_gemm" (pointwise layer as
+/* Which implementation the most recent conv2d call on this runtime launched: "igemm32" / "batched_gemm32" (fp32 on the fp32 matrix
+ * instruction: implicit GEMM, or a unit-stride pointwise layer as a batched GEMM), "direct32" (fp32, one output per thread: grouped layers,
+ * C R S % 4 != 0, conv variant 1), "pixel_gemm" (pointwise layer as
  * one GEMM over pixel slots on the persistent kernels), "tap_gemm" (3 x 3 layer as one GEMM with K = 9 C on the same kernels), "depthwise" (groups == C, 3 x 3 / 5 x 5, stride 1 / 2: the HBM-bound kernel of conv_dw.hip), "resident" (F <= 64, C <= 64: weights resident in LDS, persistent
  * workgroups), "tap_shifted" (the other kernels of conv_s1.hip), "batched_gemm", "generic", "none". A forced
  * variant falls back when a shape does not qualify; tests and measurement tools read the route instead of assuming it. */

@@ -53,6 +53,10 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
 int launch_conv_depthwise(infiniRocmRuntime_t rt, int dtype, const void *x, const void *w, const void *bias, void *y, int64_t n, int64_t c,
                           int64_t h, int64_t wd, int64_t f, int r, int s, int ph, int pw, int sh, int sw, int oh, int ow, int act); // conv_dw.hip
 
+int launch_conv_igemm32(infiniRocmRuntime_t rt, const void *x, const void *w, const void *bias, const void *res, void *y, int64_t n,
+                        int64_t c, int64_t h, int64_t wd, int64_t f, int r, int s, int ph, int pw, int sh, int sw, int dh, int dw, int oh,
+                        int ow, int act); // gemm32.hip
+
 struct ConvArgs {
     const void *x, *w, *bias, *res; // res: optional residual of y's shape, added before the activation
     void *y;
@@ -484,6 +488,23 @@ int infini_rocm_conv2d_res(infiniRocmRuntime_t rt, int dtype, const void *x, con
     IROCM_CHECK_ARG(x && w && y, "conv2d: NULL tensor");
 
     if (dtype == INFINI_DT_F32) {
+        // Round 5: fp32 convolutions on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32: exact products and sums at 157 TF/s).
+        // Unit-stride pointwise layers with 16-byte rows are batched GEMMs Y[n] = W[F x C] . X[n][C x HW] for the fp32 tile kernel
+        // (zero copy, like the 16-bit batched route); every other groups == 1 layer whose K = C R S is a multiple of 4 is the implicit
+        // GEMM of gemm32.hip. conv variant 1 keeps the one-output-per-thread kernel (A/B, tests); so do grouped layers, K % 4 != 0
+        // (a 3-channel stem) and unaligned operands.
+        if (groups == 1 && rt->conv_variant != 1) {
+            if (r == 1 && s == 1 && ph == 0 && pw == 0 && sh == 1 && sw == 1 && dh == 1 && dw == 1 && !residual && p.npix % 4 == 0 && c % 4 == 0 &&
+                ((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)y)) & 15) == 0 && (long)n * f * p.npix < (1l << 31)) {
+                rt->last_conv_route = "batched_gemm32";
+                return infini_rocm_matmul(rt, dtype, w, x, bias, y, n, f, p.npix, c, 0, 0, 0, (int64_t)c * p.npix, 0, bias ? 1 : 0, 0, act);
+            }
+            const int st = launch_conv_igemm32(rt, x, w, bias, residual, y, n, c, h, wd, f, (int)r, (int)s, ph, pw, sh, sw, dh, dw, p.oh, p.ow, act);
+            if (st >= 0) {
+                rt->last_conv_route = "igemm32";
+                return st;
+            }
+        }
         const long total = (long)n * f * p.npix;
         long g = ceil_div(total, 256);
         if (g > (long)rt->num_cu * 32) g = (long)rt->num_cu * 32;

@@ -208,6 +208,255 @@ template <int T, bool B_KMAJOR> __global__ __launch_bounds__(256, 2) void gemm_f
     }
 }
 
+
+// ---- fp32 Conv2d as an implicit GEMM on the same tile machinery (round 5) ------------------------------------------------------------
+// Reference: the fp32 convolution of src/kernels/cuda/conv.cc:57-168 (cuDNN implicit GEMM; fp32 is the dtype north_star's 1e-4 gate and
+// the intelcpu baseline are stated in). Until round 5 every fp32 convolution ran on conv_direct32 — one output per thread, a serial
+// fma chain: VALU-bound by construction.
+// GEMM view (groups == 1): Y[img][f][pix] = sum_k W[f][k] * B[k][q], k = (c R + r) S + s, q = img * OH * OW + pix (columns run across
+// images, so 7 x 7 planes do not waste tiles), B[k][q] = X[img][c][oy sh - ph + r dh][ox sw - pw + s dw] or 0 outside the image.
+//   A = the FCRS weights as they lie: [F][K] K-major rows — staged by LDS-DMA exactly like gemm_fast32's A (K % 4 == 0).
+//   B is gathered: thread t owns ONE column q = n0 + t % BN of the tile and 32 / (256 / BN) k-rows of it, so the column's geometry
+//   (image base, iy0, ix0) is three registers for the whole kernel, the k-row's (c, r, s) is WAVE-uniform scalar arithmetic, a wave's
+//   loads of one k-row are 64 consecutive pixels (coalesced wherever a row of the plane is), and the LDS writes of a k-row are
+//   conflict-free. Register-staged: the loads of K-tile t + 1 are issued before the MFMAs of tile t and written to LDS behind them
+//   (64-cycle fp32 MFMAs leave the vector ALU idle 15 cycles of 16: the gather's ~8 instructions per element ride in that shadow).
+// Exact fp32 products and sums (v_mfma_f32_32x32x2_f32), summation order over k differs from conv_direct32's chain only by the MFMA's
+// two-k interleave: 1e-4 relative is kept with orders of magnitude to spare (tests).
+struct Conv32Args {
+    const float *x, *w, *bias, *res;
+    float *y;
+    int nimg, c, h, wd, f, r, s;
+    int ph, pw, sh, sw, dh, dw;
+    int oh, ow;
+    int k;            // c * r * s
+    long ncols;       // nimg * oh * ow
+    int tiles_m, tiles_n;
+    int act;
+    unsigned x_bytes; // range of the input's buffer descriptor
+    unsigned ohw_m, ow_m, rs_m, s_m; // floor(2^32 / d) of oh * ow, ow, r * s, s
+    const void *zeros;
+    int cp;           // TAP-MAJOR form: channels per tap in the packed weights [F][R S][cp] (cp = C rounded up to 32; k = tap * cp + c)
+};
+
+// FCRS -> [F][R S][cp] (zero-filled above C): the tap-major weight image of conv_igemm32<T, true>
+__global__ __launch_bounds__(256) void conv_repack_w32(const float *__restrict__ w, float *__restrict__ o, int f, int c, int rs, int cp) {
+    const long total = (long)f * rs * cp;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cc = (int)(i % cp);
+        const long q = i / cp;
+        const int t = (int)(q % rs);
+        const int ff = (int)(q / rs);
+        o[i] = cc < c ? w[((long)ff * c + cc) * rs + t] : 0.f;
+    }
+}
+
+// TM (tap-major K): k = tap * cp + c over the re-packed weights — a K-tile is 32 channels of ONE tap, so the tap's (dy, dx), its bounds
+// test and the column's base offset are computed once per K-tile and an element costs one add + one select + its load. With k =
+// (c R + r) S + s over the FCRS weights as they lie (TM = false: layers with fewer than 32 channels) every element decodes its own
+// (c, r, s): the PMC pass of the first version showed 2.5 scalar instructions per vector one — 370 per K-tile and wave beside 16 MFMAs —
+// and the layers at 0.16-0.35 of the fp32 peak.
+template <int T, bool TM> __global__ __launch_bounds__(256, 2) void conv_igemm32(Conv32Args p) {
+    constexpr int BM = 64 * T, BN = 64 * T, WT = 32 * T;
+    constexpr int TILE_BYTES = BM * BK * 4;
+    constexpr int KR_STEP = 256 / BN;      // k-rows covered by the 256 threads at once (2 for T = 2, 4 for T = 1)
+    constexpr int NE = BK / KR_STEP;       // elements per thread and K-tile (16 / 8)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    auto a_tile = [&](int buf) -> char * { return smem + buf * TILE_BYTES; };
+    auto b_tile = [&](int buf) -> char * { return smem + (2 + buf) * TILE_BYTES; };
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+    constexpr int GROUP_M = 8;
+    const unsigned per_group = GROUP_M * p.tiles_n;
+    const unsigned group = wg / per_group;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (wg % per_group) % gsz;
+    const int tn = (wg % per_group) / gsz;
+    const int m0 = tm * BM;
+    const long n0 = (long)tn * BN;
+
+    // this thread's column: output pixel q -> (image, oy, ox)
+    const int ncol = t % BN;
+    const int kr0 = __builtin_amdgcn_readfirstlane(t / BN); // (wave-uniform: BN >= 64)
+    long q = n0 + ncol;
+    const bool qlive = q < p.ncols;
+    if (!qlive)
+        q = p.ncols - 1;
+    unsigned img, pix, oy, ox;
+    udivmod_m((unsigned)q, (unsigned)(p.oh * p.ow), p.ohw_m, img, pix);
+    udivmod_m(pix, (unsigned)p.ow, p.ow_m, oy, ox);
+    const int iy0 = (int)oy * p.sh - p.ph, ix0 = (int)ox * p.sw - p.pw;
+    const int pix_base = (int)(((long)img * p.c * p.h + iy0) * p.wd + ix0); // element index of tap (c 0, r 0, s 0); may be negative
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const int hw = p.h * p.wd;
+    const unsigned lds_col = (unsigned)((ncol & 3) * 4); // byte inside the 16-byte chunk; chunk index depends on the k-row
+
+    float stage_v[NE];
+    // tap-major state of the K-tile being gathered: tap (tr, ts), channel block c0; per thread: base offset and validity of that tap
+    int g_tr = 0, g_ts = 0, g_c0 = 0, g_base = 0;
+    bool g_ok = false;
+    auto tap_setup = [&]() __attribute__((always_inline)) {
+        const int dy = g_tr * p.dh, dx = g_ts * p.dw;
+        g_ok = qlive && g_tr < p.r && (unsigned)(iy0 + dy) < (unsigned)p.h && (unsigned)(ix0 + dx) < (unsigned)p.wd;
+        g_base = pix_base + dy * p.wd + dx + (g_c0 + kr0) * hw;
+    };
+    auto tap_advance = [&]() __attribute__((always_inline)) { // the next K-tile: 32 more channels, then the next tap
+        g_c0 += BK;
+        if (g_c0 >= p.cp) {
+            g_c0 = 0;
+            g_ts = g_ts + 1 == p.s ? 0 : g_ts + 1;
+            g_tr += g_ts == 0 ? 1 : 0;
+        }
+    };
+    auto gather_one = [&](int k0, int i) __attribute__((always_inline)) { // requests element i of K-tile k0 .. k0 + 31 of this column
+        if constexpr (TM) {
+            const bool ok = g_ok && g_c0 + kr0 + i * KR_STEP < p.c;
+            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, ok ? (g_base + i * (KR_STEP * hw)) * 4 : (int)0x7ffffff0, 0, 0));
+        } else {
+            const int k = k0 + kr0 + i * KR_STEP; // wave-uniform
+            unsigned cc, rs, rr, ss;
+            udivmod_m((unsigned)k, (unsigned)(p.r * p.s), p.rs_m, cc, rs);
+            udivmod_m(rs, (unsigned)p.s, p.s_m, rr, ss);
+            const int dy = (int)rr * p.dh, dx = (int)ss * p.dw;
+            const bool ok = qlive && k < p.k && (unsigned)(iy0 + dy) < (unsigned)p.h && (unsigned)(ix0 + dx) < (unsigned)p.wd;
+            const int off = pix_base + (int)cc * hw + dy * p.wd + dx;
+            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, ok ? off * 4 : (int)0x7ffffff0, 0, 0));
+        }
+    };
+    auto gather = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i)
+            stage_v[i] = gather_one(k0, i);
+    };
+    auto scatter = [&](int buf) __attribute__((always_inline)) { // writes them into the N-major image gemm_fast32's fragments read
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int kr = kr0 + i * KR_STEP;
+            const unsigned chunk = (unsigned)(ncol >> 2) ^ ((unsigned)((kr >> 2) & 1) << 3);
+            *(float *)(b_tile(buf) + kr * (256 * T) + chunk * 16 + lds_col) = stage_v[i];
+        }
+    };
+
+    f32x16 acc[T][T];
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                acc[i][j][e] = 0.f;
+
+    const float *Z = (const float *)p.zeros;
+    const int nk = (p.k + BK - 1) / BK;
+    // prologue: tile 0's weights by LDS-DMA, its gathered column through registers
+    stage_kmajor<T>(p.w, p.k, m0, p.f, 0, a_tile(0), w, lane, p.k, Z);
+    if constexpr (TM)
+        tap_setup();
+    gather(0);
+    scatter(0); // (hipcc waits for the loads here)
+    auto step = [&](auto bufc, int kt) {
+        constexpr int buf = decltype(bufc)::value;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // tile kt's weights have landed (and nothing else is in flight)
+        __syncthreads();                                  // ... and every thread's column of tile kt is in LDS
+        // (unconditional — past the last tile the weights come from the zero block and every gathered element is out of range — so
+        // that the gather sits in the SAME basic block as the MFMAs and can be scheduled between them)
+        stage_kmajor<T>(p.w, p.k, m0, p.f, (kt + 1) * BK, a_tile(buf ^ 1), w, lane, p.k, Z);
+        if constexpr (TM) {
+            tap_advance();
+            tap_setup();
+        }
+        const char *at = a_tile(buf), *bt = b_tile(buf);
+        // The next tile's gather rides BETWEEN this tile's MFMAs, one element (two multiply-high decodes, the bounds tests, one load: ~25
+        // instructions) behind every MFMA group: a 64-cycle fp32 MFMA leaves ~12 vector-ALU issue slots before the next one can start,
+        // but only instructions that sit between two MFMAs in program order can use them. Left alone hipcc issues the whole gather first
+        // (~2 k cycles in front of 4 k cycles of MFMAs: 0.18-0.35 of the fp32 peak at batch 32), and sched_group_barrier did not move it;
+        // the order is pinned with scheduling fences instead.
+        constexpr int PER = (16 * T * T) / NE; // MFMAs per gathered element: 4
+        int mi = 0;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            f32x4 af[T], bf[T];
+#pragma unroll
+            for (int i = 0; i < T; ++i)
+                af[i] = frag_kmajor(at, wm * WT + i * 32, blk, lane);
+#pragma unroll
+            for (int j = 0; j < T; ++j)
+                bf[j] = frag_nmajor<T>(bt, wn * WT + j * 32, blk, lane);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < T; ++i)
+#pragma unroll
+                    for (int j = 0; j < T; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][s], af[i][s], acc[i][j], 0, 0, 0);
+                        if (++mi % PER == 0) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            stage_v[mi / PER - 1] = gather_one((kt + 1) * BK, mi / PER - 1);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+        }
+        scatter(buf ^ 1); // (buffer buf ^ 1 was last read in step kt - 1, behind this step's barrier)
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(std::integral_constant<int, 0>{}, kt);
+        if (kt + 1 < nk)
+            step(std::integral_constant<int, 1>{}, kt + 1);
+    }
+
+    // epilogue: lane l holds filter m = l % 32 and, per g, four consecutive columns q
+    const int ohw = p.oh * p.ow;
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        const int frow = m0 + wm * WT + i * 32 + (lane & 31);
+        const float bv = (p.bias && frow < p.f) ? p.bias[frow] : 0.f;
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const long qc = n0 + wn * WT + j * 32 + g * 8 + (lane >> 5) * 4;
+                if (frow >= p.f || qc >= p.ncols)
+                    continue;
+                unsigned im2, px2;
+                udivmod_m((unsigned)qc, (unsigned)ohw, p.ohw_m, im2, px2);
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r] = acc[i][j][g * 4 + r] + bv;
+                const long o = ((long)im2 * p.f + frow) * ohw + px2;
+                if (px2 + 4 <= (unsigned)ohw && qc + 4 <= p.ncols && (o & 3) == 0 && ((((uintptr_t)p.y) & 15) == 0)) {
+                    if (p.res) {
+                        const f32x4 rv = *(const f32x4 *)(p.res + o);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            v[r] += rv[r];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        v[r] = apply_act(v[r], p.act);
+                    *(f32x4 *)(p.y + o) = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const long qq = qc + r;
+                        if (qq >= p.ncols)
+                            break;
+                        unsigned im3, px3;
+                        udivmod_m((unsigned)qq, (unsigned)ohw, p.ohw_m, im3, px3);
+                        const long oo = ((long)im3 * p.f + frow) * ohw + px3;
+                        float x = v[r];
+                        if (p.res)
+                            x += p.res[oo];
+                        p.y[oo] = apply_act(x, p.act);
+                    }
+                }
+            }
+    }
+}
+
 } // namespace f32k
 
 static bool al16p(const void *p) { return (((uintptr_t)p) & 15) == 0; }
@@ -247,6 +496,106 @@ int launch_fast32(infiniRocmRuntime_t rt, GemmArgs p, bool bkm, int small) {
     }
 #undef IROCM_F32K
     IROCM_LAUNCH_CHECK("gemm_fast32");
+    return INFINI_ROCM_OK;
+}
+
+
+// fp32 Conv2d (groups == 1) as an implicit GEMM on v_mfma_f32_32x32x2_f32. Returns -1 when the operands do not qualify
+// (the caller keeps conv_direct32), a status otherwise.
+int launch_conv_igemm32(infiniRocmRuntime_t rt, const void *x, const void *w, const void *bias, const void *res, void *y, int64_t n,
+                        int64_t c, int64_t h, int64_t wd, int64_t f, int r, int s, int ph, int pw, int sh, int sw, int dh, int dw, int oh,
+                        int ow, int act) {
+    const int64_t ncols = n * oh * ow;
+    const bool tm = c >= 32; // tap-major K over re-packed weights (see the kernel); layers with fewer channels decode k per element
+    const int64_t cp = tm ? (c + 31) / 32 * 32 : c;
+    const int64_t k = cp * r * s;
+    if (k % 4 != 0 || k < 4 || !al16p(w) || (((uintptr_t)x) & 3) != 0 || (((uintptr_t)y) & 3) != 0 || (res && (((uintptr_t)res) & 3) != 0))
+        return -1;
+    if (n * c * h * wd * 4 >= (1ll << 31) - 64 || ncols >= (1ll << 31) - 256 || n * f * oh * ow >= (1ll << 31) || k >= (1ll << 24))
+        return -1;
+    f32k::Conv32Args p;
+    p.x = (const float *)x; p.w = (const float *)w; p.bias = (const float *)bias; p.res = (const float *)res; p.y = (float *)y;
+    if (tm) {
+        // the tap-major weight image: cached per graph weight when the caller declared the weights constant (the plugin does), else
+        // rebuilt per call in the workspace (as conv_s1.hip does for the 16-bit kernels' [RS][F][C] image)
+        const size_t w_bytes = ((size_t)f * k * 4 + 255) & ~(size_t)255;
+        const void *packed = nullptr;
+        hipStream_t pack_stream = rt->stream;
+        bool need_pack = true;
+        const bool cached = rt->conv_const_weights != 0;
+        if (cached) {
+            packed = wcache_lookup(rt, w, (int)f, (int)c, r * s, 2);
+            if (packed) {
+                need_pack = false;
+            } else {
+                void *buf = nullptr;
+                const int st = wcache_insert(rt, w, (size_t)f * c * r * s * 4, (int)f, (int)c, r * s, 2, w_bytes, &buf, &pack_stream);
+                if (st != INFINI_ROCM_OK)
+                    return st;
+                packed = buf;
+            }
+        } else {
+            void *ws = nullptr;
+            const int st = infini_rocm_workspace(rt, w_bytes, &ws);
+            if (st != INFINI_ROCM_OK)
+                return st;
+            packed = ws;
+        }
+        if (need_pack) {
+            long g = ceil_div((long)f * k, 256);
+            if (g > 4096) g = 4096;
+            hipLaunchKernelGGL(f32k::conv_repack_w32, dim3((unsigned)g), dim3(256), 0, pack_stream, (const float *)w, (float *)const_cast<void *>(packed),
+                               (int)f, (int)c, r * s, (int)cp);
+            if (hipError_t e = hipGetLastError(); e != hipSuccess) {
+                if (cached)
+                    wcache_forget(rt, packed);
+                IROCM_FAIL(INFINI_ROCM_HIP_ERROR, "launch of conv_repack_w32 failed: %s", hipGetErrorString(e));
+            }
+            if (cached) {
+                const int st = wcache_commit(rt, pack_stream);
+                if (st != INFINI_ROCM_OK) {
+                    wcache_forget(rt, packed);
+                    return st;
+                }
+            }
+        }
+        p.w = (const float *)packed;
+    }
+    p.nimg = (int)n; p.c = (int)c; p.h = (int)h; p.wd = (int)wd; p.f = (int)f; p.r = r; p.s = s;
+    p.ph = ph; p.pw = pw; p.sh = sh; p.sw = sw; p.dh = dh; p.dw = dw;
+    p.oh = oh; p.ow = ow;
+    p.k = (int)k;
+    p.cp = (int)cp;
+    p.ncols = ncols;
+    p.act = act;
+    p.x_bytes = (unsigned)(n * c * h * wd * 4);
+    p.ohw_m = udiv_magic((unsigned long long)oh * ow);
+    p.ow_m = udiv_magic((unsigned long long)ow);
+    p.rs_m = udiv_magic((unsigned long long)r * s);
+    p.s_m = udiv_magic((unsigned long long)s);
+    p.zeros = rt->zeros;
+    // 128^2 tiles when they give at least ~half a tile per CU, 64^2 tiles otherwise (F <= 64 would leave half of a 128-row tile empty)
+    const bool small = f <= 64 || ceil_div(f, 128) * ceil_div(ncols, 128) * 2 < rt->num_cu;
+    const int bm = small ? 64 : 128;
+    p.tiles_m = (int)ceil_div(f, bm);
+    p.tiles_n = (int)ceil_div(ncols, bm);
+    const long total = (long)p.tiles_m * p.tiles_n;
+    if (total >= (1l << 31))
+        return -1;
+    const size_t lds = 4 * (size_t)bm * f32k::BK * 4;
+#define IROCM_C32(T_, TM_)                                                                         \
+    do {                                                                                           \
+        auto kern = f32k::conv_igemm32<T_, TM_>;                                                   \
+        IROCM_LDS_ATTR(kern, (int)lds, rt);                                                        \
+        hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds, rt->stream, p);            \
+    } while (0)
+    if (small) {
+        if (tm) IROCM_C32(1, true); else IROCM_C32(1, false);
+    } else {
+        if (tm) IROCM_C32(2, true); else IROCM_C32(2, false);
+    }
+#undef IROCM_C32
+    IROCM_LAUNCH_CHECK("conv_igemm32");
     return INFINI_ROCM_OK;
 }
 

@@ -835,3 +835,61 @@ def test_conv_depthwise_kernel(rt, cfg, mode, dt):
     assert np.allclose(host(y), want, rtol=tol, atol=tol), np.abs(host(y) - want).max()
     assert np.allclose(host(y), host(y2), rtol=tol, atol=tol)
     assert torch.all(block[:64] == 7.0).item() and torch.all(block[64 + n * f * oh * ow:] == 7.0).item()
+
+
+F32_CONV_CFGS = [
+    # n, c, h, w, f, r, s, ph, pw, sh, sw, dh, dw
+    (2, 16, 14, 14, 48, 3, 3, 1, 1, 1, 1, 1, 1),      # 64^2 tiles, planes of 196 (tiles span images)
+    (3, 64, 7, 7, 160, 3, 3, 1, 1, 1, 1, 1, 1),       # 49-pixel planes: element stores, ragged filters
+    (2, 32, 28, 28, 64, 3, 3, 1, 1, 2, 2, 1, 1),      # stride 2
+    (1, 8, 33, 17, 24, 5, 3, 2, 0, 1, 2, 1, 2),       # asymmetric everything, dilation
+    (2, 128, 14, 14, 256, 1, 1, 0, 0, 1, 1, 1, 1),    # unit-stride pointwise: the batched-GEMM route
+    (2, 64, 15, 15, 128, 1, 1, 0, 0, 2, 2, 1, 1),     # strided pointwise: implicit GEMM
+    (6, 4, 40, 40, 20, 7, 7, 3, 3, 2, 2, 1, 1),       # 7 x 7 / 2 on 4 channels (K = 196)
+    (16, 64, 28, 28, 128, 3, 3, 1, 1, 1, 1, 1, 1),    # enough columns for the 128^2 tiles (98 x 1 tiles ... forced below the CU count: 64^2)
+    (64, 64, 28, 28, 128, 3, 3, 1, 1, 1, 1, 1, 1),    # 128^2 tiles
+    (4, 48, 12, 12, 80, 3, 3, 1, 1, 1, 1, 1, 1),      # 48 channels: the tap-major image pads every tap to 64 (zero weights, masked loads)
+    (2, 100, 9, 9, 40, 3, 2, 1, 0, 1, 1, 2, 1),       # 100 channels (K = 600 in FCRS order; tap-major 128 per tap), dilated rows
+]
+
+
+@pytest.mark.parametrize("mode", ["plain", "bias_res_relu"])
+@pytest.mark.parametrize("cfg", F32_CONV_CFGS)
+def test_conv_fp32_on_the_matrix_cores(rt, cfg, mode):
+    """Round 5: fp32 Conv2d (the dtype of north_star's 1e-4 gate and of the intelcpu baseline; reference: cuDNN implicit GEMM,
+    src/kernels/cuda/conv.cc:57-168) as an implicit GEMM on v_mfma_f32_32x32x2_f32 (route "igemm32"; unit-stride pointwise layers with
+    16-byte rows: "batched_gemm32") against the oracle within 1e-4 RELATIVE of the output's scale per element (2e-5 absolute below 1)
+    and against the one-output-per-thread kernel it replaces (conv variant 1, route "direct32")."""
+    n, c, h, w, f, r, s, ph, pw, sh, sw, dh, dw = cfg
+    rng = np.random.default_rng(abs(hash(cfg)) % 2 ** 32)
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((f, c, r, s)) / np.sqrt(c * r * s)).astype(np.float32)
+    oh, ow = (h - (r - sh) * dh + 2 * ph) // sh, (w - (s - sw) * dw + 2 * pw) // sw
+    b = rng.standard_normal((f,)).astype(np.float32) if "bias" in mode else None
+    res = rng.standard_normal((n, f, oh, ow)).astype(np.float32) if "res" in mode else None
+    pointwise_s1 = r == 1 and s == 1 and sh == 1 and sw == 1
+    if pointwise_s1:
+        res = None  # (the batched-GEMM route has no residual operand; with one the layer takes the implicit GEMM — covered by the others)
+    act = 1 if "relu" in mode else 0
+    xd, wd = dev(x, torch.float32), dev(wt, torch.float32)
+    bd = dev(b, torch.float32) if b is not None else None
+    rd = dev(res, torch.float32) if res is not None else None
+    guard = torch.full((n, f, oh, ow), 7.0, device="cuda", dtype=torch.float32)
+    y = ops.conv2d(rt, xd, wd, ph, pw, sh, sw, dh, dw, bias=bd, act=act, residual=rd, out=guard)
+    assert ops.conv_last_route(rt) == ("batched_gemm32" if pointwise_s1 else "igemm32")
+    try:
+        ops.set_conv_variant(rt, 1)
+        y1 = ops.conv2d(rt, xd, wd, ph, pw, sh, sw, dh, dw, bias=bd, act=act, residual=rd)
+        assert ops.conv_last_route(rt) == "direct32"
+    finally:
+        ops.set_conv_variant(rt, -1)
+    want = R.conv2d(x, wt, ph, pw, sh, sw, dh, dw)
+    if b is not None:
+        want = want + b.astype(np.float64).reshape(1, f, 1, 1)
+    if res is not None:
+        want = want + res
+    if act:
+        want = np.maximum(want, 0)
+    got = host(y)
+    assert np.all(np.abs(got - want) <= 1e-4 * np.abs(want) + 2e-5), np.abs(got - want).max()
+    assert np.allclose(got, host(y1), rtol=1e-4, atol=2e-5)
