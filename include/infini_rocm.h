@@ -128,6 +128,10 @@ int infini_rocm_workspace_info(infiniRocmRuntime_t rt, size_t *bytes, size_t *re
  * its power budget — the attainable denominator next to the nominal 2.5 PFLOP/s (bench.py roofline.attainable_peak). */
 int infini_rocm_probe_mfma_ceiling(infiniRocmRuntime_t rt, int dtype, const void *data, void *sink, int iters,
                                    double *flop);
+/* The same probe on v_mfma_f32_32x32x16 (4 x 2 accumulator tiles of 32 x 32; equal FLOP per wave and iteration): which instruction
+ * shape the chip sustains more of under its power budget (round 5). */
+int infini_rocm_probe_mfma_ceiling32(infiniRocmRuntime_t rt, int dtype, const void *data, void *sink, int iters,
+                                     double *flop);
 /* Diagnostics: one launch of the persistent GEMM (bf16, row-major A [m,k] and B [k,n], no bias; tile_cols 256 or 192)
  * built with s_memtime stamps at every wave's phase boundaries. trace: [min(tiles, compute_units)][8][128] uint64
  * (0 = unused): slot 0 kernel entry, then per K-tile {L1 start, L2 start}, per tile {epilogue start, end}, last = after

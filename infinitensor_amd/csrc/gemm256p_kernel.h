@@ -79,6 +79,7 @@ struct PArgs {
     int tab_n;       // steps of a workgroup served by the LDS tile table (kTileTab, or 0: tile counts beyond 16 bits)
     unsigned per_batch_m, per_group_m; // floor(2^32 / (tiles_m * tiles_n)), floor(2^32 / (8 * tiles_n)): decode() divides by multiply-high
     unsigned long long *trace; // TRACE instantiation only: [gridDim.x][8 waves][kTraceSlots] s_memtime stamps
+    int trace_fine;            // TRACE: 1 = six stamps per K-tile (L1 | C1 | after C1's MFMAs | L2 | C2 | after C2's MFMAs) instead of two
     // tap mode, split-K (CONV = 3 only; 1 = off): `split` workgroups share ONE output tile, each sums a contiguous range of the
     // tile's K-tiles, then the slices trade accumulator row blocks through `slab` (fp32, written through) and every slice
     // finishes 8 / split of each wave's eight 16-row blocks: see exchange() in the kernel.
@@ -1119,6 +1120,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         wait_lgkm0();
         barrier();
         // C1
+        if constexpr (TRACE) { if (pa.trace_fine) stamp(); }
         __builtin_amdgcn_s_setprio(1);
         mask_b(I0{}, I2{}, bq0); // (tap mode; hipcc spreads the ANDs of the later fragments between the first MFMAs)
         if constexpr (NJ1 > 0) mask_b(I1{}, IJ1{}, bq1);
@@ -1139,6 +1141,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         }
         __builtin_amdgcn_s_setprio(0);
         fence_sched();
+        if constexpr (TRACE) { if (pa.trace_fine) stamp(); }
         finish_cursors(); // (issues behind the MFMA burst, which is still executing)
         barrier();
         // L2
@@ -1154,10 +1157,12 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         wait_lgkm0();
         barrier();
         // C2
+        if constexpr (TRACE) { if (pa.trace_fine) stamp(); }
         __builtin_amdgcn_s_setprio(1);
         if constexpr (NJ1 > 0) compute(I1{}, I1{}, IJ1{}, zeroc, aq, bq1);
         compute(I1{}, I0{}, I2{}, zeroc, aq, bq0);
         __builtin_amdgcn_s_setprio(0);
+        if constexpr (TRACE) { if (pa.trace_fine) stamp(); }
         if constexpr (TAPS)
             c_t = c_t == 8 ? 0 : c_t + 1;
         barrier();
@@ -1276,6 +1281,7 @@ template <typename Tr, int NT, bool TRACE = false>
 static int launch_p(infiniRocmRuntime_t rt, GemmArgs g, bool akm, bool bkm, unsigned long long *trace = nullptr) {
     PArgs pa;
     pa.trace = trace;
+    pa.trace_fine = (TRACE && getenv("IROCM_GEMM_TRACE_FINE")) ? 1 : 0;
     pa.split = 1; pa.slab = nullptr; pa.slab_bytes = 0; pa.flags = nullptr;
     constexpr int kLds = LDS_BYTES + (TRACE ? kTraceBytes : 0) + kExtraLds;
     if (!(g.act == 0 || g.act == 1 || g.act == 5) || (g.bias && !(g.bias_m == 0 && g.bias_n == 1)))
@@ -1329,6 +1335,7 @@ static int launch_p_conv(infiniRocmRuntime_t rt, GemmArgs g, int split = 1, char
     static_assert(!(RES && TAPS), "tap mode has no residual copy");
     PArgs pa;
     pa.trace = trace;
+    pa.trace_fine = 0;
     pa.split = TAPS ? split : 1; pa.slab = slab; pa.slab_bytes = (unsigned)slab_bytes; pa.flags = flags;
     g.tiles_m = (int)ceil_div(g.m, BM);
     g.tiles_n = (int)ceil_div(g.n, 64 * NT);

@@ -48,9 +48,72 @@ __global__ __launch_bounds__(512, 2) void mfma_ceiling_kernel(const unsigned sho
         sink[blockIdx.x * 512 + t] = s[0];
 }
 
+// The same FLOPs per wave and iteration on v_mfma_f32_32x32x16 (4 x 2 accumulator tiles of 32 x 32, four k-steps of 16): round-5
+// experiment (verdict item 3c) — does the 32 x 32 shape, whose microbenchmark ceiling is 15 % above the 16 x 16 one, sustain more
+// under the chip's power budget on the GEMM's operand data?
+template <typename Tr>
+__global__ __launch_bounds__(512, 2) void mfma_ceiling32_kernel(const unsigned short *__restrict__ data, float *__restrict__ sink, int iters) {
+    const int t = threadIdx.x;
+    const s16x8_t *src = (const s16x8_t *)data + ((size_t)(blockIdx.x & 15) * 512 + t) * 12;
+    s16x8_t a[8], b[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = src[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = src[8 + j];
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                acc[i][j][e] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (Tr::kDType == INFINI_DT_BF16)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, b[(j + ks) & 3]),
+                                                                            __builtin_bit_cast(bf16x8_t, a[(i + 2 * ks) & 7]), acc[i][j], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, b[(j + ks) & 3]),
+                                                                           __builtin_bit_cast(f16x8_t, a[(i + 2 * ks) & 7]), acc[i][j], 0, 0, 0);
+                }
+        asm volatile("" : "+v"(a[0]), "+v"(b[0]));
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                s += acc[i][j][e];
+    if (s == 123.456f)
+        sink[blockIdx.x * 512 + t] = s;
+}
+
 } // namespace irocm
 
 using namespace irocm;
+
+// As infini_rocm_probe_mfma_ceiling on v_mfma_f32_32x32x16: iters * 32 MFMAs per wave, the same FLOP count per iteration.
+extern "C" int infini_rocm_probe_mfma_ceiling32(infiniRocmRuntime_t rt, int dtype, const void *data, void *sink, int iters, double *flop) {
+    IROCM_CHECK_ARG(rt && data && sink && iters > 0, "probe: bad argument");
+    IROCM_CHECK_ARG(dtype == INFINI_DT_BF16 || dtype == INFINI_DT_F16, "probe: bf16 / f16 only");
+    const unsigned grid = (unsigned)rt->num_cu;
+    if (dtype == INFINI_DT_BF16)
+        hipLaunchKernelGGL(mfma_ceiling32_kernel<Bf16Traits>, dim3(grid), dim3(512), 0, rt->stream, (const unsigned short *)data, (float *)sink, iters);
+    else
+        hipLaunchKernelGGL(mfma_ceiling32_kernel<F16Traits>, dim3(grid), dim3(512), 0, rt->stream, (const unsigned short *)data, (float *)sink, iters);
+    IROCM_LAUNCH_CHECK("mfma_ceiling32");
+    if (flop)
+        *flop = (double)grid * 8.0 * (double)iters * 32.0 * (2.0 * 32 * 32 * 16);
+    return INFINI_ROCM_OK;
+}
 
 // data: >= 16 * 512 * 12 * 16 bytes (1.5 MiB) of 16-bit operands in device memory (random data = the realistic power
 // draw; zeros clock higher); sink: >= num_cu * 512 floats. Launches ONE kernel of num_cu workgroups x 512 threads that

@@ -15,7 +15,7 @@ from infinitensor_amd._lib import check
 from infinitensor_amd.runtime import Event
 
 
-def mfma_ceiling(rt, dtype=torch.bfloat16, iters=4000, reps=20, fill="normal") -> float:
+def mfma_ceiling(rt, dtype=torch.bfloat16, iters=4000, reps=20, fill="normal", shape32=False) -> float:
     """TFLOP/s of the MFMA-only kernel; average over `reps` back-to-back launches (HIP events on the runtime stream)."""
     n = 16 * 512 * 12 * 8
     data = (torch.randn(n, device="cuda") if fill == "normal" else torch.zeros(n, device="cuda")).to(dtype)
@@ -25,8 +25,8 @@ def mfma_ceiling(rt, dtype=torch.bfloat16, iters=4000, reps=20, fill="normal") -
     flop = C.c_double()
 
     def launch():
-        check(lib().infini_rocm_probe_mfma_ceiling(rt.handle, code, C.c_void_p(data.data_ptr()), C.c_void_p(sink.data_ptr()),
-                                                   iters, C.byref(flop)))
+        fn = lib().infini_rocm_probe_mfma_ceiling32 if shape32 else lib().infini_rocm_probe_mfma_ceiling
+        check(fn(rt.handle, code, C.c_void_p(data.data_ptr()), C.c_void_p(sink.data_ptr()), iters, C.byref(flop)))
 
     for _ in range(3):
         launch()
@@ -50,4 +50,9 @@ if __name__ == "__main__":
     out = {"dtype": a.dtype, "iters": a.iters, "mfma_per_wave": a.iters * 64,
            "random_TFLOPs": round(mfma_ceiling(rt, dt, a.iters, a.reps, "normal"), 1),
            "zeros_TFLOPs": round(mfma_ceiling(rt, dt, a.iters, a.reps, "zeros"), 1), "nominal_peak_TFLOPs": 2500.0}
+    # interleaved repeats of both instruction shapes (the clocks drift over a run)
+    for rep in range(3):
+        out[f"random_16x16x32_rep{rep}"] = round(mfma_ceiling(rt, dt, a.iters, a.reps, "normal"), 1)
+        out[f"random_32x32x16_rep{rep}"] = round(mfma_ceiling(rt, dt, a.iters, a.reps, "normal", shape32=True), 1)
+    out["zeros_32x32x16"] = round(mfma_ceiling(rt, dt, a.iters, a.reps, "zeros", shape32=True), 1)
     print(json.dumps(out))
