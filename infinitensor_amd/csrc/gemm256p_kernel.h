@@ -269,7 +269,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
             a_cb += a_t == 8 ? 1 : 0;
             a_t = a_t == 8 ? 0 : a_t + 1;
         } else {
-            stage4(a_base + (long)a_kt * a_step, a_off, smem + buf * BUF_BYTES, w);
+            if (!(TRACE && pa.trace_fine >= 2)) // (experiment: trace_fine 2 = no A DMA, 3 = no DMA at all — timing only)
+                stage4(a_base + (long)a_kt * a_step, a_off, smem + buf * BUF_BYTES, w);
         }
         ++a_G;
         if (++a_kt == nk) {
@@ -293,7 +294,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
             b_koff += b_delta(b_t);
             b_t = b_t == 8 ? 0 : b_t + 1;
         } else {
-            stage_n<NB>(b_base + (long)b_kt * b_step, b_off, smem + buf * BUF_BYTES + OPER_BYTES, w);
+            if (!(TRACE && pa.trace_fine >= 3))
+                stage_n<NB>(b_base + (long)b_kt * b_step, b_off, smem + buf * BUF_BYTES + OPER_BYTES, w);
         }
         ++b_G;
         if (++b_kt == nk) {
@@ -1120,7 +1122,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         wait_lgkm0();
         barrier();
         // C1
-        if constexpr (TRACE) { if (pa.trace_fine) stamp(); }
+        if constexpr (TRACE) { if (pa.trace_fine == 1) stamp(); }
         __builtin_amdgcn_s_setprio(1);
         mask_b(I0{}, I2{}, bq0); // (tap mode; hipcc spreads the ANDs of the later fragments between the first MFMAs)
         if constexpr (NJ1 > 0) mask_b(I1{}, IJ1{}, bq1);
@@ -1141,7 +1143,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         }
         __builtin_amdgcn_s_setprio(0);
         fence_sched();
-        if constexpr (TRACE) { if (pa.trace_fine) stamp(); }
+        if constexpr (TRACE) { if (pa.trace_fine == 1) stamp(); }
         finish_cursors(); // (issues behind the MFMA burst, which is still executing)
         barrier();
         // L2
@@ -1157,12 +1159,12 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         wait_lgkm0();
         barrier();
         // C2
-        if constexpr (TRACE) { if (pa.trace_fine) stamp(); }
+        if constexpr (TRACE) { if (pa.trace_fine == 1) stamp(); }
         __builtin_amdgcn_s_setprio(1);
         if constexpr (NJ1 > 0) compute(I1{}, I1{}, IJ1{}, zeroc, aq, bq1);
         compute(I1{}, I0{}, I2{}, zeroc, aq, bq0);
         __builtin_amdgcn_s_setprio(0);
-        if constexpr (TRACE) { if (pa.trace_fine) stamp(); }
+        if constexpr (TRACE) { if (pa.trace_fine == 1) stamp(); }
         if constexpr (TAPS)
             c_t = c_t == 8 ? 0 : c_t + 1;
         barrier();
@@ -1281,7 +1283,7 @@ template <typename Tr, int NT, bool TRACE = false>
 static int launch_p(infiniRocmRuntime_t rt, GemmArgs g, bool akm, bool bkm, unsigned long long *trace = nullptr) {
     PArgs pa;
     pa.trace = trace;
-    pa.trace_fine = (TRACE && getenv("IROCM_GEMM_TRACE_FINE")) ? 1 : 0;
+    pa.trace_fine = (TRACE && getenv("IROCM_GEMM_TRACE_FINE")) ? atoi(getenv("IROCM_GEMM_TRACE_FINE")) : 0;
     pa.split = 1; pa.slab = nullptr; pa.slab_bytes = 0; pa.flags = nullptr;
     constexpr int kLds = LDS_BYTES + (TRACE ? kTraceBytes : 0) + kExtraLds;
     if (!(g.act == 0 || g.act == 1 || g.act == 5) || (g.bias && !(g.bias_m == 0 && g.bias_n == 1)))
