@@ -536,6 +536,10 @@ int infini_rocm_pad_slice(infiniRocmRuntime_t rt, int dtype, const void *x, void
  * input / output (reference: ConcatCuda / SplitCuda, src/kernels/cuda/split_concat.cu:29-82). */
 int infini_rocm_strided_copy(infiniRocmRuntime_t rt, const void *src, void *dst, int64_t rows,
                              int64_t row_bytes, int64_t src_pitch, int64_t dst_pitch);
+/* `count` 2-D strided copies of the same `rows` as ONE launch (blockIdx.z = segment; more than 16 segments: one launch per 16): a Concat
+ * is one segment per input, a Split one per output. Segments with row_bytes == 0 are skipped. */
+int infini_rocm_strided_copy_multi(infiniRocmRuntime_t rt, int count, const void *const *srcs, void *const *dsts, int64_t rows,
+                                   const int64_t *row_bytes, const int64_t *src_pitch, const int64_t *dst_pitch);
 
 /* ------------------------------------------------------------------------------------------ */
 /* RCCL communicator + collectives (reference: NcclCommunicatorObj, include/cuda/nccl_communicator.h:22-68; */

@@ -132,6 +132,7 @@ def lib() -> C.CDLL:
     sig("infini_rocm_where_ex", [vp, i32, i32, vp, vp, vp, vp, i32, pi64, pi64, pi64, pi64])
     sig("infini_rocm_pad_slice", [vp, i32, vp, vp, i32, pi64, pi64, pi64, pi64, i32])
     sig("infini_rocm_strided_copy", [vp, vp, vp, i64, i64, i64, i64])
+    sig("infini_rocm_strided_copy_multi", [vp, i32, vp, vp, i64, vp, vp, vp])
     sig("infini_rocm_comm_init", [vp, C.c_char_p, i32, i32])
     sig("infini_rocm_comm_unique_id", [vp, C.POINTER(sz)])
     sig("infini_rocm_comm_init_id", [vp, vp, sz, i32, i32])

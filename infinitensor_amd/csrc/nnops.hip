@@ -5,6 +5,7 @@
 // poolingCudnn src/kernels/cuda/pooling.cc:6-95 (cudnnPoolingForward; AVERAGE_COUNT_INCLUDE_PADDING).
 // All HBM-bound: algorithmic bytes = (numel_in + numel_out) * sizeof(T). fp32 arithmetic throughout.
 #include "common.h"
+#include <type_traits>
 
 namespace irocm {
 
@@ -65,6 +66,33 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const T *__restrict__ 
         LdSt<T>::st(y + row, s * scale);
 }
 
+// Sum of the n 16-bit elements e0 .. e0 + n - 1 of a span staged in LDS (4-byte aligned base), fp32 accumulation: two elements per
+// LDS read and ONE instruction per pair — v_dot2c_f32_{f16,bf16}(word, weights, s) adds both halves of a word to the fp32 sum; weights
+// (1, 1) inside the row, (0, 1) / (1, 0) for the word a row shares with its neighbour.
+template <typename T> __device__ __forceinline__ float row_sum16(const unsigned *words, int e0, int n) {
+    constexpr unsigned kOne = std::is_same<T, __half>::value ? 0x3c00u : 0x3f80u;
+    auto dot = [](unsigned word, unsigned wgt, float acc) {
+        if constexpr (std::is_same<T, __half>::value) {
+            typedef _Float16 h2_ __attribute__((ext_vector_type(2)));
+            return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_, word), __builtin_bit_cast(h2_, wgt), acc, false);
+        } else {
+            typedef __bf16 b2_ __attribute__((ext_vector_type(2)));
+            return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2_, word), __builtin_bit_cast(b2_, wgt), acc, false);
+        }
+    };
+    const int e1 = e0 + n - 1;
+    const int w0 = e0 >> 1, w1 = e1 >> 1;
+    const unsigned first = (e0 & 1) ? (kOne << 16) : (kOne | (kOne << 16)); // a row starting on an odd element owns the high half only
+    const unsigned last = (e1 & 1) ? (kOne | (kOne << 16)) : kOne;          // a row ending on an even element owns the low half only
+    float s = 0.f;
+    if (w0 == w1)
+        return dot(words[w0], first & last, s);
+    s = dot(words[w0], first, s);
+    for (int w = w0 + 1; w < w1; ++w)
+        s = dot(words[w], kOne | (kOne << 16), s);
+    return dot(words[w1], last, s);
+}
+
 // ---- Reduce: trailing dims reduced, SHORT rows (n < 64: the 7 x 7 planes of a global average pool written as ReduceMean) --
 // A block takes RB consecutive rows = one contiguous span of RB * n elements: coalesced loads into LDS as fp32, then one
 // thread per row sums its n values (the general kernel below read 49 strided elements per thread: 0.6 TB/s).
@@ -89,9 +117,15 @@ __global__ __launch_bounds__(256) void reduce_short_rows_kernel(const T *__restr
         __syncthreads();
         if ((int)threadIdx.x < nrows) {
             float s = 0.f;
-            const T *r = rbuf + threadIdx.x * n;
-            for (int k = 0; k < n; ++k)
-                s += LdSt<T>::ld(r + k);
+            if constexpr (sizeof(T) == 2) {
+                // (one 2-byte read + conversion + add per element made the 7 x 7 planes of a global average pool instruction-bound:
+                // 0.48 of the HBM peak)
+                s = row_sum16<T>(reinterpret_cast<const unsigned *>(rbuf), (int)threadIdx.x * n, n);
+            } else {
+                const T *r = rbuf + threadIdx.x * n;
+                for (int k = 0; k < n; ++k)
+                    s += LdSt<T>::ld(r + k);
+            }
             LdSt<T>::st(y + row0 + threadIdx.x, s * scale);
         }
         __syncthreads();
@@ -344,10 +378,14 @@ __global__ __launch_bounds__(256) void global_avgpool_small_kernel(const T *__re
     }
     __syncthreads();
     if ((long)threadIdx.x < np) {
-        const T *pl = (const T *)smem + (long)threadIdx.x * hw;
         float s = 0.f;
-        for (int i = 0; i < hw; ++i)
-            s += LdSt<T>::ld(pl + i);
+        if constexpr (sizeof(T) == 2) {
+            s = row_sum16<T>((const unsigned *)smem, (int)threadIdx.x * hw, hw);
+        } else {
+            const T *pl = (const T *)smem + (long)threadIdx.x * hw;
+            for (int i = 0; i < hw; ++i)
+                s += LdSt<T>::ld(pl + i);
+        }
         LdSt<T>::st(y + p0 + threadIdx.x, s / (float)hw);
     }
 }

@@ -711,11 +711,17 @@ def concat(rt: RocmRuntime, xs: Sequence[torch.Tensor], axis: int, out: torch.Te
     outer = math.prod(oshape[:axis])
     inner_bytes = math.prod(oshape[axis + 1:]) * out.element_size()
     dst_pitch = oshape[axis] * inner_bytes
-    off = 0
+    # every input as one segment of ONE launch (infini_rocm_strided_copy_multi)
+    srcs, dsts, rbs, off = [], [], [], 0
     for t in xs:
         rb = t.shape[axis] * inner_bytes
-        check(lib().infini_rocm_strided_copy(rt.handle, _ptr(t), C.c_void_p(out.data_ptr() + off), outer, rb, rb, dst_pitch))
+        srcs.append(t.data_ptr())
+        dsts.append(out.data_ptr() + off)
+        rbs.append(rb)
         off += rb
+    n = len(xs)
+    check(lib().infini_rocm_strided_copy_multi(rt.handle, n, (C.c_void_p * n)(*srcs), (C.c_void_p * n)(*dsts), outer, _i64arr(rbs), _i64arr(rbs),
+                                               _i64arr([dst_pitch] * n)))
     return out
 
 
@@ -726,15 +732,17 @@ def split(rt: RocmRuntime, x: torch.Tensor, axis: int, sizes: Sequence[int]) -> 
     outer = math.prod(x.shape[:axis])
     inner_bytes = math.prod(x.shape[axis + 1:]) * x.element_size()
     src_pitch = x.shape[axis] * inner_bytes
-    outs, off = [], 0
+    outs, srcs, rbs, off = [], [], [], 0
     for sz in sizes:
         shp = list(x.shape)
         shp[axis] = sz
-        o = torch.empty(shp, dtype=x.dtype, device=x.device)
-        rb = sz * inner_bytes
-        check(lib().infini_rocm_strided_copy(rt.handle, C.c_void_p(x.data_ptr() + off), _ptr(o), outer, rb, src_pitch, rb))
-        outs.append(o)
-        off += rb
+        outs.append(torch.empty(shp, dtype=x.dtype, device=x.device))
+        srcs.append(x.data_ptr() + off)
+        rbs.append(sz * inner_bytes)
+        off += sz * inner_bytes
+    n = len(outs)
+    check(lib().infini_rocm_strided_copy_multi(rt.handle, n, (C.c_void_p * n)(*srcs), (C.c_void_p * n)(*[o.data_ptr() for o in outs]), outer,
+                                               _i64arr(rbs), _i64arr([src_pitch] * n), _i64arr(rbs)))
     return outs
 
 

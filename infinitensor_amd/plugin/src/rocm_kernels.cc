@@ -609,13 +609,20 @@ class ConcatRocm : public RocmKernelWithoutConfig {
         const int64_t outer = prod(od, 0, axis), innerBytes = prod(od, axis + 1, od.size()) * out->getDType().getSize();
         const int64_t dstPitch = od[axis] * innerBytes;
         char *dst = P<char>(out);
+        // every input as one segment of ONE launch (empty inputs — the reference accepts them, test_cuda_concat.cc:160-190 — are skipped
+        // by the library)
+        std::vector<const void *> srcs;
+        std::vector<void *> dsts;
+        std::vector<int64_t> rbs, dps;
         for (const auto &in : op->getInputs()) {
-            if (in->size() == 0)
-                continue; // the reference accepts empty inputs (test_cuda_concat.cc:160-190)
-            const int64_t rb = in->getDims()[axis] * innerBytes;
-            ROCM_CALL(infini_rocm_strided_copy(H(ctx), P(in), dst, outer, rb, rb, dstPitch));
+            const int64_t rb = in->size() == 0 ? 0 : in->getDims()[axis] * innerBytes;
+            srcs.push_back(rb ? P(in) : nullptr);
+            dsts.push_back(dst);
+            rbs.push_back(rb);
+            dps.push_back(dstPitch);
             dst += rb;
         }
+        ROCM_CALL(infini_rocm_strided_copy_multi(H(ctx), (int)srcs.size(), srcs.data(), dsts.data(), outer, rbs.data(), rbs.data(), dps.data()));
     }
 };
 REGISTER_KERNEL(Device::ROCM, OpType::Concat, ConcatRocm, "Concat_ROCM");
@@ -629,11 +636,18 @@ class SplitRocm : public RocmKernelWithoutConfig {
         const int64_t outer = prod(id, 0, axis), innerBytes = prod(id, axis + 1, id.size()) * in->getDType().getSize();
         const int64_t srcPitch = id[axis] * innerBytes;
         const char *src = P<char>(in);
-        for (const auto &out : op->getOutputs()) {
+        std::vector<const void *> srcs;
+        std::vector<void *> dsts;
+        std::vector<int64_t> rbs, sps;
+        for (const auto &out : op->getOutputs()) { // every output as one segment of ONE launch
             const int64_t rb = out->getDims()[axis] * innerBytes;
-            ROCM_CALL(infini_rocm_strided_copy(H(ctx), src, P(out), outer, rb, srcPitch, rb));
+            srcs.push_back(src);
+            dsts.push_back(P(out));
+            rbs.push_back(rb);
+            sps.push_back(srcPitch);
             src += rb;
         }
+        ROCM_CALL(infini_rocm_strided_copy_multi(H(ctx), (int)srcs.size(), srcs.data(), dsts.data(), outer, rbs.data(), sps.data(), rbs.data()));
     }
 };
 REGISTER_KERNEL(Device::ROCM, OpType::Split, SplitRocm, "Split_ROCM");
