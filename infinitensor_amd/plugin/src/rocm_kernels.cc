@@ -231,8 +231,9 @@ REGISTER_KERNEL(Device::ROCM, OpType::MatMul, MatmulRocm, "Matmul_MFMA_ROCM");
 class ConvRocm : public RocmTunableKernel {
     int setVariant(infiniRocmRuntime_t rt, int v) const override { return infini_rocm_conv2d_set_variant(rt, v); }
     // generic implicit GEMM, tap-shifted implicit GEMM (conv_s1), batched-GEMM route for pointwise shapes, patch kernel off,
-    // pointwise layers as one GEMM over pixel slots, the 8-wave patch kernel (infini_rocm.h)
-    std::vector<int> candidates() const override { return {1, 2, 3, 4, 5, 6}; }
+    // pointwise layers as one GEMM over pixel slots, the 8-wave patch kernel, 3 x 3 layers as one GEMM with K = 9 C (round 5: the tap mode of
+    // the persistent kernels, split-K where the tiles are few) (infini_rocm.h)
+    std::vector<int> candidates() const override { return {1, 2, 3, 4, 5, 6, 7}; }
     int recordType() const override { return kRocmConvRecord; }
     void launch(const Operator &_op, const RuntimeObj *ctx) const override {
         auto op = as<ConvObj>(_op);
