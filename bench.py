@@ -185,14 +185,16 @@ def extras(rt, ops, Event) -> dict:
     import membound_sweep as MS
 
     pmc, pmc_src = {}, None
-    try:
-        d = json.loads((REPO / "profiles" / "r04_membound_pmc.json").read_text())
+    for fname in ("r05_membound_pmc.json", "r04_membound_pmc.json"):
+        try:
+            d = json.loads((REPO / "profiles" / fname).read_text())
+        except Exception as e:  # noqa: BLE001
+            pmc_src = pmc_src or ("no counter file: " + repr(e)[:80])
+            continue
         if d.get("stamp") == MS.source_stamp():
-            pmc, pmc_src = d["rows"], "profiles/r04_membound_pmc.json"
-        else:
-            pmc_src = "profiles/r04_membound_pmc.json REFUSED: taken from other kernel sources (stamp %s, these are %s)" % (d.get("stamp"), MS.source_stamp())
-    except Exception as e:  # noqa: BLE001
-        pmc_src = "no counter file: " + repr(e)[:80]
+            pmc, pmc_src = d["rows"], "profiles/" + fname
+            break
+        pmc_src = "profiles/%s REFUSED: taken from other kernel sources (stamp %s, these are %s)" % (fname, d.get("stamp"), MS.source_stamp())
 
     def row(kind, shape, name, t, nbytes):
         gbs = nbytes / t / 1e9
@@ -658,7 +660,7 @@ def pmc_traffic(launched: str) -> dict:
     WRITE_SIZE of the same shape; FETCH_SIZE x2 per the gfx950 note). The counter file names the kernel variant it was
     taken from; a file from ANOTHER variant than the one this run launched is refused (traffic: null) instead of silently
     going stale when the kernel changes."""
-    for name in ("r04_gemm256p_pmc.json", "r03_gemm256p_pmc.json", "r02_gemm256p_pmc.json"):
+    for name in ("r05_gemm256p_pmc.json", "r04_gemm256p_pmc.json", "r03_gemm256p_pmc.json", "r02_gemm256p_pmc.json"):
         p = REPO / "profiles" / name
         try:
             d = json.loads(p.read_text())

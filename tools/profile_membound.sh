@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM-side traffic of every memory-bound row of tools/membound_sweep.py: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
 # SEPARATE passes (never combined with other trace domains), FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note.
-# -> gpurun_out/prof_membound/summary.json (copied to profiles/r04_membound_pmc.json), stamped with the kernel sources' hash.
+# -> gpurun_out/prof_membound/summary.json (copied to profiles/r0N_membound_pmc.json), stamped with the kernel sources' hash.
 cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_membound
