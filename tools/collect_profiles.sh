@@ -1,26 +1,23 @@
 #!/bin/bash
-# Copy the summaries of the last tools/gpu_round.sh visit (gpurun_out/round/) into profiles/ under this round's prefix.
-R=${1:-r03}
+# Copy the summaries of the last tools/gpu_round5.sh visit (gpurun_out/round5/) into profiles/ under this round's prefix.
+R=${1:-r05}
 cd $(dirname $0)/..
-S=gpurun_out/round
+S=gpurun_out/round5
 clean() { grep -v "amdgpu.ids\|^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" "$1"; }
 clean $S/bench.json | grep '^{' | tail -1 > profiles/${R}_bench_line.json
-clean $S/bench_driverflags.json | grep '^{' | tail -1 > profiles/${R}_bench_line_driver_flags.json
+clean $S/bench_driverflags.json | grep '^{' | tail -1 > profiles/${R}_bench_line_driverflags.json
+cp $S/bench_detail.json profiles/${R}_bench_detail.json
 grep '^{' $S/models.json > profiles/${R}_model_lines.json
 for f in bench resnet50 bert bert_decomposed llama; do cp $S/prof/${f}_kernel_stats.csv profiles/${R}_${f}_kernel_stats.csv; done
 cp $S/prof/bench_trace_summary.json profiles/${R}_bench_trace_summary.json
-cp $S/prof/gemm256p_pmc.json profiles/${R}_gemm256p_pmc.json
-cp $S/prof/gemm_fast32_pmc.json profiles/${R}_gemm_fast32_pmc.json
-cp $S/prof/conv_pw_c512_f256_28_pmc.json profiles/${R}_conv_pw_c512_f256_28_pmc.json
-cp $S/prof/conv_pw_c256_f1024_14_pmc.json profiles/${R}_conv_pw_c256_f1024_14_pmc.json
-clean $S/conv_layers.txt > profiles/${R}_conv_layers.txt
-clean $S/conv_layers_residual.txt > profiles/${R}_conv_layers_residual.txt
-clean $S/conv_as_gemm.txt > profiles/${R}_conv_as_gemm.txt
-clean $S/gemm_shapes_bf16.txt > profiles/${R}_gemm_shapes_bf16.txt
-clean $S/gemm_timeline.txt > profiles/${R}_gemm_timeline.txt
-clean $S/store_burst.txt > profiles/${R}_store_burst.txt
-clean $S/store_burst2.txt > profiles/${R}_store_burst2.txt
-clean $S/resnet50_fusion_log.txt > profiles/${R}_resnet50_plan_log.txt
-grep '^{' $S/rocm_launch.log | tail -1 > profiles/${R}_rocm_launch_tp1_line.json
-tail -4 $S/pytest.log | grep -v "amdgpu.ids\|^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" > profiles/${R}_pytest_gpu_tail.txt
+for f in gemm256p_pmc membound_pmc conv_stem_pool_pmc conv_tap_splitk_c512_7_pmc conv_dw_c192_75_pmc conv_igemm32_c128_28_pmc attention_kvcache_split_pmc; do
+  cp $S/prof/$f.json profiles/${R}_$f.json
+done
+for f in conv_layers conv_layers_residual gemm_shapes_bf16 gemm_shapes_f16 dwconv_layers conv32_layers kvcache conv_tap_timeline membound; do
+  clean $S/$f.txt > profiles/${R}_$f.txt
+done
+cp $S/membound.json profiles/${R}_membound_sweep.json
+clean $S/resnet50_plan_log.txt > profiles/${R}_resnet50_plan_log.txt
+clean $S/pytest.log > profiles/${R}_pytest_gpu.log
+tail -4 $S/pytest.log | grep -v "amdgpu.ids\|^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" > profiles/${R}_gpu_suite_tail.txt
 ls -la profiles | grep ${R}_ | awk '{print $5, $9}'
