@@ -542,6 +542,45 @@ int infini_rocm_strided_copy_multi(infiniRocmRuntime_t rt, int count, const void
                                    const int64_t *row_bytes, const int64_t *src_pitch, const int64_t *dst_pitch);
 
 /* ------------------------------------------------------------------------------------------ */
+/* "From-shape" forms (csrc/shaped.hip): the operators above whose arguments are strides / extents, taking the operands' SHAPES as the */
+/*   reference's operators hold them (TensorObj::getDims()). The shape -> stride glue lives once, below the ABI: the plugin kernels      */
+/*   (plugin/src/rocm_kernels.cc) and the ctypes mirror (infinitensor_amd/ops.py) both call these and nothing else for these operators. */
+/*   Reference glue they replace: the kernels' own broadcast index arithmetic (src/kernels/cuda/element_wise.cu:9-60, where.cu),        */
+/*   matmul.cc:86-137 (batch broadcast by zero stride, bias expanded to [.., m, n]), split_concat.cc:10-62, pad_slice.cc, gather.cc.    */
+/* ------------------------------------------------------------------------------------------ */
+/* strides[out_rank]: element strides of a dense tensor of `shape` viewed in `out_shape`, 0 where a dim is broadcast (a dim of 1 or a
+ * missing leading dim); INVALID_ARGUMENT when the shape does not broadcast (infer_broadcast, src/utils/operator_utils.cc:6-32). Pure. */
+int infini_rocm_broadcast_strides(int rank, const int64_t *shape, int out_rank, const int64_t *out_shape, int64_t *strides);
+int infini_rocm_binary_shaped(infiniRocmRuntime_t rt, int op, int dtype, const void *a, int a_rank, const int64_t *a_shape,
+                              const void *b, int b_rank, const int64_t *b_shape, void *out, int out_rank, const int64_t *out_shape);
+int infini_rocm_where_shaped(infiniRocmRuntime_t rt, int dtype, int cond_dtype, const void *x, int x_rank, const int64_t *x_shape,
+                             const void *y, int y_rank, const int64_t *y_shape, const void *cond, int c_rank, const int64_t *c_shape,
+                             void *out, int out_rank, const int64_t *out_shape);
+int infini_rocm_expand_shaped(infiniRocmRuntime_t rt, int dtype, const void *x, int x_rank, const int64_t *x_shape, void *out,
+                              int out_rank, const int64_t *out_shape);
+/* plan[9] = { batch, m, n, k, stride_a, stride_b, bias_batch_stride, bias_m_stride, bias_n_stride } of op(A) op(B) (+ bias broadcast to
+ * [batch dims .., m, n]); bias_rank < 0: no bias. Errors as the reference's asserts: K mismatch, batch dims that do not broadcast, a
+ * partially broadcast batch (matmul.cc:124-137). Pure. */
+int infini_rocm_matmul_plan(int a_rank, const int64_t *a_shape, int b_rank, const int64_t *b_shape, int bias_rank,
+                            const int64_t *bias_shape, int trans_a, int trans_b, int64_t *plan);
+/* infini_rocm_matmul_headsplit on that plan (bias == NULL: none; seq = head_dim = 0: the plain [.., m, n] store). */
+int infini_rocm_matmul_shaped(infiniRocmRuntime_t rt, int dtype, const void *a, int a_rank, const int64_t *a_shape, const void *b,
+                              int b_rank, const int64_t *b_shape, const void *bias, int bias_rank, const int64_t *bias_shape, void *out,
+                              int trans_a, int trans_b, int act, int64_t seq, int64_t head_dim);
+/* Concat: input i holds axis_extents[i] slices of `out`'s axis (extents add up to out_shape[axis]; empty inputs allowed) — one launch.
+ * Split: output i receives axis_extents[i] slices of `in`'s axis. elem_size in bytes. */
+int infini_rocm_concat_shaped(infiniRocmRuntime_t rt, int elem_size, int count, const void *const *inputs, const int64_t *axis_extents,
+                              void *out, int out_rank, const int64_t *out_shape, int axis);
+int infini_rocm_split_shaped(infiniRocmRuntime_t rt, int elem_size, int count, void *const *outputs, const int64_t *axis_extents,
+                             const void *in, int in_rank, const int64_t *in_shape, int axis);
+/* Constant-0 Pad; pads = begin_0 .. begin_{rank-1}, end_0 .. end_{rank-1} (include/operators/pad.h), y has in_shape[d] + begin_d + end_d. */
+int infini_rocm_pad_shaped(infiniRocmRuntime_t rt, int dtype, const void *x, void *y, int rank, const int64_t *in_shape,
+                           const int64_t *pads);
+/* Gather along `axis` of data_shape with n_indices indices (output rank = data rank - 1 + index rank, include/operators/gather.h:27-49). */
+int infini_rocm_gather_shaped(infiniRocmRuntime_t rt, int dtype, int index_dtype, const void *data, int data_rank,
+                              const int64_t *data_shape, const void *indices, int64_t n_indices, void *out, int axis);
+
+/* ------------------------------------------------------------------------------------------ */
 /* RCCL communicator + collectives (reference: NcclCommunicatorObj, include/cuda/nccl_communicator.h:22-68; */
 /*   CudaRuntimeObj::initComm, src/cuda/cuda_runtime.cc:495-509; kernels all_reduce.cc:8-63,        */
 /*   all_gather.cc:8-40, broadcast.cc:8-26, send.cc:8-37, recv.cc:8-41). One communicator per runtime, */

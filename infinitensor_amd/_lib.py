@@ -133,6 +133,17 @@ def lib() -> C.CDLL:
     sig("infini_rocm_pad_slice", [vp, i32, vp, vp, i32, pi64, pi64, pi64, pi64, i32])
     sig("infini_rocm_strided_copy", [vp, vp, vp, i64, i64, i64, i64])
     sig("infini_rocm_strided_copy_multi", [vp, i32, vp, vp, i64, vp, vp, vp])
+    # "from-shape" forms (csrc/shaped.hip): the shape -> stride glue below the ABI, shared with the plugin kernels
+    sig("infini_rocm_broadcast_strides", [i32, pi64, i32, pi64, pi64])
+    sig("infini_rocm_binary_shaped", [vp, i32, i32, vp, i32, pi64, vp, i32, pi64, vp, i32, pi64])
+    sig("infini_rocm_where_shaped", [vp, i32, i32, vp, i32, pi64, vp, i32, pi64, vp, i32, pi64, vp, i32, pi64])
+    sig("infini_rocm_expand_shaped", [vp, i32, vp, i32, pi64, vp, i32, pi64])
+    sig("infini_rocm_matmul_plan", [i32, pi64, i32, pi64, i32, pi64, i32, i32, pi64])
+    sig("infini_rocm_matmul_shaped", [vp, i32, vp, i32, pi64, vp, i32, pi64, vp, i32, pi64, vp, i32, i32, i32, i64, i64])
+    sig("infini_rocm_concat_shaped", [vp, i32, i32, vp, pi64, vp, i32, pi64, i32])
+    sig("infini_rocm_split_shaped", [vp, i32, i32, vp, pi64, vp, i32, pi64, i32])
+    sig("infini_rocm_pad_shaped", [vp, i32, vp, vp, i32, pi64, pi64])
+    sig("infini_rocm_gather_shaped", [vp, i32, i32, vp, i32, pi64, vp, i64, vp, i32])
     sig("infini_rocm_comm_init", [vp, C.c_char_p, i32, i32])
     sig("infini_rocm_comm_unique_id", [vp, C.POINTER(sz)])
     sig("infini_rocm_comm_init_id", [vp, vp, sz, i32, i32])

@@ -229,7 +229,8 @@ struct Conv32Args {
     int nimg, c, h, wd, f, r, s;
     int ph, pw, sh, sw, dh, dw;
     int oh, ow;
-    int k;            // c * r * s
+    int k;            // K of the GEMM = row pitch of the weight image: c * r * s rounded up to 4 (tap-major: r * s * cp)
+    int kreal;        // c * r * s (k-major form: elements at k >= kreal are padding)
     long ncols;       // nimg * oh * ow
     int tiles_m, tiles_n;
     int act;
@@ -321,7 +322,7 @@ template <int T, bool TM> __global__ __launch_bounds__(256, 2) void conv_igemm32
             udivmod_m((unsigned)k, (unsigned)(p.r * p.s), p.rs_m, cc, rs);
             udivmod_m(rs, (unsigned)p.s, p.s_m, rr, ss);
             const int dy = (int)rr * p.dh, dx = (int)ss * p.dw;
-            const bool ok = qlive && k < p.k && (unsigned)(iy0 + dy) < (unsigned)p.h && (unsigned)(ix0 + dx) < (unsigned)p.wd;
+            const bool ok = qlive && k < p.kreal && (unsigned)(iy0 + dy) < (unsigned)p.h && (unsigned)(ix0 + dx) < (unsigned)p.wd;
             const int off = pix_base + (int)cc * hw + dy * p.wd + dx;
             return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, ok ? off * 4 : (int)0x7ffffff0, 0, 0));
         }
@@ -508,15 +509,18 @@ int launch_conv_igemm32(infiniRocmRuntime_t rt, const void *x, const void *w, co
     const int64_t ncols = n * oh * ow;
     const bool tm = c >= 32; // tap-major K over re-packed weights (see the kernel); layers with fewer channels decode k per element
     const int64_t cp = tm ? (c + 31) / 32 * 32 : c;
-    const int64_t k = cp * r * s;
-    if (k % 4 != 0 || k < 4 || !al16p(w) || (((uintptr_t)x) & 3) != 0 || (((uintptr_t)y) & 3) != 0 || (res && (((uintptr_t)res) & 3) != 0))
+    // (k-major rows whose length is not a multiple of 4 — the 3-channel 7 x 7 stem: 147 — are copied into zero-padded 16-byte rows)
+    const bool padk = !tm && (c * r * s) % 4 != 0;
+    const int64_t k = tm ? cp * r * s : (c * r * s + 3) / 4 * 4;
+    if (k < 4 || (!tm && !padk && !al16p(w)) || (((uintptr_t)w) & 3) != 0 || (((uintptr_t)x) & 3) != 0 || (((uintptr_t)y) & 3) != 0 || (res && (((uintptr_t)res) & 3) != 0))
         return -1;
     if (n * c * h * wd * 4 >= (1ll << 31) - 64 || ncols >= (1ll << 31) - 256 || n * f * oh * ow >= (1ll << 31) || k >= (1ll << 24))
         return -1;
     f32k::Conv32Args p;
     p.x = (const float *)x; p.w = (const float *)w; p.bias = (const float *)bias; p.res = (const float *)res; p.y = (float *)y;
-    if (tm) {
-        // the tap-major weight image: cached per graph weight when the caller declared the weights constant (the plugin does), else
+    if (tm || padk) {
+        const int kind = tm ? 2 : 3;
+        // the tap-major (or row-padded) weight image: cached per graph weight when the caller declared the weights constant (the plugin does), else
         // rebuilt per call in the workspace (as conv_s1.hip does for the 16-bit kernels' [RS][F][C] image)
         const size_t w_bytes = ((size_t)f * k * 4 + 255) & ~(size_t)255;
         const void *packed = nullptr;
@@ -524,12 +528,12 @@ int launch_conv_igemm32(infiniRocmRuntime_t rt, const void *x, const void *w, co
         bool need_pack = true;
         const bool cached = rt->conv_const_weights != 0;
         if (cached) {
-            packed = wcache_lookup(rt, w, (int)f, (int)c, r * s, 2);
+            packed = wcache_lookup(rt, w, (int)f, (int)c, r * s, kind);
             if (packed) {
                 need_pack = false;
             } else {
                 void *buf = nullptr;
-                const int st = wcache_insert(rt, w, (size_t)f * c * r * s * 4, (int)f, (int)c, r * s, 2, w_bytes, &buf, &pack_stream);
+                const int st = wcache_insert(rt, w, (size_t)f * c * r * s * 4, (int)f, (int)c, r * s, kind, w_bytes, &buf, &pack_stream);
                 if (st != INFINI_ROCM_OK)
                     return st;
                 packed = buf;
@@ -544,8 +548,9 @@ int launch_conv_igemm32(infiniRocmRuntime_t rt, const void *x, const void *w, co
         if (need_pack) {
             long g = ceil_div((long)f * k, 256);
             if (g > 4096) g = 4096;
+            // (the row-padded form is the same copy with the whole row as one "tap" of c r s "channels")
             hipLaunchKernelGGL(f32k::conv_repack_w32, dim3((unsigned)g), dim3(256), 0, pack_stream, (const float *)w, (float *)const_cast<void *>(packed),
-                               (int)f, (int)c, r * s, (int)cp);
+                               (int)f, tm ? (int)c : (int)(c * r * s), tm ? r * s : 1, tm ? (int)cp : (int)k);
             if (hipError_t e = hipGetLastError(); e != hipSuccess) {
                 if (cached)
                     wcache_forget(rt, packed);
@@ -565,6 +570,7 @@ int launch_conv_igemm32(infiniRocmRuntime_t rt, const void *x, const void *w, co
     p.ph = ph; p.pw = pw; p.sh = sh; p.sw = sw; p.dh = dh; p.dw = dw;
     p.oh = oh; p.ow = ow;
     p.k = (int)k;
+    p.kreal = (int)(c * r * s);
     p.cp = (int)cp;
     p.ncols = ncols;
     p.act = act;

@@ -85,19 +85,16 @@ def infer_broadcast(a: Sequence[int], b: Sequence[int]) -> list[int]:
 
 
 def broadcast_strides(shape: Sequence[int], out_shape: Sequence[int]) -> list[int]:
-    """Element strides of a dense tensor of `shape` viewed in `out_shape` (0 where broadcast)."""
-    r, ro = len(shape), len(out_shape)
-    dense = [0] * r
-    p = 1
-    for i in range(r - 1, -1, -1):
-        dense[i] = p
-        p *= shape[i]
-    out = [0] * ro
-    for i in range(ro):
-        j = i - (ro - r)
-        if j >= 0 and shape[j] != 1:
-            out[i] = dense[j]
-    return out
+    """Element strides of a dense tensor of `shape` viewed in `out_shape` (0 where broadcast) — computed by the library
+    (infini_rocm_broadcast_strides, csrc/shaped.hip: the one implementation the plugin kernels use too)."""
+    out = _i64arr([0] * len(out_shape))
+    check(lib().infini_rocm_broadcast_strides(len(shape), _i64arr(list(shape)), len(out_shape), _i64arr(list(out_shape)), out))
+    return list(out)[:len(out_shape)]
+
+
+def _shape(t: torch.Tensor):
+    """(rank, int64 array) of a tensor's dims, as the from-shape entry points take them"""
+    return t.dim(), _i64arr(list(t.shape))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -113,26 +110,18 @@ def matmul(rt: RocmRuntime, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor
     head_split = (seq, head_dim): the [m, n] result is stored as [m / seq, n / head_dim, seq, head_dim] — MatMul ->
     Reshape([B, S, H, D]) -> Transpose(0, 2, 1, 3) in the GEMM epilogue (infini_rocm_matmul_headsplit).
     """
-    sa, sb = list(a.shape), list(b.shape)
-    if len(sa) < 2 or len(sb) < 2:
+    # batch / m / n / k, the operands' batch strides and the bias strides come from the library's plan (infini_rocm_matmul_plan: the
+    # glue of matmul.cc:86-137, shared with the plugin's MatmulRocm); only the OUTPUT shape (the operator's shape inference,
+    # src/operators/matmul.cc:26-49, which the plugin gets from the reference's MatmulObj) is derived here.
+    if a.dim() < 2 or b.dim() < 2:
         raise ValueError("matmul operands must have rank >= 2")
-    batch_shape = infer_broadcast(sa[:-2], sb[:-2])
-    batch = math.prod(batch_shape) if batch_shape else 1
-    k_a = sa[-2] if trans_a else sa[-1]
-    k_b = sb[-1] if trans_b else sb[-2]
-    if k_a != k_b:
-        raise ValueError(f"matmul K mismatch: {k_a} vs {k_b}")  # reference: IT_ASSERT(kA == kB)
-    m = sa[-1] if trans_a else sa[-2]
-    n = sb[-2] if trans_b else sb[-1]
-    k = k_a
-    out_shape = batch_shape + [m, n]
-    ba, bb = math.prod(sa[:-2]), math.prod(sb[:-2])
-    if ba not in (1, batch) or bb not in (1, batch):
-        raise ValueError("only full or size-1 batch broadcast is supported (reference matmul.cc:124-137)")
-    stride_a = 0 if (ba == 1 and batch > 1) else m * k
-    stride_b = 0 if (bb == 1 and batch > 1) else n * k
+    plan = _i64arr([0] * 9)
+    check(lib().infini_rocm_matmul_plan(*_shape(a), *_shape(b), bias.dim() if bias is not None else -1,
+                                        _i64arr(list(bias.shape)) if bias is not None else None, int(trans_a), int(trans_b), plan))
+    m, n = plan[1], plan[2]
+    batch_shape = infer_broadcast(list(a.shape[:-2]), list(b.shape[:-2]))
     seq = hd = 0
-    final_shape = out_shape
+    final_shape = batch_shape + [m, n]
     if head_split is not None:
         seq, hd = (int(v) for v in head_split)
         if seq <= 0 or hd <= 0 or m % seq or n % hd or hd % 8:
@@ -140,22 +129,9 @@ def matmul(rt: RocmRuntime, a: torch.Tensor, b: torch.Tensor, bias: torch.Tensor
         final_shape = batch_shape + [m // seq, n // hd, seq, hd]
     if out is None:
         out = torch.empty(final_shape, dtype=a.dtype, device=a.device)
-    bs_b = bs_m = bs_n = 0
-    if bias is not None:
-        st = broadcast_strides(list(bias.shape), out_shape)
-        # collapse the batch dims of the bias into one stride (dense or broadcast)
-        nb = len(out_shape) - 2
-        bs_m, bs_n = st[-2], st[-1]
-        lead = [s for s, d in zip(st[:nb], out_shape[:nb]) if d != 1]
-        if all(s == 0 for s in lead):
-            bs_b = 0
-        else:
-            bs_b = math.prod(bias.shape[-2:]) if bias.dim() >= 2 else 0
-            if list(bias.shape[:-2]) and math.prod(bias.shape[:-2]) != batch:
-                raise ValueError("partially-broadcast bias batch is not supported")
-    check(lib().infini_rocm_matmul_headsplit(rt.handle, dtype_of(a), _ptr(a), _ptr(b), _ptr(bias), _ptr(out),
-                                             batch, m, n, k, int(trans_a), int(trans_b), stride_a, stride_b,
-                                             bs_b, bs_m, bs_n, int(act), seq, hd))
+    check(lib().infini_rocm_matmul_shaped(rt.handle, dtype_of(a), _ptr(a), *_shape(a), _ptr(b), *_shape(b), _ptr(bias),
+                                          bias.dim() if bias is not None else 0, _i64arr(list(bias.shape)) if bias is not None else None,
+                                          _ptr(out), int(trans_a), int(trans_b), int(act), seq, hd))
     return out
 
 
@@ -412,12 +388,8 @@ def binary(rt: RocmRuntime, op: str, a: torch.Tensor, b: torch.Tensor,
     out_shape = infer_broadcast(list(a.shape), list(b.shape))
     if out is None:
         out = torch.empty(out_shape, dtype=a.dtype, device=a.device)
-    sa = broadcast_strides(list(a.shape), out_shape)
-    sb = broadcast_strides(list(b.shape), out_shape)
-    if len(out_shape) > 8:
-        raise ValueError("rank > 8 not supported")
-    check(lib().infini_rocm_binary(rt.handle, BINARY_OPS[op], dtype_of(a), _ptr(a), _ptr(b), _ptr(out),
-                                   len(out_shape), _i64arr(out_shape), _i64arr(sa), _i64arr(sb)))
+    check(lib().infini_rocm_binary_shaped(rt.handle, BINARY_OPS[op], dtype_of(a), _ptr(a), *_shape(a), _ptr(b), *_shape(b), _ptr(out),
+                                          len(out_shape), _i64arr(out_shape)))
     return out
 
 
@@ -604,8 +576,7 @@ def expand(rt: RocmRuntime, x: torch.Tensor, shape: Sequence[int], out: torch.Te
     oshape = infer_broadcast(list(x.shape), list(shape))
     if out is None:
         out = torch.empty(oshape, dtype=x.dtype, device=x.device)
-    check(lib().infini_rocm_expand(rt.handle, dtype_of(x), _ptr(x), _ptr(out), len(oshape), _i64arr(oshape),
-                                   _i64arr(broadcast_strides(list(x.shape), oshape))))
+    check(lib().infini_rocm_expand_shaped(rt.handle, dtype_of(x), _ptr(x), *_shape(x), _ptr(out), len(oshape), _i64arr(oshape)))
     return out
 
 
@@ -618,9 +589,8 @@ def gather(rt: RocmRuntime, data: torch.Tensor, indices: torch.Tensor, axis: int
     oshape = list(data.shape[:axis]) + list(indices.shape) + list(data.shape[axis + 1:])
     if out is None:
         out = torch.empty(oshape, dtype=data.dtype, device=data.device)
-    check(lib().infini_rocm_gather(rt.handle, dtype_of(data), dtype_of(indices), _ptr(data), _ptr(indices), _ptr(out),
-                                   math.prod(data.shape[:axis]), data.shape[axis], indices.numel(),
-                                   math.prod(data.shape[axis + 1:])))
+    check(lib().infini_rocm_gather_shaped(rt.handle, dtype_of(data), dtype_of(indices), _ptr(data), *_shape(data), _ptr(indices),
+                                          indices.numel(), _ptr(out), axis))
     return out
 
 
@@ -695,10 +665,8 @@ def where(rt: RocmRuntime, x: torch.Tensor, y: torch.Tensor, cond: torch.Tensor,
     oshape = infer_broadcast(infer_broadcast(list(x.shape), list(y.shape)), list(cond.shape))
     if out is None:
         out = torch.empty(oshape, dtype=x.dtype, device=x.device)
-    check(lib().infini_rocm_where_ex(rt.handle, dtype_of(x), dtype_of(cond), _ptr(x), _ptr(y), _ptr(cond), _ptr(out),
-                                     len(oshape), _i64arr(oshape), _i64arr(broadcast_strides(list(x.shape), oshape)),
-                                     _i64arr(broadcast_strides(list(y.shape), oshape)),
-                                     _i64arr(broadcast_strides(list(cond.shape), oshape))))
+    check(lib().infini_rocm_where_shaped(rt.handle, dtype_of(x), dtype_of(cond), _ptr(x), *_shape(x), _ptr(y), *_shape(y), _ptr(cond),
+                                         *_shape(cond), _ptr(out), len(oshape), _i64arr(oshape)))
     return out
 
 
@@ -708,20 +676,9 @@ def concat(rt: RocmRuntime, xs: Sequence[torch.Tensor], axis: int, out: torch.Te
     oshape[axis] = sum(t.shape[axis] for t in xs)
     if out is None:
         out = torch.empty(oshape, dtype=xs[0].dtype, device=xs[0].device)
-    outer = math.prod(oshape[:axis])
-    inner_bytes = math.prod(oshape[axis + 1:]) * out.element_size()
-    dst_pitch = oshape[axis] * inner_bytes
-    # every input as one segment of ONE launch (infini_rocm_strided_copy_multi)
-    srcs, dsts, rbs, off = [], [], [], 0
-    for t in xs:
-        rb = t.shape[axis] * inner_bytes
-        srcs.append(t.data_ptr())
-        dsts.append(out.data_ptr() + off)
-        rbs.append(rb)
-        off += rb
-    n = len(xs)
-    check(lib().infini_rocm_strided_copy_multi(rt.handle, n, (C.c_void_p * n)(*srcs), (C.c_void_p * n)(*dsts), outer, _i64arr(rbs), _i64arr(rbs),
-                                               _i64arr([dst_pitch] * n)))
+    n = len(xs)  # every input as one segment of ONE launch (infini_rocm_concat_shaped -> infini_rocm_strided_copy_multi)
+    check(lib().infini_rocm_concat_shaped(rt.handle, out.element_size(), n, (C.c_void_p * n)(*[t.data_ptr() for t in xs]),
+                                          _i64arr([t.shape[axis] for t in xs]), _ptr(out), len(oshape), _i64arr(oshape), axis))
     return out
 
 
@@ -729,20 +686,14 @@ def split(rt: RocmRuntime, x: torch.Tensor, axis: int, sizes: Sequence[int]) -> 
     axis = _real_axis(axis, x.dim())
     if sum(sizes) != x.shape[axis]:
         raise ValueError("split sizes do not add up")
-    outer = math.prod(x.shape[:axis])
-    inner_bytes = math.prod(x.shape[axis + 1:]) * x.element_size()
-    src_pitch = x.shape[axis] * inner_bytes
-    outs, srcs, rbs, off = [], [], [], 0
+    outs = []
     for sz in sizes:
         shp = list(x.shape)
         shp[axis] = sz
         outs.append(torch.empty(shp, dtype=x.dtype, device=x.device))
-        srcs.append(x.data_ptr() + off)
-        rbs.append(sz * inner_bytes)
-        off += sz * inner_bytes
     n = len(outs)
-    check(lib().infini_rocm_strided_copy_multi(rt.handle, n, (C.c_void_p * n)(*srcs), (C.c_void_p * n)(*[o.data_ptr() for o in outs]), outer,
-                                               _i64arr(rbs), _i64arr([src_pitch] * n), _i64arr(rbs)))
+    check(lib().infini_rocm_split_shaped(rt.handle, x.element_size(), n, (C.c_void_p * n)(*[o.data_ptr() for o in outs]),
+                                         _i64arr(list(sizes)), _ptr(x), *_shape(x), axis))
     return outs
 
 
@@ -773,8 +724,7 @@ def pad(rt: RocmRuntime, x: torch.Tensor, pads: Sequence[int]) -> torch.Tensor:
         raise ValueError("pads must have 2*rank entries")
     oshape = [x.shape[d] + pads[d] + pads[d + rank] for d in range(rank)]
     out = torch.empty(oshape, dtype=x.dtype, device=x.device)
-    check(lib().infini_rocm_pad_slice(rt.handle, dtype_of(x), _ptr(x), _ptr(out), rank, _i64arr(list(x.shape)),
-                                      _i64arr(oshape), _i64arr([-p for p in pads[:rank]]), None, 0))
+    check(lib().infini_rocm_pad_shaped(rt.handle, dtype_of(x), _ptr(x), _ptr(out), rank, _i64arr(list(x.shape)), _i64arr(list(pads))))
     return out
 
 

@@ -78,22 +78,9 @@ template <typename T = void> static T *P(const Tensor &t) {
 }
 
 static std::vector<int64_t> dims64(const Shape &s) { return std::vector<int64_t>(s.begin(), s.end()); }
-// element strides of a dense tensor of `shape` viewed in `outShape` (0 where broadcast)
-static std::vector<int64_t> bcastStrides(const Shape &shape, const Shape &outShape) {
-    const int r = shape.size(), ro = outShape.size();
-    std::vector<int64_t> dense(r), out(ro, 0);
-    int64_t p = 1;
-    for (int i = r - 1; i >= 0; --i) {
-        dense[i] = p;
-        p *= shape[i];
-    }
-    for (int i = 0; i < ro; ++i) {
-        const int j = i - (ro - r);
-        if (j >= 0 && shape[j] != 1)
-            out[i] = dense[j];
-    }
-    return out;
-}
+// (Shape -> stride glue — broadcast strides, MatMul batch / bias strides, Concat / Split segments, Pad starts, Gather extents — lives
+// below the C ABI since round 5: the *_shaped entry points of include/infini_rocm.h, csrc/shaped.hip. infinitensor_amd/ops.py calls
+// the same functions, so the C-ABI tests and these kernels exercise ONE implementation.)
 static int64_t prod(const Shape &s, size_t from, size_t to) {
     int64_t p = 1;
     for (size_t i = from; i < to; ++i)
@@ -172,27 +159,14 @@ class MatmulRocm : public RocmTunableKernel {
         auto op = as<MatmulObj>(_op);
         const auto [b, m, n, k] = op->getBMNK();
         const auto A = op->getInputs(0), B = op->getInputs(1), C = op->getOutput();
-        // batch broadcast by zero stride when the operand is rank-2 or has batch 1 (matmul.cc:124-137)
-        const int64_t ba = prod(A->getDims(), 0, A->getRank() - 2), bb = prod(B->getDims(), 0, B->getRank() - 2);
-        IT_ASSERT((ba == 1 || ba == b) && (bb == 1 || bb == b), "unsupported partial batch broadcast");
-        const int64_t strideA = (ba == 1 && b > 1) ? 0 : (int64_t)m * k;
-        const int64_t strideB = (bb == 1 && b > 1) ? 0 : (int64_t)n * k;
+        // batch broadcast by zero stride when the operand is rank-2 or has batch 1 (matmul.cc:124-137), the bias broadcast to
+        // [.., m, n] (matmul.cc:86-118): infini_rocm_matmul_shaped derives both from the shapes
+        auto sa = dims64(A->getDims()), sb = dims64(B->getDims());
         const void *bias = nullptr;
-        int64_t bsb = 0, bsm = 0, bsn = 0;
-        if (op->numInputs() == 3) { // bias broadcast to [.., m, n] (matmul.cc:86-118)
-            auto bt = op->getInputs(2);
-            bias = P(bt);
-            auto st = bcastStrides(bt->getDims(), C->getDims());
-            const int ro = C->getRank();
-            bsm = st[ro - 2];
-            bsn = st[ro - 1];
-            bool lead = false;
-            for (int i = 0; i < ro - 2; ++i)
-                lead = lead || (st[i] != 0);
-            if (lead) {
-                IT_ASSERT(prod(bt->getDims(), 0, bt->getRank() - 2) == b, "unsupported partial bias batch broadcast");
-                bsb = (int64_t)bt->getDims()[bt->getRank() - 2] * bt->getDims()[bt->getRank() - 1];
-            }
+        std::vector<int64_t> sbias;
+        if (op->numInputs() == 3) {
+            bias = P(op->getInputs(2));
+            sbias = dims64(op->getInputs(2)->getDims());
         }
         // getComputeType() (matmul.cc:51-64; onnx.py:41-47 passes `matmul_compute_type`): "bf16" / "fp16" ask for reduced-precision
         // PRODUCTS of fp32 operands — honoured below (16-bit MFMA, fp32 sums and output); "default" and "tf32" multiply exactly
@@ -215,14 +189,14 @@ class MatmulRocm : public RocmTunableKernel {
         const bool mine = ov.matmul == _op.get();
         if (mine && ov.biasPtr) {
             IT_ASSERT(bias == nullptr, "a bias was folded into a MatMul that has its own");
-            bias = ov.biasPtr;
-            bsb = bsm = 0;
-            bsn = 1;
+            bias = ov.biasPtr; // one value per output column
+            sbias = {(int64_t)n};
         }
         const bool split = mine && ov.headDim > 0;
-        ROCM_CALL(infini_rocm_matmul_headsplit(H(ctx), DTI(A), P(A), P(B), bias, P(C), b, m, n, k, op->getTransA(),
-                                               op->getTransB(), strideA, strideB, bsb, bsm, bsn, mine ? ov.act : 0,
-                                               split ? ov.seq : 0, split ? ov.headDim : 0));
+        (void)b; (void)m; (void)k;
+        ROCM_CALL(infini_rocm_matmul_shaped(H(ctx), DTI(A), P(A), (int)sa.size(), sa.data(), P(B), (int)sb.size(), sb.data(), bias,
+                                            (int)sbias.size(), sbias.data(), P(C), op->getTransA(), op->getTransB(), mine ? ov.act : 0,
+                                            split ? ov.seq : 0, split ? ov.headDim : 0));
     }
 };
 REGISTER_KERNEL(Device::ROCM, OpType::MatMul, MatmulRocm, "Matmul_MFMA_ROCM");
@@ -343,11 +317,9 @@ template <int OP> class BinaryRocm : public RocmKernelWithoutConfig {
     void compute(const Operator &_op, const RuntimeObj *ctx) const override {
         auto op = as<ElementWiseObj>(_op);
         const auto A = op->getInputs(0), B = op->getInputs(1), C = op->getOutput();
-        IT_ASSERT(C->getRank() <= INFINI_ROCM_MAX_DIMS);
-        auto shape = dims64(C->getDims());
-        auto sa = bcastStrides(A->getDims(), C->getDims()), sb = bcastStrides(B->getDims(), C->getDims());
-        ROCM_CALL(infini_rocm_binary(H(ctx), OP, DTI(A), P(A), P(B), P(C), (int)shape.size(), shape.data(),
-                                     sa.data(), sb.data()));
+        auto sa = dims64(A->getDims()), sb = dims64(B->getDims()), sc = dims64(C->getDims());
+        ROCM_CALL(infini_rocm_binary_shaped(H(ctx), OP, DTI(A), P(A), (int)sa.size(), sa.data(), P(B), (int)sb.size(), sb.data(), P(C),
+                                            (int)sc.size(), sc.data()));
     }
 };
 #define REG_BIN(OPTYPE, CODE, NAME)                                                                \
@@ -508,9 +480,8 @@ REGISTER_KERNEL(Device::ROCM, OpType::Transpose, TransposeRocm, "Transpose_ROCM"
 class ExpandRocm : public RocmKernelWithoutConfig {
     void compute(const Operator &op, const RuntimeObj *ctx) const override {
         const auto in = op->getInputs(0), out = op->getOutput();
-        auto shape = dims64(out->getDims());
-        auto st = bcastStrides(in->getDims(), out->getDims());
-        ROCM_CALL(infini_rocm_expand(H(ctx), DTI(in), P(in), P(out), (int)shape.size(), shape.data(), st.data()));
+        auto si = dims64(in->getDims()), so = dims64(out->getDims());
+        ROCM_CALL(infini_rocm_expand_shaped(H(ctx), DTI(in), P(in), (int)si.size(), si.data(), P(out), (int)so.size(), so.data()));
     }
 };
 REGISTER_KERNEL(Device::ROCM, OpType::Expand, ExpandRocm, "Expand_ROCM");
@@ -519,10 +490,9 @@ class GatherRocm : public RocmKernelWithoutConfig {
     void compute(const Operator &_op, const RuntimeObj *ctx) const override {
         auto op = as<GatherObj>(_op);
         const auto in = op->getInputs(0), idx = op->getInputs(1);
-        const auto &d = in->getDims();
-        const int axis = op->getAxis();
-        ROCM_CALL(infini_rocm_gather(H(ctx), DTI(in), DTI(idx), P(in), P(idx), P(op->getOutput()), prod(d, 0, axis),
-                                     d[axis], idx->size(), prod(d, axis + 1, d.size())));
+        auto d = dims64(in->getDims());
+        ROCM_CALL(infini_rocm_gather_shaped(H(ctx), DTI(in), DTI(idx), P(in), (int)d.size(), d.data(), P(idx), (int64_t)idx->size(),
+                                            P(op->getOutput()), op->getAxis()));
     }
 };
 REGISTER_KERNEL(Device::ROCM, OpType::Gather, GatherRocm, "Gather_ROCM");
@@ -591,12 +561,10 @@ REGISTER_KERNEL(Device::ROCM, OpType::Resize, ResizeRocm, "Resize_ROCM");
 class WhereRocm : public RocmKernelWithoutConfig {
     void compute(const Operator &op, const RuntimeObj *ctx) const override {
         const auto x = op->getInputs(0), y = op->getInputs(1), c = op->getInputs(2), out = op->getOutput();
-        auto shape = dims64(out->getDims());
-        auto sx = bcastStrides(x->getDims(), out->getDims()), sy = bcastStrides(y->getDims(), out->getDims()),
-             sc = bcastStrides(c->getDims(), out->getDims());
+        auto sx = dims64(x->getDims()), sy = dims64(y->getDims()), sc = dims64(c->getDims()), so = dims64(out->getDims());
         // the condition is read in its own dtype: a 1-byte bool input, or the full-element 1/0 a comparison wrote
-        ROCM_CALL(infini_rocm_where_ex(H(ctx), DTI(x), DTI(c), P(x), P(y), P(c), P(out), (int)shape.size(),
-                                       shape.data(), sx.data(), sy.data(), sc.data()));
+        ROCM_CALL(infini_rocm_where_shaped(H(ctx), DTI(x), DTI(c), P(x), (int)sx.size(), sx.data(), P(y), (int)sy.size(), sy.data(), P(c),
+                                           (int)sc.size(), sc.data(), P(out), (int)so.size(), so.data()));
     }
 };
 REGISTER_KERNEL(Device::ROCM, OpType::Where, WhereRocm, "Where_ROCM");
@@ -605,25 +573,18 @@ class ConcatRocm : public RocmKernelWithoutConfig {
     void compute(const Operator &_op, const RuntimeObj *ctx) const override {
         auto op = as<ConcatObj>(_op);
         const auto out = op->getOutput();
-        const auto &od = out->getDims();
+        auto od = dims64(out->getDims());
         const int axis = op->getDim();
-        const int64_t outer = prod(od, 0, axis), innerBytes = prod(od, axis + 1, od.size()) * out->getDType().getSize();
-        const int64_t dstPitch = od[axis] * innerBytes;
-        char *dst = P<char>(out);
         // every input as one segment of ONE launch (empty inputs — the reference accepts them, test_cuda_concat.cc:160-190 — are skipped
         // by the library)
         std::vector<const void *> srcs;
-        std::vector<void *> dsts;
-        std::vector<int64_t> rbs, dps;
+        std::vector<int64_t> ext;
         for (const auto &in : op->getInputs()) {
-            const int64_t rb = in->size() == 0 ? 0 : in->getDims()[axis] * innerBytes;
-            srcs.push_back(rb ? P(in) : nullptr);
-            dsts.push_back(dst);
-            rbs.push_back(rb);
-            dps.push_back(dstPitch);
-            dst += rb;
+            srcs.push_back(in->size() == 0 ? nullptr : P(in));
+            ext.push_back(in->size() == 0 ? 0 : in->getDims()[axis]);
         }
-        ROCM_CALL(infini_rocm_strided_copy_multi(H(ctx), (int)srcs.size(), srcs.data(), dsts.data(), outer, rbs.data(), rbs.data(), dps.data()));
+        ROCM_CALL(infini_rocm_concat_shaped(H(ctx), (int)out->getDType().getSize(), (int)srcs.size(), srcs.data(), ext.data(), P(out),
+                                            (int)od.size(), od.data(), axis));
     }
 };
 REGISTER_KERNEL(Device::ROCM, OpType::Concat, ConcatRocm, "Concat_ROCM");
@@ -632,23 +593,16 @@ class SplitRocm : public RocmKernelWithoutConfig {
     void compute(const Operator &_op, const RuntimeObj *ctx) const override {
         auto op = as<SplitObj>(_op);
         const auto in = op->getInputs(0);
-        const auto &id = in->getDims();
+        auto id = dims64(in->getDims());
         const int axis = op->getDim();
-        const int64_t outer = prod(id, 0, axis), innerBytes = prod(id, axis + 1, id.size()) * in->getDType().getSize();
-        const int64_t srcPitch = id[axis] * innerBytes;
-        const char *src = P<char>(in);
-        std::vector<const void *> srcs;
         std::vector<void *> dsts;
-        std::vector<int64_t> rbs, sps;
+        std::vector<int64_t> ext;
         for (const auto &out : op->getOutputs()) { // every output as one segment of ONE launch
-            const int64_t rb = out->getDims()[axis] * innerBytes;
-            srcs.push_back(src);
             dsts.push_back(P(out));
-            rbs.push_back(rb);
-            sps.push_back(srcPitch);
-            src += rb;
+            ext.push_back(out->getDims()[axis]);
         }
-        ROCM_CALL(infini_rocm_strided_copy_multi(H(ctx), (int)srcs.size(), srcs.data(), dsts.data(), outer, rbs.data(), sps.data(), rbs.data()));
+        ROCM_CALL(infini_rocm_split_shaped(H(ctx), (int)in->getDType().getSize(), (int)dsts.size(), dsts.data(), ext.data(), P(in),
+                                           (int)id.size(), id.data(), axis));
     }
 };
 REGISTER_KERNEL(Device::ROCM, OpType::Split, SplitRocm, "Split_ROCM");
@@ -669,13 +623,11 @@ class PadRocm : public RocmKernelWithoutConfig {
     void compute(const Operator &_op, const RuntimeObj *ctx) const override {
         auto op = as<PadObj>(_op);
         const auto in = op->getInputs(0), out = op->getOutput();
-        auto ishape = dims64(in->getDims()), oshape = dims64(out->getDims());
-        auto pads = op->getPads(); // begin_0..begin_{r-1}, end_0..
-        std::vector<int64_t> starts(ishape.size());
-        for (size_t i = 0; i < ishape.size(); ++i)
-            starts[i] = -(int64_t)pads[i];
-        ROCM_CALL(infini_rocm_pad_slice(H(ctx), DTI(in), P(in), P(out), (int)ishape.size(), ishape.data(),
-                                        oshape.data(), starts.data(), nullptr, 0));
+        auto ishape = dims64(in->getDims());
+        auto pv = op->getPads(); // begin_0..begin_{r-1}, end_0..
+        std::vector<int64_t> pads(pv.begin(), pv.end());
+        IT_ASSERT(pads.size() == 2 * ishape.size());
+        ROCM_CALL(infini_rocm_pad_shaped(H(ctx), DTI(in), P(in), P(out), (int)ishape.size(), ishape.data(), pads.data()));
     }
 };
 REGISTER_KERNEL(Device::ROCM, OpType::Pad, PadRocm, "Pad_ROCM");

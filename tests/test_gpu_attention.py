@@ -146,6 +146,28 @@ def test_attention_kvcache_split_over_workgroups(rt, dt, tol, split, pos, ms, d,
     assert np.array_equal(host(kc), kc_w) and np.array_equal(host(vc), vc_w)  # appended in place, nothing else touched
 
 
+@pytest.mark.parametrize("two_launch", [False, True])
+def test_attention_kvcache_consecutive_steps_merge_in_the_last_workgroup(rt, two_launch, monkeypatch):
+    """Round 5: the workgroup that finishes a (batch, head)'s last chunk merges the partial results itself (a counter word per
+    (batch, head) in the runtime's flag block, zeroed again by that workgroup). Twelve consecutive decode steps on one cache — every
+    launch must find its counters at zero — against the oracle step by step; IROCM_KVCACHE_TWO_LAUNCH keeps the separate merge kernel
+    (the form for more (batch, head) pairs than counters)."""
+    if two_launch:
+        monkeypatch.setenv("IROCM_KVCACHE_TWO_LAUNCH", "1")
+    monkeypatch.setenv("IROCM_KVCACHE_SPLIT", "7")
+    rng = np.random.default_rng(11)
+    b, h, ms, d = 2, 5, 1024, 128
+    mk = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).to(torch.float16).cuda()  # noqa: E731
+    kc, vc = mk(b, h, ms, d), mk(b, h, ms, d)
+    kc_h, vc_h = host(kc), host(vc)
+    for pos in range(600, 612):
+        q, k, v = mk(b, h, 1, d), mk(b, h, 1, d), mk(b, h, 1, d)
+        y = ops.attention_kvcache(rt, kc, vc, q, k, v, torch.tensor([pos], dtype=torch.int32).cuda())
+        want, kc_h, vc_h = R.attention_kvcache(kc_h, vc_h, host(q), host(k), host(v), pos)
+        assert np.allclose(host(y), want, rtol=2e-3, atol=2e-3), (pos, np.abs(host(y) - want).max())
+    assert np.array_equal(host(kc), kc_h) and np.array_equal(host(vc), vc_h)
+
+
 def test_attention_kvcache_llama_decode_shape(rt):
     """B x H = 32, 4096 cached keys, D = 128, f16 (a batch-1 Llama-7B decode step): the heuristic split (no env) against the oracle."""
     rng = np.random.default_rng(3)

@@ -846,6 +846,8 @@ F32_CONV_CFGS = [
     (2, 128, 14, 14, 256, 1, 1, 0, 0, 1, 1, 1, 1),    # unit-stride pointwise: the batched-GEMM route
     (2, 64, 15, 15, 128, 1, 1, 0, 0, 2, 2, 1, 1),     # strided pointwise: implicit GEMM
     (6, 4, 40, 40, 20, 7, 7, 3, 3, 2, 2, 1, 1),       # 7 x 7 / 2 on 4 channels (K = 196)
+    (5, 3, 38, 38, 72, 7, 7, 3, 3, 2, 2, 1, 1),       # the stem's form: 3 channels, K = 147 -> weight rows copied into 148-float rows
+    (2, 5, 11, 13, 9, 3, 3, 1, 1, 1, 1, 1, 1),        # K = 45 (padded to 48), 9 filters
     (16, 64, 28, 28, 128, 3, 3, 1, 1, 1, 1, 1, 1),    # enough columns for the 128^2 tiles (98 x 1 tiles ... forced below the CU count: 64^2)
     (64, 64, 28, 28, 128, 3, 3, 1, 1, 1, 1, 1, 1),    # 128^2 tiles
     (4, 48, 12, 12, 80, 3, 3, 1, 1, 1, 1, 1, 1),      # 48 channels: the tap-major image pads every tap to 64 (zero weights, masked loads)
