@@ -178,62 +178,14 @@ template <int EPL> struct KvRow<__hip_bfloat16, EPL> {
     }
 };
 
-// The merge of one (batch, head): out = sum_g o_g w_g / sum_g l_g w_g with w_g = exp(m_g - max m). Called by >= D threads of one
-// workgroup (t = thread index; threads t >= D only take part in the barrier); s_w / s_l are LDS.
-template <typename T, int D>
-__device__ __forceinline__ void kvcache_merge(const float *__restrict__ part, T *__restrict__ out, int bh, int G, int t, float *s_w, float *s_l) {
-    const float *pp = part + (long)bh * G * (D + 2);
-    if (t < 64) {
-        const float mg = t < G ? pp[(long)t * (D + 2) + D] : -INFINITY;
-        const float lg = t < G ? pp[(long)t * (D + 2) + D + 1] : 0.f;
-        float mm = mg;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1)
-            mm = fmaxf(mm, __shfl_xor(mm, o));
-        const float wgt = mg == -INFINITY ? 0.f : expf(mg - mm);
-        float ll = lg * wgt;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1)
-            ll += __shfl_xor(ll, o);
-        s_w[t] = wgt;
-        if (t == 0)
-            *s_l = ll;
-    }
-    __syncthreads();
-    if (t >= D)
-        return;
-    float oo = 0.f;
-    int g = 0;
-    for (; g + 8 <= G; g += 8) {
-        float v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            v[i] = pp[(long)(g + i) * (D + 2) + t];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            oo = fmaf(v[i], s_w[g + i], oo);
-    }
-    for (; g < G; ++g)
-        oo = fmaf(pp[(long)g * (D + 2) + t], s_w[g], oo);
-    KvLd<T>::st(out + (long)bh * D + t, oo / *s_l);
-}
-
 // part: [bh][G][D + 2] floats = o[D] (relative to the chunk's own maximum m), m, l
-// done != nullptr: one counter word per (batch, head), zero between launches. The workgroup that finishes a (batch, head)'s LAST chunk
-// merges the G partial results itself (no second launch: the merge kernel and the gap in front of it were ~4 of the step's 19 us at
-// B x H = 32, 4096 keys). Its partials come from workgroups on other XCDs, whose L2s are not coherent with this one: every writer
-// releases at agent scope (__threadfence: its stores leave its L2) before the counter is bumped, the merging workgroup acquires at
-// agent scope (its L2 drops what it holds of those lines) after it saw the count. The last workgroup zeroes the counter again.
 template <typename T, typename P, int EPL, int KPI, int NG> // KPI = keys per 16-lane group and iteration, NG = 16-lane groups per workgroup
 __global__ __launch_bounds__(NG * 16) void attention_kvcache_split_kernel(T *__restrict__ kc, T *__restrict__ vc, const T *__restrict__ q,
                                                                       const T *__restrict__ kn, const T *__restrict__ vn,
                                                                       const P *__restrict__ pos, T *__restrict__ out,
-                                                                      float *__restrict__ part, int max_seq, int G, unsigned *__restrict__ done) {
+                                                                      float *__restrict__ part, int max_seq, int G) {
     constexpr int D = EPL * 16;
-    static_assert(NG * 16 >= D, "the merge uses one thread per output column");
     __shared__ float s_m[NG], s_l[NG], s_o[NG][D];
-    __shared__ float s_w[64], s_lsum;
-    __shared__ int s_last;
     const int bh = blockIdx.x, g = blockIdx.y;
     const int t = threadIdx.x, grp = t >> 4, sub = t & 15;
     const int n = (int)pos[0] + 1; // keys 0 .. n-1; key n-1 is the new one
@@ -348,38 +300,53 @@ __global__ __launch_bounds__(NG * 16) void attention_kvcache_split_kernel(T *__r
                 pp[D] = mm; // -inf for an empty chunk (n shorter than g chunks): the merge gives it weight 0
                 pp[D + 1] = ll;
             }
-            if (done)
-                __threadfence(); // release: this thread's part of the partial result is visible device-wide
         }
-    }
-    if (G > 1 && done) { // (uniform over the workgroup)
-        __syncthreads();
-        if (t == 0) {
-            const unsigned ticket = __hip_atomic_fetch_add(done + bh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = ticket == (unsigned)(G - 1);
-        }
-        __syncthreads();
-        if (!s_last)
-            return;
-        __threadfence(); // acquire: the other chunks' partial results as their writers released them
-        kvcache_merge<T, D>(part, out, bh, G, t, s_w, &s_lsum);
-        if (t == 0)
-            done[bh] = 0u; // (plain store: the next launch is the next reader)
     }
 }
 
 // G <= 64: wave 0 reads the G (m, l) pairs in ONE round trip (lane g), reduces them with shuffles and leaves the G weights in LDS;
 // every thread then sums its column over the chunks with the loads of eight chunks in flight. (The first version walked the chunks
 // in two dependent loops: two memory round trips per chunk, 5.4 us for G = 8 — a quarter of the whole decode step.)
-// Fallback of the split kernel's own last-workgroup merge (batch_heads beyond the counter block).
 template <typename T, typename P, int D>
 __global__ __launch_bounds__(D) void attention_kvcache_merge_kernel(const float *__restrict__ part, const P *__restrict__ pos, T *__restrict__ out,
                                                                       int max_seq, int G) {
     __shared__ float s_w[64], s_l;
+    const int bh = blockIdx.x, t = threadIdx.x;
     const int n = (int)pos[0] + 1;
     if (n < 1 || n > max_seq)
         return; // (as the split kernel: a position outside the cache writes nothing)
-    kvcache_merge<T, D>(part, out, (int)blockIdx.x, G, (int)threadIdx.x, s_w, &s_l);
+    const float *pp = part + (long)bh * G * (D + 2);
+    if (t < 64) {
+        const float mg = t < G ? pp[(long)t * (D + 2) + D] : -INFINITY;
+        const float lg = t < G ? pp[(long)t * (D + 2) + D + 1] : 0.f;
+        float mm = mg;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
+            mm = fmaxf(mm, __shfl_xor(mm, o));
+        const float wgt = mg == -INFINITY ? 0.f : expf(mg - mm);
+        float ll = lg * wgt;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
+            ll += __shfl_xor(ll, o);
+        s_w[t] = wgt;
+        if (t == 0)
+            s_l = ll;
+    }
+    __syncthreads();
+    float oo = 0.f;
+    int g = 0;
+    for (; g + 8 <= G; g += 8) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            v[i] = pp[(long)(g + i) * (D + 2) + t];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            oo = fmaf(v[i], s_w[g + i], oo);
+    }
+    for (; g < G; ++g)
+        oo = fmaf(pp[(long)g * (D + 2) + t], s_w[g], oo);
+    KvLd<T>::st(out + (long)bh * D + t, oo / s_l);
 }
 
 } // namespace irocm
@@ -409,10 +376,10 @@ extern "C" int infini_rocm_attention_kvcache(infiniRocmRuntime_t rt, int dtype, 
         const int vforce = atoi(force);
         G = vforce;
     }
-    // (512-thread workgroups — 32 key groups, 128 keys per iteration — were measured: 18.8 us at B x H = 32, 4096 keys with either size)
-    // the merge runs in the split kernel's last workgroup per (batch, head) when the runtime's counter block covers batch_heads
-    constexpr int kDoneBase = 16384; // (words 0 .. 16383 of sync_flags are the conv tap GEMM's split-K flags)
-    unsigned *done = (batch_heads <= 32768 - kDoneBase && !getenv("IROCM_KVCACHE_TWO_LAUNCH")) ? rt->sync_flags + kDoneBase : nullptr;
+    // (512-thread workgroups — 32 key groups, 128 keys per iteration — were measured: 18.8 us at B x H = 32, 4096 keys with either size.
+    // So was the merge inside the split kernel — the workgroup that bumps a per-(batch, head) counter to G merges, with agent-scope
+    // release / acquire fences around the counter because the partial results cross XCDs: 26.6 instead of 18.7 us at that shape, 34.5
+    // instead of 19.1 at B x H = 8, 8192 keys, D = 256 — every writer's release is an L2 write-back. Two launches it stays.)
     float *part = nullptr;
     if (vec_ok && G > 1) {
         void *ws = nullptr;
@@ -425,8 +392,8 @@ extern "C" int infini_rocm_attention_kvcache(infiniRocmRuntime_t rt, int dtype, 
     if (vec_ok && G >= 1) {                                                                                \
         hipLaunchKernelGGL((attention_kvcache_split_kernel<T, P, E, 4, 16>), dim3((unsigned)batch_heads, (unsigned)G), dim3(256), 0, \
                                rt->stream, (T *)k_cache, (T *)v_cache, (const T *)q, (const T *)k, (const T *)v, \
-                               (const P *)position_id, (T *)out, part, (int)max_seq, G, done);             \
-        if (G > 1 && !done)                                                                                \
+                               (const P *)position_id, (T *)out, part, (int)max_seq, G);                   \
+        if (G > 1)                                                                                         \
             hipLaunchKernelGGL((attention_kvcache_merge_kernel<T, P, E * 16>), dim3((unsigned)batch_heads), dim3(E * 16), 0, \
                                rt->stream, part, (const P *)position_id, (T *)out, (int)max_seq, G);        \
     } else                                                                                                 \

@@ -488,14 +488,17 @@ int infini_rocm_conv2d_res(infiniRocmRuntime_t rt, int dtype, const void *x, con
     IROCM_CHECK_ARG(x && w && y, "conv2d: NULL tensor");
 
     if (dtype == INFINI_DT_F32) {
-        // Round 5: fp32 convolutions on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32: exact products and sums at 157 TF/s).
-        // Unit-stride pointwise layers with 16-byte rows are batched GEMMs Y[n] = W[F x C] . X[n][C x HW] for the fp32 tile kernel
-        // (zero copy, like the 16-bit batched route); every other groups == 1 layer whose K = C R S is a multiple of 4 is the implicit
-        // GEMM of gemm32.hip. conv variant 1 keeps the one-output-per-thread kernel (A/B, tests); so do grouped layers, K % 4 != 0
-        // (a 3-channel stem) and unaligned operands.
+        // Round 5: fp32 convolutions on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32: exact products and sums at 157 TF/s): every
+        // groups == 1 layer is the implicit GEMM of gemm32.hip (columns run across images; K rows that are not a multiple of 4 floats —
+        // the 3-channel stem — are copied into padded rows). Unit-stride pointwise layers were first routed to the fp32 tile GEMM as
+        // one GEMM per image (zero copy, "batched_gemm32"): measured at batch 32 the implicit GEMM with 64 x 64 tiles is faster on every
+        // ResNet-50 layer but one (C64 -> 64 @ 56^2: 25.5 vs 69 us; C1024 -> 256 @ 14^2: 52.9 vs 101; C512 -> 256 @ 28^2: 82.6 vs 79.8) —
+        // per-image GEMMs leave 23 % of a 14^2 / 7^2 plane's tiles empty and launch few workgroups; IROCM_CONV32_PW_BATCHED keeps that
+        // route for A/B. conv variant 1 keeps the one-output-per-thread kernel (A/B, tests); so do grouped layers and unaligned operands.
         if (groups == 1 && rt->conv_variant != 1) {
             if (r == 1 && s == 1 && ph == 0 && pw == 0 && sh == 1 && sw == 1 && dh == 1 && dw == 1 && !residual && p.npix % 4 == 0 && c % 4 == 0 &&
-                ((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)y)) & 15) == 0 && (long)n * f * p.npix < (1l << 31)) {
+                ((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)y)) & 15) == 0 && (long)n * f * p.npix < (1l << 31) &&
+                getenv("IROCM_CONV32_PW_BATCHED")) {
                 rt->last_conv_route = "batched_gemm32";
                 return infini_rocm_matmul(rt, dtype, w, x, bias, y, n, f, p.npix, c, 0, 0, 0, (int64_t)c * p.npix, 0, bias ? 1 : 0, 0, act);
             }

@@ -230,6 +230,9 @@ int launch_conv_depthwise(infiniRocmRuntime_t rt, int dtype, const void *x, cons
     const long cols = (long)p.planes_out * p.runs;
     long strips = std::max<long>(1, std::min<long>(ceil_div(512 * 1024, cols), ceil_div(oh, 2 * r)));
     p.th = (int)ceil_div(oh, strips);
+    if (const char *e = getenv("IROCM_DW_TH")) // measurement hook (tools/dwconv_bench.py --th): output rows per thread
+        if (atoi(e) > 0)
+            p.th = atoi(e);
     p.th = (int)ceil_div(p.th, r) * r; // (the row loop is unrolled R times)
     p.strips = (int)ceil_div(oh, p.th);
     p.items = cols * p.strips;

@@ -48,6 +48,7 @@ struct StemArgs {
     unsigned short *y;         // [n][64][ph][pw]
     int n, h, w, oh, ow, ph, pw;
     int tiles_r, tiles_c;      // pooled row / column tiles per image
+    int xcd_runs;              // 1: each XCD takes a contiguous run of tiles per step (see the tile loop)
 };
 
 // FCRS [64][3][7][7] -> fragment order. Element e of lane (g4, l15) of fragment (ks, mt): filter mt * 16 + l15,
@@ -123,10 +124,16 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pool_kernel(StemArgs p) {
                 pre[j] = *(const s16x8_t *)(X + ((long)c * p.h + iy) * p.w + ix);
         }
     };
-    if ((int)blockIdx.x < ntiles)
-        fetch(blockIdx.x);
+    // Tile order (round 5): workgroup b runs on XCD b % 8. With tile = b + step * grid, vertically adjacent tiles of an image (t and
+    // t + tiles_c) sat on DIFFERENT XCDs: the 7 input rows two row tiles share were fetched from HBM once per XCD (FETCH 99 MB for a
+    // 38.5 MB input) and the 128-byte lines of the pooled output that straddle two tiles (rows of 112 bytes) were written partially by
+    // two L2s (WRITE 71.7 MB for 51.4 MB). Each XCD now takes a CONTIGUOUS run of grid / 8 tiles per step (a little more than one
+    // image): halos and shared lines meet in one L2.
+    const int first = (p.xcd_runs && (gridDim.x & 7) == 0) ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (first < ntiles)
+        fetch(first);
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int tile = first; tile < ntiles; tile += gridDim.x) {
         int img, p0, c0;
         decode(tile, img, p0, c0);
         const int y0 = 2 * p0 - 1, x0 = 2 * c0 - 1;      // first conv row / column of the tile
@@ -307,6 +314,7 @@ extern "C" int infini_rocm_conv2d_pool(infiniRocmRuntime_t rt, int dtype, const 
     p.y = (unsigned short *)y;
     const long tiles = (long)n * p.tiles_r * p.tiles_c;
     const unsigned grid = (unsigned)std::min<long>(tiles, (long)rt->num_cu * 2); // persistent: two workgroups per CU
+    p.xcd_runs = getenv("IROCM_STEM_LINEAR") ? 0 : 1; // (measurement hook: the round-4 tile order)
     if (dtype == INFINI_DT_F16) {
         IROCM_LDS_ATTR(conv_stem_pool_kernel<F16Traits>, kStemLds, rt);
         hipLaunchKernelGGL(conv_stem_pool_kernel<F16Traits>, dim3(grid), dim3(256), kStemLds, rt->stream, p);

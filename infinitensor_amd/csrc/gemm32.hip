@@ -295,13 +295,15 @@ template <int T, bool TM> __global__ __launch_bounds__(256, 2) void conv_igemm32
     const int hw = p.h * p.wd;
     const unsigned lds_col = (unsigned)((ncol & 3) * 4); // byte inside the 16-byte chunk; chunk index depends on the k-row
 
-    float stage_v[NE];
+    float sv_a[NE], sv_b[NE]; // two register stages of gathered elements (see step below)
     // tap-major state of the K-tile being gathered: tap (tr, ts), channel block c0; per thread: base offset and validity of that tap
     int g_tr = 0, g_ts = 0, g_c0 = 0, g_base = 0;
     bool g_ok = false;
     auto tap_setup = [&]() __attribute__((always_inline)) {
         const int dy = g_tr * p.dh, dx = g_ts * p.dw;
-        g_ok = qlive && g_tr < p.r && (unsigned)(iy0 + dy) < (unsigned)p.h && (unsigned)(ix0 + dx) < (unsigned)p.wd;
+        // (bitwise &: with && hipcc built a divergent branch around the second pair of compares — a block boundary in the middle of the
+        // K loop, behind which its wait insertion no longer counts the requests in flight)
+        g_ok = qlive & (g_tr < p.r) & ((unsigned)(iy0 + dy) < (unsigned)p.h) & ((unsigned)(ix0 + dx) < (unsigned)p.wd);
         g_base = pix_base + dy * p.wd + dx + (g_c0 + kr0) * hw;
     };
     auto tap_advance = [&]() __attribute__((always_inline)) { // the next K-tile: 32 more channels, then the next tap
@@ -314,7 +316,7 @@ template <int T, bool TM> __global__ __launch_bounds__(256, 2) void conv_igemm32
     };
     auto gather_one = [&](int k0, int i) __attribute__((always_inline)) { // requests element i of K-tile k0 .. k0 + 31 of this column
         if constexpr (TM) {
-            const bool ok = g_ok && g_c0 + kr0 + i * KR_STEP < p.c;
+            const bool ok = g_ok & (g_c0 + kr0 + i * KR_STEP < p.c);
             return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, ok ? (g_base + i * (KR_STEP * hw)) * 4 : (int)0x7ffffff0, 0, 0));
         } else {
             const int k = k0 + kr0 + i * KR_STEP; // wave-uniform
@@ -322,22 +324,28 @@ template <int T, bool TM> __global__ __launch_bounds__(256, 2) void conv_igemm32
             udivmod_m((unsigned)k, (unsigned)(p.r * p.s), p.rs_m, cc, rs);
             udivmod_m(rs, (unsigned)p.s, p.s_m, rr, ss);
             const int dy = (int)rr * p.dh, dx = (int)ss * p.dw;
-            const bool ok = qlive && k < p.kreal && (unsigned)(iy0 + dy) < (unsigned)p.h && (unsigned)(ix0 + dx) < (unsigned)p.wd;
+            const bool ok = qlive & (k < p.kreal) & ((unsigned)(iy0 + dy) < (unsigned)p.h) & ((unsigned)(ix0 + dx) < (unsigned)p.wd);
             const int off = pix_base + (int)cc * hw + dy * p.wd + dx;
             return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, ok ? off * 4 : (int)0x7ffffff0, 0, 0));
         }
     };
-    auto gather = [&](int k0) __attribute__((always_inline)) {
+    auto gather = [&](float (&dst)[NE], int k0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NE; ++i)
-            stage_v[i] = gather_one(k0, i);
+            dst[i] = gather_one(k0, i);
     };
-    auto scatter = [&](int buf) __attribute__((always_inline)) { // writes them into the N-major image gemm_fast32's fragments read
+    // into the N-major image gemm_fast32's fragments read. Written as inline-asm ds_writes: hipcc orders every LDS access it can see
+    // behind the LDS-DMA in flight (it cannot tell that the DMA fills the OTHER operand's tile) — with plain stores the second step
+    // of the loop body waited vmcnt(0) here, i.e. for the elements requested a moment ago. What the asm leaves to the compiler is the
+    // register dependency on the loads of `src`, which it counts exactly; completion (lgkmcnt) is the next step's barrier wait.
+    const unsigned b_lds0 = (unsigned)(unsigned long)IROCM_LDS_PTR(smem) + 2 * TILE_BYTES;
+    auto scatter = [&](int buf, const float (&src)[NE]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
             const int kr = kr0 + i * KR_STEP;
             const unsigned chunk = (unsigned)(ncol >> 2) ^ ((unsigned)((kr >> 2) & 1) << 3);
-            *(float *)(b_tile(buf) + kr * (256 * T) + chunk * 16 + lds_col) = stage_v[i];
+            const unsigned addr = b_lds0 + (unsigned)buf * TILE_BYTES + (unsigned)kr * (256 * T) + chunk * 16 + lds_col;
+            asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(src[i]) : "memory");
         }
     };
 
@@ -352,27 +360,38 @@ template <int T, bool TM> __global__ __launch_bounds__(256, 2) void conv_igemm32
 
     const float *Z = (const float *)p.zeros;
     const int nk = (p.k + BK - 1) / BK;
-    // prologue: tile 0's weights by LDS-DMA, its gathered column through registers
+    // Pipeline (second version, round 5): the gathered elements pass through TWO register stages. Step kt multiplies tile kt out of
+    // LDS buffer kt % 2, REQUESTS the elements of tile kt + 2 between its MFMAs and, behind them, writes tile kt + 1 — requested a whole
+    // step earlier — into the other buffer. (The first version requested tile kt + 1 in step kt and wrote it at the end of the same
+    // step: `s_waitcnt vmcnt(0)` right behind the last request, one full memory round trip exposed per K-tile; MFMA busy 0.37.)
+    // Waits at the top of a step are counted: in issue order the outstanding requests are [weights of tile kt] [NE elements of tile
+    // kt + 1], so vmcnt(NE) is "the weights have landed" (hipcc's __syncthreads would drain everything).
+    // prologue: tile 0's weights by LDS-DMA, its gathered column through registers; tile 1's elements requested
     stage_kmajor<T>(p.w, p.k, m0, p.f, 0, a_tile(0), w, lane, p.k, Z);
     if constexpr (TM)
         tap_setup();
-    gather(0);
-    scatter(0); // (hipcc waits for the loads here)
-    auto step = [&](auto bufc, int kt) {
+    gather(sv_a, 0);
+    scatter(0, sv_a); // (hipcc waits for the loads here)
+    if constexpr (TM) {
+        tap_advance();
+        tap_setup();
+    }
+    gather(sv_b, BK); // (past the last tile: every element out of range — zeros, never multiplied)
+    auto step = [&](auto bufc, int kt, float (&cur)[NE], float (&nxt)[NE]) __attribute__((always_inline)) {
         constexpr int buf = decltype(bufc)::value;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // tile kt's weights have landed (and nothing else is in flight)
-        __syncthreads();                                  // ... and every thread's column of tile kt is in LDS
+        // tile kt's weights have landed; every thread's column of tile kt is in LDS (its ds_writes drained) — then the barrier
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NE) : "memory");
         // (unconditional — past the last tile the weights come from the zero block and every gathered element is out of range — so
         // that the gather sits in the SAME basic block as the MFMAs and can be scheduled between them)
         stage_kmajor<T>(p.w, p.k, m0, p.f, (kt + 1) * BK, a_tile(buf ^ 1), w, lane, p.k, Z);
         if constexpr (TM) {
-            tap_advance();
+            tap_advance(); // -> tile kt + 2
             tap_setup();
         }
         const char *at = a_tile(buf), *bt = b_tile(buf);
-        // The next tile's gather rides BETWEEN this tile's MFMAs, one element (two multiply-high decodes, the bounds tests, one load: ~25
-        // instructions) behind every MFMA group: a 64-cycle fp32 MFMA leaves ~12 vector-ALU issue slots before the next one can start,
-        // but only instructions that sit between two MFMAs in program order can use them. Left alone hipcc issues the whole gather first
+        // The gather rides BETWEEN this tile's MFMAs, one element (the bounds tests, one load: ~25 instructions in the k-major form)
+        // behind every MFMA group: a 64-cycle fp32 MFMA leaves ~12 vector-ALU issue slots before the next one can start, but only
+        // instructions that sit between two MFMAs in program order can use them. Left alone hipcc issues the whole gather first
         // (~2 k cycles in front of 4 k cycles of MFMAs: 0.18-0.35 of the fp32 peak at batch 32), and sched_group_barrier did not move it;
         // the order is pinned with scheduling fences instead.
         constexpr int PER = (16 * T * T) / NE; // MFMAs per gathered element: 4
@@ -395,17 +414,21 @@ template <int T, bool TM> __global__ __launch_bounds__(256, 2) void conv_igemm32
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][s], af[i][s], acc[i][j], 0, 0, 0);
                         if (++mi % PER == 0) {
                             __builtin_amdgcn_sched_barrier(0);
-                            stage_v[mi / PER - 1] = gather_one((kt + 1) * BK, mi / PER - 1);
+                            nxt[mi / PER - 1] = gather_one((kt + 2) * BK, mi / PER - 1);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
         }
-        scatter(buf ^ 1); // (buffer buf ^ 1 was last read in step kt - 1, behind this step's barrier)
+        scatter(buf ^ 1, cur); // tile kt + 1, requested one step ago (buffer buf ^ 1 was last read in step kt - 1, behind this step's barrier)
     };
+    // Steps come in pairs, unconditionally: with an odd tile count the last step multiplies a tile of zero weights by out-of-range
+    // (zero) elements. (An exit between the two made hipcc rotate the loop around the second step.) What the ISA shows: hipcc does not
+    // count requests across the LDS-DMA — it puts vmcnt(0) in front of the FIRST step's LDS writes (behind that step's own requests)
+    // and, everything having landed, nothing in front of the second step's: one exposed round trip per two K-tiles instead of one per
+    // K-tile. (Four steps per iteration gave vmcnt(0) in front of the first and third write blocks — the same ratio at 208 VGPRs.)
     for (int kt = 0; kt < nk; kt += 2) {
-        step(std::integral_constant<int, 0>{}, kt);
-        if (kt + 1 < nk)
-            step(std::integral_constant<int, 1>{}, kt + 1);
+        step(std::integral_constant<int, 0>{}, kt, sv_b, sv_a);
+        step(std::integral_constant<int, 1>{}, kt + 1, sv_a, sv_b);
     }
 
     // epilogue: lane l holds filter m = l % 32 and, per g, four consecutive columns q
@@ -580,8 +603,13 @@ int launch_conv_igemm32(infiniRocmRuntime_t rt, const void *x, const void *w, co
     p.rs_m = udiv_magic((unsigned long long)r * s);
     p.s_m = udiv_magic((unsigned long long)s);
     p.zeros = rt->zeros;
-    // 128^2 tiles when they give at least ~half a tile per CU, 64^2 tiles otherwise (F <= 64 would leave half of a 128-row tile empty)
-    const bool small = f <= 64 || ceil_div(f, 128) * ceil_div(ncols, 128) * 2 < rt->num_cu;
+    // Tile size, measured on ResNet-50's layers at batch 32 (tools/conv32_bench.py --forms, us with 64^2 / 128^2 tiles): C128 28^2 3 x 3
+    // 97.9 / 115.6; C128 56^2 3 x 3 / 2 99.0 / 127.7; C256 56^2 -> 128 1 x 1 (784 tiles of 128^2 = 3 per CU) 82.7 / 118.7; C256 14^2 3 x 3
+    // 109 / 217: the 64^2 tiles (83 registers, 32 KB of LDS: five workgroups per CU hide the gather's latency) win everywhere there, so
+    // the 128^2 form (182 registers, two workgroups per CU) is kept for problems with at least eight of its tiles per CU only.
+    bool small = f <= 64 || ceil_div(f, 128) * ceil_div(ncols, 128) < 8 * (int64_t)rt->num_cu;
+    if (const char *e = getenv("IROCM_CONV32_TILE")) // measurement hook (tools/conv32_bench.py --forms): 1 = 64^2 tiles, 2 = 128^2
+        small = atoi(e) == 1 ? true : (atoi(e) == 2 ? false : small);
     const int bm = small ? 64 : 128;
     p.tiles_m = (int)ceil_div(f, bm);
     p.tiles_n = (int)ceil_div(ncols, bm);

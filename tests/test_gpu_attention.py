@@ -146,14 +146,9 @@ def test_attention_kvcache_split_over_workgroups(rt, dt, tol, split, pos, ms, d,
     assert np.array_equal(host(kc), kc_w) and np.array_equal(host(vc), vc_w)  # appended in place, nothing else touched
 
 
-@pytest.mark.parametrize("two_launch", [False, True])
-def test_attention_kvcache_consecutive_steps_merge_in_the_last_workgroup(rt, two_launch, monkeypatch):
-    """Round 5: the workgroup that finishes a (batch, head)'s last chunk merges the partial results itself (a counter word per
-    (batch, head) in the runtime's flag block, zeroed again by that workgroup). Twelve consecutive decode steps on one cache — every
-    launch must find its counters at zero — against the oracle step by step; IROCM_KVCACHE_TWO_LAUNCH keeps the separate merge kernel
-    (the form for more (batch, head) pairs than counters)."""
-    if two_launch:
-        monkeypatch.setenv("IROCM_KVCACHE_TWO_LAUNCH", "1")
+def test_attention_kvcache_consecutive_decode_steps(rt, monkeypatch):
+    """Twelve consecutive decode steps on one cache with the split forced to 7 chunks (partial results and merge of every step reuse
+    the same workspace) against the oracle step by step."""
     monkeypatch.setenv("IROCM_KVCACHE_SPLIT", "7")
     rng = np.random.default_rng(11)
     b, h, ms, d = 2, 5, 1024, 128

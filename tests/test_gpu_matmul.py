@@ -273,11 +273,15 @@ def test_matmul_headline_shape_sampled_rows(rt):
 def test_matmul_rejects_bad_arguments(rt):
     a = torch.zeros(4, 5, device="cuda")
     b = torch.zeros(6, 3, device="cuda")
-    with pytest.raises(ValueError):
+    from infinitensor_amd import InfiniRocmError, lib
+    # (since round 5 the shape glue lives below the ABI — infini_rocm_matmul_plan — and its errors are the library's: a RuntimeError
+    # like the reference's infini::Exception)
+    with pytest.raises(InfiniRocmError, match="K of A is 5, K of B is 6"):
         ops.matmul(rt, a, b)  # K mismatch: reference IT_ASSERT(kA == kB)
+    with pytest.raises(InfiniRocmError, match="batch"):
+        ops.matmul(rt, torch.zeros(2, 1, 4, 5, device="cuda"), torch.zeros(1, 3, 5, 6, device="cuda"))  # partial batch broadcast
     with pytest.raises(TypeError):
         ops.matmul(rt, a.to(torch.complex64), torch.zeros(5, 3, device="cuda", dtype=torch.complex64))
-    from infinitensor_amd import InfiniRocmError, lib
     import ctypes
     with pytest.raises(InfiniRocmError):  # the C ABI itself rejects an unsupported dtype, loudly
         from infinitensor_amd._lib import check

@@ -843,7 +843,7 @@ F32_CONV_CFGS = [
     (3, 64, 7, 7, 160, 3, 3, 1, 1, 1, 1, 1, 1),       # 49-pixel planes: element stores, ragged filters
     (2, 32, 28, 28, 64, 3, 3, 1, 1, 2, 2, 1, 1),      # stride 2
     (1, 8, 33, 17, 24, 5, 3, 2, 0, 1, 2, 1, 2),       # asymmetric everything, dilation
-    (2, 128, 14, 14, 256, 1, 1, 0, 0, 1, 1, 1, 1),    # unit-stride pointwise: the batched-GEMM route
+    (2, 128, 14, 14, 256, 1, 1, 0, 0, 1, 1, 1, 1),    # unit-stride pointwise (columns across images: 392 = 6 tiles + 8)
     (2, 64, 15, 15, 128, 1, 1, 0, 0, 2, 2, 1, 1),     # strided pointwise: implicit GEMM
     (6, 4, 40, 40, 20, 7, 7, 3, 3, 2, 2, 1, 1),       # 7 x 7 / 2 on 4 channels (K = 196)
     (5, 3, 38, 38, 72, 7, 7, 3, 3, 2, 2, 1, 1),       # the stem's form: 3 channels, K = 147 -> weight rows copied into 148-float rows
@@ -855,30 +855,42 @@ F32_CONV_CFGS = [
 ]
 
 
-@pytest.mark.parametrize("mode", ["plain", "bias_res_relu"])
+def test_conv_fp32_pointwise_as_one_gemm_per_image(rt, monkeypatch):
+    """The A/B route of unit-stride pointwise fp32 layers (IROCM_CONV32_PW_BATCHED: Y[n] = W . X[n] on the fp32 tile GEMM, zero copy)."""
+    monkeypatch.setenv("IROCM_CONV32_PW_BATCHED", "1")
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((3, 64, 14, 14)).astype(np.float32)
+    wt = (rng.standard_normal((96, 64, 1, 1)) / 8).astype(np.float32)
+    b = rng.standard_normal((96,)).astype(np.float32)
+    y = ops.conv2d(rt, dev(x, torch.float32), dev(wt, torch.float32), 0, 0, 1, 1, 1, 1, bias=dev(b, torch.float32), act=1)
+    assert ops.conv_last_route(rt) == "batched_gemm32"
+    want = np.maximum(R.conv2d(x, wt, 0, 0, 1, 1, 1, 1) + b[None, :, None, None], 0)
+    assert np.allclose(host(y), want, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("mode", ["plain", "bias_res_relu", "bias_res_relu_t128"])
 @pytest.mark.parametrize("cfg", F32_CONV_CFGS)
-def test_conv_fp32_on_the_matrix_cores(rt, cfg, mode):
+def test_conv_fp32_on_the_matrix_cores(rt, cfg, mode, monkeypatch):
     """Round 5: fp32 Conv2d (the dtype of north_star's 1e-4 gate and of the intelcpu baseline; reference: cuDNN implicit GEMM,
-    src/kernels/cuda/conv.cc:57-168) as an implicit GEMM on v_mfma_f32_32x32x2_f32 (route "igemm32"; unit-stride pointwise layers with
-    16-byte rows: "batched_gemm32") against the oracle within 1e-4 RELATIVE of the output's scale per element (2e-5 absolute below 1)
-    and against the one-output-per-thread kernel it replaces (conv variant 1, route "direct32")."""
+    src/kernels/cuda/conv.cc:57-168) as an implicit GEMM on v_mfma_f32_32x32x2_f32 (route "igemm32", pointwise layers included) against the oracle within 1e-4 RELATIVE of the output's scale per element (2e-5 absolute below 1)
+    and against the one-output-per-thread kernel it replaces (conv variant 1, route "direct32"). "_t128" forces the 128 x 128 tile
+    form (IROCM_CONV32_TILE; the launcher picks it from eight such tiles per CU on — sizes the dense oracle cannot follow)."""
     n, c, h, w, f, r, s, ph, pw, sh, sw, dh, dw = cfg
+    if mode.endswith("_t128"):
+        monkeypatch.setenv("IROCM_CONV32_TILE", "2")
     rng = np.random.default_rng(abs(hash(cfg)) % 2 ** 32)
     x = rng.standard_normal((n, c, h, w)).astype(np.float32)
     wt = (rng.standard_normal((f, c, r, s)) / np.sqrt(c * r * s)).astype(np.float32)
     oh, ow = (h - (r - sh) * dh + 2 * ph) // sh, (w - (s - sw) * dw + 2 * pw) // sw
     b = rng.standard_normal((f,)).astype(np.float32) if "bias" in mode else None
     res = rng.standard_normal((n, f, oh, ow)).astype(np.float32) if "res" in mode else None
-    pointwise_s1 = r == 1 and s == 1 and sh == 1 and sw == 1
-    if pointwise_s1:
-        res = None  # (the batched-GEMM route has no residual operand; with one the layer takes the implicit GEMM — covered by the others)
     act = 1 if "relu" in mode else 0
     xd, wd = dev(x, torch.float32), dev(wt, torch.float32)
     bd = dev(b, torch.float32) if b is not None else None
     rd = dev(res, torch.float32) if res is not None else None
     guard = torch.full((n, f, oh, ow), 7.0, device="cuda", dtype=torch.float32)
     y = ops.conv2d(rt, xd, wd, ph, pw, sh, sw, dh, dw, bias=bd, act=act, residual=rd, out=guard)
-    assert ops.conv_last_route(rt) == ("batched_gemm32" if pointwise_s1 else "igemm32")
+    assert ops.conv_last_route(rt) == "igemm32"
     try:
         ops.set_conv_variant(rt, 1)
         y1 = ops.conv2d(rt, xd, wd, ph, pw, sh, sw, dh, dw, bias=bd, act=act, residual=rd)

@@ -2,6 +2,7 @@
 the model as validated): algorithmic bytes = input + output once; generic implicit GEMM (variant 1) beside the depthwise kernel.
   python tools/dwconv_bench.py [--batch 32] [--dtype f16]"""
 import argparse
+import os
 import sys
 from pathlib import Path
 
@@ -20,6 +21,8 @@ ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--dtype", default="f16")
 ap.add_argument("--generic", action="store_true", help="also time the generic implicit GEMM (slow)")
 ap.add_argument("--layers", default="", help="comma-separated indices into the layer table (default: all)")
+ap.add_argument("--th-mults", default="", help="comma-separated multiples of the kernel height: also time the depthwise kernel with that "
+                "many output rows per thread (IROCM_DW_TH), e.g. 1,2,3,4")
 a = ap.parse_args()
 dt = {"f16": torch.float16, "bf16": torch.bfloat16}[a.dtype]
 rt = RocmRuntime(0)
@@ -34,7 +37,12 @@ for c, h, k, st in ([LAYERS[int(i)] for i in a.layers.split(",")] if a.layers el
     torch.cuda.synchronize()
     nbytes = 2.0 * a.batch * c * (h * h + oh * oh)
     line = f"C{c:<5d} {h:>3d}x{h:<3d} {k}x{k}/s{st} {nbytes / 1e6:7.1f} MB |"
-    for name, var in (("dw", -1),) + ((("generic", 1),) if a.generic else ()):
+    forms = (("dw", -1, 0),) + tuple((f"th{int(m) * k}", -1, int(m) * k) for m in a.th_mults.split(",") if m) + ((("generic", 1, 0),) if a.generic else ())
+    for name, var, th in forms:
+        if th:
+            os.environ["IROCM_DW_TH"] = str(th)
+        else:
+            os.environ.pop("IROCM_DW_TH", None)
         ops.set_conv_variant(rt, var)
         for _ in range(3):
             ops.conv2d(rt, x, w, pad, pad, st, st, bias=b, act=1, out=y)
@@ -55,6 +63,9 @@ for c, h, k, st in ([LAYERS[int(i)] for i in a.layers.split(",")] if a.layers el
         if name == "dw":
             tot["dw"] += us
             tot["floor"] += nbytes / 8e12 * 1e6
+        if th:
+            line += f" {name} {us:6.1f} |"
+            continue
         line += f" {name} [{ops.conv_last_route(rt)}] {us:8.1f} us {nbytes / us / 1e3:7.0f} GB/s {nbytes / us / 1e3 / 8000:.3f} of 8 TB/s |"
     print(line, flush=True)
 ops.set_conv_variant(rt, -1)
