@@ -246,6 +246,13 @@ def extras(rt, ops, Event) -> dict:
         out[f"matmul_4096_{name}"] = {"TFLOP/s": round(2.0 * n ** 3 / t / 1e12, 1), "frac_mfma_peak": round(2.0 * n ** 3 / t / 1e12 / PEAK_BF16_TFLOPS, 4), "us": round(t * 1e6, 2)}
     del a, b, c
     torch.cuda.empty_cache()
+    # round-5 kernels outside the three BASELINE graphs: the decode-attention step, a depthwise layer, an fp32 3 x 3 layer — timed as
+    # hipGraph replays (a ctypes call costs as much as the shorter ones)
+    try:
+        out["round5_kernels"] = round5_kernels(rt, ops, Event)
+    except Exception as e:  # noqa: BLE001
+        out["round5_kernels"] = {"error": repr(e)[:200]}
+    torch.cuda.empty_cache()
     # every other memory-bound operator of the three graphs at its config shape and at an HBM-sized shape (round-3 verdict #4):
     # RoPE, RMSNorm, Gather, Transpose, broadcast Add, Relu, Gelu, MaxPool, ReduceMean, Where, Concat / Split, Cast, Silu x Mul
     try:
@@ -592,6 +599,68 @@ def tp_block(rt, ops, Event, world: int, rank: int, dist_mod) -> dict:
     }
 
 
+def round5_kernels(rt, ops, Event) -> dict:
+    """AttentionKVCache decode step (B x H = 32, 4096 cached keys, D = 128, f16: a batch-1 Llama-7B step; algorithmic bytes = K and V
+    once), one depthwise layer of EfficientNet-Lite4 (C144 150 x 150 3 x 3 / 2 at batch 32 f16; input + output once) and one fp32
+    3 x 3 layer of ResNet-50 at batch 32 (C128 28 x 28; against the 157 TF/s fp32 MFMA peak)."""
+    import torch
+
+    def graph_us(launch, iters):
+        for i in range(3):
+            launch(i)
+        rt.sync()
+        rt.begin_capture()
+        for i in range(iters):
+            launch(i)
+        g = rt.end_capture()
+        rt.launch_graph(g)
+        e0, e1 = Event(), Event()
+        rt.record(e0)
+        rt.launch_graph(g)
+        rt.record(e1)
+        rt.sync()
+        return rt.elapsed_ms(e0, e1) / iters * 1e3
+
+    out = {}
+    bh, n, d = 32, 4096, 128
+    sets = 8  # rotated: one set (67 MB) would sit in the 256 MiB Infinity Cache
+    kc = [torch.randn(1, bh, n, d, device="cuda").half() for _ in range(sets)]
+    vc = [torch.randn(1, bh, n, d, device="cuda").half() for _ in range(sets)]
+    q, k, v = (torch.randn(1, bh, 1, d, device="cuda").half() for _ in range(3))
+    pos = torch.tensor([n - 1], dtype=torch.int32, device="cuda")
+    o = torch.empty_like(q)
+    torch.cuda.synchronize()
+    us = graph_us(lambda i: ops.attention_kvcache(rt, kc[i % sets], vc[i % sets], q, k, v, pos, out=o), 40)
+    nbytes = 2.0 * bh * n * d * 2
+    out["decode_attention_bh32_n4096_d128_f16"] = {"us": round(us, 2), "frac_hbm_peak": round(nbytes / us / 1e3 / PEAK_HBM_GBS, 4)}
+    del kc, vc
+    c, h = 144, 150
+    x = torch.randn(32, c, h, h, device="cuda").half()
+    w = (torch.randn(c, 1, 3, 3, device="cuda") / 3).half()
+    b = torch.randn(c, device="cuda").half()
+    y = torch.empty(32, c, 75, 75, device="cuda", dtype=torch.float16)
+    torch.cuda.synchronize()
+    us = graph_us(lambda i: ops.conv2d(rt, x, w, 1, 1, 2, 2, bias=b, act=1, out=y), 20)
+    nbytes = 2.0 * 32 * c * (h * h + 75 * 75)
+    out["depthwise_c144_150x150_3x3_s2_bs32_f16"] = {"us": round(us, 2), "frac_hbm_peak": round(nbytes / us / 1e3 / PEAK_HBM_GBS, 4),
+                                                     "route": ops.conv_last_route(rt)}
+    del x, w, b, y
+    x = torch.randn(32, 128, 28, 28, device="cuda")
+    w = torch.randn(128, 128, 3, 3, device="cuda") / 34.0
+    b = torch.randn(128, device="cuda")
+    y = torch.empty(32, 128, 28, 28, device="cuda")
+    torch.cuda.synchronize()
+    ops.set_conv_const_weights(rt, True)  # graph weights, as the plugin declares them: the tap-major image is packed once, not per call
+    try:
+        us = graph_us(lambda i: ops.conv2d(rt, x, w, 1, 1, 1, 1, bias=b, act=1, out=y), 10)
+    finally:
+        ops.set_conv_const_weights(rt, False)
+    tf = 2.0 * 32 * 128 * 28 * 28 * 128 * 9 / us / 1e6
+    out["conv_fp32_c128_28x28_3x3_bs32"] = {"us": round(us, 2), "TFLOP/s": round(tf, 1), "frac_fp32_mfma_peak": round(tf / PEAK_F32_TFLOPS, 4),
+                                            "route": ops.conv_last_route(rt)}
+    return out
+
+
 def flat_summary(line: dict, detail: dict, world: int) -> None:
     """Copy every figure BASELINE.json's metric / north_star names out of the nested sections into FLAT scalars of `config` /
     `roofline` (the objects the driver's record keeps). tests/test_bench_line_cpu.py runs it on round 4's nested line."""
@@ -642,6 +711,12 @@ def flat_summary(line: dict, detail: dict, world: int) -> None:
             roof[short] = ex[key]["frac_hbm_peak"]
     if "matmul_4096_f32_NN" in ex:
         roof["matmul_4096_f32_frac_fp32_mfma_peak"] = ex["matmul_4096_f32_NN"].get("frac_fp32_mfma_peak")
+    r5 = ex.get("round5_kernels") or {}
+    for key, short, field in (("decode_attention_bh32_n4096_d128_f16", "decode_attn_bh32_n4096_f16_frac_hbm", "frac_hbm_peak"),
+                              ("depthwise_c144_150x150_3x3_s2_bs32_f16", "dwconv_c144_150_s2_f16_frac_hbm", "frac_hbm_peak"),
+                              ("conv_fp32_c128_28x28_3x3_bs32", "conv_fp32_c128_28_3x3_bs32_frac_fp32_mfma", "frac_fp32_mfma_peak")):
+        if key in r5 and field in r5[key]:
+            roof[short] = r5[key][field]
     rows = (ex.get("membound") or {}).get("rows") or {}
     hbm = {k: v["frac_hbm_peak"] for k, v in rows.items() if isinstance(v, dict) and k.endswith("_hbm") and "frac_hbm_peak" in v}
     if hbm:

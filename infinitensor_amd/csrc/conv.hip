@@ -502,11 +502,10 @@ int infini_rocm_conv2d_res(infiniRocmRuntime_t rt, int dtype, const void *x, con
                 rt->last_conv_route = "batched_gemm32";
                 return infini_rocm_matmul(rt, dtype, w, x, bias, y, n, f, p.npix, c, 0, 0, 0, (int64_t)c * p.npix, 0, bias ? 1 : 0, 0, act);
             }
+            rt->last_conv_route = "igemm32"; // ("igemm32_splitk" when the launcher splits K)
             const int st = launch_conv_igemm32(rt, x, w, bias, residual, y, n, c, h, wd, f, (int)r, (int)s, ph, pw, sh, sw, dh, dw, p.oh, p.ow, act);
-            if (st >= 0) {
-                rt->last_conv_route = "igemm32";
+            if (st >= 0)
                 return st;
-            }
         }
         const long total = (long)n * f * p.npix;
         long g = ceil_div(total, 256);

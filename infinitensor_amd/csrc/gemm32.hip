@@ -238,7 +238,54 @@ struct Conv32Args {
     unsigned ohw_m, ow_m, rs_m, s_m; // floor(2^32 / d) of oh * ow, ow, r * s, s
     const void *zeros;
     int cp;           // TAP-MAJOR form: channels per tap in the packed weights [F][R S][cp] (cp = C rounded up to 32; k = tap * cp + c)
+    // split-K (layers whose tiles cannot fill the chip: 7 x 7 planes at batch 32 are 200 tiles of 144 K-tiles): `split` workgroups per
+    // tile, each over a contiguous range of K-tiles, store RAW fp32 sums into partial[slice][N][F][OH][OW]; conv32_splitk_reduce adds the
+    // slices in ascending order (bit-reproducible), the bias, the residual and the activation. split == 1: none of this.
+    int split;
+    float *partial;
+    long out_elems;   // N F OH OW
 };
+
+// y = act(sum over slices of partial + bias[f] + res); V consecutive elements per thread (V = 4 when planes are multiples of 4: one filter)
+template <int V>
+__global__ __launch_bounds__(256) void conv32_splitk_reduce(const float *__restrict__ partial, int split, long out_elems, const float *__restrict__ bias,
+                                                            const float *__restrict__ res, float *__restrict__ y, int f, int ohw, unsigned ohw_m,
+                                                            unsigned f_m, int act) {
+    const long nvec = out_elems / V;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        const long e = i * V;
+        float v[V];
+#pragma unroll
+        for (int r = 0; r < V; ++r)
+            v[r] = 0.f;
+        for (int sl = 0; sl < split; ++sl) {
+            if constexpr (V == 4) {
+                const f32x4 t = *(const f32x4 *)(partial + (long)sl * out_elems + e);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r] += t[r];
+            } else {
+                v[0] += partial[(long)sl * out_elems + e];
+            }
+        }
+        unsigned plane, pix, img, ff;
+        udivmod_m((unsigned)e, (unsigned)ohw, ohw_m, plane, pix);
+        udivmod_m(plane, (unsigned)f, f_m, img, ff);
+        const float bv = bias ? bias[ff] : 0.f;
+#pragma unroll
+        for (int r = 0; r < V; ++r) {
+            float x = v[r] + bv;
+            if (res)
+                x += res[e + r];
+            v[r] = apply_act(x, act);
+        }
+        if constexpr (V == 4)
+            *(f32x4 *)(y + e) = f32x4{v[0], v[1], v[2], v[3]};
+        else
+            y[e] = v[0];
+    }
+}
+
 
 // FCRS -> [F][R S][cp] (zero-filled above C): the tap-major weight image of conv_igemm32<T, true>
 __global__ __launch_bounds__(256) void conv_repack_w32(const float *__restrict__ w, float *__restrict__ o, int f, int c, int rs, int cp) {
@@ -268,7 +315,9 @@ template <int T, bool TM> __global__ __launch_bounds__(256, 2) void conv_igemm32
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = w >> 1, wn = w & 1;
-    unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int S = p.split;
+    const int slice = S > 1 ? (int)(blockIdx.x % (unsigned)S) : 0;
+    unsigned wg = S > 1 ? xcd_remap(blockIdx.x / (unsigned)S, gridDim.x / (unsigned)S) : xcd_remap(blockIdx.x, gridDim.x);
     constexpr int GROUP_M = 8;
     const unsigned per_group = GROUP_M * p.tiles_n;
     const unsigned group = wg / per_group;
@@ -278,6 +327,11 @@ template <int T, bool TM> __global__ __launch_bounds__(256, 2) void conv_igemm32
     const int tn = (wg % per_group) / gsz;
     const int m0 = tm * BM;
     const long n0 = (long)tn * BN;
+    // this workgroup's K-tiles [kt_begin, kt_end): all of them, or an EVEN number per slice (steps come in pairs; a pair that runs past
+    // the real K multiplies zero weights, but a pair must never run into the next slice's tiles)
+    const int nk_all = (p.k + BK - 1) / BK;
+    const int nk_s = S > 1 ? (((nk_all + S - 1) / S + 1) & ~1) : nk_all;
+    const int kt_begin = slice * nk_s, kt_end = kt_begin + nk_s;
 
     // this thread's column: output pixel q -> (image, oy, ox)
     const int ncol = t % BN;
@@ -359,7 +413,6 @@ template <int T, bool TM> __global__ __launch_bounds__(256, 2) void conv_igemm32
                 acc[i][j][e] = 0.f;
 
     const float *Z = (const float *)p.zeros;
-    const int nk = (p.k + BK - 1) / BK;
     // Pipeline (second version, round 5): the gathered elements pass through TWO register stages. Step kt multiplies tile kt out of
     // LDS buffer kt % 2, REQUESTS the elements of tile kt + 2 between its MFMAs and, behind them, writes tile kt + 1 — requested a whole
     // step earlier — into the other buffer. (The first version requested tile kt + 1 in step kt and wrote it at the end of the same
@@ -367,16 +420,23 @@ template <int T, bool TM> __global__ __launch_bounds__(256, 2) void conv_igemm32
     // Waits at the top of a step are counted: in issue order the outstanding requests are [weights of tile kt] [NE elements of tile
     // kt + 1], so vmcnt(NE) is "the weights have landed" (hipcc's __syncthreads would drain everything).
     // prologue: tile 0's weights by LDS-DMA, its gathered column through registers; tile 1's elements requested
-    stage_kmajor<T>(p.w, p.k, m0, p.f, 0, a_tile(0), w, lane, p.k, Z);
-    if constexpr (TM)
+    stage_kmajor<T>(p.w, p.k, m0, p.f, kt_begin * BK, a_tile(0), w, lane, p.k, Z);
+    if constexpr (TM) {
+        if (kt_begin) { // (a later slice: which tap and channel block its first K-tile is — scalar, once)
+            const int per_tap = p.cp / BK, tap = kt_begin / per_tap;
+            g_c0 = (kt_begin - tap * per_tap) * BK;
+            g_tr = tap / p.s;
+            g_ts = tap - g_tr * p.s;
+        }
         tap_setup();
-    gather(sv_a, 0);
+    }
+    gather(sv_a, kt_begin * BK);
     scatter(0, sv_a); // (hipcc waits for the loads here)
     if constexpr (TM) {
         tap_advance();
         tap_setup();
     }
-    gather(sv_b, BK); // (past the last tile: every element out of range — zeros, never multiplied)
+    gather(sv_b, (kt_begin + 1) * BK); // (past the last tile: every element out of range — zeros, never multiplied)
     auto step = [&](auto bufc, int kt, float (&cur)[NE], float (&nxt)[NE]) __attribute__((always_inline)) {
         constexpr int buf = decltype(bufc)::value;
         // tile kt's weights have landed; every thread's column of tile kt is in LDS (its ds_writes drained) — then the barrier
@@ -426,17 +486,22 @@ template <int T, bool TM> __global__ __launch_bounds__(256, 2) void conv_igemm32
     // count requests across the LDS-DMA — it puts vmcnt(0) in front of the FIRST step's LDS writes (behind that step's own requests)
     // and, everything having landed, nothing in front of the second step's: one exposed round trip per two K-tiles instead of one per
     // K-tile. (Four steps per iteration gave vmcnt(0) in front of the first and third write blocks — the same ratio at 208 VGPRs.)
-    for (int kt = 0; kt < nk; kt += 2) {
+    for (int kt = kt_begin; kt < kt_end; kt += 2) {
         step(std::integral_constant<int, 0>{}, kt, sv_b, sv_a);
         step(std::integral_constant<int, 1>{}, kt + 1, sv_a, sv_b);
     }
 
-    // epilogue: lane l holds filter m = l % 32 and, per g, four consecutive columns q
+    // epilogue: lane l holds filter m = l % 32 and, per g, four consecutive columns q. A split-K slice stores its raw sums into its
+    // plane of `partial` (same NCHW indexing); bias / residual / activation then belong to conv32_splitk_reduce.
     const int ohw = p.oh * p.ow;
+    const bool fin = S == 1;
+    float *const Y = fin ? p.y : p.partial + (long)slice * p.out_elems;
+    const float *const R = fin ? p.res : nullptr;
+    const int act = fin ? p.act : 0;
 #pragma unroll
     for (int i = 0; i < T; ++i) {
         const int frow = m0 + wm * WT + i * 32 + (lane & 31);
-        const float bv = (p.bias && frow < p.f) ? p.bias[frow] : 0.f;
+        const float bv = (fin && p.bias && frow < p.f) ? p.bias[frow] : 0.f;
 #pragma unroll
         for (int j = 0; j < T; ++j)
 #pragma unroll
@@ -451,17 +516,17 @@ template <int T, bool TM> __global__ __launch_bounds__(256, 2) void conv_igemm32
                 for (int r = 0; r < 4; ++r)
                     v[r] = acc[i][j][g * 4 + r] + bv;
                 const long o = ((long)im2 * p.f + frow) * ohw + px2;
-                if (px2 + 4 <= (unsigned)ohw && qc + 4 <= p.ncols && (o & 3) == 0 && ((((uintptr_t)p.y) & 15) == 0)) {
-                    if (p.res) {
-                        const f32x4 rv = *(const f32x4 *)(p.res + o);
+                if (px2 + 4 <= (unsigned)ohw && qc + 4 <= p.ncols && (o & 3) == 0 && ((((uintptr_t)Y) & 15) == 0)) {
+                    if (R) {
+                        const f32x4 rv = *(const f32x4 *)(R + o);
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             v[r] += rv[r];
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        v[r] = apply_act(v[r], p.act);
-                    *(f32x4 *)(p.y + o) = f32x4{v[0], v[1], v[2], v[3]};
+                        v[r] = apply_act(v[r], act);
+                    *(f32x4 *)(Y + o) = f32x4{v[0], v[1], v[2], v[3]};
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -472,9 +537,9 @@ template <int T, bool TM> __global__ __launch_bounds__(256, 2) void conv_igemm32
                         udivmod_m((unsigned)qq, (unsigned)ohw, p.ohw_m, im3, px3);
                         const long oo = ((long)im3 * p.f + frow) * ohw + px3;
                         float x = v[r];
-                        if (p.res)
-                            x += p.res[oo];
-                        p.y[oo] = apply_act(x, p.act);
+                        if (R)
+                            x += R[oo];
+                        Y[oo] = apply_act(x, act);
                     }
                 }
             }
@@ -541,6 +606,36 @@ int launch_conv_igemm32(infiniRocmRuntime_t rt, const void *x, const void *w, co
         return -1;
     f32k::Conv32Args p;
     p.x = (const float *)x; p.w = (const float *)w; p.bias = (const float *)bias; p.res = (const float *)res; p.y = (float *)y;
+    // Tile size, measured on ResNet-50's layers at batch 32 (tools/conv32_bench.py --forms, us with 64^2 / 128^2 tiles): C128 28^2 3 x 3
+    // 97.9 / 115.6; C128 56^2 3 x 3 / 2 99.0 / 127.7; C256 56^2 -> 128 1 x 1 (784 tiles of 128^2 = 3 per CU) 82.7 / 118.7; C256 14^2 3 x 3
+    // 109 / 217: the 64^2 tiles (83 registers, 32 KB of LDS: five workgroups per CU hide the gather's latency) win everywhere there, so
+    // the 128^2 form (182 registers, two workgroups per CU) is kept for problems with at least eight of its tiles per CU only.
+    bool small = f <= 64 || ceil_div(f, 128) * ceil_div(ncols, 128) < 8 * (int64_t)rt->num_cu;
+    if (const char *e = getenv("IROCM_CONV32_TILE")) // measurement hook (tools/conv32_bench.py --forms): 1 = 64^2 tiles, 2 = 128^2
+        small = atoi(e) == 1 ? true : (atoi(e) == 2 ? false : small);
+    const int bm = small ? 64 : 128;
+    const int64_t tiles = ceil_div(f, bm) * ceil_div(ncols, bm);
+    // Split-K: the 64^2 tiles of a 7 x 7-plane layer at batch 32 number 200 (one per CU, no partner to hide the gather behind) with
+    // 64-144 K-tiles each. `split` workgroups per tile over even runs of K-tiles, raw sums to the workspace, one reduce pass. Measured
+    // (tools/conv32_bench.py --forms, us with 1 / 2 / 4 slices): 200 tiles — C512 7^2 3 x 3 150 / 120 / 116, C512 14^2 3 x 3 / 2 154 / 121 /
+    // 118, C2048 -> 512 7^2 77 / 63 / 63; 392 tiles — C256 14^2 3 x 3 (72 K-tiles) 108 / 107 / 100, C256 28^2 3 x 3 / 2 109 / 107 / 101,
+    // C1024 -> 256 14^2 (32 K-tiles) 52 / 55 / 55; 800 tiles: slower with any split. Hence four slices up to one tile per CU, and up to
+    // two tiles per CU when K is long enough to pay for the second pass.
+    const int64_t nk_all = ceil_div(k, f32k::BK);
+    int split = 1;
+    if (small && ((tiles <= rt->num_cu && nk_all >= 32) || (tiles <= 2 * (int64_t)rt->num_cu && nk_all >= 64)))
+        split = 4;
+    if (const char *e = getenv("IROCM_CONV32_SPLIT")) // measurement / test hook: 1 = never, 2 / 4 = that factor wherever a slice keeps >= 2 K-tiles
+        if (small && atoi(e) >= 1 && atoi(e) <= 8 && nk_all >= 2 * atoi(e))
+            split = atoi(e);
+    const int64_t out_elems = n * f * oh * ow;
+    const size_t partial_bytes = split > 1 ? (size_t)split * out_elems * 4 : 0;
+    float *partial = nullptr;
+    // The caller may have parked THIS layer's input in the workspace (the plugin's planner bridges a conv's input there when the fused
+    // chain's output was planned onto it): whatever this launcher takes from the workspace goes behind the input's last byte.
+    size_t front = 0;
+    if (rt->workspace && (const char *)x >= (const char *)rt->workspace && (const char *)x < (const char *)rt->workspace + rt->workspace_bytes)
+        front = (((size_t)((const char *)x - (const char *)rt->workspace) + (size_t)(n * c * h * wd * 4)) + 255) & ~(size_t)255;
     if (tm || padk) {
         const int kind = tm ? 2 : 3;
         // the tap-major (or row-padded) weight image: cached per graph weight when the caller declared the weights constant (the plugin does), else
@@ -563,10 +658,12 @@ int launch_conv_igemm32(infiniRocmRuntime_t rt, const void *x, const void *w, co
             }
         } else {
             void *ws = nullptr;
-            const int st = infini_rocm_workspace(rt, w_bytes, &ws);
+            const int st = infini_rocm_workspace(rt, front + w_bytes + partial_bytes, &ws);
             if (st != INFINI_ROCM_OK)
                 return st;
-            packed = ws;
+            packed = (char *)ws + front;
+            if (partial_bytes)
+                partial = (float *)((char *)ws + front + w_bytes);
         }
         if (need_pack) {
             long g = ceil_div((long)f * k, 256);
@@ -589,6 +686,14 @@ int launch_conv_igemm32(infiniRocmRuntime_t rt, const void *x, const void *w, co
         }
         p.w = (const float *)packed;
     }
+    if (partial_bytes && !partial) { // (weights cached or used as they lie: the workspace is all the slices')
+        void *ws = nullptr;
+        const int st = infini_rocm_workspace(rt, front + partial_bytes, &ws);
+        if (st != INFINI_ROCM_OK)
+            return st;
+        partial = (float *)((char *)ws + front);
+    }
+    p.split = split; p.partial = partial; p.out_elems = out_elems;
     p.nimg = (int)n; p.c = (int)c; p.h = (int)h; p.wd = (int)wd; p.f = (int)f; p.r = r; p.s = s;
     p.ph = ph; p.pw = pw; p.sh = sh; p.sw = sw; p.dh = dh; p.dw = dw;
     p.oh = oh; p.ow = ow;
@@ -603,14 +708,6 @@ int launch_conv_igemm32(infiniRocmRuntime_t rt, const void *x, const void *w, co
     p.rs_m = udiv_magic((unsigned long long)r * s);
     p.s_m = udiv_magic((unsigned long long)s);
     p.zeros = rt->zeros;
-    // Tile size, measured on ResNet-50's layers at batch 32 (tools/conv32_bench.py --forms, us with 64^2 / 128^2 tiles): C128 28^2 3 x 3
-    // 97.9 / 115.6; C128 56^2 3 x 3 / 2 99.0 / 127.7; C256 56^2 -> 128 1 x 1 (784 tiles of 128^2 = 3 per CU) 82.7 / 118.7; C256 14^2 3 x 3
-    // 109 / 217: the 64^2 tiles (83 registers, 32 KB of LDS: five workgroups per CU hide the gather's latency) win everywhere there, so
-    // the 128^2 form (182 registers, two workgroups per CU) is kept for problems with at least eight of its tiles per CU only.
-    bool small = f <= 64 || ceil_div(f, 128) * ceil_div(ncols, 128) < 8 * (int64_t)rt->num_cu;
-    if (const char *e = getenv("IROCM_CONV32_TILE")) // measurement hook (tools/conv32_bench.py --forms): 1 = 64^2 tiles, 2 = 128^2
-        small = atoi(e) == 1 ? true : (atoi(e) == 2 ? false : small);
-    const int bm = small ? 64 : 128;
     p.tiles_m = (int)ceil_div(f, bm);
     p.tiles_n = (int)ceil_div(ncols, bm);
     const long total = (long)p.tiles_m * p.tiles_n;
@@ -621,7 +718,7 @@ int launch_conv_igemm32(infiniRocmRuntime_t rt, const void *x, const void *w, co
     do {                                                                                           \
         auto kern = f32k::conv_igemm32<T_, TM_>;                                                   \
         IROCM_LDS_ATTR(kern, (int)lds, rt);                                                        \
-        hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds, rt->stream, p);            \
+        hipLaunchKernelGGL(kern, dim3((unsigned)(total * split)), dim3(256), lds, rt->stream, p);  \
     } while (0)
     if (small) {
         if (tm) IROCM_C32(1, true); else IROCM_C32(1, false);
@@ -630,6 +727,20 @@ int launch_conv_igemm32(infiniRocmRuntime_t rt, const void *x, const void *w, co
     }
 #undef IROCM_C32
     IROCM_LAUNCH_CHECK("conv_igemm32");
+    if (split > 1) {
+        rt->last_conv_route = "igemm32_splitk";
+        const int ohw = oh * ow;
+        const bool v4 = ohw % 4 == 0 && ((((uintptr_t)y) | ((uintptr_t)partial) | (res ? (uintptr_t)res : 0)) & 15) == 0;
+        long g = ceil_div(out_elems / (v4 ? 4 : 1), 256);
+        if (g > (long)rt->num_cu * 16) g = (long)rt->num_cu * 16;
+        if (v4)
+            hipLaunchKernelGGL(f32k::conv32_splitk_reduce<4>, dim3((unsigned)g), dim3(256), 0, rt->stream, partial, split, (long)out_elems,
+                               (const float *)bias, (const float *)res, (float *)y, (int)f, ohw, p.ohw_m, udiv_magic((unsigned long long)f), act);
+        else
+            hipLaunchKernelGGL(f32k::conv32_splitk_reduce<1>, dim3((unsigned)g), dim3(256), 0, rt->stream, partial, split, (long)out_elems,
+                               (const float *)bias, (const float *)res, (float *)y, (int)f, ohw, p.ohw_m, udiv_magic((unsigned long long)f), act);
+        IROCM_LAUNCH_CHECK("conv32_splitk_reduce");
+    }
     return INFINI_ROCM_OK;
 }
 

@@ -868,16 +868,20 @@ def test_conv_fp32_pointwise_as_one_gemm_per_image(rt, monkeypatch):
     assert np.allclose(host(y), want, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("mode", ["plain", "bias_res_relu", "bias_res_relu_t128"])
+@pytest.mark.parametrize("mode", ["plain", "bias_res_relu", "bias_res_relu_t128", "bias_res_relu_split1", "bias_res_relu_split3", "plain_split4"])
 @pytest.mark.parametrize("cfg", F32_CONV_CFGS)
 def test_conv_fp32_on_the_matrix_cores(rt, cfg, mode, monkeypatch):
     """Round 5: fp32 Conv2d (the dtype of north_star's 1e-4 gate and of the intelcpu baseline; reference: cuDNN implicit GEMM,
     src/kernels/cuda/conv.cc:57-168) as an implicit GEMM on v_mfma_f32_32x32x2_f32 (route "igemm32", pointwise layers included) against the oracle within 1e-4 RELATIVE of the output's scale per element (2e-5 absolute below 1)
-    and against the one-output-per-thread kernel it replaces (conv variant 1, route "direct32"). "_t128" forces the 128 x 128 tile
+    and against the one-output-per-thread kernel it replaces (conv variant 1, route "direct32"). Layers with few tiles split K
+    over several workgroups per tile (route "igemm32_splitk": raw sums per slice, one reduce pass with bias / residual / ReLU) — by the
+    launcher's rule or forced ("_split<S>"). "_t128" forces the 128 x 128 tile
     form (IROCM_CONV32_TILE; the launcher picks it from eight such tiles per CU on — sizes the dense oracle cannot follow)."""
     n, c, h, w, f, r, s, ph, pw, sh, sw, dh, dw = cfg
     if mode.endswith("_t128"):
         monkeypatch.setenv("IROCM_CONV32_TILE", "2")
+    if "_split" in mode:  # split-K forced: K-tile ranges per slice, raw partial sums in the workspace, the reduce pass (1 = never)
+        monkeypatch.setenv("IROCM_CONV32_SPLIT", mode[-1])
     rng = np.random.default_rng(abs(hash(cfg)) % 2 ** 32)
     x = rng.standard_normal((n, c, h, w)).astype(np.float32)
     wt = (rng.standard_normal((f, c, r, s)) / np.sqrt(c * r * s)).astype(np.float32)
@@ -890,7 +894,7 @@ def test_conv_fp32_on_the_matrix_cores(rt, cfg, mode, monkeypatch):
     rd = dev(res, torch.float32) if res is not None else None
     guard = torch.full((n, f, oh, ow), 7.0, device="cuda", dtype=torch.float32)
     y = ops.conv2d(rt, xd, wd, ph, pw, sh, sw, dh, dw, bias=bd, act=act, residual=rd, out=guard)
-    assert ops.conv_last_route(rt) == "igemm32"
+    assert ops.conv_last_route(rt) in (("igemm32",) if mode.endswith("split1") else ("igemm32", "igemm32_splitk"))
     try:
         ops.set_conv_variant(rt, 1)
         y1 = ops.conv2d(rt, xd, wd, ph, pw, sh, sw, dh, dw, bias=bd, act=act, residual=rd)

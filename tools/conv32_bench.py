@@ -32,11 +32,12 @@ for cnt, c, h, f, r, st, pad in RESNET50:
     line = f"x{cnt} C{c:<4d} {h:>3d}x{h:<3d} F{f:<4d} {r}x{r}/s{st} {flop / 1e9:7.2f} GF |"
     forms = (("mfma", -1, {}),)
     if a.forms:
-        forms += (("t64", -1, {"IROCM_CONV32_TILE": "1"}), ("t128", -1, {"IROCM_CONV32_TILE": "2"}), ("pw-batched", -1, {"IROCM_CONV32_PW_BATCHED": "1"}))
+        forms += (("t64", -1, {"IROCM_CONV32_TILE": "1"}), ("t128", -1, {"IROCM_CONV32_TILE": "2"}), ("pw-batched", -1, {"IROCM_CONV32_PW_BATCHED": "1"}),
+                  ("s1", -1, {"IROCM_CONV32_SPLIT": "1"}), ("s2", -1, {"IROCM_CONV32_SPLIT": "2"}), ("s4", -1, {"IROCM_CONV32_SPLIT": "4"}))
     if a.direct:
         forms += (("direct", 1, {}),)
     for name, var, env in forms:
-        for k in ("IROCM_CONV32_TILE", "IROCM_CONV32_PW_BATCHED"):
+        for k in ("IROCM_CONV32_TILE", "IROCM_CONV32_PW_BATCHED", "IROCM_CONV32_SPLIT"):
             os.environ.pop(k, None)
         os.environ.update(env)
         ops.set_conv_variant(rt, var)
