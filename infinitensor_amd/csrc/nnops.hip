@@ -5,6 +5,7 @@
 // poolingCudnn src/kernels/cuda/pooling.cc:6-95 (cudnnPoolingForward; AVERAGE_COUNT_INCLUDE_PADDING).
 // All HBM-bound: algorithmic bytes = (numel_in + numel_out) * sizeof(T). fp32 arithmetic throughout.
 #include "common.h"
+#include "gemm_common.h" // (udivmod_m / udiv_magic: division by multiply-high)
 #include <type_traits>
 
 namespace irocm {
@@ -301,43 +302,62 @@ __global__ __launch_bounds__(256) void pool2d_kernel(const T *__restrict__ x, T 
     }
 }
 
-// MaxPool 3x3 / stride 2 / pad 1 / dilation 1 on 16-bit types, W % 8 == 0 (the ResNet stem pool): one thread per 4
-// outputs of a row — per input row one 16-byte load (8 columns) plus the left neighbour; 8-byte store. The generic
-// kernel issues 9 two-byte loads per output and ran this 256 MB layer at 1.4 TB/s.
+// MaxPool 3x3 / stride 2 / pad 1 / dilation 1 on 16-bit types, W % 8 == 0 (the ResNet stem pool). One thread per 4 outputs of TWO
+// output rows: the five input rows 2 oy - 1 .. 2 oy + 3 as one 16-byte load each (8 columns) plus the left neighbour, horizontal
+// maxima per input row first (row 2 oy + 1 serves both output rows), two 8-byte stores. Everything is branch-free — rows outside
+// the image are loaded from a clamped row and replaced by -inf with selects — so the ten loads of a thread are in flight together.
+// History: the generic kernel issues 9 two-byte loads per output (1.4 TB/s on this layer); round 2's form — one output row per
+// thread, four integer divisions by run-time values per thread, ~150 instructions per 4 outputs — was VALU-bound at the HBM-sized
+// shape (0.58 of 8 TB/s: 19 M threads x 150 instructions = 140 us of vector issue alone); this one spends ~140 per 8 outputs.
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T *__restrict__ x, T *__restrict__ y, int planes, int h,
-                                                           int w, int oh, int ow, int relu) {
-    const int quads = ow / 4;
-    const int total = planes * oh * quads;
+                                                           int w, int oh, int ow, int relu, unsigned quads_m, unsigned oh2_m) {
+    const int quads = ow / 4, oh2 = (oh + 1) / 2;
+    const int total = planes * oh2 * quads;
+    struct alignas(16) V8 { T v[8]; };
+    struct alignas(8) V4 { T v[4]; };
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int jq = i % quads;
-        const int q = i / quads;
-        const int oy = q % oh, pl = q / oh;
-        const float m0 = relu ? 0.f : -INFINITY;
-        float m[4] = {m0, m0, m0, m0};
+        unsigned q, jq, pl, o2;
+        udivmod_m((unsigned)i, (unsigned)quads, quads_m, q, jq);
+        udivmod_m(q, (unsigned)oh2, oh2_m, pl, o2);
+        const int oy = 2 * (int)o2, iy0 = 2 * oy - 1;
+        const T *plane = x + (long)pl * h * w + 8 * jq;
+        const int lback = jq > 0 ? 1 : 0;
+        V8 c[5];
+        T lf[5];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int iy = 2 * oy - 1 + r;
-            if (iy < 0 || iy >= h)
-                continue;
-            const T *row = x + ((long)pl * h + iy) * w + 8 * jq;
-            struct alignas(16) V8 { T v[8]; };
-            const V8 c = *reinterpret_cast<const V8 *>(row);
+        for (int r = 0; r < 5; ++r) {
+            const int iy = min(max(iy0 + r, 0), h - 1);
+            const T *row = plane + (long)iy * w;
+            c[r] = *reinterpret_cast<const V8 *>(row);
+            lf[r] = *(row - lback);
+        }
+        float hm[5][4];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const bool ok = (unsigned)(iy0 + r) < (unsigned)h;
             float f[9];
-            f[0] = jq > 0 ? LdSt<T>::ld(row - 1) : -INFINITY;
+            f[0] = lback ? LdSt<T>::ld(&lf[r]) : -INFINITY;
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                f[e + 1] = LdSt<T>::ld(&c.v[e]);
+                f[e + 1] = LdSt<T>::ld(&c[r].v[e]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float m = fmaxf(f[2 * k], fmaxf(f[2 * k + 1], f[2 * k + 2]));
+                hm[r][k] = ok ? m : -INFINITY;
+            }
+        }
+        const float m0 = relu ? 0.f : -INFINITY;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (oy + half >= oh)
+                break;
+            V4 o;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                m[k] = fmaxf(m[k], fmaxf(f[2 * k], fmaxf(f[2 * k + 1], f[2 * k + 2])));
+                LdSt<T>::st(&o.v[k], fmaxf(fmaxf(m0, hm[2 * half][k]), fmaxf(hm[2 * half + 1][k], hm[2 * half + 2][k])));
+            *reinterpret_cast<V4 *>(y + ((long)pl * oh + oy + half) * ow + 4 * jq) = o;
         }
-        struct alignas(8) V4 { T v[4]; };
-        V4 o;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            LdSt<T>::st(&o.v[k], m[k]);
-        *reinterpret_cast<V4 *>(y + ((long)pl * oh + oy) * ow + 4 * jq) = o;
     }
 }
 
@@ -533,14 +553,16 @@ int infini_rocm_pool2d_relu(infiniRocmRuntime_t rt, int kind, int dtype, const v
                      w % 8 == 0 && p.ow == w / 2 && (dtype == INFINI_DT_F16 || dtype == INFINI_DT_BF16) &&
                      (((uintptr_t)x) & 15) == 0 && (((uintptr_t)y) & 7) == 0 && total / 4 + 256l * rt->num_cu * 16 < (1l << 31);
     if (mp3) {
-        long g3 = ceil_div(total / 4, 256);
+        const long items = n * c * ((p.oh + 1) / 2) * (p.ow / 4);
+        long g3 = ceil_div(items, 256);
         if (g3 > (long)rt->num_cu * 16) g3 = (long)rt->num_cu * 16;
+        const unsigned quads_m = udiv_magic((unsigned long long)(p.ow / 4)), oh2_m = udiv_magic((unsigned long long)((p.oh + 1) / 2));
         if (dtype == INFINI_DT_F16)
             hipLaunchKernelGGL(maxpool3x3s2_kernel<__half>, dim3((unsigned)g3), dim3(256), 0, rt->stream, (const __half *)x,
-                               (__half *)y, (int)(n * c), (int)h, (int)w, (int)p.oh, (int)p.ow, relu);
+                               (__half *)y, (int)(n * c), (int)h, (int)w, (int)p.oh, (int)p.ow, relu, quads_m, oh2_m);
         else
             hipLaunchKernelGGL(maxpool3x3s2_kernel<__hip_bfloat16>, dim3((unsigned)g3), dim3(256), 0, rt->stream,
-                               (const __hip_bfloat16 *)x, (__hip_bfloat16 *)y, (int)(n * c), (int)h, (int)w, (int)p.oh, (int)p.ow, relu);
+                               (const __hip_bfloat16 *)x, (__hip_bfloat16 *)y, (int)(n * c), (int)h, (int)w, (int)p.oh, (int)p.ow, relu, quads_m, oh2_m);
         IROCM_LAUNCH_CHECK("maxpool3x3s2");
         return INFINI_ROCM_OK;
     }

@@ -330,6 +330,30 @@ def test_pooling_vs_oracle(rt, cfg, dt):
         assert np.allclose(host(y), want, rtol=tol, atol=tol), kind
 
 
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("shape", [(1, 1, 2, 8), (1, 2, 3, 8), (2, 3, 5, 24), (1, 4, 16, 16), (2, 2, 31, 40), (1, 3, 64, 112), (5, 7, 12, 8)])
+def test_maxpool_3x3_stride2_kernel_shapes(rt, shape, relu, dt):
+    """The specialised MaxPool 3 x 3 / 2 / pad 1 kernel (two output rows per thread since round 5; reference pooling.cc:6-95): one and
+    two output rows, odd heights (the last thread's second row does not exist, the last input row is missing), one and several
+    4-output groups per row, with and without the fused ReLU — bit-exact (a maximum of stored values)."""
+    rng = np.random.default_rng(sum(shape))
+    x = R.round_to(rng.standard_normal(shape).astype(np.float32), dt)
+    xd = dev(x, TD[dt])
+    y = ops.max_pool(rt, xd, 3, 3, 1, 1, 1, 1, 2, 2, 0)
+    want = R.pool2d(x, "max", 3, 3, 1, 1, 1, 1, 2, 2, 0)
+    if relu:
+        import ctypes as C
+        from infinitensor_amd._lib import check, lib
+        n, c, h, w = shape
+        y = torch.empty(want.shape, device="cuda", dtype=TD[dt])
+        check(lib().infini_rocm_pool2d_relu(rt.handle, 0, ops.dtype_of(xd), C.c_void_p(xd.data_ptr()), C.c_void_p(y.data_ptr()), n, c, h, w, 3, 3, 1, 1, 1, 1,
+                                            2, 2, 0, 1))
+        want = np.maximum(want, 0)
+    assert tuple(y.shape) == want.shape
+    assert np.array_equal(host(y), want.astype(np.float32))
+
+
 CONVT = [
     # n, f, h, w, cg, r, s, ph, pw, sh, sw, dh, dw, oph, opw, groups
     (2, 8, 5, 6, 4, 3, 3, 1, 1, 2, 2, 1, 1, 1, 1, 1),   # the usual 2x up-sampling deconv
