@@ -152,6 +152,20 @@ def test_concat_split_roundtrip(rt, dtype):
     assert np.array_equal(host(ops.concat(rt, [dev(x) for x in xs], -1)), R.concat(xs, 2))
 
 
+@pytest.mark.parametrize("dtype,rows", [(np.float16, 70003), (np.int8, 131075), (np.float32, 66000)])
+def test_concat_split_tall_tensors_take_four_rows_per_trip(rt, dtype, rows):
+    """Round 5: tensors with many more rows than the copy grid take the four-consecutive-rows-per-trip form of the Concat / Split
+    kernel (all loads of a trip before its stores); row counts that are not multiples of four end in a partial group; three inputs of
+    different widths; bit-exact both ways."""
+    xs = [rnd((rows, n), dtype, n) for n in (8, 24, 16)]
+    cat = ops.concat(rt, [dev(x) for x in xs], 1)
+    want = R.concat(xs, 1)
+    assert np.array_equal(host(cat), want)
+    back = ops.split(rt, cat, 1, [8, 24, 16])
+    for b, x in zip(back, xs):
+        assert np.array_equal(host(b), x)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float16, np.int64])
 def test_slice_pad_bit_exact(rt, dtype):
     x = rnd((4, 6, 7, 9), dtype, 11)
