@@ -214,7 +214,11 @@ static int reduce_dispatch(infiniRocmRuntime_t rt, const void *x, void *y, int n
     if (trailing && p.nred < 64 && p.nred > 1 && p.nout >= 256) {
         constexpr int RB = 256;
         long g = ceil_div(p.nout, RB);
-        if (g > (long)rt->num_cu * 8) g = (long)rt->num_cu * 8;
+        // persistent workgroups, as many as are RESIDENT at once: a CU holds 160 KB / (RB rows in LDS) of them (six at 49 f16
+        // elements). With a fixed eight per CU the last two of every CU started when the first six had finished all their trips and
+        // ran at a third of the occupancy: the HBM-sized ReduceMean over 7 x 7 planes sat at 0.54-0.57 of the HBM peak.
+        const long per_cu = std::max<long>(1, std::min<long>(8, (160 * 1024) / ((long)RB * p.nred * (long)sizeof(T) + 512)));
+        if (g > (long)rt->num_cu * per_cu) g = (long)rt->num_cu * per_cu;
         hipLaunchKernelGGL((reduce_short_rows_kernel<T, RB>), dim3((unsigned)g), dim3(256), (size_t)RB * p.nred * sizeof(T), rt->stream,
                            (const T *)x, (T *)y, p.nout, (int)p.nred, p.scale);
     } else if (trailing && p.nred >= 64) {

@@ -6,7 +6,7 @@ O=gpurun_out/r5h
 rm -rf $O; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 t0=$(date +%s)
-timeout -k 10 300 python -m pytest tests/test_gpu_movement.py tests/test_gpu_plugin.py -q -x -k "concat or split or Concat or Split or tall" > $O/pytest.log 2>&1
+timeout -k 10 300 python -m pytest tests/test_gpu_nn.py -q -x -k "reduce" > $O/pytest.log 2>&1
 echo "pytest exit $? after $(( $(date +%s) - t0 )) s"; tail -3 $O/pytest.log | grep -v "version\|Hostname\|Librccl"
-timeout -k 10 200 python tools/membound_sweep.py --only concat,split > $O/membound.txt 2>&1; grep -v amdgpu $O/membound.txt
+timeout -k 10 200 python tools/membound_sweep.py --only reduce_mean,concat > $O/membound.txt 2>&1; grep -v amdgpu $O/membound.txt
 echo "total $(( $(date +%s) - t0 )) s"
