@@ -810,13 +810,23 @@ __global__ __launch_bounds__(256) void softmax_blockreg_kernel(const T *__restri
 }
 
 static inline bool is_aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
-// persistent grid: at most 8 blocks (32 waves) per CU
 static inline int env_int(const char *name, int dflt) {
     const char *e = getenv(name);
     return e ? atoi(e) : dflt;
 }
-static inline unsigned pgrid(int64_t blocks, int num_cu) {
-    static const int per_cu = env_int("IROCM_ROWOPS_BLOCKS_PER_CU", 8); // tuning hook
+// The persistent grid of ONE kernel: as many 256-thread workgroups per CU as are RESIDENT at once (asked from the HIP runtime once
+// per kernel; at most 8). With a fixed eight per CU a kernel of 86 registers (five resident) ran 5 + 3: the last three workgroups of
+// every CU started when the first five had finished all their rows — the same tail nnops.hip's short-row reduction had (0.56 -> 0.68).
+template <auto Kern> static inline unsigned pgrid_k(int64_t blocks, int num_cu) {
+    static const int per_cu = [] {
+        const int forced = env_int("IROCM_ROWOPS_BLOCKS_PER_CU", 0); // tuning hook
+        if (forced > 0)
+            return forced;
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, Kern, 256, 0) != hipSuccess || nb < 1)
+            nb = 8;
+        return nb < 8 ? nb : 8;
+    }();
     const int64_t cap = (int64_t)num_cu * per_cu;
     return (unsigned)(blocks < cap ? (blocks < 1 ? 1 : blocks) : cap);
 }
@@ -878,7 +888,7 @@ static int softmax_dispatch(infiniRocmRuntime_t rt, const T *x, T *y, int64_t ou
         static const int rpw8 = getenv("IROCM_SOFTMAX_RPW8") ? atoi(getenv("IROCM_SOFTMAX_RPW8")) : 0; // tuning hook
         const int rpw = (!al || outer < 4096) ? 1 : (row_bytes <= 1024 ? (rpw8 ? 8 : 4) : (row_bytes <= 3072 ? 2 : 1));
 #define SM_GO(C, A, R)                                                                             \
-    hipLaunchKernelGGL((softmax_wave_kernel<T, C, A, R>), dim3(pgrid(ceil_div(outer, 4 * R), rt->num_cu)), \
+    hipLaunchKernelGGL((softmax_wave_kernel<T, C, A, R>), dim3(pgrid_k<softmax_wave_kernel<T, C, A, R>>(ceil_div(outer, 4 * R), rt->num_cu)), \
                        dim3(256), 0, rt->stream, x, y, (long)outer, (int)dimsize)
         if (chunks <= 1) {
             if (!al) SM_GO(1, false, 1);
@@ -932,7 +942,7 @@ static int norm_dispatch(infiniRocmRuntime_t rt, const T *x, const T *scale, con
         return INFINI_ROCM_OK;
     }
 #define NORM_GO(C, A, R)                                                                           \
-    hipLaunchKernelGGL((norm_wave_kernel<T, C, A, RMS, R>), dim3(pgrid(ceil_div(outer, 4 * R), rt->num_cu)), \
+    hipLaunchKernelGGL((norm_wave_kernel<T, C, A, RMS, R>), dim3(pgrid_k<norm_wave_kernel<T, C, A, RMS, R>>(ceil_div(outer, 4 * R), rt->num_cu)), \
                        dim3(256), 0, rt->stream, x, scale, bias, y, (long)outer, (int)n,           \
                        (int)scale_size, (int)bias_size, eps)
     if (chunks <= 1) {
