@@ -67,6 +67,14 @@ int launch_conv_pw_gemm(infiniRocmRuntime_t rt, int dtype, const void *x, const 
     // C256 -> F1024 @14x14 with a residual 40.4 vs 46.9 us on 192-column tiles, C512 -> F2048 @7x7 30.7 vs 36.6 (IROCM_CONV_RES_NT4=0: A/B)
     static const int res_nt4 = getenv("IROCM_CONV_RES_NT4") ? atoi(getenv("IROCM_CONV_RES_NT4")) : 1;
     int nt = persist_pick_nt(f, n * hwp, c, rt->num_cu, (res && !res_nt4) ? 3 : 4);
+    // The cost model is fitted on MFMA-bound GEMMs, where a partial last round of tiles costs most of a full one. Layers with C <= 512
+    // are HBM-bound (4-8 K-tiles per tile): a partial round simply has the bandwidth to itself, and narrower tiles only add tile
+    // boundaries — measured at batch 128 (tools/gpu_r5k.sh, us with the model's width / 256 columns): C512 -> 128 @28^2 39.4 / 34.8,
+    // C512 -> 256 @28^2 40.6 / 37.5, C128 -> 512 @28^2 40.9 / 34.3; with C >= 1024 the model's narrower tiles stay (C1024 -> 256 @14^2
+    // 23.0 / 27.5). The residual form at C = 64 (ONE K-tile per tile: all epilogue) is the short-K case that likes 128 columns —
+    // half the residual registers in flight per wave, twice the tiles to balance (103.3 / 109.2).
+    if (c <= 512)
+        nt = (res && c <= 64) ? 2 : 4;
     if (const char *force = getenv("IROCM_CONV_PW_NT")) { // test hook (read per call): force the tile width 2 / 3 / 4
         const int v = atoi(force);
         if (v >= 2 && v <= 4)
