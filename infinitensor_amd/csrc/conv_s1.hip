@@ -1685,7 +1685,9 @@ int launch_conv_s1(infiniRocmRuntime_t rt, int dtype, const void *x, const void 
                            c % 64 == 0 && !res && (act == 0 || act == 1) && (long)oh * ow >= 8;
     static const int tap_on = getenv("IROCM_CONV_TAP") ? atoi(getenv("IROCM_CONV_TAP")) : 1; // A/B hook: 0 = off
     bool tap_want = tap_shape && rt->conv_variant == 7;
-    if (tap_shape && rt->conv_variant < 0 && tap_on && f >= 256) {
+    // (strided layers from 128 filters on: half of the 256-row tile is empty there, and the tap GEMM still beats the phase-plane
+    // tap-shifted kernel — C128 -> 128 @56^2 / 2 at batch 128: 98.2 vs 104.7 us; unit-stride layers need the 256 filters)
+    if (tap_shape && rt->conv_variant < 0 && tap_on && (f >= 256 || (sh == 2 && f >= 128))) {
         const long tiles256 = ceil_div(f, 256) * ceil_div((long)n * (((long)oh * ow + 7) / 8 * 8), 256);
         if (sh == 2)
             tap_want = tiles256 * 4 >= rt->num_cu / 2;                       // enough work for the persistent kernels at all

@@ -26,7 +26,7 @@ LAYERS = [
     (64, 56, 256, 1, 1, 0, "pixel_gemm", ("b", "brr")),
     (256, 56, 64, 1, 1, 0, "tap_shifted", ("br",)),
     (256, 56, 128, 1, 1, 0, "pixel_gemm", ("br",)),
-    (128, 56, 128, 3, 2, 1, "tap_shifted", ("br",)),
+    (128, 56, 128, 3, 2, 1, "tap_gemm", ("br",)),          # round 5: strided 3 x 3 layers from 128 filters on take the tap GEMM
     (128, 28, 512, 1, 1, 0, "pixel_gemm", ("brr",)),
     (256, 56, 512, 1, 2, 0, "pixel_gemm", ("b",)),
     (512, 28, 128, 1, 1, 0, "pixel_gemm", ("br",)),
