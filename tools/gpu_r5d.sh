@@ -15,7 +15,9 @@ IROCM_STEM_LINEAR=1 timeout 300 python tools/model_bench.py resnet50 2>&1 | tail
 timeout 600 python -m pytest tests/test_gpu_nn.py -q -x -k "fp32" > $O/pytest_fp32.log 2>&1; tail -3 $O/pytest_fp32.log
 timeout 400 python tools/conv32_bench.py --forms > $O/conv32.txt 2>&1; cat $O/conv32.txt | cut -c1-250
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $REPO/$O/prof_resnet -o resnet -- python $REPO/tools/model_bench.py resnet50 --iters 5 > $REPO/$O/prof_resnet.log 2>&1
+# (as first run this line had no --output-format csv and a plain `timeout`: rocprofv3's post-processing of the default database did not
+# end and ignored SIGTERM — the visit ran into gpurun's own limit. Every profiler step of the later scripts is `timeout -k` + csv.)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$O/prof_resnet -o resnet -- python $REPO/tools/model_bench.py resnet50 --iters 5 > $REPO/$O/prof_resnet.log 2>&1
 cd $REPO
 f=$(find $O/prof_resnet -name "*kernel_stats.csv" | head -1); echo $f; head -25 $f | cut -c1-200
 echo "total $(( $(date +%s) - t0 )) s"
