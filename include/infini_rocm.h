@@ -166,8 +166,9 @@ int infini_rocm_graph_destroy(infiniRocmGraph_t graph);
 /*   dtype F16 / BF16: v_mfma_f32_16x16x32_{f16,bf16}, fp32 accumulate, one rounding on store.  */
 /*   act: 0 none, 1 relu, 2 sigmoid, 3 tanh (reference ActType, include/core/common.h), 4 gelu  */
 /*   (erf form, erff), 5 gelu for 16-bit outputs: erf by a clamped odd polynomial, no            */
-/*   transcendentals, abs error < 2^-12 (what the runtime's MatMul -> Gelu fusion uses for f16  */
-/*   / bf16 outputs; an fp32 caller wants 4); the                                               */
+/*   transcendentals, ABSOLUTE error < 2^-12 — NOT a relative bound in the negative tail, see   */
+/*   INFINI_UN_GELU (what the runtime's MatMul -> Gelu fusion uses for f16 / bf16 outputs; an   */
+/*   fp32 caller wants 4); the                                                                  */
 /*   reference CUDA kernel ignores it — the plugin passes 0 to stay op-for-op identical).       */
 /* ------------------------------------------------------------------------------------------ */
 int infini_rocm_matmul(infiniRocmRuntime_t rt, int dtype, const void *a, const void *b,
@@ -347,7 +348,12 @@ typedef enum {
     INFINI_UN_TANH = 2,
     INFINI_UN_ABS = 3,
     INFINI_UN_SQRT = 4,
-    INFINI_UN_GELU = 5,       /* 0.5 x (1 + erf(x / sqrt 2)) */
+    INFINI_UN_GELU = 5,       /* 0.5 x (1 + erf(x / sqrt 2)). fp32: erff. f16 / bf16: erf by the clamped odd polynomial the GEMM epilogue
+                               * uses (act 5 of infini_rocm_matmul) so that MatMul -> Gelu is bit-identical fused or not: ABSOLUTE error
+                               * < 2^-12 (1.96e-4) everywhere — below half an ulp of the stored 16-bit value for |gelu(x)| >= 0.25, but
+                               * a growing RELATIVE error in the negative tail, where gelu(x) itself shrinks towards that bound: <= 0.3 % on
+                               * [-2, -1], <= 2.5 % on [-3, -2], <= 12 % on [-3.5, -3], of the order of the value itself below -3.5 (true
+                               * value -8e-4 .. -1.3e-4) and exactly 0 from x <= -4 on. A caller that needs the tail takes the fp32 form. */
     INFINI_UN_SILU = 6,
     INFINI_UN_NEG = 7,
     INFINI_UN_ERF = 8,
