@@ -374,7 +374,7 @@ extern "C" int infini_rocm_attention_kvcache(infiniRocmRuntime_t rt, int dtype, 
         G = 64;
     if (const char *force = getenv("IROCM_KVCACHE_SPLIT")) { // test hook (read per call): force G; 0 = the element-wise one-workgroup kernel
         const int vforce = atoi(force);
-        G = vforce;
+        G = vforce < 0 ? 0 : (vforce > 64 ? 64 : vforce); // (the merge kernel holds 64 chunk weights)
     }
     // (512-thread workgroups — 32 key groups, 128 keys per iteration — were measured: 18.8 us at B x H = 32, 4096 keys with either size.
     // So was the merge inside the split kernel — the workgroup that bumps a per-(batch, head) counter to G merges, with agent-scope

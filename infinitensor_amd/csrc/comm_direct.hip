@@ -498,8 +498,40 @@ struct DirectHello {
     char magic[8];
     int world, rank, grid, pid;
     unsigned long long cap;
+    // job: a hash of what the launcher gives every rank of ONE job (INFINI_ROCM_JOB_ID, else torchrun's TORCHELASTIC_RUN_ID, else
+    // MASTER_ADDR:MASTER_PORT), 0 when the environment holds none of them — a file with another job's value is a stale file.
+    // proc: a random token drawn once per process — "this file was written by ME" without comparing PIDs, which mean nothing
+    // across PID namespaces (containers sharing the rendezvous directory).
+    unsigned long long job, proc;
     hipIpcMemHandle_t handle;
 };
+
+static unsigned long long fnv1a(const std::string &v) {
+    unsigned long long h = 1469598103934665603ull;
+    for (unsigned char c : v)
+        h = (h ^ c) * 1099511628211ull;
+    return h ? h : 1ull;
+}
+static unsigned long long job_nonce() {
+    if (const char *v = std::getenv("INFINI_ROCM_JOB_ID"))
+        return fnv1a(std::string("id:") + v);
+    if (const char *v = std::getenv("TORCHELASTIC_RUN_ID"))
+        return fnv1a(std::string("run:") + v);
+    const char *a = std::getenv("MASTER_ADDR"), *p = std::getenv("MASTER_PORT");
+    if (a && p)
+        return fnv1a(std::string("master:") + a + ":" + p);
+    return 0ull;
+}
+static unsigned long long proc_token() {
+    static const unsigned long long tok = [] {
+        unsigned long long v = 0;
+        std::ifstream ur("/dev/urandom", std::ios::binary);
+        ur.read((char *)&v, sizeof(v));
+        v ^= (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() * 0x9e3779b97f4a7c15ull ^ (unsigned long long)getpid();
+        return v ? v : 1ull;
+    }();
+    return tok;
+}
 
 static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
@@ -555,8 +587,9 @@ int direct_init(infiniRocmRuntime *rt, const char *name, int world, int rank) {
     dc->args.base[rank] = (char *)dc->block;
     if (world > 1) {
         DirectHello me{};
-        memcpy(me.magic, "IROCMXG1", 8);
+        memcpy(me.magic, "IROCMXG2", 8);
         me.world = world, me.rank = rank, me.grid = kDGrid, me.pid = (int)getpid(), me.cap = cap;
+        me.job = job_nonce(), me.proc = proc_token();
         if ((e = hipIpcGetMemHandle(&me.handle, dc->block)) != hipSuccess)
             return fail(INFINI_ROCM_HIP_ERROR, std::string("direct transport: hipIpcGetMemHandle failed: ") + hipGetErrorString(e) +
                                                    " (is HSA_ENABLE_IPC_MODE_LEGACY=0 exported?)");
@@ -584,18 +617,27 @@ int direct_init(infiniRocmRuntime *rt, const char *name, int world, int rank) {
             DirectHello peer{};
             std::ifstream ifs(path(r), std::ios::binary);
             ifs.read((char *)&peer, sizeof(peer));
-            if (peer.pid == (int)getpid())
-                return fail(INFINI_ROCM_UNSUPPORTED, "direct transport: rank " + std::to_string(r) + " lives in THIS process; an IPC handle cannot be "
-                                                     "opened by its exporter (one process per rank; ranks may share a device)");
-            if (kill((pid_t)peer.pid, 0) != 0 && errno == ESRCH) { // a stale file of a crashed job: its writer is gone — wait for the real one
+            // "not (yet) the file of my peer" — retried until the time limit, never an immediate failure: a short read (the peer
+            // unlinked its own stale file between my stat() and my read, or the read raced a replace), a foreign magic, another
+            // job's nonce, and — only when the launcher gave no nonce — a writer PID that no longer exists in MY PID namespace.
+            const bool whole = ifs.gcount() == (std::streamsize)sizeof(peer) && memcmp(peer.magic, "IROCMXG2", 8) == 0;
+            const bool other_job = whole && peer.job != me.job;
+            const bool dead_writer = whole && me.job == 0ull && peer.proc != me.proc && kill((pid_t)peer.pid, 0) != 0 && errno == ESRCH;
+            if (!whole || other_job || dead_writer) {
                 if (std::chrono::steady_clock::now() > begin + std::chrono::seconds(120))
-                    return fail(INFINI_ROCM_RCCL_ERROR, "direct transport: " + path(r) + " was written by a process that no longer exists");
+                    return fail(INFINI_ROCM_RCCL_ERROR, "direct transport: " + path(r) +
+                                                            (!whole ? " never became a complete rendezvous record"
+                                                                    : other_job ? " belongs to another job (stale file?)"
+                                                                                : " was written by a process that no longer exists"));
                 std::this_thread::sleep_for(std::chrono::milliseconds(50));
                 --r;
                 continue;
             }
-            if (memcmp(peer.magic, "IROCMXG1", 8) || peer.world != world || peer.rank != r || peer.grid != kDGrid || peer.cap != cap)
-                return fail(INFINI_ROCM_RCCL_ERROR, "direct transport: " + path(r) + " does not match this job (stale file or different settings)");
+            if (peer.proc == me.proc)
+                return fail(INFINI_ROCM_UNSUPPORTED, "direct transport: rank " + std::to_string(r) + " lives in THIS process; an IPC handle cannot be "
+                                                     "opened by its exporter (one process per rank; ranks may share a device)");
+            if (peer.world != world || peer.rank != r || peer.grid != kDGrid || peer.cap != cap)
+                return fail(INFINI_ROCM_RCCL_ERROR, "direct transport: " + path(r) + " does not match this job (different settings)");
             if ((e = hipIpcOpenMemHandle(&dc->opened[r], peer.handle, hipIpcMemLazyEnablePeerAccess)) != hipSuccess)
                 return fail(INFINI_ROCM_HIP_ERROR, std::string("direct transport: hipIpcOpenMemHandle(rank ") + std::to_string(r) + ") failed: " +
                                                        hipGetErrorString(e));

@@ -158,6 +158,14 @@ struct infiniRocmRuntime {
     // zeroed at creation, every kernel leaves them zero (each word's single consumer resets it)
     unsigned *sync_flags = nullptr;
     static constexpr size_t kSyncFlagWords = 32768;
+    // A wait on such a flag is bounded (2 s): a partner that never shows up ends the kernel with wrong sums instead of a hung GPU.
+    // The waiting wave then sets this word — pinned HOST memory mapped into the device, so infini_rocm_runtime_sync reads it
+    // without a copy — and the sync that follows fails, re-zeroes every flag (the late producer may still have set one) and clears it.
+    // The residency argument behind these exchanges (grid <= CUs, so every slice of a tile is running) holds for kernels of ONE
+    // stream; a kernel that spins on another stream (comm_stream's direct-transport collectives, side_stream packs do not spin)
+    // can hold the CUs a slice needs — that is what the time limit and this word are for.
+    volatile unsigned *sync_err_host = nullptr; // host view
+    unsigned *sync_err_dev = nullptr;           // device view of the same word
     int num_cu = 256;
     void *comm = nullptr; // rcclComm_t, owned by comm.hip
     void *dcomm = nullptr; // irocm::DirectComm (the hand-written IPC / xGMI transport), owned by comm_direct.hip

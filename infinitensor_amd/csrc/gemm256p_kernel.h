@@ -30,6 +30,14 @@
 #pragma once
 #include "gemm256_common.h"
 
+// K-loop schedule variant of the plain-GEMM instantiations (round 6 A/B, tools/gemm_kv_ab.sh builds one library per value; the conv /
+// tap modes always run variant 0). Where the LDS-DMA pieces of a LOAD phase are issued relative to its fragment reads:
+//   0  reads, DMA, lgkm wait, barrier (rounds 2-5)        1  DMA, reads, wait, barrier
+//   2  reads, wait, DMA, barrier                           3  reads and DMA pieces interleaved (8 reads : 2 pieces)
+#ifndef IROCM_KV
+#define IROCM_KV 0
+#endif
+
 namespace irocm {
 namespace g256p {
 using namespace g256;
@@ -73,6 +81,15 @@ __device__ __forceinline__ void stage_n(const char *ubase, const unsigned (&off)
                                          IROCM_LDS_PTR(lds_oper + (w * CNT + i) * 1024), 16, 0, 0);
 }
 
+// pieces I0 .. I1 - 1 of a wave's CNT (interleaved issue: variant 3)
+template <int CNT, int I0, int I1>
+__device__ __forceinline__ void stage_part(const char *ubase, const unsigned (&off)[4], char *lds_oper, int w) {
+#pragma unroll
+    for (int i = I0; i < I1 && i < CNT; ++i)
+        __builtin_amdgcn_global_load_lds(IROCM_GLB_PTR(ubase + (unsigned long)off[i]),
+                                         IROCM_LDS_PTR(lds_oper + (w * CNT + i) * 1024), 16, 0, 0);
+}
+
 struct PArgs {
     GemmArgs g;
     int total_tiles; // tiles_m * tiles_n * batch
@@ -87,6 +104,7 @@ struct PArgs {
     char *slab;       // [tile][source slice][wave][row block][column tile][lane] x 16 bytes
     unsigned slab_bytes;
     unsigned *flags;  // [tile][source slice][destination slice][wave]: zero between launches (the consumer resets its flag)
+    unsigned *err;    // set (system scope: pinned host memory) by a wave whose bounded wait on a flag ran out — infiniRocmRuntime::sync_err_host
 };
 
 constexpr int kTraceSlots = 128;
@@ -263,14 +281,18 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     // 64-K-tile headline 2 %. B crosses in an L2 and waits for the C1 of the next K-tile (its next DMA is that K-tile's L2).
     int pend = 0; // bit 0: A, bit 1: B
     unsigned a_ent = 0u, b_ent = 0u;
-    auto stage_a_next = [&](int buf, auto directc) __attribute__((always_inline)) {
-        if constexpr (TAPS) {
+    auto stage_a_next = [&](int buf, auto directc, auto issuec) __attribute__((always_inline)) { // issuec false: advance the cursor only
+        constexpr bool ISSUE = decltype(issuec)::value;
+        if constexpr (!ISSUE) {
+        } else if constexpr (TAPS) {
             stage4(a_base + ((long)a_t * p.cv_atap + (long)a_cb * (BK * 2)), a_off, smem + buf * BUF_BYTES, w);
+        } else {
+            if (!(TRACE && (pa.trace_fine == 2 || pa.trace_fine == 3))) // (experiment: trace_fine 2 = no A DMA, 3 = no DMA at all — timing only)
+                stage4(a_base + (long)a_kt * a_step, a_off, smem + buf * BUF_BYTES, w);
+        }
+        if constexpr (TAPS) {
             a_cb += a_t == 8 ? 1 : 0;
             a_t = a_t == 8 ? 0 : a_t + 1;
-        } else {
-            if (!(TRACE && pa.trace_fine >= 2)) // (experiment: trace_fine 2 = no A DMA, 3 = no DMA at all — timing only)
-                stage4(a_base + (long)a_kt * a_step, a_off, smem + buf * BUF_BYTES, w);
         }
         ++a_G;
         if (++a_kt == nk) {
@@ -287,15 +309,19 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
             }
         }
     };
-    auto stage_b_next = [&](int buf, auto directc) __attribute__((always_inline)) {
-        if constexpr (TAPS) {
+    auto stage_b_next = [&](int buf, auto directc, auto issuec) __attribute__((always_inline)) {
+        constexpr bool ISSUE = decltype(issuec)::value;
+        if constexpr (!ISSUE) {
+        } else if constexpr (TAPS) {
             stage_n<NB>(b_base + (long)b_koff, b_off, smem + buf * BUF_BYTES + OPER_BYTES, w);
+        } else {
+            if (!(TRACE && (pa.trace_fine == 3)))
+                stage_n<NB>(b_base + (long)b_kt * b_step, b_off, smem + buf * BUF_BYTES + OPER_BYTES, w);
+        }
+        if constexpr (TAPS) {
             // the step from tap b_t to the next one (tap = 3 r + s): s 0 -> 1, s 1 -> 2, row ends, the block's last tap
             b_koff += b_delta(b_t);
             b_t = b_t == 8 ? 0 : b_t + 1;
-        } else {
-            if (!(TRACE && pa.trace_fine >= 3))
-                stage_n<NB>(b_base + (long)b_kt * b_step, b_off, smem + buf * BUF_BYTES + OPER_BYTES, w);
         }
         ++b_G;
         if (++b_kt == nk) {
@@ -333,10 +359,10 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     stamp();
     set_a_tile(0);
     set_b_tile(0);
-    stage_b_next(0, std::true_type{});
-    stage_a_next(0, std::true_type{});
+    stage_b_next(0, std::true_type{}, std::true_type{});
+    stage_a_next(0, std::true_type{}, std::true_type{});
     if (total_kt > 1)
-        stage_b_next(1, std::true_type{});
+        stage_b_next(1, std::true_type{}, std::true_type{});
     // the tile table: thread s decodes step s (under the round trip of the loads above; published by the barrier in front of the loop)
     if (t < my_tiles && t < tab_n) {
         int ib, m0, n0;
@@ -1068,8 +1094,11 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
             const long long t0 = (long long)wall_clock64();
             while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                 __builtin_amdgcn_s_sleep(2);
-                if ((long long)wall_clock64() - t0 > 200000000ll) // 2 s at 100 MHz: a lost partner ends as wrong numbers, not as a hung GPU
+                if ((long long)wall_clock64() - t0 > 200000000ll) { // 2 s at 100 MHz: a lost partner ends as wrong numbers, not as a hung GPU —
+                    if (lane_o == 0 && pa.err)                     // and as an error at the next infini_rocm_runtime_sync (which re-zeroes the flags)
+                        __hip_atomic_store(pa.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     break;
+                }
             }
             stamp(); // (TRACE: this source's flag seen)
             if (S == 2) take(std::integral_constant<int, 4>{}, src); // (the launcher admits 2 and 4)
@@ -1111,18 +1140,49 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
             });
         }
     };
+    constexpr int KV = (CONV == 0) ? IROCM_KV : 0;
+    auto fine_stamp = [&]() __attribute__((always_inline)) { // (TRACE, IROCM_GEMM_TRACE_FINE=4: two extra stamps inside each LOAD phase)
+        if constexpr (TRACE) { if (pa.trace_fine == 4) stamp(); }
+    };
     auto ktile = [&](int buf, auto zeroc) {
         // L1
         stamp();
-        read_b(I0{}, I2{}, bq0);
-        if constexpr (NJ1 > 0) read_b(I1{}, IJ1{}, bq1);
-        read_a(I0{}, aq);
-        if (a_G < total_kt)
-            stage_a_next(buf ^ 1, std::false_type{});
+        if constexpr (KV == 1) {
+            if (a_G < total_kt)
+                stage_a_next(buf ^ 1, std::false_type{}, std::true_type{});
+        }
+        if constexpr (KV == 3) {
+            // 8 B reads | A pieces 0, 1 | 8 B reads | A pieces 2, 3 | 8 A reads
+            const bool more = a_G < total_kt;
+            char *dst = smem + (buf ^ 1) * BUF_BYTES;
+            const char *src = a_base + (long)a_kt * a_step;
+            read_b(I0{}, I2{}, bq0);
+            if (more) stage_part<4, 0, 2>(src, a_off, dst, w);
+            if constexpr (NJ1 > 0) read_b(I1{}, IJ1{}, bq1);
+            if (more) stage_part<4, 2, 4>(src, a_off, dst, w);
+            read_a(I0{}, aq);
+            if (more) stage_a_next(buf ^ 1, std::false_type{}, std::false_type{}); // (cursor only)
+        } else {
+            read_b(I0{}, I2{}, bq0);
+            if constexpr (NJ1 > 0) read_b(I1{}, IJ1{}, bq1);
+            read_a(I0{}, aq);
+        }
+        if constexpr (KV == 0) {
+            if (a_G < total_kt)
+                stage_a_next(buf ^ 1, std::false_type{}, std::true_type{});
+        }
+        fine_stamp();
         wait_lgkm0();
+        if constexpr (KV == 2) {
+            if (a_G < total_kt) {
+                stage_a_next(buf ^ 1, std::false_type{}, std::true_type{});
+                wait_lgkm0(); // (a cursor that crossed into the next tile asked for its table entry: finish_cursors reads it in C1)
+            }
+        }
+        fine_stamp();
         barrier();
         // C1
-        if constexpr (TRACE) { if (pa.trace_fine == 1) stamp(); }
+        if constexpr (TRACE) { if (pa.trace_fine == 1 || pa.trace_fine == 4) stamp(); }
         __builtin_amdgcn_s_setprio(1);
         mask_b(I0{}, I2{}, bq0); // (tap mode; hipcc spreads the ANDs of the later fragments between the first MFMAs)
         if constexpr (NJ1 > 0) mask_b(I1{}, IJ1{}, bq1);
@@ -1143,28 +1203,57 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         }
         __builtin_amdgcn_s_setprio(0);
         fence_sched();
-        if constexpr (TRACE) { if (pa.trace_fine == 1) stamp(); }
+        if constexpr (TRACE) { if (pa.trace_fine == 1 || pa.trace_fine == 4) stamp(); }
         finish_cursors(); // (issues behind the MFMA burst, which is still executing)
         barrier();
         // L2
         stamp();
-        read_a(I1{}, aq);
-        flip_buf(buf ? -BUF_BYTES : BUF_BYTES); // every read of this K-tile is issued
-        if (b_G < total_kt) {
-            stage_b_next(buf, std::false_type{});
-            wait_vm<NB>(); // everything older than these NB loads has landed (C stores of a previous tile included)
-        } else {
-            wait_vm<0>();
+        const bool b_more = b_G < total_kt; // (a B tile is issued in this phase)
+        if constexpr (KV == 1) {
+            if (b_more)
+                stage_b_next(buf, std::false_type{}, std::true_type{});
         }
-        wait_lgkm0();
+        if constexpr (KV == 3) {
+            // 4 A reads | B pieces 0, 1 | 4 A reads | B pieces 2, 3  (read_a issues i-major: the first four reads are rows 0, 1)
+            const bool more = b_more;
+            char *dst = smem + buf * BUF_BYTES + OPER_BYTES;
+            const char *src = b_base + (long)b_kt * b_step;
+            if (more) stage_part<NB, 0, 2>(src, b_off, dst, w);
+            read_a(I1{}, aq);
+            if (more) stage_part<NB, 2, 4>(src, b_off, dst, w);
+            if (more) stage_b_next(buf, std::false_type{}, std::false_type{}); // (cursor only)
+        } else {
+            read_a(I1{}, aq);
+        }
+        flip_buf(buf ? -BUF_BYTES : BUF_BYTES); // every read of this K-tile is issued
+        if constexpr (KV == 0) {
+            if (b_more)
+                stage_b_next(buf, std::false_type{}, std::true_type{});
+        }
+        fine_stamp();
+        if constexpr (KV == 2) {
+            wait_lgkm0();
+            if (b_more) {
+                stage_b_next(buf, std::false_type{}, std::true_type{});
+                wait_vm<NB>();
+                wait_lgkm0();
+            } else {
+                wait_vm<0>();
+            }
+        } else {
+            if (b_more) wait_vm<NB>(); // everything older than these NB loads has landed (C stores of a previous tile included)
+            else wait_vm<0>();
+            wait_lgkm0();
+        }
+        fine_stamp();
         barrier();
         // C2
-        if constexpr (TRACE) { if (pa.trace_fine == 1) stamp(); }
+        if constexpr (TRACE) { if (pa.trace_fine == 1 || pa.trace_fine == 4) stamp(); }
         __builtin_amdgcn_s_setprio(1);
         if constexpr (NJ1 > 0) compute(I1{}, I1{}, IJ1{}, zeroc, aq, bq1);
         compute(I1{}, I0{}, I2{}, zeroc, aq, bq0);
         __builtin_amdgcn_s_setprio(0);
-        if constexpr (TRACE) { if (pa.trace_fine == 1) stamp(); }
+        if constexpr (TRACE) { if (pa.trace_fine == 1 || pa.trace_fine == 4) stamp(); }
         if constexpr (TAPS)
             c_t = c_t == 8 ? 0 : c_t + 1;
         barrier();
@@ -1284,7 +1373,7 @@ static int launch_p(infiniRocmRuntime_t rt, GemmArgs g, bool akm, bool bkm, unsi
     PArgs pa;
     pa.trace = trace;
     pa.trace_fine = (TRACE && getenv("IROCM_GEMM_TRACE_FINE")) ? atoi(getenv("IROCM_GEMM_TRACE_FINE")) : 0;
-    pa.split = 1; pa.slab = nullptr; pa.slab_bytes = 0; pa.flags = nullptr;
+    pa.split = 1; pa.slab = nullptr; pa.slab_bytes = 0; pa.flags = nullptr; pa.err = nullptr;
     constexpr int kLds = LDS_BYTES + (TRACE ? kTraceBytes : 0) + kExtraLds;
     if (!(g.act == 0 || g.act == 1 || g.act == 5) || (g.bias && !(g.bias_m == 0 && g.bias_n == 1)))
         IROCM_FAIL(INFINI_ROCM_UNSUPPORTED, "gemm256p: activation %d / this bias layout is not served by the persistent kernels", g.act);
@@ -1338,7 +1427,7 @@ static int launch_p_conv(infiniRocmRuntime_t rt, GemmArgs g, int split = 1, char
     PArgs pa;
     pa.trace = trace;
     pa.trace_fine = 0;
-    pa.split = TAPS ? split : 1; pa.slab = slab; pa.slab_bytes = (unsigned)slab_bytes; pa.flags = flags;
+    pa.split = TAPS ? split : 1; pa.slab = slab; pa.slab_bytes = (unsigned)slab_bytes; pa.flags = flags; pa.err = rt->sync_err_dev;
     g.tiles_m = (int)ceil_div(g.m, BM);
     g.tiles_n = (int)ceil_div(g.n, 64 * NT);
     const long total = (long)g.tiles_m * g.tiles_n;

@@ -799,11 +799,11 @@ int infini_rocm_strided_copy_multi(infiniRocmRuntime_t rt, int count, const void
     if (count == 0 || rows == 0)
         return INFINI_ROCM_OK;
     IROCM_CHECK_ARG(srcs && dsts && row_bytes && src_pitch && dst_pitch, "strided_copy_multi: NULL argument");
-    for (int base = 0; base < count; base += kCopySegs) { // (more than kCopySegs segments: one launch per kCopySegs)
+    for (int i = 0; i < count;) { // (more than kCopySegs non-empty segments: one launch per kCopySegs; `i` runs across the launches)
         MultiCopyArgs a;
         int n = 0, w = 16;
         long max_items = 0;
-        for (int i = base; i < count && n < kCopySegs; ++i) {
+        for (; i < count && n < kCopySegs; ++i) {
             IROCM_CHECK_ARG(row_bytes[i] >= 0, "strided_copy_multi: negative extent");
             if (row_bytes[i] == 0)
                 continue; // (an empty Concat input: the reference accepts it, test_cuda_concat.cc:160-190)

@@ -68,30 +68,33 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const T *__restrict__ 
 }
 
 // Sum of the n 16-bit elements e0 .. e0 + n - 1 of a span staged in LDS (4-byte aligned base), fp32 accumulation: two elements per
-// LDS read and ONE instruction per pair — v_dot2c_f32_{f16,bf16}(word, weights, s) adds both halves of a word to the fp32 sum; weights
-// (1, 1) inside the row, (0, 1) / (1, 0) for the word a row shares with its neighbour.
+// LDS read and ONE instruction per pair — v_dot2c_f32_{f16,bf16}(word, (1, 1), s) adds both halves of a word to the fp32 sum. The word a
+// row shares with its neighbour (or, at the very end of an odd span, with bytes nobody wrote) has the FOREIGN half cleared in the DATA
+// (+0.0), not in the weights: 0 x Inf / NaN is NaN, so a zero weight would let a neighbour's -inf mask or the stale LDS bits behind the
+// span poison this row's sum.
 template <typename T> __device__ __forceinline__ float row_sum16(const unsigned *words, int e0, int n) {
     constexpr unsigned kOne = std::is_same<T, __half>::value ? 0x3c00u : 0x3f80u;
-    auto dot = [](unsigned word, unsigned wgt, float acc) {
+    constexpr unsigned kOnes = kOne | (kOne << 16);
+    auto dot = [kOnes](unsigned word, float acc) {
         if constexpr (std::is_same<T, __half>::value) {
             typedef _Float16 h2_ __attribute__((ext_vector_type(2)));
-            return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_, word), __builtin_bit_cast(h2_, wgt), acc, false);
+            return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_, word), __builtin_bit_cast(h2_, kOnes), acc, false);
         } else {
             typedef __bf16 b2_ __attribute__((ext_vector_type(2)));
-            return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2_, word), __builtin_bit_cast(b2_, wgt), acc, false);
+            return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2_, word), __builtin_bit_cast(b2_, kOnes), acc, false);
         }
     };
     const int e1 = e0 + n - 1;
     const int w0 = e0 >> 1, w1 = e1 >> 1;
-    const unsigned first = (e0 & 1) ? (kOne << 16) : (kOne | (kOne << 16)); // a row starting on an odd element owns the high half only
-    const unsigned last = (e1 & 1) ? (kOne | (kOne << 16)) : kOne;          // a row ending on an even element owns the low half only
+    const unsigned first = (e0 & 1) ? 0xffff0000u : 0xffffffffu; // a row starting on an odd element owns the high half only
+    const unsigned last = (e1 & 1) ? 0xffffffffu : 0x0000ffffu;  // a row ending on an even element owns the low half only
     float s = 0.f;
     if (w0 == w1)
-        return dot(words[w0], first & last, s);
-    s = dot(words[w0], first, s);
+        return dot(words[w0] & first & last, s);
+    s = dot(words[w0] & first, s);
     for (int w = w0 + 1; w < w1; ++w)
-        s = dot(words[w], kOne | (kOne << 16), s);
-    return dot(words[w1], last, s);
+        s = dot(words[w], s);
+    return dot(words[w1] & last, s);
 }
 
 // ---- Reduce: trailing dims reduced, SHORT rows (n < 64: the 7 x 7 planes of a global average pool written as ReduceMean) --

@@ -123,11 +123,14 @@ int infini_rocm_runtime_create(int device, infiniRocmRuntime_t *out) {
     rt->stream = rt->own_stream;
     if (hipMalloc(&rt->zeros, 256) != hipSuccess || hipMemset(rt->zeros, 0, 256) != hipSuccess ||
         hipMalloc((void **)&rt->sync_flags, infiniRocmRuntime::kSyncFlagWords * 4) != hipSuccess ||
-        hipMemset(rt->sync_flags, 0, infiniRocmRuntime::kSyncFlagWords * 4) != hipSuccess) {
+        hipMemset(rt->sync_flags, 0, infiniRocmRuntime::kSyncFlagWords * 4) != hipSuccess ||
+        hipHostMalloc((void **)&rt->sync_err_host, 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&rt->sync_err_dev, (void *)rt->sync_err_host, 0) != hipSuccess) {
         (void)hipStreamDestroy(rt->own_stream);
         delete rt;
         IROCM_FAIL(INFINI_ROCM_HIP_ERROR, "cannot allocate the runtime's zero block");
     }
+    *rt->sync_err_host = 0u;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess)
         rt->num_cu = prop.multiProcessorCount;
@@ -161,6 +164,8 @@ int infini_rocm_runtime_destroy(infiniRocmRuntime_t rt) {
         (void)hipFree(rt->zeros);
     if (rt->sync_flags)
         (void)hipFree(rt->sync_flags);
+    if (rt->sync_err_host)
+        (void)hipHostFree((void *)rt->sync_err_host);
     if (rt->own_stream)
         (void)hipStreamDestroy(rt->own_stream);
     delete rt;
@@ -211,6 +216,18 @@ int infini_rocm_runtime_sync(infiniRocmRuntime_t rt) {
         IROCM_HIP(hipStreamSynchronize(rt->comm_stream));
     // the hand-written transport's kernels give up after a time limit instead of hanging and leave an error word: the first sync
     // behind such a collective reports it (RCCL error code) — nothing else would, and the tensors are garbage (round-4 advisor)
+    // in-launch exchanges (split-K of the conv tap GEMM): a wave whose partner slice did not arrive within the time limit left this
+    // word set; the sums of that launch are wrong and a late producer may have left a flag set — re-zero them all, report once
+    if (rt->sync_err_host && *rt->sync_err_host) {
+        *rt->sync_err_host = 0u;
+        IROCM_HIP(hipMemsetAsync(rt->sync_flags, 0, infiniRocmRuntime::kSyncFlagWords * 4, rt->stream));
+        IROCM_HIP(hipStreamSynchronize(rt->stream));
+        if (rt->dcomm && rt->dcomm_dirty)
+            (void)irocm::direct_check(rt);
+        IROCM_FAIL(INFINI_ROCM_HIP_ERROR, "split-K exchange: a partner workgroup did not arrive within the time limit (the outputs of the "
+                                          "launches since the last sync are undefined; flags re-zeroed, error cleared). Kernels spinning on "
+                                          "another stream can cause this: do not overlap direct-transport collectives with split-K convolutions");
+    }
     if (rt->dcomm && rt->dcomm_dirty)
         return irocm::direct_check(rt);
     return INFINI_ROCM_OK;

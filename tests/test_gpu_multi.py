@@ -67,8 +67,12 @@ def test_direct_transport_collectives_on_one_device(world, tmp_path):
     test_cuda_sendrecv.cc:50-87, test_nccl_comm.cc:37-52) through the C ABI and through the reference executor + plugin, plus
     the transport's own stress cases (bit-exact integer sums vs the oracle, multi-piece messages, odd counts, back-to-back
     calls, broadcast roots in a row, a send / recv ring): the first non-identity reduction evidence on a one-GPU box."""
-    outs = launch(world, REPO / "tests" / "_rccl_worker.py", tmp_path, timeout=900,
-                  extra_env={"INFINI_ROCM_COMM": "direct", "IROCM_WORKER_SHARED_DEVICE": "1", "INFINI_ROCM_DIRECT_TIMEOUT_S": "60"})
+    # world 2 also runs the chunked, overlapped MatMul -> AllReduceSum plan (INFINI_ROCM_TP_OVERLAP=1: opt-in since round 6); worlds 4
+    # and 8 run the default plan, whose assertion in the worker is ONE all-reduce per row-parallel GEMM at this size
+    extra = {"INFINI_ROCM_COMM": "direct", "IROCM_WORKER_SHARED_DEVICE": "1", "INFINI_ROCM_DIRECT_TIMEOUT_S": "60"}
+    if world == 2:
+        extra["INFINI_ROCM_TP_OVERLAP"] = "1"
+    outs = launch(world, REPO / "tests" / "_rccl_worker.py", tmp_path, timeout=900, extra_env=extra)
     for r, so in enumerate(outs):
         res = json.loads([ln for ln in so.splitlines() if ln.startswith("RESULT ")][-1][7:])
         assert res["rank"] == r and res["world"] == world

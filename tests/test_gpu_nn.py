@@ -281,6 +281,53 @@ def test_reduce_vs_oracle(rt, shape, axes, dt):
         assert np.allclose(host(y), want, rtol=tol, atol=tol * max(1.0, np.sqrt(x.size / want.size)))
 
 
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("rows,n", [(5, 7), (301, 49), (3, 63), (9, 5)])  # odd rows * n: the span ends on a half word
+def test_reduce_short_rows_inf_stays_in_its_own_row(rt, rows, n, dt):
+    """16-bit short-row sums read two elements per LDS word; the word a row shares with its neighbour must contribute the row's own
+    half only — a neighbour's +-Inf / NaN (an attention mask, an f16 overflow) may not reach this row's sum (0 x Inf = NaN), and the
+    stale half word behind an odd span may not reach the last row's."""
+    rng = np.random.default_rng(rows * 100 + n)
+    x = rng.standard_normal((rows, n)).astype(np.float32)
+    x[1, 0] = np.inf      # first element of row 1: shares its word with row 0's last element when n is odd
+    x[1, n - 1] = -np.inf if rows > 3 else np.inf  # last element of row 1: shares with row 2's first
+    if rows > 4:
+        x[4, n // 2] = np.nan
+    for kind in ("sum", "mean"):
+        # run twice behind a launch that leaves Inf patterns in LDS-sized scratch: the stale-half case must not depend on luck
+        for _ in range(2):
+            junk = ops.reduce(rt, "sum", dev(np.full((rows + 1, n + 1), np.inf, dtype=np.float32), TD[dt]), [1], keepdims=True)
+            y = host(ops.reduce(rt, kind, dev(x, TD[dt]), [1], keepdims=True)).ravel()
+            del junk
+            want = R.reduce(kind, R.round_to(x, dt), [1], True).ravel()
+            fin = np.isfinite(want)
+            assert not fin[1] and (rows <= 4 or not fin[4])
+            assert np.array_equal(np.isnan(y), np.isnan(want)) and np.array_equal(np.isinf(y), np.isinf(want)), (kind, y, want)
+            assert np.array_equal(np.sign(y[np.isinf(y)]), np.sign(want[np.isinf(want)]))
+            tol = {"f16": 2e-3, "bf16": 1.6e-2}[dt]
+            assert np.allclose(y[fin], want[fin], rtol=tol, atol=tol * np.sqrt(n)), kind
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_global_avgpool_small_planes_inf_stays_in_its_own_plane(rt, dt):
+    """The same shared-word rule in the small-plane global average pool (7 x 7 planes are 49 elements: every other plane starts on an
+    odd element); 3 x 5 x 7 x 7 = an odd element count, so the last plane's last word is half foreign."""
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((3, 5, 7, 7)).astype(np.float32)
+    x[0, 1, 0, 0] = np.inf
+    x[0, 1, 6, 6] = np.inf
+    x[2, 3, 3, 3] = -np.inf
+    for _ in range(2):
+        y = host(ops.avg_pool(rt, dev(x, TD[dt]), 7, 7, 1, 1, 0, 0, 1, 1, 0)).ravel()
+        want = R.pool2d(R.round_to(x, dt), "avg", 7, 7, 1, 1, 0, 0, 1, 1, 0).ravel()
+        fin = np.isfinite(want)
+        assert fin.sum() == 13
+        assert np.array_equal(np.isinf(y), np.isinf(want)) and not np.isnan(y).any(), (y, want)
+        assert np.array_equal(np.sign(y[~fin]), np.sign(want[~fin]))
+        tol = {"f16": 2e-3, "bf16": 1.6e-2}[dt]
+        assert np.allclose(y[fin], want[fin], rtol=tol, atol=tol)
+
+
 def test_batchnorm_reference_kat(rt):
     f = CU + "test_cuda_batch_norm.cc"
     y = ops.batch_norm(rt, dev(R.incremental((1, 3, 2, 2))), dev(kat(f, 25, "float").astype(np.float32)),
