@@ -34,6 +34,8 @@
 // tap modes always run variant 0). Where the LDS-DMA pieces of a LOAD phase are issued relative to its fragment reads:
 //   0  reads, DMA, lgkm wait, barrier (rounds 2-5)        1  DMA, reads, wait, barrier
 //   2  reads, wait, DMA, barrier                           3  reads and DMA pieces interleaved (8 reads : 2 pieces)
+//   4  = 0 with the accumulators in AGPRs                  6  NO DMA in the K loop (wrong sums: timing-only ablation)
+//   7  = 0 with a static s_setprio 1 for wave row 1 instead of per-phase flips      8  = 0 without any s_setprio
 #ifndef IROCM_KV
 #define IROCM_KV 0
 #endif
@@ -1141,17 +1143,25 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         }
     };
     constexpr int KV = (CONV == 0) ? IROCM_KV : 0;
+    if constexpr (KV == 4 || KV == 5) {
+        // variant 4: accumulators in AGPRs. hipcc selects the VGPR form of the MFMAs when a kernel is limited to 256 registers and
+        // never mentions an AGPR; one empty asm with an "a" operand flips that (SIMachineFunctionInfo: mayUseAGPRs) — the question being
+        // whether C / D traffic in the accumulator half of the file stops competing with the LDS returns for the arch-VGPR ports.
+        int agpr_probe = 0;
+        asm volatile("" : "+a"(agpr_probe));
+    }
     auto fine_stamp = [&]() __attribute__((always_inline)) { // (TRACE, IROCM_GEMM_TRACE_FINE=4: two extra stamps inside each LOAD phase)
         if constexpr (TRACE) { if (pa.trace_fine == 4) stamp(); }
     };
+    constexpr int SCHED = (KV == 4) ? 0 : KV; // (variant 4 = schedule 0 with AGPR accumulators; 6 = NO DMA in the K loop: timing-only ablation)
     auto ktile = [&](int buf, auto zeroc) {
         // L1
         stamp();
-        if constexpr (KV == 1) {
+        if constexpr (SCHED == 1) {
             if (a_G < total_kt)
                 stage_a_next(buf ^ 1, std::false_type{}, std::true_type{});
         }
-        if constexpr (KV == 3) {
+        if constexpr (SCHED == 3) {
             // 8 B reads | A pieces 0, 1 | 8 B reads | A pieces 2, 3 | 8 A reads
             const bool more = a_G < total_kt;
             char *dst = smem + (buf ^ 1) * BUF_BYTES;
@@ -1167,13 +1177,13 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
             if constexpr (NJ1 > 0) read_b(I1{}, IJ1{}, bq1);
             read_a(I0{}, aq);
         }
-        if constexpr (KV == 0) {
+        if constexpr (SCHED == 0) {
             if (a_G < total_kt)
                 stage_a_next(buf ^ 1, std::false_type{}, std::true_type{});
         }
         fine_stamp();
         wait_lgkm0();
-        if constexpr (KV == 2) {
+        if constexpr (SCHED == 2) {
             if (a_G < total_kt) {
                 stage_a_next(buf ^ 1, std::false_type{}, std::true_type{});
                 wait_lgkm0(); // (a cursor that crossed into the next tile asked for its table entry: finish_cursors reads it in C1)
@@ -1183,7 +1193,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         barrier();
         // C1
         if constexpr (TRACE) { if (pa.trace_fine == 1 || pa.trace_fine == 4) stamp(); }
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (KV != 7 && KV != 8) __builtin_amdgcn_s_setprio(1);
         mask_b(I0{}, I2{}, bq0); // (tap mode; hipcc spreads the ANDs of the later fragments between the first MFMAs)
         if constexpr (NJ1 > 0) mask_b(I1{}, IJ1{}, bq1);
         compute(I0{}, I0{}, I2{}, zeroc, aq, bq0);
@@ -1201,7 +1211,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
             }
             __builtin_amdgcn_sched_group_barrier(0x8, NT * 8 - (kRest + 1) / 2, 0);
         }
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (KV != 7 && KV != 8) __builtin_amdgcn_s_setprio(0);
         fence_sched();
         if constexpr (TRACE) { if (pa.trace_fine == 1 || pa.trace_fine == 4) stamp(); }
         finish_cursors(); // (issues behind the MFMA burst, which is still executing)
@@ -1209,11 +1219,11 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         // L2
         stamp();
         const bool b_more = b_G < total_kt; // (a B tile is issued in this phase)
-        if constexpr (KV == 1) {
+        if constexpr (SCHED == 1) {
             if (b_more)
                 stage_b_next(buf, std::false_type{}, std::true_type{});
         }
-        if constexpr (KV == 3) {
+        if constexpr (SCHED == 3) {
             // 4 A reads | B pieces 0, 1 | 4 A reads | B pieces 2, 3  (read_a issues i-major: the first four reads are rows 0, 1)
             const bool more = b_more;
             char *dst = smem + buf * BUF_BYTES + OPER_BYTES;
@@ -1226,12 +1236,12 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
             read_a(I1{}, aq);
         }
         flip_buf(buf ? -BUF_BYTES : BUF_BYTES); // every read of this K-tile is issued
-        if constexpr (KV == 0) {
+        if constexpr (SCHED == 0) {
             if (b_more)
                 stage_b_next(buf, std::false_type{}, std::true_type{});
         }
         fine_stamp();
-        if constexpr (KV == 2) {
+        if constexpr (SCHED == 2) {
             wait_lgkm0();
             if (b_more) {
                 stage_b_next(buf, std::false_type{}, std::true_type{});
@@ -1249,10 +1259,10 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         barrier();
         // C2
         if constexpr (TRACE) { if (pa.trace_fine == 1 || pa.trace_fine == 4) stamp(); }
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (KV != 7 && KV != 8) __builtin_amdgcn_s_setprio(1);
         if constexpr (NJ1 > 0) compute(I1{}, I1{}, IJ1{}, zeroc, aq, bq1);
         compute(I1{}, I0{}, I2{}, zeroc, aq, bq0);
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (KV != 7 && KV != 8) __builtin_amdgcn_s_setprio(0);
         if constexpr (TRACE) { if (pa.trace_fine == 1 || pa.trace_fine == 4) stamp(); }
         if constexpr (TAPS)
             c_t = c_t == 8 ? 0 : c_t + 1;
@@ -1268,6 +1278,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     barrier();
     if (wr == 1)
         barrier(); // stagger: wave row 1 runs one barrier interval behind wave row 0
+    if constexpr (KV == 7) { // static priority for the younger half (MI355X_MICROARCH.md, two waves per SIMD, item 4), no per-phase flips
+        if (wr == 1) __builtin_amdgcn_s_setprio(1);
+    }
     // Two nested loops over the SAME flat pipeline: the inner K loop stays a compact body with a short back edge (an
     // epilogue inlined into one flat loop pushes the back edge beyond the +-128 KB reach of s_cbranch: every K-tile then
     // pays s_getpc / s_setpc trampolines through cold code — measured 3-4 % slower than the one-shot kernel).

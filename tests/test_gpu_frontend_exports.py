@@ -11,6 +11,9 @@ import numpy as np
 import pytest
 
 sys.path.insert(0, str(Path(__file__).resolve().parent))
+import json  # noqa: E402
+
+import graph_signature as GS  # noqa: E402
 import onnx_import as OI  # noqa: E402
 
 pytestmark = pytest.mark.gpu
@@ -52,3 +55,16 @@ def test_exported_graph_on_rocm_vs_torch(plugin_backend, model, io, half, tol):
         assert np.isfinite(got).all(), mode
         assert np.abs(got - want).max() <= tol * scale, (mode, np.abs(got - want).max(), scale)
     assert np.array_equal(res["fused"], res["hipgraph"])
+
+
+@pytest.mark.parametrize("model", ["bert_layer_tiny_opset13", "bert_layer_tiny_opset17", "resnet_tiny_opset13"])
+def test_graph_on_rocm_is_the_real_front_ends_graph(plugin_backend, model):
+    """The graph the tests above run on Device::ROCM has the SIGNATURE (operators, attributes, edges, shapes, dtypes) of the graph the
+    reference's unmodified OnnxStub builds from the same bytes — the golden was written by running the real front-end in the build
+    container (tests/golden/make_frontend_goldens.py) and is re-derived there every round (tests/test_frontend_real_cpu.py)."""
+    B = plugin_backend
+    gold = json.loads((GOLD / f"{model}_frontend.json").read_text())
+    assert gold["frontend"].endswith("(OnnxStub, unmodified)")
+    h, T, feeds, ins, outs = OI.import_graph(B, B.RocmRuntime(0), (GOLD / f"{model}.onnx").read_bytes(), half=False)
+    assert GS.diff(GS.signature(B, h), gold["signature"]) is None
+    assert ins == gold["inputs"] and outs == gold["outputs"]

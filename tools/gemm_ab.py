@@ -15,6 +15,15 @@ a = torch.randn(n, n, device="cuda").to(torch.bfloat16)
 b = torch.randn(n, n, device="cuda").to(torch.bfloat16)
 c = torch.empty(n, n, device="cuda", dtype=torch.bfloat16)
 torch.cuda.synchronize()
+if "--check" in sys.argv:  # parity of THIS library's headline kernel vs fp32 torch.matmul of the same rounded operands (256 sampled rows)
+    rows = torch.randint(0, n, (256,), device="cuda")
+    for tb in (False, True):
+        ops.matmul(rt, a, b, None, False, tb, out=c)
+        rt.sync()
+        want = a[rows].float() @ (b.float().t() if tb else b.float())
+        err = (c[rows].float() - want).abs().max().item()
+        print(f"check {'NT' if tb else 'NN'}: max abs err {err:.4f} (bf16 output, |c| ~ {want.abs().mean().item():.1f}) variant {rt.last_matmul_variant() if hasattr(rt, 'last_matmul_variant') else '?'}")
+        assert err < 2.1, err  # |c| reaches ~300 at k = 4096: one bf16 ulp there is 2 (half an ulp of rounding + fp32 summation order)
 for tb in (False, True):
     ts = []
     for _ in range(5):

@@ -22,8 +22,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--m", type=int, default=4096)
 ap.add_argument("--n", type=int, default=4096)
 ap.add_argument("--k", type=int, default=1024)
+ap.add_argument("--fine", type=int, default=1, help="1: six stamps per K-tile; 4: ten (two more inside each LOAD phase: everything issued | data landed)")
 a_ = ap.parse_args()
-os.environ["IROCM_GEMM_TRACE_FINE"] = "1"
+os.environ["IROCM_GEMM_TRACE_FINE"] = str(a_.fine)
 rt = RocmRuntime(0)
 a = torch.randn(a_.m, a_.k, device="cuda").to(torch.bfloat16)
 b = torch.randn(a_.k, a_.n, device="cuda").to(torch.bfloat16)
@@ -38,20 +39,24 @@ for _ in range(3):
                                                 a_.m, a_.n, a_.k, 256, C.c_void_p(trace.data_ptr())))
 rt.sync()
 t = trace.cpu().numpy().reshape(grid, 8, 128)
-nk = min(a_.k // 64, 20)  # (the trace strip holds 128 stamps per wave: the first 20 K-tiles of a longer K)
+NS = 6 if a_.fine == 1 else 10  # stamps per K-tile
+nk = min(a_.k // 64, 20 if NS == 6 else 12)  # (the trace strip holds 128 stamps per wave: the first 20 / 12 K-tiles of a longer K)
 names = ["L1 (reads, A DMA, wait, barrier)", "C1 issue (32 MFMAs)", "C1 tail (cursors, barrier)", "L2 (reads, B DMA, waits, barrier)",
          "C2 issue (32 MFMAs)", "C2 tail (barrier)"]
+if NS == 10:
+    names = ["L1 issue (24 reads + 4 A pieces)", "L1 lgkm wait (+ pieces: variant 2)", "L1 barrier", "C1 issue (32 MFMAs)", "C1 tail (cursors, barrier)",
+             "L2 issue (8 reads + 4 B pieces)", "L2 vmcnt + lgkm wait", "L2 barrier", "C2 issue (32 MFMAs)", "C2 tail (barrier)"]
 for wv in (0, 4):
     rows = []
     for g in range(grid):
         s = t[g, wv]
         s = s[s != 0]
-        if len(s) < 1 + 6 * nk:
+        if len(s) < 1 + NS * nk:
             continue
-        kt = s[1:1 + 6 * nk + 1] if len(s) > 1 + 6 * nk else None
+        kt = s[1:1 + NS * nk + 1] if len(s) > 1 + NS * nk else None
         if kt is None:
             continue
-        d = np.diff(kt).reshape(-1)[: 6 * nk].reshape(nk, 6) if len(kt) == 6 * nk + 1 else None
+        d = np.diff(kt).reshape(-1)[: NS * nk].reshape(nk, NS) if len(kt) == NS * nk + 1 else None
         if d is None:
             continue
         rows.append(d[2:nk - 1])
