@@ -35,6 +35,7 @@
 //   0  reads, DMA, lgkm wait, barrier (rounds 2-5)        1  DMA, reads, wait, barrier
 //   2  reads, wait, DMA, barrier                           3  reads and DMA pieces interleaved (8 reads : 2 pieces)
 //   4  = 0 with the accumulators in AGPRs                  6  NO DMA in the K loop (wrong sums: timing-only ablation)
+//   9  every piece issued from a COMPUTE phase, one behind each group of 8 MFMAs (see burst9 in the kernel)
 //   7  = 0 with a static s_setprio 1 for wave row 1 instead of per-phase flips      8  = 0 without any s_setprio
 #ifndef IROCM_KV
 #define IROCM_KV 0
@@ -365,6 +366,10 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     stage_a_next(0, std::true_type{}, std::true_type{});
     if (total_kt > 1)
         stage_b_next(1, std::true_type{}, std::true_type{});
+    if constexpr ((CONV == 0) && IROCM_KV == 9) { // schedule 9: wave row 1's A cursor runs one K-tile further ahead
+        if (wr == 1 && total_kt > 1)
+            stage_a_next(1, std::true_type{}, std::true_type{});
+    }
     // the tile table: thread s decodes step s (under the round trip of the loads above; published by the barrier in front of the loop)
     if (t < my_tiles && t < tab_n) {
         int ib, m0, n0;
@@ -456,6 +461,18 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
                 for (int j = 0; j < CNT; ++j)
                     acc[qa * 4 + i][qb * 2 + j] = Tr::mfma(bq[j][ks].get(), aq[i][ks].get(),
                                                            (ZERO && ks == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[qa * 4 + i][qb * 2 + j]);
+    };
+
+    // one k-step (ks) of compute(): 4 CNT MFMAs — the schedule-9 bursts put an LDS-DMA piece between such groups
+    auto compute_ks = [&](auto qac, auto qbc, auto cntc, auto ksc, auto zeroc, FA(&aq)[4][2], FB(&bq)[2][2]) __attribute__((always_inline)) {
+        constexpr int qa = decltype(qac)::value, qb = decltype(qbc)::value, CNT = decltype(cntc)::value, ks = decltype(ksc)::value;
+        constexpr bool ZERO = decltype(zeroc)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < CNT; ++j)
+                acc[qa * 4 + i][qb * 2 + j] = Tr::mfma(bq[j][ks].get(), aq[i][ks].get(),
+                                                       (ZERO && ks == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[qa * 4 + i][qb * 2 + j]);
     };
 
     using I0 = std::integral_constant<int, 0>;
@@ -1153,8 +1170,146 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     auto fine_stamp = [&]() __attribute__((always_inline)) { // (TRACE, IROCM_GEMM_TRACE_FINE=4: two extra stamps inside each LOAD phase)
         if constexpr (TRACE) { if (pa.trace_fine == 4) stamp(); }
     };
-    constexpr int SCHED = (KV == 4) ? 0 : KV; // (variant 4 = schedule 0 with AGPR accumulators; 6 = NO DMA in the K loop: timing-only ablation)
+    constexpr int SCHED = (KV == 4 || KV == 7 || KV == 8) ? 0 : KV; // (variant 4 = schedule 0 with AGPR accumulators; 6 = NO DMA in the K loop: timing-only ablation)
+    // Schedule 9 (round 6): NO LDS-DMA in the LOAD phases — every piece is issued by a wave in a COMPUTE phase, one piece behind each
+    // group of 8 MFMAs, so that the 16 pieces of a phase no longer reach the texture addresser as one burst in front of the barrier the
+    // partner row waits at (the no-DMA ablation, variant 6, runs 14-16 % faster than variant 0: that is what the bursts cost).
+    // Which operand in which phase is fixed by when its LDS region is free (row 0 runs one interval ahead of row 1):
+    //   row 0:  C1(t): A(t + 1) -> other buffer    C2(t): B(t + 2) -> this buffer, then the counted wait (A(t + 1), B(t + 1) landed)
+    //   row 1:  C1(t): B(t + 2) -> this buffer     C2(t): A(t + 2) -> this buffer  (its A cursor runs one K-tile further ahead: the
+    //           prologue issues its pieces of A(1)); its counted wait stays at the end of L2 (behind C1's B pieces).
+    // A cursor that crosses into the next tile finishes in place (table entry + lgkm wait): the piece sequence sits behind MFMAs in flight.
+    // Two GENERIC cursors, one per COMPUTE phase — X is staged in C1, Y in C2 — loaded BY VALUE from the A / B cursors behind the
+    // prologue (row 0: X = A, Y = B; row 1: X = B, Y = A) and used alone from then on: every run-time "A or B" choice on the named
+    // cursors (arrays, counters bumped in two branches) made hipcc keep them in scratch memory behind a selected pointer.
+    const char *x_base = nullptr, *y_base = nullptr;
+    unsigned x_off[4] = {0u, 0u, 0u, 0u}, y_off[4] = {0u, 0u, 0u, 0u};
+    int x_kt = 0, x_s = 0, x_G = 0, y_kt = 0, y_s = 0, y_G = 0;
+    long x_step = 0, y_step = 0;
+    bool x_is_a = true;   // (y is the other operand)
+    int x_np = 4, y_np = 4; // pieces per wave and K-tile
+    int x_lds = 0, y_lds = 0; // byte offset of this wave's first piece inside a K-tile buffer
+    auto cursor_set = [&](bool is_a, int ib, int m0, int n0, const char *&base, unsigned (&off)[4]) __attribute__((always_inline)) {
+        if (is_a) { // (wave-uniform; both arms write the SAME variables)
+            base = (const char *)((const unsigned short *)p.a + (long)ib * p.a_bs);
+            if constexpr (A_KMAJOR) offs_k(off, lda, m0, p.m, w, lane);
+            else offs_mn(off, lda, m0, p.m, w, lane);
+        } else {
+            base = (const char *)((const unsigned short *)p.b + (long)ib * p.b_bs);
+            if constexpr (B_KMAJOR) offs_k_n<NT>(off, ldb, n0, p.n, w, lane);
+            else offs_mn(off, ldb, n0, p.n, w, lane);
+        }
+    };
+    auto cursor_cross = [&](bool is_a, int step_s, const char *&base, unsigned (&off)[4]) __attribute__((always_inline)) {
+        int ib, m0, n0;
+        if (step_s < tab_n) {
+            unsigned e0 = tab_read(step_s, 0), e1 = tab_read(step_s, 1);
+            wait_lgkm0();
+            asm volatile("" : "+v"(e0), "+v"(e1));
+            e0 = (unsigned)__builtin_amdgcn_readfirstlane((int)e0);
+            e1 = (unsigned)__builtin_amdgcn_readfirstlane((int)e1);
+            ib = (int)(e0 >> 16);
+            m0 = (int)(e0 & 0xffffu) * BM;
+            n0 = (int)(e1 & 0xffffu) * BN_;
+        } else {
+            decode(step_s, ib, m0, n0);
+        }
+        cursor_set(is_a, ib, m0, n0, base, off);
+    };
+    auto burst9 = [&](auto qac, auto zeroc, auto isxc, int dbuf) __attribute__((always_inline)) {
+        constexpr int qa = decltype(qac)::value;
+        constexpr bool ISX = decltype(isxc)::value; // the cursor of this phase: compile time (C1: X, C2: Y)
+        const char *&base = ISX ? x_base : y_base;
+        unsigned (&off)[4] = ISX ? x_off : y_off;
+        int &kt = ISX ? x_kt : y_kt, &st = ISX ? x_s : y_s, &G_ = ISX ? x_G : y_G;
+        const long step = ISX ? x_step : y_step;
+        const int np = ISX ? x_np : y_np, lds = ISX ? x_lds : y_lds;
+        const bool is_a = ISX ? x_is_a : !x_is_a;
+        const bool issue = G_ < total_kt;
+        const char *src = base + (long)kt * step;
+        char *dst = smem + dbuf * BUF_BYTES + lds;
+        auto piece = [&](auto pc) __attribute__((always_inline)) {
+            constexpr int P = decltype(pc)::value;
+            fence_sched();
+            if (issue && P < np) // (wave-uniform)
+                __builtin_amdgcn_global_load_lds(IROCM_GLB_PTR(src + (unsigned long)off[P]), IROCM_LDS_PTR(dst + P * 1024), 16, 0, 0);
+            fence_sched();
+        };
+        if constexpr (qa == 0) {
+            compute_ks(qac, I0{}, I2{}, I0{}, zeroc, aq, bq0);
+            piece(I0{});
+            compute_ks(qac, I0{}, I2{}, I1{}, zeroc, aq, bq0);
+            piece(I1{});
+            if constexpr (NJ1 > 0) compute_ks(qac, I1{}, IJ1{}, I0{}, zeroc, aq, bq1);
+            piece(I2{});
+            if constexpr (NJ1 > 0) compute_ks(qac, I1{}, IJ1{}, I1{}, zeroc, aq, bq1);
+            piece(std::integral_constant<int, 3>{});
+        } else {
+            if constexpr (NJ1 > 0) compute_ks(qac, I1{}, IJ1{}, I0{}, zeroc, aq, bq1);
+            piece(I0{});
+            if constexpr (NJ1 > 0) compute_ks(qac, I1{}, IJ1{}, I1{}, zeroc, aq, bq1);
+            piece(I1{});
+            compute_ks(qac, I0{}, I2{}, I0{}, zeroc, aq, bq0);
+            piece(I2{});
+            compute_ks(qac, I0{}, I2{}, I1{}, zeroc, aq, bq0);
+            piece(std::integral_constant<int, 3>{});
+        }
+        if (issue) { // advance; a cursor that crosses into the next tile finishes here, behind the MFMAs still in flight
+            ++G_;
+            if (++kt == nk) {
+                kt = 0;
+                if (++st < my_tiles)
+                    cursor_cross(is_a, st, base, off);
+            }
+        }
+        return issue;
+    };
     auto ktile = [&](int buf, auto zeroc) {
+        if constexpr (SCHED == 9) {
+            const bool row0 = wr == 0;
+            // L1
+            stamp();
+            read_b(I0{}, I2{}, bq0);
+            if constexpr (NJ1 > 0) read_b(I1{}, IJ1{}, bq1);
+            read_a(I0{}, aq);
+            fine_stamp();
+            wait_lgkm0();
+            fine_stamp();
+            barrier();
+            // C1
+            if constexpr (TRACE) { if (pa.trace_fine == 1 || pa.trace_fine == 4) stamp(); }
+            __builtin_amdgcn_s_setprio(1);
+            const bool c1_issue = burst9(I0{}, zeroc, std::true_type{}, row0 ? (buf ^ 1) : buf); // X: row 0 A(t + 1) -> the other buffer, row 1 B(t + 2) -> this one
+            __builtin_amdgcn_s_setprio(0);
+            fence_sched();
+            if constexpr (TRACE) { if (pa.trace_fine == 1 || pa.trace_fine == 4) stamp(); }
+            barrier();
+            // L2
+            stamp();
+            read_a(I1{}, aq);
+            flip_buf(buf ? -BUF_BYTES : BUF_BYTES);
+            fine_stamp();
+            if (!row0) { // row 1: everything older than the B pieces of its C1 has landed (its A one K-tile ahead included)
+                if (c1_issue) wait_vm<NB>();
+                else wait_vm<0>();
+            }
+            wait_lgkm0();
+            fine_stamp();
+            barrier();
+            // C2
+            if constexpr (TRACE) { if (pa.trace_fine == 1 || pa.trace_fine == 4) stamp(); }
+            __builtin_amdgcn_s_setprio(1);
+            const bool c2_issue = burst9(I1{}, zeroc, std::false_type{}, buf); // Y: row 0 B(t + 2), row 1 A(t + 2), both -> this buffer
+            __builtin_amdgcn_s_setprio(0);
+            fence_sched();
+            if (row0) { // row 0: A(t + 1) (issued in C1) and everything older has landed; the B pieces just issued may still fly
+                if (c2_issue) wait_vm<NB>();
+                else wait_vm<0>();
+            }
+            if constexpr (TRACE) { if (pa.trace_fine == 1 || pa.trace_fine == 4) stamp(); }
+            barrier();
+            return;
+        }
         // L1
         stamp();
         if constexpr (SCHED == 1) {
@@ -1270,12 +1425,40 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     };
 
     // (the first K-tiles were requested at the top of the kernel, before the address arithmetic and the accumulator clear)
-    if (total_kt > 1)
-        wait_vm<NB>();
-    else
-        wait_vm<0>();
+    if constexpr ((CONV == 0) && IROCM_KV == 9) {
+        if (total_kt > 1) {
+            if (wr == 1) wait_vm<NB + 4>(); // (B(1) and its own A(1) may still fly)
+            else wait_vm<NB>();
+        } else {
+            wait_vm<0>();
+        }
+    } else {
+        if (total_kt > 1)
+            wait_vm<NB>();
+        else
+            wait_vm<0>();
+    }
     wait_lgkm0(); // (the tile table's ds_write)
     barrier();
+    if constexpr ((CONV == 0) && IROCM_KV == 9) { // schedule 9: the generic cursors take over (by value)
+        const bool r0 = wr == 0;
+        x_is_a = r0;
+        x_base = r0 ? a_base : b_base;
+        y_base = r0 ? b_base : a_base;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            x_off[i] = r0 ? a_off[i] : b_off[i];
+            y_off[i] = r0 ? b_off[i] : a_off[i];
+        }
+        x_kt = r0 ? a_kt : b_kt; y_kt = r0 ? b_kt : a_kt;
+        x_s = r0 ? a_s : b_s;    y_s = r0 ? b_s : a_s;
+        x_G = r0 ? a_G : b_G;    y_G = r0 ? b_G : a_G;
+        x_step = r0 ? a_step : b_step; y_step = r0 ? b_step : a_step;
+        x_np = r0 ? 4 : NB;      y_np = r0 ? NB : 4;
+        x_lds = r0 ? w * 4 * 1024 : OPER_BYTES + w * NB * 1024;
+        y_lds = r0 ? OPER_BYTES + w * NB * 1024 : w * 4 * 1024;
+        // (the prologue's stage calls decode in place: no table request is pending here)
+    }
     if (wr == 1)
         barrier(); // stagger: wave row 1 runs one barrier interval behind wave row 0
     if constexpr (KV == 7) { // static priority for the younger half (MI355X_MICROARCH.md, two waves per SIMD, item 4), no per-phase flips
