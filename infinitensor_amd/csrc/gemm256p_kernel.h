@@ -36,6 +36,7 @@
 //   2  reads, wait, DMA, barrier                           3  reads and DMA pieces interleaved (8 reads : 2 pieces)
 //   4  = 0 with the accumulators in AGPRs                  6  NO DMA in the K loop (wrong sums: timing-only ablation)
 //   9  every piece issued from a COMPUTE phase, one behind each group of 8 MFMAs (see burst9 in the kernel)
+//  10  = 0 with EVERY piece issued by wave row 0 (8 per LOAD phase), none by row 1
 //   7  = 0 with a static s_setprio 1 for wave row 1 instead of per-phase flips      8  = 0 without any s_setprio
 #ifndef IROCM_KV
 #define IROCM_KV 0
@@ -233,6 +234,11 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
 
     // ---- staging cursors: the next K-tile each operand will fetch, in flat order ------------------
     unsigned a_off[4], b_off[4];
+    // variant 10: wave row 0 issues EVERY piece (its own and those of the wave four below), row 1 none — row 0's LOAD phases end 440-540
+    // cycles before the barrier (they wait for row 1's slower COMPUTE phases), row 1's are what row 0's bursts wait for
+    constexpr bool ROW0DMA = (CONV == 0) && IROCM_KV == 10;
+    constexpr int NBW = ROW0DMA ? 2 * NB : NB; // loads a counted wait may leave in flight
+    unsigned a_off2[ROW0DMA ? 4 : 1], b_off2[ROW0DMA ? 4 : 1];
     const char *a_base, *b_base;
     int a_s = 0, a_kt = 0, a_G = 0; // tile step, K-tile inside it, flat index
     int b_s = 0, b_kt = 0, b_G = 0;
@@ -258,12 +264,20 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         if constexpr (CONV == 3) offs_k_rot(a_off, lda, m0, p.m, w, lane, sp_slice * (8 / S));
         else if constexpr (A_KMAJOR) offs_k(a_off, lda, m0, p.m, w, lane);
         else offs_mn(a_off, lda, m0, p.m, w, lane);
+        if constexpr (ROW0DMA) {
+            if constexpr (A_KMAJOR) offs_k(a_off2, lda, m0, p.m, w + 4, lane);
+            else offs_mn(a_off2, lda, m0, p.m, w + 4, lane);
+        }
     };
     auto set_b_at = [&](int ib, int n0) __attribute__((always_inline)) {
         b_base = (const char *)((const unsigned short *)p.b + (long)ib * p.b_bs);
         if constexpr (CONV) offs_mn_conv(b_off, p.cv_hw, p.cv_hwp, p.cv_hwp_m, (long)(CONV == 3 ? p.k / 9 : p.k) * p.cv_hw, n0, p.n, w, lane);
         else if constexpr (B_KMAJOR) offs_k_n<NT>(b_off, ldb, n0, p.n, w, lane);
         else offs_mn(b_off, ldb, n0, p.n, w, lane);
+        if constexpr (ROW0DMA) {
+            if constexpr (B_KMAJOR) offs_k_n<NT>(b_off2, ldb, n0, p.n, w + 4, lane);
+            else offs_mn(b_off2, ldb, n0, p.n, w + 4, lane);
+        }
     };
     auto set_a_tile = [&](int s) {
         int ib, m0, n0;
@@ -290,7 +304,12 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         } else if constexpr (TAPS) {
             stage4(a_base + ((long)a_t * p.cv_atap + (long)a_cb * (BK * 2)), a_off, smem + buf * BUF_BYTES, w);
         } else {
-            if (!(TRACE && (pa.trace_fine == 2 || pa.trace_fine == 3))) // (experiment: trace_fine 2 = no A DMA, 3 = no DMA at all — timing only)
+            if constexpr (ROW0DMA) {
+                if (wr == 0) {
+                    stage4(a_base + (long)a_kt * a_step, a_off, smem + buf * BUF_BYTES, w);
+                    stage4(a_base + (long)a_kt * a_step, a_off2, smem + buf * BUF_BYTES, w + 4);
+                }
+            } else if (!(TRACE && (pa.trace_fine == 2 || pa.trace_fine == 3))) // (experiment: trace_fine 2 = no A DMA, 3 = no DMA at all — timing only)
                 stage4(a_base + (long)a_kt * a_step, a_off, smem + buf * BUF_BYTES, w);
         }
         if constexpr (TAPS) {
@@ -318,7 +337,12 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         } else if constexpr (TAPS) {
             stage_n<NB>(b_base + (long)b_koff, b_off, smem + buf * BUF_BYTES + OPER_BYTES, w);
         } else {
-            if (!(TRACE && (pa.trace_fine == 3)))
+            if constexpr (ROW0DMA) {
+                if (wr == 0) {
+                    stage_n<NB>(b_base + (long)b_kt * b_step, b_off, smem + buf * BUF_BYTES + OPER_BYTES, w);
+                    stage_n<NB>(b_base + (long)b_kt * b_step, b_off2, smem + buf * BUF_BYTES + OPER_BYTES, w + 4);
+                }
+            } else if (!(TRACE && (pa.trace_fine == 3)))
                 stage_n<NB>(b_base + (long)b_kt * b_step, b_off, smem + buf * BUF_BYTES + OPER_BYTES, w);
         }
         if constexpr (TAPS) {
@@ -1170,7 +1194,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     auto fine_stamp = [&]() __attribute__((always_inline)) { // (TRACE, IROCM_GEMM_TRACE_FINE=4: two extra stamps inside each LOAD phase)
         if constexpr (TRACE) { if (pa.trace_fine == 4) stamp(); }
     };
-    constexpr int SCHED = (KV == 4 || KV == 7 || KV == 8) ? 0 : KV; // (variant 4 = schedule 0 with AGPR accumulators; 6 = NO DMA in the K loop: timing-only ablation)
+    constexpr int SCHED = (KV == 4 || KV == 7 || KV == 8 || KV == 10) ? 0 : KV; // (variant 4 = schedule 0 with AGPR accumulators; 6 = NO DMA in the K loop: timing-only ablation)
     // Schedule 9 (round 6): NO LDS-DMA in the LOAD phases — every piece is issued by a wave in a COMPUTE phase, one piece behind each
     // group of 8 MFMAs, so that the 16 pieces of a phase no longer reach the texture addresser as one burst in front of the barrier the
     // partner row waits at (the no-DMA ablation, variant 6, runs 14-16 % faster than variant 0: that is what the bursts cost).
@@ -1406,7 +1430,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
                 wait_vm<0>();
             }
         } else {
-            if (b_more) wait_vm<NB>(); // everything older than these NB loads has landed (C stores of a previous tile included)
+            if (b_more) wait_vm<NBW>(); // everything older than these NB loads has landed (C stores of a previous tile included)
             else wait_vm<0>();
             wait_lgkm0();
         }
@@ -1434,7 +1458,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         }
     } else {
         if (total_kt > 1)
-            wait_vm<NB>();
+            wait_vm<NBW>();
         else
             wait_vm<0>();
     }
