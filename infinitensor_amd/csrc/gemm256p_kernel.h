@@ -384,8 +384,12 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
     // The first K-tiles go out NOW: the fragment address arithmetic, the accumulator clear (128 v_mov per lane) and everything
     // else up to the first barrier then run under their memory round trip instead of in front of it.
     stamp();
-    set_a_tile(0);
-    set_b_tile(0);
+    { // (ONE decode for both cursors: the scalar decode is ~1 k cycles and sits in front of the kernel's first memory request)
+        int ib0, m00, n00;
+        decode(0, ib0, m00, n00);
+        set_a_at(ib0, m00);
+        set_b_at(ib0, n00);
+    }
     stage_b_next(0, std::true_type{}, std::true_type{});
     stage_a_next(0, std::true_type{}, std::true_type{});
     if (total_kt > 1)
@@ -877,6 +881,10 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(PArgs pa) {
         // inside the store sequence would have to drain the stores in front of it (loads and stores share vmcnt).
         u32x4_t rq[has_res ? 8 : 1][has_res ? (NT / 2 > 0 ? NT / 2 : 1) : 1];
         u32x2_t rq_odd[has_res ? 8 : 1];
+        // (Round 6: requesting the NEXT tile's runs from the current epilogue — 32 registers live across the K loop in the 128-column
+        // copy, inline-asm loads the K loop's counted waits cover — was built, parity-green, and moved nothing: C64 -> F256 @56 x 56
+        // 108.6 us with and without. A tile moves 176 KB in 18.5 k cycles = 9.5 B / clk / CU, the per-CU streaming rate of this chip
+        // (MI355X_MICROARCH.md: ~10): these layers are bound by the mixed read / write bandwidth, not by the round trip. Removed.)
         if constexpr (has_res) {
             const long total_bytes = (long)p.cv_res_bytes;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.cv_res), 0, (int)p.cv_res_bytes, 0x00020000);
