@@ -185,7 +185,7 @@ def extras(rt, ops, Event) -> dict:
     import membound_sweep as MS
 
     pmc, pmc_src = {}, None
-    for fname in ("r05_membound_pmc.json", "r04_membound_pmc.json"):
+    for fname in ("r06_membound_pmc.json", "r05_membound_pmc.json", "r04_membound_pmc.json"):
         try:
             d = json.loads((REPO / "profiles" / fname).read_text())
         except Exception as e:  # noqa: BLE001
@@ -735,12 +735,19 @@ def pmc_traffic(launched: str) -> dict:
     WRITE_SIZE of the same shape; FETCH_SIZE x2 per the gfx950 note). The counter file names the kernel variant it was
     taken from; a file from ANOTHER variant than the one this run launched is refused (traffic: null) instead of silently
     going stale when the kernel changes."""
-    for name in ("r05_gemm256p_pmc.json", "r04_gemm256p_pmc.json", "r03_gemm256p_pmc.json", "r02_gemm256p_pmc.json"):
+    sys.path.insert(0, str(REPO / "tools"))
+    import source_stamps
+
+    for name in ("r06_gemm256p_pmc.json", "r05_gemm256p_pmc.json", "r04_gemm256p_pmc.json", "r03_gemm256p_pmc.json", "r02_gemm256p_pmc.json"):
         p = REPO / "profiles" / name
         try:
             d = json.loads(p.read_text())
         except Exception:  # noqa: BLE001
             continue
+        # (round 6: the file carries the hash of the GEMM sources it measured; files of earlier rounds have none and are judged by the
+        # variant name alone — their kernel's K loop is unchanged, its prologue is not)
+        if d.get("stamp") and d["stamp"] != source_stamps.gemm_stamp():
+            return {"traffic": None, "traffic_source": f"profiles/{name} REFUSED: taken from other GEMM sources (stamp {d['stamp']}, these are {source_stamps.gemm_stamp()})"}
         try:
             from infinitensor_amd import ops
 

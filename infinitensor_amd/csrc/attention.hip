@@ -40,6 +40,24 @@ struct AttnArgs {
 // 2^-126 flush to 0, which is what a softmax weight that small is worth
 __device__ static inline float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Cross-lane maximum / sum over the four 16-lane groups of a wave (a query column's keys are spread over lanes l15 + 16 g4) WITHOUT the
+// LDS crossbar: v_permlane16_swap / v_permlane32_swap hand every lane its partner's value as one VALU operation each. __shfl_xor(x, 16 / 32)
+// compiles to ds_bpermute_b32 + s_waitcnt lgkmcnt(0) — two serialised LDS round trips (and a drain of every other LDS request in flight)
+// on the dependency chain between the score MFMAs and the exponentials of EVERY key tile and query tile (round 6).
+// Returns {x of this lane, x of lane ^ 16} resp. ^ 32 as two values the caller combines (max3 / add).
+__device__ static inline void lanes_xor16(float x, float &a, float &b) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const u32x2_t r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    a = __builtin_bit_cast(float, r[0]);
+    b = __builtin_bit_cast(float, r[1]);
+}
+__device__ static inline void lanes_xor32(float x, float &a, float &b) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const u32x2_t r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    a = __builtin_bit_cast(float, r[0]);
+    b = __builtin_bit_cast(float, r[1]);
+}
+
 // CAUSAL / MASK are compile-time so that the unmasked, non-causal sweep carries no select / compare per score.
 template <typename Tr, int D, int NT, bool CAUSAL, int MASK> // MASK: 0 none, 1 per key, 2 per (query, key)
 __global__ __launch_bounds__(256, (NT == 2 && D == 64) ? 3 : 2) void attention_kernel(AttnArgs p) {
@@ -260,9 +278,19 @@ __global__ __launch_bounds__(256, (NT == 2 && D == 64) ? 3 : 2) void attention_k
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     mx = fmaxf(mx, s[mt][nt][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run[nt], mx);
+            float m_new;
+            // (the causal + masked D = 64 copies sit at the 168-register limit of three waves per SIMD: the swap's register pairs
+            // spilled three registers there — they keep the LDS crossbar form; tests/test_kernel_resources_cpu.py watches this)
+            if constexpr (CAUSAL && D == 64 && MASK != 0) {
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                m_new = fmaxf(m_run[nt], mx);
+            } else {
+                float xa, xb;
+                lanes_xor16(mx, xa, xb);
+                lanes_xor32(fmaxf(xa, xb), xa, xb);
+                m_new = fmaxf(m_run[nt], fmaxf(xa, xb)); // (one v_max3_f32)
+            }
             const float m_use = m_new == -INFINITY ? 0.f : m_new;
             const float alpha = fast_exp2((m_run[nt] - m_use) * c);
             const float nmc = -m_use * c;
@@ -343,9 +371,10 @@ __global__ __launch_bounds__(256, (NT == 2 && D == 64) ? 3 : 2) void attention_k
         if constexpr (MMA_SUM) {
             l = osum[nt][0]; // every row of the ones tile holds the column's sum over all 64 keys of every tile
         } else {
-            l = l_run[nt];
-            l += __shfl_xor(l, 16);
-            l += __shfl_xor(l, 32);
+            float xa, xb;
+            lanes_xor16(l_run[nt], xa, xb);
+            lanes_xor32(xa + xb, xa, xb);
+            l = xa + xb;
         }
         const float inv = l > 0.f ? 1.0f / l : 0.f;
         const int qi = q0 + nt * 16 + l15;

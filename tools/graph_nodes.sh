@@ -10,32 +10,30 @@ rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python $REPO/tools/
 tail -1 $OUT/run.log | cut -c1-400
 python3 - <<PY
 import csv, glob, re
+from collections import Counter
 rows = []
-for f in glob.glob("$OUT/**/*kernel_trace.csv", recursive=True):
+for f in sorted(set(glob.glob("$OUT/**/*kernel_trace.csv", recursive=True))):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def short(n):
-    n = re.sub(r"\(.*", "", n); n = n.replace("void irocm::", "").replace("irocm::", "")
-    return n[:70]
+    n = re.sub(r"\\(.*", "", n)
+    return n.replace("void irocm::", "").replace("irocm::", "")[:64]
 names = [short(r["Kernel_Name"]) for r in rows]
-# a replay = the sequence between two occurrences of the graph's first kernel; take the last full one
-first = None
-for cand in names[::-1]:
-    first = cand; break
-# find the period: the last kernel name of the stream ends a replay; look for the previous identical tail
-last = len(names) - 1
-seq = []
-i = last
-# walk back until we see the same kernel as names[last] again (the previous replay's end)
-j = last - 1
-while j > 0 and not (names[j] == names[last] and j < last - 3): j -= 1
-seq = list(range(j + 1, last + 1))
-print(f"{len(rows)} kernels traced; last replay = {len(seq)} launches")
-helpers = 0
-for k in seq:
-    r = rows[k]; d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    mark = "  <== helper" if "rocclr" in names[k] else ""
-    helpers += bool(mark)
-    print(f"  {d:8.1f} us  {names[k]}{mark}")
-print(f"helpers in the replay: {helpers}")
+end = len(names) - 1  # (the very last kernel is the output's copy-out: leave it outside)
+period = None
+for pp in range(5, 800):
+    if end - 3 * pp < 0:
+        break
+    if names[end - pp:end] == names[end - 2 * pp:end - pp] == names[end - 3 * pp:end - 2 * pp]:
+        period = pp
+        break
+print(f"{len(rows)} kernels traced; one replay = {period} launches")
+if period:
+    seq = range(end - period, end)
+    c = Counter(names[k] for k in seq)
+    print("helper (memcpy / memset) nodes per replay:", {k: v for k, v in c.items() if "rocclr" in k} or "none")
+    for k in seq:
+        r = rows[k]; d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        if period <= 40 or "rocclr" in names[k]:
+            print(f"  {d:8.1f} us  {names[k]}" + (f"   (after {names[k-1]} | before {names[k+1]})" if "rocclr" in names[k] and period > 40 else ""))
 PY

@@ -258,14 +258,10 @@ def sweep(rt, ops, Event, only=None, budget_s: float | None = None) -> dict:
 
 def source_stamp() -> str:
     """sha1 over the kernel sources: a counter file is only valid for the kernels it was taken from (bench.py refuses others)."""
-    import hashlib
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    import source_stamps
 
-    h = hashlib.sha1()
-    csrc = Path(__file__).resolve().parent.parent / "infinitensor_amd" / "csrc"
-    for f in sorted(csrc.glob("*.hip")) + sorted(csrc.glob("*.h")):
-        if f.name in ("rowops.hip", "elementwise.hip", "movement.hip", "nnops.hip", "rope.hip", "common.h"):
-            h.update(f.read_bytes())
-    return h.hexdigest()[:16]
+    return source_stamps.membound_stamp()
 
 
 def pmc_run(rt, ops, only=None):

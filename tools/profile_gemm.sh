@@ -31,7 +31,9 @@ try:
 except Exception:
     vname = None
 kern = sorted({r["Kernel_Name"] for f in glob.glob("$OUT/**/*counter_collection.csv", recursive=True) for r in csv.DictReader(open(f)) if "gemm" in r.get("Kernel_Name", "")})
-out = {"command": "rocprofv3 --kernel-trace --pmc <one set per pass> -- python tools/run_gemm.py 4096 $V 0 5 (bf16 NN 4096^3)",
+sys.path.insert(0, "$REPO/tools")
+import source_stamps
+out = {"stamp": source_stamps.gemm_stamp(), "command": "rocprofv3 --kernel-trace --pmc <one set per pass> -- python tools/run_gemm.py 4096 $V 0 5 (bf16 NN 4096^3)",
        "variant": int("$V"), "variant_name": vname, "kernel": kern[0] if kern else None, "pmc_per_dispatch_mean": tot}
 if "GRBM_GUI_ACTIVE" in tot and "SQ_VALU_MFMA_BUSY_CYCLES" in tot:
     # SQ counters are summed over 1024 SIMDs (256 CU x 4), GRBM_GUI_ACTIVE over 8 XCDs
