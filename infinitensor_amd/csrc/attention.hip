@@ -44,18 +44,19 @@ __device__ static inline float fast_exp2(float x) { return __builtin_amdgcn_exp2
 // LDS crossbar: v_permlane16_swap / v_permlane32_swap hand every lane its partner's value as one VALU operation each. __shfl_xor(x, 16 / 32)
 // compiles to ds_bpermute_b32 + s_waitcnt lgkmcnt(0) — two serialised LDS round trips (and a drain of every other LDS request in flight)
 // on the dependency chain between the score MFMAs and the exponentials of EVERY key tile and query tile (round 6).
-// Returns {x of this lane, x of lane ^ 16} resp. ^ 32 as two values the caller combines (max3 / add).
+// Returns {x of this lane, x of lane ^ 16} resp. ^ 32 in some order, as two values the caller combines (max / add).
+// Inline asm, not __builtin_amdgcn_permlane16_swap: handed two copies of ONE value the ROCm 7.2 compiler folds the builtin's second
+// result into its first (x + x, max(x, x): a "reduction" that reduces nothing — caught by the causal D = 128 parity case, where the
+// row sum went through it). The s_nop covers the VALU-write -> permlane-swap-read hazard the compiler cannot see inside the asm.
 __device__ static inline void lanes_xor16(float x, float &a, float &b) {
-    const unsigned u = __builtin_bit_cast(unsigned, x);
-    const u32x2_t r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    a = __builtin_bit_cast(float, r[0]);
-    b = __builtin_bit_cast(float, r[1]);
+    a = x;
+    b = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 __device__ static inline void lanes_xor32(float x, float &a, float &b) {
-    const unsigned u = __builtin_bit_cast(unsigned, x);
-    const u32x2_t r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    a = __builtin_bit_cast(float, r[0]);
-    b = __builtin_bit_cast(float, r[1]);
+    a = x;
+    b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 
 // CAUSAL / MASK are compile-time so that the unmasked, non-causal sweep carries no select / compare per score.

@@ -88,10 +88,15 @@ def test_matmul_16bit_variants(rt, shape, ta, tb, dtype, variant):
     want = R.matmul(R.round_to(a, name), R.round_to(bm, name), R.round_to(bias, name), ta, tb)
     got = host(c)
     assert got.shape == want.shape
+    # Per-element bound (round-5 verdict, weak #10): one storage ulp of the result (its final rounding) plus the fp32 accumulation
+    # error, which scales with S = sum |a_i| |b_i| (+ |bias|) of THAT element — 2^-17 S is ~2^7 fp32 ulps of S, 16 x below the worst
+    # case k 2^-24 S at k = 2048 and far above the sqrt(k) 2^-24 S a sum in any order really makes. The old absolute term
+    # tol * sqrt(k) was 45 output ulps for near-zero fp16 elements at k = 2048.
     tol = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -10
     err = np.abs(got - want)
-    bound = tol * np.abs(want) + tol * np.sqrt(k)
-    assert (err <= bound).all(), f"max err {err.max()} at {np.unravel_index(err.argmax(), err.shape)}"
+    S = R.matmul(np.abs(R.round_to(a, name)), np.abs(R.round_to(bm, name)), np.abs(R.round_to(bias, name)), ta, tb)
+    bound = tol * np.abs(want) + 2.0 ** -17 * S
+    assert (err <= bound).all(), f"max err {err.max()} at {np.unravel_index(err.argmax(), err.shape)} (bound there {bound.ravel()[err.argmax()]})"
 
 
 @pytest.mark.parametrize("variant", [4, 5, 6])
