@@ -480,7 +480,7 @@ class FusionPlanner {
     bool tryRules(size_t i) {
         const auto type = ops[i]->getOpType();
         if (type == OpType::MatMul)
-            return planAttentionAt(i) || planMatmul(i) || planRowParallelAllReduce(i) || planGroupedAhead(i);
+            return planAttentionAt(i) || planMatmul(i) || planRowParallelAllReduce(i) || planGroupedAhead(i) || planIntoCopy(i);
         if (type == OpType::Transpose)
             return planAttentionFromTranspose(i) || planIntoCopy(i);
         if (type == OpType::Conv)
