@@ -244,7 +244,9 @@ struct Conv32Args {
     int split;
     float *partial;
     long out_elems;   // N F OH OW
+    unsigned long long *trace; // TRACE instantiation only (tools/conv32_timeline.py): [grid][4 waves][kC32Slots] s_memtime stamps
 };
+constexpr int kC32Slots = 128;
 
 // y = act(sum over slices of partial + bias[f] + res); V consecutive elements per thread (V = 4 when planes are multiples of 4: one filter)
 template <int V>
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(256) void conv_repack_w32(const float *__restrict__
 // (c R + r) S + s over the FCRS weights as they lie (TM = false: layers with fewer than 32 channels) every element decodes its own
 // (c, r, s): the PMC pass of the first version showed 2.5 scalar instructions per vector one — 370 per K-tile and wave beside 16 MFMAs —
 // and the layers at 0.16-0.35 of the fp32 peak.
-template <int T, bool TM> __global__ __launch_bounds__(256, 2) void conv_igemm32(Conv32Args p) {
+template <int T, bool TM, bool TRACE = false> __global__ __launch_bounds__(256, 2) void conv_igemm32(Conv32Args p) {
     constexpr int BM = 64 * T, BN = 64 * T, WT = 32 * T;
     constexpr int TILE_BYTES = BM * BK * 4;
     constexpr int KR_STEP = 256 / BN;      // k-rows covered by the 256 threads at once (2 for T = 2, 4 for T = 1)
@@ -315,6 +317,17 @@ template <int T, bool TM> __global__ __launch_bounds__(256, 2) void conv_igemm32
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = w >> 1, wn = w & 1;
+    // TRACE (round 6; tools/conv32_timeline.py): every wave stamps s_memtime at four points of every step into an LDS strip behind the
+    // tiles (no VMEM traffic: the counted waits are untouched) and dumps it at the end
+    int tslot = 0;
+    auto stamp = [&]() __attribute__((always_inline)) {
+        if constexpr (TRACE) {
+            const unsigned long long tm_ = __builtin_amdgcn_s_memtime();
+            if (tslot < kC32Slots && lane == 0)
+                *(unsigned long long *)(smem + 4 * TILE_BYTES + (w * kC32Slots + tslot) * 8) = tm_;
+            ++tslot;
+        }
+    };
     const int S = p.split;
     const int slice = S > 1 ? (int)(blockIdx.x % (unsigned)S) : 0;
     unsigned wg = S > 1 ? xcd_remap(blockIdx.x / (unsigned)S, gridDim.x / (unsigned)S) : xcd_remap(blockIdx.x, gridDim.x);
@@ -439,8 +452,16 @@ template <int T, bool TM> __global__ __launch_bounds__(256, 2) void conv_igemm32
     gather(sv_b, (kt_begin + 1) * BK); // (past the last tile: every element out of range — zeros, never multiplied)
     auto step = [&](auto bufc, int kt, float (&cur)[NE], float (&nxt)[NE]) __attribute__((always_inline)) {
         constexpr int buf = decltype(bufc)::value;
+        stamp(); // (TRACE: step entry)
         // tile kt's weights have landed; every thread's column of tile kt is in LDS (its ds_writes drained) — then the barrier
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NE) : "memory");
+        if constexpr (TRACE) { // (the same wait in two parts, a stamp between them: what the counted wait costs, what the barrier costs)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NE) : "memory");
+            stamp();
+            asm volatile("s_barrier" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NE) : "memory");
+        }
+        stamp(); // (TRACE: behind the barrier)
         // (unconditional — past the last tile the weights come from the zero block and every gathered element is out of range — so
         // that the gather sits in the SAME basic block as the MFMAs and can be scheduled between them)
         stage_kmajor<T>(p.w, p.k, m0, p.f, (kt + 1) * BK, a_tile(buf ^ 1), w, lane, p.k, Z);
@@ -479,6 +500,8 @@ template <int T, bool TM> __global__ __launch_bounds__(256, 2) void conv_igemm32
                         }
                     }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(); // (TRACE: the 16 T^2 MFMAs and the NE requests are issued)
         scatter(buf ^ 1, cur); // tile kt + 1, requested one step ago (buffer buf ^ 1 was last read in step kt - 1, behind this step's barrier)
     };
     // Steps come in pairs, unconditionally: with an odd tile count the last step multiplies a tile of zero weights by out-of-range
@@ -491,6 +514,14 @@ template <int T, bool TM> __global__ __launch_bounds__(256, 2) void conv_igemm32
         step(std::integral_constant<int, 1>{}, kt + 1, sv_a, sv_b);
     }
 
+    if constexpr (TRACE) {
+        stamp();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int i = lane; i < kC32Slots; i += 64)
+            p.trace[((size_t)blockIdx.x * 4 + w) * kC32Slots + i] =
+                i < tslot ? *(unsigned long long *)(smem + 4 * TILE_BYTES + (w * kC32Slots + i) * 8) : 0ull;
+    }
     // epilogue: lane l holds filter m = l % 32 and, per g, four consecutive columns q. A split-K slice stores its raw sums into its
     // plane of `partial` (same NCHW indexing); bias / residual / activation then belong to conv32_splitk_reduce.
     const int ohw = p.oh * p.ow;
@@ -714,6 +745,19 @@ int launch_conv_igemm32(infiniRocmRuntime_t rt, const void *x, const void *w, co
     if (total >= (1l << 31))
         return -1;
     const size_t lds = 4 * (size_t)bm * f32k::BK * 4;
+    p.trace = nullptr;
+    // timeline build (tools/conv32_timeline.py): IROCM_CONV32_TRACE = device address (hex) of [grid][4][128] uint64 stamps; 64 x 64 tap-major form
+    if (const char *tr = getenv("IROCM_CONV32_TRACE")) {
+        p.trace = (unsigned long long *)strtoull(tr, nullptr, 16);
+        if (p.trace && small && tm) {
+            auto kern = f32k::conv_igemm32<1, true, true>;
+            const size_t lds_t = lds + 4 * f32k::kC32Slots * 8;
+            IROCM_LDS_ATTR(kern, (int)lds_t, rt);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(total * split)), dim3(256), lds_t, rt->stream, p);
+            IROCM_LAUNCH_CHECK("conv_igemm32(trace)");
+            return INFINI_ROCM_OK; // (timing only: a split launch's reduce pass is not run)
+        }
+    }
 #define IROCM_C32(T_, TM_)                                                                         \
     do {                                                                                           \
         auto kern = f32k::conv_igemm32<T_, TM_>;                                                   \
