@@ -709,6 +709,10 @@ def flat_summary(line: dict, detail: dict, world: int) -> None:
                        ("layernorm_262144x768_f16", "layernorm_262144x768_f16_frac_hbm")):
         if key in ex and "frac_hbm_peak" in ex[key]:
             roof[short] = ex[key]["frac_hbm_peak"]
+            # HBM-side bytes over algorithmic bytes from the source-stamped counter passes (null when the committed file was taken from
+            # other kernel sources: `traffic_source` in the detail file says which)
+            if key != "layernorm_262144x768_f16": # (the counter passes cover the two config shapes; the HBM-sized shapes are in extras.membound)
+                roof[short.replace("_frac_hbm", "_traffic_over_algorithmic")] = ex[key].get("traffic_over_algorithmic")
     if "matmul_4096_f32_NN" in ex:
         roof["matmul_4096_f32_frac_fp32_mfma_peak"] = ex["matmul_4096_f32_NN"].get("frac_fp32_mfma_peak")
     r5 = ex.get("round5_kernels") or {}
