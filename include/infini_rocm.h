@@ -132,6 +132,11 @@ int infini_rocm_probe_mfma_ceiling(infiniRocmRuntime_t rt, int dtype, const void
  * shape the chip sustains more of under its power budget (round 5). */
 int infini_rocm_probe_mfma_ceiling32(infiniRocmRuntime_t rt, int dtype, const void *data, void *sink, int iters,
                                      double *flop);
+/* Round 6: the same MFMA stream with the A fragments of every K-tile loaded straight from an L2-resident [2048][k] panel (16
+ * fragment-shaped 16-byte loads per wave and K-tile, register double-buffered) and NO LDS, barrier or B traffic — the upper bound of a
+ * GEMM design that streams one operand L2 -> VGPR (the reference has no counterpart: cuBLAS picks its own kernels, matmul.cc:67-174). */
+int infini_rocm_probe_mfma_a_from_l2(infiniRocmRuntime_t rt, int dtype, const void *a, const void *bdata, void *sink, int k, int iters,
+                                     double *flop);
 /* Diagnostics: one launch of the persistent GEMM (bf16, row-major A [m,k] and B [k,n], no bias; tile_cols 256 or 192)
  * built with s_memtime stamps at every wave's phase boundaries. trace: [min(tiles, compute_units)][8][128] uint64
  * (0 = unused): slot 0 kernel entry, then per K-tile {L1 start, L2 start}, per tile {epilogue start, end}, last = after

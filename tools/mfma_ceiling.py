@@ -39,6 +39,31 @@ def mfma_ceiling(rt, dtype=torch.bfloat16, iters=4000, reps=20, fill="normal", s
     return flop.value / s / 1e12
 
 
+def a_from_l2(rt, dtype=torch.bfloat16, iters=4000, reps=20, k=512) -> float:
+    """TFLOP/s of the MFMA stream with the A fragments loaded straight from an L2-resident panel (no LDS, no B traffic): the upper bound of
+    a GEMM that streams one operand L2 -> VGPR (round 6)."""
+    a = torch.randn(2048, k, device="cuda").to(dtype)
+    bdata = torch.randn(16 * 512 * 8 * 8, device="cuda").to(dtype)
+    sink = torch.empty(rt.device_info()["compute_units"] * 512, device="cuda", dtype=torch.float32)
+    torch.cuda.synchronize()
+    code = 16 if dtype == torch.bfloat16 else 10
+    flop = C.c_double()
+
+    def launch():
+        check(lib().infini_rocm_probe_mfma_a_from_l2(rt.handle, code, C.c_void_p(a.data_ptr()), C.c_void_p(bdata.data_ptr()), C.c_void_p(sink.data_ptr()),
+                                                     k, iters, C.byref(flop)))
+
+    for _ in range(3):
+        launch()
+    e0, e1 = Event(), Event()
+    rt.record(e0)
+    for _ in range(reps):
+        launch()
+    rt.record(e1)
+    s = rt.elapsed_ms(e0, e1) * 1e-3 / reps
+    return flop.value / s / 1e12
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="bf16")
@@ -55,4 +80,9 @@ if __name__ == "__main__":
         out[f"random_16x16x32_rep{rep}"] = round(mfma_ceiling(rt, dt, a.iters, a.reps, "normal"), 1)
         out[f"random_32x32x16_rep{rep}"] = round(mfma_ceiling(rt, dt, a.iters, a.reps, "normal", shape32=True), 1)
     out["zeros_32x32x16"] = round(mfma_ceiling(rt, dt, a.iters, a.reps, "zeros", shape32=True), 1)
+    # the L2 -> VGPR design's upper bound, interleaved with the MFMA-only stream on the same box
+    for rep in range(3):
+        out[f"a_from_l2_k512_rep{rep}"] = round(a_from_l2(rt, dt, a.iters, a.reps, 512), 1)
+        out[f"mfma_only_rep{rep}"] = round(mfma_ceiling(rt, dt, a.iters, a.reps, "normal"), 1)
+    out["a_from_l2_k4096"] = round(a_from_l2(rt, dt, a.iters, a.reps, 4096), 1)
     print(json.dumps(out))
