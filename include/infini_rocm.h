@@ -137,6 +137,10 @@ int infini_rocm_probe_mfma_ceiling32(infiniRocmRuntime_t rt, int dtype, const vo
  * GEMM design that streams one operand L2 -> VGPR (the reference has no counterpart: cuBLAS picks its own kernels, matmul.cc:67-174). */
 int infini_rocm_probe_mfma_a_from_l2(infiniRocmRuntime_t rt, int dtype, const void *a, const void *bdata, void *sink, int k, int iters,
                                      double *flop);
+/* Round 6: four waves per workgroup with 128 x 128 wave tiles (one wave per SIMD, 256 accumulator registers): per K-tile of 64 and wave 128
+ * MFMAs, 32 LDS fragment reads and (pieces != 0) 16 LDS-DMA pieces interleaved, one barrier — the upper bound of that tile shape with the
+ * library's staging machinery; timing only (no counterpart in the reference: matmul.cc:67-174 calls cuBLAS). */
+int infini_rocm_probe_mfma_wave128(infiniRocmRuntime_t rt, int dtype, const void *panel, void *sink, int pieces, int iters, double *flop);
 /* Diagnostics: one launch of the persistent GEMM (bf16, row-major A [m,k] and B [k,n], no bias; tile_cols 256 or 192)
  * built with s_memtime stamps at every wave's phase boundaries. trace: [min(tiles, compute_units)][8][128] uint64
  * (0 = unused): slot 0 kernel entry, then per K-tile {L1 start, L2 start}, per tile {epilogue start, end}, last = after

@@ -76,6 +76,7 @@ def lib() -> C.CDLL:
     sig("infini_rocm_probe_mfma_ceiling", [vp, i32, vp, vp, i32, C.POINTER(C.c_double)])
     sig("infini_rocm_probe_mfma_ceiling32", [vp, i32, vp, vp, i32, C.POINTER(C.c_double)])
     sig("infini_rocm_probe_mfma_a_from_l2", [vp, i32, vp, vp, vp, i32, i32, C.POINTER(C.c_double)])
+    sig("infini_rocm_probe_mfma_wave128", [vp, i32, vp, vp, i32, i32, C.POINTER(C.c_double)])
     sig("infini_rocm_probe_gemm_timeline", [vp, vp, vp, vp, i64, i64, i64, i32, vp])
     sig("infini_rocm_event_create", [pvp])
     sig("infini_rocm_event_destroy", [vp])

@@ -198,6 +198,109 @@ extern "C" int infini_rocm_probe_mfma_a_from_l2(infiniRocmRuntime_t rt, int dtyp
     return INFINI_ROCM_OK;
 }
 
+// Round 6 (verdict item 1, the first design it names): 128 x 128 wave tiles — FOUR waves per workgroup, one per SIMD, 8 x 8 accumulator tiles
+// each (256 accumulator registers) — as an upper bound with today's staging machinery. Per K-tile of 64 a wave issues what the 256 x 256 x 64
+// tile needs of it: 128 MFMAs, 32 fragment reads (ds_read_b128: 8 A + 8 B per k-step) and 16 LDS-DMA pieces (its quarter of the 64 KB
+// K-tile, from an L2-resident panel), one piece and two reads behind every eight MFMAs, one barrier per K-tile, two LDS buffers. The LDS
+// addresses are conflict-free but arbitrary and the sums meaningless: timing only. PIECES = 0 removes the DMA (what the schedule would do
+// if the pieces were free).
+template <typename Tr, int PIECES>
+__global__ __launch_bounds__(256, 1) void mfma_wave128_kernel(const unsigned short *__restrict__ panel, float *__restrict__ sink, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the LDS starts out holding the caller's (random) operand data: the fragments toggle like a real GEMM's with or without the DMA
+    for (int i = t; i < 2 * 65536 / 16; i += 256)
+        *(u32x4_t *)(smem + i * 16) = ((const u32x4_t *)panel)[i];
+    __syncthreads();
+    const unsigned lds0 = (unsigned)(unsigned long)IROCM_LDS_PTR(smem);
+    const unsigned rd = lds0 + (unsigned)lane * 16u; // lane-linear 16-byte reads: conflict-free
+    const char *src = (const char *)panel + (size_t)(blockIdx.x & 7) * (2u << 20) + (size_t)w * 16384 + (size_t)lane * 16;
+    // fragments of k-step s + 1 are read WHILE the 64 MFMAs of k-step s issue (two reads behind every eight MFMAs, into the other register
+    // set), so no read latency is exposed: what is left beside the MFMAs is the issue cost of the reads and of the pieces
+    s16x8_t af[2][8], bf[2][8];
+    auto read_pair = [&](int set, int i, unsigned rbase) __attribute__((always_inline)) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[set][i]) : "v"(rbase), "i"(0));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[set][i]) : "v"(rbase), "i"(1024));
+    };
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        read_pair(0, i, rd);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int it = 0; it < iters; ++it) {
+        const int buf = it & 1;
+        const unsigned rbase = rd + (unsigned)buf * 65536u, rnext = rd + (unsigned)(buf ^ 1) * 65536u;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    acc[i][j] = Tr::mfma(bf[ks][j], af[ks][i], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks == 0)
+                    read_pair(1, i, rbase); // k-step 1 of this K-tile
+                if (PIECES) { // one piece behind every eight MFMAs: 16 per K-tile
+                    __builtin_amdgcn_global_load_lds(IROCM_GLB_PTR(src + (size_t)((it * 16 + ks * 8 + i) & 255) * 1024),
+                                                     IROCM_LDS_PTR(smem + (buf ^ 1) * 65536 + w * 16384 + (ks * 8 + i) * 1024), 16, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (ks == 0)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        // PIECES 1: wait for everything (two K-tile buffers: the next K-tile reads what was just requested — the shortest lookahead);
+        // PIECES 2: leave this K-tile's 16 pieces in flight (what a ring of more, smaller stages would allow; the data hazard is ignored:
+        // timing only)
+        if (PIECES == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            read_pair(0, i, rnext); // k-step 0 of the next K-tile (a real kernel would hide these eight pairs as well)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            s += acc[i][j];
+    if (s[0] + s[1] + s[2] + s[3] == 123.456f)
+        sink[blockIdx.x * 256 + t] = s[0];
+}
+
+// panel: >= 16 MB + 256 KB of 16-bit data (L2-resident per XCD), sink: >= num_cu * 256 floats; pieces: 0 = no LDS-DMA, 1 = with it and a full
+// wait per K-tile, 2 = with it, one K-tile's pieces left in flight across the barrier.
+extern "C" int infini_rocm_probe_mfma_wave128(infiniRocmRuntime_t rt, int dtype, const void *panel, void *sink, int pieces, int iters, double *flop) {
+    IROCM_CHECK_ARG(rt && panel && sink && iters > 0, "probe: bad argument");
+    IROCM_CHECK_ARG(dtype == INFINI_DT_BF16 || dtype == INFINI_DT_F16, "probe: bf16 / f16 only");
+    const unsigned grid = (unsigned)rt->num_cu;
+    constexpr int kLds = 2 * 65536;
+#define IROCM_W128(TR, P)                                                                                                   \
+    do {                                                                                                                    \
+        auto kern = mfma_wave128_kernel<TR, P>;                                                                             \
+        IROCM_LDS_ATTR(kern, kLds, rt);                                                                                     \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kLds, rt->stream, (const unsigned short *)panel, (float *)sink, iters); \
+    } while (0)
+    if (dtype == INFINI_DT_BF16) {
+        if (pieces == 2) IROCM_W128(Bf16Traits, 2); else if (pieces) IROCM_W128(Bf16Traits, 1); else IROCM_W128(Bf16Traits, 0);
+    } else {
+        if (pieces == 2) IROCM_W128(F16Traits, 2); else if (pieces) IROCM_W128(F16Traits, 1); else IROCM_W128(F16Traits, 0);
+    }
+#undef IROCM_W128
+    IROCM_LAUNCH_CHECK("mfma_wave128");
+    if (flop)
+        *flop = (double)grid * 4.0 * (double)iters * 128.0 * (2.0 * 16 * 16 * 32);
+    return INFINI_ROCM_OK;
+}
+
 // data: >= 16 * 512 * 12 * 16 bytes (1.5 MiB) of 16-bit operands in device memory (random data = the realistic power
 // draw; zeros clock higher); sink: >= num_cu * 512 floats. Launches ONE kernel of num_cu workgroups x 512 threads that
 // issues iters * 64 MFMAs per wave; *flop receives the FLOP count of the launch (time it with events).

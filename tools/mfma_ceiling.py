@@ -64,6 +64,28 @@ def a_from_l2(rt, dtype=torch.bfloat16, iters=4000, reps=20, k=512) -> float:
     return flop.value / s / 1e12
 
 
+def wave128(rt, dtype=torch.bfloat16, iters=2000, reps=20, pieces=1) -> float:
+    """TFLOP/s of the 4-wave, 128 x 128-wave-tile form (one wave per SIMD): 128 MFMAs + 32 LDS reads (+ 16 LDS-DMA pieces) per K-tile and wave."""
+    panel = torch.randn((16 << 20) // 2 + (256 << 10) // 2, device="cuda").to(dtype)
+    sink = torch.empty(rt.device_info()["compute_units"] * 256, device="cuda", dtype=torch.float32)
+    torch.cuda.synchronize()
+    code = 16 if dtype == torch.bfloat16 else 10
+    flop = C.c_double()
+
+    def launch():
+        check(lib().infini_rocm_probe_mfma_wave128(rt.handle, code, C.c_void_p(panel.data_ptr()), C.c_void_p(sink.data_ptr()), pieces, iters, C.byref(flop)))
+
+    for _ in range(3):
+        launch()
+    e0, e1 = Event(), Event()
+    rt.record(e0)
+    for _ in range(reps):
+        launch()
+    rt.record(e1)
+    s = rt.elapsed_ms(e0, e1) * 1e-3 / reps
+    return flop.value / s / 1e12
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="bf16")
@@ -85,4 +107,8 @@ if __name__ == "__main__":
         out[f"a_from_l2_k512_rep{rep}"] = round(a_from_l2(rt, dt, a.iters, a.reps, 512), 1)
         out[f"mfma_only_rep{rep}"] = round(mfma_ceiling(rt, dt, a.iters, a.reps, "normal"), 1)
     out["a_from_l2_k4096"] = round(a_from_l2(rt, dt, a.iters, a.reps, 4096), 1)
+    for rep in range(2):
+        out[f"wave128_with_dma_rep{rep}"] = round(wave128(rt, dt, a.iters // 2, a.reps, 1), 1)
+        out[f"wave128_no_dma_rep{rep}"] = round(wave128(rt, dt, a.iters // 2, a.reps, 0), 1)
+        out[f"wave128_with_dma_deep_rep{rep}"] = round(wave128(rt, dt, a.iters // 2, a.reps, 2), 1)
     print(json.dumps(out))
