@@ -742,7 +742,8 @@ def pmc_traffic(launched: str) -> dict:
     sys.path.insert(0, str(REPO / "tools"))
     import source_stamps
 
-    for name in ("r06_gemm256p_pmc.json", "r05_gemm256p_pmc.json", "r04_gemm256p_pmc.json", "r03_gemm256p_pmc.json", "r02_gemm256p_pmc.json"):
+    refusal = None
+    for name in ("r06_gemm_pmc.json", "r06_gemm256p_pmc.json", "r05_gemm256p_pmc.json", "r04_gemm256p_pmc.json", "r03_gemm256p_pmc.json", "r02_gemm256p_pmc.json"):
         p = REPO / "profiles" / name
         try:
             d = json.loads(p.read_text())
@@ -760,9 +761,11 @@ def pmc_traffic(launched: str) -> dict:
             file_variant = None
         src = f"profiles/{name} (variant {file_variant})"
         if file_variant != launched:
-            return {"traffic": None, "traffic_source": f"{src} REFUSED: this run launched {launched}"}
+            # (round 6 keeps one file per GEMM kernel: the next name may be the launched one's)
+            refusal = refusal or {"traffic": None, "traffic_source": f"{src} REFUSED: this run launched {launched}"}
+            continue
         return {"traffic": float(d["traffic_bytes_per_launch"]), "traffic_source": src}
-    return {"traffic": None, "traffic_source": "no counter file under profiles/"}
+    return refusal or {"traffic": None, "traffic_source": "no counter file under profiles/"}
 
 
 # Test mode (tests/test_gpu_multi.py): IROCM_BENCH_ONE_DEVICE=1 with INFINI_ROCM_COMM=direct runs the N ranks on ONE device — the

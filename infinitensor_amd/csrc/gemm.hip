@@ -417,6 +417,10 @@ int launch_gemm256p_trace(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, 
 } // namespace g256p
 int launch_gemm256_splitk(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool a_kmajor, bool b_kmajor, int splits);
 int launch_gemm256_f32out(infiniRocmRuntime_t rt, int dtype16, const GemmArgs &p, bool a_kmajor, bool b_kmajor, int splits, float *planes);
+namespace g128w { // four waves x 128 x 128 wave tiles, four-stage ring (gemm128w.hip): plain GEMMs on whole 256^2 tiles, K % 128 == 0
+bool supported(const GemmArgs &p);
+int launch_gemm128w(infiniRocmRuntime_t rt, int dtype, const GemmArgs &p, bool akm, bool bkm);
+} // namespace g128w
 // implemented in gemm32.hip: the fp32 128^2 LDS-DMA tile kernel (v_mfma_f32_32x32x2_f32)
 bool fast32_supported(const GemmArgs &p, bool a_kmajor, bool b_kmajor);
 int launch_fast32(infiniRocmRuntime_t rt, GemmArgs p, bool b_kmajor, int small_tiles);
@@ -458,8 +462,8 @@ static bool fast128_supported(const GemmArgs &p, bool akm, bool bkm) {
 }
 
 static const char *kVariantNames[] = {"generic64", "fast128_glds", "tile256", "tile256_splitk", "persist256", "persist192",
-                                      "persist128", "fast32"};
-constexpr int kNumVariants = 8; // 1-6 serve f16 / bf16, 7 serves f32, 0 everything
+                                      "persist128", "fast32", "wave128"};
+constexpr int kNumVariants = 9; // 1-6 and 8 serve f16 / bf16, 7 serves f32, 0 everything
 
 // Cost model behind the heuristic (microseconds; fitted to tools/gemm_shapes.py on MI355X, bf16 / f16, N(0,1) data).
 // A workgroup of the persistent kernel walks its tiles: a K-tile of a 256 x 64 NT tile costs kKt[NT]; every tile pays its
@@ -655,6 +659,8 @@ int infini_rocm_matmul_grouped(infiniRocmRuntime_t rt, int dtype, const void *a,
         variant = (want && fast32_supported(p, akm, bkm)) ? 7 : 0;
     } else if (variant == 7) {
         variant = -1;
+    } else if (variant == 8 && !g128w::supported(p)) {
+        variant = -1;
     }
     // split-K factor for the 256^2 kernel: fill the CUs when the tiles alone cannot and K is long enough that every
     // slice still runs >= 8 K-tiles (the fp32 partial planes cost 8 bytes per output element and slice)
@@ -685,6 +691,11 @@ int infini_rocm_matmul_grouped(infiniRocmRuntime_t rt, int dtype, const void *a,
             if (splits >= 2 && splitk_cost(m, n, k, batch, splits) < best * 0.97)
                 variant = 3;
         }
+        // the four-wave kernel (gemm128w.hip) where it measured ahead of persist256 (profiles/r06_gemm_wave128_ab.txt: + 2-8 %): plain
+        // single-batch GEMMs of one or two rounds of whole 256^2 tiles with a long K, any layout but NT (both operands K-major: - 3.5 %)
+        if (variant == 4 && batch == 1 && k >= 2048 && !(akm && bkm) && tiles256 >= rt->num_cu && tiles256 <= 2l * rt->num_cu &&
+            g128w::supported(p))
+            variant = 8;
         if (variant < 0)
             variant = fast128_supported(p, akm, bkm) ? 1 : 0;
     } else if (dtype == INFINI_DT_F32) {
@@ -701,6 +712,8 @@ int infini_rocm_matmul_grouped(infiniRocmRuntime_t rt, int dtype, const void *a,
     rt->last_matmul_variant = variant;
     if (variant == 7) // 128^2 tiles when they give at least ~half a tile per CU, 64^2 tiles otherwise (512^3: 64 tiles)
         return launch_fast32(rt, p, bkm, ceil_div(m, 128) * ceil_div(n, 128) * batch * 2 < rt->num_cu ? 1 : 0);
+    if (variant == 8)
+        return g128w::launch_gemm128w(rt, dtype, p, akm, bkm);
     if (variant == 4)
         return g256p::launch_gemm256p_nt4(rt, dtype, p, akm, bkm);
     if (variant == 5)

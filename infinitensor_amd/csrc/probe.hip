@@ -6,9 +6,20 @@
 // of v_mfma_f32_16x16x32 per wave, 12 distinct operand fragments of the caller's data, one workgroup per CU) with NO
 // memory or LDS instruction in the loop. Its TFLOP/s is the measured denominator for "how far is the GEMM from what the
 // matrix pipes can do at the clock the chip sustains" (bench.py: roofline.attainable_peak).
+#include <type_traits>
 #include "gemm_common.h"
 
 namespace irocm {
+
+// Workgroup 0's first lane leaves the loop's length on both of the chip's counters in the first 16 bytes of `sink`: s_memtime (the shader
+// core clock) and s_memrealtime (the constant 100 MHz reference) — their ratio is the core clock the loop actually ran at.
+__device__ __forceinline__ void stamp_clocks(float *sink, unsigned long long tc0, unsigned long long tr0) {
+    const unsigned long long tc1 = __builtin_amdgcn_s_memtime(), tr1 = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ((unsigned long long *)sink)[0] = tc1 - tc0;
+        ((unsigned long long *)sink)[1] = tr1 - tr0;
+    }
+}
 
 template <typename Tr>
 __global__ __launch_bounds__(512, 2) void mfma_ceiling_kernel(const unsigned short *__restrict__ data, float *__restrict__ sink,
@@ -27,6 +38,7 @@ __global__ __launch_bounds__(512, 2) void mfma_ceiling_kernel(const unsigned sho
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned long long tc0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -38,6 +50,7 @@ __global__ __launch_bounds__(512, 2) void mfma_ceiling_kernel(const unsigned sho
         // keep the loop a loop (no cross-iteration folding), no memory traffic
         asm volatile("" : "+v"(a[0]), "+v"(b[0]));
     }
+    stamp_clocks(sink, tc0, tr0);
     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -232,6 +245,19 @@ __global__ __launch_bounds__(256, 1) void mfma_wave128_kernel(const unsigned sho
     for (int i = 0; i < 8; ++i)
         read_pair(0, i, rd);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // PIECES 4: the classic staging instead of LDS-DMA — global_load_dwordx4 into 64 staging registers a whole K-tile ahead, ds_write_b128
+    // of the previous K-tile's registers at the same 16 slots
+    const unsigned long long tc0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
+    u32x4_t stage[16];
+    const char *sbase = (const char *)panel + (size_t)(blockIdx.x & 7) * (2u << 20) + (size_t)__builtin_amdgcn_readfirstlane(w) * 16384;
+    const unsigned wr = lds0 + (unsigned)w * 16384u + (unsigned)lane * 16u;
+    if (PIECES == 4) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(stage[i]) : "v"(lane * 16), "s"(sbase + (size_t)i * 1024) : "memory");
+    }
+    int ws;
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(ws) : "v"(w));
     for (int it = 0; it < iters; ++it) {
         const int buf = it & 1;
         const unsigned rbase = rd + (unsigned)buf * 65536u, rnext = rd + (unsigned)(buf ^ 1) * 65536u;
@@ -241,14 +267,27 @@ __global__ __launch_bounds__(256, 1) void mfma_wave128_kernel(const unsigned sho
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
+                for (int j = 0; j < 8; ++j) {
                     acc[i][j] = Tr::mfma(bf[ks][j], af[ks][i], acc[i][j]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                if (ks == 0)
-                    read_pair(1, i, rbase); // k-step 1 of this K-tile
-                if (PIECES) { // one piece behind every eight MFMAs: 16 per K-tile
-                    __builtin_amdgcn_global_load_lds(IROCM_GLB_PTR(src + (size_t)((it * 16 + ks * 8 + i) & 255) * 1024),
-                                                     IROCM_LDS_PTR(smem + (buf ^ 1) * 65536 + w * 16384 + (ks * 8 + i) * 1024), 16, 0, 0);
+                if (ks == 0 && PIECES != 3)
+                    read_pair(1, i, rbase); // k-step 1 of this K-tile (PIECES 3: no reads in the loop — pieces beside MFMAs only)
+                if (PIECES == 4) {
+                    asm volatile("s_waitcnt vmcnt(15)\n\tds_write_b128 %0, %1 offset:%2" ::"v"(wr + (unsigned)(buf ^ 1) * 65536u),
+                                 "v"(stage[ks * 8 + i]), "i"(0)
+                                 : "memory");
+                    asm volatile("global_load_dwordx4 %0, %1, %2"
+                                 : "=v"(stage[ks * 8 + i])
+                                 : "v"(lane * 16), "s"(sbase + (size_t)((it * 16 + ks * 8 + i) & 255) * 1024)
+                                 : "memory");
+                } else if (PIECES) { // one piece behind every eight MFMAs: 16 per K-tile
+                    if (PIECES == 7) // into 32 KB nobody reads, from the panel's tail (random or zeros: the caller's choice)
+                        __builtin_amdgcn_global_load_lds(IROCM_GLB_PTR(src + (256u << 10) + (size_t)((it * 16 + ks * 8 + i) & 255) * 1024),
+                                                         IROCM_LDS_PTR(smem + 131072 + w * 8192 + i * 1024), 16, 0, 0);
+                    else
+                        __builtin_amdgcn_global_load_lds(IROCM_GLB_PTR(src + (size_t)((it * 16 + ks * 8 + i) & 255) * 1024),
+                                                         IROCM_LDS_PTR(smem + (buf ^ 1) * 65536 + w * 16384 + (ks * 8 + i) * 1024), 16, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -258,13 +297,28 @@ __global__ __launch_bounds__(256, 1) void mfma_wave128_kernel(const unsigned sho
         // PIECES 1: wait for everything (two K-tile buffers: the next K-tile reads what was just requested — the shortest lookahead);
         // PIECES 2: leave this K-tile's 16 pieces in flight (what a ring of more, smaller stages would allow; the data hazard is ignored:
         // timing only)
-        if (PIECES == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (PIECES == 2 || PIECES == 5 || PIECES == 7) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (PIECES == 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the writes; the loads stay in flight
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (PIECES == 5) { // skew: wave w leaves the barrier 32 w cycles late, so the four waves' pieces reach the address path apart
+            if (ws >= 1) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+            if (ws >= 2) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+            if (ws >= 3) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        }
+        if (PIECES != 3) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            read_pair(0, i, rnext); // k-step 0 of the next K-tile (a real kernel would hide these eight pairs as well)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int i = 0; i < 8; ++i)
+                read_pair(0, i, rnext); // k-step 0 of the next K-tile (a real kernel would hide these eight pairs as well)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+    const unsigned long long tc1 = __builtin_amdgcn_s_memtime(), tr1 = __builtin_amdgcn_s_memrealtime();
+    if (PIECES == 4) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            acc[0][0][0] += __builtin_bit_cast(float, stage[i][0]);
     }
     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -274,25 +328,142 @@ __global__ __launch_bounds__(256, 1) void mfma_wave128_kernel(const unsigned sho
             s += acc[i][j];
     if (s[0] + s[1] + s[2] + s[3] == 123.456f)
         sink[blockIdx.x * 256 + t] = s[0];
+    if (blockIdx.x == 0 && t == 0) { // as stamp_clocks, written once the accumulators are dead
+        ((unsigned long long *)sink)[0] = tc1 - tc0;
+        ((unsigned long long *)sink)[1] = tr1 - tr0;
+    }
 }
 
-// panel: >= 16 MB + 256 KB of 16-bit data (L2-resident per XCD), sink: >= num_cu * 256 floats; pieces: 0 = no LDS-DMA, 1 = with it and a full
-// wait per K-tile, 2 = with it, one K-tile's pieces left in flight across the barrier.
+// The same four waves x 128 x 128 wave tiles as a schedule a real kernel could run: a ring of FOUR 32 KB stages, one k-step of 32 each
+// (barrier per 64 MFMAs), and every non-MFMA instruction placed ALONE between two MFMAs — with one wave per SIMD a wave owns one issue slot
+// in four, an MFMA needs one slot in four, so a clump of eight other instructions behind a group of MFMAs (mfma_wave128_kernel) drains the
+// matrix pipe while a spread of them does not. Per k-step and wave: 64 MFMAs, the 16 fragment reads of the NEXT k-step (stage s + 1, landed
+// and barriered one step ago), 8 LDS-DMA pieces into stage s + 2 (s_add m0 behind MFMA 4, the load behind MFMA 6 of each group of eight),
+// s_waitcnt vmcnt(8) — the pieces of the step before — and the barrier. Timing only (arbitrary conflict-free addresses).
+template <typename Tr, bool DMA>
+__global__ __launch_bounds__(256, 1) void mfma_wave128i_kernel(const unsigned short *__restrict__ panel, float *__restrict__ sink, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = t; i < 2 * 65536 / 16; i += 256)
+        *(u32x4_t *)(smem + i * 16) = ((const u32x4_t *)panel)[i];
+    __syncthreads();
+    const unsigned lds0 = (unsigned)(unsigned long)IROCM_LDS_PTR(smem);
+    const unsigned rd = lds0 + (unsigned)lane * 16u;
+    int ws;
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(ws) : "v"(w));
+    unsigned lds0s;
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(lds0s) : "v"(lds0));
+    const char *sbase = (const char *)panel + (256u << 10) + (size_t)(blockIdx.x & 7) * (2u << 20) + (size_t)ws * 8192;
+    const int voff = lane * 16;
+    s16x8_t af[2][8], bf[2][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(af[0][i]) : "v"(rd + (unsigned)i * 2048u));
+        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(bf[0][i]) : "v"(rd + (unsigned)i * 2048u));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long tc0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) { // two k-steps per iteration (register sets 0 / 1)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int step = it * 2 + ks;
+            const unsigned rnext = rd + (unsigned)((step + 1) & 3) * 32768u;      // stage s + 1
+            const unsigned m0base = lds0s + (unsigned)((step + 2) & 3) * 32768u + (unsigned)ws * 8192u; // stage s + 2
+            const char *sp = sbase + (size_t)(step & 31) * 65536; // stays inside the 2 MB slice of this XCD
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    // accumulators pinned to AGPRs, fragments to VGPRs: 256 + 128 registers leave the allocator no room to choose otherwise
+                    if constexpr (Tr::kDType == INFINI_DT_BF16)
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(bf[ks][j]), "v"(af[ks][i]));
+                    else
+                        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(bf[ks][j]), "v"(af[ks][i]));
+                    if (j == 0) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[ks ^ 1][i]) : "v"(rnext), "i"(i * 2048));
+                    if (j == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[ks ^ 1][i]) : "v"(rnext), "i"(i * 2048 + 1024));
+                    if (DMA && j == 4) asm volatile("s_add_u32 m0, %0, %1" ::"s"(m0base), "i"(i * 1024) : "memory");
+                    if (DMA && j == 6)
+                        asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(voff), "s"(sp + (i >> 2) * 4096), "i"((i & 3) * 1024) : "memory");
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (DMA) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    const unsigned long long tc1 = __builtin_amdgcn_s_memtime(), tr1 = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            s += acc[i][j];
+    if (s[0] + s[1] + s[2] + s[3] == 123.456f)
+        sink[blockIdx.x * 256 + t] = s[0];
+    if (blockIdx.x == 0 && t == 0) {
+        ((unsigned long long *)sink)[0] = tc1 - tc0;
+        ((unsigned long long *)sink)[1] = tr1 - tr0;
+    }
+}
+
+// panel: >= 16 MB + 512 KB of 16-bit data (L2-resident per XCD), sink: >= num_cu * 256 floats; pieces: 0 = no LDS-DMA, 1 = with it and a full
+// wait per K-tile, 2 = with it, one K-tile's pieces left in flight across the barrier, 3 = pieces but NO fragment reads in the loop (what the
+// pieces cost the MFMA stream alone), 4 = classic staging: global_load_dwordx4 into registers + ds_write_b128, no LDS-DMA, 5 = mode 2 with the
+// four waves SKEWED by 32 w cycles after every barrier (their pieces reach the address path apart), 7 = mode 2 with the pieces read from
+// panel + 256 KB and written to 32 KB of LDS nobody reads (random against zero source data: what the moved bits cost), 8 / 9 =
+// mfma_wave128i_kernel with / without its pieces (every non-MFMA instruction alone between two MFMAs, four-stage ring).
 extern "C" int infini_rocm_probe_mfma_wave128(infiniRocmRuntime_t rt, int dtype, const void *panel, void *sink, int pieces, int iters, double *flop) {
     IROCM_CHECK_ARG(rt && panel && sink && iters > 0, "probe: bad argument");
     IROCM_CHECK_ARG(dtype == INFINI_DT_BF16 || dtype == INFINI_DT_F16, "probe: bf16 / f16 only");
     const unsigned grid = (unsigned)rt->num_cu;
-    constexpr int kLds = 2 * 65536;
+    constexpr int kLds = 2 * 65536 + 32768;
 #define IROCM_W128(TR, P)                                                                                                   \
     do {                                                                                                                    \
         auto kern = mfma_wave128_kernel<TR, P>;                                                                             \
         IROCM_LDS_ATTR(kern, kLds, rt);                                                                                     \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kLds, rt->stream, (const unsigned short *)panel, (float *)sink, iters); \
     } while (0)
-    if (dtype == INFINI_DT_BF16) {
-        if (pieces == 2) IROCM_W128(Bf16Traits, 2); else if (pieces) IROCM_W128(Bf16Traits, 1); else IROCM_W128(Bf16Traits, 0);
+    if (pieces == 8 || pieces == 9) { // the spread schedule on a four-stage ring
+#define IROCM_W128I(TR, D)                                                                                                  \
+    do {                                                                                                                    \
+        auto kern = mfma_wave128i_kernel<TR, D>;                                                                            \
+        IROCM_LDS_ATTR(kern, kLds, rt);                                                                                     \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kLds, rt->stream, (const unsigned short *)panel, (float *)sink, iters); \
+    } while (0)
+        if (dtype == INFINI_DT_BF16) {
+            if (pieces == 8) IROCM_W128I(Bf16Traits, true); else IROCM_W128I(Bf16Traits, false);
+        } else {
+            if (pieces == 8) IROCM_W128I(F16Traits, true); else IROCM_W128I(F16Traits, false);
+        }
+#undef IROCM_W128I
+    } else if (dtype == INFINI_DT_BF16) {
+        switch (pieces) {
+        case 0: IROCM_W128(Bf16Traits, 0); break;
+        case 2: IROCM_W128(Bf16Traits, 2); break;
+        case 3: IROCM_W128(Bf16Traits, 3); break;
+        case 4: IROCM_W128(Bf16Traits, 4); break;
+        case 5: IROCM_W128(Bf16Traits, 5); break;
+        case 7: IROCM_W128(Bf16Traits, 7); break;
+        default: IROCM_W128(Bf16Traits, 1); break;
+        }
     } else {
-        if (pieces == 2) IROCM_W128(F16Traits, 2); else if (pieces) IROCM_W128(F16Traits, 1); else IROCM_W128(F16Traits, 0);
+        switch (pieces) {
+        case 0: IROCM_W128(F16Traits, 0); break;
+        case 2: IROCM_W128(F16Traits, 2); break;
+        case 3: IROCM_W128(F16Traits, 3); break;
+        case 4: IROCM_W128(F16Traits, 4); break;
+        case 5: IROCM_W128(F16Traits, 5); break;
+        case 7: IROCM_W128(F16Traits, 7); break;
+        default: IROCM_W128(F16Traits, 1); break;
+        }
     }
 #undef IROCM_W128
     IROCM_LAUNCH_CHECK("mfma_wave128");

@@ -99,6 +99,75 @@ def test_matmul_16bit_variants(rt, shape, ta, tb, dtype, variant):
     assert (err <= bound).all(), f"max err {err.max()} at {np.unravel_index(err.argmax(), err.shape)} (bound there {bound.ravel()[err.argmax()]})"
 
 
+W128_SHAPES = [
+    # b, m, n, k — whole 256^2 tiles, K % 128 == 0 (gemm128w.hip's contract)
+    (1, 256, 256, 128),    # one tile, one block of four k-steps: prologue -> last block -> epilogue
+    (1, 512, 768, 256),    # six tiles on six workgroups
+    (3, 512, 256, 384),    # batch strides on both operands
+    (1, 1280, 2304, 640),  # 45 tiles: ragged last tile-row group (5 rows in groups of 4)
+    (2, 4096, 4608, 128),  # 576 tiles: every workgroup walks 2-3 tiles, the next tile's pieces requested under the epilogue
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("shape", W128_SHAPES)
+def test_wave128_gemm_all_layouts(rt, shape, ta, tb, dtype):
+    """The four-wave kernel (gemm128w.hip, variant "wave128": 128 x 128 wave tiles, four-stage LDS ring, inline-asm K loop) against the
+    fp64 product of the rounded operands, per-element bound as above, in every layout — K-major operands take the cache-line-pair path
+    (sibling pieces with an instruction offset), M/N-major ones the transpose reads."""
+    b, m, n, k = shape
+    rng = np.random.default_rng(hash((shape, ta, tb, 128)) % 2 ** 32)
+    a = rng.standard_normal((b, k, m) if ta else (b, m, k)).astype(np.float32)
+    bm = rng.standard_normal((b, n, k) if tb else (b, k, n)).astype(np.float32)
+    name = "bf16" if dtype == torch.bfloat16 else "f16"
+    ops.set_matmul_variant(rt, ops.matmul_variants().index("wave128"))
+    try:
+        c = ops.matmul(rt, dev(a, dtype), dev(bm, dtype), None, ta, tb)
+        assert ops.matmul_last_variant(rt) == "wave128"
+    finally:
+        ops.set_matmul_variant(rt, -1)
+    ar, br = R.round_to(a, name), R.round_to(bm, name)
+    want = R.matmul(ar, br, None, ta, tb)
+    got = host(c)
+    tol = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -10
+    err = np.abs(got - want)
+    bound = tol * np.abs(want) + 2.0 ** -17 * R.matmul(np.abs(ar), np.abs(br), None, ta, tb)
+    assert (err <= bound).all(), f"max err {err.max()} at {np.unravel_index(err.argmax(), err.shape)}"
+
+
+def test_wave128_gemm_routing_and_fallback(rt):
+    """The heuristic hands the four-wave kernel plain single-batch GEMMs of one or two rounds of whole tiles with K >= 2048 (not NT);
+    forced on a problem outside its contract (bias, ragged m) the library falls back to the heuristic instead of failing."""
+    dt = torch.bfloat16
+    a = torch.randn(4096, 4096, device="cuda").to(dt)
+    b = torch.randn(4096, 4096, device="cuda").to(dt)
+    c = ops.matmul(rt, a, b)
+    assert ops.matmul_last_variant(rt) == "wave128"
+    ops.set_matmul_variant(rt, 4)
+    try:
+        c4 = ops.matmul(rt, a, b)
+        assert ops.matmul_last_variant(rt) == "persist256"
+    finally:
+        ops.set_matmul_variant(rt, -1)
+    # two kernels, two summation orders: a storage ulp of the result plus the accumulation slack
+    diff = (c.double() - c4.double()).abs()
+    assert bool((diff <= 2.0 ** -7 * c4.double().abs() + 2.0 ** -17 * (a.double().abs() @ b.double().abs())).all())
+    ops.matmul(rt, a, b, trans_b=True)
+    assert ops.matmul_last_variant(rt) == "persist256"  # NT stays on the eight-wave kernel
+    ops.matmul(rt, a, b, bias=torch.zeros(4096, device="cuda", dtype=dt))
+    assert ops.matmul_last_variant(rt) == "persist256"  # a bias: not the plain case
+    ops.set_matmul_variant(rt, ops.matmul_variants().index("wave128"))
+    try:
+        x = torch.randn(300, 256, device="cuda").to(dt)
+        y = torch.randn(256, 256, device="cuda").to(dt)
+        z = ops.matmul(rt, x, y)
+        assert ops.matmul_last_variant(rt) != "wave128"
+        assert torch.allclose(z.float(), (x.float() @ y.float()), rtol=2 ** -6, atol=0.25)
+    finally:
+        ops.set_matmul_variant(rt, -1)
+
+
 @pytest.mark.parametrize("variant", [4, 5, 6])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False)])
 @pytest.mark.parametrize("shape", [(1, 16384, 1536, 192), (1, 8192, 4096, 64), (1, 4104, 3080, 128), (3, 2048, 2560, 256),

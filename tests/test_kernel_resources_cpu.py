@@ -30,6 +30,16 @@ ALLOWED_SCRATCH = {
     # one-shot 256^2 kernel with BOTH operands M/N-major (transposing reads for A and B; no graph of the configs uses it)
     "irocm::g256::gemm256_kernel<irocm::Bf16Traits, false, false, false>": 12,
     "irocm::g256::gemm256_kernel<irocm::F16Traits, false, false, false>": 12,
+    # the four-wave GEMM at 512 registers, builds with two operands of the same kind: ONE loop-invariant register, stored in front of the
+    # tile loop and reloaded once per tile at the top of the epilogue (never inside a K loop; the NN / TT builds have none)
+    "irocm::g128w::gemm128w_kernel<irocm::Bf16Traits, true, true>": 8,
+    "irocm::g128w::gemm128w_kernel<irocm::F16Traits, true, true>": 8,
+    "irocm::g128w::gemm128w_kernel<irocm::Bf16Traits, false, false>": 8,
+    "irocm::g128w::gemm128w_kernel<irocm::F16Traits, false, false>": 8,
+    # diagnostics (probe.hip, tools/mfma_ceiling.py): 512-register upper-bound kernels, the spilled register lives outside their loops
+    "mfma_wave128_kernel<irocm::Bf16Traits, 4>": 16,
+    "mfma_wave128_kernel<irocm::F16Traits, 4>": 16,
+    "mfma_wave128i_kernel": 8,
 }
 
 

@@ -21,7 +21,7 @@ def test_current_round_counter_files_match_the_sources():
         if "stamp" not in d or d["stamp"] is None:
             continue
         seen += 1
-        kind = "membound" if "membound" in f.name else ("gemm" if "gemm256p" in f.name else None)
+        kind = "membound" if "membound" in f.name else ("gemm" if "_gemm" in f.name else None)
         if kind and d["stamp"] != want[kind]:
             stale.append(f"{f.name}: stamp {d['stamp']}, sources are {want[kind]}")
     assert not stale, "stale counter evidence (rerun tools/gpu_evidence.sh and copy its files): " + "; ".join(stale)
@@ -29,4 +29,4 @@ def test_current_round_counter_files_match_the_sources():
 
 def test_bench_reads_this_rounds_counter_files_first():
     src = (REPO / "bench.py").read_text()
-    assert f'"{ROUND}_membound_pmc.json"' in src and f'"{ROUND}_gemm256p_pmc.json"' in src
+    assert f'"{ROUND}_membound_pmc.json"' in src and f'"{ROUND}_gemm_pmc.json"' in src

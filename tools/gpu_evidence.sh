@@ -19,7 +19,9 @@ timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.
 step "tests + smoke"
 # 2. counter passes (stamped)
 timeout -k 10 400 bash tools/profile_membound.sh > $O/prof_membound.log 2>&1 && cp gpurun_out/prof_membound/summary.json $O/${R}_membound_pmc.json
-timeout -k 10 400 bash tools/profile_gemm.sh 4 > $O/prof_gemm.log 2>&1 && cp gpurun_out/prof_gemm/summary.json $O/${R}_gemm256p_pmc.json
+# (the headline GEMM on the kernel the heuristic launches for it — wave128, gemm128w.hip — and on the eight-wave kernel beside it)
+timeout -k 10 400 bash tools/profile_gemm.sh 8 > $O/prof_gemm.log 2>&1 && cp gpurun_out/prof_gemm/summary.json $O/${R}_gemm_pmc.json
+timeout -k 10 400 bash tools/profile_gemm.sh 4 > $O/prof_gemm4.log 2>&1 && cp gpurun_out/prof_gemm/summary.json $O/${R}_gemm256p_pmc.json
 timeout -k 10 300 bash tools/profile_cmd.sh attention_kernel attn_bert -- python tools/attn_cmd.py > $O/prof_attn.log 2>&1 && cp gpurun_out/prof_attn_bert/summary.json $O/${R}_attention_bert_pmc.json
 step "pmc"
 # 3. the bench line (default flags, the driver's flags)
@@ -36,6 +38,8 @@ timeout -k 10 400 python tools/conv_bench.py --variants=-1,2,7 2>&1 | clean > $O
 timeout -k 10 200 python tools/conv_bench.py --variants=-1,2 --res --layers 3,7,13,19 2>&1 | clean > $O/${R}_conv_layers_residual.txt
 timeout -k 10 300 python tools/gemm_shapes.py 2>&1 | clean > $O/${R}_gemm_shapes_bf16.txt
 timeout -k 10 200 python tools/gemm_ktile_ledger.py 2>&1 | clean > $O/${R}_gemm_ktile_ledger.txt
+timeout -k 10 500 python tools/gemm_wave128.py --ab 2>&1 | clean > $O/${R}_gemm_wave128_ab.txt
+IROCM_W128_DBG=8 timeout -k 10 200 python tools/gemm_wave128.py --clock 2>&1 | clean > $O/${R}_gemm_wave128_clock.txt
 step "models + sweeps"
 # 5. kernel traces of the graphs and of the headline command
 rm -rf gpurun_out/prof_models; timeout -k 10 700 bash tools/profile_models.sh > $O/prof_models.log 2>&1
@@ -50,4 +54,4 @@ echo "total $(( $(date +%s) - t0 )) s" | tee -a $O/visit.log
 cat $O/${R}_gpu_suite_tail.txt; tail -2 $O/smoke.log; cut -c1-600 $O/${R}_bench_line_driverflags.json; echo; cut -c1-260 $O/${R}_model_lines.json
 python3 -c "
 import json;d=json.load(open('$O/${R}_membound_pmc.json'));print('membound stamp',d['stamp'],{k:v['traffic_over_algorithmic'] for k,v in list(d['rows'].items())[:6]})
-g=json.load(open('$O/${R}_gemm256p_pmc.json'));print('gemm stamp',g.get('stamp'),'mfma busy',g.get('mfma_busy_frac'),'traffic',g.get('traffic_bytes_per_launch'))"
+g=json.load(open('$O/${R}_gemm_pmc.json'));print('gemm stamp',g.get('stamp'),'mfma busy',g.get('mfma_busy_frac'),'traffic',g.get('traffic_bytes_per_launch'))"

@@ -36,7 +36,18 @@ def mfma_ceiling(rt, dtype=torch.bfloat16, iters=4000, reps=20, fill="normal", s
         launch()
     rt.record(e1)
     s = rt.elapsed_ms(e0, e1) * 1e-3 / reps
+    CLOCKS[f"ceiling_{fill}{'_32' if shape32 else ''}"] = core_clock(sink)
     return flop.value / s / 1e12
+
+
+CLOCKS = {}
+
+
+def core_clock(sink):
+    """(core-clock ticks, 100 MHz ticks) the last launch's workgroup 0 stamped -> MHz of the shader clock inside the loop."""
+    torch.cuda.synchronize()
+    tc, tr = sink.view(torch.int64)[:2].tolist()
+    return round(tc / max(tr, 1) * 100.0, 1)
 
 
 def a_from_l2(rt, dtype=torch.bfloat16, iters=4000, reps=20, k=512) -> float:
@@ -64,9 +75,11 @@ def a_from_l2(rt, dtype=torch.bfloat16, iters=4000, reps=20, k=512) -> float:
     return flop.value / s / 1e12
 
 
-def wave128(rt, dtype=torch.bfloat16, iters=2000, reps=20, pieces=1) -> float:
+def wave128(rt, dtype=torch.bfloat16, iters=2000, reps=20, pieces=1, zero_tail=False) -> float:
     """TFLOP/s of the 4-wave, 128 x 128-wave-tile form (one wave per SIMD): 128 MFMAs + 32 LDS reads (+ 16 LDS-DMA pieces) per K-tile and wave."""
-    panel = torch.randn((16 << 20) // 2 + (256 << 10) // 2, device="cuda").to(dtype)
+    panel = torch.randn((16 << 20) // 2 + (512 << 10) // 2, device="cuda").to(dtype)
+    if zero_tail:
+        panel[(256 << 10) // 2:] = 0
     sink = torch.empty(rt.device_info()["compute_units"] * 256, device="cuda", dtype=torch.float32)
     torch.cuda.synchronize()
     code = 16 if dtype == torch.bfloat16 else 10
@@ -83,6 +96,7 @@ def wave128(rt, dtype=torch.bfloat16, iters=2000, reps=20, pieces=1) -> float:
         launch()
     rt.record(e1)
     s = rt.elapsed_ms(e0, e1) * 1e-3 / reps
+    CLOCKS[f"wave128_mode{pieces}{'_zeros' if zero_tail else ''}"] = core_clock(sink)
     return flop.value / s / 1e12
 
 
@@ -111,4 +125,12 @@ if __name__ == "__main__":
         out[f"wave128_with_dma_rep{rep}"] = round(wave128(rt, dt, a.iters // 2, a.reps, 1), 1)
         out[f"wave128_no_dma_rep{rep}"] = round(wave128(rt, dt, a.iters // 2, a.reps, 0), 1)
         out[f"wave128_with_dma_deep_rep{rep}"] = round(wave128(rt, dt, a.iters // 2, a.reps, 2), 1)
+        out[f"wave128_dma_no_reads_rep{rep}"] = round(wave128(rt, dt, a.iters // 2, a.reps, 3), 1)
+        out[f"wave128_classic_staging_rep{rep}"] = round(wave128(rt, dt, a.iters // 2, a.reps, 4), 1)
+        out[f"wave128_with_dma_deep_skewed_rep{rep}"] = round(wave128(rt, dt, a.iters // 2, a.reps, 5), 1)
+        out[f"wave128_dma_aside_random_rep{rep}"] = round(wave128(rt, dt, a.iters // 2, a.reps, 7), 1)
+        out[f"wave128_spread_with_dma_rep{rep}"] = round(wave128(rt, dt, a.iters // 2, a.reps, 8), 1)
+        out[f"wave128_spread_no_dma_rep{rep}"] = round(wave128(rt, dt, a.iters // 2, a.reps, 9), 1)
+        out[f"wave128_dma_aside_zeros_rep{rep}"] = round(wave128(rt, dt, a.iters // 2, a.reps, 7, True), 1)
+    out["core_clock_MHz_last_launch"] = CLOCKS
     print(json.dumps(out))

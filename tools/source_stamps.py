@@ -7,7 +7,7 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent.parent / "infinitensor_amd" / "csrc"
 MEMBOUND_SOURCES = ("rowops.hip", "elementwise.hip", "movement.hip", "nnops.hip", "rope.hip", "common.h")
-GEMM_SOURCES = ("gemm256p_kernel.h", "gemm256_common.h", "gemm_common.h", "gemm256p_nt4.hip", "common.h")
+GEMM_SOURCES = ("gemm128w.hip", "gemm256p_kernel.h", "gemm256_common.h", "gemm_common.h", "gemm256p_nt4.hip", "common.h")
 
 
 def _stamp(names) -> str:
