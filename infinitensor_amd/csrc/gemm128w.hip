@@ -16,8 +16,11 @@
 //     the piece behind MFMA 6 — inline asm throughout, accumulators pinned to AGPRs ("+a"), fragments to VGPRs;
 //   * persistent over tiles (XCD-chunked, 4-row groups), the k-step stream runs THROUGH tile boundaries: the last three steps of a tile
 //     request the next tile's first three, the epilogue (permlane16 swap -> 16-byte stores) runs under them.
-// LDS images. K-major operand (k contiguous in memory): [256 rows][64 B], physical 16-byte chunk c' of row r holds logical chunk
-// c' ^ ((r >> 2) & 3): the 16 lanes of a ds_read_b128 phase (16 rows, one logical chunk) hit 16 distinct 16-byte slots. M/N-major
+// LDS images. K-major operand (k contiguous in memory): 16-row blocks of sixteen 64-byte SLOTS; row l15 of a block sits in slot
+// s = b0 | b3 << 1 | (b2 b1) << 2 of its bits and physical 16-byte chunk c' of slot s holds logical chunk c' ^ (s >> 2). The bit
+// permutation is what makes ds_read_b128 conflict-free: the counters (SQ_LDS_BANK_CONFLICT) showed that a b128 read is served in four
+// passes of the lanes with EQUAL (l15 >> 1) & 3 — rows l15 = {2p, 2p + 1, 2p + 8, 2p + 9} of all four lane groups — and with rows in
+// plain order those four rows cover only two of the four 64-byte bank quarters (a 2-way conflict on every read: + 4 cycles). M/N-major
 // operand: gemm256_common.h's image [32 k][512 B] with the mn_f XOR, read by ds_read_b64_tr_b16 pairs.
 #include "gemm256_common.h"
 
@@ -43,7 +46,8 @@ template <> struct Frags<true> {
     s16x8_t v[2][8];
     unsigned base[2]; // lane address in stage 0 / stage 2 (stages 1 / 3 by the immediate offset)
     __device__ __forceinline__ void init(unsigned lds_oper, int half, int l15, int g4) {
-        base[0] = lds_oper + (unsigned)(half * 8192 + l15 * 64 + ((g4 ^ (l15 >> 2)) & 3) * 16);
+        const int slot = (l15 & 1) | (((l15 >> 3) & 1) << 1) | (((l15 >> 1) & 3) << 2); // row l15 of a 16-row block -> its 64-byte slot
+        base[0] = lds_oper + (unsigned)(half * 8192 + slot * 64 + ((g4 ^ (slot >> 2)) & 3) * 16);
         base[1] = base[0] + 2u * kStage;
     }
     template <int SET, int F, int STAGE> __device__ __forceinline__ void read0() {
@@ -84,8 +88,9 @@ template <bool KMAJOR> __device__ __forceinline__ void piece_offs(unsigned (&off
     for (int i = 0; i < 4; ++i) {
         const int piece = w * 4 + i;
         if constexpr (KMAJOR) {
-            const int r = piece * 16 + (lane >> 2);
-            const int c_log = (lane & 3) ^ ((r >> 2) & 3);
+            const int slot = lane >> 2; // the lane's 64-byte slot of the piece's 1 KB; it holds row (bit permutation below) of the block
+            const int r = piece * 16 + ((slot & 1) | (((slot >> 2) & 3) << 1) | (((slot >> 1) & 1) << 3));
+            const int c_log = (lane & 3) ^ ((slot >> 2) & 3);
             off[i] = (unsigned)(((long)r * ld + c_log * 8) * 2);
         } else {
             const int kr = piece * 2 + (lane >> 5);
