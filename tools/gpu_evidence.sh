@@ -14,7 +14,7 @@ t0=$(date +%s)
 step() { echo "== $1 after $(( $(date +%s) - t0 )) s" | tee -a $O/visit.log; }
 # 1. parity suite + smoke
 timeout -k 10 1500 python -m pytest tests -m gpu -q --durations=12 > $O/pytest.log 2>&1
-echo "pytest exit $?" >> $O/pytest.log; tail -5 $O/pytest.log | clean > $O/${R}_gpu_suite_tail.txt
+echo "pytest exit $?" >> $O/pytest.log; grep -E "passed|failed|error" $O/pytest.log | tail -3 > $O/${R}_gpu_suite_tail.txt; tail -1 $O/pytest.log >> $O/${R}_gpu_suite_tail.txt
 timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke exit $?" >> $O/smoke.log
 step "tests + smoke"
 # 2. counter passes (stamped)
