@@ -16,6 +16,7 @@ rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "2024")))
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 ACT = {0: lambda x: x, 1: torch.relu, 2: torch.sigmoid, 3: torch.tanh, 4: lambda x: torch.nn.functional.gelu(x),
        5: lambda x: torch.nn.functional.gelu(x)}
+W128 = ops.matmul_variants().index("wave128")
 bad = 0
 for case in range(n_cases):
     dt = [torch.float16, torch.bfloat16][case % 2]
@@ -28,6 +29,10 @@ for case in range(n_cases):
     act = int(rng.choice([0, 0, 1, 5, 2, 3, 4]))
     variant = int(rng.choice([-1, -1, 0, 1, 2, 3, 4, 5, 6]))
     bias_kind = int(rng.choice([0, 1, 1, 2, 3]))  # none, row [n], column [m,1], full [m,n]
+    w128 = case % 5 == 4  # every fifth case: the four-wave kernel's contract (whole 256^2 tiles, K % 128 == 0, plain store), forced
+    if w128:
+        m, n, k = 256 * int(rng.integers(1, 14)), 256 * int(rng.integers(1, 10)), 128 * int(rng.integers(1, 34))
+        act, bias_kind, variant = 0, 0, W128
     a_shape = (batch, k, m) if ta else (batch, m, k)
     bcast_b = batch > 1 and rng.random() < 0.5
     b_shape = ((k, n) if not tb else (n, k)) if bcast_b else ((batch, k, n) if not tb else (batch, n, k))
@@ -50,6 +55,8 @@ for case in range(n_cases):
     try:
         y = ops.matmul(rt, a, b, bias, ta, tb, act=act)
         torch.cuda.synchronize()
+        if w128 and ops.matmul_last_variant(rt) != "wave128":
+            raise RuntimeError("wave128 refused a problem inside its contract")
         tol = 4e-3 if dt == torch.float16 else 2.5e-2
         err = ((y.float() - ref).abs() / (ref.abs() + 1)).max().item()
         ok = err <= tol and bool(torch.isfinite(y.float()).all())
