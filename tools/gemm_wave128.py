@@ -83,10 +83,13 @@ def ab(rt, w, dt, m, n, k, ta, tb, rounds=8, reps=30):
     return {k2: {"min": min(v), "median": round(statistics.median(v), 1), "max": max(v)} for k2, v in res.items()}
 
 
-def clock(rt, w, m, n, k, ta, tb):
+def clock(rt, w, m, n, k, ta, tb, zeros=False):
     dt = torch.bfloat16
     a = torch.randn((k, m) if ta else (m, k), device="cuda").to(dt)
     b = torch.randn((n, k) if tb else (k, n), device="cuda").to(dt)
+    if zeros:  # the same instruction stream on operands that toggle nothing: what the DATA costs in clock
+        a.zero_()
+        b.zero_()
     out = torch.empty(m, n, device="cuda", dtype=dt)
     ops.set_matmul_variant(rt, w)
     try:
@@ -99,7 +102,7 @@ def clock(rt, w, m, n, k, ta, tb):
     us = tr / 100.0
     mhz = tc / max(tr, 1) * 100
     tf = 2.0 * m * n * k / max(us, 1e-9) / 1e6
-    return {"shape": [m, n, k], "ta": ta, "tb": tb, "core_MHz": round(mhz, 1), "K_loops_us_workgroup0": us, "TFLOPs_workgroup0": round(tf, 1),
+    return {"shape": [m, n, k], "ta": ta, "tb": tb, "operands": "zeros" if zeros else "N(0,1)", "core_MHz": round(mhz, 1), "K_loops_us_workgroup0": us, "TFLOPs_workgroup0": round(tf, 1),
             "issue_efficiency": round(tf / (2500.0 * mhz / 2400.0), 3)}
 
 
@@ -120,6 +123,7 @@ if __name__ == "__main__":
         for rep in range(3):
             for (m, n, k, ta, tb) in [(4096, 4096, 4096, False, False), (4096, 4096, 4096, True, False), (8192, 8192, 8192, False, False)]:
                 print(json.dumps(clock(rt, w, m, n, k, ta, tb)), flush=True)
+            print(json.dumps(clock(rt, w, 4096, 4096, 4096, False, False, zeros=True)), flush=True)
         sys.exit(0)
     if a.ab:
         for dt in (torch.bfloat16, torch.float16):
