@@ -139,7 +139,11 @@ int infini_rocm_probe_mfma_a_from_l2(infiniRocmRuntime_t rt, int dtype, const vo
                                      double *flop);
 /* Round 6: four waves per workgroup with 128 x 128 wave tiles (one wave per SIMD, 256 accumulator registers): per K-tile of 64 and wave 128
  * MFMAs, 32 LDS fragment reads and (pieces != 0) 16 LDS-DMA pieces interleaved, one barrier — the upper bound of that tile shape with the
- * library's staging machinery; timing only (no counterpart in the reference: matmul.cc:67-174 calls cuBLAS). */
+ * library's staging machinery; timing only (no counterpart in the reference: matmul.cc:67-174 calls cuBLAS). pieces: 0 none, 1 with a
+ * full wait per K-tile, 2 one K-tile's pieces left in flight, 3 pieces but no fragment reads, 4 classic staging (global_load_dwordx4 +
+ * ds_write_b128), 5 mode 2 with the waves skewed, 7 mode 2 into LDS nobody reads (random against zero source data), 8 / 9 the SPREAD
+ * schedule (every non-MFMA instruction alone between two MFMAs, four-stage ring: what csrc/gemm128w.hip implements) with / without its
+ * pieces. Workgroup 0 leaves (core-clock ticks, 100 MHz ticks) of its loop in the first 16 bytes of sink. */
 int infini_rocm_probe_mfma_wave128(infiniRocmRuntime_t rt, int dtype, const void *panel, void *sink, int pieces, int iters, double *flop);
 /* Diagnostics: one launch of the persistent GEMM (bf16, row-major A [m,k] and B [k,n], no bias; tile_cols 256 or 192)
  * built with s_memtime stamps at every wave's phase boundaries. trace: [min(tiles, compute_units)][8][128] uint64
