@@ -461,6 +461,14 @@ static bool fast128_supported(const GemmArgs &p, bool akm, bool bkm) {
     return true;
 }
 
+// gemm128w.hip keeps a lane's byte offset from the tile corner — the rows of its pieces PLUS the whole k advance of a tile — in 32 bits
+static bool w128_offsets_fit(const GemmArgs &p, bool akm, bool bkm) {
+    const long lda = akm ? p.a_rs : p.a_cs, ldb = bkm ? p.b_cs : p.b_rs;
+    const long a_max = akm ? (255 * lda + p.k + 64) * 2 : ((long)(p.k + 32) * lda + 256) * 2;
+    const long b_max = bkm ? (255 * ldb + p.k + 64) * 2 : ((long)(p.k + 32) * ldb + 256) * 2;
+    return a_max < (1ll << 32) && b_max < (1ll << 32);
+}
+
 static const char *kVariantNames[] = {"generic64", "fast128_glds", "tile256", "tile256_splitk", "persist256", "persist192",
                                       "persist128", "fast32", "wave128"};
 constexpr int kNumVariants = 9; // 1-6 and 8 serve f16 / bf16, 7 serves f32, 0 everything
@@ -659,7 +667,7 @@ int infini_rocm_matmul_grouped(infiniRocmRuntime_t rt, int dtype, const void *a,
         variant = (want && fast32_supported(p, akm, bkm)) ? 7 : 0;
     } else if (variant == 7) {
         variant = -1;
-    } else if (variant == 8 && !g128w::supported(p)) {
+    } else if (variant == 8 && !(g128w::supported(p) && w128_offsets_fit(p, akm, bkm))) {
         variant = -1;
     }
     // split-K factor for the 256^2 kernel: fill the CUs when the tiles alone cannot and K is long enough that every
@@ -694,7 +702,7 @@ int infini_rocm_matmul_grouped(infiniRocmRuntime_t rt, int dtype, const void *a,
         // the four-wave kernel (gemm128w.hip) where it measured ahead of persist256 (profiles/r06_gemm_wave128_ab.txt: + 2-8 %): plain
         // single-batch GEMMs of one or two rounds of whole 256^2 tiles with a long K, any layout but NT (both operands K-major: - 3.5 %)
         if (variant == 4 && batch == 1 && k >= 2048 && !(akm && bkm) && tiles256 >= rt->num_cu && tiles256 <= 2l * rt->num_cu &&
-            g128w::supported(p))
+            g128w::supported(p) && w128_offsets_fit(p, akm, bkm))
             variant = 8;
         if (variant < 0)
             variant = fast128_supported(p, akm, bkm) ? 1 : 0;
